@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C-ABI.
+
+Names follow the reference (``GMM.renderView`` + ``searchCorrespondence`` ->
+``GMM.search2d``, ``GMM.queryPoint``, ``optimize_current_pose`` =
+``Tracking::optimizeCurrentPose`` ...).  Device buffers are torch CUDA tensors
+(PyTorch-ROCm is used for memory, streams and torch.distributed only); every
+function launches hand-written HIP kernels through ``libgmmloc_hip.so``.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+ASSOC_BRUTE = 0
+ASSOC_KNN5_EUCLID = 1
+
+F_MEAN, F_COV, F_COV_INV, F_DET, F_SCALE, F_AXIS, F_SQRT_INFO, F_FLAGS, F_NBS_PTR, F_NBS_IDX, F_NBS_DIST = range(11)
+TIMER_ASSOC, TIMER_REFINE_POSE, TIMER_BA = 0, 1, 2
+
+
+class GLError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise GLError("libgmmloc_hip error %d: %s" % (rc, _lib.load().gl_last_error_string().decode()))
+
+
+@dataclass
+class Camera:
+    """PinholeCamera + camera::bf.  Defaults: gmmloc_ros/cfg/v1.yaml:5-17 read as float
+    (config.h:38: `extern float fx, fy, cx, cy`)."""
+    fx: float = float(np.float32(435.2046959714599))
+    fy: float = float(np.float32(435.2046959714599))
+    cx: float = float(np.float32(367.4517211914062))
+    cy: float = float(np.float32(252.2008514404297))
+    bf: float = float(np.float32(47.90639384423901))
+    width: int = 752
+    height: int = 480
+
+    def c(self):
+        return _lib.gl_camera(self.fx, self.fy, self.cx, self.cy, self.bf, self.width, self.height)
+
+
+class Params:
+    """Hot-path config values (config.h:31-89); defaults = cfg/v1.yaml."""
+
+    def __init__(self, **kw):
+        self._c = _lib.gl_params()
+        _lib.load().gl_default_params(C.byref(self._c))
+        for k, v in kw.items():
+            setattr(self._c, k, v)
+
+    def c(self):
+        return self._c
+
+    @property
+    def sigma2_inv(self):
+        return np.array(list(self._c.sigma2_inv), dtype=np.float32)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device buffers must be contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """gl_ctx_t: device + HIP stream + scratch.  stream=None -> torch's current stream."""
+
+    def __init__(self, device=0, stream="torch"):
+        import torch
+        self.lib = _lib.load()
+        self.device = device
+        if stream == "torch":
+            with torch.cuda.device(device):
+                s = torch.cuda.current_stream(device).cuda_stream
+            stream = s if s else None  # 0 = the default (null) stream
+        h = C.c_void_p()
+        _check(self.lib.gl_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+
+    def synchronize(self):
+        _check(self.lib.gl_ctx_synchronize(self.h))
+
+    def timing(self, on):
+        _check(self.lib.gl_ctx_timing_enable(self.h, 1 if on else 0))
+
+    def timing_read(self, timer, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib.gl_ctx_timing_read(self.h, timer, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GMM:
+    """gmmloc::GMM (gaussian_mixture.h:98-170) on the GPU."""
+
+    def __init__(self, ctx, mean, cov, params=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.params = params or Params()
+        mean = np.ascontiguousarray(mean, dtype=np.float64).reshape(-1, 3)
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 9)
+        assert mean.shape[0] == cov.shape[0]
+        h = C.c_void_p()
+        _check(self.lib.gl_gmm_create(ctx.h, mean.ctypes.data, cov.ctypes.data, mean.shape[0],
+                                      C.byref(self.params.c()), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def load(cls, ctx, path, params=None):
+        """GMMUtility::loadGMMModel (gmm_utils.cpp:9-67)."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib = ctx, ctx.lib
+        self.params = params or Params()
+        h = C.c_void_p()
+        _check(self.lib.gl_gmm_load_file(ctx.h, str(path).encode(), C.byref(self.params.c()), C.byref(h)))
+        self.h = h
+        return self
+
+    def save(self, path):
+        _check(self.lib.gl_gmm_save_file(self.h, str(path).encode()))
+
+    def countComponents(self):
+        return self.lib.gl_gmm_count(self.h)
+
+    K = property(countComponents)
+
+    def get(self, field):
+        K = self.K
+        nnz = self.lib.gl_gmm_nbs_count(self.h)
+        shape, dt = {
+            F_MEAN: ((K, 3), np.float64), F_COV: ((K, 9), np.float64), F_COV_INV: ((K, 9), np.float64),
+            F_DET: ((K,), np.float64), F_SCALE: ((K, 3), np.float64), F_AXIS: ((K, 9), np.float64),
+            F_SQRT_INFO: ((K, 9), np.float64), F_FLAGS: ((K,), np.uint8), F_NBS_PTR: ((K + 1,), np.int32),
+            F_NBS_IDX: ((nnz,), np.int32), F_NBS_DIST: ((nnz,), np.float64)}[field]
+        out = np.zeros(shape, dtype=dt)
+        _check(self.lib.gl_gmm_get(self.h, field, out.ctypes.data, out.nbytes))
+        return out
+
+    # ---- association ----------------------------------------------------------
+    def associate3d(self, pts, mode=ASSOC_BRUTE, want_d2=True):
+        """pts: (N,3) float64 CUDA tensor -> (idx int32 (N,), d2 float64 (N,))."""
+        import torch
+        N = pts.shape[0]
+        idx = torch.empty(N, dtype=torch.int32, device=pts.device)
+        d2 = torch.empty(N, dtype=torch.float64, device=pts.device) if want_d2 else None
+        _check(self.lib.gl_associate3d(self.ctx.h, self.h, _ptr(pts), N, mode, _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def knn3d(self, pts, k=5):
+        import torch
+        N = pts.shape[0]
+        idx = torch.empty((N, k), dtype=torch.int32, device=pts.device)
+        dist = torch.empty((N, k), dtype=torch.float64, device=pts.device)
+        _check(self.lib.gl_knn3d(self.ctx.h, self.h, _ptr(pts), N, k, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def queryPoint(self, pts):
+        """GMM::queryPoint (gaussian_mixture.cpp:545-576), batched."""
+        return self.associate3d(pts, ASSOC_KNN5_EUCLID)[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gl_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octave):
+    """Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217) for B frames.
+    pose (B,7) in/out, Xw (B,M,3), obs (B,M,3), octave (B,M) int32 (<0: no map point).
+    Returns (outlier uint8 (B,M), ninlier int32 (B,))."""
+    import torch
+    B, M = octave.shape
+    outlier = torch.zeros((B, M), dtype=torch.uint8, device=pose.device)
+    nin = torch.zeros(B, dtype=torch.int32, device=pose.device)
+    _check(ctx.lib.gl_optimize_current_pose(ctx.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
+                                            _ptr(obs), _ptr(octave), _ptr(outlier), _ptr(nin)))
+    return outlier, nin

@@ -1,0 +1,189 @@
+// Context management, error strings, params, device-memory helpers.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gl_internal.hpp"
+
+namespace gl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ctx_scratch(Ctx* c, size_t bytes, void** out) {
+  if (bytes > c->scratch_bytes) {
+    if (c->scratch) {
+      GL_HIP(hipStreamSynchronize(c->stream));
+      GL_HIP(hipFree(c->scratch));
+      c->scratch = nullptr;
+      c->scratch_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 2;
+    if (hipMalloc(&c->scratch, want) != hipSuccess) {
+      set_error("scratch hipMalloc(%zu) failed", want);
+      return GL_ERR_NOMEM;
+    }
+    c->scratch_bytes = want;
+  }
+  *out = c->scratch;
+  return GL_OK;
+}
+
+TimerScope::TimerScope(Ctx* ctx, int timer) : c(ctx), id(timer) {
+  if (!c->timing) return;
+  if (!c->pool.empty()) {
+    e0 = c->pool.back().first;
+    e1 = c->pool.back().second;
+    c->pool.pop_back();
+  } else {
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+      e0 = e1 = nullptr;
+      return;
+    }
+  }
+  (void)hipEventRecord(e0, c->stream);
+}
+TimerScope::~TimerScope() {
+  if (!c->timing || !e0) return;
+  (void)hipEventRecord(e1, c->stream);
+  c->pending.push_back({id, {e0, e1}});
+}
+
+static void drain_timers(Ctx* c) {
+  for (auto& p : c->pending) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(p.second.second);
+    if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+      c->timer_ms[p.first] += ms;
+      c->timer_n[p.first] += 1;
+    }
+    c->pool.push_back(p.second);
+  }
+  c->pending.clear();
+}
+
+}  // namespace gl
+
+extern "C" {
+
+const char* gl_last_error_string(void) { return gl::g_err; }
+
+int gl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// frame::sigma2_inv: init_config.hpp:60-79 (float arithmetic throughout);
+// scalar defaults: gmmloc_ros/cfg/v1.yaml:27,32,35,37,40
+void gl_default_params(gl_params* p) {
+  if (!p) return;
+  p->neighbor_dist_thresh = 2.5;
+  p->tri_lambda2 = 400.0f;
+  p->tri_str_thresh = 0.0064f;
+  p->ba_lambda2 = 400.0f;
+  p->tri_check_str_chi2 = 1;
+  p->ba_first_as_prior = 1;
+  float sf = 1.0f;
+  p->sigma2_inv[0] = 1.0f;
+  const float scale_factor = 1.2f;
+  for (int i = 1; i < 8; ++i) {
+    sf = sf * scale_factor;
+    const float s2 = sf * sf;
+    p->sigma2_inv[i] = 1.0f / s2;
+  }
+}
+
+int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out) {
+  GL_REQUIRE(out, "null argument");
+  int n = 0;
+  GL_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) {
+    gl::set_error("gl_ctx_create: device %d out of range (%d devices)", device, n);
+    return GL_ERR_ARG;
+  }
+  GL_HIP(hipSetDevice(device));
+  gl::Ctx* c = new gl::Ctx();
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
+  *out = (gl_ctx_t*)c;
+  return GL_OK;
+}
+
+int gl_ctx_destroy(gl_ctx_t* ctx) {
+  if (!ctx) return GL_OK;
+  gl::Ctx* c = gl::C(ctx);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  gl::drain_timers(c);
+  for (auto& p : c->pool) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return GL_OK;
+}
+
+int gl_ctx_synchronize(gl_ctx_t* ctx) {
+  GL_REQUIRE(ctx, "null argument");
+  GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
+  return GL_OK;
+}
+
+void* gl_ctx_stream(gl_ctx_t* ctx) { return ctx ? (void*)gl::C(ctx)->stream : nullptr; }
+
+int gl_ctx_timing_enable(gl_ctx_t* ctx, int on) {
+  GL_REQUIRE(ctx, "null argument");
+  gl::C(ctx)->timing = on != 0;
+  return GL_OK;
+}
+
+int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* launches, int reset) {
+  GL_REQUIRE(ctx && timer >= 0 && timer < GL_TIMER_COUNT, "bad argument");
+  gl::Ctx* c = gl::C(ctx);
+  gl::drain_timers(c);
+  if (total_ms) *total_ms = c->timer_ms[timer];
+  if (launches) *launches = c->timer_n[timer];
+  if (reset) {
+    c->timer_ms[timer] = 0.0;
+    c->timer_n[timer] = 0;
+  }
+  return GL_OK;
+}
+
+int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out) {
+  GL_REQUIRE(ctx && dev_out, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
+  if (hipMalloc(dev_out, bytes ? bytes : 1) != hipSuccess) {
+    gl::set_error("gl_malloc(%zu) failed", bytes);
+    return GL_ERR_NOMEM;
+  }
+  return GL_OK;
+}
+int gl_free(gl_ctx_t* ctx, void* dev) {
+  GL_REQUIRE(ctx, "null argument");
+  if (dev) GL_HIP(hipFree(dev));
+  return GL_OK;
+}
+int gl_memcpy_h2d(gl_ctx_t* ctx, void* dst_dev, const void* src, size_t bytes) {
+  GL_REQUIRE(ctx && dst_dev && src, "null argument");
+  GL_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, gl::C(ctx)->stream));
+  GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
+  return GL_OK;
+}
+int gl_memcpy_d2h(gl_ctx_t* ctx, void* dst, const void* src_dev, size_t bytes) {
+  GL_REQUIRE(ctx && dst && src_dev, "null argument");
+  GL_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, gl::C(ctx)->stream));
+  GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
+  return GL_OK;
+}
+
+}  // extern "C"

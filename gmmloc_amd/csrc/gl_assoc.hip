@@ -1,0 +1,273 @@
+// Association kernels (gfx950, wave64).
+//
+//  k_assoc_brute : for every point, argmin_k of GaussianComponent::chi2
+//                  (gaussian.cpp:65-70) over a K-range.  The {mean, cov_inv}
+//                  records (96 B) of a K-tile are staged in LDS with coalesced
+//                  16-byte loads; every lane owns PPT points in registers and
+//                  sweeps the tile with broadcast LDS reads (all lanes read the
+//                  same record -> one LDS cycle per lane group, no conflicts).
+//                  fp64 VALU bound: 15 v_{mul,fma,add}_f64 + compare/select
+//                  per (point, Gaussian) pair.
+//  grid = (point tiles, K splits); K is split so that even one frame (2k
+//  points) produces >= ~2k waves for the 1024 SIMDs; partial minima are
+//  merged by k_assoc_merge in ascending-k order, so ties keep the lowest index
+//  exactly like the sequential CPU loop.
+//
+//  k_knn3d       : exact k-NN (k <= 8) on the means, ascending squared L2,
+//                  ties by lower index (GMM::queryPoint's knnSearch,
+//                  gaussian_mixture.cpp:553-558).
+//
+// Compiled with -ffp-contract=off; the only fused ops are the explicit fma()
+// of the canonical chi2 (gl_device.hpp) -> bit-identical to the fp64 CPU order.
+#include "gl_device.hpp"
+#include "gl_internal.hpp"
+
+using namespace gld;
+
+namespace {
+
+constexpr int kTileG = 128;  // Gaussians per LDS tile (12 KiB)
+
+template <int PPT>
+__global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ rec12, int K, int kchunk,
+                                                     const double* __restrict__ pts, int N,
+                                                     double* __restrict__ out_d2, int32_t* __restrict__ out_idx) {
+  __shared__ __attribute__((aligned(16))) double tile[kTileG * 12];
+  const int tid = threadIdx.x;
+  const int k_begin = blockIdx.y * kchunk;
+  const int k_end = min(K, k_begin + kchunk);
+  const int p0 = (blockIdx.x * 256 + tid) * PPT;
+
+  double px[PPT], py[PPT], pz[PPT], best[PPT];
+  int bi[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int n = min(p0 + p, N - 1);
+    px[p] = pts[(size_t)n * 3 + 0];
+    py[p] = pts[(size_t)n * 3 + 1];
+    pz[p] = pts[(size_t)n * 3 + 2];
+    best[p] = __builtin_inf();
+    bi[p] = -1;
+  }
+
+  for (int k0 = k_begin; k0 < k_end; k0 += kTileG) {
+    const int ng = min(kTileG, k_end - k0);
+    __syncthreads();
+    {  // coalesced 16-byte copy of ng*96 bytes
+      const double2* src = reinterpret_cast<const double2*>(rec12 + (size_t)k0 * 12);
+      double2* dst = reinterpret_cast<double2*>(tile);
+      for (int i = tid; i < ng * 6; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int g = 0; g < ng; ++g) {
+      const double* rec = &tile[g * 12];
+      const double m0 = rec[0], m1 = rec[1], m2 = rec[2];
+      const double a0 = rec[3], a1 = rec[4], a2 = rec[5], a3 = rec[6], a4 = rec[7], a5 = rec[8], a6 = rec[9],
+                   a7 = rec[10], a8 = rec[11];
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        const double d0 = px[p] - m0, d1 = py[p] - m1, d2 = pz[p] - m2;
+        const double r0 = fma(d2, a6, fma(d1, a3, d0 * a0));
+        const double r1 = fma(d2, a7, fma(d1, a4, d0 * a1));
+        const double r2 = fma(d2, a8, fma(d1, a5, d0 * a2));
+        const double d = fma(r2, d2, fma(r1, d1, r0 * d0));
+        if (d < best[p]) {
+          best[p] = d;
+          bi[p] = k0 + g;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int n = p0 + p;
+    if (n < N) {
+      out_d2[(size_t)blockIdx.y * N + n] = best[p];
+      out_idx[(size_t)blockIdx.y * N + n] = bi[p];
+    }
+  }
+}
+
+// merge the per-K-split partial minima in ascending split (= ascending k) order
+__global__ void k_assoc_merge(const double* __restrict__ part_d2, const int32_t* __restrict__ part_idx, int nsplit,
+                              int N, int32_t* __restrict__ idx, double* __restrict__ d2) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double best = __builtin_inf();
+  int bi = -1;
+  for (int s = 0; s < nsplit; ++s) {
+    const double d = part_d2[(size_t)s * N + n];
+    if (d < best) {
+      best = d;
+      bi = part_idx[(size_t)s * N + n];
+    }
+  }
+  idx[n] = bi;
+  if (d2) d2[n] = best;
+}
+
+// exact k-NN on the means: one thread per query, means staged in LDS tiles.
+template <int KNN>
+__global__ __launch_bounds__(256) void k_knn3d(const double* __restrict__ mean, int K, const double* __restrict__ pts,
+                                               int N, int32_t* __restrict__ out_idx, double* __restrict__ out_dist) {
+  constexpr int TG = 512;
+  __shared__ double tile[TG * 3];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x * 256 + tid;
+  const int nn = min(n, N - 1);
+  const double qx = pts[(size_t)nn * 3 + 0], qy = pts[(size_t)nn * 3 + 1], qz = pts[(size_t)nn * 3 + 2];
+  double dist[KNN];
+  int idx[KNN];
+#pragma unroll
+  for (int i = 0; i < KNN; ++i) {
+    dist[i] = __builtin_inf();
+    idx[i] = -1;
+  }
+  for (int k0 = 0; k0 < K; k0 += TG) {
+    const int ng = min(TG, K - k0);
+    __syncthreads();
+    for (int i = tid; i < ng * 3; i += 256) tile[i] = mean[(size_t)k0 * 3 + i];
+    __syncthreads();
+    for (int g = 0; g < ng; ++g) {
+      const double d0 = qx - tile[g * 3 + 0], d1 = qy - tile[g * 3 + 1], d2 = qz - tile[g * 3 + 2];
+      const double d = (d0 * d0 + d1 * d1) + d2 * d2;  // kdtree_distance, gaussian_mixture.h:33-39
+      if (d < dist[KNN - 1]) {
+        // insert after every entry with dist <= d (KNNResultSet::addPoint order)
+        double cd = d;
+        int ci = k0 + g;
+#pragma unroll
+        for (int i = 0; i < KNN; ++i) {
+          const bool sw = cd < dist[i];
+          const double td = sw ? dist[i] : cd;
+          const int ti = sw ? idx[i] : ci;
+          dist[i] = sw ? cd : dist[i];
+          idx[i] = sw ? ci : idx[i];
+          cd = td;
+          ci = ti;
+        }
+      }
+    }
+  }
+  if (n < N) {
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) {
+      out_idx[(size_t)n * KNN + i] = idx[i];
+      if (out_dist) out_dist[(size_t)n * KNN + i] = dist[i];
+    }
+  }
+}
+
+// queryPoint: nearest mean (ret_index[0]) + its chi2 (gaussian_mixture.cpp:545-576)
+__global__ void k_nearest_chi2(const int32_t* __restrict__ knn_idx, int knn, const double* __restrict__ rec12,
+                               const double* __restrict__ pts, int N, int32_t* __restrict__ idx,
+                               double* __restrict__ d2) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int k = knn_idx[(size_t)n * knn];
+  idx[n] = k;
+  if (d2) d2[n] = k >= 0 ? chi2_rec(rec12 + (size_t)k * 12, pts[(size_t)n * 3], pts[(size_t)n * 3 + 1], pts[(size_t)n * 3 + 2]) : __builtin_inf();
+}
+
+}  // namespace
+
+namespace gl {
+
+// shared with gl_track.hip: brute association of N points; outputs on device
+int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2) {
+  const int K = g->K;
+  // points per thread: more points amortise the broadcast LDS reads; fewer keep the grid wide
+  int ppt = 1;
+  if (N >= 32768) ppt = 2;
+  if (N >= 262144) ppt = 4;
+  const int ptiles = (N + 256 * ppt - 1) / (256 * ppt);
+  // K split: aim for >= 2048 workgroups-worth of waves (256 CUs x 4 SIMDs x 2)
+  int nsplit = (2048 + ptiles * 4 - 1) / (ptiles * 4);
+  const int max_split = (K + kTileG - 1) / kTileG * 2;  // >= 64 Gaussians per split
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  int kchunk = (K + nsplit - 1) / nsplit;
+  nsplit = (K + kchunk - 1) / kchunk;
+  void* scratch = nullptr;
+  double* part_d2;
+  int32_t* part_idx;
+  if (nsplit > 1 || !d2) {
+    const size_t bytes = (size_t)nsplit * N * 12 + 64;
+    int rc = ctx_scratch(c, bytes, &scratch);
+    if (rc != GL_OK) return rc;
+    part_d2 = (double*)scratch;
+    part_idx = (int32_t*)((char*)scratch + (size_t)nsplit * N * 8);
+  } else {
+    part_d2 = d2;
+    part_idx = idx;
+  }
+  {
+    TimerScope ts(c, GL_TIMER_ASSOC);
+    const dim3 grid(ptiles, nsplit);
+    if (ppt == 1)
+      k_assoc_brute<1><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx);
+    else if (ppt == 2)
+      k_assoc_brute<2><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx);
+    else
+      k_assoc_brute<4><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx);
+  }
+  GL_HIP(hipGetLastError());
+  if (part_idx != idx) {
+    k_assoc_merge<<<(N + 255) / 256, 256, 0, c->stream>>>(part_d2, part_idx, nsplit, N, idx, d2);
+    GL_HIP(hipGetLastError());
+  }
+  return GL_OK;
+}
+
+}  // namespace gl
+
+extern "C" {
+
+int gl_knn3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int k, int32_t* idx_dev,
+             double* dist_dev) {
+  GL_REQUIRE(ctx && gmm && idx_dev, "null argument");
+  GL_REQUIRE(k >= 1 && k <= 8, "k must be in [1, 8]");
+  if (N == 0) return GL_OK;
+  GL_REQUIRE(N > 0 && pts_dev, "bad N / pts");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  const int grid = (N + 255) / 256;
+#define GL_KNN_CASE(KK) \
+  case KK: k_knn3d<KK><<<grid, 256, 0, c->stream>>>(g->mean, g->K, pts_dev, N, idx_dev, dist_dev); break;
+  switch (k) {
+    GL_KNN_CASE(1)
+    GL_KNN_CASE(2)
+    GL_KNN_CASE(3)
+    GL_KNN_CASE(4)
+    GL_KNN_CASE(5)
+    GL_KNN_CASE(6)
+    GL_KNN_CASE(7)
+    GL_KNN_CASE(8)
+  }
+#undef GL_KNN_CASE
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int mode, int32_t* idx_dev,
+                   double* d2_dev) {
+  GL_REQUIRE(ctx && gmm && idx_dev, "null argument");
+  GL_REQUIRE(mode == GL_ASSOC_BRUTE || mode == GL_ASSOC_KNN5_EUCLID, "unknown mode");
+  if (N == 0) return GL_OK;
+  GL_REQUIRE(N > 0 && pts_dev, "bad N / pts");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  if (mode == GL_ASSOC_BRUTE) return gl::launch_assoc_brute(c, g, pts_dev, N, idx_dev, d2_dev);
+  void* scratch = nullptr;
+  int rc = gl::ctx_scratch(c, (size_t)N * 5 * 4, &scratch);
+  if (rc != GL_OK) return rc;
+  k_knn3d<5><<<(N + 255) / 256, 256, 0, c->stream>>>(g->mean, g->K, pts_dev, N, (int32_t*)scratch, nullptr);
+  GL_HIP(hipGetLastError());
+  k_nearest_chi2<<<(N + 255) / 256, 256, 0, c->stream>>>((int32_t*)scratch, 5, g->rec12, pts_dev, N, idx_dev, d2_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Internal host-side structures of libgmmloc_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "gmmloc_hip.h"
+
+namespace gl {
+
+void set_error(const char* fmt, ...);
+
+#define GL_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      gl::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return GL_ERR_DEVICE;                                                           \
+    }                                                                                 \
+  } while (0)
+
+#define GL_REQUIRE(cond, msg)              \
+  do {                                     \
+    if (!(cond)) {                         \
+      gl::set_error("%s: %s", __func__, msg); \
+      return GL_ERR_ARG;                   \
+    }                                      \
+  } while (0)
+
+// Device-resident, immutable GMM (SoA).  Layout (all fp64 unless noted):
+//   rec12   K x 12   {mean[3], cov_inv[9]}  -- the association record, 96 B
+//   cov     K x 9    row-major covariance
+//   det     K
+//   scale   K x 3    ascending eigenvalues
+//   axis    K x 9    row-major, column c = eigenvector c
+//   sqrt_info K x 9  lower Cholesky factor of cov_inv
+//   flags   K uint8  bit0 degenerated, bit1 salient
+//   plane   K x 8    {normal[3] (= axis col 0), mean[3], pad, pad}
+//   nbs_ptr K+1 int32, nbs_idx nnz int32, nbs_dist nnz  (CSR of nbs_)
+struct Gmm {
+  int device = 0;
+  int K = 0;
+  std::vector<double> h_mean, h_cov;  // host copies (save_file / get)
+  double* rec12 = nullptr;
+  double* mean = nullptr;  // K x 3 (kNN kernels)
+  double* cov = nullptr;
+  double* det = nullptr;
+  double* scale = nullptr;
+  double* axis = nullptr;
+  double* sqrt_info = nullptr;
+  uint8_t* flags = nullptr;
+  int32_t* nbs_ptr = nullptr;
+  int32_t* nbs_idx = nullptr;
+  double* nbs_dist = nullptr;
+  int nnz = 0;
+  gl_params prm;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // scratch (grown on demand)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // timing
+  bool timing = false;
+  double timer_ms[GL_TIMER_COUNT] = {0};
+  int64_t timer_n[GL_TIMER_COUNT] = {0};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+
+int ctx_scratch(Ctx* c, size_t bytes, void** out);
+// bracket a launch region with events when timing is enabled
+struct TimerScope {
+  Ctx* c;
+  int id;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  TimerScope(Ctx* ctx, int timer);
+  ~TimerScope();
+};
+
+inline gl::Gmm* G(const gl_gmm_t* g) { return (gl::Gmm*)g; }
+inline gl::Ctx* C(gl_ctx_t* c) { return (gl::Ctx*)c; }
+
+// .gmm stream (gl_io.cpp)
+int read_gmm_file(const char* path, std::vector<double>& mean, std::vector<double>& cov);
+int write_gmm_file(const char* path, const double* mean, const double* cov, const uint8_t* flags, int K);
+
+// launchers implemented across the .hip files
+int launch_build_components(Ctx* c, Gmm* g);
+int launch_build_neighbours(Ctx* c, Gmm* g);
+
+}  // namespace gl

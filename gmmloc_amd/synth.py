@@ -1,0 +1,146 @@
+"""Synthetic workloads for the tests and the benchmark.
+
+No EuRoC imagery exists in this environment (the reference's .MISSING_LARGE_BLOBS),
+so frame problems are synthesised from a GMM map + camera poses and labelled so.
+Pure numpy, deterministic per seed; nothing here is measured or shipped.
+"""
+import numpy as np
+
+V1_BBOX = np.array([[-5.0, 4.0], [-4.0, 5.0], [0.0, 3.5]])  # V1 map extent
+
+
+def _haar(rng, n):
+    q, r = np.linalg.qr(rng.standard_normal((n, 3, 3)))
+    q = q * np.sign(np.diagonal(r, axis1=1, axis2=2))[:, None, :]
+    det = np.linalg.det(q)
+    q[:, :, 0] *= det[:, None]
+    return q
+
+
+def synth_gmm(K, seed=1, planar_frac=0.95):
+    """Config 2 map: means ~U(bbox); Sigma = R diag(l) R^T, 95 % planar
+    l=(1e-6, LogU[1e-3,0.1], LogU[1e-3,2]), 5 % volumetric l~LogU[1e-3,0.1]^3."""
+    rng = np.random.default_rng(seed)
+    mean = rng.uniform(V1_BBOX[:, 0], V1_BBOX[:, 1], size=(K, 3))
+    R = _haar(rng, K)
+    planar = rng.uniform(size=K) < planar_frac
+    lam = np.empty((K, 3))
+    lam[:, 0] = np.where(planar, 1e-6, np.exp(rng.uniform(np.log(1e-3), np.log(0.1), K)))
+    lam[:, 1] = np.exp(rng.uniform(np.log(1e-3), np.log(0.1), K))
+    lam[:, 2] = np.where(planar, np.exp(rng.uniform(np.log(1e-3), np.log(2.0), K)),
+                         np.exp(rng.uniform(np.log(1e-3), np.log(0.1), K)))
+    cov = np.einsum("kij,kj,klj->kil", R, lam, R)
+    cov = 0.5 * (cov + cov.transpose(0, 2, 1))  # bit-symmetric
+    return mean, cov.reshape(K, 9)
+
+
+def synth_points(mean, cov, N, seed=1, frac_on=0.8):
+    """80 % drawn from a random component, 20 % uniform in the bbox."""
+    rng = np.random.default_rng(seed + 1000)
+    K = mean.shape[0]
+    comp = rng.integers(0, K, N)
+    L = np.linalg.cholesky(cov.reshape(K, 3, 3)[comp] + 1e-15 * np.eye(3))
+    pts = mean[comp] + np.einsum("nij,nj->ni", L, rng.standard_normal((N, 3)))
+    uni = rng.uniform(size=N) >= frac_on
+    lo, hi = mean.min(0) - 0.5, mean.max(0) + 0.5
+    pts[uni] = rng.uniform(lo, hi, size=(int(uni.sum()), 3))
+    return np.ascontiguousarray(pts)
+
+
+# ---- SE3 helpers (numpy, independent of oracle/ and of the kernels) --------
+def quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def R_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[3] = (R[k, j] - R[j, k]) / s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-9:
+        return np.eye(3) + W
+    return np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W @ W
+
+
+def gt_row_to_Tcw(row):
+    """gt_sync row (t x y z qx qy qz qw) = T_wc  ->  pose7 of T_cw (qx qy qz qw tx ty tz)."""
+    Rwc = quat_to_R(row[4:8] / np.linalg.norm(row[4:8]))
+    Rcw = Rwc.T
+    tcw = -Rcw @ row[1:4]
+    return np.concatenate([R_to_quat(Rcw), tcw])
+
+
+def perturb_pose(pose7, rng, sig_rot=0.01, sig_t=0.02):
+    """init = exp(xi) * T_cw, xi ~ N(0, diag(sig_rot, sig_t)^2)."""
+    R = quat_to_R(pose7[:4])
+    dR = so3_exp(rng.standard_normal(3) * sig_rot)
+    return np.concatenate([R_to_quat(dR @ R), dR @ pose7[4:] + rng.standard_normal(3) * sig_t])
+
+
+def synth_frame(mean, cov, pose7, cam, M, seed, outlier_frac=0.1, mono_frac=0.15, sigma2_inv=None,
+                min_vis=20):
+    """One frame problem from a map and a camera pose.
+    Returns dict(pose_init, pose_gt, Xw (M,3), obs (M,3: u v u_right), octave (M,), comp (M,))."""
+    rng = np.random.default_rng(seed)
+    K = mean.shape[0]
+    R, t = quat_to_R(pose7[:4]), pose7[4:]
+    mc = mean @ R.T + t
+    z = mc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = cam.fx * mc[:, 0] / z + cam.cx
+        v = cam.fy * mc[:, 1] / z + cam.cy
+    vis = np.nonzero((z > 0.3) & (z < 8.0) & (u >= 0) & (u < cam.width) & (v >= 0) & (v < cam.height))[0]
+    if vis.size < min_vis:  # camera looks away from the map: fall back to the nearest components
+        vis = np.argsort(np.abs(z - 2.0))[:max(min_vis, 64)]
+    comp = vis[rng.integers(0, vis.size, M)]
+    Lc = np.linalg.cholesky(cov.reshape(K, 3, 3)[comp] + 1e-15 * np.eye(3))
+    Xw = mean[comp] + np.einsum("nij,nj->ni", Lc, rng.standard_normal((M, 3)))
+    pc = Xw @ R.T + t
+    pc[:, 2] = np.maximum(pc[:, 2], 0.2)
+    octave = rng.integers(0, 8, M).astype(np.int32)
+    sig = 1.2 ** octave
+    uo = cam.fx * pc[:, 0] / pc[:, 2] + cam.cx + rng.standard_normal(M) * sig
+    vo = cam.fy * pc[:, 1] / pc[:, 2] + cam.cy + rng.standard_normal(M) * sig
+    ur = uo - cam.bf / pc[:, 2] + rng.standard_normal(M) * sig * 0.5
+    out = rng.uniform(size=M) < outlier_frac
+    uo[out] += rng.choice([-30.0, 30.0], int(out.sum()))
+    vo[out] += rng.choice([-30.0, 30.0], int(out.sum()))
+    mono = rng.uniform(size=M) < mono_frac
+    ur[mono] = -1.0
+    ur[~mono] = np.maximum(ur[~mono], 0.0)
+    # the reference stores u_right as float (types/feature.h:37)
+    ur = ur.astype(np.float32).astype(np.float64)
+    obs = np.stack([uo, vo, ur], 1)
+    return dict(pose_init=perturb_pose(pose7, rng), pose_gt=pose7.copy(), Xw=np.ascontiguousarray(Xw),
+                obs=np.ascontiguousarray(obs), octave=octave, comp=comp.astype(np.int32))
+
+
+def look_at_pose(eye, target, up=(0.0, 0.0, 1.0)):
+    """T_cw of a camera at `eye` looking at `target` (z forward, x right, y down)."""
+    zc = np.asarray(target, float) - np.asarray(eye, float)
+    zc /= np.linalg.norm(zc)
+    xc = np.cross(zc, np.asarray(up, float))
+    xc /= np.linalg.norm(xc)
+    yc = np.cross(zc, xc)
+    Rcw = np.stack([xc, yc, zc], 0)
+    return np.concatenate([R_to_quat(Rcw), -Rcw @ np.asarray(eye, float)])

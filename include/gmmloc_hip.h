@@ -1,0 +1,224 @@
+/*
+ * gmmloc_hip.h -- C-ABI of libgmmloc_hip.so: the MI355X (gfx950) drop-in for the
+ * GMM association + structure-constrained refinement hot path of
+ * HyHuang1995/gmmloc.  extern "C", plain pointers and sizes, no C++ types, no
+ * exceptions across the boundary.
+ *
+ * The reference has NO plugin / FFI interface for this path: it is ordinary C++
+ * methods on heap objects.  Each entry point below names the
+ * reference function it replaces (paths relative to the reference root); the
+ * adapter a maintainer would add to the reference host is in INTEGRATION.md and
+ * include/gmmloc_hip/gmm_adapter.hpp.
+ *
+ * Conventions
+ *   - every call returns int: 0 = GL_OK, <0 = error (gl_last_error_string()).
+ *     "not converged" / "no association" are results, not errors.
+ *   - components are identified by int32 index = order in the .gmm file
+ *     (GMM::getComponent3d(idx), gaussian_mixture.h:147-149); -1 = none.
+ *   - poses are 7 doubles  (qx qy qz qw tx ty tz)  = g2o::SE3Quat T_cw
+ *     (world -> camera), Eigen coefficient order.
+ *   - pointers suffixed _dev are DEVICE pointers valid on the context's device;
+ *     those calls are asynchronous on the context's HIP stream.  Pointers
+ *     without the suffix are host pointers and the call is synchronous.
+ *   - all arithmetic is IEEE fp64 (the reference's scalar_t = double,
+ *     common/eigen_types.h:6); float config scalars stay float (config.h:38-89).
+ *   - a gl_gmm_t is immutable after creation and may be shared by contexts /
+ *     host threads; a gl_ctx_t (stream + scratch) belongs to one host thread.
+ */
+#ifndef GMMLOC_HIP_H_
+#define GMMLOC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gl_gmm gl_gmm_t;
+typedef struct gl_ctx gl_ctx_t;
+
+enum gl_status {
+  GL_OK = 0,
+  GL_ERR_ARG = -1,     /* bad argument (reference: CHECK / CHECK_NOTNULL aborts) */
+  GL_ERR_IO = -2,      /* file cannot be opened (gmm_utils.cpp:19-22 -> false)   */
+  GL_ERR_FORMAT = -3,  /* malformed .gmm stream (gmm_utils.cpp:27-35,44-51)      */
+  GL_ERR_DEVICE = -4,  /* HIP runtime error                                      */
+  GL_ERR_NOMEM = -5
+};
+
+/* PinholeCamera (cv/pinhole_camera.h) + camera::bf (config.h:38-52). */
+typedef struct gl_camera {
+  double fx, fy, cx, cy, bf;
+  int32_t width, height;
+} gl_camera;
+
+/* Hot-path configuration values (config.h:31-89, cfg/v1.yaml). */
+typedef struct gl_params {
+  double neighbor_dist_thresh; /* gmmmap::neighbor_dist_thresh (2.5)          */
+  float tri_lambda2;           /* loc::tri_lambda2   (400)                    */
+  float tri_str_thresh;        /* loc::tri_str_thresh (0.0064)                */
+  float ba_lambda2;            /* loc::ba_lambda2    (400)                    */
+  int32_t tri_check_str_chi2;  /* loc::tri_check_str_chi2 (true)              */
+  int32_t ba_first_as_prior;   /* loc::ba_first_as_prior  (true)              */
+  float sigma2_inv[8];         /* frame::sigma2_inv, init_config.hpp:60-79    */
+} gl_params;
+
+/* Fills the values of gmmloc_ros/cfg/v1.yaml and the float 1.2^(-2l) table. */
+void gl_default_params(gl_params* p);
+
+const char* gl_last_error_string(void); /* thread-local */
+int gl_device_count(void);
+
+/* ---- context: device + stream + scratch --------------------------------- */
+/* hip_stream: the hipStream_t to launch on (e.g. torch's current stream); NULL = the
+ * device's default (null) stream. */
+int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out);
+int gl_ctx_destroy(gl_ctx_t* ctx);
+int gl_ctx_synchronize(gl_ctx_t* ctx);
+void* gl_ctx_stream(gl_ctx_t* ctx);
+/* Kernel timing with HIP events on the context's stream: while enabled, every
+ * launch of the named hot kernel class is bracketed by events.  Returns the
+ * accumulated milliseconds / launch count since the last reset. */
+enum gl_timer { GL_TIMER_ASSOC = 0, GL_TIMER_REFINE_POSE = 1, GL_TIMER_BA = 2, GL_TIMER_COUNT = 8 };
+int gl_ctx_timing_enable(gl_ctx_t* ctx, int on);
+int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* launches, int reset);
+
+/* ---- GMM map: replaces GMMUtility::loadGMMModel (gmm_utils.cpp:9-67),
+ *      GaussianComponent ctor + decompose (gaussian.h:30-39, gaussian.cpp:36-63)
+ *      and the GMM::GMM neighbour graph (gaussian_mixture.cpp:43-91) ---------- */
+/* mean: K x 3, cov: K x 9 row-major, host pointers. Builds the device-resident
+ * SoA (inverse, det, eigen axes/scales, chol(cov^-1), flags) and the
+ * Bhattacharyya neighbour graph (CSR) on the GPU. */
+int gl_gmm_create(gl_ctx_t* ctx, const double* mean, const double* cov, int K, const gl_params* prm,
+                  gl_gmm_t** out);
+/* .gmm stream reader: varint32 count, then count x {varint32 size, ComponentProto}
+ * (protobuf_utils.cpp:12-29,42-80; GMM.proto:5-14). */
+int gl_gmm_load_file(gl_ctx_t* ctx, const char* path, const gl_params* prm, gl_gmm_t** out);
+/* GMMUtility::saveGMMModel (gmm_utils.cpp:69-119): same stream, byte-compatible. */
+int gl_gmm_save_file(const gl_gmm_t* gmm, const char* path);
+int gl_gmm_destroy(gl_gmm_t* gmm);
+int gl_gmm_count(const gl_gmm_t* gmm);
+
+enum gl_gmm_field {
+  GL_F_MEAN = 0,      /* K x 3 double */
+  GL_F_COV = 1,       /* K x 9 double */
+  GL_F_COV_INV = 2,   /* K x 9 double   cov_inv_                         */
+  GL_F_DET = 3,       /* K double       det_                             */
+  GL_F_SCALE = 4,     /* K x 3 double   scale_ (ascending eigenvalues)   */
+  GL_F_AXIS = 5,      /* K x 9 double   axis_ row-major, column = vector */
+  GL_F_SQRT_INFO = 6, /* K x 9 double   sqrt_info_ = chol_L(cov_inv_)    */
+  GL_F_FLAGS = 7,     /* K uint8        bit0 is_degenerated, bit1 is_salient */
+  GL_F_NBS_PTR = 8,   /* (K+1) int32    CSR row pointer of nbs_          */
+  GL_F_NBS_IDX = 9,   /* nnz int32      neighbour component index        */
+  GL_F_NBS_DIST = 10  /* nnz double     NeighbourInfo::dist              */
+};
+/* Copies a derived array to host memory (bytes = capacity of host_out). */
+int gl_gmm_get(const gl_gmm_t* gmm, int field, void* host_out, size_t bytes);
+int gl_gmm_nbs_count(const gl_gmm_t* gmm);
+
+/* ---- association --------------------------------------------------------- */
+enum gl_assoc_mode {
+  GL_ASSOC_BRUTE = 0,      /* argmin_k GaussianComponent::chi2 (gaussian.cpp:65-70) over ALL K:
+                              the north-star `associate`; first index wins ties        */
+  GL_ASSOC_KNN5_EUCLID = 1 /* GMM::queryPoint (gaussian_mixture.cpp:545-576): nearest mean
+                              of the exact 5-NN; d2 = its chi2                          */
+};
+/* pts_dev: N x 3; idx_dev: N int32; d2_dev: N double (may be NULL). */
+int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int mode, int32_t* idx_dev,
+                   double* d2_dev);
+/* exact k-NN (k <= 8) on the 3-D means, ascending squared L2 (queryPoint's knnSearch).
+ * idx_dev: N x k (-1 padded); dist_dev: N x k (may be NULL). */
+int gl_knn3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int k, int32_t* idx_dev,
+             double* dist_dev);
+
+/* GMM::renderView (gaussian_mixture.cpp:271-371) + GMM::searchCorrespondence
+ * (gaussian_mixture.cpp:484-534) for B key-frames at once
+ * (= GMMLoc::associateMapElements, gmmloc_opt.cpp:115-135).
+ *  pose_dev: B x 7; uv_dev: B x N x 2; nfeat_dev: B int32 (<= N) or NULL (= N);
+ *  cand_dev: B x N x k int32 parent indices in kNN order, gated by 2-D MDist2 < 9, -1 padded;
+ *  ncand_dev: B x N int32;
+ *  view_ids_dev (optional): B x view_cap int32 rendered parent ids sorted by depth
+ *  descending (components2d_ order), -1 padded; nview_dev (optional): B int32. */
+int gl_search2d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, int B, const double* pose_dev, int N,
+                const double* uv_dev, const int32_t* nfeat_dev, int k, int32_t* cand_dev, int32_t* ncand_dev,
+                int view_cap, int32_t* view_ids_dev, int32_t* nview_dev);
+
+/* ---- point refinement ----------------------------------------------------- */
+/* GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N independent problems.
+ * pts N x 3, uvr N x 3 (u, v, u_right), octave N, pose N x 7, comp N, proj_z2 N.
+ * out: res N uint8, chi2_proj N, chi2_str N, pt_est N x 3. */
+int gl_optimize_point(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int N,
+                      const double* pts_dev, const double* uvr_dev, const int32_t* octave_dev,
+                      const double* pose_dev, const int32_t* comp_dev, const double* proj_z2_dev,
+                      uint8_t* res_dev, double* chi2_proj_dev, double* chi2_str_dev, double* pt_est_dev);
+
+/* GMMLoc::checkMapAssociation (gmmloc_opt.cpp:156-258) for the N features of B
+ * key-frames: pose_dev B x 7; pts_dev B x N x 3 in/out (written where the reference
+ * writes pt3d); uvr B x N x 3; octave B x N (<0 = skip feature); cand B x N x k,
+ * ncand B x N (from gl_search2d); out_comp B x N (component or -1). */
+int gl_check_map_association(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
+                             int B, int N, const double* pose_dev, double* pts_dev, const double* uvr_dev,
+                             const int32_t* octave_dev, const int32_t* cand_dev, const int32_t* ncand_dev, int k,
+                             int32_t* out_comp_dev);
+
+/* Localization::optimizeTriangulationVec (localization_opt.cpp:27-204), N problems.
+ * x3d N x 3 in/out; pose1/pose2 N x 7; uvr1/uvr2 N x 3 (u_right < 0 => mono edge);
+ * oct1/oct2 N; cand1/cand2 N x k with n1/n2 N; out_comp N. */
+int gl_optimize_triangulation(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
+                              int N, double* x3d_dev, const double* pose1_dev, const double* uvr1_dev,
+                              const int32_t* oct1_dev, const double* pose2_dev, const double* uvr2_dev,
+                              const int32_t* oct2_dev, const int32_t* cand1_dev, const int32_t* n1_dev,
+                              const int32_t* cand2_dev, const int32_t* n2_dev, int k, int32_t* out_comp_dev);
+
+/* ---- pose refinement ------------------------------------------------------ */
+/* Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217) for B frames.
+ *  pose_dev B x 7 in/out; Xw_dev B x M x 3; obs_dev B x M x 3 (u, v, u_right; u_right < 0
+ *  => monocular edge); octave_dev B x M int32 (< 0 => feature has no map point);
+ *  outlier_dev B x M uint8 (is_outlier_); ninlier_dev B int32 (return value). */
+int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M,
+                             double* pose_dev, const double* Xw_dev, const double* obs_dev,
+                             const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev);
+
+/* Localization::jointOptimization (localization_opt.cpp:456-925) on B flat problems
+ * sharing one shape.  Per problem: P free poses (local key-frames, [0,P)), F fixed
+ * poses ([P,P+F)), L points (all marginalised) each with <= 1 GMM association, and
+ * observations in CSR order by point.
+ *  poses_dev   B x (P+F) x 7   in/out for [0,P)
+ *  prior_dev   B x P uint8     1 = key-frame idx_ 0 (prior edge / fixed, :556-581)
+ *  points_dev  B x L x 3       in/out
+ *  assoc_dev   B x L int32     component or -1
+ *  obs_ptr_dev B x (L+1) int32; obs_pose_dev B x NOBS int32; obs_uvr_dev B x NOBS x 3;
+ *  obs_oct_dev B x NOBS int32  (NOBS = stride; only obs_ptr[L] entries are used)
+ *  out: assoc_dropped_dev B x L uint8 (:837-853), obs_erase_dev B x NOBS uint8 (:855-879),
+ *       iters_dev B int32 (actual_iter of the last optimize(40), :827-828). */
+int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
+                          int P, int F, int L, int NOBS, double* poses_dev, const uint8_t* prior_dev,
+                          double* points_dev, const int32_t* assoc_dev, const int32_t* obs_ptr_dev,
+                          const int32_t* obs_pose_dev, const double* obs_uvr_dev, const int32_t* obs_oct_dev,
+                          uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev);
+
+/* North-star per-frame path: associate + structure-constrained pose refinement for B
+ * frames of M map points each:
+ *   1. idx = argmin_k chi2_k(Xw)  (GL_ASSOC_BRUTE), association kept iff chi2 <= 9
+ *      (the gate of checkMapAssociation, gmmloc_opt.cpp:230-232);
+ *   2. jointOptimization restricted to the frame: 1 free pose, M free marginalised points,
+ *      one reprojection edge per point (mono / stereo, Huber) + its GMM edge
+ *      (EdgePt2GaussianDeg x ba_lambda2 or EdgePt2Gaussian), schedule 5 / 5 / 40.
+ *  pose_dev B x 7 in/out; Xw_dev B x M x 3 in/out; obs_dev B x M x 3; octave_dev B x M
+ *  (<0 = no point); assoc_dev B x M int32 out (association after the final gate, -1 = none);
+ *  d2_dev B x M double out (chi2 of the argmin at the INPUT point, may be NULL). */
+int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
+                    double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
+                    int32_t* assoc_dev, double* d2_dev);
+
+/* ---- device memory helpers for hosts without their own HIP allocator ------ */
+int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out);
+int gl_free(gl_ctx_t* ctx, void* dev);
+int gl_memcpy_h2d(gl_ctx_t* ctx, void* dst_dev, const void* src, size_t bytes); /* synchronous */
+int gl_memcpy_d2h(gl_ctx_t* ctx, void* dst, const void* src_dev, size_t bytes); /* synchronous */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMMLOC_HIP_H_ */

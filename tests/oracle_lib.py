@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+
+class orc_camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("bf", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class orc_params(C.Structure):
+    _fields_ = [("neighbor_dist_thresh", C.c_double), ("tri_lambda2", C.c_float),
+                ("tri_str_thresh", C.c_float), ("ba_lambda2", C.c_float),
+                ("tri_check_str_chi2", C.c_int32), ("ba_first_as_prior", C.c_int32),
+                ("sigma2_inv", C.c_float * 8)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Oracle:
+    def __init__(self, lib, nf):
+        self.lib, self.nf = lib, nf
+        lib.orc_gmm_create.restype = C.c_void_p
+        self.prm = orc_params()
+        lib.orc_default_params(C.byref(self.prm))
+
+    def camera(self, cam):
+        return orc_camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.width, cam.height)
+
+    # ---- gmm ----
+    def gmm_create(self, mean, cov):
+        mean, cov = _f64(mean), _f64(cov)
+        return C.c_void_p(self.lib.orc_gmm_create(_p(mean), _p(cov), mean.shape[0]))
+
+    def gmm_destroy(self, h):
+        self.lib.orc_gmm_destroy(h)
+
+    def gmm_get(self, h):
+        K = self.lib.orc_gmm_count(h)
+        out = dict(cov_inv=np.zeros((K, 9)), det=np.zeros(K), scale=np.zeros((K, 3)), axis=np.zeros((K, 9)),
+                   sqrt_info=np.zeros((K, 9)), flags=np.zeros(K, np.uint8))
+        self.lib.orc_gmm_get(h, _p(out["cov_inv"]), _p(out["det"]), _p(out["scale"]), _p(out["axis"]),
+                             _p(out["sqrt_info"]), _p(out["flags"]))
+        return out
+
+    def neighbours(self, h, thresh=2.5):
+        K = self.lib.orc_gmm_count(h)
+        ptr = np.zeros(K + 1, np.int32)
+        nnz = self.lib.orc_gmm_neighbours(h, C.c_double(thresh), _p(ptr), None, None)
+        col, dist = np.zeros(nnz, np.int32), np.zeros(nnz)
+        self.lib.orc_gmm_neighbours(h, C.c_double(thresh), _p(ptr), _p(col), _p(dist))
+        return ptr, col, dist
+
+    def neighbour_rows(self, h, r0, r1, thresh=2.5, cap=1 << 16):
+        ptr = np.zeros(r1 - r0 + 1, np.int32)
+        col, dist = np.zeros(cap, np.int32), np.zeros(cap)
+        nnz = self.lib.orc_gmm_neighbour_rows(h, C.c_double(thresh), r0, r1, _p(ptr), _p(col), _p(dist), cap)
+        assert nnz <= cap
+        return ptr, col[:nnz], dist[:nnz]
+
+    def associate3d(self, h, pts):
+        pts = _f64(pts)
+        N = pts.shape[0]
+        idx, d2 = np.zeros(N, np.int32), np.zeros(N)
+        self.lib.orc_associate3d(h, _p(pts), N, _p(idx), _p(d2))
+        return idx, d2
+
+    def chi2(self, h, comp, pts):
+        pts, comp = _f64(pts), _i32(comp)
+        out = np.zeros(pts.shape[0])
+        self.lib.orc_chi2(h, _p(comp), _p(pts), pts.shape[0], _p(out))
+        return out
+
+    def knn3d(self, h, pts, k=5):
+        pts = _f64(pts)
+        N = pts.shape[0]
+        idx, dist, cnt = np.zeros((N, k), np.int32), np.zeros((N, k)), np.zeros(N, np.int32)
+        self.lib.orc_knn3d(h, _p(pts), N, k, _p(idx), _p(dist), _p(cnt))
+        return idx, dist, cnt
+
+    def render_view(self, h, cam, pose, cap=8192):
+        pose = _f64(pose)
+        ids, m2, c2, dep = np.zeros(cap, np.int32), np.zeros((cap, 2)), np.zeros((cap, 4)), np.zeros(cap)
+        c = self.camera(cam)
+        V = self.lib.orc_render_view(h, C.byref(c), _p(pose), cap, _p(ids), _p(m2), _p(c2), _p(dep))
+        return ids[:V].copy(), m2[:V].copy(), c2[:V].copy(), dep[:V].copy()
+
+    def search_correspondence(self, h, uv, k=5):
+        uv = _f64(uv)
+        N = uv.shape[0]
+        cand, ncand = np.zeros((N, k), np.int32), np.zeros(N, np.int32)
+        self.lib.orc_search_correspondence(h, _p(uv), N, k, _p(cand), _p(ncand))
+        return cand, ncand
+
+    def optimize_point(self, h, cam, pts, uvr, octave, poses, comp, proj_z2, prm=None):
+        pts, uvr, poses, proj_z2 = _f64(pts), _f64(uvr), _f64(poses), _f64(proj_z2)
+        octave, comp = _i32(octave), _i32(comp)
+        N = pts.shape[0]
+        res, c2p, c2s, est = np.zeros(N, np.uint8), np.zeros(N), np.zeros(N), np.zeros((N, 3))
+        c = self.camera(cam)
+        self.lib.orc_optimize_point(h, C.byref(c), C.byref(prm or self.prm), N, _p(pts), _p(uvr), _p(octave),
+                                    _p(poses), _p(comp), _p(proj_z2), _p(res), _p(c2p), _p(c2s), _p(est))
+        return res, c2p, c2s, est
+
+    def check_map_association(self, h, cam, pose, pts, uvr, octave, cand, ncand, prm=None):
+        pts = _f64(pts).copy()
+        uvr, pose = _f64(uvr), _f64(pose)
+        octave, cand, ncand = _i32(octave), _i32(cand), _i32(ncand)
+        N, k = cand.shape
+        out = np.zeros(N, np.int32)
+        c = self.camera(cam)
+        self.lib.orc_check_map_association(h, C.byref(c), C.byref(prm or self.prm), _p(pose), N, _p(pts), _p(uvr),
+                                           _p(octave), _p(cand), _p(ncand), k, _p(out))
+        return out, pts
+
+    def optimize_triangulation(self, h, cam, x3d, pose1, uvr1, oct1, pose2, uvr2, oct2, cand1, n1, cand2, n2,
+                               prm=None):
+        x3d = _f64(x3d).copy()
+        pose1, uvr1, pose2, uvr2 = _f64(pose1), _f64(uvr1), _f64(pose2), _f64(uvr2)
+        oct1, oct2, cand1, n1, cand2, n2 = _i32(oct1), _i32(oct2), _i32(cand1), _i32(n1), _i32(cand2), _i32(n2)
+        N, k = cand1.shape
+        out = np.zeros(N, np.int32)
+        c = self.camera(cam)
+        self.lib.orc_optimize_triangulation(h, C.byref(c), C.byref(prm or self.prm), N, _p(x3d), _p(pose1), _p(uvr1),
+                                            _p(oct1), _p(pose2), _p(uvr2), _p(oct2), _p(cand1), _p(n1), _p(cand2),
+                                            _p(n2), k, _p(out))
+        return out, x3d
+
+    def optimize_current_pose(self, cam, pose, Xw, obs, octave, prm=None):
+        pose = _f64(pose).copy()
+        Xw, obs = _f64(Xw), _f64(obs)
+        octave = _i32(octave)
+        N = Xw.shape[0]
+        has = (octave >= 0).astype(np.uint8)
+        oc = np.maximum(octave, 0).astype(np.int32)
+        outl = np.zeros(N, np.uint8)
+        c = self.camera(cam)
+        n = self.lib.orc_optimize_current_pose(C.byref(c), C.byref(prm or self.prm), _p(pose), N, _p(Xw), _p(obs),
+                                               _p(oc), _p(has), _p(outl))
+        return pose, outl, n
+
+    def joint_optimization(self, h, cam, P, F, poses, has_prior, points, assoc, obs_ptr, obs_pose, obs_uvr,
+                           obs_oct, prm=None):
+        poses, points, obs_uvr = _f64(poses).copy(), _f64(points).copy(), _f64(obs_uvr)
+        has_prior = np.ascontiguousarray(has_prior, np.uint8)
+        assoc, obs_ptr, obs_pose, obs_oct = _i32(assoc), _i32(obs_ptr), _i32(obs_pose), _i32(obs_oct)
+        L, nobs = points.shape[0], obs_pose.shape[0]
+        dropped, erase = np.zeros(L, np.uint8), np.zeros(max(nobs, 1), np.uint8)
+        c = self.camera(cam)
+        it = self.lib.orc_joint_optimization(h, C.byref(c), C.byref(prm or self.prm), P, F, L, nobs, _p(poses),
+                                             _p(has_prior), _p(points), _p(assoc), _p(obs_ptr), _p(obs_pose),
+                                             _p(obs_uvr), _p(obs_oct), _p(dropped), _p(erase))
+        return poses, points, dropped, erase[:nobs], it
+
+    def se3_exp(self, u):
+        out = np.zeros(7)
+        self.lib.orc_se3_exp(_p(_f64(u)), _p(out))
+        return out
+
+    def se3_log(self, pose):
+        out = np.zeros(6)
+        self.lib.orc_se3_log(_p(_f64(pose)), _p(out))
+        return out
+
+    # ---- real nanoflann (oracle/_ref) ----
+    def nanoflann_knn(self, pts, q, k):
+        assert self.nf is not None, "oracle/_ref/libnanoflann_ref.so missing"
+        pts, q = _f64(pts), _f64(q)
+        dim = pts.shape[1]
+        nq = q.shape[0]
+        idx, dist, cnt = np.zeros((nq, k), np.int32), np.zeros((nq, k)), np.zeros(nq, np.int32)
+        fn = self.nf.nfref_knn2d if dim == 2 else self.nf.nfref_knn3d
+        fn(_p(pts), pts.shape[0], _p(q), nq, k, _p(idx), _p(dist), _p(cnt))
+        return idx, dist, cnt
+
+
+_cached = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ODIR])
+
+
+def load():
+    global _cached
+    if _cached is not None:
+        return _cached
+    so = os.path.join(ODIR, "liboracle.so")
+    if not os.path.exists(so):
+        build()
+    lib = C.CDLL(so)
+    nfp = os.path.join(ODIR, "_ref", "libnanoflann_ref.so")
+    nf = C.CDLL(nfp) if os.path.exists(nfp) else None
+    _cached = Oracle(lib, nf)
+    return _cached

@@ -1,0 +1,138 @@
+"""GPU parity: GMM construction (A0, A2) and association (A1 exhaustive, A6) vs the oracle.
+Bit-exact for indices / flags; the Mahalanobis values themselves are bit-identical because
+both sides evaluate the same canonical fp64 expression."""
+import os
+
+import numpy as np
+import pytest
+
+from gmmloc_amd import synth
+from gmmloc_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(gpu, oracle, mean, cov):
+    torch, ctx = gpu
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    return g, h
+
+
+@pytest.mark.parametrize("which", ["v1", "v2", "synth4096"])
+def test_component_build_matches_oracle(gpu, oracle, map_v1, map_v2, which):
+    mean, cov = {"v1": map_v1, "v2": map_v2, "synth4096": synth.synth_gmm(4096, 1)}[which]
+    g, h = _mk(gpu, oracle, mean, cov)
+    ref = oracle.gmm_get(h)
+    assert g.K == mean.shape[0]
+    # cov_inv feeds the bit-exact indices: must be bit-identical
+    assert np.array_equal(g.get(api.F_COV_INV), ref["cov_inv"])
+    assert np.array_equal(g.get(api.F_DET), ref["det"])
+    assert np.array_equal(g.get(api.F_FLAGS), ref["flags"])
+    np.testing.assert_allclose(g.get(api.F_SCALE), ref["scale"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(g.get(api.F_SQRT_INFO), ref["sqrt_info"], rtol=1e-13, atol=0)
+    # eigenvectors up to sign: compare n n^T of the plane normal (axis_.col(0)) where it is used
+    A, B = g.get(api.F_AXIS).reshape(-1, 3, 3), ref["axis"].reshape(-1, 3, 3)
+    deg = (ref["flags"] & 1).astype(bool)
+    n0, n1 = A[deg][:, :, 0], B[deg][:, :, 0]
+    assert np.abs(np.abs(np.einsum("ki,ki->k", n0, n1)) - 1).max() < 1e-12
+    oracle.gmm_destroy(h)
+
+
+@pytest.mark.parametrize("which", ["v1", "v2"])
+def test_neighbour_graph_matches_oracle(gpu, oracle, map_v1, map_v2, which):
+    mean, cov = {"v1": map_v1, "v2": map_v2}[which]
+    g, h = _mk(gpu, oracle, mean, cov)
+    ptr, col, dist = oracle.neighbours(h)
+    assert np.array_equal(g.get(api.F_NBS_PTR), ptr)
+    assert np.array_equal(g.get(api.F_NBS_IDX), col)
+    np.testing.assert_allclose(g.get(api.F_NBS_DIST), dist, rtol=0, atol=1e-12)
+    if which == "v1":  # 16 048 directed edges, max degree 29
+        assert len(col) == 16048 and np.diff(ptr).max() == 29
+    oracle.gmm_destroy(h)
+
+
+@pytest.mark.parametrize("which,N,seed", [("v1", 2000, 1), ("v2", 2000, 2), ("synth4096", 2000, 1),
+                                           ("synth4096", 2000, 2), ("synth4096", 2000, 3), ("synth4096", 1, 5),
+                                           ("synth4096", 63, 6), ("synth4096", 257, 7), ("synth300", 5000, 8)])
+def test_associate3d_brute_bit_exact(gpu, oracle, map_v1, map_v2, which, N, seed):
+    torch, ctx = gpu
+    mean, cov = {"v1": map_v1, "v2": map_v2, "synth4096": synth.synth_gmm(4096, seed),
+                 "synth300": synth.synth_gmm(300, seed)}[which]
+    g, h = _mk(gpu, oracle, mean, cov)
+    pts = synth.synth_points(mean, cov, N, seed)
+    idx_ref, d2_ref = oracle.associate3d(h, pts)
+    idx, d2 = g.associate3d(torch.from_numpy(pts).cuda())
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(d2.cpu().numpy(), d2_ref)  # same expression, same rounding
+    oracle.gmm_destroy(h)
+
+
+def test_associate3d_ties_and_exact_hits(gpu, oracle):
+    """Duplicate components: the lowest index must win; a point at a mean has d2 == 0."""
+    torch, ctx = gpu
+    mean, cov = synth.synth_gmm(200, 11)
+    mean = np.concatenate([mean, mean[:50]])
+    cov = np.concatenate([cov, cov[:50]])
+    g, h = _mk(gpu, oracle, mean, cov)
+    pts = mean[:50].copy()
+    idx, d2 = g.associate3d(torch.from_numpy(pts).cuda())
+    idx_ref, d2_ref = oracle.associate3d(h, pts)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert (d2.cpu().numpy() == 0).all() and (idx.cpu().numpy() < 200).all()
+    oracle.gmm_destroy(h)
+
+
+def test_associate3d_empty(gpu, map_v1):
+    torch, ctx = gpu
+    g = api.GMM(ctx, *map_v1)
+    idx, d2 = g.associate3d(torch.empty((0, 3), dtype=torch.float64, device="cuda"))
+    assert idx.numel() == 0
+
+
+def test_associate3d_order_invariance(gpu, map_v1):
+    """argmin must not depend on the order / batching of the points."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    g = api.GMM(ctx, mean, cov)
+    pts = synth.synth_points(mean, cov, 3000, 4)
+    perm = np.random.default_rng(0).permutation(3000)
+    a, _ = g.associate3d(torch.from_numpy(pts).cuda())
+    b, _ = g.associate3d(torch.from_numpy(np.ascontiguousarray(pts[perm])).cuda())
+    assert np.array_equal(a.cpu().numpy()[perm], b.cpu().numpy())
+
+
+@pytest.mark.parametrize("which", ["v1", "v2"])
+def test_knn3d_and_query_point(gpu, oracle, map_v1, map_v2, which):
+    torch, ctx = gpu
+    mean, cov = {"v1": map_v1, "v2": map_v2}[which]
+    g, h = _mk(gpu, oracle, mean, cov)
+    pts = synth.synth_points(mean, cov, 1500, 9)
+    ki, kd, _ = oracle.knn3d(h, pts, 5)
+    gi, gd = g.knn3d(torch.from_numpy(pts).cuda(), 5)
+    assert np.array_equal(gi.cpu().numpy(), ki)
+    assert np.array_equal(gd.cpu().numpy(), kd)
+    if oracle.nf is not None:  # the reference's own vendored nanoflann
+        ni, nd, _ = oracle.nanoflann_knn(mean, pts, 5)
+        assert np.array_equal(gi.cpu().numpy(), ni)
+    q = g.queryPoint(torch.from_numpy(pts).cuda())
+    assert np.array_equal(q.cpu().numpy(), ki[:, 0])
+    oracle.gmm_destroy(h)
+
+
+def test_gmm_file_roundtrip(gpu, map_v1, tmp_path):
+    torch, ctx = gpu
+    mean, cov = map_v1
+    g = api.GMM(ctx, mean, cov)
+    p = tmp_path / "m.gmm"
+    g.save(p)
+    g2 = api.GMM.load(ctx, p)
+    assert g2.K == g.K
+    assert np.array_equal(g2.get(api.F_MEAN), mean)
+    # saveGMMModel writes cov(i) column-major and loadGMMModel reads row-major (gmm_utils.cpp:54-59,102-104)
+    assert np.array_equal(g2.get(api.F_COV).reshape(-1, 3, 3), cov.reshape(-1, 3, 3).transpose(0, 2, 1))
+    with pytest.raises(api.GLError):
+        api.GMM.load(ctx, tmp_path / "does_not_exist.gmm")
+    (tmp_path / "bad.gmm").write_bytes(b"\x02\x05\x08")
+    with pytest.raises(api.GLError):
+        api.GMM.load(ctx, tmp_path / "bad.gmm")

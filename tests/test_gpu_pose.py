@@ -1,0 +1,83 @@
+"""GPU parity: Tracking::optimizeCurrentPose (B3) vs the oracle.
+Tolerance (north_star): pose within 1e-6 m / 1e-6 rad; outlier masks and inlier counts equal."""
+import numpy as np
+import pytest
+
+from gmmloc_amd import synth, api
+import gmmloc_amd
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_R = 1e-6, 1e-6
+
+
+def pose_err(a, b):
+    Ra, Rb = synth.quat_to_R(a[:4]), synth.quat_to_R(b[:4])
+    dR = Ra @ Rb.T
+    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
+    return np.linalg.norm(a[4:] - b[4:]), ang
+
+
+def make_frames(mean, cov, gt, cam, B, M, seed0, **kw):
+    fr = []
+    for i in range(B):
+        row = gt[(i * 37) % gt.shape[0]]
+        fr.append(synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(row), cam, M, seed0 + i, **kw))
+    return fr
+
+
+def run_gpu(gpu, cam, prm, frames):
+    torch, ctx = gpu
+    pose = torch.from_numpy(np.stack([f["pose_init"] for f in frames])).cuda()
+    Xw = torch.from_numpy(np.stack([f["Xw"] for f in frames])).cuda()
+    obs = torch.from_numpy(np.stack([f["obs"] for f in frames])).cuda()
+    octv = torch.from_numpy(np.stack([f["octave"] for f in frames])).cuda()
+    outl, nin = gmmloc_amd.optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octv)
+    torch.cuda.synchronize()
+    return pose.cpu().numpy(), outl.cpu().numpy(), nin.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,seed", [(300, 100), (1200, 200), (2000, 300), (37, 400)])
+def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, M, seed):
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 6, M, seed)
+    pose, outl, nin = run_gpu(gpu, cam, prm, frames)
+    for i, f in enumerate(frames):
+        p_ref, o_ref, n_ref = oracle.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
+        dt, dr = pose_err(pose[i], p_ref)
+        assert dt < TOL_T and dr < TOL_R, (i, dt, dr)
+        assert np.array_equal(outl[i], o_ref), (i, int((outl[i] != o_ref).sum()))
+        assert nin[i] == n_ref
+        # and the optimiser actually recovers the generating pose to noise level
+        gt_dt, gt_dr = pose_err(pose[i], f["pose_gt"])
+        if M >= 300:
+            assert gt_dt < 0.05 and gt_dr < 0.02
+
+
+def test_optimize_current_pose_edge_cases(gpu, oracle, map_v1, gt_sync):
+    """< 3 correspondences -> returns 0 and leaves the pose; < 10 -> single round; features
+    without map point (octave < 0) are skipped; noise-free input recovers the pose."""
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, 4, 64, 900, outlier_frac=0.0)
+    frames[0]["octave"][2:] = -1  # 2 edges
+    frames[1]["octave"][7:] = -1  # 7 edges
+    frames[2]["octave"][::3] = -1
+    # frame 3: noise-free
+    f = frames[3]
+    R, t = synth.quat_to_R(f["pose_gt"][:4]), f["pose_gt"][4:]
+    pc = f["Xw"] @ R.T + t
+    f["obs"][:, 0] = cam.fx * pc[:, 0] / pc[:, 2] + cam.cx
+    f["obs"][:, 1] = cam.fy * pc[:, 1] / pc[:, 2] + cam.cy
+    f["obs"][:, 2] = f["obs"][:, 0] - cam.bf / pc[:, 2]
+    pose, outl, nin = run_gpu(gpu, cam, prm, frames)
+    for i, f in enumerate(frames):
+        p_ref, o_ref, n_ref = oracle.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
+        dt, dr = pose_err(pose[i], p_ref)
+        assert dt < TOL_T and dr < TOL_R, (i, dt, dr)
+        assert nin[i] == n_ref
+        assert np.array_equal(outl[i], o_ref)
+    assert nin[0] == 0 and np.allclose(pose[0], frames[0]["pose_init"] / np.r_[np.ones(4) * np.linalg.norm(frames[0]["pose_init"][:4]), 1, 1, 1])
+    dt, dr = pose_err(pose[3], frames[3]["pose_gt"])
+    assert dt < 1e-8 and dr < 1e-8
