@@ -70,19 +70,36 @@ def _ptr(t):
 
 
 class Context:
-    """gl_ctx_t: device + HIP stream + scratch.  stream=None -> torch's current stream."""
+    """gl_ctx_t: device + HIP stream + scratch.
 
-    def __init__(self, device=0, stream="torch"):
+    The context owns a dedicated torch stream (``ctx.stream``) and launches every kernel on
+    it.  (torch's default stream is NOT ordered with kernels an external library puts on
+    HIP's null stream -- measured on the MI355X box -- so the null stream is never used.)
+    The wrappers below order the context stream against torch's current stream with
+    events (``_enter`` / ``_exit``); under ``with torch.cuda.stream(ctx.stream):`` both are
+    no-ops and calls are fully asynchronous.
+    """
+
+    def __init__(self, device=0):
         import torch
+        self.torch = torch
         self.lib = _lib.load()
         self.device = device
-        if stream == "torch":
-            with torch.cuda.device(device):
-                s = torch.cuda.current_stream(device).cuda_stream
-            stream = s if s else None  # 0 = the default (null) stream
+        with torch.cuda.device(device):
+            self.stream = torch.cuda.Stream(device)
         h = C.c_void_p()
-        _check(self.lib.gl_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        _check(self.lib.gl_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.h = h
+
+    def _enter(self):
+        cur = self.torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+
+    def _exit(self):
+        cur = self.torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
 
     def synchronize(self):
         _check(self.lib.gl_ctx_synchronize(self.h))
@@ -159,7 +176,9 @@ class GMM:
         N = pts.shape[0]
         idx = torch.empty(N, dtype=torch.int32, device=pts.device)
         d2 = torch.empty(N, dtype=torch.float64, device=pts.device) if want_d2 else None
+        self.ctx._enter()
         _check(self.lib.gl_associate3d(self.ctx.h, self.h, _ptr(pts), N, mode, _ptr(idx), _ptr(d2)))
+        self.ctx._exit()
         return idx, d2
 
     def knn3d(self, pts, k=5):
@@ -167,7 +186,9 @@ class GMM:
         N = pts.shape[0]
         idx = torch.empty((N, k), dtype=torch.int32, device=pts.device)
         dist = torch.empty((N, k), dtype=torch.float64, device=pts.device)
+        self.ctx._enter()
         _check(self.lib.gl_knn3d(self.ctx.h, self.h, _ptr(pts), N, k, _ptr(idx), _ptr(dist)))
+        self.ctx._exit()
         return idx, dist
 
     def queryPoint(self, pts):
@@ -194,6 +215,8 @@ def optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octave):
     B, M = octave.shape
     outlier = torch.zeros((B, M), dtype=torch.uint8, device=pose.device)
     nin = torch.zeros(B, dtype=torch.int32, device=pose.device)
+    ctx._enter()
     _check(ctx.lib.gl_optimize_current_pose(ctx.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
                                             _ptr(obs), _ptr(octave), _ptr(outlier), _ptr(nin)))
+    ctx._exit()
     return outlier, nin

@@ -225,9 +225,10 @@ extern "C" {
 
 int gl_knn3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int k, int32_t* idx_dev,
              double* dist_dev) {
-  GL_REQUIRE(ctx && gmm && idx_dev, "null argument");
+  GL_REQUIRE(ctx && gmm, "null argument");
   GL_REQUIRE(k >= 1 && k <= 8, "k must be in [1, 8]");
   if (N == 0) return GL_OK;
+  GL_REQUIRE(idx_dev, "null argument");
   GL_REQUIRE(N > 0 && pts_dev, "bad N / pts");
   gl::Ctx* c = gl::C(ctx);
   gl::Gmm* g = gl::G(gmm);
@@ -252,9 +253,10 @@ int gl_knn3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, i
 
 int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int mode, int32_t* idx_dev,
                    double* d2_dev) {
-  GL_REQUIRE(ctx && gmm && idx_dev, "null argument");
+  GL_REQUIRE(ctx && gmm, "null argument");
   GL_REQUIRE(mode == GL_ASSOC_BRUTE || mode == GL_ASSOC_KNN5_EUCLID, "unknown mode");
   if (N == 0) return GL_OK;
+  GL_REQUIRE(idx_dev, "null argument");
   GL_REQUIRE(N > 0 && pts_dev, "bad N / pts");
   gl::Ctx* c = gl::C(ctx);
   gl::Gmm* g = gl::G(gmm);

@@ -1,0 +1,549 @@
+"""TEST INFRASTRUCTURE ONLY -- an independent numpy restatement of the gmmloc hot path.
+
+Purpose: pin the C++ oracle (oracle/gmmloc_oracle.cpp).  The reference ships no tests
+and cannot be compiled here (Eigen / g2o / OpenCV / ROS absent), so this second,
+differently-structured implementation (LAPACK inverses / eigh / cholesky, vectorised
+pair sweeps, a dense *un-reduced* Levenberg system instead of the Schur complement,
+geometric Jacobians J = -Jpi [ -[p]x | I ]) is what the golden vectors under
+tests/golden/ are generated from (tools/make_golden.py).  Reference lines are cited per
+function; g2o semantics per SURVEY.md Appendix A.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def default_sigma2_inv():
+    # init_config.hpp:60-79 -- float arithmetic
+    sf = F32(1.0)
+    out = [F32(1.0)]
+    for _ in range(1, 8):
+        sf = F32(sf * F32(1.2))
+        out.append(F32(F32(1.0) / F32(sf * sf)))
+    return np.array(out, dtype=np.float32)
+
+
+class Cam:
+    def __init__(self, fx, fy, cx, cy, bf, width, height):
+        self.fx, self.fy, self.cx, self.cy, self.bf, self.width, self.height = fx, fy, cx, cy, bf, width, height
+
+
+class Prm:
+    def __init__(self):
+        self.neighbor_dist_thresh = 2.5
+        self.tri_lambda2 = F32(400.0)
+        self.tri_str_thresh = F32(0.0064)
+        self.ba_lambda2 = F32(400.0)
+        self.tri_check_str_chi2 = True
+        self.ba_first_as_prior = True
+        self.sigma2_inv = default_sigma2_inv()
+
+
+# ------------------------------------------------------------------ A0 / A1 / A2
+def build_components(mean, cov):
+    """gaussian.h:30-39, gaussian.cpp:36-63."""
+    C = cov.reshape(-1, 3, 3)
+    inv = np.linalg.inv(C)
+    det = np.linalg.det(C)
+    w, V = np.linalg.eigh(C)
+    L = np.linalg.cholesky(0.5 * (inv + inv.transpose(0, 2, 1)))
+    return dict(cov_inv=inv, det=det, scale=w, axis=V, sqrt_info=L, is_deg=w[:, 0] < 1e-4,
+                is_salient=(w[:, 1] > 0.2) & (w[:, 2] > 0.2))
+
+
+def chi2_all(mean, cov_inv, pts):
+    """gaussian.cpp:65-70 for every (point, component): (N, K)."""
+    d = pts[:, None, :] - mean[None, :, :]
+    return np.einsum("nki,kij,nkj->nk", d, cov_inv, d)
+
+
+def bh(mean0, cov0, det0, mean1, cov1, det1):
+    """gmm_utils.h:30-52, broadcasting over leading dims (any dimension 2 or 3)."""
+    c = (cov0 + cov1) / 2.0
+    d = mean1 - mean0
+    d0 = np.einsum("...i,...ij,...j->...", d, np.linalg.inv(c), d) / 8.0
+    d1 = np.log(np.linalg.det(c) / np.sqrt(det0 * det1)) / 2.0
+    return d0 + d1
+
+
+def neighbour_rows(mean, cov, det, rows, thresh=2.5):
+    """gaussian_mixture.cpp:61-78 for the given rows -> list of (idx array, dist array)."""
+    C = cov.reshape(-1, 3, 3)
+    out = []
+    for i in rows:
+        dist = bh(mean[i], C[i], det[i], mean, C, det)
+        dist[i] = np.inf
+        j = np.nonzero(dist < thresh)[0]
+        out.append((j, dist[j]))
+    return out
+
+
+# ------------------------------------------------------------------ SE3 (g2o se3quat.h)
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def q2R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def R2q(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0)
+        q = np.array([(R[2, 1] - R[1, 2]) * 0.5 / s, (R[0, 2] - R[2, 0]) * 0.5 / s, (R[1, 0] - R[0, 1]) * 0.5 / s,
+                      0.5 * s])
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]:
+            i = 1
+        if R[2, 2] > R[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q = np.zeros(4)
+        q[i] = 0.5 * s
+        q[3] = (R[k, j] - R[j, k]) * 0.5 / s
+        q[j] = (R[j, i] + R[i, j]) * 0.5 / s
+        q[k] = (R[k, i] + R[i, k]) * 0.5 / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+class SE3:
+    """T = (R, t), x -> R x + t; kept as a rotation matrix (the C++ oracle keeps quaternions)."""
+
+    def __init__(self, R, t):
+        self.R, self.t = np.array(R, float), np.array(t, float)
+
+    @staticmethod
+    def from7(p):
+        q = np.asarray(p[:4], float)
+        q = q / np.linalg.norm(q)
+        return SE3(q2R(q), p[4:7])
+
+    def to7(self):
+        return np.concatenate([R2q(self.R), self.t])
+
+    def map(self, x):
+        return x @ self.R.T + self.t
+
+    def mul(self, o):
+        return SE3(self.R @ o.R, self.R @ o.t + self.t)
+
+    def inv(self):
+        return SE3(self.R.T, -self.R.T @ self.t)
+
+    @staticmethod
+    def exp(u):
+        w, v = u[:3], u[3:]
+        th = np.linalg.norm(w)
+        W = skew(w)
+        if th < 1e-5:
+            R = np.eye(3) + W + 0.5 * W @ W
+            V = np.eye(3) + 0.5 * W + W @ W / 6.0
+        else:
+            R = np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W @ W
+            V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * W + (th - np.sin(th)) / th ** 3 * W @ W
+        # g2o re-normalises through a quaternion
+        return SE3(q2R(R2q(R)), V @ v)
+
+    def log(self):
+        R = self.R
+        d = 0.5 * (np.trace(R) - 1)
+        dR = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        if abs(d) > 0.99999:
+            w = 0.5 * dR
+            W = skew(w)
+            Vi = np.eye(3) - 0.5 * W + W @ W / 12.0
+        else:
+            th = np.arccos(d)
+            w = th / (2 * np.sqrt(1 - d * d)) * dR
+            W = skew(w)
+            Vi = np.eye(3) - 0.5 * W + (1 - th / (2 * np.tan(th / 2))) / th ** 2 * W @ W
+        return np.concatenate([w, Vi @ self.t])
+
+    def adj(self):
+        A = np.zeros((6, 6))
+        A[:3, :3] = self.R
+        A[3:, 3:] = self.R
+        A[3:, :3] = skew(self.t) @ self.R
+        return A
+
+
+# ------------------------------------------------------------------ A3 / A4 / A5
+def project_gaussian(mu, C, cam, R, t):
+    """gmm_utils.cpp:121-146, pinhole_camera.cpp:68-150 -> (mean2d, cov2d, depth) or None."""
+    pc = R @ mu + t
+    x, y, z = pc
+    if not z > 0:
+        return None
+    u, v = cam.fx * x / z + cam.cx, cam.fy * y / z + cam.cy
+    if not (u >= 0 and v >= 0 and u < cam.width and v < cam.height):
+        return None
+    J = np.array([[cam.fx / z, 0, -cam.fx * x / z ** 2], [0, cam.fy / z, -cam.fy * y / z ** 2]])
+    return np.array([u, v]), J @ R @ C @ R.T @ J.T, z
+
+
+def render_view(mean, cov, comps, cam, pose7):
+    """gaussian_mixture.cpp:271-371 -> list of dict(id, mean, cov, det, depth), depth-descending."""
+    T = SE3.from7(pose7)
+    R, t = T.R, T.t
+    twc = -R.T @ t
+    C3 = cov.reshape(-1, 3, 3)
+    out = []
+    cos_thr = np.cos(78.0 * np.pi / 180.0)
+    for k in range(mean.shape[0]):
+        if comps["is_deg"][k]:
+            po = mean[k] - twc
+            po = po / np.linalg.norm(po)
+            if abs(po @ comps["axis"][k][:, 0]) < cos_thr:
+                continue
+        pg = project_gaussian(mean[k], C3[k], cam, R, t)
+        if pg is None:
+            continue
+        m2, c2, z = pg
+        w = np.linalg.eigvalsh(0.5 * (c2 + c2.T))
+        if w[0] < 4.0 and w[1] < 4.0:
+            continue
+        g = dict(id=k, mean=m2, cov=c2, det=np.linalg.det(c2), depth=z)
+        if out:
+            d = np.array([bh(o["mean"], o["cov"], o["det"], g["mean"], g["cov"], g["det"]) for o in out])
+            d = np.where(np.isnan(d), np.inf, d)
+            j = int(np.argmin(d))
+            if d[j] < 0.8:
+                if g["depth"] < out[j]["depth"]:
+                    out[j] = g
+            else:
+                out.append(g)
+        else:
+            out.append(g)
+    order = sorted(range(len(out)), key=lambda i: -out[i]["depth"])  # stable
+    return [out[i] for i in order]
+
+
+def search_correspondence(view, uv, k=5):
+    """gaussian_mixture.cpp:484-534 -> (cand (N,k) parent ids / -1, ncand)."""
+    N = uv.shape[0]
+    cand = -np.ones((N, k), np.int32)
+    ncand = np.zeros(N, np.int32)
+    if not view:
+        return cand, ncand
+    m = np.stack([g["mean"] for g in view])
+    inv = np.stack([np.linalg.inv(g["cov"]) for g in view])
+    for n in range(N):
+        d = ((uv[n] - m) ** 2).sum(1)
+        order = np.argsort(d, kind="stable")[:k]
+        c = 0
+        for j in order:
+            dd = uv[n] - m[j]
+            if dd @ inv[j] @ dd < 9.0:
+                cand[n, c] = view[j]["id"]
+                c += 1
+        ncand[n] = c
+    return cand, ncand
+
+
+# ------------------------------------------------------------------ edges
+def proj_stereo(pc, cam):
+    iz = 1.0 / pc[2]
+    u = pc[0] * iz * cam.fx + cam.cx
+    return np.array([u, pc[1] * iz * cam.fy + cam.cy, u - cam.bf * iz])
+
+
+def dproj(pc, cam, stereo):
+    x, y, z = pc
+    J = np.array([[cam.fx / z, 0, -cam.fx * x / z ** 2], [0, cam.fy / z, -cam.fy * y / z ** 2]])
+    if stereo:
+        J = np.vstack([J, J[0] + np.array([0, 0, cam.bf / z ** 2])])
+    return J
+
+
+def huber(e, delta):
+    d2 = delta * delta
+    if e <= d2:
+        return e, 1.0
+    s = np.sqrt(e)
+    return 2 * s * delta - d2, delta / s
+
+
+def fdelta(c):
+    return float(F32(np.sqrt(c)))
+
+
+# ------------------------------------------------------------------ B1
+def optimize_point(pt, uvr, octave, pose7, normal, mu, proj_z2, cam, prm):
+    """gmmloc_opt.cpp:260-342: 5 Gauss-Newton steps; chi2 values are those of the LAST
+    computeActiveErrors(), i.e. evaluated before the 5th update (g2o does not re-evaluate)."""
+    T = SE3.from7(pose7)
+    s = float(prm.sigma2_inv[octave])
+    lam = float(prm.tri_lambda2) * proj_z2
+    x = np.array(pt, float)
+    for _ in range(5):
+        pc = T.map(x)
+        e = uvr - proj_stereo(pc, cam)
+        J = -dproj(pc, cam, True) @ T.R
+        es = normal @ (x - mu)
+        H = s * J.T @ J + lam * np.outer(normal, normal)
+        b = -(s * J.T @ e + lam * normal * es)
+        chi2_proj, chi2_str = s * e @ e, lam * es * es
+        x = x + np.linalg.solve(H, b)
+    res = True
+    if chi2_proj > 7.815:
+        res = False
+    if prm.tri_check_str_chi2 and chi2_str > float(F32(prm.tri_str_thresh * prm.tri_lambda2)):
+        res = False
+    return res, chi2_proj, chi2_str, x
+
+
+# ------------------------------------------------------------------ generic dense LM (B3 / B4)
+class Problem:
+    """Un-reduced dense Levenberg-Marquardt over free poses (6) and free points (3) with the
+    g2o control flow (OptimizationAlgorithmLevenberg::solve).  Edges are dicts."""
+
+    def __init__(self, cam, prm):
+        self.cam, self.prm = cam, prm
+        self.poses, self.pose_fixed = [], []
+        self.points = []
+        self.edges = []
+
+    def residual(self, e):
+        cam = self.cam
+        k = e["kind"]
+        if k in ("pose_mono", "pose_stereo", "ba_mono", "ba_stereo"):
+            T = self.poses[e["pose"]]
+            X = e["Xw"] if k.startswith("pose") else self.points[e["pt"]]
+            pc = T.map(X)
+            pr = proj_stereo(pc, cam)
+            st = k.endswith("stereo")
+            r = e["meas"][:3 if st else 2] - pr[:3 if st else 2]
+            Jp = -dproj(pc, cam, st) @ np.hstack([-skew(pc), np.eye(3)])
+            Jx = -dproj(pc, cam, st) @ T.R
+            return r, Jp, Jx, pc
+        if k == "deg":
+            x = self.points[e["pt"]]
+            return np.array([e["normal"] @ (x - e["mean"])]), None, e["normal"][None, :], None
+        if k == "gauss":
+            x = self.points[e["pt"]]
+            Lt = e["sqrt_info"].T
+            return Lt @ (x - e["mean"]), None, Lt, None
+        if k == "prior":
+            T = self.poses[e["pose"]]
+            d = e["inv_meas"].mul(T)
+            dv = d.log()
+            Jr = np.zeros((6, 6))
+            Jr[:3, :3] = skew(dv[:3])
+            Jr[3:, 3:] = skew(dv[:3])
+            Jr[:3, 3:] = skew(dv[3:])
+            Jr = np.eye(6) + 0.5 * Jr
+            return dv, Jr @ T.inv().adj(), None, None
+        raise ValueError(k)
+
+    def chi2(self, e):
+        r = self.residual(e)[0]
+        return float(r @ e["info"] @ r)
+
+    def activate(self, level):
+        self.active = [e for e in self.edges if e["level"] == level and not self._all_fixed(e)]
+        fp = sorted({e["pose"] for e in self.active if "pose" in e and not self.pose_fixed[e["pose"]]})
+        fx = sorted({e["pt"] for e in self.active if "pt" in e})
+        self.ip = {p: 6 * i for i, p in enumerate(fp)}
+        self.ix = {x: 6 * len(fp) + 3 * i for i, x in enumerate(fx)}
+        self.n = 6 * len(fp) + 3 * len(fx)
+
+    def _all_fixed(self, e):
+        if "pt" in e:
+            return False
+        return self.pose_fixed[e["pose"]]
+
+    def compute_errors(self):
+        for e in self.active:
+            e["chi2"] = self.chi2(e)
+
+    def robust_chi2(self):
+        return sum(huber(e["chi2"], e["delta"])[0] if e["robust"] else e["chi2"] for e in self.active)
+
+    def build(self):
+        H, b = np.zeros((self.n, self.n)), np.zeros(self.n)
+        for e in self.active:
+            r, Jp, Jx, _ = self.residual(e)
+            w = huber(e["chi2"], e["delta"])[1] if e["robust"] else 1.0
+            blocks = []
+            if Jp is not None and not self.pose_fixed[e["pose"]]:
+                blocks.append((self.ip[e["pose"]], Jp))
+            if Jx is not None and "pt" in e:
+                blocks.append((self.ix[e["pt"]], Jx))
+            for (o1, J1) in blocks:
+                b[o1:o1 + J1.shape[1]] -= w * J1.T @ e["info"] @ r
+                for (o2, J2) in blocks:
+                    H[o1:o1 + J1.shape[1], o2:o2 + J2.shape[1]] += w * J1.T @ e["info"] @ J2
+        return H, b
+
+    def state(self):
+        return [SE3(T.R.copy(), T.t.copy()) for T in self.poses], [x.copy() for x in self.points]
+
+    def restore(self, s):
+        self.poses, self.points = s[0], s[1]
+
+    def apply(self, dx):
+        for p, o in self.ip.items():
+            self.poses[p] = SE3.exp(dx[o:o + 6]).mul(self.poses[p])
+        for x, o in self.ix.items():
+            self.points[x] = self.points[x] + dx[o:o + 3]
+
+    def optimize(self, iters):
+        if self.n == 0:
+            return -1
+        done = 0
+        for it in range(iters):
+            self.compute_errors()
+            cur = self.robust_chi2()
+            H, b = self.build()
+            if it == 0:
+                self.lam = 1e-5 * np.max(np.abs(np.diag(H)))
+                self.ni = 2.0
+            rho, q = 0.0, 0
+            while True:
+                saved = self.state()
+                try:
+                    Hl = H + self.lam * np.eye(self.n)
+                    np.linalg.cholesky(Hl)
+                    dx = np.linalg.solve(Hl, b)
+                    ok = True
+                except np.linalg.LinAlgError:
+                    dx, ok = np.zeros(self.n), False
+                self.apply(dx)
+                self.compute_errors()
+                tmp = self.robust_chi2() if ok else np.finfo(float).max
+                rho = (cur - tmp) / (dx @ (self.lam * dx + b) + 1e-3)
+                if rho > 0 and np.isfinite(tmp):
+                    a = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                    self.lam *= max(1.0 / 3.0, a)
+                    self.ni = 2.0
+                    cur = tmp
+                else:
+                    self.lam *= self.ni
+                    self.ni *= 2
+                    self.restore(saved)
+                q += 1
+                if not (rho < 0 and q < 10):
+                    break
+            done += 1
+            if q == 10 or rho == 0:
+                break
+        return done
+
+
+def optimize_current_pose(pose7, Xw, obs, octave, cam, prm):
+    """tracking_opt.cpp:21-217 -> (pose7, is_outlier, n_inliers)."""
+    N = Xw.shape[0]
+    pb = Problem(cam, prm)
+    T0 = SE3.from7(pose7)
+    pb.poses, pb.pose_fixed = [T0], [False]
+    idx = []
+    for i in range(N):
+        if octave[i] < 0:
+            continue
+        mono = obs[i, 2] < 0
+        s = float(prm.sigma2_inv[octave[i]])
+        pb.edges.append(dict(kind="pose_mono" if mono else "pose_stereo", pose=0, Xw=Xw[i], meas=obs[i],
+                             info=s * np.eye(2 if mono else 3), robust=True,
+                             delta=fdelta(5.991 if mono else 7.815), level=0, chi2=0.0))
+        idx.append(i)
+    outl = np.zeros(N, np.uint8)
+    if len(idx) < 3:
+        return pose7.copy(), outl, 0
+    nbad = 0
+    for rnd in range(4):
+        pb.poses = [SE3(T0.R.copy(), T0.t.copy())]
+        pb.activate(0)
+        pb.optimize(10)
+        nbad = 0
+        for e, i in zip(pb.edges, idx):
+            if outl[i]:
+                e["chi2"] = pb.chi2(e)
+            thr = F32(5.991) if e["kind"] == "pose_mono" else F32(7.815)
+            if F32(e["chi2"]) > thr:
+                outl[i], e["level"] = 1, 1
+                nbad += 1
+            else:
+                outl[i], e["level"] = 0, 0
+            if rnd == 2:
+                e["robust"] = False
+        if len(pb.edges) < 10:
+            break
+    return pb.poses[0].to7(), outl, len(idx) - nbad
+
+
+def joint_optimization(P, F, poses7, has_prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_oct, comps, mean,
+                       cam, prm):
+    """localization_opt.cpp:456-925 on the flat problem (see oracle/gmmloc_oracle.cpp)."""
+    pb = Problem(cam, prm)
+    pb.poses = [SE3.from7(p) for p in poses7]
+    pb.pose_fixed = [False] * P + [True] * F
+    pb.points = [np.array(x, float) for x in points]
+    L = len(points)
+    gmm_deg = [None] * L
+    eobs = []
+    for i in range(P):
+        if has_prior[i]:
+            if prm.ba_first_as_prior:
+                sr = 1.0 / (2.0 * np.pi / 180.0) ** 2
+                info = np.diag([sr] * 3 + [1.0 / 0.01 ** 2] * 3)
+                pb.edges.append(dict(kind="prior", pose=i, inv_meas=pb.poses[i].inv(), info=info, robust=False,
+                                     delta=0.0, level=0, chi2=0.0))
+            else:
+                pb.pose_fixed[i] = True
+    for l in range(L):
+        a = assoc[l]
+        if a >= 0:
+            if comps["is_deg"][a]:
+                e = dict(kind="deg", pt=l, normal=comps["axis"][a][:, 0].copy(), mean=mean[a].copy(),
+                         info=float(prm.ba_lambda2) * np.eye(1), robust=False, delta=0.0, level=0, chi2=0.0)
+                gmm_deg[l] = e
+            else:
+                e = dict(kind="gauss", pt=l, sqrt_info=comps["sqrt_info"][a], mean=mean[a].copy(), info=np.eye(3),
+                         robust=False, delta=0.0, level=0, chi2=0.0)
+            pb.edges.append(e)
+        for o in range(obs_ptr[l], obs_ptr[l + 1]):
+            mono = obs_uvr[o, 2] < 0
+            s = float(prm.sigma2_inv[obs_oct[o]])
+            e = dict(kind="ba_mono" if mono else "ba_stereo", pt=l, pose=int(obs_pose[o]), meas=obs_uvr[o],
+                     info=s * np.eye(2 if mono else 3), robust=True, delta=fdelta(5.991 if mono else 7.815),
+                     level=0, chi2=0.0)
+            pb.edges.append(e)
+            eobs.append(e)
+    thr_str = float(F32(prm.tri_str_thresh * prm.ba_lambda2))
+    pb.activate(0)
+    pb.optimize(5)
+    for e in gmm_deg:
+        if e is None:
+            continue
+        e["chi2"] = pb.chi2(e)
+        if e["chi2"] > thr_str:
+            e["level"] = 1
+        e["robust"] = False
+    pb.activate(0)
+    pb.optimize(5)
+    for e in eobs:
+        th = 5.991 if e["kind"] == "ba_mono" else 7.815
+        pc = pb.poses[e["pose"]].map(pb.points[e["pt"]])
+        if e["chi2"] > th or not pc[2] > 0:
+            e["level"] = 1
+        e["robust"] = False
+    pb.activate(0)
+    iters = pb.optimize(40)
+    dropped = np.zeros(L, np.uint8)
+    for l, e in enumerate(gmm_deg):
+        if e is not None and pb.chi2(e) > thr_str:
+            dropped[l] = 1
+    erase = np.zeros(len(eobs), np.uint8)
+    for o, e in enumerate(eobs):
+        th = 5.991 if e["kind"] == "ba_mono" else 7.815
+        pc = pb.poses[e["pose"]].map(pb.points[e["pt"]])
+        erase[o] = 1 if (e["chi2"] > th or not pc[2] > 0) else 0
+    return (np.stack([T.to7() for T in pb.poses[:P]]), np.stack(pb.points), dropped, erase, iters)
