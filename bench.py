@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the gmmloc hot path on MI355X: frames/sec (associate + pose-refine),
+2 000 map points x 4 096 Gaussians (BASELINE.json configs[1] shape).
+
+A "step" = one pass of gl_track_frames over one batch of --batch synthetic frames that are
+already resident in HBM: exhaustive fp64 Mahalanobis association of every frame's 2 000 map
+points against the 4 096 map Gaussians + the structure-constrained refinement (single free
+pose, Schur-marginalised points, 5/5/40 LM schedule).  The in-place state (poses, points) is
+restored from pristine device copies inside the timed region.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Frames are independent units: with N > 1 every rank owns its own batch (weak scaling, GMM
+replicated, no data-path collective); the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is reported.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PTS, K_GAUSS = 2000, 4096
+FLOP_PER_PAIR = 21           # centred symmetric Mahalanobis form
+PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X fp64 vector peak (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_workload(B, seed0=20200901):
+    from gmmloc_amd import synth, api
+    cam = api.Camera()
+    mean, cov = synth.synth_gmm(K_GAUSS, 1)
+    rng = np.random.default_rng(seed0)
+    frames = []
+    for i in range(B):
+        eye = rng.uniform([-3.5, -2.5, 0.8], [2.5, 3.5, 2.2])
+        tgt = eye + np.array([np.cos(rng.uniform(0, 2 * np.pi)), np.sin(rng.uniform(0, 2 * np.pi)), rng.uniform(-0.3, 0.3)]) * 3.0
+        frames.append(synth.synth_frame(mean, cov, synth.look_at_pose(eye, tgt), cam, N_PTS, seed0 + i))
+    return mean, cov, cam, frames
+
+
+def cpu_baseline(mean, cov, cam, frames, budget_s=15.0):
+    """The oracle (CPU port of the reference algorithm) on the same workload, 1 thread,
+    bounded sample."""
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+    h = orc.gmm_create(mean, cov)
+    t0 = time.perf_counter()
+    n = 0
+    t_assoc = 0.0
+    for f in frames:
+        ta = time.perf_counter()
+        idx, d2 = orc.associate3d(h, f["Xw"])
+        t_assoc += time.perf_counter() - ta
+        assoc = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
+        L = f["Xw"].shape[0]
+        orc.joint_optimization(h, cam, 1, 0, f["pose_init"][None], np.zeros(1, np.uint8), f["Xw"], assoc,
+                               np.arange(L + 1, dtype=np.int32), np.zeros(L, np.int32), f["obs"], f["octave"])
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    orc.gmm_destroy(h)
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same workload (oracle associate3d + joint_optimization, 1 thread); "
+                      "association alone %.1f ms/frame" % (n, 1e3 * t_assoc / n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gmmloc_amd
+    from gmmloc_amd import api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B = args.batch
+    mean, cov, cam, frames = make_workload(B, 20200901 + 100000 * rank)
+    prm = api.Params()
+    ctx = gmmloc_amd.Context(local)
+    gmm = gmmloc_amd.GMM(ctx, mean, cov, prm)
+
+    def dev_t(key):
+        return torch.from_numpy(np.stack([f[key] for f in frames])).to(dev)
+
+    pose0, Xw0, obs, octv = dev_t("pose_init"), dev_t("Xw"), dev_t("obs"), dev_t("octave")
+    pose, Xw = pose0.clone(), Xw0.clone()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        pose.copy_(pose0)
+        Xw.copy_(Xw0)
+        return gmmloc_amd.track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octv, want_d2=False)
+
+    with torch.cuda.stream(ctx.stream):
+        for _ in range(args.warmup):
+            step()
+        ctx.timing(True)
+        ctx.timing_read(api.TIMER_ASSOC, reset=True)
+        ctx.timing_read(api.TIMER_BA, reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            assoc, _ = step()
+        barrier()
+        dt = time.perf_counter() - t0
+    assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
+    ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
+    ctx.timing(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        frames_total = B * args.steps * world
+        pairs = float(B) * N_PTS * K_GAUSS
+        assoc_s = assoc_ms / 1e3 / max(assoc_n, 1)
+        ach_tflops = FLOP_PER_PAIR * pairs / assoc_s / 1e12 if assoc_n else None
+        # algorithmic HBM bytes of one association launch: points in, records in, idx+d2 out
+        alg_bytes = B * N_PTS * 24 + K_GAUSS * 96 + B * N_PTS * 12
+        out = {
+            "metric": "frames/sec (associate+pose-refine), 2k pts x 4k GMM",
+            "value": frames_total / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 2000 map points x 4096 Gaussians per frame "
+                                   "(95% planar map, SURVEY 8d), associate3d(brute) + structure-constrained "
+                                   "refine (1 free pose, Schur, LM 5/5/40)",
+                       "frames_per_step_per_gpu": B, "points_per_frame": N_PTS, "gaussians": K_GAUSS,
+                       "parallelism": "frames sharded, %d rank(s)" % world},
+            "roofline": {
+                "kernel": "k_assoc_brute (fp64 Mahalanobis argmin)",
+                "bound": "valu_fp64",
+                "achieved": ach_tflops,
+                "peak": PEAK_FP64_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (ach_tflops / PEAK_FP64_VALU_TFLOPS) if ach_tflops else None,
+                "traffic": None,
+                "avg_launch_ms": 1e3 * assoc_s,
+                "flop_per_launch": FLOP_PER_PAIR * pairs,
+                "hbm": {"achieved_GBs": alg_bytes / assoc_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes},
+            },
+            "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine": ba_ms / max(args.steps, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mean, cov, cam, frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

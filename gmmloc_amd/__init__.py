@@ -15,4 +15,5 @@ from .api import (  # noqa: F401
     ASSOC_BRUTE,
     ASSOC_KNN5_EUCLID,
     optimize_current_pose,
+    track_frames,
 )

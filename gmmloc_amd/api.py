@@ -220,3 +220,19 @@ def optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octave):
                                             _ptr(obs), _ptr(octave), _ptr(outlier), _ptr(nin)))
     ctx._exit()
     return outlier, nin
+
+
+def track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octave, want_d2=True):
+    """North-star per-frame path (gl_track_frames): exhaustive Mahalanobis association of the
+    M map points of each of the B frames against the K Gaussians + structure-constrained
+    refinement (jointOptimization with one free pose).  pose (B,7) and Xw (B,M,3) are updated
+    in place.  Returns (assoc int32 (B,M), d2 float64 (B,M) or None)."""
+    import torch
+    B, M = octave.shape
+    assoc = torch.empty((B, M), dtype=torch.int32, device=pose.device)
+    d2 = torch.empty((B, M), dtype=torch.float64, device=pose.device) if want_d2 else None
+    ctx._enter()
+    _check(ctx.lib.gl_track_frames(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
+                                   _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2)))
+    ctx._exit()
+    return assoc, d2

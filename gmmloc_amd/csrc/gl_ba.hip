@@ -1,0 +1,789 @@
+// Structure-constrained refinement: Localization::jointOptimization
+// (localization_opt.cpp:456-925) restricted to ONE free pose and L free,
+// marginalised map points, each with one reprojection edge (mono / stereo,
+// Huber) and at most one GMM edge (EdgePt2GaussianDeg x ba_lambda2, or
+// EdgePt2Gaussian), optional EdgeSE3QuatPrior -- the north-star "Gauss-Newton /
+// Schur reduction of reprojection + point-to-ellipsoid residuals".
+//
+// One persistent workgroup per frame, everything on-chip:
+//   pass A (state, lambda): per point, in the CAMERA frame q = R p + t
+//       A  = w Jpi^T Jpi,  a = w Jpi^T e            (reprojection, w = rho' / sigma^2)
+//       Hc = R Hg R^T,     bc = R bg                (GMM edge)
+//       D  = A + Hc + lambda I  -> D^-1 (cofactors, as g2o's Dinv = D->inverse())
+//       Schur:  S += G^T (A - A D^-1 A) G,  g += G^T (a - A D^-1 (a + bc)),  G = [-[q]x | I]
+//     (the orthogonal change of variables eps = R dp leaves lambda I and
+//     computeScale() invariant), then ONE deterministic 28-value workgroup
+//     reduction (gld::block_reduce), 6x6 LDL^T and exp() redundantly per thread;
+//   pass B: back-substitution eps = D^-1 (b - A G dx), trial state, new chi2.
+// Control flow = g2o OptimizationAlgorithmLevenberg::solve / SparseOptimizer::
+// optimize + the 5 / gate GMM / 5 / gate reprojection / 40 schedule
+// (localization_opt.cpp:770-828), incl. stale e->chi2() semantics.
+#include "gl_device.hpp"
+#include "gl_internal.hpp"
+
+#pragma clang fp contract(fast)
+
+using namespace gld;
+
+namespace {
+
+struct BaK {
+  double fx, fy, cx, cy, bf;
+  double s2inv[8];
+  double delta_mono, delta_stereo;
+  double ba_lambda2;   // (double) loc::ba_lambda2
+  double str_thresh;   // (double)(tri_str_thresh * ba_lambda2) in float
+  double gate_chi2;    // association gate of gl_track_frames (9.0), < 0 = keep all
+  int first_as_prior;
+};
+
+constexpr int T_BA = 256;
+constexpr int NW_BA = T_BA / 64;
+
+struct PtLin {
+  double q[3];
+  double A[6];   // sym: 00 01 02 11 12 22
+  double a[3];
+  double Hc[6];
+  double bc[3];
+  double chi_r, rho0_r, chi_g;
+  bool act_r, act_g;
+};
+
+GL_DEV void sym3_mul_vec(const double* S, const double* v, double* o) {
+  o[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
+  o[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
+  o[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+}
+// inverse of a symmetric 3x3 by cofactors (Eigen compute_inverse<3>); result symmetric
+GL_DEV void sym3_inv(const double* S, double* I) {
+  const double c00 = S[3] * S[5] - S[4] * S[4];
+  const double c01 = S[2] * S[4] - S[1] * S[5];
+  const double c02 = S[1] * S[4] - S[2] * S[3];
+  const double det = S[0] * c00 + S[1] * c01 + S[2] * c02;
+  const double id = 1.0 / det;
+  I[0] = c00 * id;
+  I[1] = c01 * id;
+  I[2] = c02 * id;
+  I[3] = (S[0] * S[5] - S[2] * S[2]) * id;
+  I[4] = (S[1] * S[2] - S[0] * S[4]) * id;
+  I[5] = (S[0] * S[3] - S[1] * S[1]) * id;
+}
+// P = X * Y for symmetric X, Y (full 3x3 row-major result)
+GL_DEV void sym3_mul(const double* X, const double* Y, double* P) {
+  const double x[9] = {X[0], X[1], X[2], X[1], X[3], X[4], X[2], X[4], X[5]};
+  const double y[9] = {Y[0], Y[1], Y[2], Y[1], Y[3], Y[4], Y[2], Y[4], Y[5]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P[i * 3 + j] = x[i * 3] * y[j] + x[i * 3 + 1] * y[3 + j] + x[i * 3 + 2] * y[6 + j];
+}
+
+// reprojection residual / chi2 at camera point q (un-robustified chi2 = s |e|^2)
+GL_DEV double reproj_err(const BaK& k, const double* q, const double* ob, bool stereo, double s, double* e,
+                         double& iz) {
+  iz = 1.0 / q[2];
+  const double pu = q[0] * iz * k.fx + k.cx, pv = q[1] * iz * k.fy + k.cy;
+  e[0] = ob[0] - pu;
+  e[1] = ob[1] - pv;
+  e[2] = stereo ? (ob[2] - (pu - k.bf * iz)) : 0.0;
+  return e[0] * (s * e[0]) + e[1] * (s * e[1]) + e[2] * (s * e[2]);
+}
+
+struct GmmRef {  // per-point association data (world frame)
+  bool has, deg;
+  double n[3];   // deg: plane normal (axis_.col(0))
+  double L[9];   // non-deg: sqrt_info_ (lower)
+  double mu[3];
+};
+
+GL_DEV void load_gmm(int a, const double* __restrict__ axis, const double* __restrict__ rec12,
+                     const double* __restrict__ sqrt_info, const uint8_t* __restrict__ flags, GmmRef& g) {
+  g.has = a >= 0;
+  g.deg = false;
+  if (!g.has) return;
+  g.deg = flags[a] & 1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g.mu[i] = rec12[(size_t)a * 12 + i];
+  if (g.deg) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.n[i] = axis[(size_t)a * 9 + i * 3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g.L[i] = sqrt_info[(size_t)a * 9 + i];
+  }
+}
+
+// un-robustified chi2 of the GMM edge at world point p
+GL_DEV double gmm_chi2(const BaK& k, const GmmRef& g, const double* p) {
+  const double d[3] = {p[0] - g.mu[0], p[1] - g.mu[1], p[2] - g.mu[2]};
+  if (g.deg) {
+    const double e = g.n[0] * d[0] + g.n[1] * d[1] + g.n[2] * d[2];
+    return e * (k.ba_lambda2 * e);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double e = g.L[0 * 3 + i] * d[0] + g.L[1 * 3 + i] * d[1] + g.L[2 * 3 + i] * d[2];  // L^T d
+    s += e * e;
+  }
+  return s;
+}
+
+// linearise one point at (R, t, p)
+GL_DEV void lin_point(const BaK& k, const double* R, const double* t, const double* p, const double* ob, int oc,
+                      const GmmRef& g, bool act_r, bool act_g, bool robust, PtLin& o) {
+  o.act_r = act_r;
+  o.act_g = act_g && g.has;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o.q[i] = R[i * 3] * p[0] + R[i * 3 + 1] * p[1] + R[i * 3 + 2] * p[2] + t[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    o.A[i] = 0.0;
+    o.Hc[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o.a[i] = 0.0;
+    o.bc[i] = 0.0;
+  }
+  o.chi_r = o.rho0_r = o.chi_g = 0.0;
+  if (o.act_r) {
+    const bool stereo = !(ob[2] < 0);
+    const double s = k.s2inv[oc];
+    double e[3], iz;
+    o.chi_r = reproj_err(k, o.q, ob, stereo, s, e, iz);
+    double rho1 = 1.0;
+    o.rho0_r = o.chi_r;
+    if (robust) huber(o.chi_r, stereo ? k.delta_stereo : k.delta_mono, o.rho0_r, rho1);
+    const double w = rho1 * s;
+    const double iz2 = iz * iz;
+    const double al = k.fx * iz, ga = k.fy * iz;
+    const double b0 = -k.fx * o.q[0] * iz2, b1 = -k.fy * o.q[1] * iz2;
+    const double b2 = b0 + k.bf * iz2;
+    const double sb = stereo ? 1.0 : 0.0;
+    o.A[0] = w * (al * al + sb * al * al);
+    o.A[1] = 0.0;
+    o.A[2] = w * (al * b0 + sb * al * b2);
+    o.A[3] = w * ga * ga;
+    o.A[4] = w * ga * b1;
+    o.A[5] = w * (b0 * b0 + b1 * b1 + sb * b2 * b2);
+    o.a[0] = w * al * (e[0] + sb * e[2]);
+    o.a[1] = w * ga * e[1];
+    o.a[2] = w * (b0 * e[0] + b1 * e[1] + sb * b2 * e[2]);
+  }
+  if (o.act_g) {
+    const double d[3] = {p[0] - g.mu[0], p[1] - g.mu[1], p[2] - g.mu[2]};
+    if (g.deg) {
+      const double eg = g.n[0] * d[0] + g.n[1] * d[1] + g.n[2] * d[2];
+      o.chi_g = eg * (k.ba_lambda2 * eg);
+      double nc[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) nc[i] = R[i * 3] * g.n[0] + R[i * 3 + 1] * g.n[1] + R[i * 3 + 2] * g.n[2];
+      const double l = k.ba_lambda2;
+      o.Hc[0] = l * nc[0] * nc[0];
+      o.Hc[1] = l * nc[0] * nc[1];
+      o.Hc[2] = l * nc[0] * nc[2];
+      o.Hc[3] = l * nc[1] * nc[1];
+      o.Hc[4] = l * nc[1] * nc[2];
+      o.Hc[5] = l * nc[2] * nc[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o.bc[i] = -l * eg * nc[i];
+    } else {
+      // e = L^T d, J = L^T: Hg = L L^T, bg = -L e
+      double e[3], bg[3], Hg[9], RH[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e[i] = g.L[0 * 3 + i] * d[0] + g.L[1 * 3 + i] * d[1] + g.L[2 * 3 + i] * d[2];
+      o.chi_g = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bg[i] = -(g.L[i * 3] * e[0] + g.L[i * 3 + 1] * e[1] + g.L[i * 3 + 2] * e[2]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Hg[i * 3 + j] = g.L[i * 3] * g.L[j * 3] + g.L[i * 3 + 1] * g.L[j * 3 + 1] + g.L[i * 3 + 2] * g.L[j * 3 + 2];
+      mm3(R, Hg, RH);
+      // Hc = RH * R^T (symmetric)
+      o.Hc[0] = RH[0] * R[0] + RH[1] * R[1] + RH[2] * R[2];
+      o.Hc[1] = RH[0] * R[3] + RH[1] * R[4] + RH[2] * R[5];
+      o.Hc[2] = RH[0] * R[6] + RH[1] * R[7] + RH[2] * R[8];
+      o.Hc[3] = RH[3] * R[3] + RH[4] * R[4] + RH[5] * R[5];
+      o.Hc[4] = RH[3] * R[6] + RH[4] * R[7] + RH[5] * R[8];
+      o.Hc[5] = RH[6] * R[6] + RH[7] * R[7] + RH[8] * R[8];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o.bc[i] = R[i * 3] * bg[0] + R[i * 3 + 1] * bg[1] + R[i * 3 + 2] * bg[2];
+    }
+  }
+}
+
+// D^-1 (with LM damping), u = D^-1 b
+GL_DEV void point_solve(const PtLin& o, double lambda, double* Dinv, double* b, double* u) {
+  double D[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) D[i] = o.A[i] + o.Hc[i];
+  D[0] += lambda;
+  D[3] += lambda;
+  D[5] += lambda;
+  sym3_inv(D, Dinv);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) b[i] = o.a[i] + o.bc[i];
+  sym3_mul_vec(Dinv, b, u);
+}
+
+GL_DEV void cross(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// acc[0..20] += upper(G^T C G), acc[21..26] += G^T c ; G = [-[q]x | I], C symmetric (full 3x3 given)
+GL_DEV void accum_pose(const double* q, const double* Cf, const double* c, double* acc) {
+  // M = Q C : column j of M = q x C[:,j]  -> rows m_i
+  double M[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double col[3] = {Cf[0 * 3 + j], Cf[1 * 3 + j], Cf[2 * 3 + j]};
+    double r[3];
+    cross(q, col, r);
+    M[0 * 3 + j] = r[0];
+    M[1 * 3 + j] = r[1];
+    M[2 * 3 + j] = r[2];
+  }
+  // TL row i = q x (row i of M)   (= -M Q)
+  double TL[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double r[3];
+    cross(q, &M[i * 3], r);
+    TL[i * 3] = r[0];
+    TL[i * 3 + 1] = r[1];
+    TL[i * 3 + 2] = r[2];
+  }
+  // upper-triangle order of the 6x6: rows 0..2 -> [TL(i, i..2), TR(i, 0..2)], rows 3..5 -> [BR(i, i..2)]
+  acc[0] += TL[0];
+  acc[1] += TL[1];
+  acc[2] += TL[2];
+  acc[3] += M[0];
+  acc[4] += M[1];
+  acc[5] += M[2];
+  acc[6] += TL[4];
+  acc[7] += TL[5];
+  acc[8] += M[3];
+  acc[9] += M[4];
+  acc[10] += M[5];
+  acc[11] += TL[8];
+  acc[12] += M[6];
+  acc[13] += M[7];
+  acc[14] += M[8];
+  acc[15] += Cf[0];
+  acc[16] += Cf[1];
+  acc[17] += Cf[2];
+  acc[18] += Cf[4];
+  acc[19] += Cf[5];
+  acc[20] += Cf[8];
+  double qc[3];
+  cross(q, c, qc);
+  acc[21] += qc[0];
+  acc[22] += qc[1];
+  acc[23] += qc[2];
+  acc[24] += c[0];
+  acc[25] += c[1];
+  acc[26] += c[2];
+}
+
+GL_DEV void unpack6(const double* acc, double* H) {
+  int qi = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      H[i * 6 + j] = acc[qi];
+      H[j * 6 + i] = acc[qi];
+      ++qi;
+    }
+}
+
+GL_DEV double block_max(double v, double* lds) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v = fmax(v, shfl_xor_f64(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double m = lds[0];
+#pragma unroll
+  for (int w = 1; w < NW_BA; ++w) m = fmax(m, lds[w]);
+  return m;
+}
+
+// EdgeSE3QuatPrior (factors.cpp:19-53): adds J^T Omega J / -J^T Omega e, returns chi2
+GL_DEV double prior_terms(const SE3& inv_meas, const SE3& T, bool build, double* H /*6x6 +=*/, double* b /*+=*/) {
+  const SE3 d = se3_mul(inv_meas, T);
+  double e[6];
+  se3_log(d, e);
+  const double sr = 1.0 / ((2.0 * M_PI / 180.0) * (2.0 * M_PI / 180.0));
+  const double st = 1.0 / (0.01 * 0.01);
+  const double om[6] = {sr, sr, sr, st, st, st};
+  double chi = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) chi += e[i] * om[i] * e[i];
+  if (build) {
+    double Jr[36], Adj[36], J[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Jr[i] = 0.0;
+    double ps[9], ls[9];
+    skew(e, ps);
+    skew(e + 3, ls);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Jr[i * 6 + j] = 0.5 * ps[i * 3 + j];
+        Jr[(i + 3) * 6 + j + 3] = 0.5 * ps[i * 3 + j];
+        Jr[i * 6 + j + 3] = 0.5 * ls[i * 3 + j];
+      }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Jr[i * 6 + i] += 1.0;
+    const SE3 Ti = se3_inverse(T);
+    double R[9], S[9], SR[9];
+    qtoR(Ti.r, R);
+    skew(Ti.t, S);
+    mm3(S, R, SR);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Adj[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Adj[i * 6 + j] = R[i * 3 + j];
+        Adj[(i + 3) * 6 + j + 3] = R[i * 3 + j];
+        Adj[(i + 3) * 6 + j] = SR[i * 3 + j];
+      }
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        double s = 0.0;
+        for (int l = 0; l < 6; ++l) s += Jr[i * 6 + l] * Adj[l * 6 + j];
+        J[i * 6 + j] = s;
+      }
+    for (int i = 0; i < 6; ++i) {
+      double s = 0.0;
+      for (int r = 0; r < 6; ++r) s += J[r * 6 + i] * om[r] * e[r];
+      b[i] -= s;
+      for (int j = 0; j < 6; ++j) {
+        double h = 0.0;
+        for (int r = 0; r < 6; ++r) h += J[r * 6 + i] * om[r] * J[r * 6 + j];
+        H[i * 6 + j] += h;
+      }
+    }
+  }
+  return chi;
+}
+
+// per-frame state in global memory
+struct FrameView {
+  int L;
+  double* p;         // L x 3 current points (in/out)
+  double* pn;        // L x 3 trial points (scratch)
+  const double* obs; // L x 3
+  const int32_t* oct;
+  const int32_t* assoc;
+  double* chi_r;     // stale e->chi2() of the reprojection edges
+  uint8_t* lev;      // bit0: reprojection edge level, bit1: GMM edge level
+};
+
+struct GmmDev {
+  const double* rec12;
+  const double* axis;
+  const double* sqrt_info;
+  const uint8_t* flags;
+};
+
+// SparseOptimizer::optimize(iters) with the LM algorithm; returns cjIterations (-1: nothing active)
+GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bool pose_fixed, bool has_prior,
+                       const SE3& prior_inv, bool robust, int iters, double* red) {
+  double acc[32];
+  // active census (initializeOptimization(0))
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  for (int l = threadIdx.x; l < fv.L; l += T_BA) {
+    if (fv.oct[l] < 0) continue;
+    const bool ar = !(fv.lev[l] & 1), ag = fv.assoc[l] >= 0 && !(fv.lev[l] & 2);
+    if (ar) acc[0] += 1.0;
+    if (ar || ag) acc[1] += 1.0;
+  }
+  block_reduce<2, NW_BA>(acc, red);
+  const bool pose_active = !pose_fixed && ((int)acc[0] > 0 || has_prior);
+  const bool any_point = (int)acc[1] > 0;
+  if (!pose_active && !any_point) return -1;
+
+  double lambda = 0.0, ni = 2.0;
+  int cj = 0;
+  for (int it = 0; it < iters; ++it) {
+    double rho = 0.0;
+    int qmax = 0;
+    double currentChi = 0.0;
+    double R[9];
+    qtoR(T.r, R);
+    if (it == 0) {  // computeLambdaInit: tau * max |H(j,j)| over pose and (world-frame) landmark blocks
+      double md = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      for (int l = threadIdx.x; l < fv.L; l += T_BA) {
+        const int oc = fv.oct[l];
+        if (oc < 0) continue;
+        const bool ar = !(fv.lev[l] & 1), ag = !(fv.lev[l] & 2);
+        GmmRef g;
+        load_gmm(fv.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+        if (!(ar || (ag && g.has))) continue;
+        PtLin o;
+        lin_point(k, R, T.t, fv.p + (size_t)l * 3, fv.obs + (size_t)l * 3, oc, g, ar, ag, robust, o);
+        double Hs[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Hs[i] = o.A[i] + o.Hc[i];
+        // diag of R^T Hs R
+        const double Hf[9] = {Hs[0], Hs[1], Hs[2], Hs[1], Hs[3], Hs[4], Hs[2], Hs[4], Hs[5]};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) s += R[a * 3 + j] * Hf[a * 3 + b] * R[b * 3 + j];
+          md = fmax(md, fabs(s));
+        }
+        if (pose_active && o.act_r) {
+          double Af[9];
+          const double zero[3] = {0, 0, 0};
+          Af[0] = o.A[0]; Af[1] = o.A[1]; Af[2] = o.A[2]; Af[3] = o.A[1]; Af[4] = o.A[3]; Af[5] = o.A[4];
+          Af[6] = o.A[2]; Af[7] = o.A[4]; Af[8] = o.A[5];
+          accum_pose(o.q, Af, zero, acc);
+        }
+      }
+      block_reduce<21, NW_BA>(acc, red);
+      if (pose_active) {
+        double Hp[36], bp[6] = {0, 0, 0, 0, 0, 0};
+        unpack6(acc, Hp);
+        if (has_prior) prior_terms(prior_inv, T, true, Hp, bp);
+        double mdp = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) mdp = fmax(mdp, fabs(Hp[i * 6 + i]));
+        md = fmax(md, mdp);
+      }
+      md = block_max(md, red);
+      lambda = 1e-5 * md;
+      ni = 2.0;
+    }
+    do {
+      // ---- pass A: linearise at (T, p), Schur-reduce with the current lambda -------------
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      for (int l = threadIdx.x; l < fv.L; l += T_BA) {
+        const int oc = fv.oct[l];
+        if (oc < 0) continue;
+        const bool ar = !(fv.lev[l] & 1), ag = !(fv.lev[l] & 2);
+        GmmRef g;
+        load_gmm(fv.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+        if (!(ar || (ag && g.has))) continue;
+        PtLin o;
+        lin_point(k, R, T.t, fv.p + (size_t)l * 3, fv.obs + (size_t)l * 3, oc, g, ar, ag, robust, o);
+        if (o.act_r) fv.chi_r[l] = o.chi_r;  // computeActiveErrors
+        acc[27] += o.rho0_r + o.chi_g;
+        if (pose_active && o.act_r) {
+          double Dinv[6], b[3], u[3];
+          point_solve(o, lambda, Dinv, b, u);
+          double AD[9], Cf[9], Au[3], c[3];
+          sym3_mul(o.A, Dinv, AD);  // A D^-1
+          const double Af[9] = {o.A[0], o.A[1], o.A[2], o.A[1], o.A[3], o.A[4], o.A[2], o.A[4], o.A[5]};
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Af[i * 3 + j] - (AD[i * 3] * Af[j] + AD[i * 3 + 1] * Af[3 + j] + AD[i * 3 + 2] * Af[6 + j]);
+          sym3_mul_vec(o.A, u, Au);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) c[i] = o.a[i] - Au[i];
+          accum_pose(o.q, Cf, c, acc);
+        }
+      }
+      block_reduce<28, NW_BA>(acc, red);
+      double S[36], gvec[6], dx[6] = {0, 0, 0, 0, 0, 0};
+      unpack6(acc, S);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gvec[i] = acc[21 + i];
+      double chiA = acc[27];
+      double bp_prior[6] = {0, 0, 0, 0, 0, 0};
+      if (has_prior && pose_active) {
+        chiA += prior_terms(prior_inv, T, true, S, bp_prior);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gvec[i] += bp_prior[i];
+      }
+      if (qmax == 0) currentChi = chiA;  // activeRobustChi2() at the start of solve()
+      bool ok2 = true;
+      if (pose_active) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) S[i * 6 + i] += lambda;
+        ok2 = ldlt_solve<6>(S, gvec, dx, false);
+      }
+      // ---- pass B: back-substitute, trial state, new errors --------------------------------
+      SE3 Tn = T;
+      if (pose_active && ok2) Tn = se3_mul(se3_exp(dx), T);
+      double Rn[9];
+      qtoR(Tn.r, Rn);
+      double tempChi = 1.7976931348623157e308, scale = 0.0, bdotx = 0.0;
+      {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+        for (int l = threadIdx.x; l < fv.L; l += T_BA) {
+          const int oc = fv.oct[l];
+          if (oc < 0) continue;
+          const bool ar = !(fv.lev[l] & 1), ag = !(fv.lev[l] & 2);
+          GmmRef g;
+          load_gmm(fv.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+          const double* p = fv.p + (size_t)l * 3;
+          if (!(ar || (ag && g.has))) continue;
+          PtLin o;
+          lin_point(k, R, T.t, p, fv.obs + (size_t)l * 3, oc, g, ar, ag, robust, o);
+          double Dinv[6], b[3], u[3];
+          point_solve(o, lambda, Dinv, b, u);
+          // eps = D^-1 (b - A (w x q + v))
+          double gd[3], Agd[3], rhs[3], eps[3];
+          cross(dx, o.q, gd);
+          gd[0] += dx[3];
+          gd[1] += dx[4];
+          gd[2] += dx[5];
+          if (o.act_r && pose_active) {
+            sym3_mul_vec(o.A, gd, Agd);
+            acc[2] += gd[0] * o.a[0] + gd[1] * o.a[1] + gd[2] * o.a[2];  // (G dx) . a
+          } else {
+            Agd[0] = Agd[1] = Agd[2] = 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) rhs[i] = b[i] - Agd[i];
+          sym3_mul_vec(Dinv, rhs, eps);
+          // computeScale(): x (lambda x + b), landmark part (rotation invariant)
+          acc[0] += eps[0] * (lambda * eps[0] + b[0]) + eps[1] * (lambda * eps[1] + b[1]) + eps[2] * (lambda * eps[2] + b[2]);
+          double pn[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pn[i] = p[i] + (R[0 * 3 + i] * eps[0] + R[1 * 3 + i] * eps[1] + R[2 * 3 + i] * eps[2]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) fv.pn[(size_t)l * 3 + i] = pn[i];
+          // errors at the trial state
+          if (o.act_r) {
+            double qn[3], e[3], iz;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) qn[i] = Rn[i * 3] * pn[0] + Rn[i * 3 + 1] * pn[1] + Rn[i * 3 + 2] * pn[2] + Tn.t[i];
+            const bool stereo = !(fv.obs[(size_t)l * 3 + 2] < 0);
+            const double c2 = reproj_err(k, qn, fv.obs + (size_t)l * 3, stereo, k.s2inv[oc], e, iz);
+            fv.chi_r[l] = c2;
+            double r0 = c2, r1;
+            if (robust) huber(c2, stereo ? k.delta_stereo : k.delta_mono, r0, r1);
+            acc[1] += r0;
+          }
+          if (o.act_g) acc[1] += gmm_chi2(k, g, pn);
+        }
+        block_reduce<3, NW_BA>(acc, red);
+        scale = acc[0];
+        bdotx = acc[2];
+        if (ok2) tempChi = acc[1] + ((has_prior && pose_active) ? prior_terms(prior_inv, Tn, false, nullptr, nullptr) : 0.0);
+      }
+      // pose block of computeScale(): x_p . (lambda x_p + b_p), b_p = sum G^T a (+ prior)
+      double scale_p = 0.0;
+      if (pose_active) {
+        scale_p = bdotx;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) scale_p += dx[i] * (lambda * dx[i] + bp_prior[i]);
+      }
+      scale += scale_p + 1e-3;
+      rho = (currentChi - tempChi) / scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        const double uu = 2 * rho - 1;
+        double alpha = 1. - uu * uu * uu;
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        T = Tn;
+        qtoR(T.r, R);
+        // p <- pn for active points
+        for (int l = threadIdx.x; l < fv.L; l += T_BA) {
+          if (fv.oct[l] < 0) continue;
+          const bool ar = !(fv.lev[l] & 1), ag = fv.assoc[l] >= 0 && !(fv.lev[l] & 2);
+          if (!(ar || ag)) continue;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) fv.p[(size_t)l * 3 + i] = fv.pn[(size_t)l * 3 + i];
+        }
+      } else {
+        lambda *= ni;
+        ni *= 2;
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 10);
+    ++cj;
+    if (qmax == 10 || rho == 0) break;
+  }
+  return cj;
+}
+
+__global__ __launch_bounds__(T_BA) void k_ba1(BaK k, GmmDev gm, int B, int L, double* __restrict__ pose_io,
+                                              const uint8_t* __restrict__ has_prior_all, double* __restrict__ pts_io,
+                                              const double* __restrict__ obs_all, const int32_t* __restrict__ oct_all,
+                                              int32_t* __restrict__ assoc_all, const double* __restrict__ d2_all,
+                                              double* __restrict__ pn_all, double* __restrict__ chi_all,
+                                              uint8_t* __restrict__ lev_all, uint8_t* __restrict__ dropped_all,
+                                              uint8_t* __restrict__ erase_all, int32_t* __restrict__ iters_out) {
+  __shared__ double red[NW_BA * 32];
+  const int f = blockIdx.x;
+  if (f >= B) return;
+  FrameView fv;
+  fv.L = L;
+  fv.p = pts_io + (size_t)f * L * 3;
+  fv.pn = pn_all + (size_t)f * L * 3;
+  fv.obs = obs_all + (size_t)f * L * 3;
+  fv.oct = oct_all + (size_t)f * L;
+  fv.assoc = assoc_all + (size_t)f * L;
+  fv.chi_r = chi_all + (size_t)f * L;
+  fv.lev = lev_all + (size_t)f * L;
+
+  // gl_track_frames: association gate chi2 <= 9 (checkMapAssociation, gmmloc_opt.cpp:230-232)
+  for (int l = threadIdx.x; l < L; l += T_BA) {
+    fv.lev[l] = 0;
+    fv.chi_r[l] = 0.0;
+    if (d2_all && k.gate_chi2 >= 0) {
+      if (!(d2_all[(size_t)f * L + l] <= k.gate_chi2)) assoc_all[(size_t)f * L + l] = -1;
+    }
+    if (fv.oct[l] < 0) assoc_all[(size_t)f * L + l] = -1;
+  }
+  __syncthreads();
+
+  SE3 T = se3_load(pose_io + (size_t)f * 7);
+  const bool prior_flag = has_prior_all ? (has_prior_all[f] != 0) : false;
+  const bool has_prior = prior_flag && k.first_as_prior;
+  const bool pose_fixed = prior_flag && !k.first_as_prior;  // vSE3->setFixed(idx_ == 0)
+  const SE3 prior_inv = se3_inverse(T);                     // e->setMeasurement(kfi->getTcw())
+
+  // optimize(5)  (:770-771)
+  ba_optimize(k, gm, fv, T, pose_fixed, has_prior, prior_inv, true, 5, red);
+  __syncthreads();
+  // gate the degenerate GMM edges on a FRESH error (:773-786)
+  for (int l = threadIdx.x; l < L; l += T_BA) {
+    if (fv.oct[l] < 0) continue;
+    GmmRef g;
+    load_gmm(fv.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+    if (g.has && g.deg && gmm_chi2(k, g, fv.p + (size_t)l * 3) > k.str_thresh) fv.lev[l] |= 2;
+  }
+  __syncthreads();
+  ba_optimize(k, gm, fv, T, pose_fixed, has_prior, prior_inv, true, 5, red);  // :788-789
+  __syncthreads();
+  // gate the reprojection edges: STALE chi2, fresh depth test; robust kernels off (:799-825)
+  {
+    double R[9];
+    qtoR(T.r, R);
+    for (int l = threadIdx.x; l < L; l += T_BA) {
+      if (fv.oct[l] < 0) continue;
+      const double* p = fv.p + (size_t)l * 3;
+      const double z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + T.t[2];
+      const bool stereo = !(fv.obs[(size_t)l * 3 + 2] < 0);
+      if (fv.chi_r[l] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) fv.lev[l] |= 1;
+    }
+  }
+  __syncthreads();
+  const int it3 = ba_optimize(k, gm, fv, T, pose_fixed, has_prior, prior_inv, false, 40, red);  // :827-828
+  __syncthreads();
+  // outputs (:837-879)
+  {
+    double R[9];
+    qtoR(T.r, R);
+    for (int l = threadIdx.x; l < L; l += T_BA) {
+      uint8_t dr = 0, er = 0;
+      if (fv.oct[l] >= 0) {
+        GmmRef g;
+        load_gmm(fv.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+        const double* p = fv.p + (size_t)l * 3;
+        if (g.has && g.deg && gmm_chi2(k, g, p) > k.str_thresh) dr = 1;
+        const double z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + T.t[2];
+        const bool stereo = !(fv.obs[(size_t)l * 3 + 2] < 0);
+        if (fv.chi_r[l] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
+      }
+      if (dropped_all) dropped_all[(size_t)f * L + l] = dr;
+      if (erase_all) erase_all[(size_t)f * L + l] = er;
+      if (!dropped_all && dr) assoc_all[(size_t)f * L + l] = -1;  // gl_track_frames: final association
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (!pose_fixed) se3_store(T, pose_io + (size_t)f * 7);
+    if (iters_out) iters_out[f] = it3;
+  }
+}
+
+}  // namespace
+
+namespace gl {
+
+int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
+
+static BaK make_bak(const gl_camera* cam, const gl_params* prm, double gate) {
+  BaK k;
+  k.fx = cam->fx;
+  k.fy = cam->fy;
+  k.cx = cam->cx;
+  k.cy = cam->cy;
+  k.bf = cam->bf;
+  for (int i = 0; i < 8; ++i) k.s2inv[i] = (double)prm->sigma2_inv[i];
+  k.delta_mono = (double)(float)sqrt(5.991);    // thHuberMono   (:629)
+  k.delta_stereo = (double)(float)sqrt(7.815);  // thHuberStereo (:630)
+  k.ba_lambda2 = (double)prm->ba_lambda2;
+  k.str_thresh = (double)(prm->tri_str_thresh * prm->ba_lambda2);  // float product (:782)
+  k.gate_chi2 = gate;
+  k.first_as_prior = prm->ba_first_as_prior;
+  return k;
+}
+
+// Single-free-pose jointOptimization for B frames; assoc in/out; scratch from ctx.
+int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
+               const uint8_t* has_prior, double* pts, const double* obs, const int32_t* oct, int32_t* assoc,
+               const double* d2, double gate, uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
+  BaK k = make_bak(cam, prm, gate);
+  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->flags};
+  char* s = (char*)scratch;
+  double* pn = (double*)s;
+  s += (size_t)B * L * 24;
+  double* chi = (double*)s;
+  s += (size_t)B * L * 8;
+  uint8_t* lev = (uint8_t*)s;
+  {
+    TimerScope ts(c, GL_TIMER_BA);
+    k_ba1<<<B, T_BA, 0, c->stream>>>(k, gm, B, L, pose, has_prior, pts, obs, oct, assoc, d2, pn, chi, lev, dropped, erase,
+                                     iters);
+  }
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * (24 + 8 + 1) + 256; }
+
+}  // namespace gl
+
+extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
+                               int M, double* pose_dev, double* Xw_dev, const double* obs_dev,
+                               const int32_t* octave_dev, int32_t* assoc_dev, double* d2_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (B == 0 || M == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && M > 0, "bad B / M");
+  GL_REQUIRE(pose_dev && Xw_dev && obs_dev && octave_dev && assoc_dev, "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  const size_t n = (size_t)B * M;
+  // scratch: [d2 (if the caller does not want it)] [ba1 scratch]; the association kernel's own
+  // partial buffers come from the same context scratch, so carve everything from one block.
+  // Layout: | assoc partials (used first, dead afterwards) ... reused by ba1 | d2 |
+  void* scratch = nullptr;
+  const size_t ba_bytes = gl::ba1_scratch_bytes(B, M);
+  // generous upper bound for the association partials: nsplit <= 2*ceil(K/128)+1
+  const size_t assoc_bytes = (size_t)(2 * ((g->K + 127) / 128) + 1) * n * 12 + 64;
+  const size_t work = ba_bytes > assoc_bytes ? ba_bytes : assoc_bytes;
+  int rc = gl::ctx_scratch(c, work + n * 8 + 64, &scratch);
+  if (rc != GL_OK) return rc;
+  double* d2 = d2_dev ? d2_dev : (double*)((char*)scratch + ((work + 63) / 64) * 64);
+  rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
+  if (rc != GL_OK) return rc;
+  return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, nullptr, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
+                        nullptr, nullptr, nullptr, scratch);
+}
