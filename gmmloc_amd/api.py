@@ -236,3 +236,85 @@ def track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octave, want_d2=True):
                                    _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2)))
     ctx._exit()
     return assoc, d2
+
+
+def read_gmm_file(path):
+    """Host-only .gmm reader (gl_gmm_file_read) -> (mean (K,3), cov (K,9))."""
+    lib = _lib.load()
+    K = C.c_int32()
+    _check(lib.gl_gmm_file_read(str(path).encode(), None, None, 0, C.byref(K)))
+    mean, cov = np.zeros((K.value, 3)), np.zeros((K.value, 9))
+    _check(lib.gl_gmm_file_read(str(path).encode(), mean.ctypes.data, cov.ctypes.data, K.value, C.byref(K)))
+    return mean, cov
+
+
+def write_gmm_file(path, mean, cov, flags):
+    lib = _lib.load()
+    mean = np.ascontiguousarray(mean, np.float64)
+    cov = np.ascontiguousarray(cov, np.float64)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    _check(lib.gl_gmm_file_write(str(path).encode(), mean.ctypes.data, cov.ctypes.data, flags.ctypes.data,
+                                 mean.shape[0]))
+
+
+def _gmm_search2d(self, cam, pose, uv, nfeat=None, k=5, view_cap=0):
+    """GMMLoc::associateMapElements = GMM::renderView + GMM::searchCorrespondence for B key-frames.
+    pose (B,7), uv (B,N,2) -> (cand int32 (B,N,k), ncand int32 (B,N), view_ids (B,view_cap) | None,
+    nview (B,) | None)."""
+    import torch
+    B, N = uv.shape[0], uv.shape[1]
+    cand = torch.empty((B, N, k), dtype=torch.int32, device=uv.device)
+    ncand = torch.empty((B, N), dtype=torch.int32, device=uv.device)
+    vids = torch.empty((B, view_cap), dtype=torch.int32, device=uv.device) if view_cap else None
+    nview = torch.empty(B, dtype=torch.int32, device=uv.device) if view_cap else None
+    self.ctx._enter()
+    _check(self.lib.gl_search2d(self.ctx.h, self.h, C.byref(cam.c()), B, _ptr(pose), N, _ptr(uv), _ptr(nfeat), k,
+                                _ptr(cand), _ptr(ncand), view_cap, _ptr(vids), _ptr(nview)))
+    self.ctx._exit()
+    return cand, ncand, vids, nview
+
+
+GMM.search2d = _gmm_search2d
+
+
+def optimize_point(ctx, gmm, cam, prm, pts, uvr, octave, pose, comp, proj_z2):
+    """GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N problems -> (res, chi2_proj, chi2_str, pt_est)."""
+    import torch
+    N = pts.shape[0]
+    dev = pts.device
+    res = torch.empty(N, dtype=torch.uint8, device=dev)
+    c2p = torch.empty(N, dtype=torch.float64, device=dev)
+    c2s = torch.empty(N, dtype=torch.float64, device=dev)
+    est = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_optimize_point(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), N, _ptr(pts), _ptr(uvr),
+                                     _ptr(octave), _ptr(pose), _ptr(comp), _ptr(proj_z2), _ptr(res), _ptr(c2p),
+                                     _ptr(c2s), _ptr(est)))
+    ctx._exit()
+    return res, c2p, c2s, est
+
+
+def check_map_association(ctx, gmm, cam, prm, pose, pts, uvr, octave, cand, ncand):
+    """GMMLoc::checkMapAssociation (gmmloc_opt.cpp:156-258): pose (B,7), pts (B,N,3) in/out, uvr (B,N,3),
+    octave (B,N), cand (B,N,k), ncand (B,N) -> out_comp (B,N)."""
+    import torch
+    B, N, k = cand.shape
+    out = torch.empty((B, N), dtype=torch.int32, device=pts.device)
+    ctx._enter()
+    _check(ctx.lib.gl_check_map_association(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, N, _ptr(pose),
+                                            _ptr(pts), _ptr(uvr), _ptr(octave), _ptr(cand), _ptr(ncand), k, _ptr(out)))
+    ctx._exit()
+    return out
+
+
+def optimize_triangulation(ctx, gmm, cam, prm, x3d, pose1, uvr1, oct1, pose2, uvr2, oct2, cand1, n1, cand2, n2):
+    """Localization::optimizeTriangulationVec (localization_opt.cpp:27-204), N problems; x3d in/out."""
+    import torch
+    N, k = cand1.shape
+    out = torch.empty(N, dtype=torch.int32, device=x3d.device)
+    ctx._enter()
+    _check(ctx.lib.gl_optimize_triangulation(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), N, _ptr(x3d),
+                                             _ptr(pose1), _ptr(uvr1), _ptr(oct1), _ptr(pose2), _ptr(uvr2), _ptr(oct2),
+                                             _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k, _ptr(out)))
+    ctx._exit()
+    return out

@@ -152,3 +152,27 @@ int write_gmm_file(const char* path, const double* mean, const double* cov, cons
 }
 
 }  // namespace gl
+
+extern "C" {
+
+int gl_gmm_file_read(const char* path, double* mean, double* cov, int cap, int* K_out) {
+  GL_REQUIRE(path && K_out, "null argument");
+  std::vector<double> m, c;
+  const int rc = gl::read_gmm_file(path, m, c);
+  if (rc != GL_OK) return rc;
+  const int K = (int)(m.size() / 3);
+  *K_out = K;
+  if (mean || cov) {
+    GL_REQUIRE(cap >= K, "output capacity too small");
+    if (mean) memcpy(mean, m.data(), sizeof(double) * 3 * K);
+    if (cov) memcpy(cov, c.data(), sizeof(double) * 9 * K);
+  }
+  return GL_OK;
+}
+
+int gl_gmm_file_write(const char* path, const double* mean, const double* cov, const uint8_t* flags, int K) {
+  GL_REQUIRE(path && mean && cov && flags && K > 0, "bad argument");
+  return gl::write_gmm_file(path, mean, cov, flags, K);
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+// Point refinement against the GMM, one thread per independent problem:
+//   k_optimize_point        GMMLoc::optimizePoint              (gmmloc_opt.cpp:260-342)   B1
+//   k_check_map_association GMMLoc::checkMapAssociation        (gmmloc_opt.cpp:156-258)   A8
+//   k_optimize_triangulation Localization::optimizeTriangulationVec (localization_opt.cpp:27-204) B2
+// Each problem is a 3-DoF Gauss-Newton (g2o OptimizationAlgorithmGaussNewton, BlockSolverX +
+// LinearSolverEigen on one 3x3 block) over EdgeProjectXYZOnly{,Stereo} + EdgePt2GaussianDeg
+// (factors.cpp:55-168).  The reference pays a g2o graph construction (heap allocations,
+// virtual dispatch) per call; here the whole solve lives in registers.
+// g2o semantic kept: e->chi2() after optimize(n) is the error of the LAST
+// computeActiveErrors(), i.e. evaluated before the final update.
+#include "gl_device.hpp"
+#include "gl_internal.hpp"
+
+using namespace gld;
+
+namespace {
+
+struct PtK {
+  double fx, fy, cx, cy, bf;
+  double s2inv[8];
+  double tri_lambda2;      // (double) loc::tri_lambda2
+  double str_thresh;       // (double)(tri_str_thresh * tri_lambda2), float product
+  int check_str;
+};
+
+struct Plane {
+  double n[3], mu[3];
+};
+
+struct FixedPose {
+  double R[9], t[3];
+};
+
+GL_DEV FixedPose load_pose(const double* p) {
+  const SE3 T = se3_load(p);
+  FixedPose f;
+  qtoR(T.r, f.R);
+  f.t[0] = T.t[0];
+  f.t[1] = T.t[1];
+  f.t[2] = T.t[2];
+  return f;
+}
+
+// 3x3 symmetric solve by LDL^T (SimplicialLDLT: fails on a zero pivot only)
+GL_DEV bool solve3(const double* H, const double* b, double* x) { return ldlt_solve<3>(H, b, x, false); }
+
+// accumulate one fixed-pose reprojection edge at point x: returns chi2 (= s |e|^2)
+GL_DEV double reproj_edge(const PtK& k, const FixedPose& P, const double* x, const double* uvr, bool stereo, double s,
+                          double* H, double* b) {
+  const double X = P.R[0] * x[0] + P.R[1] * x[1] + P.R[2] * x[2] + P.t[0];
+  const double Y = P.R[3] * x[0] + P.R[4] * x[1] + P.R[5] * x[2] + P.t[1];
+  const double Z = P.R[6] * x[0] + P.R[7] * x[1] + P.R[8] * x[2] + P.t[2];
+  double J[9], e[3];
+  int D;
+  if (stereo) {  // factors.cpp:116-131 (error), :133-168 (Jacobian)
+    const double invz = 1.0 / Z;
+    const double pu = X * invz * k.fx + k.cx, pv = Y * invz * k.fy + k.cy;
+    e[0] = uvr[0] - pu;
+    e[1] = uvr[1] - pv;
+    e[2] = uvr[2] - (pu - k.bf * invz);
+    const double z2 = Z * Z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      J[0 * 3 + c] = -k.fx * P.R[0 * 3 + c] / Z + k.fx * X * P.R[2 * 3 + c] / z2;
+      J[1 * 3 + c] = -k.fy * P.R[1 * 3 + c] / Z + k.fy * Y * P.R[2 * 3 + c] / z2;
+      J[2 * 3 + c] = J[0 * 3 + c] - k.bf * P.R[2 * 3 + c] / z2;
+    }
+    D = 3;
+  } else {  // factors.cpp:66-82 (error), :84-107 (Jacobian)
+    e[0] = uvr[0] - (X / Z * k.fx + k.cx);
+    e[1] = uvr[1] - (Y / Z * k.fy + k.cy);
+    e[2] = 0.0;
+    const double tmp[6] = {k.fx, 0.0, -X / Z * k.fx, 0.0, k.fy, -Y / Z * k.fy};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        J[r * 3 + c] = -1. / Z * (tmp[r * 3] * P.R[c] + tmp[r * 3 + 1] * P.R[3 + c] + tmp[r * 3 + 2] * P.R[6 + c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J[6 + c] = 0.0;
+    D = 2;
+  }
+  double chi = 0.0;
+  for (int r = 0; r < D; ++r) chi += e[r] * (s * e[r]);
+  if (H) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double bi = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) bi += J[r * 3 + i] * (s * e[r]);
+      b[i] -= bi;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double h = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) h += J[r * 3 + i] * s * J[r * 3 + j];
+        H[i * 3 + j] += h;
+      }
+    }
+  }
+  return chi;
+}
+
+// EdgePt2GaussianDeg (factors.cpp:55-64) with information `lam`
+GL_DEV double plane_edge(const Plane& pl, const double* x, double lam, double* H, double* b) {
+  const double es = pl.n[0] * (x[0] - pl.mu[0]) + pl.n[1] * (x[1] - pl.mu[1]) + pl.n[2] * (x[2] - pl.mu[2]);
+  if (H) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      b[i] -= pl.n[i] * (lam * es);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) H[i * 3 + j] += pl.n[i] * lam * pl.n[j];
+    }
+  }
+  return es * (lam * es);
+}
+
+struct StrOptStat {  // types/map.h:30-35
+  bool res;
+  double chi2_proj, chi2_str;
+  double pt[3];
+};
+
+// GMMLoc::optimizePoint
+GL_DEV StrOptStat optimize_point(const PtK& k, const FixedPose& P, const double* pt, const double* uvr, int octave,
+                                 const Plane& pl, double proj_z2) {
+  const double s = k.s2inv[octave];
+  const double lam = 1.0 * k.tri_lambda2 * proj_z2;
+  StrOptStat r;
+  double x[3] = {pt[0], pt[1], pt[2]};
+  r.chi2_proj = r.chi2_str = 0.0;
+  for (int it = 0; it < 5; ++it) {
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, dx[3];
+    r.chi2_proj = reproj_edge(k, P, x, uvr, true, s, H, b);
+    r.chi2_str = plane_edge(pl, x, lam, H, b);
+    if (!solve3(H, b, dx)) break;  // SolverResult::Fail ends optimize()
+    x[0] += dx[0];
+    x[1] += dx[1];
+    x[2] += dx[2];
+  }
+  r.pt[0] = x[0];
+  r.pt[1] = x[1];
+  r.pt[2] = x[2];
+  r.res = true;
+  if (r.chi2_proj > 7.815) r.res = false;
+  if (k.check_str && r.chi2_str > k.str_thresh) r.res = false;
+  return r;
+}
+
+GL_DEV Plane load_plane(const double* __restrict__ rec12, const double* __restrict__ axis, int c) {
+  Plane pl;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    pl.n[i] = axis[(size_t)c * 9 + i * 3];  // axis_.col(0)
+    pl.mu[i] = rec12[(size_t)c * 12 + i];
+  }
+  return pl;
+}
+
+__global__ void k_optimize_point(PtK k, int N, const double* __restrict__ rec12, const double* __restrict__ axis,
+                                 const double* __restrict__ pts, const double* __restrict__ uvr,
+                                 const int32_t* __restrict__ octave, const double* __restrict__ pose,
+                                 const int32_t* __restrict__ comp, const double* __restrict__ proj_z2,
+                                 uint8_t* __restrict__ res, double* __restrict__ chi2_proj,
+                                 double* __restrict__ chi2_str, double* __restrict__ pt_est) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const FixedPose P = load_pose(pose + (size_t)n * 7);
+  const Plane pl = load_plane(rec12, axis, comp[n]);
+  const StrOptStat r = optimize_point(k, P, pts + (size_t)n * 3, uvr + (size_t)n * 3, octave[n], pl, proj_z2[n]);
+  res[n] = r.res ? 1 : 0;
+  chi2_proj[n] = r.chi2_proj;
+  chi2_str[n] = r.chi2_str;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pt_est[(size_t)n * 3 + i] = r.pt[i];
+}
+
+// GMMLoc::checkMapAssociation, one thread per feature
+__global__ void k_check_map_association(PtK k, int B, int N, int K, const double* __restrict__ rec12,
+                                        const double* __restrict__ axis, const uint8_t* __restrict__ flags,
+                                        const int32_t* __restrict__ nbs_ptr, const int32_t* __restrict__ nbs_idx,
+                                        const double* __restrict__ pose_all, double* __restrict__ pts_all,
+                                        const double* __restrict__ uvr_all, const int32_t* __restrict__ oct_all,
+                                        const int32_t* __restrict__ cand_all, const int32_t* __restrict__ ncand_all,
+                                        int kc, int32_t* __restrict__ out_comp) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * N) return;
+  const int f = gid / N;
+  int result = -1;
+  const int oc = oct_all[gid];
+  const int nc = ncand_all[gid];
+  if (oc >= 0 && nc > 0) {  // comps.empty() -> nullptr (:162-164)
+    const SE3 T = se3_load(pose_all + (size_t)f * 7);
+    FixedPose P;
+    qtoR(T.r, P.R);
+    P.t[0] = T.t[0];
+    P.t[1] = T.t[1];
+    P.t[2] = T.t[2];
+    double* pt3d = pts_all + (size_t)gid * 3;
+    const double pt_init[3] = {pt3d[0], pt3d[1], pt3d[2]};
+    const double* uvr = uvr_all + (size_t)gid * 3;
+    double ptc[3];
+    qrot(T.r, pt_init, ptc);
+    double proj_z = ptc[2] + T.t[2];
+    proj_z = proj_z > 1.0 ? 1.0 : proj_z;  // :169-172
+    const double proj_z2 = proj_z * proj_z;
+    int min_idx = -1;
+    double min_value = 1.7976931348623157e308;
+    double min_res[3] = {0, 0, 0};
+    const int32_t* cand = cand_all + (size_t)gid * kc;
+    for (int i = 0; i < nc; ++i) {  // :179-197
+      const int c = cand[i];
+      if (c < 0) continue;
+      const StrOptStat r = optimize_point(k, P, pt_init, uvr, oc, load_plane(rec12, axis, c), proj_z2);
+      if (r.res && r.chi2_proj < min_value) {
+        min_idx = i;
+        min_value = r.chi2_proj;
+        min_res[0] = r.pt[0];
+        min_res[1] = r.pt[1];
+        min_res[2] = r.pt[2];
+      }
+    }
+    if (min_idx != -1) {
+      const int g3d = cand[min_idx];
+      double ll = chi2_rec(rec12 + (size_t)g3d * 12, min_res[0], min_res[1], min_res[2]);
+      int str = g3d;
+      for (int e = nbs_ptr[g3d]; e < nbs_ptr[g3d + 1]; ++e) {  // neighbour refinement (:203-217)
+        const int np = nbs_idx[e];
+        const double ln = chi2_rec(rec12 + (size_t)np * 12, min_res[0], min_res[1], min_res[2]);
+        if (ln < ll) {
+          ll = ln;
+          str = np;
+        }
+      }
+      if (str != g3d) {  // :219-228
+        const StrOptStat r = optimize_point(k, P, pt_init, uvr, oc, load_plane(rec12, axis, str), proj_z2);
+        if (r.res) {
+          min_res[0] = r.pt[0];
+          min_res[1] = r.pt[1];
+          min_res[2] = r.pt[2];
+        } else {
+          str = g3d;
+          ll = chi2_rec(rec12 + (size_t)g3d * 12, min_res[0], min_res[1], min_res[2]);
+        }
+      }
+      if (!(ll > 9.0)) {  // :230-235
+        pt3d[0] = min_res[0];
+        pt3d[1] = min_res[1];
+        pt3d[2] = min_res[2];
+        result = str;
+      }
+    } else {
+      // GMM::queryPoint: nearest mean (:237-256); moves the point but still returns nullptr
+      int gi = -1;
+      double best = __builtin_inf();
+      for (int c = 0; c < K; ++c) {
+        const double d0 = pt_init[0] - rec12[(size_t)c * 12], d1 = pt_init[1] - rec12[(size_t)c * 12 + 1],
+                     d2 = pt_init[2] - rec12[(size_t)c * 12 + 2];
+        const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+        if (d < best) {
+          best = d;
+          gi = c;
+        }
+      }
+      if (gi >= 0 && (flags[gi] & 1)) {
+        const StrOptStat r = optimize_point(k, P, pt_init, uvr, oc, load_plane(rec12, axis, gi), proj_z2);
+        if (r.res) {
+          pt3d[0] = r.pt[0];
+          pt3d[1] = r.pt[1];
+          pt3d[2] = r.pt[2];
+        }
+      }
+    }
+  }
+  out_comp[gid] = result;
+}
+
+// Localization::optimizeTriangulationVec, one thread per triangulated match
+__global__ void k_optimize_triangulation(PtK k, int N, const double* __restrict__ rec12,
+                                         const double* __restrict__ axis, const uint8_t* __restrict__ flags,
+                                         double* __restrict__ x3d_all, const double* __restrict__ pose1,
+                                         const double* __restrict__ uvr1, const int32_t* __restrict__ oct1,
+                                         const double* __restrict__ pose2, const double* __restrict__ uvr2,
+                                         const int32_t* __restrict__ cand1, const int32_t* __restrict__ n1,
+                                         const int32_t* __restrict__ cand2, const int32_t* __restrict__ n2, int kc,
+                                         int32_t* __restrict__ out_comp) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const FixedPose P1 = load_pose(pose1 + (size_t)n * 7), P2 = load_pose(pose2 + (size_t)n * 7);
+  const double* u1 = uvr1 + (size_t)n * 3;
+  const double* u2 = uvr2 + (size_t)n * 3;
+  const bool st1 = !(u1[2] < 0), st2 = !(u2[2] < 0);  // kp.depth > 0 <=> u_right >= 0
+  const double th1 = st1 ? 7.8 : 5.991, th2 = st2 ? 7.8 : 5.991;  // :120-136
+  const double s1 = k.s2inv[oct1[n]];  // both edges use kp1's sigma2_inv (:132,135)
+  double* x3d = x3d_all + (size_t)n * 3;
+  const double pt_init[3] = {x3d[0], x3d[1], x3d[2]};
+  int min_comp = -1;
+  double min_value = 1.7976931348623157e308;
+  double min_res[3] = {0, 0, 0};
+  const int c1n = n1[n], c2n = n2[n];
+  for (int ci = 0; ci < c1n + c2n; ++ci) {
+    const int c = ci < c1n ? cand1[(size_t)n * kc + ci] : cand2[(size_t)n * kc + (ci - c1n)];
+    if (c < 0) continue;
+    bool dup = false;  // the reference de-duplicates through an unordered_set (:143-152)
+    for (int cj = 0; cj < ci; ++cj) {
+      const int o = cj < c1n ? cand1[(size_t)n * kc + cj] : cand2[(size_t)n * kc + (cj - c1n)];
+      if (o == c) dup = true;
+    }
+    if (dup) continue;
+    if (!(flags[c] & 1)) continue;  // only degenerate components (:155-157)
+    const Plane pl = load_plane(rec12, axis, c);
+    double x[3] = {pt_init[0], pt_init[1], pt_init[2]};
+    double e1 = 0, e2 = 0, es = 0;
+    for (int it = 0; it < 20; ++it) {  // :169-171
+      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, dx[3];
+      e1 = reproj_edge(k, P1, x, u1, st1, s1, H, b);
+      e2 = reproj_edge(k, P2, x, u2, st2, s1, H, b);
+      es = plane_edge(pl, x, 1.0 * k.tri_lambda2, H, b);
+      if (!solve3(H, b, dx)) break;
+      x[0] += dx[0];
+      x[1] += dx[1];
+      x[2] += dx[2];
+    }
+    bool ok = true;
+    if (k.check_str && es > k.str_thresh) ok = false;
+    const double err_sum = e1 + e2;
+    if (e1 > th1 || e2 > th2) ok = false;
+    if (ok && err_sum < min_value) {
+      min_res[0] = x[0];
+      min_res[1] = x[1];
+      min_res[2] = x[2];
+      min_comp = c;
+      min_value = err_sum;
+    }
+  }
+  if (min_comp >= 0) {
+    x3d[0] = min_res[0];
+    x3d[1] = min_res[1];
+    x3d[2] = min_res[2];
+  }
+  out_comp[n] = min_comp;
+}
+
+PtK make_ptk(const gl_camera* cam, const gl_params* prm) {
+  PtK k;
+  k.fx = cam->fx;
+  k.fy = cam->fy;
+  k.cx = cam->cx;
+  k.cy = cam->cy;
+  k.bf = cam->bf;
+  for (int i = 0; i < 8; ++i) k.s2inv[i] = (double)prm->sigma2_inv[i];
+  k.tri_lambda2 = (double)prm->tri_lambda2;
+  k.str_thresh = (double)(prm->tri_str_thresh * prm->tri_lambda2);  // float product (gmmloc_opt.cpp:337)
+  k.check_str = prm->tri_check_str_chi2;
+  return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gl_optimize_point(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int N,
+                      const double* pts_dev, const double* uvr_dev, const int32_t* octave_dev,
+                      const double* pose_dev, const int32_t* comp_dev, const double* proj_z2_dev, uint8_t* res_dev,
+                      double* chi2_proj_dev, double* chi2_str_dev, double* pt_est_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (N == 0) return GL_OK;
+  GL_REQUIRE(N > 0 && pts_dev && uvr_dev && octave_dev && pose_dev && comp_dev && proj_z2_dev && res_dev &&
+                 chi2_proj_dev && chi2_str_dev && pt_est_dev,
+             "bad N / null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  k_optimize_point<<<(N + 127) / 128, 128, 0, c->stream>>>(make_ptk(cam, prm), N, g->rec12, g->axis, pts_dev, uvr_dev,
+                                                           octave_dev, pose_dev, comp_dev, proj_z2_dev, res_dev,
+                                                           chi2_proj_dev, chi2_str_dev, pt_est_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_check_map_association(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
+                             int N, const double* pose_dev, double* pts_dev, const double* uvr_dev,
+                             const int32_t* octave_dev, const int32_t* cand_dev, const int32_t* ncand_dev, int k,
+                             int32_t* out_comp_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (B == 0 || N == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && N > 0 && k >= 1 && k <= 8, "bad B / N / k");
+  GL_REQUIRE(pose_dev && pts_dev && uvr_dev && octave_dev && cand_dev && ncand_dev && out_comp_dev, "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  const int total = B * N;
+  k_check_map_association<<<(total + 63) / 64, 64, 0, c->stream>>>(make_ptk(cam, prm), B, N, g->K, g->rec12, g->axis,
+                                                                   g->flags, g->nbs_ptr, g->nbs_idx, pose_dev, pts_dev,
+                                                                   uvr_dev, octave_dev, cand_dev, ncand_dev, k,
+                                                                   out_comp_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_optimize_triangulation(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int N,
+                              double* x3d_dev, const double* pose1_dev, const double* uvr1_dev,
+                              const int32_t* oct1_dev, const double* pose2_dev, const double* uvr2_dev,
+                              const int32_t* oct2_dev, const int32_t* cand1_dev, const int32_t* n1_dev,
+                              const int32_t* cand2_dev, const int32_t* n2_dev, int k, int32_t* out_comp_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (N == 0) return GL_OK;
+  GL_REQUIRE(N > 0 && k >= 1 && k <= 8, "bad N / k");
+  GL_REQUIRE(x3d_dev && pose1_dev && uvr1_dev && oct1_dev && pose2_dev && uvr2_dev && oct2_dev && cand1_dev &&
+                 n1_dev && cand2_dev && n2_dev && out_comp_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  (void)oct2_dev;  // kp2's octave is unused by the reference (it re-uses kp1's sigma, :132,135)
+  k_optimize_triangulation<<<(N + 63) / 64, 64, 0, c->stream>>>(make_ptk(cam, prm), N, g->rec12, g->axis, g->flags,
+                                                                x3d_dev, pose1_dev, uvr1_dev, oct1_dev, pose2_dev,
+                                                                uvr2_dev, cand1_dev, n1_dev, cand2_dev, n2_dev, k,
+                                                                out_comp_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+}  // extern "C"

@@ -99,6 +99,11 @@ int gl_gmm_load_file(gl_ctx_t* ctx, const char* path, const gl_params* prm, gl_g
 int gl_gmm_save_file(const gl_gmm_t* gmm, const char* path);
 int gl_gmm_destroy(gl_gmm_t* gmm);
 int gl_gmm_count(const gl_gmm_t* gmm);
+/* Host-only halves of the two calls above (no device needed): parse a .gmm stream into
+ * caller arrays (mean cap x 3, cov cap x 9 row-major; either may be NULL to query *K_out),
+ * and write one (flags: bit0 is_degenerated, bit1 is_salient per component). */
+int gl_gmm_file_read(const char* path, double* mean, double* cov, int cap, int* K_out);
+int gl_gmm_file_write(const char* path, const double* mean, const double* cov, const uint8_t* flags, int K);
 
 enum gl_gmm_field {
   GL_F_MEAN = 0,      /* K x 3 double */

@@ -1,0 +1,157 @@
+"""GPU parity: renderView + searchCorrespondence (A3-A5), optimizePoint (B1),
+checkMapAssociation (A8), optimizeTriangulationVec (B2) vs the oracle."""
+import numpy as np
+import pytest
+
+import gmmloc_amd
+from gmmloc_amd import synth, api
+
+pytestmark = pytest.mark.gpu
+
+
+def _poses(gt, n, step=61):
+    return np.stack([synth.gt_row_to_Tcw(gt[(7 + i * step) % gt.shape[0]]) for i in range(n)])
+
+
+@pytest.mark.parametrize("mapname,seq", [("v1", "V1_01_easy"), ("v1", "V1_03_difficult"), ("v2", "V2_02_medium")])
+def test_search2d_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, mapname, seq):
+    torch, ctx = gpu
+    mean, cov = map_v1 if mapname == "v1" else map_v2
+    cam = api.Camera()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    B, N = 6, 600
+    poses = _poses(gt_sync[seq], B)
+    rng = np.random.default_rng(3)
+    uv = np.stack([rng.uniform(0, 752, (B, N)), rng.uniform(0, 480, (B, N))], 2)
+    nfeat = np.array([N, N - 7, N, 1, N, N], np.int32)
+    cand, ncand, vids, nview = g.search2d(cam, torch.from_numpy(poses).cuda(), torch.from_numpy(uv).cuda(),
+                                          torch.from_numpy(nfeat).cuda(), k=5, view_cap=2048)
+    torch.cuda.synchronize()
+    cand, ncand, vids, nview = cand.cpu().numpy(), ncand.cpu().numpy(), vids.cpu().numpy(), nview.cpu().numpy()
+    tot = 0
+    for b in range(B):
+        ids, m2, c2, dep = oracle.render_view(h, cam, poses[b])
+        assert nview[b] == len(ids), (b, nview[b], len(ids))
+        assert np.array_equal(vids[b][:len(ids)], ids)  # same set AND same (depth-sorted) order
+        assert (vids[b][len(ids):] == -1).all()
+        c_ref, n_ref = oracle.search_correspondence(h, uv[b], 5)
+        nf = nfeat[b]
+        assert np.array_equal(ncand[b][:nf], n_ref[:nf])
+        assert np.array_equal(cand[b][:nf], c_ref[:nf])
+        assert (ncand[b][nf:] == 0).all() and (cand[b][nf:] == -1).all()
+        tot += len(ids)
+    assert tot > 100 * B / 2  # views are not trivially empty
+    oracle.gmm_destroy(h)
+
+
+def _frames(mean, cov, gt, cam, B, M, seed, **kw):
+    return [synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(gt[(11 + i * 43) % gt.shape[0]]), cam, M, seed + i, **kw)
+            for i in range(B)]
+
+
+def test_optimize_point_matches_oracle(gpu, oracle, map_v1, gt_sync):
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    flags = g.get(api.F_FLAGS)
+    deg = np.nonzero(flags & 1)[0]
+    f = _frames(mean, cov, gt_sync["V1_01_easy"], cam, 1, 500, 5, mono_frac=0.0, outlier_frac=0.2)[0]
+    N = 500
+    comp = f["comp"].copy()
+    comp[(flags[comp] & 1) == 0] = deg[3]
+    pose = np.tile(f["pose_gt"], (N, 1))
+    R, t = synth.quat_to_R(f["pose_gt"][:4]), f["pose_gt"][4:]
+    pz2 = np.minimum(1.0, (f["Xw"] @ R.T + t)[:, 2]) ** 2
+    X0 = f["Xw"] + np.random.default_rng(1).standard_normal((N, 3)) * 0.03
+    r_ref = oracle.optimize_point(h, cam, X0, f["obs"], f["octave"], pose, comp, pz2)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    res, c2p, c2s, est = gmmloc_amd.api.optimize_point(ctx, g, cam, prm, T(X0), T(f["obs"]), T(f["octave"]), T(pose),
+                                                       T(comp.astype(np.int32)), T(pz2))
+    torch.cuda.synchronize()
+    assert np.array_equal(res.cpu().numpy(), r_ref[0])
+    np.testing.assert_allclose(est.cpu().numpy(), r_ref[3], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c2p.cpu().numpy(), r_ref[1], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(c2s.cpu().numpy(), r_ref[2], rtol=1e-8, atol=1e-10)
+    assert 0 < r_ref[0].sum() < N
+    oracle.gmm_destroy(h)
+
+
+@pytest.mark.parametrize("mapname", ["v1", "v2"])
+def test_check_map_association_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, mapname):
+    """Full key-frame association chain: search2d -> checkMapAssociation."""
+    torch, ctx = gpu
+    mean, cov = map_v1 if mapname == "v1" else map_v2
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    B, N = 3, 700
+    fr = _frames(mean, cov, gt_sync["V1_02_medium" if mapname == "v1" else "V2_01_easy"], cam, B, N, 50,
+                 mono_frac=0.0, outlier_frac=0.1)
+    poses = np.stack([f["pose_gt"] for f in fr])
+    # stereo feature -> unprojected map point (frame.cpp:27-35), perturbed in depth
+    pts = np.stack([f["Xw"] for f in fr]) + np.random.default_rng(2).standard_normal((B, N, 3)) * 0.02
+    uvr = np.stack([f["obs"] for f in fr])
+    octv = np.stack([f["octave"] for f in fr])
+    octv[0, ::9] = -1
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    cand, ncand, _, _ = g.search2d(cam, T(poses), T(uvr[:, :, :2].copy()), None, k=5)
+    pts_d = T(pts)
+    out = gmmloc_amd.api.check_map_association(ctx, g, cam, prm, T(poses), pts_d, T(uvr), T(octv), cand, ncand)
+    torch.cuda.synchronize()
+    out, pts_o, cand, ncand = out.cpu().numpy(), pts_d.cpu().numpy(), cand.cpu().numpy(), ncand.cpu().numpy()
+    n_assoc = 0
+    for b in range(B):
+        oracle.render_view(h, cam, poses[b])
+        c_ref, n_ref = oracle.search_correspondence(h, uvr[b][:, :2].copy(), 5)
+        assert np.array_equal(cand[b], c_ref) and np.array_equal(ncand[b], n_ref)
+        keep = octv[b] >= 0
+        o_ref, p_ref = oracle.check_map_association(h, cam, poses[b], pts[b][keep], uvr[b][keep],
+                                                    octv[b][keep], c_ref[keep], n_ref[keep])
+        assert np.array_equal(out[b][keep], o_ref), int((out[b][keep] != o_ref).sum())
+        np.testing.assert_allclose(pts_o[b][keep], p_ref, rtol=0, atol=1e-9)
+        assert (out[b][~keep] == -1).all() and np.array_equal(pts_o[b][~keep], pts[b][~keep])
+        n_assoc += int((o_ref >= 0).sum())
+    assert n_assoc > 50
+    oracle.gmm_destroy(h)
+
+
+def test_optimize_triangulation_matches_oracle(gpu, oracle, map_v1, gt_sync):
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    gt = gt_sync["V1_01_easy"]
+    N = 400
+    p1 = synth.gt_row_to_Tcw(gt[900])
+    p2 = synth.gt_row_to_Tcw(gt[912])
+    f = synth.synth_frame(mean, cov, p1, cam, N, 9, outlier_frac=0.05, mono_frac=0.5)
+    rng = np.random.default_rng(4)
+    R2, t2 = synth.quat_to_R(p2[:4]), p2[4:]
+    pc2 = f["Xw"] @ R2.T + t2
+    u2 = cam.fx * pc2[:, 0] / pc2[:, 2] + cam.cx + rng.standard_normal(N) * 0.7
+    v2 = cam.fy * pc2[:, 1] / pc2[:, 2] + cam.cy + rng.standard_normal(N) * 0.7
+    ur2 = np.where(rng.uniform(size=N) < 0.5, -1.0, u2 - cam.bf / pc2[:, 2])
+    uvr2 = np.stack([u2, v2, ur2], 1)
+    oct2 = rng.integers(0, 8, N).astype(np.int32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    poses = np.stack([p1, p2])
+    uv = np.stack([f["obs"][:, :2], uvr2[:, :2]])
+    cand, ncand, _, _ = g.search2d(cam, T(poses), T(uv), None, k=5)
+    torch.cuda.synchronize()
+    c, n = cand.cpu().numpy(), ncand.cpu().numpy()
+    x0 = f["Xw"] + rng.standard_normal((N, 3)) * 0.03
+    xd = T(x0)
+    out = gmmloc_amd.api.optimize_triangulation(ctx, g, cam, prm, xd, T(np.tile(p1, (N, 1))), T(f["obs"]),
+                                                T(f["octave"]), T(np.tile(p2, (N, 1))), T(uvr2), T(oct2),
+                                                T(c[0]), T(n[0]), T(c[1]), T(n[1]))
+    torch.cuda.synchronize()
+    o_ref, x_ref = oracle.optimize_triangulation(h, cam, x0, np.tile(p1, (N, 1)), f["obs"], f["octave"],
+                                                 np.tile(p2, (N, 1)), uvr2, oct2, c[0], n[0], c[1], n[1])
+    assert np.array_equal(out.cpu().numpy(), o_ref), int((out.cpu().numpy() != o_ref).sum())
+    np.testing.assert_allclose(xd.cpu().numpy(), x_ref, rtol=0, atol=1e-9)
+    assert (o_ref >= 0).sum() > 20
+    oracle.gmm_destroy(h)

@@ -1,0 +1,102 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/gmmloc_hip.h declares,
+and its host-only logic (.gmm reader / writer, default parameters, error reporting) works.
+No compute entry point is called here (there is no GPU and no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, GOLDEN
+
+REF_MAP = "/root/reference/gmmloc_ros/data/map"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gmmloc_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "gmmloc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(gl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert not lib._gl_missing, lib._gl_missing
+    # and the python binding table covers the header
+    assert names == set(lib._gl_signatures), names ^ set(lib._gl_signatures)
+
+
+def test_default_params_match_reference_config(lib):
+    from gmmloc_amd import api
+    p = api.Params()
+    c = p.c()
+    assert c.neighbor_dist_thresh == 2.5 and c.tri_lambda2 == 400.0 and c.ba_lambda2 == 400.0
+    assert c.tri_str_thresh == np.float32(0.0064) and c.tri_check_str_chi2 == 1 and c.ba_first_as_prior == 1
+    # frame::sigma2_inv (init_config.hpp:60-79), float arithmetic
+    sf, ref = np.float32(1.0), [np.float32(1.0)]
+    for _ in range(7):
+        sf = np.float32(sf * np.float32(1.2))
+        ref.append(np.float32(1.0) / np.float32(sf * sf))
+    assert np.array_equal(p.sigma2_inv, np.array(ref, np.float32))
+
+
+def test_no_gpu_calls_fail_loudly(lib):
+    """Without a device every compute path must return an error, never a CPU result."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.gl_ctx_create(0, None, C.byref(h))
+    assert rc != 0 and lib.gl_last_error_string() != b""
+    assert lib.gl_device_count() == 0
+
+
+def test_gmm_file_roundtrip_host(lib, tmp_path):
+    from gmmloc_amd import api
+    d = np.load(os.path.join(GOLDEN, "map_v1.npz"))
+    mean, cov = d["mean"], d["cov"]
+    sym = 0.5 * (cov.reshape(-1, 3, 3) + cov.reshape(-1, 3, 3).transpose(0, 2, 1))
+    flags = (np.arange(mean.shape[0]) % 4).astype(np.uint8)
+    p = tmp_path / "rt.gmm"
+    api.write_gmm_file(p, mean, sym.reshape(-1, 9), flags)
+    m2, c2 = api.read_gmm_file(p)
+    assert np.array_equal(m2, mean) and np.array_equal(c2, sym.reshape(-1, 9))
+    assert os.path.getsize(p) == 105 * mean.shape[0] + 2  # 105 B / component
+
+
+def test_gmm_file_errors(lib, tmp_path):
+    from gmmloc_amd import api
+    with pytest.raises(api.GLError, match="Could not open"):
+        api.read_gmm_file(tmp_path / "nope.gmm")
+    (tmp_path / "empty.gmm").write_bytes(b"\x00")
+    with pytest.raises(api.GLError, match="empty"):
+        api.read_gmm_file(tmp_path / "empty.gmm")
+    (tmp_path / "trunc.gmm").write_bytes(b"\x01\x69\x08\x01")
+    with pytest.raises(api.GLError):
+        api.read_gmm_file(tmp_path / "trunc.gmm")
+    # a component with 2 mean values (reference: CHECK_EQ(mean_size, 3) aborts)
+    msg = b"\x1a\x10" + np.zeros(2).tobytes() + b"\x22\x48" + np.zeros(9).tobytes()
+    (tmp_path / "bad.gmm").write_bytes(b"\x01" + bytes([len(msg)]) + msg)
+    with pytest.raises(api.GLError, match="mean_size"):
+        api.read_gmm_file(tmp_path / "bad.gmm")
+    # unpacked doubles (wire type 1) are accepted like protobuf does
+    msg = b"".join(b"\x19" + np.float64(v).tobytes() for v in (1.0, 2.0, 3.0)) + b"\x22\x48" + np.eye(3).tobytes()
+    (tmp_path / "unpacked.gmm").write_bytes(b"\x01" + bytes([len(msg)]) + msg)
+    m, c = api.read_gmm_file(tmp_path / "unpacked.gmm")
+    assert np.array_equal(m, [[1.0, 2.0, 3.0]]) and np.array_equal(c.reshape(3, 3), np.eye(3))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MAP), reason="reference data files not present")
+@pytest.mark.parametrize("name", ["v1", "v2"])
+def test_reader_on_the_shipped_maps(lib, name):
+    """The C++ reader on the reference's own .gmm files == the independently decoded fixture."""
+    from gmmloc_amd import api
+    m, c = api.read_gmm_file(os.path.join(REF_MAP, name + ".gmm"))
+    d = np.load(os.path.join(GOLDEN, "map_%s.npz" % name))
+    assert np.array_equal(m, d["mean"]) and np.array_equal(c, d["cov"])
+    assert m.shape[0] == {"v1": 3299, "v2": 5096}[name]
