@@ -318,3 +318,23 @@ def optimize_triangulation(ctx, gmm, cam, prm, x3d, pose1, uvr1, oct1, pose2, uv
                                              _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k, _ptr(out)))
     ctx._exit()
     return out
+
+
+def joint_optimization(ctx, gmm, cam, prm, P, F, poses, prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_oct):
+    """Localization::jointOptimization (localization_opt.cpp:456-925) on B flat problems of one shape.
+    poses (B,P+F,7) and points (B,L,3) are updated in place.
+    Returns (assoc_dropped uint8 (B,L), obs_erase uint8 (B,NOBS), iters int32 (B,))."""
+    import torch
+    B, L = points.shape[0], points.shape[1]
+    NOBS = obs_pose.shape[1]
+    dev = points.device
+    dropped = torch.zeros((B, L), dtype=torch.uint8, device=dev)
+    erase = torch.zeros((B, NOBS), dtype=torch.uint8, device=dev)
+    iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_joint_optimization(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
+                                         _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
+                                         _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
+                                         _ptr(iters)))
+    ctx._exit()
+    return dropped, erase, iters

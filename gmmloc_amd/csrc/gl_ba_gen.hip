@@ -1,0 +1,806 @@
+// General local bundle adjustment: Localization::jointOptimization
+// (localization_opt.cpp:456-925) with P free poses, F fixed poses, L marginalised points
+// observed by any number of poses (mono / stereo, Huber), one GMM edge per point, optional
+// pose prior.  One persistent workgroup per problem; no atomics, deterministic:
+//   P1  one thread per point: linearise every active observation in its camera frame
+//       (q, A = w Jpi^T Jpi, a = w Jpi^T e stored per observation), gather the world-frame
+//       point block D = sum R^T A R + Hg + lambda I, D^-1 by cofactors, u = D^-1 b.
+//   P2  one WAVE per reduced-camera block (j1, j2): lanes stride over pose j1's observation
+//       list (pose-major CSR built once on the device), find the partner observation of
+//       the same point in pose j2 through a precomputed match table, and accumulate
+//       G1^T [A1 R1 D^-1 R2^T A2] G2 in registers; a wave reduce-scatter (gld::
+//       wave_reduce_scatter32) then writes the 6x6 block -- the Schur complement
+//       S = Hpp - sum W D^-1 W^T and g = bp - sum W D^-1 b without a single atomic.
+//   solve  in-place right-looking LDL^T of the 6P x 6P system by the whole workgroup.
+//   P3  back-substitution per point, trial state, new errors, rho test.
+// Control flow and gating as in gl_ba.hip (g2o Levenberg, 5 / 5 / 40 schedule).
+#include "gl_ba_common.hpp"
+
+using namespace gld;
+using namespace glba;
+
+namespace {
+
+struct GenP {
+  int P, F, L, nobs;
+  double* poses;
+  const uint8_t* prior;
+  double* pts;
+  const int32_t* assoc;
+  const int32_t* optr;
+  const int32_t* opose;
+  const double* ouvr;
+  const int32_t* ooct;
+  // scratch
+  double* Rt;      // (P+F) x 12 current R, t
+  double* RtN;     // P x 12 trial
+  double* qN;      // P x 7 trial poses
+  double* pinv;    // P x 7 prior inverse measurement
+  double* pn;      // L x 3 trial points
+  double* lin;     // nobs x 12: q3 A6 a3
+  double* ptw;     // L x 12: Dinv6 u3 bl3
+  double* chi_o;   // nobs
+  double* S;       // n x n
+  double* gv;      // n
+  double* bp;      // n
+  double* dxv;     // n
+  double* pchi;    // P prior chi2 (current / trial)
+  int32_t* opoint; // nobs
+  int32_t* pl_ptr; // P + 1
+  int32_t* pl_obs; // nobs
+  int32_t* match;  // nobs x P
+  uint8_t* lev_o;  // nobs
+  uint8_t* lev_g;  // L
+  uint8_t* pfree;  // P + F
+  uint8_t* pact;   // P
+  uint8_t* lact;   // L  point active this optimize()
+};
+
+GL_DEV void load_Rt(const double* Rt, double* R, double* t) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+  t[0] = Rt[9];
+  t[1] = Rt[10];
+  t[2] = Rt[11];
+}
+GL_DEV void store_pose_Rt(const SE3& T, double* Rt) {
+  double R[9];
+  qtoR(T.r, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rt[i] = R[i];
+  Rt[9] = T.t[0];
+  Rt[10] = T.t[1];
+  Rt[11] = T.t[2];
+}
+
+// reprojection linearisation in the camera frame: q, A (sym6), a; returns chi2, rho0
+GL_DEV void lin_obs(const BaK& k, const double* R, const double* t, const double* p, const double* ob, int oc,
+                    bool robust, double* q, double* A, double* a, double& chi2, double& rho0) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = R[i * 3] * p[0] + R[i * 3 + 1] * p[1] + R[i * 3 + 2] * p[2] + t[i];
+  const bool stereo = !(ob[2] < 0);
+  const double s = k.s2inv[oc];
+  double e[3], iz;
+  chi2 = reproj_err(k, q, ob, stereo, s, e, iz);
+  double rho1 = 1.0;
+  rho0 = chi2;
+  if (robust) huber(chi2, stereo ? k.delta_stereo : k.delta_mono, rho0, rho1);
+  const double w = rho1 * s;
+  const double iz2 = iz * iz;
+  const double al = k.fx * iz, ga = k.fy * iz;
+  const double b0 = -k.fx * q[0] * iz2, b1 = -k.fy * q[1] * iz2;
+  const double b2 = b0 + k.bf * iz2;
+  const double sb = stereo ? 1.0 : 0.0;
+  A[0] = w * (al * al + sb * al * al);
+  A[1] = 0.0;
+  A[2] = w * (al * b0 + sb * al * b2);
+  A[3] = w * ga * ga;
+  A[4] = w * ga * b1;
+  A[5] = w * (b0 * b0 + b1 * b1 + sb * b2 * b2);
+  a[0] = w * al * (e[0] + sb * e[2]);
+  a[1] = w * ga * e[1];
+  a[2] = w * (b0 * e[0] + b1 * e[1] + sb * b2 * e[2]);
+}
+
+GL_DEV void sym_to_full(const double* S, double* F) {
+  F[0] = S[0];
+  F[1] = S[1];
+  F[2] = S[2];
+  F[3] = S[1];
+  F[4] = S[3];
+  F[5] = S[4];
+  F[6] = S[2];
+  F[7] = S[4];
+  F[8] = S[5];
+}
+GL_DEV void mm3t(const double* A, const double* B, double* C) {  // C = A * B^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+GL_DEV void mmt3(const double* A, const double* B, double* C) {  // C = A^T * B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+// blk (6x6 row-major) = G1^T M G2 with G = [-[q]x | I]  ->  [[-Q1 M Q2, Q1 M], [-M Q2, M]]
+GL_DEV void gmg(const double* q1, const double* M, const double* q2, double* blk) {
+  double Q1M[9], MQ2[9], Q1MQ2[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {  // column j of Q1 M = q1 x M[:, j]
+    const double col[3] = {M[j], M[3 + j], M[6 + j]};
+    double r[3];
+    cross(q1, col, r);
+    Q1M[j] = r[0];
+    Q1M[3 + j] = r[1];
+    Q1M[6 + j] = r[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // row i of M Q2 = (M[i,:]) Q2 = -(q2 x M[i,:]) ... (v^T Q) = (Q^T v)^T = -(q x v)^T
+    double r[3];
+    cross(q2, &M[i * 3], r);
+    MQ2[i * 3] = -r[0];
+    MQ2[i * 3 + 1] = -r[1];
+    MQ2[i * 3 + 2] = -r[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double r[3];
+    cross(q2, &Q1M[i * 3], r);
+    Q1MQ2[i * 3] = -r[0];
+    Q1MQ2[i * 3 + 1] = -r[1];
+    Q1MQ2[i * 3 + 2] = -r[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      blk[i * 6 + j] = -Q1MQ2[i * 3 + j];
+      blk[i * 6 + 3 + j] = Q1M[i * 3 + j];
+      blk[(i + 3) * 6 + j] = -MQ2[i * 3 + j];
+      blk[(i + 3) * 6 + 3 + j] = M[i * 3 + j];
+    }
+}
+
+// ---- P1 -------------------------------------------------------------------------------------
+// returns (per-thread partial) robust chi2; mdiag = max landmark diagonal (world frame)
+GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
+  double chi = 0.0;
+  for (int l = threadIdx.x; l < G.L; l += T_BA) {
+    if (!G.lact[l]) continue;
+    const double p[3] = {G.pts[(size_t)l * 3], G.pts[(size_t)l * 3 + 1], G.pts[(size_t)l * 3 + 2]};
+    double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+      if (G.lev_o[o]) continue;
+      const int j = G.opose[o];
+      double R[9], t[3], q[3], A[6], a[3], c2, r0;
+      load_Rt(G.Rt + (size_t)j * 12, R, t);
+      lin_obs(k, R, t, p, G.ouvr + (size_t)o * 3, G.ooct[o], robust, q, A, a, c2, r0);
+      G.chi_o[o] = c2;
+      chi += r0;
+      double* lo = G.lin + (size_t)o * 12;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) lo[i] = q[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) lo[3 + i] = A[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) lo[9 + i] = a[i];
+      double Af[9], AR[9], RAR[9];
+      sym_to_full(A, Af);
+      mm3(Af, R, AR);
+      mmt3(R, AR, RAR);
+      H[0] += RAR[0];
+      H[1] += RAR[1];
+      H[2] += RAR[2];
+      H[3] += RAR[4];
+      H[4] += RAR[5];
+      H[5] += RAR[8];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bl[i] += R[i] * a[0] + R[3 + i] * a[1] + R[6 + i] * a[2];
+    }
+    if (G.assoc[l] >= 0 && !G.lev_g[l]) {
+      GmmRef g;
+      load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+      const double d[3] = {p[0] - g.mu[0], p[1] - g.mu[1], p[2] - g.mu[2]};
+      if (g.deg) {
+        const double eg = g.n[0] * d[0] + g.n[1] * d[1] + g.n[2] * d[2];
+        const double lm = k.ba_lambda2;
+        chi += eg * (lm * eg);
+        H[0] += lm * g.n[0] * g.n[0];
+        H[1] += lm * g.n[0] * g.n[1];
+        H[2] += lm * g.n[0] * g.n[2];
+        H[3] += lm * g.n[1] * g.n[1];
+        H[4] += lm * g.n[1] * g.n[2];
+        H[5] += lm * g.n[2] * g.n[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bl[i] -= lm * eg * g.n[i];
+      } else {
+        double e[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = g.L[i] * d[0] + g.L[3 + i] * d[1] + g.L[6 + i] * d[2];
+        chi += e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        double Hg[9];
+        mm3t(g.L, g.L, Hg);
+        H[0] += Hg[0];
+        H[1] += Hg[1];
+        H[2] += Hg[2];
+        H[3] += Hg[4];
+        H[4] += Hg[5];
+        H[5] += Hg[8];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bl[i] -= g.L[i * 3] * e[0] + g.L[i * 3 + 1] * e[1] + g.L[i * 3 + 2] * e[2];
+      }
+    }
+    mdiag = fmax(mdiag, fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))));
+    double D[6] = {H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda}, Dinv[6], u[3];
+    sym3_inv(D, Dinv);
+    sym3_mul_vec(Dinv, bl, u);
+    double* pw = G.ptw + (size_t)l * 12;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pw[i] = Dinv[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pw[6 + i] = u[i];
+      pw[9 + i] = bl[i];
+    }
+  }
+  return chi;
+}
+
+// ---- P2 -------------------------------------------------------------------------------------
+GL_DEV void pass_blocks(const GenP& G, bool schur) {
+  const int P = G.P, n = 6 * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = P * (P + 1) / 2;
+  for (int b = wave; b < nblk; b += NW_BA) {
+    // decode (j1 <= j2)
+    int j1 = 0, rem = b;
+    while (rem >= P - j1) {
+      rem -= P - j1;
+      ++j1;
+    }
+    const int j2 = j1 + rem;
+    if (!G.pact[j1] || !G.pact[j2]) continue;
+    if (!schur && j1 != j2) continue;
+    double v1[32], v2[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      v1[i] = 0.0;
+      v2[i] = 0.0;
+    }
+    double R1[9], t1[3], R2[9], t2[3];
+    load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
+    load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
+    for (int e = G.pl_ptr[j1] + lane; e < G.pl_ptr[j1 + 1]; e += 64) {
+      const int o1 = G.pl_obs[e];
+      if (G.lev_o[o1]) continue;
+      const int o2 = (j1 == j2) ? o1 : G.match[(size_t)o1 * P + j2];
+      if (o2 < 0 || G.lev_o[o2]) continue;
+      const int l = G.opoint[o1];
+      const double* l1 = G.lin + (size_t)o1 * 12;
+      const double* l2 = G.lin + (size_t)o2 * 12;
+      const double* pw = G.ptw + (size_t)l * 12;
+      double A1[9], A2[9], Dv[9];
+      sym_to_full(l1 + 3, A1);
+      sym_to_full(l2 + 3, A2);
+      sym_to_full(pw, Dv);
+      double blk[36];
+      if (schur) {
+        // M = A1 R1 D^-1 R2^T A2
+        double X[9], Y[9], Z[9], M[9];
+        mm3(A1, R1, X);
+        mm3(X, Dv, Y);
+        mm3t(Y, R2, Z);
+        mm3(Z, A2, M);
+        gmg(l1, M, l2, blk);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
+      }
+      double gq[6] = {0, 0, 0, 0, 0, 0}, bq[6] = {0, 0, 0, 0, 0, 0};
+      if (j1 == j2) {
+        double hpp[36];
+        gmg(l1, A1, l1, hpp);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = hpp[i] - blk[i];
+        // bp = G^T a ; g = G^T (a - A1 R1 u)
+        const double* a = l1 + 9;
+        double c[3] = {a[0], a[1], a[2]};
+        if (schur) {
+          const double* u = pw + 6;
+          double Ru[3], ARu[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Ru[i] = R1[i * 3] * u[0] + R1[i * 3 + 1] * u[1] + R1[i * 3 + 2] * u[2];
+          sym3_mul_vec(l1 + 3, Ru, ARu);
+          c[0] -= ARu[0];
+          c[1] -= ARu[1];
+          c[2] -= ARu[2];
+        }
+        double qc[3], qa[3];
+        cross(l1, c, qc);
+        cross(l1, a, qa);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          gq[i] = qc[i];
+          gq[3 + i] = c[i];
+          bq[i] = qa[i];
+          bq[3 + i] = a[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = -blk[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v1[i] += blk[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v2[i] += blk[32 + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        v2[4 + i] += gq[i];
+        v2[10 + i] += bq[i];
+      }
+    }
+    const double r1 = wave_reduce_scatter32(v1);
+    const double r2 = wave_reduce_scatter32(v2);
+    if (lane < 32) {
+      const int s = wave_slot(lane);
+      {
+        const int r = s / 6, c = s % 6;
+        G.S[(size_t)(6 * j1 + r) * n + 6 * j2 + c] = r1;
+        if (j1 != j2) G.S[(size_t)(6 * j2 + c) * n + 6 * j1 + r] = r1;
+      }
+      if (s < 4) {
+        const int r = (32 + s) / 6, c = (32 + s) % 6;
+        G.S[(size_t)(6 * j1 + r) * n + 6 * j2 + c] = r2;
+        if (j1 != j2) G.S[(size_t)(6 * j2 + c) * n + 6 * j1 + r] = r2;
+      } else if (s < 10 && j1 == j2) {
+        G.gv[6 * j1 + (s - 4)] = r2;
+      } else if (s < 16 && j1 == j2) {
+        G.bp[6 * j1 + (s - 10)] = r2;
+      }
+    }
+  }
+}
+
+// in-place LDL^T solve of S x = g (lower triangle), whole workgroup; returns ok
+GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag) {
+  const int tid = threadIdx.x;
+  if (tid == 0) *s_flag = 1;
+  __syncthreads();
+  for (int kk = 0; kk < n; ++kk) {
+    const double d = S[(size_t)kk * n + kk];
+    if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
+    // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
+    const double id = 1.0 / d;
+    for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
+      const double ci = S[(size_t)i * n + kk] * id;
+      for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * n + j] -= ci * S[(size_t)j * n + kk];
+    }
+    __syncthreads();
+    for (int i = kk + 1 + tid; i < n; i += T_BA) S[(size_t)i * n + kk] *= id;  // l_ik
+    __syncthreads();
+  }
+  // forward: L y = g
+  for (int kk = 0; kk < n; ++kk) {
+    const double yk = g[kk];
+    __syncthreads();
+    for (int i = kk + 1 + tid; i < n; i += T_BA) g[i] -= S[(size_t)i * n + kk] * yk;
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += T_BA) g[i] /= S[(size_t)i * n + i];
+  __syncthreads();
+  // backward: L^T x = z
+  for (int kk = n - 1; kk >= 0; --kk) {
+    const double xk = g[kk];
+    __syncthreads();
+    for (int i = tid; i < kk; i += T_BA) g[i] -= S[(size_t)kk * n + i] * xk;
+    __syncthreads();
+  }
+  return *s_flag != 0;
+}
+
+GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag) {
+  const int P = G.P, n = 6 * P, tid = threadIdx.x;
+  double acc[32];
+  // ---- initializeOptimization(0): active poses / points -----------------------------------
+  for (int j = tid; j < P; j += T_BA) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  for (int l = tid; l < G.L; l += T_BA) {
+    bool any = G.assoc[l] >= 0 && !G.lev_g[l];
+    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o)
+      if (!G.lev_o[o]) {
+        any = true;
+        const int j = G.opose[o];
+        if (G.pfree[j]) G.pact[j] = 1;  // benign same-value race
+      }
+    G.lact[l] = any ? 1 : 0;
+    if (any) acc[0] += 1.0;
+  }
+  __syncthreads();
+  for (int j = tid; j < P; j += T_BA)
+    if (G.pact[j]) acc[1] += 1.0;
+  block_reduce<2, NW_BA>(acc, red);
+  const bool any_point = acc[0] > 0.0, any_pose = acc[1] > 0.0;
+  if (!any_point && !any_pose) return -1;
+
+  double lambda = 0.0, ni = 2.0;
+  int cj = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (it == 0) {  // computeLambdaInit
+      double md = 0.0;
+      pass_points(k, gm, G, robust, 0.0, md);
+      for (int i = tid; i < n * n; i += T_BA) G.S[i] = 0.0;
+      __syncthreads();
+      pass_blocks(G, false);
+      __syncthreads();
+      for (int j = tid; j < P; j += T_BA) {
+        if (!G.pact[j]) continue;
+        double H[36], b[6] = {0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < 36; ++r) H[r] = 0.0;
+        if (G.prior[j] && k.first_as_prior) {
+          const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
+          prior_terms(Pi, T, true, H, b);
+        }
+        for (int r = 0; r < 6; ++r) md = fmax(md, fabs(G.S[(size_t)(6 * j + r) * n + 6 * j + r] + H[r * 6 + r]));
+      }
+      md = block_max(md, red);
+      lambda = 1e-5 * md;
+      ni = 2.0;
+    }
+    double rho = 0.0, currentChi = 0.0;
+    int qmax = 0;
+    do {
+      // ---- P1 + P2 at the current state -------------------------------------------------------
+      double md_unused = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      acc[0] = pass_points(k, gm, G, robust, lambda, md_unused);
+      for (int i = tid; i < n * n; i += T_BA) G.S[i] = 0.0;
+      for (int i = tid; i < n; i += T_BA) {
+        G.gv[i] = 0.0;
+        G.bp[i] = 0.0;
+      }
+      block_reduce<1, NW_BA>(acc, red);
+      double chiA = acc[0];
+      pass_blocks(G, true);
+      __syncthreads();
+      // priors and inactive poses
+      for (int j = tid; j < P; j += T_BA) {
+        G.pchi[j] = 0.0;
+        if (!G.pact[j]) {
+          for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * n + 6 * j + r] = 1.0;
+          continue;
+        }
+        if (G.prior[j] && k.first_as_prior) {
+          double H[36], b[6] = {0, 0, 0, 0, 0, 0};
+          for (int r = 0; r < 36; ++r) H[r] = 0.0;
+          const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
+          G.pchi[j] = prior_terms(Pi, T, true, H, b);
+          for (int r = 0; r < 6; ++r) {
+            G.gv[6 * j + r] += b[r];
+            G.bp[6 * j + r] += b[r];
+            for (int c = 0; c < 6; ++c) G.S[(size_t)(6 * j + r) * n + 6 * j + c] += H[r * 6 + c];
+          }
+        }
+        for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
+      }
+      __syncthreads();
+      for (int j = 0; j < P; ++j) chiA += G.pchi[j];
+      if (qmax == 0) currentChi = chiA;
+      for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
+      __syncthreads();
+      bool ok2 = true;
+      if (any_pose) ok2 = block_ldlt_solve(G.S, G.dxv, n, s_flag);
+      __syncthreads();
+      // ---- P3: trial poses -----------------------------------------------------------------------
+      for (int j = tid; j < P; j += T_BA) {
+        const SE3 T = se3_load(G.poses + (size_t)j * 7);
+        SE3 Tn = T;
+        if (G.pact[j] && ok2) {
+          double dx[6];
+          for (int r = 0; r < 6; ++r) dx[r] = G.dxv[6 * j + r];
+          Tn = se3_mul(se3_exp(dx), T);
+        } else {
+          for (int r = 0; r < 6; ++r) G.dxv[6 * j + r] = 0.0;
+        }
+        se3_store(Tn, G.qN + (size_t)j * 7);
+        store_pose_Rt(Tn, G.RtN + (size_t)j * 12);
+        G.pchi[j] = (G.pact[j] && G.prior[j] && k.first_as_prior)
+                        ? prior_terms(se3_load(G.pinv + (size_t)j * 7), Tn, false, nullptr, nullptr)
+                        : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      for (int l = tid; l < G.L; l += T_BA) {
+        if (!G.lact[l]) continue;
+        const double* pw = G.ptw + (size_t)l * 12;
+        double rhs[3] = {pw[9], pw[10], pw[11]};
+        for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+          if (G.lev_o[o]) continue;
+          const int j = G.opose[o];
+          if (j >= P || !G.pact[j]) continue;
+          const double* lo = G.lin + (size_t)o * 12;
+          const double* dx = G.dxv + 6 * j;
+          double gd[3], Ag[3];
+          cross(dx, lo, gd);
+          gd[0] += dx[3];
+          gd[1] += dx[4];
+          gd[2] += dx[5];
+          sym3_mul_vec(lo + 3, gd, Ag);
+          const double* R = G.Rt + (size_t)j * 12;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) rhs[i] -= R[i] * Ag[0] + R[3 + i] * Ag[1] + R[6 + i] * Ag[2];
+        }
+        double dl[3];
+        sym3_mul_vec(pw, rhs, dl);
+        acc[0] += dl[0] * (lambda * dl[0] + pw[9]) + dl[1] * (lambda * dl[1] + pw[10]) + dl[2] * (lambda * dl[2] + pw[11]);
+        const double pn[3] = {G.pts[(size_t)l * 3] + dl[0], G.pts[(size_t)l * 3 + 1] + dl[1], G.pts[(size_t)l * 3 + 2] + dl[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) G.pn[(size_t)l * 3 + i] = pn[i];
+        for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+          if (G.lev_o[o]) continue;
+          const int j = G.opose[o];
+          const double* Rt = (j < P) ? G.RtN + (size_t)j * 12 : G.Rt + (size_t)j * 12;
+          double q[3], e[3], iz;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) q[i] = Rt[i * 3] * pn[0] + Rt[i * 3 + 1] * pn[1] + Rt[i * 3 + 2] * pn[2] + Rt[9 + i];
+          const double* ob = G.ouvr + (size_t)o * 3;
+          const bool stereo = !(ob[2] < 0);
+          const double c2 = reproj_err(k, q, ob, stereo, k.s2inv[G.ooct[o]], e, iz);
+          G.chi_o[o] = c2;
+          double r0 = c2, r1;
+          if (robust) huber(c2, stereo ? k.delta_stereo : k.delta_mono, r0, r1);
+          acc[1] += r0;
+        }
+        if (G.assoc[l] >= 0 && !G.lev_g[l]) {
+          GmmRef g;
+          load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+          acc[1] += gmm_chi2(k, g, pn);
+        }
+      }
+      block_reduce<2, NW_BA>(acc, red);
+      double scale = acc[0], tempChi = acc[1];
+      for (int j = 0; j < P; ++j) tempChi += G.pchi[j];
+      for (int i = 0; i < n; ++i) scale += G.dxv[i] * (lambda * G.dxv[i] + G.bp[i]);
+      if (!ok2) tempChi = 1.7976931348623157e308;
+      scale += 1e-3;
+      rho = (currentChi - tempChi) / scale;
+      __syncthreads();
+      if (rho > 0 && isfinite(tempChi)) {
+        const double uu = 2 * rho - 1;
+        double alpha = 1. - uu * uu * uu;
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        for (int j = tid; j < P; j += T_BA) {
+          if (!G.pact[j]) continue;
+          for (int r = 0; r < 7; ++r) G.poses[(size_t)j * 7 + r] = G.qN[(size_t)j * 7 + r];
+          for (int r = 0; r < 12; ++r) G.Rt[(size_t)j * 12 + r] = G.RtN[(size_t)j * 12 + r];
+        }
+        for (int l = tid; l < G.L; l += T_BA) {
+          if (!G.lact[l]) continue;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) G.pts[(size_t)l * 3 + i] = G.pn[(size_t)l * 3 + i];
+        }
+      } else {
+        lambda *= ni;
+        ni *= 2;
+      }
+      __syncthreads();
+      qmax++;
+    } while (rho < 0 && qmax < 10);
+    ++cj;
+    if (qmax == 10 || rho == 0) break;
+  }
+  return cj;
+}
+
+__global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P, int F, int L, int NOBS,
+                                                 double* __restrict__ poses_all, const uint8_t* __restrict__ prior_all,
+                                                 double* __restrict__ pts_all, const int32_t* __restrict__ assoc_all,
+                                                 const int32_t* __restrict__ optr_all,
+                                                 const int32_t* __restrict__ opose_all,
+                                                 const double* __restrict__ ouvr_all,
+                                                 const int32_t* __restrict__ ooct_all,
+                                                 uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
+                                                 int32_t* __restrict__ iters_all, char* __restrict__ scratch,
+                                                 size_t scratch_per_problem) {
+  __shared__ double red[NW_BA * 32];
+  __shared__ int s_flag;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= B) return;
+  GenP G;
+  G.P = P;
+  G.F = F;
+  G.L = L;
+  G.poses = poses_all + (size_t)f * (P + F) * 7;
+  G.prior = prior_all + (size_t)f * P;
+  G.pts = pts_all + (size_t)f * L * 3;
+  G.assoc = assoc_all + (size_t)f * L;
+  G.optr = optr_all + (size_t)f * (L + 1);
+  G.opose = opose_all + (size_t)f * NOBS;
+  G.ouvr = ouvr_all + (size_t)f * NOBS * 3;
+  G.ooct = ooct_all + (size_t)f * NOBS;
+  G.nobs = G.optr[L];
+  const int nobs = G.nobs, n = 6 * P;
+  // carve the scratch (doubles first, then ints, then bytes)
+  char* s = scratch + (size_t)f * scratch_per_problem;
+  auto takeD = [&](size_t cnt) {
+    double* p = (double*)s;
+    s += cnt * 8;
+    return p;
+  };
+  G.Rt = takeD((size_t)(P + F) * 12);
+  G.RtN = takeD((size_t)P * 12);
+  G.qN = takeD((size_t)P * 7);
+  G.pinv = takeD((size_t)P * 7);
+  G.pn = takeD((size_t)L * 3);
+  G.lin = takeD((size_t)NOBS * 12);
+  G.ptw = takeD((size_t)L * 12);
+  G.chi_o = takeD((size_t)NOBS);
+  G.S = takeD((size_t)n * n);
+  G.gv = takeD(n);
+  G.bp = takeD(n);
+  G.dxv = takeD(n);
+  G.pchi = takeD(P);
+  auto takeI = [&](size_t cnt) {
+    int32_t* p = (int32_t*)s;
+    s += ((cnt * 4 + 7) / 8) * 8;
+    return p;
+  };
+  G.opoint = takeI(NOBS);
+  G.pl_ptr = takeI(P + 1);
+  G.pl_obs = takeI(NOBS);
+  G.match = takeI((size_t)NOBS * P);
+  auto takeB = [&](size_t cnt) {
+    uint8_t* p = (uint8_t*)s;
+    s += ((cnt + 7) / 8) * 8;
+    return p;
+  };
+  G.lev_o = takeB(NOBS);
+  G.lev_g = takeB(L);
+  G.pfree = takeB(P + F);
+  G.pact = takeB(P);
+  G.lact = takeB(L);
+
+  // ---- setup --------------------------------------------------------------------------------------
+  for (int j = tid; j < P + F; j += T_BA) {
+    const SE3 T = se3_load(G.poses + (size_t)j * 7);
+    store_pose_Rt(T, G.Rt + (size_t)j * 12);
+    bool fr = j < P;
+    if (fr && G.prior[j] && !k.first_as_prior) fr = false;  // vSE3->setFixed(idx_ == 0) (:578-580)
+    G.pfree[j] = fr ? 1 : 0;
+    if (j < P) se3_store(se3_inverse(T), G.pinv + (size_t)j * 7);  // e->setMeasurement(kf->getTcw())
+  }
+  for (int l = tid; l < L; l += T_BA) {
+    G.lev_g[l] = 0;
+    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+      G.opoint[o] = l;
+      G.lev_o[o] = 0;
+      G.chi_o[o] = 0.0;
+    }
+  }
+  for (size_t i = tid; i < (size_t)nobs * P; i += T_BA) G.match[i] = -1;
+  __syncthreads();
+  for (int l = tid; l < L; l += T_BA)
+    for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1)
+      for (int o2 = G.optr[l]; o2 < G.optr[l + 1]; ++o2) {
+        const int j2 = G.opose[o2];
+        if (j2 < P) G.match[(size_t)o1 * P + j2] = o2;
+      }
+  // pose-major CSR: wave-per-pose ordered compaction (two sweeps: count, fill)
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < P; j += NW_BA) {
+      int cnt = 0;
+      for (int o0 = 0; o0 < nobs; o0 += 64) {
+        const int o = o0 + lane;
+        const bool hit = o < nobs && G.opose[o] == j;
+        cnt += __popcll(__ballot(hit));
+      }
+      if (lane == 0) G.pl_ptr[j + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      G.pl_ptr[0] = 0;
+      for (int j = 0; j < P; ++j) G.pl_ptr[j + 1] += G.pl_ptr[j];
+    }
+    __syncthreads();
+    for (int j = wave; j < P; j += NW_BA) {
+      int base = G.pl_ptr[j];
+      for (int o0 = 0; o0 < nobs; o0 += 64) {
+        const int o = o0 + lane;
+        const bool hit = o < nobs && G.opose[o] == j;
+        const unsigned long long m = __ballot(hit);
+        if (hit) G.pl_obs[base + __popcll(m & ((1ull << lane) - 1ull))] = o;
+        base += __popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- schedule (:770-828) ---------------------------------------------------------------------------
+  gen_optimize(k, gm, G, true, 5, red, &s_flag);
+  __syncthreads();
+  for (int l = tid; l < L; l += T_BA) {
+    GmmRef g;
+    load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+    if (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) G.lev_g[l] = 1;
+  }
+  __syncthreads();
+  gen_optimize(k, gm, G, true, 5, red, &s_flag);
+  __syncthreads();
+  for (int l = tid; l < L; l += T_BA)
+    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+      const double* Rt = G.Rt + (size_t)G.opose[o] * 12;
+      const double* p = G.pts + (size_t)l * 3;
+      const double z = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
+      const bool stereo = !(G.ouvr[(size_t)o * 3 + 2] < 0);
+      if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
+    }
+  __syncthreads();
+  const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag);
+  __syncthreads();
+  // ---- outputs (:837-879) ---------------------------------------------------------------------------
+  for (int l = tid; l < L; l += T_BA) {
+    GmmRef g;
+    load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+    const double* p = G.pts + (size_t)l * 3;
+    dropped_all[(size_t)f * L + l] = (g.has && g.deg && gmm_chi2(k, g, p) > k.str_thresh) ? 1 : 0;
+    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+      const double* Rt = G.Rt + (size_t)G.opose[o] * 12;
+      const double z = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
+      const bool stereo = !(G.ouvr[(size_t)o * 3 + 2] < 0);
+      erase_all[(size_t)f * NOBS + o] = (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) ? 1 : 0;
+    }
+  }
+  if (tid == 0 && iters_all) iters_all[f] = it3;
+}
+
+size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
+  const size_t n = 6 * (size_t)P;
+  size_t d = (size_t)(P + F) * 12 + (size_t)P * 12 + (size_t)P * 7 * 2 + (size_t)L * 3 + (size_t)NOBS * 12 +
+             (size_t)L * 12 + NOBS + n * n + 3 * n + P;
+  size_t i = (size_t)NOBS * 2 + (P + 1) + (size_t)NOBS * P + 16;
+  size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
+  return d * 8 + i * 4 + b + 256;
+}
+
+}  // namespace
+
+extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
+                                     int B, int P, int F, int L, int NOBS, double* poses_dev,
+                                     const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                                     const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev,
+                                     const double* obs_uvr_dev, const int32_t* obs_oct_dev,
+                                     uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && P >= 1 && F >= 0 && L >= 1 && NOBS >= 1, "bad problem shape");
+  GL_REQUIRE(poses_dev && prior_dev && points_dev && assoc_dev && obs_ptr_dev && obs_pose_dev && obs_uvr_dev &&
+                 obs_oct_dev && assoc_dropped_dev && obs_erase_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
+  void* scratch = nullptr;
+  int rc = gl::ctx_scratch(c, per * B, &scratch);
+  if (rc != GL_OK) return rc;
+  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->flags};
+  {
+    gl::TimerScope ts(c, GL_TIMER_BA);
+    k_ba_gen<<<B, T_BA, 0, c->stream>>>(make_bak(cam, prm, -1.0), gm, B, P, F, L, NOBS, poses_dev, prior_dev,
+                                        points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev, obs_uvr_dev, obs_oct_dev,
+                                        assoc_dropped_dev, obs_erase_dev, iters_dev, (char*)scratch, per);
+  }
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}

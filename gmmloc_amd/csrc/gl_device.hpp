@@ -432,6 +432,30 @@ GL_DEV bool ldlt_solve(const double* H, const double* b, double* x, bool require
 // ---------------------------------------------------------------------------
 GL_DEV double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
+// wave-only variant: 32 values per lane in, the wave total of value `wave_slot(lane)` out
+GL_DEV int wave_slot(int lane) {
+  return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+}
+GL_DEV double wave_reduce_scatter32(double* v) {
+  const int lane = threadIdx.x & 63;
+  int n = 32;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int h = n >> 1;
+    const bool hi = (lane >> s) & 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i < h) {
+        const double keep = hi ? v[i + h] : v[i];
+        const double send = hi ? v[i] : v[i + h];
+        v[i] = keep + shfl_xor_f64(send, 1 << s);
+      }
+    }
+    n = h;
+  }
+  return v[0] + shfl_xor_f64(v[0], 32);
+}
+
 template <int NV, int NWAVES>
 GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -59,7 +59,6 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
   __shared__ double s_rd[NW_VIEW];
   __shared__ int s_ri[NW_VIEW];
   __shared__ double s_cand[REC];
-  __shared__ int s_state[2];  // 0: nslots
   const int f = blockIdx.x;
   if (f >= B) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
