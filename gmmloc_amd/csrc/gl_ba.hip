@@ -18,6 +18,8 @@
 // Control flow = g2o OptimizationAlgorithmLevenberg::solve / SparseOptimizer::
 // optimize + the 5 / gate GMM / 5 / gate reprojection / 40 schedule
 // (localization_opt.cpp:770-828), incl. stale e->chi2() semantics.
+#include <cstdlib>
+
 #include "gl_ba_common.hpp"
 
 #pragma clang fp contract(fast)
@@ -441,13 +443,17 @@ __global__ __launch_bounds__(T_BA) void k_ba1(BaK k, GmmDev gm, int B, int L, do
 namespace gl {
 
 int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
+bool ba1_fast_supported(int L);
+int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
+                    double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
+                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch);
 
 // Single-free-pose jointOptimization for B frames; assoc in/out; scratch from ctx.
 int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                const uint8_t* has_prior, double* pts, const double* obs, const int32_t* oct, int32_t* assoc,
                const double* d2, double gate, uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
   BaK k = make_bak(cam, prm, gate);
-  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->flags};
+  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   char* s = (char*)scratch;
   double* pn = (double*)s;
   s += (size_t)B * L * 24;
@@ -491,6 +497,11 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   double* d2 = d2_dev ? d2_dev : (double*)((char*)scratch + ((work + 63) / 64) * 64);
   rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
   if (rc != GL_OK) return rc;
+  // on-chip fast path (gl_ba_fast.hip) for M <= 2048; GMMLOC_BA_SLOW=1 forces the general kernel
+  static const bool force_slow = getenv("GMMLOC_BA_SLOW") != nullptr;
+  if (!force_slow && gl::ba1_fast_supported(M))
+    return gl::launch_ba1_fast(c, g, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
+                               nullptr, nullptr, nullptr, scratch);
   return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, nullptr, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
                         nullptr, nullptr, nullptr, scratch);
 }

@@ -282,6 +282,7 @@ struct GmmDev {
   const double* rec12;
   const double* axis;
   const double* sqrt_info;
+  const double* hgw;
   const uint8_t* flags;
 };
 

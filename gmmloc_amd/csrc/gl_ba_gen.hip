@@ -794,7 +794,7 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   void* scratch = nullptr;
   int rc = gl::ctx_scratch(c, per * B, &scratch);
   if (rc != GL_OK) return rc;
-  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->flags};
+  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   {
     gl::TimerScope ts(c, GL_TIMER_BA);
     k_ba_gen<<<B, T_BA, 0, c->stream>>>(make_bak(cam, prm, -1.0), gm, B, P, F, L, NOBS, poses_dev, prior_dev,

@@ -432,27 +432,28 @@ GL_DEV bool ldlt_solve(const double* H, const double* b, double* x, bool require
 // ---------------------------------------------------------------------------
 GL_DEV double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
-// wave-only variant: 32 values per lane in, the wave total of value `wave_slot(lane)` out
+// one butterfly stage: keep H values, trade the other H with the xor-partner (all indices static,
+// so the value array stays in registers)
+template <int H>
+GL_DEV void rs_stage(double* v, bool hi, int mask) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const double keep = hi ? v[i + H] : v[i];
+    const double send = hi ? v[i] : v[i + H];
+    v[i] = keep + shfl_xor_f64(send, mask);
+  }
+}
+// wave-only reduce-scatter: 32 values per lane in, the wave total of value `wave_slot(lane)` out
 GL_DEV int wave_slot(int lane) {
   return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
 }
 GL_DEV double wave_reduce_scatter32(double* v) {
   const int lane = threadIdx.x & 63;
-  int n = 32;
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int h = n >> 1;
-    const bool hi = (lane >> s) & 1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < h) {
-        const double keep = hi ? v[i + h] : v[i];
-        const double send = hi ? v[i] : v[i + h];
-        v[i] = keep + shfl_xor_f64(send, 1 << s);
-      }
-    }
-    n = h;
-  }
+  rs_stage<16>(v, lane & 1, 1);
+  rs_stage<8>(v, lane & 2, 2);
+  rs_stage<4>(v, lane & 4, 4);
+  rs_stage<2>(v, lane & 8, 8);
+  rs_stage<1>(v, lane & 16, 16);
   return v[0] + shfl_xor_f64(v[0], 32);
 }
 
@@ -461,26 +462,9 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = NV; i < 32; ++i) v[i] = 0.0;
-  int n = 32;
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int h = n >> 1;
-    const bool hi = (lane >> s) & 1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i < h) {
-        const double keep = hi ? v[i + h] : v[i];
-        const double send = hi ? v[i] : v[i + h];
-        v[i] = keep + shfl_xor_f64(send, 1 << s);
-      }
-    }
-    n = h;
-  }
-  v[0] += shfl_xor_f64(v[0], 32);
-  // slot held by this lane: bit-reversed low 5 lane bits
-  const int slot = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+  const double r = wave_reduce_scatter32(v);
   __syncthreads();
-  if (lane < 32) lds[wave * 32 + slot] = v[0];
+  if (lane < 32) lds[wave * 32 + wave_slot(lane)] = r;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NV; ++i) {

@@ -50,6 +50,7 @@ struct Gmm {
   double* scale = nullptr;
   double* axis = nullptr;
   double* sqrt_info = nullptr;
+  double* hgw = nullptr;  // K x 6 sym: sqrt_info * sqrt_info^T (EdgePt2Gaussian J^T J, world frame)
   uint8_t* flags = nullptr;
   int32_t* nbs_ptr = nullptr;
   int32_t* nbs_idx = nullptr;
