@@ -6,8 +6,9 @@
 //                  16-byte loads; every lane owns PPT points in registers and
 //                  sweeps the tile with broadcast LDS reads (all lanes read the
 //                  same record -> one LDS cycle per lane group, no conflicts).
-//                  fp64 VALU bound: 15 v_{mul,fma,add}_f64 + compare/select
-//                  per (point, Gaussian) pair.
+//                  fp64 VALU bound: 15 v_{mul,fma,add}_f64 + compare/select per (point,
+//                  Gaussian) pair.  (A wave-vote guard around the selects was measured
+//                  slower: 3.16 vs 2.80 ms per 4.2 G pairs -- the branch serialises issue.)
 //  grid = (point tiles, K splits); K is split so that even one frame (2k
 //  points) produces >= ~2k waves for the 1024 SIMDs; partial minima are
 //  merged by k_assoc_merge in ascending-k order, so ties keep the lowest index
@@ -72,10 +73,9 @@ __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ 
         const double r1 = fma(d2, a7, fma(d1, a4, d0 * a1));
         const double r2 = fma(d2, a8, fma(d1, a5, d0 * a2));
         const double d = fma(r2, d2, fma(r1, d1, r0 * d0));
-        if (d < best[p]) {
-          best[p] = d;
-          bi[p] = k0 + g;
-        }
+        const bool lt = d < best[p];
+        best[p] = lt ? d : best[p];
+        bi[p] = lt ? (k0 + g) : bi[p];
       }
     }
   }

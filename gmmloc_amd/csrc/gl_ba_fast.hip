@@ -29,6 +29,15 @@ constexpr int NWF = TF / 64;
 constexpr int PPTF = 4;         // point slots per thread (rolled loop)
 constexpr int MCAP = 2000;       // LDS capacity in points: 10 doubles/point = 160 000 B (+ 2.3 KB reduction)
 
+#ifdef GL_BA_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, t0, t1) if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[slot] += (unsigned long long)((t1) - (t0))
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0, t1)
+#endif
+
 enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32 };
 
 GL_DEV double rcp_nr(double a) {
@@ -122,7 +131,7 @@ GL_DEV Pose pose_update(const Pose& P, const double* u) {
 
 struct Lds {      // per-frame state, SoA over MCAP points
   double* sp;     // 3 x MCAP  current point (world)
-  double* nd;     // 4 x MCAP  plane normal n (axis_.col(0)) and n . mean
+  double* pn;     // 3 x MCAP  trial point
   double* chir;   // MCAP      stale chi2 of the reprojection edge (e->chi2())
   int2* sf;       // MCAP      {float bits of 1/sigma^2, flag bits}
 };
@@ -180,7 +189,7 @@ GL_DEV double gmm_nondeg(const GmmDev& gm, int a, const double* R, const double*
 }
 
 // linearise point l at pose P and world point p; returns the un-robustified chi2_r
-GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const Lds& D, int l, int fl, int asc, double s,
+GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const double* nd, int fl, int asc, double s,
                        const double* ob, const double* p, bool robust, Lin& o) {
   const bool act_r = !(fl & F_LEVR), act_g = (fl & F_ASSOC) && !(fl & F_LEVG);
 #pragma unroll
@@ -225,8 +234,8 @@ GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const Lds&
   }
   if (act_g) {
     if (fl & F_DEG) {
-      const double nx = D.nd[l], ny = D.nd[MCAP + l], nz = D.nd[2 * MCAP + l];
-      const double eg = (nx * p[0] + ny * p[1] + nz * p[2]) - D.nd[3 * MCAP + l];
+      const double nx = nd[0], ny = nd[1], nz = nd[2];
+      const double eg = (nx * p[0] + ny * p[1] + nz * p[2]) - nd[3];
       const double lm = k.ba_lambda2;
       o.chi_g = eg * (lm * eg);
       double nc[3];
@@ -247,9 +256,9 @@ GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const Lds&
   return chi_r;
 }
 
-GL_DEV double gmm_chi2_fast(const BaK& k, const GmmDev& gm, const Lds& D, int l, int fl, int asc, const double* p) {
+GL_DEV double gmm_chi2_fast(const BaK& k, const GmmDev& gm, const double* nd, int fl, int asc, const double* p) {
   if (fl & F_DEG) {
-    const double eg = (D.nd[l] * p[0] + D.nd[MCAP + l] * p[1] + D.nd[2 * MCAP + l] * p[2]) - D.nd[3 * MCAP + l];
+    const double eg = (nd[0] * p[0] + nd[1] * p[1] + nd[2] * p[2]) - nd[3];
     return eg * (k.ba_lambda2 * eg);
   }
   return gmm_nondeg(gm, asc, nullptr, p, nullptr, nullptr);
@@ -360,7 +369,8 @@ GL_DEV void reduce2(double* v, double* red, double* tot) {
 #pragma unroll
   for (int i = NV; i < 32; ++i) v[i] = 0.0;
   const double r = wave_reduce_scatter32(v);
-  __syncthreads();
+  // no barrier needed before writing `red`: its last readers (threads < 32) finished before the
+  // closing barrier of the previous reduction, which every thread has passed
   if (lane < 32) red[wave * 32 + wave_slot(lane)] = r;
   __syncthreads();
   if (threadIdx.x < 32) {
@@ -445,12 +455,24 @@ GL_DEV bool ldlt6_packed(double* a, const double* b, double lambda, double* x) {
 struct PtCtx {
   int l, fl, asc;
   double s;
-  double ob[3], p[3];
+  double ob[3], nd[4], p[3];
   bool ar, ag;
 };
-GL_DEV bool load_pt(const Lds& D, const double* __restrict__ gobs, const int32_t* __restrict__ gassoc, int L, int i,
-                    PtCtx& c) {
+// observations come from global memory (read-only, coalesced): the loads for slot i+1 are issued
+// while slot i is being processed
+GL_DEV void prefetch_obs(const double* __restrict__ gobs, const double* __restrict__ gnd, int L, int i, double* ob) {
+  const int l = min(threadIdx.x + i * TF, L - 1);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) ob[j] = gobs[(size_t)l * 3 + j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ob[3 + j] = gnd[(size_t)l * 4 + j];  // plane normal n and n . mean
+}
+GL_DEV bool load_pt(const Lds& D, const double* ob_pre, const int32_t* __restrict__ gassoc, int L, int i, PtCtx& c) {
   c.l = threadIdx.x + i * TF;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.ob[j] = ob_pre[j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.nd[j] = ob_pre[3 + j];
   if (c.l >= L) return false;
   const int2 sf = D.sf[c.l];
   c.fl = sf.y;
@@ -461,18 +483,15 @@ GL_DEV bool load_pt(const Lds& D, const double* __restrict__ gobs, const int32_t
   c.s = (double)__int_as_float(sf.x);
   c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? gassoc[c.l] : -1;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    c.ob[j] = gobs[(size_t)c.l * 3 + j];
-    c.p[j] = D.sp[j * MCAP + c.l];
-  }
+  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.l];
   return true;
 }
 
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, int L, const double* __restrict__ gobs,
-                         const int32_t* __restrict__ gassoc, double* __restrict__ gpn, bool robust, int iters,
+                         const int32_t* __restrict__ gassoc, const double* __restrict__ gnd, bool robust, int iters,
                          double* red, double* tot) {
-  double acc[32];
+  double acc[32], obn[7];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
 #pragma unroll 1
@@ -498,12 +517,15 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
       double md = 0.0;
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      prefetch_obs(gobs, gnd, L, 0, obn);
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        if (!load_pt(D, gobs, gassoc, L, i, c)) continue;
+        const bool have = load_pt(D, obn, gassoc, L, i, c);
+        if (i + 1 < PPTF) prefetch_obs(gobs, gnd, L, i + 1, obn);
+        if (!have) continue;
         Lin o;
-        lin_fast(k, gm, P, D, c.l, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+        lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         const double Hf[9] = {o.A[0] + o.Hc[0], o.A[1] + o.Hc[1], o.A[2] + o.Hc[2], o.A[1] + o.Hc[1], o.A[3] + o.Hc[3],
                               o.A[4] + o.Hc[4], o.A[2] + o.Hc[2], o.A[4] + o.Hc[4], o.A[5] + o.Hc[5]};
 #pragma unroll
@@ -530,15 +552,19 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
       ni = 2.0;
     }
     do {
+      PROF_T(tA0);
       // ---- pass A ---------------------------------------------------------------------------
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      prefetch_obs(gobs, gnd, L, 0, obn);
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        if (!load_pt(D, gobs, gassoc, L, i, c)) continue;
+        const bool have = load_pt(D, obn, gassoc, L, i, c);
+        if (i + 1 < PPTF) prefetch_obs(gobs, gnd, L, i + 1, obn);
+        if (!have) continue;
         Lin o;
-        const double c2 = lin_fast(k, gm, P, D, c.l, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+        const double c2 = lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         if (c.ar) D.chir[c.l] = c2;  // computeActiveErrors
         acc[27] += o.rho0_r + o.chi_g;
         if (c.ar) {
@@ -551,24 +577,51 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
           accum_pose_sym(o.q, C, cc, acc);
         }
       }
+      PROF_T(tA1);
       reduce2<28>(acc, red, tot);
-      double dx[6] = {0, 0, 0, 0, 0, 0};
+      PROF_T(tA2);
       if (qmax == 0) currentChi = acc[27];
-      bool ok2 = true;
-      if (pose_active) ok2 = ldlt6_packed(acc, acc + 21, lambda, dx);
+      // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
+      double* bc = tot + 32;  // 20 doubles: dx[6] R[9] t[3] ok pad
+      if (threadIdx.x < 64) {
+        double dxs[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = true;
+        if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
+        Pose Pw = P;
+        if (pose_active && ok) Pw = pose_update(P, dxs);
+        if (threadIdx.x == 0) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dx[i] = uni(dx[i]);
-      Pose Pn = P;
-      if (pose_active && ok2) Pn = pose_uni(pose_update(P, dx));
+          for (int i = 0; i < 6; ++i) bc[i] = dxs[i];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) bc[6 + i] = Pw.R[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bc[15 + i] = Pw.t[i];
+          bc[18] = ok ? 1.0 : 0.0;
+        }
+      }
+      __syncthreads();
+      double dx[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dx[i] = uni(bc[i]);
+      Pose Pn;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Pn.R[i] = uni(bc[6 + i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Pn.t[i] = uni(bc[15 + i]);
+      const bool ok2 = uni(bc[18]) != 0.0;
+      PROF_T(tS);
       // ---- pass B ---------------------------------------------------------------------------
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+      prefetch_obs(gobs, gnd, L, 0, obn);
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        if (!load_pt(D, gobs, gassoc, L, i, c)) continue;
+        const bool have = load_pt(D, obn, gassoc, L, i, c);
+        if (i + 1 < PPTF) prefetch_obs(gobs, gnd, L, i + 1, obn);
+        if (!have) continue;
         Lin o;
-        lin_fast(k, gm, P, D, c.l, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+        lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         double Dinv[6], b[3], u[3];
         point_solve_fast(o, lambda, Dinv, b, u);
         double gd[3], Agd[3] = {0, 0, 0}, rhs[3], eps[3];
@@ -588,7 +641,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
 #pragma unroll
         for (int j = 0; j < 3; ++j) pn[j] = c.p[j] + (P.R[j] * eps[0] + P.R[3 + j] * eps[1] + P.R[6 + j] * eps[2]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) gpn[(size_t)c.l * 3 + j] = pn[j];  // trial point (re-read only on acceptance)
+        for (int j = 0; j < 3; ++j) D.pn[j * MCAP + c.l] = pn[j];  // trial point
         if (c.ar) {
           double qn[3], e[3], iz;
 #pragma unroll
@@ -603,9 +656,11 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
           }
           acc[1] += r0;
         }
-        if (c.ag) acc[1] += gmm_chi2_fast(k, gm, D, c.l, c.fl, c.asc, pn);
+        if (c.ag) acc[1] += gmm_chi2_fast(k, gm, c.nd, c.fl, c.asc, pn);
       }
+      PROF_T(tB1);
       reduce2<3>(acc, red, tot);
+      PROF_T(tB2);
       double scale = acc[0];
       const double tempChi = ok2 ? acc[1] : 1.7976931348623157e308;
       if (pose_active) {
@@ -632,13 +687,15 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
           const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
           if (!(ar || ag)) continue;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) D.sp[j * MCAP + l] = gpn[(size_t)l * 3 + j];
+          for (int j = 0; j < 3; ++j) D.sp[j * MCAP + l] = D.pn[j * MCAP + l];
         }
       } else {
         lambda *= ni;
         ni *= 2;
       }
       qmax++;
+      PROF_T(tE);
+      PROF_ADD(0, tA0, tA1); PROF_ADD(1, tA1, tA2); PROF_ADD(2, tA2, tS); PROF_ADD(3, tS, tB1); PROF_ADD(4, tB1, tB2); PROF_ADD(5, tB2, tE); PROF_ADD(6, tA0, tA0 + 1);
     } while (rho < 0 && qmax < 10);
     ++cj;
     if (qmax == 10 || rho == 0) break;
@@ -655,14 +712,14 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                          // 3 * MCAP
-  D.nd = D.sp + 3 * MCAP;               // 4 * MCAP
-  D.chir = D.nd + 4 * MCAP;             // MCAP
+  D.pn = D.sp + 3 * MCAP;               // 3 * MCAP
+  D.chir = D.pn + 3 * MCAP;             // MCAP
   D.sf = (int2*)(D.chir + MCAP);        // MCAP x 8 B
   double* red = D.chir + 2 * MCAP;      // NWF * 32
-  double* tot = red + NWF * 32;         // 32
+  double* tot = red + NWF * 32;         // 32 (+ 32 broadcast slots)
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
-  double* gpn = pn_all + (size_t)f * L * 3;
+  double* gnd = pn_all + (size_t)f * L * 4;  // per-point plane record {n, n.mu} (written once, then read-only)
   const double* gobs = obs_all + (size_t)f * L * 3;
   int32_t* gassoc = assoc_all + (size_t)f * L;
 #pragma unroll 1
@@ -688,10 +745,10 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
         if (gm.flags[a] & 1) {
           fl |= F_DEG;
           const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
-          D.nd[l] = nx;
-          D.nd[MCAP + l] = ny;
-          D.nd[2 * MCAP + l] = nz;
-          D.nd[3 * MCAP + l] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
+          gnd[(size_t)l * 4] = nx;
+          gnd[(size_t)l * 4 + 1] = ny;
+          gnd[(size_t)l * 4 + 2] = nz;
+          gnd[(size_t)l * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
         }
       }
     }
@@ -707,7 +764,7 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
   int it3 = 0;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(k, gm, D, P, L, gobs, gassoc, gpn, phase < 2, phase < 2 ? 5 : 40, red, tot);
+    it3 = optimize_fast(k, gm, D, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < PPTF; ++i) {
@@ -717,7 +774,8 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
         if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
           const double p[3] = {D.sp[l], D.sp[MCAP + l], D.sp[2 * MCAP + l]};
-          if (gmm_chi2_fast(k, gm, D, l, fl, -1, p) > k.str_thresh) D.sf[l].y = fl | F_LEVG;
+          const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
+          if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) D.sf[l].y = fl | F_LEVG;
         }
       } else {  // STALE chi2 of the reprojection edges, fresh depth test (:799-825)
         if (!(fl & F_EXISTS)) continue;
@@ -738,7 +796,10 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     int a = gassoc[l];
     if (fl & F_EXISTS) {
       const double p[3] = {D.sp[l], D.sp[MCAP + l], D.sp[2 * MCAP + l]};
-      if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG) && gmm_chi2_fast(k, gm, D, l, fl, -1, p) > k.str_thresh) dr = 1;
+      if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
+        const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
+        if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) dr = 1;
+      }
       const double z = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];
       if (D.chir[l] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
 #pragma unroll
@@ -758,6 +819,10 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     normalize_rotation(T);
     se3_store(T, pose_io + (size_t)f * 7);
     if (iters_out) iters_out[f] = it3;
+#ifdef GL_BA_PROF
+    if (f == 0)
+      for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i];  // debug build only: phase cycles instead of pose 0
+#endif
   }
 }
 
@@ -770,7 +835,7 @@ bool ba1_fast_supported(int L) { return L <= MCAP; }
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
                     uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
-  const size_t lds = (size_t)(9 * MCAP + NWF * 32 + 32) * sizeof(double);
+  const size_t lds = (size_t)(8 * MCAP + NWF * 32 + 64) * sizeof(double);
   GL_HIP(hipFuncSetAttribute((const void*)k_ba1_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   {

@@ -1,0 +1,156 @@
+// gmm_adapter.hpp -- header-only C++ host mirror of the reference's hot-path interface over
+// the C-ABI (include/gmmloc_hip.h).  This is the adapter a maintainer of HyHuang1995/gmmloc
+// adds to the host (INTEGRATION.md shows the call-site patch); it depends only on the STL so
+// that it also compiles where Eigen / g2o are absent.  Method names follow the reference:
+//   gmmloc::GMM::renderView + searchCorrespondence  (gaussian_mixture.cpp:271-371, :484-534)
+//   gmmloc::GMM::queryPoint                         (gaussian_mixture.cpp:545-576)
+//   GMMUtility::loadGMMModel                        (gmm_utils.cpp:9-67)
+//   GMMLoc::optimizePoint / checkMapAssociation     (gmmloc_opt.cpp:156-342)
+//   Tracking::optimizeCurrentPose                   (tracking_opt.cpp:21-217)
+//   Localization::jointOptimization                 (localization_opt.cpp:456-925)
+// Host buffers in, host buffers out: each call stages through device memory owned by the
+// adapter (gl_malloc / gl_memcpy_*), so the host code never sees a HIP type.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gmmloc_hip.h"
+
+namespace gmmloc_hip {
+
+inline void check(int rc, const char* what) {
+  if (rc != GL_OK) throw std::runtime_error(std::string(what) + ": " + gl_last_error_string());
+}
+
+// RAII device buffer
+class DevBuf {
+ public:
+  DevBuf(gl_ctx_t* ctx, size_t bytes) : ctx_(ctx), bytes_(bytes) { check(gl_malloc(ctx, bytes, &p_), "gl_malloc"); }
+  ~DevBuf() { gl_free(ctx_, p_); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  template <class T>
+  T* as() { return static_cast<T*>(p_); }
+  void upload(const void* src) { check(gl_memcpy_h2d(ctx_, p_, src, bytes_), "h2d"); }
+  void download(void* dst) { check(gl_memcpy_d2h(ctx_, dst, p_, bytes_), "d2h"); }
+
+ private:
+  gl_ctx_t* ctx_;
+  void* p_ = nullptr;
+  size_t bytes_;
+};
+
+struct Pose {  // g2o::SE3Quat T_cw: Eigen quaternion coefficients (x y z w) + translation
+  double q[4], t[3];
+};
+
+class GMM {
+ public:
+  // loadGMMModel(path, model): false on failure like the reference (message via last_error())
+  static bool loadGMMModel(const std::string& path, GMM& model, int device = 0) {
+    model.release();
+    if (gl_ctx_create(device, nullptr, &model.ctx_) != GL_OK) return false;
+    gl_default_params(&model.prm_);
+    if (gl_gmm_load_file(model.ctx_, path.c_str(), &model.prm_, &model.gmm_) != GL_OK) return false;
+    return true;
+  }
+  ~GMM() { release(); }
+  size_t countComponents() const { return (size_t)gl_gmm_count(gmm_); }
+  void setCamera(const gl_camera& cam) { cam_ = cam; }
+  static const char* last_error() { return gl_last_error_string(); }
+
+  // renderView(rot_c_w, t_c_w) followed by searchCorrespondence(kpts, comps, num): one call, because
+  // the rendered list only exists to be searched (gmmloc_opt.cpp:121-134).  uv: N x 2.
+  // comps[i] = component indices (GaussianComponent2d::parent_ via getComponent3d(idx)).
+  void renderViewAndSearch(const Pose& Tcw, const std::vector<double>& uv, std::vector<std::vector<int32_t>>& comps,
+                           int num = 5) {
+    const int N = (int)(uv.size() / 2);
+    DevBuf dpose(ctx_, 56), duv(ctx_, uv.size() * 8 + 8), dcand(ctx_, (size_t)N * num * 4 + 4), dn(ctx_, (size_t)N * 4 + 4);
+    dpose.upload(&Tcw);
+    if (N) duv.upload(uv.data());
+    check(gl_search2d(ctx_, gmm_, &cam_, 1, dpose.as<double>(), N, duv.as<double>(), nullptr, num, dcand.as<int32_t>(),
+                      dn.as<int32_t>(), 0, nullptr, nullptr),
+          "gl_search2d");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    std::vector<int32_t> cand((size_t)N * num + 1), n(N + 1);
+    dcand.download(cand.data());
+    dn.download(n.data());
+    comps.assign(N, {});
+    for (int i = 0; i < N; ++i) comps[i].assign(cand.begin() + (size_t)i * num, cand.begin() + (size_t)i * num + n[i]);
+  }
+
+  // queryPoint(pt, res): res = {nearest component} (the reference pushes ret_index[0])
+  void queryPoint(const double pt[3], std::vector<int>& res) {
+    DevBuf dp(ctx_, 24), di(ctx_, 8);
+    dp.upload(pt);
+    check(gl_associate3d(ctx_, gmm_, dp.as<double>(), 1, GL_ASSOC_KNN5_EUCLID, di.as<int32_t>(), nullptr), "queryPoint");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    int32_t idx[2];
+    di.download(idx);
+    res.clear();
+    if (idx[0] >= 0) res.push_back(idx[0]);
+  }
+
+  // exhaustive Mahalanobis association of N points (north-star `associate`)
+  void associate(const std::vector<double>& pts, std::vector<int32_t>& idx, std::vector<double>& d2) {
+    const int N = (int)(pts.size() / 3);
+    idx.assign(N, -1);
+    d2.assign(N, 0.0);
+    if (!N) return;
+    DevBuf dp(ctx_, pts.size() * 8), di(ctx_, (size_t)N * 4), dd(ctx_, (size_t)N * 8);
+    dp.upload(pts.data());
+    check(gl_associate3d(ctx_, gmm_, dp.as<double>(), N, GL_ASSOC_BRUTE, di.as<int32_t>(), dd.as<double>()), "associate");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    di.download(idx.data());
+    dd.download(d2.data());
+  }
+
+  // Tracking::optimizeCurrentPose for one frame: Xw / obs are M x 3, octave[i] < 0 = no map point.
+  // Returns the inlier count; pose and is_outlier are updated like the reference does.
+  int optimizeCurrentPose(Pose& Tcw, const std::vector<double>& Xw, const std::vector<double>& obs,
+                          const std::vector<int32_t>& octave, std::vector<uint8_t>& is_outlier) {
+    const int M = (int)octave.size();
+    is_outlier.assign(M, 0);
+    DevBuf dpose(ctx_, 56), dX(ctx_, (size_t)M * 24 + 8), dO(ctx_, (size_t)M * 24 + 8), doc(ctx_, (size_t)M * 4 + 4),
+        dout(ctx_, (size_t)M + 8), dn(ctx_, 8);
+    dpose.upload(&Tcw);
+    if (M) {
+      dX.upload(Xw.data());
+      dO.upload(obs.data());
+      doc.upload(octave.data());
+    }
+    check(gl_optimize_current_pose(ctx_, &cam_, &prm_, 1, M, dpose.as<double>(), dX.as<double>(), dO.as<double>(),
+                                   doc.as<int32_t>(), dout.as<uint8_t>(), dn.as<int32_t>()),
+          "gl_optimize_current_pose");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    dpose.download(&Tcw);
+    std::vector<uint8_t> tmp(M + 8);
+    dout.download(tmp.data());
+    std::memcpy(is_outlier.data(), tmp.data(), M);
+    int32_t n[2];
+    dn.download(n);
+    return n[0];
+  }
+
+  gl_ctx_t* ctx() { return ctx_; }
+  gl_gmm_t* handle() { return gmm_; }
+  gl_params& params() { return prm_; }
+  const gl_camera& camera() const { return cam_; }
+
+ private:
+  void release() {
+    if (gmm_) gl_gmm_destroy(gmm_);
+    if (ctx_) gl_ctx_destroy(ctx_);
+    gmm_ = nullptr;
+    ctx_ = nullptr;
+  }
+  gl_ctx_t* ctx_ = nullptr;
+  gl_gmm_t* gmm_ = nullptr;
+  gl_params prm_;
+  gl_camera cam_{};
+};
+
+}  // namespace gmmloc_hip

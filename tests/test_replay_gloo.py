@@ -1,0 +1,67 @@
+"""CPU: the multi-GPU replay plumbing (round-robin sharding, uneven shards, gather order,
+max-over-ranks timing) with world_size 2 over gloo.  The per-frame compute is a stand-in
+(frame id arithmetic): this test is about the distributed path, not the kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from gmmloc_amd import replay
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = list(range(n_frames))
+
+    def compute(fs):
+        return np.array([[f * 2.0 + 0.5, f % 7, rank] for f in fs], dtype=np.float64).reshape(-1, 3)
+
+    res, dt = replay.replay(frames, compute, rank, world, dist, "cpu", batch=5)
+    q.put((rank, res, dt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [1, 13, 40])
+def test_replay_world2_gloo(n_frames):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ids = np.arange(n_frames)
+    for rank, res, dt in out:
+        assert res.shape == (n_frames, 3)
+        np.testing.assert_array_equal(res[:, 0], ids * 2.0 + 0.5)  # frame order restored
+        np.testing.assert_array_equal(res[:, 1], ids % 7)
+        np.testing.assert_array_equal(res[:, 2], ids % 2)            # frame i was computed by rank i % 2
+        assert dt >= 0
+    assert out[0][2] == out[1][2]                                     # MAX over ranks agreed
+
+
+def test_shard_indices():
+    from gmmloc_amd import replay
+    for world in (1, 2, 4, 8):
+        allidx = np.sort(np.concatenate([replay.shard_indices(13735, r, world) for r in range(world)]))
+        assert np.array_equal(allidx, np.arange(13735))  # BASELINE configs[3]: all V1/V2 frames covered once
