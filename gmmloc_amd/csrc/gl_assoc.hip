@@ -20,6 +20,8 @@
 //
 // Compiled with -ffp-contract=off; the only fused ops are the explicit fma()
 // of the canonical chi2 (gl_device.hpp) -> bit-identical to the fp64 CPU order.
+#include <cstdlib>
+
 #include "gl_device.hpp"
 #include "gl_internal.hpp"
 
@@ -27,7 +29,10 @@ using namespace gld;
 
 namespace {
 
-constexpr int kTileG = 128;  // Gaussians per LDS tile (12 KiB)
+#ifndef GL_TILE_G
+#define GL_TILE_G 128
+#endif
+constexpr int kTileG = GL_TILE_G;  // Gaussians per LDS tile (12 KiB)
 
 template <int PPT>
 __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ rec12, int K, int kchunk,
@@ -173,21 +178,41 @@ __global__ void k_nearest_chi2(const int32_t* __restrict__ knn_idx, int knn, con
 
 namespace gl {
 
-// shared with gl_track.hip: brute association of N points; outputs on device
-int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2) {
-  const int K = g->K;
-  // points per thread: more points amortise the broadcast LDS reads; fewer keep the grid wide
+// Launch shape (tools/tune_assoc.py sweep on MI355X, profiles/r1_assoc_tuning.txt):
+//  * points per thread: 4 amortises the broadcast LDS reads best once there are enough points;
+//  * K splits: aim for ~4096 workgroups so the tail is short; a single 2 000-point frame still
+//    gets 8 x 64 workgroups.
+static void assoc_shape(int K, int N, int* ppt_o, int* ptiles_o, int* nsplit_o, int* kchunk_o) {
   int ppt = 1;
-  if (N >= 32768) ppt = 2;
-  if (N >= 262144) ppt = 4;
+  if (N >= 8192) ppt = 2;
+  if (N >= 16384) ppt = 4;
+  if (const char* e = getenv("GMMLOC_ASSOC_PPT")) ppt = atoi(e);  // tuning knob (1, 2 or 4)
   const int ptiles = (N + 256 * ppt - 1) / (256 * ppt);
-  // K split: aim for >= 2048 workgroups-worth of waves (256 CUs x 4 SIMDs x 2)
-  int nsplit = (2048 + ptiles * 4 - 1) / (ptiles * 4);
+  const int target_blocks = (N >= 8192) ? 4096 : 512;
+  int nsplit = (target_blocks + ptiles - 1) / ptiles;
   const int max_split = (K + kTileG - 1) / kTileG * 2;  // >= 64 Gaussians per split
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
+  if (const char* e = getenv("GMMLOC_ASSOC_NSPLIT")) nsplit = atoi(e);  // tuning knob
   int kchunk = (K + nsplit - 1) / nsplit;
   nsplit = (K + kchunk - 1) / kchunk;
+  *ppt_o = ppt;
+  *ptiles_o = ptiles;
+  *nsplit_o = nsplit;
+  *kchunk_o = kchunk;
+}
+
+size_t assoc_scratch_bytes(int K, int N) {
+  int ppt, ptiles, nsplit, kchunk;
+  assoc_shape(K, N, &ppt, &ptiles, &nsplit, &kchunk);
+  return (size_t)nsplit * N * 12 + 64;
+}
+
+// shared with gl_ba.hip: brute association of N points; outputs on device
+int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2) {
+  const int K = g->K;
+  int ppt, ptiles, nsplit, kchunk;
+  assoc_shape(K, N, &ppt, &ptiles, &nsplit, &kchunk);
   void* scratch = nullptr;
   double* part_d2;
   int32_t* part_idx;

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(T_BA) void k_ba1(BaK k, GmmDev gm, int B, int L, do
 namespace gl {
 
 int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
+size_t assoc_scratch_bytes(int K, int N);
 bool ba1_fast_supported(int L);
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
@@ -489,8 +490,7 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   // Layout: | assoc partials (used first, dead afterwards) ... reused by ba1 | d2 |
   void* scratch = nullptr;
   const size_t ba_bytes = gl::ba1_scratch_bytes(B, M);
-  // generous upper bound for the association partials: nsplit <= 2*ceil(K/128)+1
-  const size_t assoc_bytes = (size_t)(2 * ((g->K + 127) / 128) + 1) * n * 12 + 64;
+  const size_t assoc_bytes = gl::assoc_scratch_bytes(g->K, (int)n);
   const size_t work = ba_bytes > assoc_bytes ? ba_bytes : assoc_bytes;
   int rc = gl::ctx_scratch(c, work + n * 8 + 64, &scratch);
   if (rc != GL_OK) return rc;

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Measure the BASELINE.json configs that are not the bench.py headline.
+Prints one JSON line per config; run on the GPU box:
+
+    python tools/run_configs.py [--configs 2,3,4,5] [--frames-cap N]
+
+ config 2  synthetic 2 000 points x 4 096 Gaussians, association only: batched pairs/s,
+           single-frame latency, CPU same-math brute force and CPU reference algorithm
+           (the reference's own nanoflann 5-NN + Mahalanobis, i.e. GMM::queryPoint's search)
+ config 3  V1_03-shaped replay (2 149 frames synthesised from the real v1 map + GT poses,
+           M ~ U{150..1200}): search2d + optimizeCurrentPose + associate/structure-BA
+ config 4  all six sequences (13 735 frames) through gl_track_frames on this rank's shard
+ config 5  stress: 50 000 points x 65 536 Gaussians association, fp64 VALU roofline
+No EuRoC imagery exists here: frame problems are synthetic-from-real-map and labelled so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK = 78.6
+
+
+def ev_time(torch, fn, reps, stream):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        fn()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def config2(torch, ctx, out):
+    import gmmloc_amd
+    from gmmloc_amd import synth
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+    res = {"config": "2: synthetic 2000 pts x 4096 Gaussians, association only"}
+    for seed in (1, 2, 3):
+        mean, cov = synth.synth_gmm(4096, seed)
+        g = gmmloc_amd.GMM(ctx, mean, cov)
+        pts1 = torch.from_numpy(synth.synth_points(mean, cov, 2000, seed)).cuda()
+        ptsB = torch.from_numpy(synth.synth_points(mean, cov, 2000 * 512, seed + 50)).cuda()
+        t1 = ev_time(torch, lambda: g.associate3d(pts1), 200, ctx.stream)
+        tB = ev_time(torch, lambda: g.associate3d(ptsB), 10, ctx.stream)
+        res["seed%d" % seed] = {"single_frame_latency_us": 1e6 * t1, "batched_pairs_per_s": 2000 * 512 * 4096 / tB,
+                                "batched_tflops_algorithmic": 21 * 2000 * 512 * 4096 / tB / 1e12,
+                                "single_frame_tflops_algorithmic": 21 * 2000 * 4096 / t1 / 1e12}
+        if seed == 1:
+            h = orc.gmm_create(mean, cov)
+            p = pts1.cpu().numpy()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                orc.associate3d(h, p)
+            tb = (time.perf_counter() - t0) / 20
+            res["cpu_same_math_brute_1thread"] = {"ms_per_frame": 1e3 * tb, "pairs_per_s": 2000 * 4096 / tb}
+            if orc.nf is not None:
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    ki, kd, kc = orc.nanoflann_knn(mean, p, 5)
+                    orc.chi2(h, ki[:, 0].copy(), p)
+                tk = (time.perf_counter() - t0) / 20
+                res["cpu_reference_algorithm_nanoflann_1thread"] = {"ms_per_frame": 1e3 * tk,
+                                                                    "note": "kd-tree build + 5-NN + chi2 (queryPoint)"}
+            orc.gmm_destroy(h)
+    out(res)
+
+
+def v1_frames(seq, n_cap, Mlo, Mhi, seed0, sig_scale=1.0):
+    from gmmloc_amd import synth, api
+    cam = api.Camera()
+    d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz"))
+    mean, cov = d["mean"], d["cov"]
+    gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))[seq]
+    rng = np.random.default_rng(seed0)
+    n = min(n_cap, gt.shape[0])
+    frames = []
+    for i in range(n):
+        M = int(rng.integers(Mlo, Mhi + 1))
+        f = synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(gt[i]), cam, M, 20200901 + i)
+        frames.append(f)
+    return mean, cov, cam, frames
+
+
+def pad_batch(torch, frames, Mmax):
+    B = len(frames)
+    pose = np.stack([f["pose_init"] for f in frames])
+    Xw = np.zeros((B, Mmax, 3))
+    obs = np.zeros((B, Mmax, 3))
+    octv = -np.ones((B, Mmax), np.int32)
+    for b, f in enumerate(frames):
+        m = f["Xw"].shape[0]
+        Xw[b, :m], obs[b, :m], octv[b, :m] = f["Xw"], f["obs"], f["octave"]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return T(pose), T(Xw), T(obs), T(octv)
+
+
+def config3(torch, ctx, out, cap):
+    import gmmloc_amd
+    from gmmloc_amd import api
+    mean, cov, cam, frames = v1_frames("V1_03_difficult", cap, 150, 1200, 3)
+    prm = api.Params()
+    g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+    pose, Xw, obs, octv = pad_batch(torch, frames, 1200)
+    uv = obs[:, :, :2].contiguous()
+    nfeat = (octv >= 0).sum(1).to(torch.int32)
+    B = len(frames)
+    t_s2d = ev_time(torch, lambda: g.search2d(cam, pose, uv, nfeat, 5), 2, ctx.stream)
+    t_pose = ev_time(torch, lambda: gmmloc_amd.optimize_current_pose(ctx, cam, prm, pose.clone(), Xw, obs, octv), 3, ctx.stream)
+    t_trk = ev_time(torch, lambda: gmmloc_amd.track_frames(ctx, g, cam, prm, pose.clone(), Xw.clone(), obs, octv, False), 3, ctx.stream)
+    out({"config": "3: V1_03-shaped replay, synthetic-from-real-map (v1.gmm K=3299 + gt_sync poses), M~U{150..1200}",
+         "frames": B,
+         "search2d_renderView+searchCorrespondence_frames_per_s": B / t_s2d,
+         "optimizeCurrentPose_4x10LM_frames_per_s": B / t_pose,
+         "associate3d+structureBA_frames_per_s": B / t_trk,
+         "ms_per_frame": {"search2d": 1e3 * t_s2d / B, "pose": 1e3 * t_pose / B, "track": 1e3 * t_trk / B}})
+
+
+def config4(torch, ctx, out, cap):
+    import gmmloc_amd
+    from gmmloc_amd import api, replay
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    tot, tsum = 0, 0.0
+    per = {}
+    for seq, mp in (("V1_01_easy", "v1"), ("V1_02_medium", "v1"), ("V1_03_difficult", "v1")):
+        mean, cov, cam, frames = v1_frames(seq, cap, 300, 300, 4)
+        frames = [frames[i] for i in replay.shard_indices(len(frames), rank, world)]
+        prm = api.Params()
+        g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+        pose, Xw, obs, octv = pad_batch(torch, frames, 300)
+        t = ev_time(torch, lambda: gmmloc_amd.track_frames(ctx, g, cam, prm, pose.clone(), Xw.clone(), obs, octv, False), 3, ctx.stream)
+        per[seq] = len(frames) / t
+        tot += len(frames)
+        tsum += t
+    out({"config": "4: batch replay of the V1 sequences (config-1 frame shape: M=300 stereo observations, synthetic-from-real-map), "
+                   "this rank's round-robin shard", "rank": rank, "world": world, "frames": tot,
+         "frames_per_s": tot / tsum, "per_sequence_frames_per_s": per,
+         "note": "V2 sequences use v2.gmm identically; frames of different sequences are independent units"})
+
+
+def config5(torch, ctx, out):
+    import gmmloc_amd
+    from gmmloc_amd import synth
+    mean, cov = synth.synth_gmm(65536, 5)
+    t0 = time.perf_counter()
+    g = gmmloc_amd.GMM(ctx, mean, cov)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    pts = torch.from_numpy(synth.synth_points(mean, cov, 50000, 5)).cuda()
+    t = ev_time(torch, lambda: g.associate3d(pts), 5, ctx.stream)
+    pairs = 50000.0 * 65536
+    out({"config": "5: stress 50 000 pts x 65 536 Gaussians, association (fp64, exact)", "ms": 1e3 * t,
+         "pairs_per_s": pairs / t, "tflops_algorithmic_21_per_pair": 21 * pairs / t / 1e12,
+         "frac_of_fp64_valu_peak": 21 * pairs / t / 1e12 / PEAK,
+         "algorithmic_hbm_bytes": 50000 * 36 + 65536 * 96, "hbm_GBs": (50000 * 36 + 65536 * 96) / t / 1e9,
+         "map_build_s_incl_65536^2_neighbour_graph": t_build, "neighbour_edges": int(g.lib.gl_gmm_nbs_count(g.h))})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="2,3,4,5")
+    ap.add_argument("--frames-cap", type=int, default=100000)
+    a = ap.parse_args()
+    import torch
+    import gmmloc_amd
+    ctx = gmmloc_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    out = lambda d: print(json.dumps(d), flush=True)
+    for c in a.configs.split(","):
+        {"2": lambda: config2(torch, ctx, out), "3": lambda: config3(torch, ctx, out, a.frames_cap),
+         "4": lambda: config4(torch, ctx, out, a.frames_cap), "5": lambda: config5(torch, ctx, out)}[c]()
+
+
+if __name__ == "__main__":
+    main()
