@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmmloc_hip.so")
+LIB_PATH = os.environ.get("GMMLOC_HIP_LIB", os.path.join(_HERE, "libgmmloc_hip.so"))  # override: A/B builds
 
 
 class gl_camera(C.Structure):
