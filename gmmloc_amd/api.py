@@ -112,6 +112,11 @@ class Context:
         _check(self.lib.gl_ctx_timing_read(self.h, timer, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
+    def set_stats_buffer(self, trials):
+        """Register (or clear with None) an int32 CUDA tensor that receives per-frame LM trial counts."""
+        self._stats = trials
+        _check(self.lib.gl_ctx_set_stats_buffer(self.h, _ptr(trials), trials.numel() if trials is not None else 0))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.gl_ctx_destroy(self.h)

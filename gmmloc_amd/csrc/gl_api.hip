@@ -159,6 +159,13 @@ int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* laun
   return GL_OK;
 }
 
+int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n) {
+  GL_REQUIRE(ctx && n >= 0, "bad argument");
+  gl::C(ctx)->stats = n > 0 ? trials_dev : nullptr;
+  gl::C(ctx)->stats_n = trials_dev ? n : 0;
+  return GL_OK;
+}
+
 int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out) {
   GL_REQUIRE(ctx && dev_out, "null argument");
   GL_HIP(hipSetDevice(gl::C(ctx)->device));

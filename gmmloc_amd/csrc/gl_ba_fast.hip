@@ -490,7 +490,7 @@ GL_DEV bool load_pt(const Lds& D, const double* ob_pre, const int32_t* __restric
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, int L, const double* __restrict__ gobs,
                          const int32_t* __restrict__ gassoc, const double* __restrict__ gnd, bool robust, int iters,
-                         double* red, double* tot) {
+                         double* red, double* tot, int& trials) {
   double acc[32], obn[7];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -694,6 +694,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
         ni *= 2;
       }
       qmax++;
+      ++trials;
       PROF_T(tE);
       PROF_ADD(0, tA0, tA1); PROF_ADD(1, tA1, tA2); PROF_ADD(2, tA2, tS); PROF_ADD(3, tS, tB1); PROF_ADD(4, tB1, tB2); PROF_ADD(5, tB2, tE); PROF_ADD(6, tA0, tA0 + 1);
     } while (rho < 0 && qmax < 10);
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
                                                  const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
                                                  const double* __restrict__ d2_all, uint8_t* __restrict__ dropped_all,
                                                  uint8_t* __restrict__ erase_all, int32_t* __restrict__ iters_out,
-                                                 double* __restrict__ pn_all) {
+                                                 double* __restrict__ pn_all, int32_t* __restrict__ trials_out) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                          // 3 * MCAP
@@ -761,10 +762,10 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
 
   // schedule (:770-828): optimize(5) -> gate degenerate GMM edges -> optimize(5) -> gate reprojection
   // edges, robust kernels off -> optimize(40).  One rolled phase loop = one copy of the optimiser code.
-  int it3 = 0;
+  int it3 = 0, trials = 0;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(k, gm, D, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot);
+    it3 = optimize_fast(k, gm, D, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot, trials);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < PPTF; ++i) {
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     normalize_rotation(T);
     se3_store(T, pose_io + (size_t)f * 7);
     if (iters_out) iters_out[f] = it3;
+    if (trials_out) trials_out[f] = trials;
 #ifdef GL_BA_PROF
     if (f == 0)
       for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i];  // debug build only: phase cycles instead of pose 0
@@ -841,7 +843,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   {
     TimerScope ts(c, GL_TIMER_BA);
     k_ba1_fast<<<B, TF, lds, c->stream>>>(make_bak(cam, prm, gate), gm, B, L, pose, pts, obs, oct, assoc, d2, dropped,
-                                          erase, iters, (double*)scratch);
+                                          erase, iters, (double*)scratch, (c->stats && c->stats_n >= B) ? c->stats : nullptr);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

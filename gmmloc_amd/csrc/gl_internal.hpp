@@ -66,6 +66,9 @@ struct Ctx {
   // scratch (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // optional statistics buffer (gl_ctx_set_stats_buffer)
+  int32_t* stats = nullptr;
+  int stats_n = 0;
   // timing
   bool timing = false;
   double timer_ms[GL_TIMER_COUNT] = {0};

@@ -83,6 +83,10 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
 enum gl_timer { GL_TIMER_ASSOC = 0, GL_TIMER_REFINE_POSE = 1, GL_TIMER_BA = 2, GL_TIMER_COUNT = 8 };
 int gl_ctx_timing_enable(gl_ctx_t* ctx, int on);
 int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* launches, int reset);
+/* Optional statistics: while a device buffer of n int32 is registered, gl_track_frames writes the
+ * number of Levenberg trials (linearise + solve + evaluate) each frame b < n spent, so that the
+ * algorithmic work of a launch can be reported.  NULL / 0 unregisters. */
+int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n);
 
 /* ---- GMM map: replaces GMMUtility::loadGMMModel (gmm_utils.cpp:9-67),
  *      GaussianComponent ctor + decompose (gaussian.h:30-39, gaussian.cpp:36-63)
