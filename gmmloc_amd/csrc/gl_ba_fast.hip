@@ -458,22 +458,20 @@ struct PtCtx {
   double ob[3], nd[4], p[3];
   bool ar, ag;
 };
-// observations come from global memory (read-only, coalesced): the loads for slot i+1 are issued
-// while slot i is being processed
-GL_DEV void prefetch_obs(const double* __restrict__ gobs, const double* __restrict__ gnd, int L, int i, double* ob) {
-  const int l = min(threadIdx.x + i * TF, L - 1);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) ob[j] = gobs[(size_t)l * 3 + j];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ob[3 + j] = gnd[(size_t)l * 4 + j];  // plane normal n and n . mean
-}
-GL_DEV bool load_pt(const Lds& D, const double* ob_pre, const int32_t* __restrict__ gassoc, int L, int i, PtCtx& c) {
+// observations and plane records come from global memory (read-only, coalesced, L2-resident).
+// (Software-prefetching slot i+1 was measured: it costs 14 VGPRs -> 6 spilled registers and
+// ~1 GB of scratch writes per launch for no gain; the second wave of the SIMD hides the latency.)
+GL_DEV bool load_pt(const Lds& D, const double* __restrict__ gobs, const double* __restrict__ gnd,
+                    const int32_t* __restrict__ gassoc, int L, int i, PtCtx& c) {
   c.l = threadIdx.x + i * TF;
+  {  // issue the observation loads first (clamped index): they overlap the LDS reads / flag tests below
+    const int lc = min(c.l, L - 1);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) c.ob[j] = ob_pre[j];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c.nd[j] = ob_pre[3 + j];
+    for (int j = 0; j < 3; ++j) c.ob[j] = gobs[(size_t)lc * 3 + j];
+  }
   if (c.l >= L) return false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)c.l * 4 + j];  // plane normal n and n . mean
   const int2 sf = D.sf[c.l];
   c.fl = sf.y;
   if (!(c.fl & F_EXISTS)) return false;
@@ -491,7 +489,7 @@ GL_DEV bool load_pt(const Lds& D, const double* ob_pre, const int32_t* __restric
 GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, int L, const double* __restrict__ gobs,
                          const int32_t* __restrict__ gassoc, const double* __restrict__ gnd, bool robust, int iters,
                          double* red, double* tot, int& trials) {
-  double acc[32], obn[7];
+  double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
 #pragma unroll 1
@@ -517,13 +515,10 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
       double md = 0.0;
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      prefetch_obs(gobs, gnd, L, 0, obn);
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        const bool have = load_pt(D, obn, gassoc, L, i, c);
-        if (i + 1 < PPTF) prefetch_obs(gobs, gnd, L, i + 1, obn);
-        if (!have) continue;
+        if (!load_pt(D, gobs, gnd, gassoc, L, i, c)) continue;
         Lin o;
         lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         const double Hf[9] = {o.A[0] + o.Hc[0], o.A[1] + o.Hc[1], o.A[2] + o.Hc[2], o.A[1] + o.Hc[1], o.A[3] + o.Hc[3],
@@ -556,13 +551,10 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
       // ---- pass A ---------------------------------------------------------------------------
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      prefetch_obs(gobs, gnd, L, 0, obn);
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        const bool have = load_pt(D, obn, gassoc, L, i, c);
-        if (i + 1 < PPTF) prefetch_obs(gobs, gnd, L, i + 1, obn);
-        if (!have) continue;
+        if (!load_pt(D, gobs, gnd, gassoc, L, i, c)) continue;
         Lin o;
         const double c2 = lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         if (c.ar) D.chir[c.l] = c2;  // computeActiveErrors
@@ -613,13 +605,10 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
       // ---- pass B ---------------------------------------------------------------------------
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      prefetch_obs(gobs, gnd, L, 0, obn);
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        const bool have = load_pt(D, obn, gassoc, L, i, c);
-        if (i + 1 < PPTF) prefetch_obs(gobs, gnd, L, i + 1, obn);
-        if (!have) continue;
+        if (!load_pt(D, gobs, gnd, gassoc, L, i, c)) continue;
         Lin o;
         lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         double Dinv[6], b[3], u[3];
