@@ -395,18 +395,6 @@ GL_DEV double reduce_max(double v, double* red) {
   return m;
 }
 
-GL_DEV void unpack6f(const double* acc, double* H) {
-  int qi = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = i; j < 6; ++j) {
-      H[i * 6 + j] = acc[qi];
-      H[j * 6 + i] = acc[qi];
-      ++qi;
-    }
-}
-
 // 6x6 LDL^T in place on the packed upper triangle (21 values, row-major i <= j as produced by the
 // reduction), reciprocal pivots; SimplicialLDLT semantics: fail on a zero pivot.
 // Packed index of (i, j), i <= j.

@@ -611,7 +611,8 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
                                                  const int32_t* __restrict__ ooct_all,
                                                  uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                  int32_t* __restrict__ iters_all, char* __restrict__ scratch,
-                                                 size_t scratch_per_problem) {
+                                                 size_t scratch_per_problem, int s_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // reduced camera system when it fits
   __shared__ double red[NW_BA * 32];
   __shared__ int s_flag;
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
   G.ptw = takeD((size_t)L * 12);
   G.chi_o = takeD((size_t)NOBS);
   G.S = takeD((size_t)n * n);
+  if (s_in_lds) G.S = dyn_lds;  // the in-place LDL^T does ~4n barriers: keep S next to the CU (6P <= 120)
   G.gv = takeD(n);
   G.bp = takeD(n);
   G.dxv = takeD(n);
@@ -797,9 +799,15 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   {
     gl::TimerScope ts(c, GL_TIMER_BA);
-    k_ba_gen<<<B, T_BA, 0, c->stream>>>(make_bak(cam, prm, -1.0), gm, B, P, F, L, NOBS, poses_dev, prior_dev,
-                                        points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev, obs_uvr_dev, obs_oct_dev,
-                                        assoc_dropped_dev, obs_erase_dev, iters_dev, (char*)scratch, per);
+    const size_t n = 6 * (size_t)P;
+    const size_t s_bytes = n * n * sizeof(double);
+    const int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;
+    if (s_in_lds)
+      GL_HIP(hipFuncSetAttribute((const void*)k_ba_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_bytes));
+    k_ba_gen<<<B, T_BA, s_in_lds ? s_bytes : 0, c->stream>>>(make_bak(cam, prm, -1.0), gm, B, P, F, L, NOBS, poses_dev,
+                                                             prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
+                                                             obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev,
+                                                             iters_dev, (char*)scratch, per, s_in_lds);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

@@ -165,6 +165,35 @@ def config5(torch, ctx, out):
          "map_build_s_incl_65536^2_neighbour_graph": t_build, "neighbour_edges": int(g.lib.gl_gmm_nbs_count(g.h))})
 
 
+def config_ba(torch, ctx, out):
+    """Local BA (gl_joint_optimization) timing on synthetic multi-view problems over the real v1 map."""
+    import gmmloc_amd
+    from gmmloc_amd import api
+    from tests.test_gpu_ba import make_ba_problem
+    d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz"))
+    mean, cov = d["mean"], d["cov"]
+    gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_01_easy"]
+    cam, prm = api.Camera(), api.Params()
+    g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+    res = {"config": "local BA (jointOptimization), synthetic multi-view problems on v1.gmm"}
+    for (P, F, L, B) in ((8, 4, 1500, 1), (8, 4, 1500, 64), (20, 8, 3000, 1)):
+        probs = [make_ba_problem(mean, cov, gt, cam, P, F, L, 100 + b) for b in range(min(B, 4))]
+        probs = [probs[b % len(probs)] for b in range(B)]
+        NOBS = max(len(p["obs_pose"]) for p in probs)
+        pad = lambda a, n: np.concatenate([a, np.zeros((n - len(a),) + a.shape[1:], a.dtype)])
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        idx, d2 = g.associate3d(T(np.concatenate([p["points"] for p in probs])))
+        assoc = torch.where(d2 <= 9.0, idx, torch.full_like(idx, -1)).reshape(B, L).contiguous()
+        poses0, pts0 = T(np.stack([p["poses"] for p in probs])), T(np.stack([p["points"] for p in probs]))
+        prior, optr = T(np.stack([p["prior"] for p in probs])), T(np.stack([p["obs_ptr"] for p in probs]))
+        opose = T(np.stack([pad(p["obs_pose"], NOBS) for p in probs]))
+        ouvr = T(np.stack([pad(p["obs_uvr"], NOBS) for p in probs]))
+        ooct = T(np.stack([pad(p["obs_oct"], NOBS) for p in probs]))
+        t = ev_time(torch, lambda: api.joint_optimization(ctx, g, cam, prm, P, F, poses0.clone(), prior, pts0.clone(), assoc, optr, opose, ouvr, ooct), 3, ctx.stream)
+        res["P%d_F%d_L%d_B%d" % (P, F, L, B)] = {"ms_per_call": 1e3 * t, "ms_per_problem": 1e3 * t / B, "observations": int(NOBS)}
+    out(res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4,5")
@@ -176,7 +205,8 @@ def main():
     out = lambda d: print(json.dumps(d), flush=True)
     for c in a.configs.split(","):
         {"2": lambda: config2(torch, ctx, out), "3": lambda: config3(torch, ctx, out, a.frames_cap),
-         "4": lambda: config4(torch, ctx, out, a.frames_cap), "5": lambda: config5(torch, ctx, out)}[c]()
+         "4": lambda: config4(torch, ctx, out, a.frames_cap), "5": lambda: config5(torch, ctx, out),
+         "ba": lambda: config_ba(torch, ctx, out)}[c]()
 
 
 if __name__ == "__main__":
