@@ -432,28 +432,63 @@ GL_DEV bool ldlt_solve(const double* H, const double* b, double* x, bool require
 // ---------------------------------------------------------------------------
 GL_DEV double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
-// one butterfly stage: keep H values, trade the other H with the xor-partner (all indices static,
-// so the value array stays in registers)
-template <int H>
-GL_DEV void rs_stage(double* v, bool hi, int mask) {
+// Cross-lane moves for the reduce-scatter.  The four in-row stages use DPP (no LDS traffic, no
+// address VGPR): quad_perm xor-1 / xor-2, row_half_mirror (lane ^ 7), row_mirror (lane ^ 15);
+// the 16-lane stage uses ds_swizzle (xor 16), the last one ds_bpermute (xor 32).
+template <int CTRL>
+GL_DEV double dpp_f64(double v) {
+  union {
+    double d;
+    int i[2];
+  } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, false);
+  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, false);
+  return b.d;
+}
+GL_DEV double swz16_f64(double v) {
+  union {
+    double d;
+    int i[2];
+  } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_ds_swizzle(a.i[0], 0x401F);  // bit-mask mode: and 0x1F, or 0, xor 0x10
+  b.i[1] = __builtin_amdgcn_ds_swizzle(a.i[1], 0x401F);
+  return b.d;
+}
+// one butterfly stage: keep H values, trade the other H with the partner (all indices static, so
+// the value array stays in registers)
+template <int H, int MODE>
+GL_DEV void rs_stage(double* v, bool hi) {
 #pragma unroll
   for (int i = 0; i < H; ++i) {
     const double keep = hi ? v[i + H] : v[i];
     const double send = hi ? v[i] : v[i + H];
-    v[i] = keep + shfl_xor_f64(send, mask);
+    double recv;
+    if (MODE == 0) recv = dpp_f64<0xB1>(send);        // quad_perm [1,0,3,2]
+    else if (MODE == 1) recv = dpp_f64<0x4E>(send);   // quad_perm [2,3,0,1]
+    else if (MODE == 2) recv = dpp_f64<0x141>(send);  // row_half_mirror
+    else if (MODE == 3) recv = dpp_f64<0x140>(send);  // row_mirror
+    else recv = swz16_f64(send);
+    v[i] = keep + recv;
   }
 }
+// Mirror partners flip several lane bits at once, so the stages select on the bits of a VIRTUAL lane
+// id v with  lane = v ^ ((v & 4) ? 3 : 0) ^ ((v & 8) ? 7 : 0)  (then v^1, v^2, v^4, v^8 are exactly
+// lane^1, lane^2, lane^7, lane^15):  v0 = l0^l2, v1 = l1^l2, v2 = l2^l3, v3 = l3.
 // wave-only reduce-scatter: 32 values per lane in, the wave total of value `wave_slot(lane)` out
 GL_DEV int wave_slot(int lane) {
-  return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+  const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1, l4 = (lane >> 4) & 1;
+  return ((l0 ^ l2) << 4) | ((l1 ^ l2) << 3) | ((l2 ^ l3) << 2) | (l3 << 1) | l4;
 }
 GL_DEV double wave_reduce_scatter32(double* v) {
   const int lane = threadIdx.x & 63;
-  rs_stage<16>(v, lane & 1, 1);
-  rs_stage<8>(v, lane & 2, 2);
-  rs_stage<4>(v, lane & 4, 4);
-  rs_stage<2>(v, lane & 8, 8);
-  rs_stage<1>(v, lane & 16, 16);
+  const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
+  rs_stage<16, 0>(v, l0 ^ l2);
+  rs_stage<8, 1>(v, l1 ^ l2);
+  rs_stage<4, 2>(v, l2 ^ l3);
+  rs_stage<2, 3>(v, l3);
+  rs_stage<1, 4>(v, lane & 16);
   return v[0] + shfl_xor_f64(v[0], 32);
 }
 
