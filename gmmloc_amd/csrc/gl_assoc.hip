@@ -1,14 +1,14 @@
 // Association kernels (gfx950, wave64).
 //
 //  k_assoc_brute : for every point, argmin_k of GaussianComponent::chi2
-//                  (gaussian.cpp:65-70) over a K-range.  The {mean, cov_inv}
-//                  records (96 B) of a K-tile are staged in LDS with coalesced
-//                  16-byte loads; every lane owns PPT points in registers and
-//                  sweeps the tile with broadcast LDS reads (all lanes read the
-//                  same record -> one LDS cycle per lane group, no conflicts).
-//                  fp64 VALU bound: 15 v_{mul,fma,add}_f64 + compare/select per (point,
-//                  Gaussian) pair.  (A wave-vote guard around the selects was measured
-//                  slower: 3.16 vs 2.80 ms per 4.2 G pairs -- the branch serialises issue.)
+//                  (gaussian.cpp:65-70) over a K-range.  Every lane owns PPT points in
+//                  registers; the {mean, cov_inv} record (96 B) of the current Gaussian is
+//                  wave-uniform and comes in through scalar loads as SGPR operands.
+//                  The kernel is VALU-issue bound (every wave64 instruction occupies its SIMD
+//                  for 4 cycles): 15 v_{mul,fma,add}_f64 + 1 v_min_f64 per (point, Gaussian)
+//                  pair, exact argmin recovered per 8-Gaussian chunk (see the kernel).
+//                  History: LDS-staged tiles + compare/select were 20.9 slots/pair; a wave-vote
+//                  guard around the selects was slower still (the branch serialises issue).
 //  grid = (point tiles, K splits); K is split so that even one frame (2k
 //  points) produces >= ~2k waves for the 1024 SIMDs; partial minima are
 //  merged by k_assoc_merge in ascending-k order, so ties keep the lowest index
@@ -29,23 +29,32 @@ using namespace gld;
 
 namespace {
 
-#ifndef GL_TILE_G
-#define GL_TILE_G 128
-#endif
-constexpr int kTileG = GL_TILE_G;  // Gaussians per LDS tile (12 KiB)
 
+// The record of Gaussian k is the same for every lane, so it is fetched with SCALAR loads
+// (constant address space -> s_load_dwordx8/x16 through the scalar cache) and used as the SGPR
+// operand of the VALU instructions: no LDS staging, no barriers, no VGPRs for the record.
+typedef const double __attribute__((address_space(4))) cdouble;
+
+constexpr int kChunk = 8;  // Gaussians per min-chunk
+
+// Per (point, Gaussian) pair the loop issues the 15 canonical v_{add,mul,fma}_f64 + ONE v_min_f64.
+// The argmin index is recovered exactly afterwards: per chunk of 8 Gaussians only {chunk-min < best}
+// is tracked (3 instructions per chunk), and the winning chunk is re-evaluated at the end with the
+// same operation sequence (bit-identical values) to find the first k whose chi2 equals the minimum
+// -- the same lowest-index tie rule as the sequential compare/select loop it replaces
+// (GaussianComponent::chi2 sweep, gaussian.cpp:65-70), at 16.4 instead of 20.9 issue slots per pair.
 template <int PPT>
 __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ rec12, int K, int kchunk,
                                                      const double* __restrict__ pts, int N,
                                                      double* __restrict__ out_d2, int32_t* __restrict__ out_idx) {
-  __shared__ __attribute__((aligned(16))) double tile[kTileG * 12];
   const int tid = threadIdx.x;
   const int k_begin = blockIdx.y * kchunk;
   const int k_end = min(K, k_begin + kchunk);
   const int p0 = (blockIdx.x * 256 + tid) * PPT;
+  cdouble* rc = (cdouble*)rec12;
 
   double px[PPT], py[PPT], pz[PPT], best[PPT];
-  int bi[PPT];
+  int bc[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
     const int n = min(p0 + p, N - 1);
@@ -53,44 +62,60 @@ __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ 
     py[p] = pts[(size_t)n * 3 + 1];
     pz[p] = pts[(size_t)n * 3 + 2];
     best[p] = __builtin_inf();
-    bi[p] = -1;
+    bc[p] = -1;
   }
 
-  for (int k0 = k_begin; k0 < k_end; k0 += kTileG) {
-    const int ng = min(kTileG, k_end - k0);
-    __syncthreads();
-    {  // coalesced 16-byte copy of ng*96 bytes
-      const double2* src = reinterpret_cast<const double2*>(rec12 + (size_t)k0 * 12);
-      double2* dst = reinterpret_cast<double2*>(tile);
-      for (int i = tid; i < ng * 6; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int g = 0; g < ng; ++g) {
-      const double* rec = &tile[g * 12];
-      const double m0 = rec[0], m1 = rec[1], m2 = rec[2];
-      const double a0 = rec[3], a1 = rec[4], a2 = rec[5], a3 = rec[6], a4 = rec[7], a5 = rec[8], a6 = rec[9],
-                   a7 = rec[10], a8 = rec[11];
+  auto pair_chi2 = [&](cdouble* rec, int p) {
+    const double d0 = px[p] - rec[0], d1 = py[p] - rec[1], d2 = pz[p] - rec[2];
+    const double r0 = fma(d2, rec[9], fma(d1, rec[6], d0 * rec[3]));
+    const double r1 = fma(d2, rec[10], fma(d1, rec[7], d0 * rec[4]));
+    const double r2 = fma(d2, rec[11], fma(d1, rec[8], d0 * rec[5]));
+    return fma(r2, d2, fma(r1, d1, r0 * d0));
+  };
+  for (int k0 = k_begin; k0 < k_end; k0 += kChunk) {
+    double cmin[PPT];
+    cdouble* rec = rc + (size_t)k0 * 12;
+    if (k0 + kChunk <= k_end) {  // whole chunk: straight-line code, the scheduler hoists the scalar loads
 #pragma unroll
-      for (int p = 0; p < PPT; ++p) {
-        const double d0 = px[p] - m0, d1 = py[p] - m1, d2 = pz[p] - m2;
-        const double r0 = fma(d2, a6, fma(d1, a3, d0 * a0));
-        const double r1 = fma(d2, a7, fma(d1, a4, d0 * a1));
-        const double r2 = fma(d2, a8, fma(d1, a5, d0 * a2));
-        const double d = fma(r2, d2, fma(r1, d1, r0 * d0));
-        const bool lt = d < best[p];
-        best[p] = lt ? d : best[p];
-        bi[p] = lt ? (k0 + g) : bi[p];
-      }
+      for (int p = 0; p < PPT; ++p) cmin[p] = pair_chi2(rec, p);
+#pragma unroll
+      for (int g = 1; g < kChunk; ++g)
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) cmin[p] = __builtin_fmin(cmin[p], pair_chi2(rec + g * 12, p));  // NaN-ignoring, like `d < best`
+    } else {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) cmin[p] = pair_chi2(rec, p);
+      for (int g = 1; g < k_end - k0; ++g)
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) cmin[p] = __builtin_fmin(cmin[p], pair_chi2(rec + g * 12, p));
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const bool lt = cmin[p] < best[p];
+      best[p] = __builtin_fmin(best[p], cmin[p]);
+      bc[p] = lt ? k0 : bc[p];
     }
   }
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
     const int n = p0 + p;
-    if (n < N) {
-      out_d2[(size_t)blockIdx.y * N + n] = best[p];
-      out_idx[(size_t)blockIdx.y * N + n] = bi[p];
+    if (n >= N) continue;
+    int bi = -1;
+    double bd = __builtin_inf();
+    if (bc[p] >= 0) {
+      for (int g = kChunk - 1; g >= 0; --g) {  // descending: the lowest matching index is kept
+        const int kk = bc[p] + g;
+        if (kk < k_end) {
+          const double d = chi2_rec(rec12 + (size_t)kk * 12, px[p], py[p], pz[p]);
+          if (d == best[p]) {
+            bi = kk;
+            bd = d;
+          }
+        }
+      }
     }
+    out_d2[(size_t)blockIdx.y * N + n] = bd;
+    out_idx[(size_t)blockIdx.y * N + n] = bi;
   }
 }
 
@@ -190,11 +215,12 @@ static void assoc_shape(int K, int N, int* ppt_o, int* ptiles_o, int* nsplit_o, 
   const int ptiles = (N + 256 * ppt - 1) / (256 * ppt);
   const int target_blocks = (N >= 8192) ? 4096 : 512;
   int nsplit = (target_blocks + ptiles - 1) / ptiles;
-  const int max_split = (K + kTileG - 1) / kTileG * 2;  // >= 64 Gaussians per split
+  const int max_split = (K + 63) / 64;  // >= 64 Gaussians per split
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
   if (const char* e = getenv("GMMLOC_ASSOC_NSPLIT")) nsplit = atoi(e);  // tuning knob
   int kchunk = (K + nsplit - 1) / nsplit;
+  kchunk = (kchunk + kChunk - 1) / kChunk * kChunk;  // whole min-chunks per split
   nsplit = (K + kchunk - 1) / kchunk;
   *ppt_o = ppt;
   *ptiles_o = ptiles;

@@ -131,10 +131,22 @@ GL_DEV Pose pose_update(const Pose& P, const double* u) {
 
 struct Lds {      // per-frame state, SoA over MCAP points
   double* sp;     // 3 x MCAP  current point (world)
-  double* pn;     // 3 x MCAP  trial point
   double* chir;   // MCAP      stale chi2 of the reprojection edge (e->chi2())
-  int2* sf;       // MCAP      {float bits of 1/sigma^2, flag bits}
+  // 12 x MCAP 32-bit words, two lifetimes sharing one slot per point:
+  //   pass A -> pass B : fp32 {u = D^-1 b (3), A D^-1 (3x3)} -- the per-point solve, so pass B does not
+  //                      re-linearise: eps = u - (A D^-1)^T gd.  Both are O(1)-conditioned (unlike D^-1
+  //                      itself, whose 1/lambda eigenvalue along an unconstrained ray would swamp fp32),
+  //                      and the step only needs ~1e-7 relative accuracy: the trial state it produces is
+  //                      evaluated exactly in fp64;
+  //   pass B -> accept : the trial point as 3 x {lo, hi} words (exact fp64).
+  int* un;
+  double* stab;   // 8: 1/sigma^2 per pyramid octave
 };
+// per-point flag bits + octave (bits 8..10) live in REGISTERS: thread t owns points t + i*TF, i < 4,
+// 16 bits each in one 64-bit word
+typedef unsigned long long FlagW;
+GL_DEV int fw_get(FlagW fw, int i) { return (int)((fw >> (16 * i)) & 0xffffull); }
+GL_DEV void fw_or(FlagW& fw, int i, int bits) { fw |= (FlagW)bits << (16 * i); }
 
 struct Lin {
   double q[3];
@@ -344,10 +356,8 @@ GL_DEV void accum_pose_sym(const double* q, const double* C, const double* c, do
   acc[26] += c[2];
 }
 
-// C = A - A Dinv A (symmetric), all sym6
-GL_DEV void schur_C(const double* A, const double* Dinv, double* C) {
-  double AD[9];
-  sym3_mul(A, Dinv, AD);
+// C = A - (A Dinv) A (symmetric sym6), AD = A Dinv (3x3)
+GL_DEV void schur_C(const double* A, const double* AD, double* C) {
   const double Af[9] = {A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5]};
   double ADA[9];
 #pragma unroll
@@ -449,7 +459,7 @@ struct PtCtx {
 // observations and plane records come from global memory (read-only, coalesced, L2-resident).
 // (Software-prefetching slot i+1 was measured: it costs 14 VGPRs -> 6 spilled registers and
 // ~1 GB of scratch writes per launch for no gain; the second wave of the SIMD hides the latency.)
-GL_DEV bool load_pt(const Lds& D, const double* __restrict__ gobs, const double* __restrict__ gnd,
+GL_DEV bool load_pt(const Lds& D, FlagW fw, const double* __restrict__ gobs, const double* __restrict__ gnd,
                     const int32_t* __restrict__ gassoc, int L, int i, PtCtx& c) {
   c.l = threadIdx.x + i * TF;
   {  // issue the observation loads first (clamped index): they overlap the LDS reads / flag tests below
@@ -460,13 +470,12 @@ GL_DEV bool load_pt(const Lds& D, const double* __restrict__ gobs, const double*
   if (c.l >= L) return false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)c.l * 4 + j];  // plane normal n and n . mean
-  const int2 sf = D.sf[c.l];
-  c.fl = sf.y;
+  c.fl = fw_get(fw, i);
   if (!(c.fl & F_EXISTS)) return false;
   c.ar = !(c.fl & F_LEVR);
   c.ag = (c.fl & F_ASSOC) && !(c.fl & F_LEVG);
   if (!(c.ar || c.ag)) return false;
-  c.s = (double)__int_as_float(sf.x);
+  c.s = D.stab[(c.fl >> 8) & 7];
   c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? gassoc[c.l] : -1;
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.l];
@@ -474,7 +483,7 @@ GL_DEV bool load_pt(const Lds& D, const double* __restrict__ gobs, const double*
 }
 
 // SparseOptimizer::optimize(iters), Levenberg
-GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, int L, const double* __restrict__ gobs,
+GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw, Pose& P, int L, const double* __restrict__ gobs,
                          const int32_t* __restrict__ gassoc, const double* __restrict__ gnd, bool robust, int iters,
                          double* red, double* tot, int& trials) {
   double acc[32];
@@ -484,7 +493,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
   for (int i = 0; i < PPTF; ++i) {
     const int l = threadIdx.x + i * TF;
     if (l >= L) break;
-    const int fl = D.sf[l].y;
+    const int fl = fw_get(fw, i);
     if (!(fl & F_EXISTS)) continue;
     const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
     if (ar) acc[0] += 1.0;
@@ -506,7 +515,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        if (!load_pt(D, gobs, gnd, gassoc, L, i, c)) continue;
+        if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
         Lin o;
         lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         const double Hf[9] = {o.A[0] + o.Hc[0], o.A[1] + o.Hc[1], o.A[2] + o.Hc[2], o.A[1] + o.Hc[1], o.A[3] + o.Hc[3],
@@ -542,23 +551,33 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        if (!load_pt(D, gobs, gnd, gassoc, L, i, c)) continue;
+        if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
         Lin o;
         const double c2 = lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         if (c.ar) D.chir[c.l] = c2;  // computeActiveErrors
         acc[27] += o.rho0_r + o.chi_g;
+        double Dinv[6], b[3], u[3];
+        point_solve_fast(o, lambda, Dinv, b, u);
+        acc[28] += u[0] * b[0] + u[1] * b[1] + u[2] * b[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) D.un[j * MCAP + c.l] = __float_as_int((float)u[j]);
         if (c.ar) {
-          double Dinv[6], b[3], u[3], C[6], Au[3], cc[3];
-          point_solve_fast(o, lambda, Dinv, b, u);
-          schur_C(o.A, Dinv, C);
+          double C[6], Au[3], cc[3], AD[9];
+          sym3_mul(o.A, Dinv, AD);
+#pragma unroll
+          for (int j = 0; j < 9; ++j) D.un[(3 + j) * MCAP + c.l] = __float_as_int((float)AD[j]);
+          schur_C(o.A, AD, C);
           sym3_mul_vec(o.A, u, Au);
 #pragma unroll
           for (int j = 0; j < 3; ++j) cc[j] = o.a[j] - Au[j];
           accum_pose_sym(o.q, C, cc, acc);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 9; ++j) D.un[(3 + j) * MCAP + c.l] = 0;
         }
       }
       PROF_T(tA1);
-      reduce2<28>(acc, red, tot);
+      reduce2<29>(acc, red, tot);
       PROF_T(tA2);
       if (qmax == 0) currentChi = acc[27];
       // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
@@ -577,6 +596,9 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
 #pragma unroll
           for (int i = 0; i < 3; ++i) bc[15 + i] = Pw.t[i];
           bc[18] = ok ? 1.0 : 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) bc[19 + i] = acc[21 + i];  // reduced rhs g and sum u.b, for computeScale
+          bc[25] = acc[28];
         }
       }
       __syncthreads();
@@ -596,29 +618,31 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
 #pragma unroll 1
       for (int i = 0; i < PPTF; ++i) {
         PtCtx c;
-        if (!load_pt(D, gobs, gnd, gassoc, L, i, c)) continue;
-        Lin o;
-        lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
-        double Dinv[6], b[3], u[3];
-        point_solve_fast(o, lambda, Dinv, b, u);
-        double gd[3], Agd[3] = {0, 0, 0}, rhs[3], eps[3];
-        cross(dx, o.q, gd);
+        if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
+        // eps = D^-1 (b - A gd) = u - (A D^-1)^T gd,  gd = omega x q + upsilon  (u, A D^-1: pass-A cache)
+        double q[3], gd[3], eps[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q[j] = P.R[j * 3] * c.p[0] + P.R[j * 3 + 1] * c.p[1] + P.R[j * 3 + 2] * c.p[2] + P.t[j];
+        cross(dx, q, gd);
         gd[0] += dx[3];
         gd[1] += dx[4];
         gd[2] += dx[5];
-        if (c.ar && pose_active) {
-          sym3_mul_vec(o.A, gd, Agd);
-          acc[2] += gd[0] * o.a[0] + gd[1] * o.a[1] + gd[2] * o.a[2];
-        }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) rhs[j] = b[j] - Agd[j];
-        sym3_mul_vec(Dinv, rhs, eps);
-        acc[0] += eps[0] * (lambda * eps[0] + b[0]) + eps[1] * (lambda * eps[1] + b[1]) + eps[2] * (lambda * eps[2] + b[2]);
+        for (int j = 0; j < 3; ++j) {
+          double e = (double)__int_as_float(D.un[j * MCAP + c.l]);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) e -= (double)__int_as_float(D.un[(3 + a * 3 + j) * MCAP + c.l]) * gd[a];
+          eps[j] = e;
+        }
+        acc[0] += eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2];
         double pn[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) pn[j] = c.p[j] + (P.R[j] * eps[0] + P.R[3 + j] * eps[1] + P.R[6 + j] * eps[2]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) D.pn[j * MCAP + c.l] = pn[j];  // trial point
+        for (int j = 0; j < 3; ++j) {  // trial point (overwrites this point's cache slot)
+          D.un[(2 * j) * MCAP + c.l] = __double2loint(pn[j]);
+          D.un[(2 * j + 1) * MCAP + c.l] = __double2hiint(pn[j]);
+        }
         if (c.ar) {
           double qn[3], e[3], iz;
 #pragma unroll
@@ -636,14 +660,15 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
         if (c.ag) acc[1] += gmm_chi2_fast(k, gm, c.nd, c.fl, c.asc, pn);
       }
       PROF_T(tB1);
-      reduce2<3>(acc, red, tot);
+      reduce2<2>(acc, red, tot);
       PROF_T(tB2);
-      double scale = acc[0];
+      // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
+      // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
+      double scale = lambda * acc[0] + uni(bc[25]);
       const double tempChi = ok2 ? acc[1] : 1.7976931348623157e308;
       if (pose_active) {
-        scale += acc[2];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) scale += dx[i] * (lambda * dx[i]);
+        for (int i = 0; i < 6; ++i) scale += dx[i] * (lambda * dx[i] + uni(bc[19 + i]));
       }
       scale += 1e-3;
       rho = (currentChi - tempChi) / scale;
@@ -659,12 +684,13 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, Pose& P, 
         for (int i = 0; i < PPTF; ++i) {
           const int l = threadIdx.x + i * TF;
           if (l >= L) break;
-          const int fl = D.sf[l].y;
+          const int fl = fw_get(fw, i);
           if (!(fl & F_EXISTS)) continue;
           const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
           if (!(ar || ag)) continue;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) D.sp[j * MCAP + l] = D.pn[j * MCAP + l];
+          for (int j = 0; j < 3; ++j)
+            D.sp[j * MCAP + l] = __hiloint2double(D.un[(2 * j + 1) * MCAP + l], D.un[(2 * j) * MCAP + l]);
         }
       } else {
         lambda *= ni;
@@ -690,11 +716,12 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                          // 3 * MCAP
-  D.pn = D.sp + 3 * MCAP;               // 3 * MCAP
-  D.chir = D.pn + 3 * MCAP;             // MCAP
-  D.sf = (int2*)(D.chir + MCAP);        // MCAP x 8 B
-  double* red = D.chir + 2 * MCAP;      // NWF * 32
+  D.chir = D.sp + 3 * MCAP;             // MCAP
+  D.un = (int*)(D.chir + MCAP);         // 12 * MCAP words = 6 * MCAP doubles
+  double* red = D.chir + 7 * MCAP;      // NWF * 32
   double* tot = red + NWF * 32;         // 32 (+ 32 broadcast slots)
+  D.stab = tot + 64;                    // 8
+  FlagW fw = 0;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
   double* gnd = pn_all + (size_t)f * L * 4;  // per-point plane record {n, n.mu} (written once, then read-only)
@@ -711,13 +738,11 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     if (d2_all && k.gate_chi2 >= 0 && !(d2_all[g] <= k.gate_chi2)) a = -1;
     if (oc < 0) a = -1;
     int fl = 0;
-    float sv = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) D.sp[j * MCAP + l] = pts_io[g * 3 + j];
     if (oc >= 0) {
-      fl = F_EXISTS;
+      fl = F_EXISTS | ((oc & 7) << 8);
       if (!(gobs[(size_t)l * 3 + 2] < 0)) fl |= F_STEREO;
-      sv = (float)k.s2inv[oc];  // exact: the table is float (init_config.hpp:60-79)
       if (a >= 0) {
         fl |= F_ASSOC;
         if (gm.flags[a] & 1) {
@@ -732,7 +757,11 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     }
     gassoc[l] = a;
     D.chir[l] = 0.0;
-    D.sf[l] = make_int2(__float_as_int(sv), fl);
+    fw_or(fw, i, fl);
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) D.stab[j] = k.s2inv[j];  // static indices: a lane-indexed kernarg array would go through scratch
   }
   Pose P = pose_from_se3(se3_load(pose_io + (size_t)f * 7));
   __syncthreads();
@@ -742,23 +771,23 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
   int it3 = 0, trials = 0;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(k, gm, D, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot, trials);
+    it3 = optimize_fast(k, gm, D, fw, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot, trials);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < PPTF; ++i) {
       const int l = tid + i * TF;
       if (l >= L) break;
-      const int fl = D.sf[l].y;
+      const int fl = fw_get(fw, i);
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
         if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
           const double p[3] = {D.sp[l], D.sp[MCAP + l], D.sp[2 * MCAP + l]};
           const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
-          if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) D.sf[l].y = fl | F_LEVG;
+          if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) fw_or(fw, i, F_LEVG);
         }
       } else {  // STALE chi2 of the reprojection edges, fresh depth test (:799-825)
         if (!(fl & F_EXISTS)) continue;
         const double z = P.R[6] * D.sp[l] + P.R[7] * D.sp[MCAP + l] + P.R[8] * D.sp[2 * MCAP + l] + P.t[2];
-        if (D.chir[l] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) D.sf[l].y = fl | F_LEVR;
+        if (D.chir[l] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) fw_or(fw, i, F_LEVR);
       }
     }
     __syncthreads();
@@ -769,7 +798,7 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     const int l = tid + i * TF;
     if (l >= L) break;
     const size_t g = (size_t)f * L + l;
-    const int fl = D.sf[l].y;
+    const int fl = fw_get(fw, i);
     uint8_t dr = 0, er = 0;
     int a = gassoc[l];
     if (fl & F_EXISTS) {
@@ -814,7 +843,7 @@ bool ba1_fast_supported(int L) { return L <= MCAP; }
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
                     uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
-  const size_t lds = (size_t)(8 * MCAP + NWF * 32 + 64) * sizeof(double);
+  const size_t lds = (size_t)(10 * MCAP + NWF * 32 + 64 + 8) * sizeof(double);  // 162 624 B of the CU's 163 840
   GL_HIP(hipFuncSetAttribute((const void*)k_ba1_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   {
