@@ -35,7 +35,6 @@ namespace {
 // operand of the VALU instructions: no LDS staging, no barriers, no VGPRs for the record.
 typedef const double __attribute__((address_space(4))) cdouble;
 
-constexpr int kChunk = 8;  // Gaussians per min-chunk
 
 // Per (point, Gaussian) pair the loop issues the 15 canonical v_{add,mul,fma}_f64 + ONE v_min_f64.
 // The argmin index is recovered exactly afterwards: per chunk of 8 Gaussians only {chunk-min < best}
@@ -43,7 +42,7 @@ constexpr int kChunk = 8;  // Gaussians per min-chunk
 // same operation sequence (bit-identical values) to find the first k whose chi2 equals the minimum
 // -- the same lowest-index tie rule as the sequential compare/select loop it replaces
 // (GaussianComponent::chi2 sweep, gaussian.cpp:65-70), at 16.4 instead of 20.9 issue slots per pair.
-template <int PPT>
+template <int PPT, int kChunk>
 __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ rec12, int K, int kchunk,
                                                      const double* __restrict__ pts, int N,
                                                      double* __restrict__ out_d2, int32_t* __restrict__ out_idx) {
@@ -207,7 +206,12 @@ namespace gl {
 //  * points per thread: 4 amortises the broadcast LDS reads best once there are enough points;
 //  * K splits: aim for ~4096 workgroups so the tail is short; a single 2 000-point frame still
 //    gets 8 x 64 workgroups.
+static int assoc_minchunk() {
+  if (const char* e = getenv("GMMLOC_ASSOC_CHUNK")) return atoi(e) == 16 ? 16 : 8;  // tuning knob
+  return 8;
+}
 static void assoc_shape(int K, int N, int* ppt_o, int* ptiles_o, int* nsplit_o, int* kchunk_o) {
+  const int kChunk = assoc_minchunk();
   int ppt = 1;
   if (N >= 8192) ppt = 2;
   if (N >= 16384) ppt = 4;
@@ -255,12 +259,20 @@ int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   {
     TimerScope ts(c, GL_TIMER_ASSOC);
     const dim3 grid(ptiles, nsplit);
-    if (ppt == 1)
-      k_assoc_brute<1><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx);
-    else if (ppt == 2)
-      k_assoc_brute<2><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx);
-    else
-      k_assoc_brute<4><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx);
+    const int ch = assoc_minchunk();
+#define GL_ASSOC_LAUNCH(P, C) k_assoc_brute<P, C><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx)
+    if (ch == 16) {
+      if (ppt == 1) GL_ASSOC_LAUNCH(1, 16);
+      else if (ppt == 2) GL_ASSOC_LAUNCH(2, 16);
+      else if (ppt == 8) GL_ASSOC_LAUNCH(8, 16);
+      else GL_ASSOC_LAUNCH(4, 16);
+    } else {
+      if (ppt == 1) GL_ASSOC_LAUNCH(1, 8);
+      else if (ppt == 2) GL_ASSOC_LAUNCH(2, 8);
+      else if (ppt == 8) GL_ASSOC_LAUNCH(8, 8);
+      else GL_ASSOC_LAUNCH(4, 8);
+    }
+#undef GL_ASSOC_LAUNCH
   }
   GL_HIP(hipGetLastError());
   if (part_idx != idx) {

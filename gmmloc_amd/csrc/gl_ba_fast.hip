@@ -97,13 +97,16 @@ GL_DEV Pose pose_from_se3(const SE3& T) {
 // exp(dx) * P  (g2o SE3Quat::exp, VertexSE3Expmap::oplusImpl) without the quaternion detour
 GL_DEV Pose pose_update(const Pose& P, const double* u) {
   const double th2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-  const double theta = sqrt(th2);
   double a, b, c;
-  if (theta < 0.00001) {
-    a = 1.0;
-    b = 0.5;
-    c = 1.0 / 6.0;
+  if (th2 < 1e-4) {
+    // a = sin t/t, b = (1-cos t)/t^2, c = (t-sin t)/t^3 as series in t^2; for |t| < 0.01 (every LM step but
+    // the first few) four terms reach 1e-19, and this also covers g2o's small-angle branch; avoids
+    // sqrt, sincos and three divisions on the serial path between the two passes
+    a = fma(fma(fma(-1.0 / 5040, th2, 1.0 / 120), th2, -1.0 / 6), th2, 1.0);
+    b = fma(fma(fma(-1.0 / 40320, th2, 1.0 / 720), th2, -1.0 / 24), th2, 0.5);
+    c = fma(fma(fma(-1.0 / 362880, th2, 1.0 / 5040), th2, -1.0 / 120), th2, 1.0 / 6);
   } else {
+    const double theta = sqrt(th2);
     double st, ct;
     sincos(theta, &st, &ct);
     const double it = 1.0 / theta;
@@ -138,7 +141,8 @@ struct Lds {      // per-frame state, SoA over MCAP points
   //                      itself, whose 1/lambda eigenvalue along an unconstrained ray would swamp fp32),
   //                      and the step only needs ~1e-7 relative accuracy: the trial state it produces is
   //                      evaluated exactly in fp64;
-  //   pass B -> accept : the trial point as 3 x {lo, hi} words (exact fp64).
+  //   pass B -> accept : backup of the point (3 x {lo, hi} words, exact fp64) while the trial point sits
+  //                      in `sp`; restored only when the trial is rejected.
   int* un;
   double* stab;   // 8: 1/sigma^2 per pyramid octave
 };
@@ -381,7 +385,7 @@ GL_DEV void reduce2(double* v, double* red, double* tot) {
   const double r = wave_reduce_scatter32(v);
   // no barrier needed before writing `red`: its last readers (threads < 32) finished before the
   // closing barrier of the previous reduction, which every thread has passed
-  if (lane < 32) red[wave * 32 + wave_slot(lane)] = r;
+  if (wave_slot_owner(lane)) red[wave * 32 + wave_slot(lane)] = r;
   __syncthreads();
   if (threadIdx.x < 32) {
     double s = red[threadIdx.x];
@@ -392,6 +396,27 @@ GL_DEV void reduce2(double* v, double* red, double* tot) {
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = uni(tot[i]);
+}
+// same, but only wave 0 (the one that solves the reduced system) reads the totals back
+template <int NV>
+GL_DEV void reduce2_w0(double* v, double* red, double* tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = NV; i < 32; ++i) v[i] = 0.0;
+  const double r = wave_reduce_scatter32(v);
+  if (wave_slot_owner(lane)) red[wave * 32 + wave_slot(lane)] = r;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double s = red[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NWF; ++w) s += red[w * 32 + threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = uni(tot[i]);
+  }
 }
 GL_DEV double reduce_max(double v, double* red) {
 #pragma unroll
@@ -577,9 +602,9 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         }
       }
       PROF_T(tA1);
-      reduce2<29>(acc, red, tot);
+      reduce2_w0<29>(acc, red, tot);
       PROF_T(tA2);
-      if (qmax == 0) currentChi = acc[27];
+      if (qmax == 0) currentChi = uni(tot[27]);
       // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
       double* bc = tot + 32;  // 20 doubles: dx[6] R[9] t[3] ok pad
       if (threadIdx.x < 64) {
@@ -639,9 +664,10 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
 #pragma unroll
         for (int j = 0; j < 3; ++j) pn[j] = c.p[j] + (P.R[j] * eps[0] + P.R[3 + j] * eps[1] + P.R[6 + j] * eps[2]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {  // trial point (overwrites this point's cache slot)
-          D.un[(2 * j) * MCAP + c.l] = __double2loint(pn[j]);
-          D.un[(2 * j + 1) * MCAP + c.l] = __double2hiint(pn[j]);
+        for (int j = 0; j < 3; ++j) {  // the trial point goes in place; the old point is backed up in the cache slot
+          D.sp[j * MCAP + c.l] = pn[j];
+          D.un[(2 * j) * MCAP + c.l] = __double2loint(c.p[j]);
+          D.un[(2 * j + 1) * MCAP + c.l] = __double2hiint(c.p[j]);
         }
         if (c.ar) {
           double qn[3], e[3], iz;
@@ -680,8 +706,11 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         ni = 2;
         currentChi = tempChi;
         P = Pn;
+      } else {
+        lambda *= ni;
+        ni *= 2;
 #pragma unroll 1
-        for (int i = 0; i < PPTF; ++i) {
+        for (int i = 0; i < PPTF; ++i) {  // discardTop: restore the backed-up points
           const int l = threadIdx.x + i * TF;
           if (l >= L) break;
           const int fl = fw_get(fw, i);
@@ -692,9 +721,6 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
           for (int j = 0; j < 3; ++j)
             D.sp[j * MCAP + l] = __hiloint2double(D.un[(2 * j + 1) * MCAP + l], D.un[(2 * j) * MCAP + l]);
         }
-      } else {
-        lambda *= ni;
-        ni *= 2;
       }
       qmax++;
       ++trials;

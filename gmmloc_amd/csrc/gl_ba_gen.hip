@@ -345,7 +345,7 @@ GL_DEV void pass_blocks(const GenP& G, bool schur) {
     }
     const double r1 = wave_reduce_scatter32(v1);
     const double r2 = wave_reduce_scatter32(v2);
-    if (lane < 32) {
+    if (wave_slot_owner(lane)) {
       const int s = wave_slot(lane);
       {
         const int r = s / 6, c = s % 6;

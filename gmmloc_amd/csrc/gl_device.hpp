@@ -432,9 +432,9 @@ GL_DEV bool ldlt_solve(const double* H, const double* b, double* x, bool require
 // ---------------------------------------------------------------------------
 GL_DEV double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
-// Cross-lane moves for the reduce-scatter.  The four in-row stages use DPP (no LDS traffic, no
-// address VGPR): quad_perm xor-1 / xor-2, row_half_mirror (lane ^ 7), row_mirror (lane ^ 15);
-// the 16-lane stage uses ds_swizzle (xor 16), the last one ds_bpermute (xor 32).
+// Cross-lane moves for the reduce-scatter.  The in-row stages use DPP (no LDS traffic, no address
+// VGPR): quad_perm xor-1 / xor-2, row_half_mirror (lane ^ 7), row_mirror (lane ^ 15); the two
+// widest stages use the gfx950 v_permlane{32,16}_swap (see rs_swap_stage).
 template <int CTRL>
 GL_DEV double dpp_f64(double v) {
   union {
@@ -473,23 +473,57 @@ GL_DEV void rs_stage(double* v, bool hi) {
     v[i] = keep + recv;
   }
 }
-// Mirror partners flip several lane bits at once, so the stages select on the bits of a VIRTUAL lane
-// id v with  lane = v ^ ((v & 4) ? 3 : 0) ^ ((v & 8) ? 7 : 0)  (then v^1, v^2, v^4, v^8 are exactly
-// lane^1, lane^2, lane^7, lane^15):  v0 = l0^l2, v1 = l1^l2, v2 = l2^l3, v3 = l3.
-// wave-only reduce-scatter: 32 values per lane in, the wave total of value `wave_slot(lane)` out
-GL_DEV int wave_slot(int lane) {
-  const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1, l4 = (lane >> 4) & 1;
-  return ((l0 ^ l2) << 4) | ((l1 ^ l2) << 3) | ((l2 ^ l3) << 2) | (l3 << 1) | l4;
+// gfx950 lane-swap stages: v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes
+// 0..31 of the second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the
+// second.  With a = v[i], b = v[i+H] the swap IS the select-and-exchange of a reduce-scatter stage:
+// afterwards a + b holds value i in the low half / even rows and value i+H in the high half / odd
+// rows -- 3 instructions per pair instead of 4 selects + 2 DPP moves + 1 add.
+typedef unsigned gl_v2u __attribute__((ext_vector_type(2)));
+template <int H, int WIDE>
+GL_DEV void rs_swap_stage(double* v) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    union {
+      double d;
+      unsigned u[2];
+    } a, b;
+    a.d = v[i];
+    b.d = v[i + H];
+    gl_v2u lo, hi;
+    if (WIDE == 32) {
+      lo = __builtin_amdgcn_permlane32_swap(a.u[0], b.u[0], false, false);
+      hi = __builtin_amdgcn_permlane32_swap(a.u[1], b.u[1], false, false);
+    } else {
+      lo = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+      hi = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+    }
+    a.u[0] = lo.x;
+    b.u[0] = lo.y;
+    a.u[1] = hi.x;
+    b.u[1] = hi.y;
+    v[i] = a.d + b.d;
+  }
 }
+// wave-only reduce-scatter: 32 values per lane in; out: the wave total of value `wave_slot(lane)`,
+// present in the two lanes l and l ^ 15 (store from the lanes with wave_slot_owner(lane)).
+// Stages: lane bit 5 (permlane32_swap), bit 4 (permlane16_swap), then DPP quad_perm xor-1 / xor-2 and
+// row_half_mirror (lane ^ 7) inside a row, and a row_mirror (lane ^ 15) add to finish.  Mirror
+// partners flip several lane bits at once, so those stages select on VIRTUAL bits that are equal in
+// the partners of every later stage: v0 = l0^l2, v1 = l1^l2, v2 = l2^l3.
+GL_DEV int wave_slot(int lane) {
+  const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
+  return (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 3) | ((l0 ^ l2) << 2) | ((l1 ^ l2) << 1) | (l2 ^ l3);
+}
+GL_DEV bool wave_slot_owner(int lane) { return !(lane & 8); }
 GL_DEV double wave_reduce_scatter32(double* v) {
   const int lane = threadIdx.x & 63;
   const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
-  rs_stage<16, 0>(v, l0 ^ l2);
-  rs_stage<8, 1>(v, l1 ^ l2);
-  rs_stage<4, 2>(v, l2 ^ l3);
-  rs_stage<2, 3>(v, l3);
-  rs_stage<1, 4>(v, lane & 16);
-  return v[0] + shfl_xor_f64(v[0], 32);
+  rs_swap_stage<16, 32>(v);
+  rs_swap_stage<8, 16>(v);
+  rs_stage<4, 0>(v, l0 ^ l2);
+  rs_stage<2, 1>(v, l1 ^ l2);
+  rs_stage<1, 2>(v, l2 ^ l3);
+  return v[0] + dpp_f64<0x140>(v[0]);
 }
 
 template <int NV, int NWAVES>
@@ -499,7 +533,7 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
   for (int i = NV; i < 32; ++i) v[i] = 0.0;
   const double r = wave_reduce_scatter32(v);
   __syncthreads();
-  if (lane < 32) lds[wave * 32 + wave_slot(lane)] = r;
+  if (wave_slot_owner(lane)) lds[wave * 32 + wave_slot(lane)] = r;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
