@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     GLError,
     ASSOC_BRUTE,
     ASSOC_KNN5_EUCLID,
+    ASSOC_EXHAUSTIVE,
     optimize_current_pose,
     track_frames,
 )

@@ -317,15 +317,21 @@ int gl_knn3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, i
 int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int mode, int32_t* idx_dev,
                    double* d2_dev) {
   GL_REQUIRE(ctx && gmm, "null argument");
-  GL_REQUIRE(mode == GL_ASSOC_BRUTE || mode == GL_ASSOC_KNN5_EUCLID, "unknown mode");
+  GL_REQUIRE(mode == GL_ASSOC_BRUTE || mode == GL_ASSOC_KNN5_EUCLID || mode == GL_ASSOC_EXHAUSTIVE, "unknown mode");
   if (N == 0) return GL_OK;
   GL_REQUIRE(idx_dev, "null argument");
   GL_REQUIRE(N > 0 && pts_dev, "bad N / pts");
   gl::Ctx* c = gl::C(ctx);
   gl::Gmm* g = gl::G(gmm);
   GL_HIP(hipSetDevice(c->device));
-  if (mode == GL_ASSOC_BRUTE) return gl::launch_assoc_brute(c, g, pts_dev, N, idx_dev, d2_dev);
+  if (mode == GL_ASSOC_EXHAUSTIVE || (mode == GL_ASSOC_BRUTE && !g->grid.enabled))
+    return gl::launch_assoc_brute(c, g, pts_dev, N, idx_dev, d2_dev);
   void* scratch = nullptr;
+  if (mode == GL_ASSOC_BRUTE) {  // same result through the exact cell index (gl_grid.hip)
+    int rc = gl::ctx_scratch(c, gl::assoc_index_scratch_bytes(N), &scratch);
+    if (rc != GL_OK) return rc;
+    return gl::launch_assoc_index(c, g, pts_dev, N, idx_dev, d2_dev, true, scratch);
+  }
   int rc = gl::ctx_scratch(c, (size_t)N * 5 * 4, &scratch);
   if (rc != GL_OK) return rc;
   k_knn3d<5><<<(N + 255) / 256, 256, 0, c->stream>>>(g->mean, g->K, pts_dev, N, (int32_t*)scratch, nullptr);

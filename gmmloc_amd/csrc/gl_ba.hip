@@ -442,8 +442,6 @@ __global__ __launch_bounds__(T_BA) void k_ba1(BaK k, GmmDev gm, int B, int L, do
 
 namespace gl {
 
-int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
-size_t assoc_scratch_bytes(int K, int N);
 bool ba1_fast_supported(int L);
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
@@ -490,12 +488,18 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   // Layout: | assoc partials (used first, dead afterwards) ... reused by ba1 | d2 |
   void* scratch = nullptr;
   const size_t ba_bytes = gl::ba1_scratch_bytes(B, M);
-  const size_t assoc_bytes = gl::assoc_scratch_bytes(g->K, (int)n);
+  const size_t assoc_bytes =
+      g->grid.enabled ? gl::assoc_index_scratch_bytes((int)n) : gl::assoc_scratch_bytes(g->K, (int)n);
   const size_t work = ba_bytes > assoc_bytes ? ba_bytes : assoc_bytes;
   int rc = gl::ctx_scratch(c, work + n * 8 + 64, &scratch);
   if (rc != GL_OK) return rc;
   double* d2 = d2_dev ? d2_dev : (double*)((char*)scratch + ((work + 63) / 64) * 64);
-  rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
+  // Only chi2 <= 9 survives the gate below, so the points the cell index cannot resolve (minimum
+  // above 9) need their exact argmin only when the caller asked for the chi2 values.
+  if (g->grid.enabled)
+    rc = gl::launch_assoc_index(c, g, Xw_dev, (int)n, assoc_dev, d2, d2_dev != nullptr, scratch);
+  else
+    rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
   if (rc != GL_OK) return rc;
   // on-chip fast path (gl_ba_fast.hip) for M <= 2048; GMMLOC_BA_SLOW=1 forces the general kernel
   static const bool force_slow = getenv("GMMLOC_BA_SLOW") != nullptr;

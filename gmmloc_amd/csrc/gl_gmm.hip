@@ -196,6 +196,7 @@ int gl_gmm_create(gl_ctx_t* ctx, const double* mean, const double* cov, int K, c
   alloc((void**)&g->flags, K);
   if (rc == GL_OK) rc = gl::launch_build_components(c, g);
   if (rc == GL_OK) rc = gl::launch_build_neighbours(c, g);
+  if (rc == GL_OK) rc = gl::build_cell_index(c, g);
   if (rc != GL_OK) {
     gl_gmm_destroy((gl_gmm_t*)g);
     return rc;
@@ -228,6 +229,7 @@ int gl_gmm_destroy(gl_gmm_t* gmm) {
   void* ptrs[] = {g->rec12, g->mean, g->cov, g->det, g->scale, g->axis, g->sqrt_info, g->hgw, g->flags, g->nbs_ptr, g->nbs_idx, g->nbs_dist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  gl::free_cell_index(g);
   delete g;
   return GL_OK;
 }

@@ -1,0 +1,365 @@
+// Exact cell index for the Mahalanobis argmin (GL_ASSOC_BRUTE).
+//
+// The north-star association is  argmin_k chi2_k(p)  over ALL K components
+// (GaussianComponent::chi2, gaussian.cpp:65-70), and what the callers keep is gated at
+// chi2 <= 9 (gmmloc_opt.cpp:230-232).  A component can only reach chi2_k(p) <= T if p lies in
+// its T-ellipsoid, so a uniform grid over the map in which every cell lists the components whose
+// T-ellipsoid can touch the cell answers the query exactly for every point whose minimum is
+// <= T: all candidates with chi2 <= T are in the point's cell list, the minimum over the list is
+// the global minimum, and ties resolve to the lowest index because the lists are ascending.
+// Points whose list minimum is > T (outliers, ~15 % of a frame) are either reported as
+// "no association" (the fused tracking path, where chi2 > 9 is dropped anyway) or re-done by an
+// exhaustive sweep (k_assoc_rest), so GL_ASSOC_BRUTE keeps returning exactly what the all-pairs
+// sweep (GL_ASSOC_EXHAUSTIVE, k_assoc_brute) returns -- with ~10-20 instead of K evaluations
+// per point on the EuRoC maps and on the synthetic configs[1] map.
+//
+// Conservative registration (host, at gl_gmm_create), component k in cell C iff
+//   (1) C overlaps the axis-aligned box  mu_k +- sqrt(T cov_ii)  (exact AABB of the ellipsoid), and
+//   (2) the cell centre c passes  (c-mu)^T ((1+1/b) T cov + (1+b) rho^2 I)^-1 (c-mu) <= 1  for
+//       b in {1/2, 1, 2}, rho = half diagonal of the cell: the outer ellipsoidal bound of
+//       E(T cov) (+) Ball(rho), which contains the centre of every cell the ellipsoid touches.
+// Rounding is covered by margins: T is inflated by 4e-6 for registration and by 1e-6 for the
+// "resolved" test, cells by 1e-9; components that are not SPD / finite, have a condition number
+// above 1e8 (where the computed chi2 may differ from the exact form by more than the margin) or
+// would cover more than 2^16 cells go to a short global list every point evaluates.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "gl_device.hpp"
+#include "gl_internal.hpp"
+
+using namespace gld;
+
+namespace {
+
+typedef const double __attribute__((address_space(4))) cdouble;
+
+struct GridDev {
+  double lo[3];
+  double inv_h;
+  int dim[3];
+  int nglob;
+  double t_resolve;
+  const int32_t* ptr;
+  const int32_t* idx;
+  const int32_t* glob;
+};
+
+// lexicographic (chi2, index) minimum: the all-pairs sweep keeps the FIRST index of the minimum
+GL_DEV void upd_min(double d, int k, double& best, int& bi) {
+  const bool take = (d < best) || (d == best && k < bi);
+  best = take ? d : best;
+  bi = take ? k : bi;
+}
+
+__global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ rec12, GridDev G,
+                                                     const double* __restrict__ pts, int N,
+                                                     int32_t* __restrict__ out_idx, double* __restrict__ out_d2,
+                                                     int32_t* __restrict__ rest_list, int32_t* __restrict__ rest_count) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const double x = pts[(size_t)n * 3], y = pts[(size_t)n * 3 + 1], z = pts[(size_t)n * 3 + 2];
+  double best = __builtin_inf();
+  int bi = 0x7fffffff;
+  cdouble* rc = (cdouble*)rec12;
+  for (int j = 0; j < G.nglob; ++j) {  // wave-uniform: records through scalar loads
+    const int k = G.glob[j];
+    cdouble* r = rc + (size_t)k * 12;
+    const double d0 = x - r[0], d1 = y - r[1], d2 = z - r[2];
+    const double r0 = fma(d2, r[9], fma(d1, r[6], d0 * r[3]));
+    const double r1 = fma(d2, r[10], fma(d1, r[7], d0 * r[4]));
+    const double r2 = fma(d2, r[11], fma(d1, r[8], d0 * r[5]));
+    upd_min(fma(r2, d2, fma(r1, d1, r0 * d0)), k, best, bi);
+  }
+  const double fx = (x - G.lo[0]) * G.inv_h, fy = (y - G.lo[1]) * G.inv_h, fz = (z - G.lo[2]) * G.inv_h;
+  const bool inside = fx >= 0.0 && fx < (double)G.dim[0] && fy >= 0.0 && fy < (double)G.dim[1] && fz >= 0.0 &&
+                      fz < (double)G.dim[2];  // false for NaN
+  if (inside) {
+    const int c = ((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx;
+    const int e0 = G.ptr[c], e1 = G.ptr[c + 1];
+    for (int e = e0; e < e1; ++e) {
+      const int k = G.idx[e];
+      upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
+    }
+  }
+  if (best <= G.t_resolve) {
+    out_idx[n] = bi;
+    if (out_d2) out_d2[n] = best;
+  } else {
+    out_idx[n] = -1;
+    if (out_d2) out_d2[n] = __builtin_inf();
+    if (rest_list) rest_list[atomicAdd(rest_count, 1)] = n;
+  }
+}
+
+// exhaustive sweep for the points the index could not resolve: one wave per point, lane l takes the
+// components l, l+64, ... (coalesced 6 KB record reads), then a lexicographic wave minimum.
+__global__ __launch_bounds__(256) void k_assoc_rest(const double* __restrict__ rec12, int K,
+                                                    const double* __restrict__ pts,
+                                                    const int32_t* __restrict__ rest_list,
+                                                    const int32_t* __restrict__ rest_count,
+                                                    int32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  const int count = *rest_count;
+  for (int i = wave; i < count; i += nwaves) {
+    const int n = rest_list[i];
+    const double x = pts[(size_t)n * 3], y = pts[(size_t)n * 3 + 1], z = pts[(size_t)n * 3 + 2];
+    double best = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+      const double d = chi2_rec(rec12 + (size_t)k * 12, x, y, z);
+      const bool lt = d < best;  // ascending k per lane: strict < keeps the first
+      best = lt ? d : best;
+      bi = lt ? k : bi;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double od = shfl_xor_f64(best, o);
+      const int ok = __shfl_xor(bi, o, 64);
+      upd_min(od, ok, best, bi);
+    }
+    if (lane == 0) {
+      out_idx[n] = (bi == 0x7fffffff) ? -1 : bi;
+      if (out_d2) out_d2[n] = best;
+    }
+  }
+}
+
+// ---- host build ------------------------------------------------------------------------------
+// eigenvalues of a symmetric 3x3 (cyclic Jacobi), ascending
+void eig3_sym(const double* c, double* w) {
+  double a[3][3] = {{c[0], c[1], c[2]}, {c[1], c[4], c[5]}, {c[2], c[5], c[8]}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = a[k][p], akq = a[k][q];
+          a[k][p] = cs * akp - sn * akq;
+          a[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = cs * apk - sn * aqk;
+          a[q][k] = sn * apk + cs * aqk;
+        }
+      }
+  }
+  w[0] = a[0][0];
+  w[1] = a[1][1];
+  w[2] = a[2][2];
+  std::sort(w, w + 3);
+}
+
+// inverse of a symmetric positive definite 3x3 given as sym6 {00 01 02 11 12 22}
+void sym3_inv_host(const double* S, double* I) {
+  const double c00 = S[3] * S[5] - S[4] * S[4], c01 = S[2] * S[4] - S[1] * S[5], c02 = S[1] * S[4] - S[2] * S[3];
+  const double id = 1.0 / (S[0] * c00 + S[1] * c01 + S[2] * c02);
+  I[0] = c00 * id;
+  I[1] = c01 * id;
+  I[2] = c02 * id;
+  I[3] = (S[0] * S[5] - S[2] * S[2]) * id;
+  I[4] = (S[1] * S[2] - S[0] * S[4]) * id;
+  I[5] = (S[0] * S[3] - S[1] * S[1]) * id;
+}
+
+}  // namespace
+
+namespace gl {
+
+constexpr double kT0 = 9.0;  // the association gate (gmmloc_opt.cpp:230-232)
+
+void free_cell_index(Gmm* g) {
+  if (g->grid.ptr) (void)hipFree(g->grid.ptr);
+  if (g->grid.idx) (void)hipFree(g->grid.idx);
+  if (g->grid.glob) (void)hipFree(g->grid.glob);
+  g->grid = CellIndex();
+}
+
+int build_cell_index(Ctx* c, Gmm* g) {
+  (void)c;
+  g->grid = CellIndex();
+  if (const char* e = getenv("GMMLOC_ASSOC_GRID"))
+    if (atoi(e) == 0) return GL_OK;  // knob: serve GL_ASSOC_BRUTE with the all-pairs sweep
+  const int K = g->K;
+  const double T = kT0;
+  const double t_reg = T * (1.0 + 4e-6);
+  std::vector<double> ext((size_t)K * 3);
+  std::vector<uint8_t> ok(K, 0);
+  std::vector<int32_t> glob;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int k = 0; k < K; ++k) {
+    const double* cv = &g->h_cov[(size_t)k * 9];
+    const double* mu = &g->h_mean[(size_t)k * 3];
+    bool fin = true;
+    for (int i = 0; i < 9; ++i) fin = fin && std::isfinite(cv[i]);
+    for (int i = 0; i < 3; ++i) fin = fin && std::isfinite(mu[i]);
+    if (!fin) continue;  // chi2 is NaN for every point: never the argmin of the sweep either
+    double w[3];
+    eig3_sym(cv, w);
+    const double asym = std::fabs(cv[1] - cv[3]) + std::fabs(cv[2] - cv[6]) + std::fabs(cv[5] - cv[7]);
+    if (!(w[0] > 0.0) || !(w[2] / w[0] <= 1e8) || asym > 1e-12 * w[2]) {
+      glob.push_back(k);  // no usable bound: evaluated for every point
+      continue;
+    }
+    ok[k] = 1;
+    for (int a = 0; a < 3; ++a) {
+      ext[(size_t)k * 3 + a] = std::sqrt(t_reg * cv[a * 4]) * (1.0 + 1e-9);
+      lo[a] = std::min(lo[a], mu[a] - ext[(size_t)k * 3 + a]);
+      hi[a] = std::max(hi[a], mu[a] + ext[(size_t)k * 3 + a]);
+    }
+  }
+  if ((int)glob.size() > K / 4 || lo[0] > hi[0]) return GL_OK;  // index would not pay: stay exhaustive
+  double span[3], smax = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    const double m = 1e-6 * (hi[a] - lo[a]) + 1e-9;
+    lo[a] -= m;
+    hi[a] += m;
+    span[a] = hi[a] - lo[a];
+    smax = std::max(smax, span[a]);
+  }
+  // finest power-of-two subdivision of the longest side within the cell / entry budgets
+  const double max_cells = 4.0e6, max_ins = 12.0e6;
+  double h = smax;
+  for (int lvl = 1; lvl <= 10; ++lvl) {
+    const double hc = smax / (double)(1 << lvl);
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) cells *= std::ceil(span[a] / hc);
+    if (cells > max_cells) break;
+    double ins = 0.0;
+    for (int k = 0; k < K && ins <= max_ins; ++k) {
+      if (!ok[k]) continue;
+      double nk = 1.0;
+      for (int a = 0; a < 3; ++a) nk *= std::floor(2.0 * ext[(size_t)k * 3 + a] / hc) + 2.0;
+      ins += std::min(nk, 65536.0);
+    }
+    if (ins > max_ins) break;
+    h = hc;
+  }
+  if (const char* e = getenv("GMMLOC_ASSOC_CELL")) h = atof(e);  // tuning knob (metres)
+  int dim[3];
+  for (int a = 0; a < 3; ++a) dim[a] = std::max(1, (int)std::ceil(span[a] / h));
+  const size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
+  const double eps_idx = 1e-9;
+  const double rho = h * std::sqrt(3.0) * 0.5 * (1.0 + 1e-9) + 1e-9 * smax;
+  std::vector<uint32_t> e_cell;
+  std::vector<int32_t> e_k;
+  e_cell.reserve(1 << 20);
+  e_k.reserve(1 << 20);
+  const double betas[3] = {0.5, 1.0, 2.0};
+  for (int k = 0; k < K; ++k) {
+    if (!ok[k]) continue;
+    const double* cv = &g->h_cov[(size_t)k * 9];
+    const double* mu = &g->h_mean[(size_t)k * 3];
+    int i0[3], i1[3];
+    double ncells_k = 1.0;
+    for (int a = 0; a < 3; ++a) {
+      i0[a] = (int)std::floor((mu[a] - ext[(size_t)k * 3 + a] - lo[a]) / h - eps_idx);
+      i1[a] = (int)std::floor((mu[a] + ext[(size_t)k * 3 + a] - lo[a]) / h + eps_idx);
+      i0[a] = std::max(i0[a], 0);
+      i1[a] = std::min(i1[a], dim[a] - 1);
+      ncells_k *= (double)(i1[a] - i0[a] + 1);
+    }
+    if (ncells_k > 65536.0) {
+      glob.push_back(k);
+      continue;
+    }
+    double Minv[3][6];
+    for (int b = 0; b < 3; ++b) {
+      const double s1 = (1.0 + 1.0 / betas[b]) * t_reg, s2 = (1.0 + betas[b]) * rho * rho;
+      const double M[6] = {s1 * cv[0] + s2, s1 * cv[1], s1 * cv[2], s1 * cv[4] + s2, s1 * cv[5], s1 * cv[8] + s2};
+      sym3_inv_host(M, Minv[b]);
+    }
+    for (int iz = i0[2]; iz <= i1[2]; ++iz)
+      for (int iy = i0[1]; iy <= i1[1]; ++iy)
+        for (int ix = i0[0]; ix <= i1[0]; ++ix) {
+          const double d[3] = {lo[0] + (ix + 0.5) * h - mu[0], lo[1] + (iy + 0.5) * h - mu[1],
+                               lo[2] + (iz + 0.5) * h - mu[2]};
+          bool in = true;
+          for (int b = 0; b < 3 && in; ++b) {
+            const double* I = Minv[b];
+            const double q = d[0] * (I[0] * d[0] + I[1] * d[1] + I[2] * d[2]) +
+                             d[1] * (I[1] * d[0] + I[3] * d[1] + I[4] * d[2]) +
+                             d[2] * (I[2] * d[0] + I[4] * d[1] + I[5] * d[2]);
+            in = q <= 1.0 + 1e-9;
+          }
+          if (!in) continue;
+          e_cell.push_back((uint32_t)(((size_t)iz * dim[1] + iy) * dim[0] + ix));
+          e_k.push_back(k);
+        }
+  }
+  if ((int)glob.size() > K / 4) return GL_OK;
+  std::sort(glob.begin(), glob.end());
+  // CSR by cell; the entries were generated with ascending k, a stable counting sort keeps that
+  std::vector<int32_t> ptr(ncell + 1, 0), idx(e_k.size());
+  for (uint32_t cidx : e_cell) ptr[cidx + 1]++;
+  for (size_t i = 0; i < ncell; ++i) ptr[i + 1] += ptr[i];
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (size_t i = 0; i < e_k.size(); ++i) idx[fill[e_cell[i]]++] = e_k[i];
+  }
+  CellIndex& G = g->grid;
+  GL_HIP(hipSetDevice(g->device));
+  GL_HIP(hipMalloc((void**)&G.ptr, (ncell + 1) * 4));
+  GL_HIP(hipMalloc((void**)&G.idx, std::max<size_t>(idx.size(), 1) * 4));
+  GL_HIP(hipMalloc((void**)&G.glob, std::max<size_t>(glob.size(), 1) * 4));
+  GL_HIP(hipMemcpy(G.ptr, ptr.data(), (ncell + 1) * 4, hipMemcpyHostToDevice));
+  if (!idx.empty()) GL_HIP(hipMemcpy(G.idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+  if (!glob.empty()) GL_HIP(hipMemcpy(G.glob, glob.data(), glob.size() * 4, hipMemcpyHostToDevice));
+  for (int a = 0; a < 3; ++a) {
+    G.lo[a] = lo[a];
+    G.dim[a] = dim[a];
+  }
+  G.h = h;
+  G.inv_h = 1.0 / h;
+  G.t_resolve = T * (1.0 + 1e-6);
+  G.nglob = (int)glob.size();
+  G.nnz = idx.size();
+  G.ncell = ncell;
+  G.enabled = true;
+  return GL_OK;
+}
+
+size_t assoc_index_scratch_bytes(int N) { return (size_t)N * 4 + 64; }
+
+// idx / d2 (d2 may be NULL) for N points.  With resolve_all the unresolved points are swept
+// exhaustively (exact GL_ASSOC_BRUTE result); without, they are reported as -1 / +inf (callers that
+// drop chi2 > 9 anyway).  scratch: assoc_index_scratch_bytes(N).
+int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, bool resolve_all,
+                       void* scratch) {
+  const CellIndex& I = g->grid;
+  GridDev G;
+  for (int a = 0; a < 3; ++a) {
+    G.lo[a] = I.lo[a];
+    G.dim[a] = I.dim[a];
+  }
+  G.inv_h = I.inv_h;
+  G.nglob = I.nglob;
+  G.t_resolve = I.t_resolve;
+  G.ptr = I.ptr;
+  G.idx = I.idx;
+  G.glob = I.glob;
+  int32_t* count = (int32_t*)scratch;
+  int32_t* list = count + 16;
+  TimerScope ts(c, GL_TIMER_ASSOC);
+  if (resolve_all) GL_HIP(hipMemsetAsync(count, 0, 4, c->stream));
+  k_assoc_cells<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr,
+                                                        count);
+  GL_HIP(hipGetLastError());
+  if (resolve_all) {
+    const int blocks = std::min(2048, (N + 3) / 4);
+    k_assoc_rest<<<blocks, 256, 0, c->stream>>>(g->rec12, g->K, pts, list, count, idx, d2);
+    GL_HIP(hipGetLastError());
+  }
+  return GL_OK;
+}
+
+}  // namespace gl

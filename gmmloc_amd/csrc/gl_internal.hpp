@@ -39,6 +39,20 @@ void set_error(const char* fmt, ...);
 //   flags   K uint8  bit0 degenerated, bit1 salient
 //   plane   K x 8    {normal[3] (= axis col 0), mean[3], pad, pad}
 //   nbs_ptr K+1 int32, nbs_idx nnz int32, nbs_dist nnz  (CSR of nbs_)
+// Exact cell index of the Mahalanobis argmin (gl_grid.hip): CSR lists of candidate components per
+// grid cell + a short list of components every point must evaluate.
+struct CellIndex {
+  bool enabled = false;
+  double lo[3] = {0, 0, 0};
+  double h = 0, inv_h = 0, t_resolve = 0;
+  int dim[3] = {0, 0, 0};
+  int nglob = 0;
+  size_t nnz = 0, ncell = 0;
+  int32_t* ptr = nullptr;   // ncell + 1
+  int32_t* idx = nullptr;   // nnz, ascending within a cell
+  int32_t* glob = nullptr;  // nglob, ascending
+};
+
 struct Gmm {
   int device = 0;
   int K = 0;
@@ -56,6 +70,7 @@ struct Gmm {
   int32_t* nbs_idx = nullptr;
   double* nbs_dist = nullptr;
   int nnz = 0;
+  CellIndex grid;
   gl_params prm;
 };
 
@@ -97,5 +112,13 @@ int write_gmm_file(const char* path, const double* mean, const double* cov, cons
 // launchers implemented across the .hip files
 int launch_build_components(Ctx* c, Gmm* g);
 int launch_build_neighbours(Ctx* c, Gmm* g);
+int build_cell_index(Ctx* c, Gmm* g);
+void free_cell_index(Gmm* g);
+// association launchers (gl_assoc.hip: all-pairs sweep; gl_grid.hip: cell index + sweep of the rest)
+int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
+size_t assoc_scratch_bytes(int K, int N);
+int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, bool resolve_all,
+                       void* scratch);
+size_t assoc_index_scratch_bytes(int N);
 
 }  // namespace gl

@@ -128,10 +128,14 @@ int gl_gmm_nbs_count(const gl_gmm_t* gmm);
 
 /* ---- association --------------------------------------------------------- */
 enum gl_assoc_mode {
-  GL_ASSOC_BRUTE = 0,      /* argmin_k GaussianComponent::chi2 (gaussian.cpp:65-70) over ALL K:
-                              the north-star `associate`; first index wins ties        */
-  GL_ASSOC_KNN5_EUCLID = 1 /* GMM::queryPoint (gaussian_mixture.cpp:545-576): nearest mean
-                              of the exact 5-NN; d2 = its chi2                          */
+  GL_ASSOC_BRUTE = 0,       /* argmin_k GaussianComponent::chi2 (gaussian.cpp:65-70) over ALL K:
+                               the north-star `associate`; first index wins ties.  Served by an
+                               exact cell index built at gl_gmm_create (candidates whose chi2 <= 9
+                               ellipsoid can reach the point's cell) + an all-pairs sweep of the
+                               points it cannot resolve: identical output to GL_ASSOC_EXHAUSTIVE */
+  GL_ASSOC_KNN5_EUCLID = 1, /* GMM::queryPoint (gaussian_mixture.cpp:545-576): nearest mean
+                               of the exact 5-NN; d2 = its chi2                          */
+  GL_ASSOC_EXHAUSTIVE = 2   /* the same argmin by the plain N x K sweep (no index)       */
 };
 /* pts_dev: N x 3; idx_dev: N int32; d2_dev: N double (may be NULL). */
 int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int mode, int32_t* idx_dev,

@@ -136,3 +136,74 @@ def test_gmm_file_roundtrip(gpu, map_v1, tmp_path):
     (tmp_path / "bad.gmm").write_bytes(b"\x02\x05\x08")
     with pytest.raises(api.GLError):
         api.GMM.load(ctx, tmp_path / "bad.gmm")
+
+
+# ---- the exact cell index behind ASSOC_BRUTE vs the plain N x K sweep (ASSOC_EXHAUSTIVE) -------
+
+def _both(torch, g, pts):
+    t = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+    a = g.associate3d(t, api.ASSOC_BRUTE)
+    b = g.associate3d(t, api.ASSOC_EXHAUSTIVE)
+    return [x.cpu().numpy() for x in a], [x.cpu().numpy() for x in b]
+
+
+@pytest.mark.parametrize("which,N,seed", [("v1", 20000, 21), ("v2", 20000, 22), ("synth4096", 50000, 23),
+                                           ("synth300", 5000, 24), ("synth65536", 4000, 25)])
+def test_cell_index_equals_exhaustive(gpu, oracle, map_v1, map_v2, which, N, seed):
+    """idx and chi2 bit-identical to the all-pairs sweep, for inliers, outliers (swept again) and
+    points far outside the map."""
+    torch, ctx = gpu
+    mean, cov = {"v1": map_v1, "v2": map_v2, "synth4096": synth.synth_gmm(4096, seed),
+                 "synth300": synth.synth_gmm(300, seed), "synth65536": synth.synth_gmm(65536, seed)}[which]
+    g = api.GMM(ctx, mean, cov)
+    rng = np.random.default_rng(seed)
+    pts = synth.synth_points(mean, cov, N, seed)
+    # + uniform points in and far around the bounding box, + points exactly on means and cell-ish lattices
+    lo, hi = mean.min(0), mean.max(0)
+    pts = np.concatenate([pts, rng.uniform(lo - 5, hi + 5, (N // 4, 3)), rng.uniform(lo, hi, (N // 4, 3)),
+                          mean[rng.integers(0, len(mean), 200)],
+                          np.round(rng.uniform(lo, hi, (500, 3)) * 8) / 8, np.array([[1e6, -1e6, 3.0], [0.0, 0.0, 1e12]])])
+    (i1, d1), (i2, d2) = _both(torch, g, pts)
+    assert np.array_equal(i1, i2)
+    assert np.array_equal(d1, d2)
+    # and against the oracle on a slice (the sweep itself is pinned by test_associate3d_brute_bit_exact)
+    h = oracle.gmm_create(mean, cov)
+    ir, dr = oracle.associate3d(h, pts[:1500])
+    assert np.array_equal(i1[:1500], ir) and np.array_equal(d1[:1500], dr)
+    oracle.gmm_destroy(h)
+
+
+def test_cell_index_adversarial_components(gpu):
+    """Components the index cannot bound (singular, indefinite, huge, needle-like with cond > 1e8,
+    non-finite) must not change the result; duplicates must keep the lowest index."""
+    torch, ctx = gpu
+    mean, cov = synth.synth_gmm(500, 31)
+    pts0 = synth.synth_points(mean, cov, 20000, 3)
+    cov = cov.reshape(-1, 3, 3).copy()
+    mean = mean.copy()
+    cov[3] = np.diag([1e-12, 1.0, 1.0])            # cond 1e12
+    cov[7] = np.diag([100.0, 100.0, 100.0])        # covers the whole map
+    cov[11] = np.diag([1.0, -1.0, 1.0])            # indefinite
+    cov[13] = np.zeros((3, 3))                     # singular
+    cov[17] = np.array([[1, 2, 0], [0.5, 1, 0], [0, 0, 1.0]])  # asymmetric
+    mean[19] = np.nan                              # never selected
+    cov[23][0, 0] = np.inf
+    mean = np.concatenate([mean, mean[100:140]])   # duplicates (ties)
+    cov = np.concatenate([cov, cov[100:140]]).reshape(-1, 9)
+    g = api.GMM(ctx, mean, cov)
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([pts0, mean[100:140], rng.uniform(-20, 20, (3000, 3))])
+    with np.errstate(all="ignore"):
+        (i1, d1), (i2, d2) = _both(torch, g, pts)
+    assert np.array_equal(i1, i2)
+    assert np.array_equal(d1, d2, equal_nan=True)
+
+
+def test_cell_index_single_component_and_tiny_maps(gpu):
+    torch, ctx = gpu
+    for K in (1, 2, 5):
+        mean, cov = synth.synth_gmm(K, 40 + K)
+        g = api.GMM(ctx, mean, cov)
+        pts = np.concatenate([synth.synth_points(mean, cov, 500, K), np.random.default_rng(K).uniform(-9, 9, (500, 3))])
+        (i1, d1), (i2, d2) = _both(torch, g, pts)
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
