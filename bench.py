@@ -3,9 +3,10 @@
 2 000 map points x 4 096 Gaussians (BASELINE.json configs[1] shape).
 
 A "step" = one pass of gl_track_frames over one batch of --batch synthetic frames that are
-already resident in HBM: exhaustive fp64 Mahalanobis association of every frame's 2 000 map
-points against the 4 096 map Gaussians + the structure-constrained refinement (single free
-pose, Schur-marginalised points, 5/5/40 LM schedule).  The in-place state (poses, points) is
+already resident in HBM: the exact fp64 Mahalanobis argmin of every frame's 2 000 map points
+over the 4 096 map Gaussians (GL_ASSOC_BRUTE: cell index + same result as the N x K sweep,
+gated at chi2 <= 9) + the structure-constrained refinement (single free pose,
+Schur-marginalised points, 5/5/40 LM schedule).  The in-place state (poses, points) is
 restored from pristine device copies inside the timed region.
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
@@ -78,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,6 +140,25 @@ def main():
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
     ctx.timing(False)
 
+    # outside the timed region: the plain N x K sweep on the same points (its roofline record), and
+    # the number of chi2 evaluations the cell index needed for them
+    sweep_ms = None
+    idx_pairs = None
+    if rank == 0:
+        flat = Xw0.reshape(-1, 3)
+        with torch.cuda.stream(ctx.stream):
+            gmm.associate3d(flat, api.ASSOC_EXHAUSTIVE)
+            ctx.timing(True)
+            ctx.timing_read(api.TIMER_ASSOC, reset=True)
+            for _ in range(3):
+                gmm.associate3d(flat, api.ASSOC_EXHAUSTIVE)
+            torch.cuda.synchronize()
+            ms, nn = ctx.timing_read(api.TIMER_ASSOC, reset=True)
+            ctx.timing(False)
+            sweep_ms = ms / max(nn, 1)
+            idx_pairs = gmm.index_work(flat)
+        torch.cuda.synchronize()
+
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -148,9 +168,11 @@ def main():
         frames_total = B * args.steps * world
         pairs = float(B) * N_PTS * K_GAUSS
         assoc_s = assoc_ms / 1e3 / max(assoc_n, 1)
-        ach_tflops = FLOP_PER_PAIR * pairs / assoc_s / 1e12 if assoc_n else None
+        sweep_s = sweep_ms / 1e3
+        ach_tflops = FLOP_PER_PAIR * pairs / sweep_s / 1e12
         # algorithmic HBM bytes of one association launch: points in, records in, idx+d2 out
         alg_bytes = B * N_PTS * 24 + K_GAUSS * 96 + B * N_PTS * 12
+        info = gmm.index_info()
         n_trials = float(trials.sum().item())
         ba_s = ba_ms / 1e3 / max(ba_n, 1)
         ba_flop = FLOP_PER_POINT_TRIAL * N_PTS * n_trials
@@ -170,11 +192,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 2000 map points x 4096 Gaussians per frame "
-                                   "(95% planar map, SURVEY 8d), associate3d(brute) + structure-constrained "
+                                   "(95% planar map, SURVEY 8d), exact chi2 argmin over all Gaussians + structure-constrained "
                                    "refine (1 free pose, Schur, LM 5/5/40)",
                        "frames_per_step_per_gpu": B, "points_per_frame": N_PTS, "gaussians": K_GAUSS,
                        "parallelism": "frames sharded, %d rank(s)" % world},
-            # dominant kernel of the step (~54 % of the time): the structure-constrained refine
+            # dominant kernel of the step (~95 % of the time): the structure-constrained refine
             "roofline": {
                 "kernel": "k_ba1_fast (single-pose LM + Schur, reprojection + point-to-plane/ellipsoid)",
                 "bound": "valu_fp64",
@@ -189,18 +211,29 @@ def main():
                 "hbm": {"achieved_GBs": ba_bytes / ba_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
                         "algorithmic_bytes_per_launch": ba_bytes},
             },
-            # the other half of the step: exhaustive fp64 Mahalanobis argmin
+            # the association inside the step: exact argmin through the cell index (gather bound)
+            "assoc_index": {
+                "kernel": "k_assoc_cells (exact cell index, chi2 <= 9 resolved, the rest gated out)",
+                "avg_launch_ms": 1e3 * assoc_s,
+                "pairs_evaluated": idx_pairs,
+                "pairs_per_point": idx_pairs / float(B * N_PTS),
+                "pairs_exhaustive": pairs,
+                "gather_bytes": idx_pairs * 96 + B * N_PTS * 36,
+                "gather_GBs": (idx_pairs * 96 + B * N_PTS * 36) / assoc_s / 1e9 if assoc_n else None,
+                "index": info,
+            },
+            # the plain N x K sweep (GL_ASSOC_EXHAUSTIVE) on the same points, timed outside the step
             "roofline_assoc": {
-                "kernel": "k_assoc_brute (fp64 Mahalanobis argmin)",
+                "kernel": "k_assoc_brute (fp64 Mahalanobis argmin, all pairs)",
                 "bound": "valu_fp64",
                 "achieved": ach_tflops,
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": (ach_tflops / PEAK_FP64_VALU_TFLOPS) if ach_tflops else None,
+                "frac": ach_tflops / PEAK_FP64_VALU_TFLOPS,
                 "traffic": None,
-                "avg_launch_ms": 1e3 * assoc_s,
+                "avg_launch_ms": 1e3 * sweep_s,
                 "flop_per_launch": FLOP_PER_PAIR * pairs,
-                "hbm": {"achieved_GBs": alg_bytes / assoc_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                "hbm": {"achieved_GBs": alg_bytes / sweep_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
             "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine": ba_ms / max(args.steps, 1)},

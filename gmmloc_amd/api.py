@@ -187,6 +187,23 @@ class GMM:
         self.ctx._exit()
         return idx, d2
 
+    def index_info(self):
+        """Cell index behind ASSOC_BRUTE: dict(enabled, cell, dims, entries, always, t_resolve)."""
+        import ctypes as C
+        info = (C.c_double * 8)()
+        _check(self.lib.gl_gmm_index_info(self.h, info))
+        return {"enabled": bool(info[0]), "cell": info[1], "dims": (int(info[2]), int(info[3]), int(info[4])),
+                "entries": int(info[5]), "always": int(info[6]), "t_resolve": info[7]}
+
+    def index_work(self, pts):
+        """Number of (point, component) evaluations the cell index performs for these points."""
+        import torch
+        out = torch.zeros(1, dtype=torch.int64, device=pts.device)
+        self.ctx._enter()
+        _check(self.lib.gl_assoc_index_work(self.ctx.h, self.h, _ptr(pts), pts.shape[0], _ptr(out)))
+        self.ctx._exit()
+        return int(out.item())
+
     def knn3d(self, pts, k=5):
         import torch
         N = pts.shape[0]

@@ -128,6 +128,24 @@ __global__ __launch_bounds__(256) void k_assoc_rest(const double* __restrict__ r
   }
 }
 
+__global__ __launch_bounds__(256) void k_index_work(GridDev G, const double* __restrict__ pts, int N,
+                                                    unsigned long long* __restrict__ total) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long w = 0;
+  if (n < N) {
+    w = (unsigned long long)G.nglob;
+    const double fx = (pts[(size_t)n * 3] - G.lo[0]) * G.inv_h, fy = (pts[(size_t)n * 3 + 1] - G.lo[1]) * G.inv_h,
+                 fz = (pts[(size_t)n * 3 + 2] - G.lo[2]) * G.inv_h;
+    if (fx >= 0.0 && fx < (double)G.dim[0] && fy >= 0.0 && fy < (double)G.dim[1] && fz >= 0.0 && fz < (double)G.dim[2]) {
+      const int c = ((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx;
+      w += (unsigned long long)(G.ptr[c + 1] - G.ptr[c]);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) w += __shfl_xor(w, o, 64);
+  if ((threadIdx.x & 63) == 0 && w) atomicAdd(total, w);
+}
+
 // ---- host build ------------------------------------------------------------------------------
 // eigenvalues of a symmetric 3x3 (cyclic Jacobi), ascending
 void eig3_sym(const double* c, double* w) {
@@ -330,12 +348,7 @@ int build_cell_index(Ctx* c, Gmm* g) {
 
 size_t assoc_index_scratch_bytes(int N) { return (size_t)N * 4 + 64; }
 
-// idx / d2 (d2 may be NULL) for N points.  With resolve_all the unresolved points are swept
-// exhaustively (exact GL_ASSOC_BRUTE result); without, they are reported as -1 / +inf (callers that
-// drop chi2 > 9 anyway).  scratch: assoc_index_scratch_bytes(N).
-int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, bool resolve_all,
-                       void* scratch) {
-  const CellIndex& I = g->grid;
+static GridDev grid_dev(const CellIndex& I) {
   GridDev G;
   for (int a = 0; a < 3; ++a) {
     G.lo[a] = I.lo[a];
@@ -347,6 +360,15 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   G.ptr = I.ptr;
   G.idx = I.idx;
   G.glob = I.glob;
+  return G;
+}
+
+// idx / d2 (d2 may be NULL) for N points.  With resolve_all the unresolved points are swept
+// exhaustively (exact GL_ASSOC_BRUTE result); without, they are reported as -1 / +inf (callers that
+// drop chi2 > 9 anyway).  scratch: assoc_index_scratch_bytes(N).
+int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, bool resolve_all,
+                       void* scratch) {
+  const GridDev G = grid_dev(g->grid);
   int32_t* count = (int32_t*)scratch;
   int32_t* list = count + 16;
   TimerScope ts(c, GL_TIMER_ASSOC);
@@ -363,3 +385,34 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
 }
 
 }  // namespace gl
+
+extern "C" {
+
+int gl_gmm_index_info(const gl_gmm_t* gmm, double info[8]) {
+  GL_REQUIRE(gmm && info, "null argument");
+  const gl::CellIndex& I = gl::G(gmm)->grid;
+  info[0] = I.enabled ? 1.0 : 0.0;
+  info[1] = I.h;
+  info[2] = I.dim[0];
+  info[3] = I.dim[1];
+  info[4] = I.dim[2];
+  info[5] = (double)I.nnz;
+  info[6] = I.nglob;
+  info[7] = I.t_resolve;
+  return GL_OK;
+}
+
+int gl_assoc_index_work(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int64_t* pairs_dev) {
+  GL_REQUIRE(ctx && gmm && pairs_dev, "null argument");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  GL_HIP(hipMemsetAsync(pairs_dev, 0, 8, c->stream));
+  if (N == 0 || !g->grid.enabled) return GL_OK;
+  GL_REQUIRE(N > 0 && pts_dev, "bad N / pts");
+  k_index_work<<<(N + 255) / 256, 256, 0, c->stream>>>(gl::grid_dev(g->grid), pts_dev, N, (unsigned long long*)pairs_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+}  // extern "C"

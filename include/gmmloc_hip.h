@@ -140,6 +140,15 @@ enum gl_assoc_mode {
 /* pts_dev: N x 3; idx_dev: N int32; d2_dev: N double (may be NULL). */
 int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int mode, int32_t* idx_dev,
                    double* d2_dev);
+/* Diagnostics of the cell index behind GL_ASSOC_BRUTE (gl_grid.hip).
+ * info[8] = {enabled, cell size [m], dim x, dim y, dim z, entries (sum of list lengths),
+ *            always-evaluated components, resolve threshold (chi2)}. */
+int gl_gmm_index_info(const gl_gmm_t* gmm, double info[8]);
+/* Number of (point, component) chi2 evaluations the index performs for these N points (its
+ * algorithmic work, excluding the exhaustive sweep of unresolved points): *pairs_dev (device
+ * int64) is overwritten. */
+int gl_assoc_index_work(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int64_t* pairs_dev);
+
 /* exact k-NN (k <= 8) on the 3-D means, ascending squared L2 (queryPoint's knnSearch).
  * idx_dev: N x k (-1 padded); dist_dev: N x k (may be NULL). */
 int gl_knn3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, int N, int k, int32_t* idx_dev,
