@@ -214,20 +214,25 @@ GL_DEV Quat qfromR(const double* m) {  // Eigen rotation matrix -> quaternion
     c[1] = (m[2] - m[6]) * t;
     c[2] = (m[3] - m[1]) * t;
   } else {
+    // Eigen picks the largest diagonal element i and sets j = (i+1)%3, k = (j+1)%3.  Written as three
+    // static-index cases: a run-time index into m[] would move the caller's whole rotation (and any
+    // struct it lives in) to scratch memory, with a store on every update.
     int i = 0;
     if (m[4] > m[0]) i = 1;
-    if (m[8] > m[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-    double ci = 0.5 * t;
-    t = 0.5 / t;
-    const double cw = (m[k * 3 + j] - m[j * 3 + k]) * t;
-    const double cj = (m[j * 3 + i] + m[i * 3 + j]) * t;
-    const double ck = (m[k * 3 + i] + m[i * 3 + k]) * t;
-    c[0] = (i == 0) ? ci : ((j == 0) ? cj : ck);
-    c[1] = (i == 1) ? ci : ((j == 1) ? cj : ck);
-    c[2] = (i == 2) ? ci : ((j == 2) ? cj : ck);
-    c[3] = cw;
+    if (m[8] > (i == 0 ? m[0] : m[4])) i = 2;
+#define GL_QFROMR_CASE(I, J, K)                                            \
+  {                                                                        \
+    t = sqrt(m[I * 3 + I] - m[J * 3 + J] - m[K * 3 + K] + 1.0);            \
+    c[I] = 0.5 * t;                                                        \
+    t = 0.5 / t;                                                           \
+    c[3] = (m[K * 3 + J] - m[J * 3 + K]) * t;                              \
+    c[J] = (m[J * 3 + I] + m[I * 3 + J]) * t;                              \
+    c[K] = (m[K * 3 + I] + m[I * 3 + K]) * t;                              \
+  }
+    if (i == 0) GL_QFROMR_CASE(0, 1, 2)
+    else if (i == 1) GL_QFROMR_CASE(1, 2, 0)
+    else GL_QFROMR_CASE(2, 0, 1)
+#undef GL_QFROMR_CASE
   }
   return Quat{c[0], c[1], c[2], c[3]};
 }

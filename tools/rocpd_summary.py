@@ -26,7 +26,7 @@ def main(path):
         seen.add(key)
         print("%-50s %5d %5d %6d %8d %8d %8dx%d/%d" % (short, r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]))
     try:
-        rows = list(c.execute("select name, counter_name, sum(value), count(*) from counters_collection group by 1,2"))
+        rows = list(c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by 1,2"))
         if rows:
             print("\n%-50s %-28s %18s %8s" % ("kernel", "counter", "sum", "dispatches"))
             for name, cn, v, n in rows:
