@@ -1,21 +1,34 @@
 // On-chip fast path of the single-pose structure-constrained refinement (same algorithm and
 // control flow as k_ba1 in gl_ba.hip, which stays as the general / large-M path and as the
-// A/B reference).  Motivation (profiles/r1a_*): the first version round-tripped per-point
-// state through global memory and spilled, so it was wait-bound (SQ_WAIT_ANY 64 % of wave
-// cycles, ~15 GB of HBM writes per 512-frame launch).  Here, for M <= 2000 points per frame:
+// A/B reference).  For M <= 2000 points per frame:
 //   * 512 threads (8 waves, 2 per SIMD) per frame; the frame's mutable state lives in LDS as
-//     SoA for the whole 5/5/40 schedule -- current points (3), plane normal n and n.mu of the
-//     associated component (4), stale chi2 (1), {1/sigma^2, level/flag bits} (1): 72 B/point,
-//     144 KB for 2000 points -- so a Levenberg trial touches global memory only for the
-//     read-only observations (coalesced, L2) and the trial points (written once, re-read only
-//     on acceptance); fp64 needs 2 VGPRs per value, so the per-point working set (not the
-//     data) is what limits occupancy: one point at a time per thread, no spills;
+//     SoA for the whole 5/5/40 schedule: current point (3 fp64), stale chi2 (1 fp64) and a
+//     12-word slot with two lifetimes -- between the two passes of a Levenberg trial it caches
+//     the per-point solve in fp32 {u = D^-1 b, A D^-1}, so pass B computes the point step
+//     eps = u - (A D^-1)^T (omega x q + upsilon) without re-linearising (the step only needs
+//     ~1e-7 relative accuracy, the trial state is then evaluated exactly in fp64; D^-1 itself
+//     is NOT cached: its 1/lambda eigenvalue along an unconstrained ray would swamp fp32);
+//     after pass B it holds the backup of the point while the trial point sits in place
+//     (nothing to copy on acceptance).  80 B/point = 160 000 B + 2.6 KB of reduction scratch
+//     of the CU's 160 KB.  Flag / level / octave bits of a thread's 4 points are a 64-bit
+//     register word.  A trial touches global memory only for the read-only observations and
+//     plane records (56 B/point per pass, coalesced); measured (cache-hot substitute) their
+//     latency is fully hidden by the second wave of the SIMD;
+//   * computeScale is evaluated as  lambda (sum|eps|^2 + |dx|^2) + sum u.b + dx.g  (the b-terms
+//     of the point blocks collapse onto the reduced rhs g), so pass B needs neither b nor A;
 //   * the pose is kept as (R, t) in SGPRs (v_readfirstlane after the solve: there is no scalar
-//     fp64 ALU, uniform results otherwise occupy VGPRs) and updated by Rodrigues directly;
-//     reciprocals / inverse square roots use v_rcp_f64 / v_rsq_f64 + two Newton steps
-//     instead of the IEEE division sequence; Huber is branch-free;
-//   * two-level deterministic reduction: wave reduce-scatter -> LDS -> 32 lanes sum the 8
-//     wave partials -> broadcast.
+//     fp64 ALU, uniform results otherwise occupy VGPRs) and updated by Rodrigues directly
+//     (short series for |theta| < 0.01); reciprocals / inverse square roots use v_rcp_f64 /
+//     v_rsq_f64 + two Newton steps instead of the IEEE division sequence; Huber is branch-free;
+//   * fp64 needs 2 VGPRs per value, so the per-point working set (not the data) is what limits
+//     occupancy: one point at a time per thread in rolled loops, no spills in the trial loop;
+//   * two-level deterministic reduction: wave reduce-scatter (v_permlane32/16_swap + DPP) ->
+//     LDS -> 32 lanes sum the 8 wave partials -> only the solving wave reads the totals back;
+//     the 6x6 LDL^T + exp() run on wave 0 and are broadcast through LDS.
+// The kernel is VALU-issue bound (every wave64 instruction holds its SIMD for 4 cycles; ~3100
+// instructions per wave and trial at 2 waves/SIMD + ~450 on the serial solve).  Measured and
+// dropped: software prefetch (spills), alternating s_setprio between the two waves of a SIMD
+// (-1.4 %), trial pose through LDS, 256-thread blocks; see DESIGN.md section 8.
 // Results agree with k_ba1 / the oracle to the north-star tolerance (tests/test_gpu_track.py).
 #include "gl_ba_common.hpp"
 
@@ -27,7 +40,7 @@ namespace {
 constexpr int TF = 512;
 constexpr int NWF = TF / 64;
 constexpr int PPTF = 4;         // point slots per thread (rolled loop)
-constexpr int MCAP = 2000;       // LDS capacity in points: 10 doubles/point = 160 000 B (+ 2.3 KB reduction)
+constexpr int MCAP = 2000;       // LDS capacity in points: 80 B/point = 160 000 B (+ 2.6 KB reduction / broadcast)
 
 #ifdef GL_BA_PROF
 __device__ unsigned long long g_prof[16];
@@ -709,6 +722,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
       } else {
         lambda *= ni;
         ni *= 2;
+        PROF_ADD(7, 0, 1);  // rejected trials
 #pragma unroll 1
         for (int i = 0; i < PPTF; ++i) {  // discardTop: restore the backed-up points
           const int l = threadIdx.x + i * TF;
@@ -855,7 +869,7 @@ __global__ __launch_bounds__(TF) void k_ba1_fast(BaK k, GmmDev gm, int B, int L,
     if (trials_out) trials_out[f] = trials;
 #ifdef GL_BA_PROF
     if (f == 0)
-      for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i];  // debug build only: phase cycles instead of pose 0
+      for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections  // debug build only: phase cycles instead of pose 0
 #endif
   }
 }
