@@ -47,6 +47,21 @@ def make_workload(B, seed0=20200901):
     return mean, cov, cam, frames
 
 
+def measured_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
+    frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
+    None when the summary is missing: bench.py itself cannot run under two profilers."""
+    for name in ("r1h_traffic.json", "r1g_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                t = json.load(f).get(kernel)
+            if t:
+                return t["hbm_bytes_per_frame"] * frames_per_launch, "profiles/" + name
+    return None, None
+
+
 def cpu_baseline(mean, cov, cam, frames, budget_s=15.0):
     """The oracle (CPU port of the reference algorithm) on the same workload, 1 thread,
     bounded sample."""
@@ -178,6 +193,7 @@ def main():
         ba_flop = FLOP_PER_POINT_TRIAL * N_PTS * n_trials
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
         ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8) + 56)  # Xw, obs, octave, assoc, d2 in; pose in/out (points rewritten: +24)
+        ba_traffic, ba_traffic_src = measured_traffic("k_ba1_fast", B)
         out = {
             "metric": "frames/sec (associate+pose-refine), 2k pts x 4k GMM",
             "value": frames_total / dt,
@@ -204,7 +220,8 @@ def main():
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (ba_tflops / PEAK_FP64_VALU_TFLOPS) if ba_tflops else None,
-                "traffic": None,
+                "traffic": ba_traffic,
+                "traffic_source": ba_traffic_src,
                 "avg_launch_ms": 1e3 * ba_s,
                 "flop_per_launch": ba_flop,
                 "units": "%d frames x %d points x %.1f LM trials/frame x %d flop" % (B, N_PTS, n_trials / B, FLOP_PER_POINT_TRIAL),

@@ -44,8 +44,14 @@ typedef const double __attribute__((address_space(4))) cdouble;
 // (GaussianComponent::chi2 sweep, gaussian.cpp:65-70), at 16.4 instead of 20.9 issue slots per pair.
 template <int PPT, int kChunk>
 __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ rec12, int K, int kchunk,
-                                                     const double* __restrict__ pts, int N,
-                                                     double* __restrict__ out_d2, int32_t* __restrict__ out_idx) {
+                                                     const double* __restrict__ pts, int Nstride,
+                                                     double* __restrict__ out_d2, int32_t* __restrict__ out_idx,
+                                                     const int32_t* __restrict__ list,
+                                                     const int32_t* __restrict__ count_dev) {
+  // optional indirection: sweep only the points list[0 .. *count_dev) (the ones the cell index left
+  // unresolved); partial results are stored compactly (entry i belongs to point list[i])
+  const int N = count_dev ? *count_dev : Nstride;
+  if (blockIdx.x * 256 * PPT >= N) return;
   const int tid = threadIdx.x;
   const int k_begin = blockIdx.y * kchunk;
   const int k_end = min(K, k_begin + kchunk);
@@ -56,7 +62,8 @@ __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ 
   int bc[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
-    const int n = min(p0 + p, N - 1);
+    int n = min(p0 + p, N - 1);
+    if (list) n = list[n];
     px[p] = pts[(size_t)n * 3 + 0];
     py[p] = pts[(size_t)n * 3 + 1];
     pz[p] = pts[(size_t)n * 3 + 2];
@@ -113,27 +120,30 @@ __global__ __launch_bounds__(256) void k_assoc_brute(const double* __restrict__ 
         }
       }
     }
-    out_d2[(size_t)blockIdx.y * N + n] = bd;
-    out_idx[(size_t)blockIdx.y * N + n] = bi;
+    out_d2[(size_t)blockIdx.y * Nstride + n] = bd;
+    out_idx[(size_t)blockIdx.y * Nstride + n] = bi;
   }
 }
 
 // merge the per-K-split partial minima in ascending split (= ascending k) order
 __global__ void k_assoc_merge(const double* __restrict__ part_d2, const int32_t* __restrict__ part_idx, int nsplit,
-                              int N, int32_t* __restrict__ idx, double* __restrict__ d2) {
+                              int Nstride, int32_t* __restrict__ idx, double* __restrict__ d2,
+                              const int32_t* __restrict__ list, const int32_t* __restrict__ count_dev) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = count_dev ? *count_dev : Nstride;
   if (n >= N) return;
   double best = __builtin_inf();
   int bi = -1;
   for (int s = 0; s < nsplit; ++s) {
-    const double d = part_d2[(size_t)s * N + n];
+    const double d = part_d2[(size_t)s * Nstride + n];
     if (d < best) {
       best = d;
-      bi = part_idx[(size_t)s * N + n];
+      bi = part_idx[(size_t)s * Nstride + n];
     }
   }
-  idx[n] = bi;
-  if (d2) d2[n] = best;
+  const int o = list ? list[n] : n;
+  idx[o] = bi;
+  if (d2) d2[o] = best;
 }
 
 // exact k-NN on the means: one thread per query, means staged in LDS tiles.
@@ -240,16 +250,24 @@ size_t assoc_scratch_bytes(int K, int N) {
 
 // shared with gl_ba.hip: brute association of N points; outputs on device
 int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2) {
+  return launch_assoc_sweep(c, g, pts, N, idx, d2, nullptr, nullptr, nullptr);
+}
+
+// all-pairs sweep of N points, or (list / count_dev given) of the listed subset; `scratch` (may be
+// NULL: taken from the context) must hold assoc_scratch_bytes(K, N)
+int launch_assoc_sweep(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, const int32_t* list,
+                       const int32_t* count_dev, void* scratch) {
   const int K = g->K;
   int ppt, ptiles, nsplit, kchunk;
   assoc_shape(K, N, &ppt, &ptiles, &nsplit, &kchunk);
-  void* scratch = nullptr;
   double* part_d2;
   int32_t* part_idx;
-  if (nsplit > 1 || !d2) {
+  if (nsplit > 1 || !d2 || list) {
     const size_t bytes = (size_t)nsplit * N * 12 + 64;
-    int rc = ctx_scratch(c, bytes, &scratch);
-    if (rc != GL_OK) return rc;
+    if (!scratch) {
+      int rc = ctx_scratch(c, bytes, &scratch);
+      if (rc != GL_OK) return rc;
+    }
     part_d2 = (double*)scratch;
     part_idx = (int32_t*)((char*)scratch + (size_t)nsplit * N * 8);
   } else {
@@ -260,7 +278,8 @@ int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
     TimerScope ts(c, GL_TIMER_ASSOC);
     const dim3 grid(ptiles, nsplit);
     const int ch = assoc_minchunk();
-#define GL_ASSOC_LAUNCH(P, C) k_assoc_brute<P, C><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx)
+#define GL_ASSOC_LAUNCH(P, C) \
+  k_assoc_brute<P, C><<<grid, 256, 0, c->stream>>>(g->rec12, K, kchunk, pts, N, part_d2, part_idx, list, count_dev)
     if (ch == 16) {
       if (ppt == 1) GL_ASSOC_LAUNCH(1, 16);
       else if (ppt == 2) GL_ASSOC_LAUNCH(2, 16);
@@ -276,7 +295,7 @@ int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   }
   GL_HIP(hipGetLastError());
   if (part_idx != idx) {
-    k_assoc_merge<<<(N + 255) / 256, 256, 0, c->stream>>>(part_d2, part_idx, nsplit, N, idx, d2);
+    k_assoc_merge<<<(N + 255) / 256, 256, 0, c->stream>>>(part_d2, part_idx, nsplit, N, idx, d2, list, count_dev);
     GL_HIP(hipGetLastError());
   }
   return GL_OK;
@@ -324,11 +343,15 @@ int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, in
   gl::Ctx* c = gl::C(ctx);
   gl::Gmm* g = gl::G(gmm);
   GL_HIP(hipSetDevice(c->device));
-  if (mode == GL_ASSOC_EXHAUSTIVE || (mode == GL_ASSOC_BRUTE && !g->grid.enabled))
+  // small problems are launch-bound: the sweep's two launches beat index + list + sweep of the rest
+  double min_pairs = 6.7e7;
+  if (const char* e = getenv("GMMLOC_ASSOC_INDEX_MIN")) min_pairs = atof(e);  // knob (tests force the index with 0)
+  const bool small = (double)N * g->K < min_pairs;
+  if (mode == GL_ASSOC_EXHAUSTIVE || (mode == GL_ASSOC_BRUTE && (!g->grid.enabled || small)))
     return gl::launch_assoc_brute(c, g, pts_dev, N, idx_dev, d2_dev);
   void* scratch = nullptr;
   if (mode == GL_ASSOC_BRUTE) {  // same result through the exact cell index (gl_grid.hip)
-    int rc = gl::ctx_scratch(c, gl::assoc_index_scratch_bytes(N), &scratch);
+    int rc = gl::ctx_scratch(c, gl::assoc_index_scratch_bytes(g->K, N, true), &scratch);
     if (rc != GL_OK) return rc;
     return gl::launch_assoc_index(c, g, pts_dev, N, idx_dev, d2_dev, true, scratch);
   }

@@ -489,7 +489,7 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   void* scratch = nullptr;
   const size_t ba_bytes = gl::ba1_scratch_bytes(B, M);
   const size_t assoc_bytes =
-      g->grid.enabled ? gl::assoc_index_scratch_bytes((int)n) : gl::assoc_scratch_bytes(g->K, (int)n);
+      g->grid.enabled ? gl::assoc_index_scratch_bytes(g->K, (int)n, d2_dev != nullptr) : gl::assoc_scratch_bytes(g->K, (int)n);
   const size_t work = ba_bytes > assoc_bytes ? ba_bytes : assoc_bytes;
   int rc = gl::ctx_scratch(c, work + n * 8 + 64, &scratch);
   if (rc != GL_OK) return rc;

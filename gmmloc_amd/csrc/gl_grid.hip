@@ -9,7 +9,7 @@
 // the global minimum, and ties resolve to the lowest index because the lists are ascending.
 // Points whose list minimum is > T (outliers, ~15 % of a frame) are either reported as
 // "no association" (the fused tracking path, where chi2 > 9 is dropped anyway) or re-done by an
-// exhaustive sweep (k_assoc_rest), so GL_ASSOC_BRUTE keeps returning exactly what the all-pairs
+// all-pairs sweep restricted to them (k_assoc_brute with a point list), so GL_ASSOC_BRUTE keeps returning exactly what the all-pairs
 // sweep (GL_ASSOC_EXHAUSTIVE, k_assoc_brute) returns -- with ~10-20 instead of K evaluations
 // per point on the EuRoC maps and on the synthetic configs[1] map.
 //
@@ -91,40 +91,6 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
     out_idx[n] = -1;
     if (out_d2) out_d2[n] = __builtin_inf();
     if (rest_list) rest_list[atomicAdd(rest_count, 1)] = n;
-  }
-}
-
-// exhaustive sweep for the points the index could not resolve: one wave per point, lane l takes the
-// components l, l+64, ... (coalesced 6 KB record reads), then a lexicographic wave minimum.
-__global__ __launch_bounds__(256) void k_assoc_rest(const double* __restrict__ rec12, int K,
-                                                    const double* __restrict__ pts,
-                                                    const int32_t* __restrict__ rest_list,
-                                                    const int32_t* __restrict__ rest_count,
-                                                    int32_t* __restrict__ out_idx, double* __restrict__ out_d2) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-  const int count = *rest_count;
-  for (int i = wave; i < count; i += nwaves) {
-    const int n = rest_list[i];
-    const double x = pts[(size_t)n * 3], y = pts[(size_t)n * 3 + 1], z = pts[(size_t)n * 3 + 2];
-    double best = __builtin_inf();
-    int bi = 0x7fffffff;
-    for (int k = lane; k < K; k += 64) {
-      const double d = chi2_rec(rec12 + (size_t)k * 12, x, y, z);
-      const bool lt = d < best;  // ascending k per lane: strict < keeps the first
-      best = lt ? d : best;
-      bi = lt ? k : bi;
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const double od = shfl_xor_f64(best, o);
-      const int ok = __shfl_xor(bi, o, 64);
-      upd_min(od, ok, best, bi);
-    }
-    if (lane == 0) {
-      out_idx[n] = (bi == 0x7fffffff) ? -1 : bi;
-      if (out_d2) out_d2[n] = best;
-    }
   }
 }
 
@@ -346,7 +312,11 @@ int build_cell_index(Ctx* c, Gmm* g) {
   return GL_OK;
 }
 
-size_t assoc_index_scratch_bytes(int N) { return (size_t)N * 4 + 64; }
+// | count (64 B) | list N x 4 | (resolve_all: partial minima of the sweep) |
+static size_t index_list_bytes(int N) { return (((size_t)N * 4 + 64) + 63) / 64 * 64; }
+size_t assoc_index_scratch_bytes(int K, int N, bool resolve_all) {
+  return index_list_bytes(N) + (resolve_all ? assoc_scratch_bytes(K, N) : 0);
+}
 
 static GridDev grid_dev(const CellIndex& I) {
   GridDev G;
@@ -365,7 +335,7 @@ static GridDev grid_dev(const CellIndex& I) {
 
 // idx / d2 (d2 may be NULL) for N points.  With resolve_all the unresolved points are swept
 // exhaustively (exact GL_ASSOC_BRUTE result); without, they are reported as -1 / +inf (callers that
-// drop chi2 > 9 anyway).  scratch: assoc_index_scratch_bytes(N).
+// drop chi2 > 9 anyway).  scratch: assoc_index_scratch_bytes(K, N, resolve_all).
 int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, bool resolve_all,
                        void* scratch) {
   const GridDev G = grid_dev(g->grid);
@@ -376,11 +346,8 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   k_assoc_cells<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr,
                                                         count);
   GL_HIP(hipGetLastError());
-  if (resolve_all) {
-    const int blocks = std::min(2048, (N + 3) / 4);
-    k_assoc_rest<<<blocks, 256, 0, c->stream>>>(g->rec12, g->K, pts, list, count, idx, d2);
-    GL_HIP(hipGetLastError());
-  }
+  if (resolve_all)  // the unresolved points go through the all-pairs sweep (grid sized for N, empty tiles exit)
+    return launch_assoc_sweep(c, g, pts, N, idx, d2, list, count, (char*)scratch + index_list_bytes(N));
   return GL_OK;
 }
 

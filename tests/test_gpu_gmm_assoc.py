@@ -142,7 +142,11 @@ def test_gmm_file_roundtrip(gpu, map_v1, tmp_path):
 
 def _both(torch, g, pts):
     t = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
-    a = g.associate3d(t, api.ASSOC_BRUTE)
+    os.environ["GMMLOC_ASSOC_INDEX_MIN"] = "0"  # small problems default to the sweep; force the index
+    try:
+        a = g.associate3d(t, api.ASSOC_BRUTE)
+    finally:
+        del os.environ["GMMLOC_ASSOC_INDEX_MIN"]
     b = g.associate3d(t, api.ASSOC_EXHAUSTIVE)
     return [x.cpu().numpy() for x in a], [x.cpu().numpy() for x in b]
 

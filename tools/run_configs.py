@@ -50,11 +50,18 @@ def config2(torch, ctx, out):
         g = gmmloc_amd.GMM(ctx, mean, cov)
         pts1 = torch.from_numpy(synth.synth_points(mean, cov, 2000, seed)).cuda()
         ptsB = torch.from_numpy(synth.synth_points(mean, cov, 2000 * 512, seed + 50)).cuda()
-        t1 = ev_time(torch, lambda: g.associate3d(pts1), 200, ctx.stream)
-        tB = ev_time(torch, lambda: g.associate3d(ptsB), 10, ctx.stream)
-        res["seed%d" % seed] = {"single_frame_latency_us": 1e6 * t1, "batched_pairs_per_s": 2000 * 512 * 4096 / tB,
-                                "batched_tflops_algorithmic": 21 * 2000 * 512 * 4096 / tB / 1e12,
-                                "single_frame_tflops_algorithmic": 21 * 2000 * 4096 / t1 / 1e12}
+        from gmmloc_amd import api
+        EX = api.ASSOC_EXHAUSTIVE
+        t1 = ev_time(torch, lambda: g.associate3d(pts1, EX), 200, ctx.stream)
+        tB = ev_time(torch, lambda: g.associate3d(ptsB, EX), 10, ctx.stream)
+        t1i = ev_time(torch, lambda: g.associate3d(pts1), 200, ctx.stream)
+        tBi = ev_time(torch, lambda: g.associate3d(ptsB), 10, ctx.stream)
+        res["seed%d" % seed] = {"sweep_single_frame_latency_us": 1e6 * t1, "sweep_batched_pairs_per_s": 2000 * 512 * 4096 / tB,
+                                "sweep_batched_tflops_algorithmic": 21 * 2000 * 512 * 4096 / tB / 1e12,
+                                "sweep_single_frame_tflops_algorithmic": 21 * 2000 * 4096 / t1 / 1e12,
+                                "index_single_frame_latency_us": 1e6 * t1i, "index_batched_points_per_s": 2000 * 512 / tBi,
+                                "index_pairs_per_point": g.index_work(ptsB) / (2000.0 * 512),
+                                "index_unresolved_frac": float((g.associate3d(ptsB)[1] > 9.000009).float().mean().item())}
         if seed == 1:
             h = orc.gmm_create(mean, cov)
             p = pts1.cpu().numpy()
@@ -156,9 +163,13 @@ def config5(torch, ctx, out):
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
     pts = torch.from_numpy(synth.synth_points(mean, cov, 50000, 5)).cuda()
-    t = ev_time(torch, lambda: g.associate3d(pts), 5, ctx.stream)
+    from gmmloc_amd import api
+    t = ev_time(torch, lambda: g.associate3d(pts, api.ASSOC_EXHAUSTIVE), 5, ctx.stream)
+    ti = ev_time(torch, lambda: g.associate3d(pts), 5, ctx.stream)
     pairs = 50000.0 * 65536
     out({"config": "5: stress 50 000 pts x 65 536 Gaussians, association (fp64, exact)", "ms": 1e3 * t,
+         "index_ms": 1e3 * ti, "index": g.index_info(), "index_pairs_per_point": g.index_work(pts) / 50000.0,
+         "index_unresolved_frac": float((g.associate3d(pts)[1] > 9.000009).float().mean().item()),
          "pairs_per_s": pairs / t, "tflops_algorithmic_21_per_pair": 21 * pairs / t / 1e12,
          "frac_of_fp64_valu_peak": 21 * pairs / t / 1e12 / PEAK,
          "algorithmic_hbm_bytes": 50000 * 36 + 65536 * 96, "hbm_GBs": (50000 * 36 + 65536 * 96) / t / 1e9,
