@@ -168,10 +168,10 @@ GL_DEV void fw_or(FlagW& fw, int i, int bits) { fw |= (FlagW)bits << (16 * i); }
 
 struct Lin {
   double q[3];
-  double A[6];
-  double a[3];
-  double Hc[6];
-  double bc[3];
+  double A[6];   // reprojection block w Jpi^T Jpi (camera frame, sym6; A[1] == 0)
+  double a[3];   // its rhs
+  double D[6];   // A + GMM block (no damping yet)
+  double b[3];   // a + GMM rhs
   double rho0_r, chi_g;
 };
 
@@ -225,15 +225,9 @@ GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const doub
 #pragma unroll
   for (int c = 0; c < 3; ++c) o.q[c] = P.R[c * 3] * p[0] + P.R[c * 3 + 1] * p[1] + P.R[c * 3 + 2] * p[2] + P.t[c];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    o.A[c] = 0.0;
-    o.Hc[c] = 0.0;
-  }
+  for (int c = 0; c < 6; ++c) o.A[c] = 0.0;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    o.a[c] = 0.0;
-    o.bc[c] = 0.0;
-  }
+  for (int c = 0; c < 3; ++c) o.a[c] = 0.0;
   o.rho0_r = 0.0;
   o.chi_g = 0.0;
   double chi_r = 0.0;
@@ -247,40 +241,54 @@ GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const doub
       const double dl = stereo ? k.delta_stereo : k.delta_mono;
       huber_bf(chi_r, dl, dl * dl, o.rho0_r, rho1);
     }
+    // rows of Jpi: (al, 0, b0), (0, ga, b1) and, stereo only, (al, 0, b2); t = w on the stereo row, else 0
     const double w = rho1 * s;
+    const double t = stereo ? w : 0.0;
     const double iz2 = iz * iz;
     const double al = k.fx * iz, ga = k.fy * iz;
     const double b0 = -k.fx * o.q[0] * iz2, b1 = -k.fy * o.q[1] * iz2;
-    const double b2 = b0 + k.bf * iz2;
-    const double sb = stereo ? 1.0 : 0.0;
-    o.A[0] = w * (al * al + sb * al * al);
-    o.A[2] = w * (al * b0 + sb * al * b2);
-    o.A[3] = w * ga * ga;
-    o.A[4] = w * ga * b1;
-    o.A[5] = w * (b0 * b0 + b1 * b1 + sb * b2 * b2);
-    o.a[0] = w * al * (e[0] + sb * e[2]);
-    o.a[1] = w * ga * e[1];
-    o.a[2] = w * (b0 * e[0] + b1 * e[1] + sb * b2 * e[2]);
+    const double b2 = fma(k.bf, iz2, b0);
+    const double wga = w * ga, tb2 = t * b2;
+    o.A[0] = (w + t) * al * al;
+    o.A[2] = al * fma(t, b2, w * b0);
+    o.A[3] = wga * ga;
+    o.A[4] = wga * b1;
+    o.A[5] = fma(tb2, b2, w * fma(b1, b1, b0 * b0));
+    o.a[0] = al * fma(t, e[2], w * e[0]);
+    o.a[1] = wga * e[1];
+    o.a[2] = fma(tb2, e[2], w * fma(b1, e[1], b0 * e[0]));
   }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o.D[c] = o.A[c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o.b[c] = o.a[c];
   if (act_g) {
-    if (fl & F_DEG) {
+    if (fl & F_DEG) {  // EdgePt2GaussianDeg x ba_lambda2: D += lm n' n'^T, b -= lm eg n'  (n' = R n)
       const double nx = nd[0], ny = nd[1], nz = nd[2];
-      const double eg = (nx * p[0] + ny * p[1] + nz * p[2]) - nd[3];
+      const double eg = fma(nz, p[2], fma(ny, p[1], nx * p[0])) - nd[3];
       const double lm = k.ba_lambda2;
       o.chi_g = eg * (lm * eg);
-      double nc[3];
+      double nc[3], tn[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) nc[c] = P.R[c * 3] * nx + P.R[c * 3 + 1] * ny + P.R[c * 3 + 2] * nz;
-      o.Hc[0] = lm * nc[0] * nc[0];
-      o.Hc[1] = lm * nc[0] * nc[1];
-      o.Hc[2] = lm * nc[0] * nc[2];
-      o.Hc[3] = lm * nc[1] * nc[1];
-      o.Hc[4] = lm * nc[1] * nc[2];
-      o.Hc[5] = lm * nc[2] * nc[2];
+      for (int c = 0; c < 3; ++c) {
+        nc[c] = fma(P.R[c * 3 + 2], nz, fma(P.R[c * 3 + 1], ny, P.R[c * 3] * nx));
+        tn[c] = lm * nc[c];
+      }
+      o.D[0] = fma(tn[0], nc[0], o.D[0]);
+      o.D[1] = fma(tn[0], nc[1], o.D[1]);
+      o.D[2] = fma(tn[0], nc[2], o.D[2]);
+      o.D[3] = fma(tn[1], nc[1], o.D[3]);
+      o.D[4] = fma(tn[1], nc[2], o.D[4]);
+      o.D[5] = fma(tn[2], nc[2], o.D[5]);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o.bc[c] = -lm * eg * nc[c];
+      for (int c = 0; c < 3; ++c) o.b[c] = fma(-eg, tn[c], o.b[c]);
     } else {
-      o.chi_g = gmm_nondeg(gm, asc, P.R, p, o.Hc, o.bc);
+      double Hc[6], bc[3];
+      o.chi_g = gmm_nondeg(gm, asc, P.R, p, Hc, bc);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) o.D[c] += Hc[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o.b[c] += bc[c];
     }
   }
   return chi_r;
@@ -308,53 +316,36 @@ GL_DEV void sym3_inv_fast(const double* S, double* I) {
   I[5] = (S[0] * S[3] - S[1] * S[1]) * id;
 }
 
-GL_DEV void point_solve_fast(const Lin& o, double lambda, double* Dinv, double* b, double* u) {
-  double D[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) D[c] = o.A[c] + o.Hc[c];
-  D[0] += lambda;
-  D[3] += lambda;
-  D[5] += lambda;
+GL_DEV void point_solve_fast(const Lin& o, double lambda, double* Dinv, double* u) {
+  const double D[6] = {o.D[0] + lambda, o.D[1], o.D[2], o.D[3] + lambda, o.D[4], o.D[5] + lambda};
   sym3_inv_fast(D, Dinv);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) b[c] = o.a[c] + o.bc[c];
-  sym3_mul_vec(Dinv, b, u);
+  sym3_mul_vec(Dinv, o.b, u);
 }
 
 // acc[0..20] += upper(G^T C G), acc[21..26] += G^T c,  C symmetric (sym6)  (callers pass a zeroed v)
 GL_DEV void accum_pose_sym(const double* q, const double* C, const double* c, double* acc) {
+  // M = [q]x C (row r, column j) = (q x C[:, j])[r];  TL = [q]x C [q]x^T accumulated straight into acc
+  // with two FMAs per entry (explicit: contraction alone would leave mul + fma + add)
   const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
   double M[9];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const double col[3] = {Cf[j], Cf[3 + j], Cf[6 + j]};
-    double r[3];
-    cross(q, col, r);
-    M[j] = r[0];
-    M[3 + j] = r[1];
-    M[6 + j] = r[2];
+    M[j] = fma(q[1], Cf[6 + j], -q[2] * Cf[3 + j]);
+    M[3 + j] = fma(q[2], Cf[j], -q[0] * Cf[6 + j]);
+    M[6 + j] = fma(q[0], Cf[3 + j], -q[1] * Cf[j]);
   }
-  double TL[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    double r[3];
-    cross(q, &M[i * 3], r);
-    TL[i * 3] = r[0];
-    TL[i * 3 + 1] = r[1];
-    TL[i * 3 + 2] = r[2];
-  }
-  acc[0] += TL[0];
-  acc[1] += TL[1];
-  acc[2] += TL[2];
+  acc[0] = fma(q[1], M[2], fma(-q[2], M[1], acc[0]));
+  acc[1] = fma(q[2], M[0], fma(-q[0], M[2], acc[1]));
+  acc[2] = fma(q[0], M[1], fma(-q[1], M[0], acc[2]));
   acc[3] += M[0];
   acc[4] += M[1];
   acc[5] += M[2];
-  acc[6] += TL[4];
-  acc[7] += TL[5];
+  acc[6] = fma(q[2], M[3], fma(-q[0], M[5], acc[6]));
+  acc[7] = fma(q[0], M[4], fma(-q[1], M[3], acc[7]));
   acc[8] += M[3];
   acc[9] += M[4];
   acc[10] += M[5];
-  acc[11] += TL[8];
+  acc[11] = fma(q[0], M[7], fma(-q[1], M[6], acc[11]));
   acc[12] += M[6];
   acc[13] += M[7];
   acc[14] += M[8];
@@ -364,11 +355,9 @@ GL_DEV void accum_pose_sym(const double* q, const double* C, const double* c, do
   acc[18] += C[3];
   acc[19] += C[4];
   acc[20] += C[5];
-  double qc[3];
-  cross(q, c, qc);
-  acc[21] += qc[0];
-  acc[22] += qc[1];
-  acc[23] += qc[2];
+  acc[21] = fma(q[1], c[2], fma(-q[2], c[1], acc[21]));
+  acc[22] = fma(q[2], c[0], fma(-q[0], c[2], acc[22]));
+  acc[23] = fma(q[0], c[1], fma(-q[1], c[0], acc[23]));
   acc[24] += c[0];
   acc[25] += c[1];
   acc[26] += c[2];
@@ -377,17 +366,12 @@ GL_DEV void accum_pose_sym(const double* q, const double* C, const double* c, do
 // C = A - (A Dinv) A (symmetric sym6), AD = A Dinv (3x3)
 GL_DEV void schur_C(const double* A, const double* AD, double* C) {
   const double Af[9] = {A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5]};
-  double ADA[9];
+  const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = i; j < 3; ++j) ADA[i * 3 + j] = AD[i * 3] * Af[j] + AD[i * 3 + 1] * Af[3 + j] + AD[i * 3 + 2] * Af[6 + j];
-  C[0] = A[0] - ADA[0];
-  C[1] = A[1] - ADA[1];
-  C[2] = A[2] - ADA[2];
-  C[3] = A[3] - ADA[4];
-  C[4] = A[4] - ADA[5];
-  C[5] = A[5] - ADA[8];
+  for (int e = 0; e < 6; ++e) {
+    const int i = ij[e][0], j = ij[e][1];
+    C[e] = fma(-AD[i * 3], Af[j], fma(-AD[i * 3 + 1], Af[3 + j], fma(-AD[i * 3 + 2], Af[6 + j], A[e])));
+  }
 }
 
 // two-level deterministic workgroup reduction (all threads get the NV totals)
@@ -559,8 +543,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
         Lin o;
         lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
-        const double Hf[9] = {o.A[0] + o.Hc[0], o.A[1] + o.Hc[1], o.A[2] + o.Hc[2], o.A[1] + o.Hc[1], o.A[3] + o.Hc[3],
-                              o.A[4] + o.Hc[4], o.A[2] + o.Hc[2], o.A[4] + o.Hc[4], o.A[5] + o.Hc[5]};
+        const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           double s = 0.0;
@@ -597,20 +580,20 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         const double c2 = lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
         if (c.ar) D.chir[c.l] = c2;  // computeActiveErrors
         acc[27] += o.rho0_r + o.chi_g;
-        double Dinv[6], b[3], u[3];
-        point_solve_fast(o, lambda, Dinv, b, u);
-        acc[28] += u[0] * b[0] + u[1] * b[1] + u[2] * b[2];
+        double Dinv[6], u[3];
+        point_solve_fast(o, lambda, Dinv, u);
+        acc[28] = fma(u[0], o.b[0], fma(u[1], o.b[1], fma(u[2], o.b[2], acc[28])));
 #pragma unroll
         for (int j = 0; j < 3; ++j) D.un[j * MCAP + c.l] = __float_as_int((float)u[j]);
         if (c.ar) {
-          double C[6], Au[3], cc[3], AD[9];
+          double C[6], cc[3], AD[9];
           sym3_mul(o.A, Dinv, AD);
 #pragma unroll
           for (int j = 0; j < 9; ++j) D.un[(3 + j) * MCAP + c.l] = __float_as_int((float)AD[j]);
           schur_C(o.A, AD, C);
-          sym3_mul_vec(o.A, u, Au);
-#pragma unroll
-          for (int j = 0; j < 3; ++j) cc[j] = o.a[j] - Au[j];
+          cc[0] = fma(-o.A[0], u[0], fma(-o.A[1], u[1], fma(-o.A[2], u[2], o.a[0])));
+          cc[1] = fma(-o.A[1], u[0], fma(-o.A[3], u[1], fma(-o.A[4], u[2], o.a[1])));
+          cc[2] = fma(-o.A[2], u[0], fma(-o.A[4], u[1], fma(-o.A[5], u[2], o.a[2])));
           accum_pose_sym(o.q, C, cc, acc);
         } else {
 #pragma unroll
