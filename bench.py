@@ -62,46 +62,48 @@ def measured_traffic(kernel, frames_per_launch):
     return None, None
 
 
-def cpu_baseline(mean, cov, cam, frames, budget_s=15.0):
-    """The oracle (CPU port of the reference algorithm) on the same workload, 1 thread,
-    bounded sample."""
-    from tests import oracle_lib
-    orc = oracle_lib.load()
-    h = orc.gmm_create(mean, cov)
-    t0 = time.perf_counter()
-    n = 0
-    t_assoc = 0.0
-    for f in frames:
-        ta = time.perf_counter()
-        idx, d2 = orc.associate3d(h, f["Xw"])
-        t_assoc += time.perf_counter() - ta
-        assoc = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
-        L = f["Xw"].shape[0]
-        orc.joint_optimization(h, cam, 1, 0, f["pose_init"][None], np.zeros(1, np.uint8), f["Xw"], assoc,
-                               np.arange(L + 1, dtype=np.int32), np.zeros(L, np.int32), f["obs"], f["octave"])
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    # the same work on all host cores (one frame per thread; the oracle is re-entrant and ctypes
-    # releases the GIL) -- reported beside the 1-thread figure, never mixed with it (SURVEY 8d)
-    ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    allc = None
-    if ncore > 1:
-        from concurrent.futures import ThreadPoolExecutor
+_W = {}
 
-        def one(f):
-            idx, d2 = orc.associate3d(h, f["Xw"])
-            assoc = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
-            L = f["Xw"].shape[0]
-            orc.joint_optimization(h, cam, 1, 0, f["pose_init"][None], np.zeros(1, np.uint8), f["Xw"].copy(), assoc,
-                                   np.arange(L + 1, dtype=np.int32), np.zeros(L, np.int32), f["obs"], f["octave"])
-        m = min(len(frames), max(2 * ncore, int(0.5 * budget_s * ncore * n / dt)))
-        ta = time.perf_counter()
-        with ThreadPoolExecutor(ncore) as ex:
-            list(ex.map(one, frames[:m]))
-        allc = {"value": m / (time.perf_counter() - ta), "unit": "frames/s", "cores": ncore, "frames": m}
-    orc.gmm_destroy(h)
+
+def _cpu_one(i):
+    """One frame through the oracle (CPU port of the reference algorithm): all-pairs association,
+    chi2 <= 9 gate, joint_optimization with one free pose."""
+    orc, h, cam, frames = _W["orc"], _W["h"], _W["cam"], _W["frames"]
+    f = frames[i]
+    ta = time.perf_counter()
+    idx, d2 = orc.associate3d(h, f["Xw"])
+    ta = time.perf_counter() - ta
+    assoc = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
+    L = f["Xw"].shape[0]
+    orc.joint_optimization(h, cam, 1, 0, f["pose_init"][None].copy(), np.zeros(1, np.uint8), f["Xw"].copy(), assoc,
+                           np.arange(L + 1, dtype=np.int32), np.zeros(L, np.int32), f["obs"], f["octave"])
+    return ta
+
+
+def cpu_baseline_worker(seed0, budget_s):
+    """Runs in a fresh process (no HIP state, so forking a pool is safe): the oracle on the first
+    frames of the same workload, 1 thread, then one frame per worker process on all host cores."""
+    import multiprocessing as mp
+    from tests import oracle_lib
+    ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_all = 4 * ncore if ncore > 1 else 0
+    mean, cov, cam, frames = make_workload(max(n_all, 400), seed0)
+    orc = oracle_lib.load()
+    _W.update(orc=orc, h=orc.gmm_create(mean, cov), cam=cam, frames=frames)
+    t0 = time.perf_counter()
+    n, t_assoc = 0, 0.0
+    while n < len(frames) and time.perf_counter() - t0 < budget_s:
+        t_assoc += _cpu_one(n)
+        n += 1
+    dt = time.perf_counter() - t0
+    allc = None
+    if n_all:
+        with mp.get_context("fork").Pool(ncore) as pool:
+            pool.map(_cpu_one, range(ncore))  # warm the workers
+            ta = time.perf_counter()
+            pool.map(_cpu_one, range(n_all), chunksize=1)
+            allc = {"value": n_all / (time.perf_counter() - ta), "unit": "frames/s", "cores": ncore, "frames": n_all,
+                    "how": "one frame per forked worker process"}
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -111,10 +113,20 @@ def cpu_baseline(mean, cov, cam, frames, budget_s=15.0):
                     break
     except OSError:
         pass
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same workload (oracle = CPU port of the reference algorithm: all-pairs "
-                      "associate3d + joint_optimization, 1 thread); association alone %.1f ms/frame" % (n, 1e3 * t_assoc / n),
-            "cpu_model": model, "host_cores": ncore, "all_cores": allc}
+    print(json.dumps({"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                      "sample": "%d frames of the same workload (oracle = CPU port of the reference algorithm: all-pairs "
+                                "associate3d + joint_optimization, 1 thread); association alone %.1f ms/frame"
+                                % (n, 1e3 * t_assoc / n),
+                      "cpu_model": model, "host_cores": ncore, "all_cores": allc}))
+
+
+def cpu_baseline(seed0, budget_s=15.0):
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(seed0), str(budget_s)],
+                       capture_output=True, text=True, cwd=ROOT)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline worker failed: " + r.stderr[-2000:])
+    return json.loads(r.stdout.strip().split("\n")[-1])
 
 
 def main():
@@ -124,7 +136,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("SEED", "BUDGET_S"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(int(args.cpu_baseline_worker[0]), float(args.cpu_baseline_worker[1]))
+        return
 
     import torch
     import torch.distributed as dist
@@ -284,7 +300,7 @@ def main():
             "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine": ba_ms / max(args.steps, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mean, cov, cam, frames)
+            out["cpu_baseline"] = cpu_baseline(20200901 + 100000 * rank)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

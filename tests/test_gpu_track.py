@@ -1,4 +1,4 @@
-"""GPU parity: gl_track_frames (exhaustive association + single-pose jointOptimization with
+"""GPU parity: gl_track_frames (exact all-component association + single-pose jointOptimization with
 Schur-marginalised points) vs the oracle's associate3d + joint_optimization.
 Tolerance (north_star): pose within 1e-6 m / 1e-6 rad; indices exact."""
 import numpy as np
@@ -38,8 +38,13 @@ def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, mapname, M, s
     Xw = torch.from_numpy(np.stack([f["Xw"] for f in frames])).cuda()
     obs = torch.from_numpy(np.stack([f["obs"] for f in frames])).cuda()
     octv = torch.from_numpy(np.stack([f["octave"] for f in frames])).cuda()
+    pose_b, Xw_b = pose.clone(), Xw.clone()
     assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, obs, octv)
+    # without the chi2 output the cell index does not resolve the points above the gate (they are
+    # dropped either way): the results must be bit-identical
+    assoc_b, _ = gmmloc_amd.track_frames(ctx, g, cam, prm, pose_b, Xw_b, obs, octv, want_d2=False)
     torch.cuda.synchronize()
+    assert torch.equal(assoc, assoc_b) and torch.equal(pose, pose_b) and torch.equal(Xw, Xw_b)
     pose, Xw, assoc, d2 = pose.cpu().numpy(), Xw.cpu().numpy(), assoc.cpu().numpy(), d2.cpu().numpy()
     for i, f in enumerate(frames):
         keep, p_ref, pts_ref, a_ref, idx0, d20 = oracle_track(oracle, h, cam, f)
