@@ -80,12 +80,35 @@ def _cpu_one(i):
     return ta
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a box
+    can expose 256 hardware threads and grant 8 of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(float(txt[0]) / float(txt[1])))))
+            else:
+                q = float(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    per = float(fh.read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline_worker(seed0, budget_s):
     """Runs in a fresh process (no HIP state, so forking a pool is safe): the oracle on the first
     frames of the same workload, 1 thread, then one frame per worker process on all host cores."""
     import multiprocessing as mp
     from tests import oracle_lib
-    ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncore = host_cores()
     n_all = 4 * ncore if ncore > 1 else 0
     mean, cov, cam, frames = make_workload(max(n_all, 400), seed0)
     orc = oracle_lib.load()
@@ -117,7 +140,8 @@ def cpu_baseline_worker(seed0, budget_s):
                       "sample": "%d frames of the same workload (oracle = CPU port of the reference algorithm: all-pairs "
                                 "associate3d + joint_optimization, 1 thread); association alone %.1f ms/frame"
                                 % (n, 1e3 * t_assoc / n),
-                      "cpu_model": model, "host_cores": ncore, "all_cores": allc}))
+                      "cpu_model": model, "host_cores": ncore,
+                      "host_hw_threads": os.cpu_count(), "all_cores": allc}))
 
 
 def cpu_baseline(seed0, budget_s=15.0):
