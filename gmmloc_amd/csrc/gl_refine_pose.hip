@@ -14,6 +14,8 @@
 // 1e-5 max diag, rho test with +1e-3, x1/3..2/3 / x nu schedule, 10 trials),
 // SparseOptimizer::optimize, levels via initializeOptimization(0), stale per-edge
 // errors read by e->chi2() after the last trial.
+#include <cstdlib>
+
 #include "gl_device.hpp"
 #include "gl_internal.hpp"
 
@@ -123,7 +125,7 @@ GL_DEV void unpack_sym6(const double* acc, double* H) {
     }
 }
 
-__global__ __launch_bounds__(T_POSE) void k_optimize_current_pose(PoseKParams kp, int B, int M,
+__global__ __launch_bounds__(T_POSE) void k_optimize_current_pose_block(PoseKParams kp, int B, int M,
                                                                   double* __restrict__ pose_io,
                                                                   const double* __restrict__ Xw_all,
                                                                   const double* __restrict__ obs_all,
@@ -288,6 +290,358 @@ __global__ __launch_bounds__(T_POSE) void k_optimize_current_pose(PoseKParams kp
   }
 }
 
+
+// =============================================================================================
+// One WAVE per frame (the default path).  The workgroup version above spends its time in the
+// serial 6x6 solve + exp() that every LM trial needs (all 256 threads repeat it, 1 frame per CU at
+// 256 VGPRs); a frame's edges (<= 1200) are little work per pass, so the frame fits one wave:
+//   * lane l owns the edges l, l+64, ...; no workgroup barrier and no LDS anywhere;
+//   * the 28 sums are reduced with the wave reduce-scatter into 28 LDS words; the current and the
+//     trial system live there (224 B each), not in registers;
+//   * 6x6 LDL^T on the packed triangle with reciprocal pivots, pose kept as (R, t) in SGPRs and
+//     updated by Rodrigues (short series below |theta| = 0.01);
+//   * <= 128 VGPRs: 4 waves per SIMD = 16 frames per CU in flight, so the serial sections of
+//     different frames overlap.
+// Same control flow as above (g2o Levenberg restated, 4 gating rounds x optimize(10)).
+// =============================================================================================
+GL_DEV double rcp_nr(double a) {
+  double x = __builtin_amdgcn_rcp(a);
+  x = fma(fma(-a, x, 1.0), x, x);
+  x = fma(fma(-a, x, 1.0), x, x);
+  return x;
+}
+GL_DEV double uni(double v) {  // wave-uniform value -> SGPR pair
+  union {
+    double d;
+    int i[2];
+  } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+// the 28 wave totals of acc[] -> dst[0..27] in LDS (one wave per workgroup: the barrier is a no-op
+// that orders the LDS write before the broadcast reads)
+GL_DEV void wave_totals28(double* acc, double* dst) {
+#pragma unroll
+  for (int i = 28; i < 32; ++i) acc[i] = 0.0;
+  const double r = wave_reduce_scatter32(acc);
+  const int lane = threadIdx.x & 63;
+  __syncthreads();
+  if (wave_slot_owner(lane)) dst[wave_slot(lane)] = r;
+  __syncthreads();
+}
+GL_DEV double wave_total1(double v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += shfl_xor_f64(v, o);
+  return uni(v);
+}
+
+struct PoseRt {
+  double R[9], t[3];
+};
+GL_DEV PoseRt rt_uni(const PoseRt& P) {
+  PoseRt U;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) U.R[i] = uni(P.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) U.t[i] = uni(P.t[i]);
+  return U;
+}
+// exp(dx) * P   (SE3Quat::exp, VertexSE3Expmap::oplusImpl) on the rotation matrix
+GL_DEV PoseRt rt_update(const PoseRt& P, const double* u) {
+  const double th2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+  double a, b, c;
+  if (th2 < 1e-4) {
+    a = fma(fma(fma(-1.0 / 5040, th2, 1.0 / 120), th2, -1.0 / 6), th2, 1.0);
+    b = fma(fma(fma(-1.0 / 40320, th2, 1.0 / 720), th2, -1.0 / 24), th2, 0.5);
+    c = fma(fma(fma(-1.0 / 362880, th2, 1.0 / 5040), th2, -1.0 / 120), th2, 1.0 / 6);
+  } else {
+    const double theta = sqrt(th2);
+    double st, ct;
+    sincos(theta, &st, &ct);
+    const double it = 1.0 / theta;
+    a = st * it;
+    b = (1 - ct) * it * it;
+    c = (theta - st) * it * it * it;
+  }
+  double Om[9], Om2[9], dR[9], V[9];
+  skew(u, Om);
+  mm3(Om, Om, Om2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    dR[i] = I + a * Om[i] + b * Om2[i];
+    V[i] = I + b * Om[i] + c * Om2[i];
+  }
+  PoseRt N;
+  mm3(dR, P.R, N.R);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    N.t[i] = dR[i * 3] * P.t[0] + dR[i * 3 + 1] * P.t[1] + dR[i * 3 + 2] * P.t[2] + V[i * 3] * u[3] + V[i * 3 + 1] * u[4] +
+             V[i * 3 + 2] * u[5];
+  return rt_uni(N);
+}
+
+// 6x6 LDL^T on the packed upper triangle (row-major i <= j, as accumulated), (H + lambda I) x = b;
+// fails on a non-positive / non-finite pivot like ldlt_solve<6>(..., require_positive = true)
+#define GL_PU(i, j) ((i) * 6 - (i) * ((i)-1) / 2 + ((j) - (i)))
+GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, double* x) {
+  double a[21], iD[6], y[6];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) a[i] = H[i];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = a[GL_PU(j, j)] + lambda;
+#pragma unroll
+    for (int kk = 0; kk < j; ++kk) d -= a[GL_PU(kk, j)] * a[GL_PU(kk, j)] * a[GL_PU(kk, kk)];
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+    a[GL_PU(j, j)] = d;
+    iD[j] = rcp_nr(d);
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double s = a[GL_PU(j, i)];
+#pragma unroll
+      for (int kk = 0; kk < j; ++kk) s -= a[GL_PU(kk, i)] * a[GL_PU(kk, j)] * a[GL_PU(kk, kk)];
+      a[GL_PU(j, i)] = s * iD[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int kk = 0; kk < i; ++kk) s -= a[GL_PU(kk, i)] * y[kk];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] *= iD[i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+#pragma unroll
+    for (int kk = i + 1; kk < 6; ++kk) s -= a[GL_PU(i, kk)] * x[kk];
+    x[i] = s;
+  }
+  return ok;
+}
+
+// one pass over the lane's edges at pose P: acc[0..20] H upper triangle, acc[21..26] b, acc[27] robust chi2
+GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int M,
+                           const double* __restrict__ Xw, const double* __restrict__ obs,
+                           const int32_t* __restrict__ octave, const uint8_t* __restrict__ level,
+                           double* __restrict__ chi2_e, double* acc) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  for (int e = threadIdx.x & 63; e < M; e += 64) {
+    const int oc = octave[e];
+    if (oc < 0 || level[e] != 0) continue;
+    const double X = Xw[(size_t)e * 3 + 0], Y = Xw[(size_t)e * 3 + 1], Z = Xw[(size_t)e * 3 + 2];
+    const double ou = obs[(size_t)e * 3 + 0], ov = obs[(size_t)e * 3 + 1], our = obs[(size_t)e * 3 + 2];
+    const bool stereo = !(our < 0);
+    const double x = P.R[0] * X + P.R[1] * Y + P.R[2] * Z + P.t[0];
+    const double y = P.R[3] * X + P.R[4] * Y + P.R[5] * Z + P.t[1];
+    const double z = P.R[6] * X + P.R[7] * Y + P.R[8] * Z + P.t[2];
+    const double invz = rcp_nr(z), invz2 = invz * invz;
+    const double pu = x * invz * kp.fx + kp.cx;
+    const double pv = y * invz * kp.fy + kp.cy;
+    const double e0 = ou - pu, e1 = ov - pv;
+    const double e2 = stereo ? (our - (pu - kp.bf * invz)) : 0.0;
+    const double s = s2tab[oc];
+    const double chi2 = e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2);
+    chi2_e[e] = chi2;
+    double rho0 = chi2, rho1 = 1.0;
+    if (robust) huber(chi2, stereo ? kp.delta_stereo : kp.delta_mono, rho0, rho1);
+    const double w = rho1 * s;
+    double J0[6], J1[6], J2[6];
+    J0[0] = x * y * invz2 * kp.fx;
+    J0[1] = -(1 + (x * x * invz2)) * kp.fx;
+    J0[2] = y * invz * kp.fx;
+    J0[3] = -invz * kp.fx;
+    J0[4] = 0;
+    J0[5] = x * invz2 * kp.fx;
+    J1[0] = (1 + y * y * invz2) * kp.fy;
+    J1[1] = -x * y * invz2 * kp.fy;
+    J1[2] = -x * invz * kp.fy;
+    J1[3] = 0;
+    J1[4] = -invz * kp.fy;
+    J1[5] = y * invz2 * kp.fy;
+    const double sb = stereo ? 1.0 : 0.0;
+    J2[0] = sb * (J0[0] - kp.bf * y * invz2);
+    J2[1] = sb * (J0[1] + kp.bf * x * invz2);
+    J2[2] = sb * J0[2];
+    J2[3] = sb * J0[3];
+    J2[4] = 0;
+    J2[5] = sb * (J0[5] - kp.bf * invz2);
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double w0 = w * J0[i], w1 = w * J1[i], w2 = w * J2[i];
+#pragma unroll
+      for (int j = i; j < 6; ++j) {
+        acc[q] = fma(w0, J0[j], fma(w1, J1[j], fma(w2, J2[j], acc[q])));
+        ++q;
+      }
+      acc[21 + i] = fma(-w0, e0, fma(-w1, e1, fma(-w2, e2, acc[21 + i])));
+    }
+    acc[27] += rho0;
+  }
+}
+
+#ifndef GL_POSE_WPS
+#define GL_POSE_WPS 3  // waves per SIMD the register budget is capped for (measured: 3 > 2 > 4, tools/pose_ab.py)
+#endif
+__global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseKParams kp, int B, int M,
+                                                                 double* __restrict__ pose_io,
+                                                                 const double* __restrict__ Xw_all,
+                                                                 const double* __restrict__ obs_all,
+                                                                 const int32_t* __restrict__ oct_all,
+                                                                 uint8_t* __restrict__ outlier_all,
+                                                                 int32_t* __restrict__ ninlier,
+                                                                 double* __restrict__ chi2_all) {
+  __shared__ double s2tab[8];
+  __shared__ double H[32], Hn[32];  // current / trial system {H upper (21), b (6), chi2}
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= B) return;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s2tab[j] = kp.s2inv[j];
+  }
+  __syncthreads();  // single wave: orders the table write before the reads
+  const double* Xw = Xw_all + (size_t)f * M * 3;
+  const double* obs = obs_all + (size_t)f * M * 3;
+  const int32_t* octave = oct_all + (size_t)f * M;
+  uint8_t* level = outlier_all + (size_t)f * M;  // is_outlier_ <=> level 1
+  double* chi2_e = chi2_all + (size_t)f * M;
+
+  // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
+  double cnt = 0.0;
+  for (int e = lane; e < M; e += 64) {
+    level[e] = 0;
+    if (octave[e] >= 0) cnt += 1.0;
+  }
+  const int n_init = (int)wave_total1(cnt);
+  if (n_init < 3) {  // :139-140
+    if (lane == 0) ninlier[f] = 0;
+    return;
+  }
+  PoseRt P0;
+  {
+    const SE3 T0 = se3_load(pose_io + (size_t)f * 7);
+    qtoR(T0.r, P0.R);
+    P0.t[0] = T0.t[0];
+    P0.t[1] = T0.t[1];
+    P0.t[2] = T0.t[2];
+    P0 = rt_uni(P0);
+  }
+  PoseRt P = P0;
+  double acc[32];
+  bool robust = true;
+  int nbad = 0;
+#pragma unroll 1
+  for (int round = 0; round < 4; ++round) {
+    P = P0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
+    cnt = 0.0;
+    for (int e = lane; e < M; e += 64)
+      if (octave[e] >= 0 && level[e] == 0) cnt += 1.0;
+    const int nactive = (int)wave_total1(cnt);
+    if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
+      wave_pose_eval(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
+      wave_totals28(acc, H);
+      double currentChi = uni(H[27]);
+      bool sys_valid = true;
+      double lambda = 0.0, ni = 2.0;
+#pragma unroll 1
+      for (int it = 0; it < 10; ++it) {
+        if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
+          wave_pose_eval(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
+          wave_totals28(acc, H);
+          currentChi = uni(H[27]);
+          sys_valid = true;
+        }
+        if (it == 0) {  // computeLambdaInit: tau * max |diag|
+          double md = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) md = fmax(fabs(H[GL_PU(i, i)]), md);
+          lambda = uni(1e-5 * md);
+          ni = 2.0;
+        }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+          double dx[6];
+          const bool ok2 = ldlt6_packed_pos(H, H + 21, lambda, dx);
+          PoseRt Pn = P;
+          double tempChi;
+          if (ok2) {
+            Pn = rt_update(P, dx);
+            wave_pose_eval(kp, s2tab, Pn, robust, M, Xw, obs, octave, level, chi2_e, acc);
+            wave_totals28(acc, Hn);
+            tempChi = uni(Hn[27]);
+          } else {
+            tempChi = 1.7976931348623157e308;
+          }
+          double scale = 0.0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) scale += dx[j] * (lambda * dx[j] + H[21 + j]);
+          scale += 1e-3;
+          rho = uni((currentChi - tempChi) / scale);
+          if (rho > 0 && isfinite(tempChi)) {
+            const double u = 2 * rho - 1;
+            double alpha = 1. - u * u * u;
+            alpha = fmin(alpha, 2. / 3.);
+            lambda *= fmax(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+            P = Pn;
+            __syncthreads();
+            if (lane < 27) H[lane] = Hn[lane];
+            __syncthreads();
+          } else {
+            lambda *= ni;
+            ni *= 2;
+            // estimate restored (pop); H, b stay; per-edge errors stay those of the rejected trial
+            // until the next computeActiveErrors
+            if (!(rho < 0)) sys_valid = false;
+          }
+          qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) break;  // Terminate
+      }
+    }
+    // gating (:156-203): outliers are re-evaluated at the current estimate, inliers use the error of
+    // the last computeActiveErrors; chi2 compared as float.
+    cnt = 0.0;
+    for (int e = lane; e < M; e += 64) {
+      const int oc = octave[e];
+      if (oc < 0) continue;
+      double c2;
+      if (level[e] != 0)
+        c2 = pose_edge_chi2(kp, P.R, P.t, Xw + (size_t)e * 3, obs + (size_t)e * 3, oc);
+      else
+        c2 = chi2_e[e];
+      const bool stereo = !(obs[(size_t)e * 3 + 2] < 0);
+      const float thr = stereo ? 7.815f : 5.991f;
+      const bool bad = (float)c2 > thr;
+      level[e] = bad ? 1 : 0;
+      if (bad) cnt += 1.0;
+    }
+    nbad = (int)wave_total1(cnt);
+    if (round == 2) robust = false;  // e->setRobustKernel(0) at it == 2
+    if (n_init < 10) break;          // optimizer.edges().size() < 10
+  }
+  if (lane == 0) {
+    SE3 T;
+    T.r = qfromR(P.R);
+    T.t[0] = P.t[0];
+    T.t[1] = P.t[1];
+    T.t[2] = P.t[2];
+    normalize_rotation(T);
+    se3_store(T, pose_io + (size_t)f * 7);
+    ninlier[f] = n_init - nbad;
+  }
+}
+
 }  // namespace
 
 extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M,
@@ -313,8 +667,13 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   if (rc != GL_OK) return rc;
   {
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
-    k_optimize_current_pose<<<B, T_POSE, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                         ninlier_dev, (double*)scratch);
+    static const bool block_version = getenv("GMMLOC_POSE_BLOCK") != nullptr;  // A/B knob: the workgroup-per-frame kernel
+    if (block_version)
+      k_optimize_current_pose_block<<<B, T_POSE, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev,
+                                                                 outlier_dev, ninlier_dev, (double*)scratch);
+    else
+      k_optimize_current_pose<<<B, 64, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                       ninlier_dev, (double*)scratch);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

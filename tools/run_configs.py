@@ -124,7 +124,17 @@ def config3(torch, ctx, out, cap):
     t_s2d = ev_time(torch, lambda: g.search2d(cam, pose, uv, nfeat, 5), 2, ctx.stream)
     t_pose = ev_time(torch, lambda: gmmloc_amd.optimize_current_pose(ctx, cam, prm, pose.clone(), Xw, obs, octv), 3, ctx.stream)
     t_trk = ev_time(torch, lambda: gmmloc_amd.track_frames(ctx, g, cam, prm, pose.clone(), Xw.clone(), obs, octv, False), 3, ctx.stream)
+    # the same frames grouped by size on the host (<= 500 / <= 1000 / rest), each group padded to its
+    # own maximum: the refine then runs 4 / 2 / 1 frames per CU
+    groups = [[f for f in frames if lo < f["Xw"].shape[0] <= hi] for lo, hi in ((0, 500), (500, 1000), (1000, 1 << 30))]
+    packed = [pad_batch(torch, gfr, max(f["Xw"].shape[0] for f in gfr)) for gfr in groups if gfr]
+
+    def run_groups():
+        for gp, gx, go, gc in packed:
+            gmmloc_amd.track_frames(ctx, g, cam, prm, gp.clone(), gx.clone(), go, gc, False)
+    t_trk_g = ev_time(torch, run_groups, 3, ctx.stream)
     out({"config": "3: V1_03-shaped replay, synthetic-from-real-map (v1.gmm K=3299 + gt_sync poses), M~U{150..1200}",
+         "associate3d+structureBA_grouped_by_size_frames_per_s": B / t_trk_g,
          "frames": B,
          "search2d_renderView+searchCorrespondence_frames_per_s": B / t_s2d,
          "optimizeCurrentPose_4x10LM_frames_per_s": B / t_pose,
