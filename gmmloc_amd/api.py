@@ -361,3 +361,21 @@ def joint_optimization(ctx, gmm, cam, prm, P, F, poses, prior, points, assoc, ob
                                          _ptr(iters)))
     ctx._exit()
     return dropped, erase, iters
+
+
+def search_by_projection(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
+                         mp_valid, mp_desc, th=3.0, nn_ratio=0.8, scale_factor=1.2):
+    """ORBmatcher::searchByProjection (orb_matcher.cpp:27-110) for B frames.  feat_* (B,NF,...), mp_* (B,NP,...)
+    device tensors -> (feat_match int32 (B,NF), nmatches int32 (B,))."""
+    import torch
+    B, NF = feat_oct.shape
+    NP = mp_level.shape[1]
+    match = torch.empty((B, NF), dtype=torch.int32, device=feat_oct.device)
+    nm = torch.empty(B, dtype=torch.int32, device=feat_oct.device)
+    ctx._enter()
+    _check(ctx.lib.gl_search_by_projection(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv),
+                                           _ptr(feat_ur), _ptr(feat_oct), _ptr(feat_desc), _ptr(feat_taken), _ptr(mp_uvr),
+                                           _ptr(mp_level), _ptr(mp_viewcos), _ptr(mp_valid), _ptr(mp_desc), float(th),
+                                           float(nn_ratio), _ptr(match), _ptr(nm)))
+    ctx._exit()
+    return match, nm

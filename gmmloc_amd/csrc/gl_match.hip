@@ -1,0 +1,276 @@
+// ORBmatcher::searchByProjection(Frame&, mappts, stats, th) (orb_matcher.cpp:27-110) for B frames:
+// the step that produces the 3-D / 2-D correspondences Tracking::optimizeCurrentPose consumes
+// (SURVEY.md 8f rank 2).  Integer / byte work: a 64 x 48 bucket grid of the frame's features
+// (Frame::assignFeaturesToGrid, frame.cpp:54-79), a window walk per projected map point
+// (Frame::getFeaturesInArea, frame.cpp:121-177), 256-bit Hamming distances
+// (ORBmatcher::DescriptorDistance, orb_matcher.cpp:580-596), best / second-best with the
+// level-aware ratio test.
+//
+// The reference loop is ORDER DEPENDENT: a feature taken by map point m is skipped by every later
+// map point, which then falls back to its next-best candidate.  The kernel reproduces that exactly
+// with a fixed-point iteration: in every round each map point m picks its best feature among those
+// not owned by a map point < m (owners of the previous round), then owner[f] = min{m : choice(m) = f}
+// is rebuilt with LDS atomics; by induction the choices of map points 0..r-1 are final after round
+// r, and the iteration stops when the owner table repeats (2-5 rounds on realistic frames).
+//
+// One workgroup per frame; grid CSR, owner tables and choices live in LDS.  Every float / double
+// conversion of the reference (float window, float grid scale, double feature coordinates) is kept
+// so that the candidate sets, their visiting order (cell column, cell row, feature index) and hence
+// the ties are identical.
+#include <climits>
+
+#include "gl_internal.hpp"
+
+namespace {
+
+constexpr int GC = 64, GR = 48, NCELL = GC * GR;  // frame::grid_cols / grid_rows (config.h:57)
+constexpr int T_M = 512;
+
+struct MatchP {
+  int NF, NP;
+  float col_inv, row_inv, th, nn_ratio;
+  float sf[8];
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* __restrict__ b) {
+  int d = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) d += __popc(a[w] ^ b[w]);
+  return d;
+}
+
+__global__ __launch_bounds__(T_M) void k_search_by_projection(
+    MatchP P, int B, const double* __restrict__ feat_uv_all, const float* __restrict__ feat_ur_all,
+    const int32_t* __restrict__ feat_oct_all, const uint8_t* __restrict__ feat_desc_all,
+    const uint8_t* __restrict__ feat_taken_all, const double* __restrict__ mp_uvr_all,
+    const int32_t* __restrict__ mp_level_all, const double* __restrict__ mp_viewcos_all,
+    const uint8_t* __restrict__ mp_valid_all, const uint8_t* __restrict__ mp_desc_all,
+    int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  int32_t* cell_ptr = lds;                   // NCELL + 1
+  int32_t* cursor = cell_ptr + NCELL + 1;    // NCELL (grid build only)
+  int32_t* cell_idx = cursor + NCELL;        // NF
+  int32_t* owner = cell_idx + P.NF;          // NF   owner of the previous round (-1: taken on entry)
+  int32_t* owner_n = owner + P.NF;           // NF   being rebuilt
+  int32_t* choice = owner_n + P.NF;          // NP
+  // per CSR entry, so that the window walk touches LDS only: {u, v} double, {u_right bits, octave}
+  double2* rec_uv = (double2*)(lds + ((2 * NCELL + 1 + 3 * P.NF + P.NP + 3) & ~3));  // 16-byte aligned
+  int2* rec_ro = (int2*)(rec_uv + P.NF);
+  __shared__ int s_changed, s_scan[T_M];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= B) return;
+  const int NF = P.NF, NP = P.NP;
+  const double* feat_uv = feat_uv_all + (size_t)f * NF * 2;
+  const float* feat_ur = feat_ur_all + (size_t)f * NF;
+  const int32_t* feat_oct = feat_oct_all + (size_t)f * NF;
+  const uint32_t* feat_desc = (const uint32_t*)(feat_desc_all + (size_t)f * NF * 32);
+  const uint8_t* feat_taken = feat_taken_all + (size_t)f * NF;
+  const double* mp_uvr = mp_uvr_all + (size_t)f * NP * 3;
+  const int32_t* mp_level = mp_level_all + (size_t)f * NP;
+  const double* mp_viewcos = mp_viewcos_all + (size_t)f * NP;
+  const uint8_t* mp_valid = mp_valid_all + (size_t)f * NP;
+  const uint32_t* mp_desc = (const uint32_t*)(mp_desc_all + (size_t)f * NP * 32);
+
+  // ---- assignFeaturesToGrid: CSR by cell (ix * GR + iy), ascending feature index inside a cell ----
+  for (int c = tid; c <= NCELL; c += T_M) cell_ptr[c] = 0;
+  __syncthreads();
+  auto cell_of = [&](int i) -> int {
+    if (feat_oct[i] < 0) return -1;  // padding slot
+    const double px = round((feat_uv[2 * i] - 0.0f) * P.col_inv), py = round((feat_uv[2 * i + 1] - 0.0f) * P.row_inv);
+    if (!(px >= 0 && px < GC && py >= 0 && py < GR)) return -1;  // also rejects NaN
+    return (int)px * GR + (int)py;
+  };
+  for (int i = tid; i < NF; i += T_M) {
+    const int c = cell_of(i);
+    if (c >= 0) atomicAdd(&cell_ptr[c + 1], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of NCELL counts: each thread scans a contiguous chunk, then the chunk sums
+    constexpr int CH = (NCELL + T_M - 1) / T_M;
+    const int c0 = tid * CH, c1 = min(NCELL, c0 + CH);
+    int s = 0;
+    for (int c = c0; c < c1; ++c) s += cell_ptr[c + 1];
+    s_scan[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int t = 0; t < T_M; ++t) {
+        const int v = s_scan[t];
+        s_scan[t] = run;
+        run += v;
+      }
+    }
+    __syncthreads();
+    int run = s_scan[tid];
+    for (int c = c0; c < c1; ++c) {
+      const int v = cell_ptr[c + 1];
+      cell_ptr[c + 1] = run + v;  // inclusive end; cell_ptr[c] (= end of c-1) is its start
+      run += v;
+    }
+    __syncthreads();
+  }
+  // fill through a per-cell cursor, then put every (short) cell list in ascending feature order: that
+  // is the push_back order of the reference and decides ties between equal Hamming distances
+  for (int c = tid; c < NCELL; c += T_M) cursor[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < NF; i += T_M) {
+    const int c = cell_of(i);
+    if (c >= 0) cell_idx[cell_ptr[c] + atomicAdd(&cursor[c], 1)] = i;
+  }
+  __syncthreads();
+  for (int c = tid; c < NCELL; c += T_M) {
+    const int e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+    for (int e = e0 + 1; e < e1; ++e) {  // insertion sort
+      const int v = cell_idx[e];
+      int k = e - 1;
+      while (k >= e0 && cell_idx[k] > v) {
+        cell_idx[k + 1] = cell_idx[k];
+        --k;
+      }
+      cell_idx[k + 1] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < cell_ptr[NCELL]; e += T_M) {
+    const int i = cell_idx[e];
+    rec_uv[e] = make_double2(feat_uv[2 * i], feat_uv[2 * i + 1]);
+    rec_ro[e] = make_int2(__float_as_int(feat_ur[i]), feat_oct[i]);
+  }
+  __syncthreads();
+
+  // ---- owners on entry -------------------------------------------------------------------------------
+  for (int i = tid; i < NF; i += T_M) owner[i] = feat_taken[i] ? -1 : INT_MAX;
+  __syncthreads();
+
+  const bool bFactor = P.th != 1.0;
+  int rounds = 0;
+  while (true) {
+    for (int i = tid; i < NF; i += T_M) owner_n[i] = feat_taken[i] ? -1 : INT_MAX;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int m = tid; m < NP; m += T_M) {
+      int bestIdx = -1;
+      if (mp_valid[m]) {
+        const int lvl = mp_level[m];
+        float r = ((float)mp_viewcos[m] > 0.998) ? 2.5f : 4.0f;
+        if (bFactor) r *= P.th;
+        const float rr = r * P.sf[lvl & 7];
+        const float x = (float)mp_uvr[3 * m], y = (float)mp_uvr[3 * m + 1];
+        const int x0 = max(0, (int)floorf((x - 0.0f - rr) * P.col_inv));
+        const int x1 = min(GC - 1, (int)ceilf((x - 0.0f + rr) * P.col_inv));
+        const int y0 = max(0, (int)floorf((y - 0.0f - rr) * P.row_inv));
+        const int y1 = min(GR - 1, (int)ceilf((y - 0.0f + rr) * P.row_inv));
+        if (x0 < GC && x1 >= 0 && y0 < GR && y1 >= 0) {
+          const int minLevel = lvl - 1, maxLevel = lvl;
+          const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+          uint32_t dm[8];
+#pragma unroll
+          for (int w = 0; w < 8; ++w) dm[w] = mp_desc[(size_t)m * 8 + w];
+          int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
+          for (int ix = x0; ix <= x1; ++ix) {
+            // cells (ix, y0..y1) are contiguous in the CSR
+            const int e0 = cell_ptr[ix * GR + y0], e1 = cell_ptr[ix * GR + y1 + 1];
+            for (int e = e0; e < e1; ++e) {
+              const int2 ro = rec_ro[e];
+              const int oc = ro.y;
+              if (bCheckLevels) {
+                if (oc < minLevel) continue;
+                if (maxLevel >= 0 && oc > maxLevel) continue;
+              }
+              const double2 fuv = rec_uv[e];
+              const float distx = (float)(fuv.x - (double)x), disty = (float)(fuv.y - (double)y);
+              if (!(fabsf(distx) < rr && fabsf(disty) < rr)) continue;
+              const int idx = cell_idx[e];
+              if (owner[idx] < m) continue;  // taken on entry (-1) or by an earlier map point
+              const float ur = __int_as_float(ro.x);
+              if (ur > 0) {
+                const float er = (float)fabs(mp_uvr[3 * m + 2] - (double)ur);
+                if (er > rr) continue;
+              }
+              const int dist = hamming256(dm, feat_desc + (size_t)idx * 8);
+              if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = oc;
+                bestIdx = idx;
+              } else if (dist < bestDist2) {
+                bestLevel2 = oc;
+                bestDist2 = dist;
+              }
+            }
+          }
+          if (!(bestDist <= 100)) bestIdx = -1;  // TH_HIGH
+          else if (bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2) bestIdx = -1;
+        }
+      }
+      choice[m] = bestIdx;
+      if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
+    }
+    __syncthreads();
+    int ch = 0;
+    for (int i = tid; i < NF; i += T_M) {
+      const int o = owner_n[i];
+      if (o != owner[i]) ch = 1;
+      owner[i] = o;
+    }
+    if (ch) s_changed = 1;
+    __syncthreads();
+    ++rounds;
+    if (!s_changed || rounds > NP + 1) break;
+    __syncthreads();
+  }
+
+  // ---- outputs ------------------------------------------------------------------------------------------
+  int32_t* feat_match = feat_match_all + (size_t)f * NF;
+  for (int i = tid; i < NF; i += T_M) {
+    const int o = owner[i];
+    feat_match[i] = (o >= 0 && o != INT_MAX) ? o : -1;
+  }
+  int cnt = 0;
+  for (int m = tid; m < NP; m += T_M) cnt += (choice[m] >= 0) ? 1 : 0;
+  s_scan[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int t = 0; t < T_M; ++t) tot += s_scan[t];
+    nmatches_all[f] = tot;
+  }
+}
+
+}  // namespace
+
+extern "C" int gl_search_by_projection(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NP,
+                                       const double* feat_uv_dev, const float* feat_ur_dev, const int32_t* feat_oct_dev,
+                                       const uint8_t* feat_desc_dev, const uint8_t* feat_taken_dev,
+                                       const double* mp_uvr_dev, const int32_t* mp_level_dev,
+                                       const double* mp_viewcos_dev, const uint8_t* mp_valid_dev,
+                                       const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
+                                       int32_t* nmatches_dev) {
+  GL_REQUIRE(ctx && cam, "null argument");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && NF >= 1 && NP >= 1, "bad B / NF / NP");
+  GL_REQUIRE(NF <= 3072 && NP <= 4096, "NF / NP above the on-chip capacity (3072 features, 4096 map points)");
+  GL_REQUIRE(cam->width > 0 && cam->height > 0, "camera width / height not set");
+  GL_REQUIRE(feat_uv_dev && feat_ur_dev && feat_oct_dev && feat_desc_dev && feat_taken_dev && mp_uvr_dev &&
+                 mp_level_dev && mp_viewcos_dev && mp_valid_dev && mp_desc_dev && feat_match_dev && nmatches_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  MatchP P;
+  P.NF = NF;
+  P.NP = NP;
+  P.col_inv = static_cast<float>(GC) / cam->width;   // init_config.hpp:50-54
+  P.row_inv = static_cast<float>(GR) / cam->height;
+  P.th = th;
+  P.nn_ratio = nn_ratio;
+  P.sf[0] = 1.0f;  // init_config.hpp:63-79
+  for (int i = 1; i < 8; ++i) P.sf[i] = P.sf[i - 1] * scale_factor;
+  const size_t lds = (((size_t)2 * NCELL + 1 + 3 * (size_t)NF + NP + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 24;
+  GL_HIP(hipFuncSetAttribute((const void*)k_search_by_projection, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_search_by_projection<<<B, T_M, lds, c->stream>>>(P, B, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev,
+                                                     feat_taken_dev, mp_uvr_dev, mp_level_dev, mp_viewcos_dev,
+                                                     mp_valid_dev, mp_desc_dev, feat_match_dev, nmatches_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}

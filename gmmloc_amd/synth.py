@@ -144,3 +144,42 @@ def look_at_pose(eye, target, up=(0.0, 0.0, 1.0)):
     yc = np.cross(zc, xc)
     Rcw = np.stack([xc, yc, zc], 0)
     return np.concatenate([R_to_quat(Rcw), -Rcw @ np.asarray(eye, float)])
+
+
+def synth_match_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2, dup_frac=0.25):
+    """Inputs of ORBmatcher::searchByProjection for one frame: NF ORB-like features (uv, u_right, octave,
+    256-bit descriptor, taken flag) and NP projected map points (uvr, predicted level, viewing cosine, valid,
+    descriptor).  70 % of the map points are generated from a feature (projection within the search window,
+    descriptor = the feature's with 0..70 flipped bits), `dup_frac` of those share their feature with another
+    map point (conflicts: the earlier one must win), the rest are distractors."""
+    rng = np.random.default_rng(seed)
+    uv = np.stack([rng.uniform(-5, width + 5, NF), rng.uniform(-5, height + 5, NF)], 1)
+    octv = rng.integers(0, 8, NF).astype(np.int32)
+    octv[rng.uniform(size=NF) < 0.03] = -1  # padding slots
+    ur = np.where(rng.uniform(size=NF) < 0.7, uv[:, 0] - rng.uniform(2, 60, NF), -1.0).astype(np.float32)
+    desc = rng.integers(0, 256, (NF, 32), dtype=np.uint8)
+    taken = (rng.uniform(size=NF) < 0.05).astype(np.uint8)
+    sf = 1.2 ** np.arange(8)
+    src = rng.integers(0, NF, NP)
+    n_dup = int(dup_frac * NP)
+    src[rng.integers(0, NP, n_dup)] = src[rng.integers(0, NP, n_dup)]
+    from_feat = rng.uniform(size=NP) < 0.7
+    level = np.clip(octv[src] + rng.integers(0, 2, NP), 0, 7).astype(np.float64)
+    level = np.where(from_feat, level, rng.integers(0, 8, NP)).astype(np.float64)
+    win = 4.0 * 3.0 * sf[level.astype(int)]
+    mp_uv = np.where(from_feat[:, None], uv[src] + rng.uniform(-1.2, 1.2, (NP, 2)) * win[:, None],
+                     np.stack([rng.uniform(-30, width + 30, NP), rng.uniform(-30, height + 30, NP)], 1))
+    mp_ur = np.where(ur[src] > 0, ur[src] + rng.uniform(-1.2, 1.2, NP) * win, mp_uv[:, 0] - rng.uniform(2, 60, NP))
+    mp_uvr = np.concatenate([mp_uv, mp_ur[:, None]], 1)
+    viewcos = np.where(rng.uniform(size=NP) < 0.5, rng.uniform(0.9981, 1.0, NP), rng.uniform(0.5, 0.9979, NP))
+    valid = (rng.uniform(size=NP) < 0.9).astype(np.uint8)
+    mp_desc = desc[src].copy()
+    nflip = rng.integers(0, 71, NP)
+    for m in range(NP):
+        if from_feat[m]:
+            bits = rng.choice(256, nflip[m], replace=False)
+            np.bitwise_xor.at(mp_desc[m], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+        else:
+            mp_desc[m] = rng.integers(0, 256, 32, dtype=np.uint8)
+    return dict(width=width, height=height, feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_desc=desc, feat_taken=taken,
+                mp_uvr=mp_uvr, mp_level=level, mp_viewcos=viewcos, mp_valid=valid, mp_desc=mp_desc)

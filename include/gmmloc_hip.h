@@ -166,6 +166,30 @@ int gl_search2d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, int B,
                 const double* uv_dev, const int32_t* nfeat_dev, int k, int32_t* cand_dev, int32_t* ncand_dev,
                 int view_cap, int32_t* view_ids_dev, int32_t* nview_dev);
 
+/* ---- feature matching (the producer of optimizeCurrentPose's correspondences) ---- */
+/* ORBmatcher::searchByProjection(Frame&, mappts, stats, th) (orb_matcher.cpp:27-110) with
+ * Frame::assignFeaturesToGrid / getFeaturesInArea (frame.cpp:54-79, 121-177),
+ * ORBmatcher::DescriptorDistance (orb_matcher.cpp:580-596) and computeRadiusByViewingCos (:112-117),
+ * for B frames of NF <= 3072 feature slots and NP <= 4096 projected map points.
+ *  cam: width / height size the 64 x 48 feature grid (init_config.hpp:50-54); scale_factor: ORB pyramid
+ *  factor (frame::scale_factor, 1.2).
+ *  feat_uv B x NF x 2 double; feat_ur B x NF float (u_right, <= 0: none); feat_oct B x NF int32
+ *  (< 0: empty slot); feat_desc B x NF x 32 bytes; feat_taken B x NF uint8 (1 = F.mappoints_[i] is set and
+ *  has observations on entry);
+ *  mp_uvr B x NP x 3 double (ProjStat::uvr); mp_level B x NP int32 (scale_pred, 0..7); mp_viewcos B x NP
+ *  double; mp_valid B x NP uint8 (is_in_view_ && !not_valid_); mp_desc B x NP x 32 bytes;
+ *  th (3 / 5 in searchLocalPoints, tracking.cpp:258-266), nn_ratio (0.8).
+ *  out: feat_match B x NF int32 = index of the map point this call assigned to the feature
+ *  (F.mappoints_[bestIdx] = mappt), -1 none; nmatches B int32 (the return value).
+ *  The map points are processed in index order exactly like the reference loop: a feature assigned to a
+ *  map point is not offered to the later ones. */
+int gl_search_by_projection(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NP,
+                            const double* feat_uv_dev, const float* feat_ur_dev, const int32_t* feat_oct_dev,
+                            const uint8_t* feat_desc_dev, const uint8_t* feat_taken_dev, const double* mp_uvr_dev,
+                            const int32_t* mp_level_dev, const double* mp_viewcos_dev, const uint8_t* mp_valid_dev,
+                            const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
+                            int32_t* nmatches_dev);
+
 /* ---- point refinement ----------------------------------------------------- */
 /* GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N independent problems.
  * pts N x 3, uvr N x 3 (u, v, u_right), octave N, pose N x 7, comp N, proj_z2 N.

@@ -963,6 +963,99 @@ int orc_joint_optimization(void* h, const orc_camera* cam, const orc_params* prm
 }
 
 // SE3 helpers exposed for tests
+// ---- ORBmatcher::searchByProjection(Frame&, mappts, stats, th) (orb_matcher.cpp:27-110) ---------
+// with Frame::assignFeaturesToGrid (frame.cpp:54-79), Frame::getFeaturesInArea (frame.cpp:121-177),
+// ORBmatcher::DescriptorDistance (orb_matcher.cpp:580-596), computeRadiusByViewingCos (:112-117),
+// the float config scalars of init_config.hpp:50-54,63-79.  Sequential restatement, one frame.
+//   feat_taken[idx] != 0  <=>  F.mappoints_[idx] && F.mappoints_[idx]->countObservations() > 0 on entry;
+//   a map point assigned by this call has observations (it comes from the local map), so the feature it
+//   takes is skipped by the later map points exactly as in the reference loop.
+//   out feat_match[idx] = index of the map point the call assigned to feature idx, else -1.
+int orc_search_by_projection(int width, int height, float scale_factor, int NF, const double* feat_uv,
+                             const float* feat_ur, const int32_t* feat_oct, const uint8_t* feat_desc,
+                             const uint8_t* feat_taken, int NP, const double* mp_uvr, const double* mp_level,
+                             const double* mp_viewcos, const uint8_t* mp_valid, const uint8_t* mp_desc, float th,
+                             float nn_ratio, int32_t* feat_match) {
+  const int grid_cols = 64, grid_rows = 48;  // config.h:57
+  const float col_inv = static_cast<float>(grid_cols) / width, row_inv = static_cast<float>(grid_rows) / height;
+  float sf[8];
+  sf[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) sf[i] = sf[i - 1] * scale_factor;
+  std::vector<std::vector<int>> grid((size_t)grid_cols * grid_rows);
+  for (int i = 0; i < NF; ++i) {
+    if (feat_oct[i] < 0) continue;  // padding slot, not a feature
+    const int px = (int)round((feat_uv[2 * i] - 0.0f) * col_inv), py = (int)round((feat_uv[2 * i + 1] - 0.0f) * row_inv);
+    if (px < 0 || px >= grid_cols || py < 0 || py >= grid_rows) continue;
+    grid[(size_t)px * grid_rows + py].push_back(i);
+  }
+  std::vector<uint8_t> taken(feat_taken, feat_taken + NF);
+  for (int i = 0; i < NF; ++i) feat_match[i] = -1;
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int m = 0; m < NP; ++m) {
+    if (!mp_valid[m]) continue;
+    const int lvl_pred = (int)mp_level[m];
+    float r = ((float)mp_viewcos[m] > 0.998) ? 2.5f : 4.0f;  // const float& viewCos
+    if (bFactor) r *= th;
+    const float x = (float)mp_uvr[3 * m], y = (float)mp_uvr[3 * m + 1], rr = r * sf[lvl_pred];
+    const int minLevel = lvl_pred - 1, maxLevel = lvl_pred;
+    // getFeaturesInArea
+    const int x0 = std::max(0, (int)floor((x - 0.0f - rr) * col_inv));
+    if (x0 >= grid_cols) continue;
+    const int x1 = std::min(grid_cols - 1, (int)ceil((x - 0.0f + rr) * col_inv));
+    if (x1 < 0) continue;
+    const int y0 = std::max(0, (int)floor((y - 0.0f - rr) * row_inv));
+    if (y0 >= grid_rows) continue;
+    const int y1 = std::min(grid_rows - 1, (int)ceil((y - 0.0f + rr) * row_inv));
+    if (y1 < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int ix = x0; ix <= x1; ++ix)
+      for (int iy = y0; iy <= y1; ++iy)
+        for (int idx : grid[(size_t)ix * grid_rows + iy]) {
+          const int oc = feat_oct[idx];
+          if (bCheckLevels) {
+            if (oc < minLevel) continue;
+            if (maxLevel >= 0 && oc > maxLevel) continue;
+          }
+          const float distx = feat_uv[2 * idx] - x, disty = feat_uv[2 * idx + 1] - y;
+          if (!(fabs(distx) < rr && fabs(disty) < rr)) continue;
+          // searchByProjection body
+          if (taken[idx]) continue;
+          if (feat_ur[idx] > 0) {
+            const float er = fabs(mp_uvr[3 * m + 2] - feat_ur[idx]);
+            if (er > r * sf[lvl_pred]) continue;
+          }
+          const int32_t* pa = (const int32_t*)(mp_desc + (size_t)m * 32);
+          const int32_t* pb = (const int32_t*)(feat_desc + (size_t)idx * 32);
+          int dist = 0;
+          for (int w = 0; w < 8; ++w) {
+            unsigned int v = pa[w] ^ pb[w];
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+          }
+          if (dist < bestDist) {
+            bestDist2 = bestDist;
+            bestDist = dist;
+            bestLevel2 = bestLevel;
+            bestLevel = oc;
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = oc;
+            bestDist2 = dist;
+          }
+        }
+    if (bestDist <= 100) {  // TH_HIGH
+      if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+      feat_match[bestIdx] = m;
+      taken[bestIdx] = 1;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
 void orc_se3_exp(const double* u, double* pose) { from_se3(se3_exp(u), pose); }
 void orc_se3_log(const double* pose, double* u) { se3_log(to_se3(pose), u); }
 void orc_se3_mul(const double* a, const double* b, double* out) { from_se3(se3_mul(to_se3(a), to_se3(b)), out); }

@@ -547,3 +547,72 @@ def joint_optimization(P, F, poses7, has_prior, points, assoc, obs_ptr, obs_pose
         pc = pb.poses[e["pose"]].map(pb.points[e["pt"]])
         erase[o] = 1 if (e["chi2"] > th or not pc[2] > 0) else 0
     return (np.stack([T.to7() for T in pb.poses[:P]]), np.stack(pb.points), dropped, erase, iters)
+
+
+# ---- ORBmatcher::searchByProjection (orb_matcher.cpp:27-110), independent restatement ----------------
+_POP8 = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+
+def search_by_projection(width, height, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
+                         mp_valid, mp_desc, th=3.0, nn_ratio=0.8, scale_factor=1.2):
+    """Brute force over ALL features per map point instead of the 64x48 grid walk: a feature passes
+    getFeaturesInArea (frame.cpp:121-177) iff it is registered in the grid (frame.cpp:54-79), its octave is in
+    [level-1, level] and |du|, |dv| < r (float); the grid only fixes the visiting ORDER (cell column, cell
+    row, feature index), which decides ties of `dist < bestDist`.  Hamming distance by byte popcount table."""
+    f32 = np.float32
+    col_inv, row_inv = f32(64) / f32(width), f32(48) / f32(height)
+    sf = [f32(1.0)]
+    for _ in range(7):
+        sf.append(f32(sf[-1] * f32(scale_factor)))
+    NF, NP = len(feat_oct), len(mp_valid)
+    # std::round = half away from zero
+    rnd = lambda v: np.where(v >= 0, np.floor(v + 0.5), np.ceil(v - 0.5)).astype(np.int64)
+    px = rnd(feat_uv[:, 0] * np.float64(col_inv))
+    py = rnd(feat_uv[:, 1] * np.float64(row_inv))
+    in_grid = (feat_oct >= 0) & (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    order = np.lexsort((np.arange(NF), py, px))  # primary px, then py, then index
+    order = order[in_grid[order]]
+    taken = np.array(feat_taken, bool).copy()
+    match = -np.ones(NF, np.int32)
+    n = 0
+    th = f32(th)
+    for m in range(NP):
+        if not mp_valid[m]:
+            continue
+        lvl = int(mp_level[m])
+        r = f32(2.5) if np.float64(f32(mp_viewcos[m])) > 0.998 else f32(4.0)
+        if np.float64(th) != 1.0:
+            r = f32(r * th)
+        rr = f32(r * sf[lvl])
+        x, y = f32(mp_uvr[m, 0]), f32(mp_uvr[m, 1])
+        # empty-range early outs of getFeaturesInArea (only matter for points far outside the image)
+        if int(np.floor(f32(f32(x - rr) * col_inv))) >= 64 or int(np.ceil(f32(f32(x + rr) * col_inv))) < 0:
+            continue
+        if int(np.floor(f32(f32(y - rr) * row_inv))) >= 48 or int(np.ceil(f32(f32(y + rr) * row_inv))) < 0:
+            continue
+        best, best2, lvl1, lvl2, bidx = 256, 256, -1, -1, -1
+        for idx in order:
+            oc = int(feat_oct[idx])
+            if oc < lvl - 1 or (lvl >= 0 and oc > lvl):
+                continue
+            dx, dy = f32(feat_uv[idx, 0] - np.float64(x)), f32(feat_uv[idx, 1] - np.float64(y))
+            if not (abs(dx) < rr and abs(dy) < rr):
+                continue
+            if taken[idx]:
+                continue
+            if feat_ur[idx] > 0:
+                er = f32(abs(mp_uvr[m, 2] - np.float64(feat_ur[idx])))
+                if er > rr:
+                    continue
+            d = int(_POP8[np.bitwise_xor(mp_desc[m], feat_desc[idx])].sum())
+            if d < best:
+                best2, best, lvl2, lvl1, bidx = best, d, lvl1, oc, idx
+            elif d < best2:
+                lvl2, best2 = oc, d
+        if best <= 100:
+            if lvl1 == lvl2 and f32(best) > f32(f32(nn_ratio) * f32(best2)):
+                continue
+            match[bidx] = m
+            taken[bidx] = True
+            n += 1
+    return match, n

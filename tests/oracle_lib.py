@@ -168,6 +168,26 @@ class Oracle:
                                              _p(obs_uvr), _p(obs_oct), _p(dropped), _p(erase))
         return poses, points, dropped, erase[:nobs], it
 
+    def search_by_projection(self, width, height, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level,
+                             mp_viewcos, mp_valid, mp_desc, th=3.0, nn_ratio=0.8, scale_factor=1.2):
+        """ORBmatcher::searchByProjection for one frame -> (feat_match int32 [NF], nmatches)."""
+        feat_uv, mp_uvr = _f64(feat_uv), _f64(mp_uvr)
+        feat_ur = np.ascontiguousarray(feat_ur, dtype=np.float32)
+        feat_oct = _i32(feat_oct)
+        feat_desc = np.ascontiguousarray(feat_desc, dtype=np.uint8)
+        mp_desc = np.ascontiguousarray(mp_desc, dtype=np.uint8)
+        feat_taken = np.ascontiguousarray(feat_taken, dtype=np.uint8)
+        mp_valid = np.ascontiguousarray(mp_valid, dtype=np.uint8)
+        mp_level, mp_viewcos = _f64(mp_level), _f64(mp_viewcos)
+        NF, NP = feat_uv.shape[0], mp_uvr.shape[0]
+        out = np.zeros(NF, np.int32)
+        self.lib.orc_search_by_projection.restype = C.c_int
+        n = self.lib.orc_search_by_projection(C.c_int(width), C.c_int(height), C.c_float(scale_factor), NF, _p(feat_uv),
+                                              _p(feat_ur), _p(feat_oct), _p(feat_desc), _p(feat_taken), NP, _p(mp_uvr),
+                                              _p(mp_level), _p(mp_viewcos), _p(mp_valid), _p(mp_desc), C.c_float(th),
+                                              C.c_float(nn_ratio), _p(out))
+        return out, int(n)
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

@@ -159,6 +159,17 @@ def main():
                b_obs_uvr=np.array(obs_uvr), b_obs_oct=np.array(obs_oct, np.int32), b_out_poses=r[0],
                b_out_points=r[1], b_dropped=r[2], b_erase=r[3], b_iters=np.array(r[4]))
     np.savez_compressed(os.path.join(G, "golden_ba.npz"), **out)
+
+    # ---- searchByProjection: three small frames through the independent (brute-force, table popcount)
+    #      restatement; inputs are regenerated from the seeds by the tests, only the outputs are stored
+    out = {}
+    for i, (NF, NP, seed, th) in enumerate(((250, 300, 101, 3.0), (600, 500, 102, 5.0), (400, 700, 103, 1.0))):
+        fr = synth.synth_match_frame(NF, NP, seed)
+        m, n = nr.search_by_projection(th=th, **fr)
+        out["m%d_args" % i] = np.array([NF, NP, seed, th])
+        out["m%d_match" % i] = m
+        out["m%d_n" % i] = np.array(n)
+    np.savez_compressed(os.path.join(G, "golden_match.npz"), **out)
     print("golden vectors written to", G)
 
 

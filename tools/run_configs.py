@@ -215,6 +215,84 @@ def config_ba(torch, ctx, out):
     out(res)
 
 
+def config_kf(torch, ctx, out):
+    """Key-frame association chain (A7 + A8: search2d -> checkMapAssociation) and the batched point
+    refinements (B1 optimizePoint, B2 optimizeTriangulationVec) on the real v1 map."""
+    import gmmloc_amd
+    from gmmloc_amd import api, synth
+    d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz"))
+    mean, cov = d["mean"], d["cov"]
+    gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_02_medium"]
+    cam, prm = api.Camera(), api.Params()
+    g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+    B, N = 128, 1000
+    fr = [synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(gt[(11 + i * 13) % gt.shape[0]]), cam, N, 50 + i,
+                            mono_frac=0.0, outlier_frac=0.1) for i in range(B)]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    poses = T(np.stack([f["pose_gt"] for f in fr]))
+    pts0 = T(np.stack([f["Xw"] for f in fr]) + np.random.default_rng(2).standard_normal((B, N, 3)) * 0.02)
+    uvr = T(np.stack([f["obs"] for f in fr]))
+    octv = T(np.stack([f["octave"] for f in fr]))
+    uv = uvr[:, :, :2].contiguous()
+    cand, ncand, _, _ = g.search2d(cam, poses, uv, None, k=5)
+    t_s2d = ev_time(torch, lambda: g.search2d(cam, poses, uv, None, k=5), 3, ctx.stream)
+    t_cma = ev_time(torch, lambda: api.check_map_association(ctx, g, cam, prm, poses, pts0.clone(), uvr, octv, cand, ncand), 3, ctx.stream)
+    # B1 on B*N independent problems (component = first candidate, else a degenerate one)
+    flags = g.get(api.F_FLAGS)
+    deg0 = int(np.nonzero(flags & 1)[0][3])
+    comp = cand[:, :, 0].reshape(-1).clone()
+    comp[comp < 0] = deg0
+    comp = torch.where(torch.from_numpy((flags & 1).astype(bool)).cuda()[comp.long()], comp, torch.full_like(comp, deg0))
+    poseN = poses[:, None, :].expand(B, N, 7).reshape(-1, 7).contiguous()
+    pz2 = torch.ones(B * N, dtype=torch.float64, device="cuda")
+    t_b1 = ev_time(torch, lambda: api.optimize_point(ctx, g, cam, prm, pts0.reshape(-1, 3), uvr.reshape(-1, 3), octv.reshape(-1),
+                                                     poseN, comp.to(torch.int32), pz2), 3, ctx.stream)
+    # B2: pair frame b with frame b+1 (same points seen from two poses is not needed for timing: the
+    # kernel cost is the candidates x 20 GN iterations)
+    M2 = (B // 2) * N
+    p1 = poses[0::2][:, None, :].expand(B // 2, N, 7).reshape(-1, 7).contiguous()
+    p2 = poses[1::2][:, None, :].expand(B // 2, N, 7).reshape(-1, 7).contiguous()
+    x3 = pts0[0::2].reshape(-1, 3).clone()
+    t_b2 = ev_time(torch, lambda: api.optimize_triangulation(ctx, g, cam, prm, x3.clone(), p1, uvr[0::2].reshape(-1, 3).contiguous(),
+                                                             octv[0::2].reshape(-1).contiguous(), p2, uvr[1::2].reshape(-1, 3).contiguous(),
+                                                             octv[1::2].reshape(-1).contiguous(), cand[0::2].reshape(M2, 5).contiguous(),
+                                                             ncand[0::2].reshape(-1).contiguous(), cand[1::2].reshape(M2, 5).contiguous(),
+                                                             ncand[1::2].reshape(-1).contiguous()), 3, ctx.stream)
+    out({"config": "key-frame chain on v1.gmm: %d key-frames x %d features" % (B, N),
+         "search2d_keyframes_per_s": B / t_s2d, "checkMapAssociation_keyframes_per_s": B / t_cma,
+         "checkMapAssociation_features_per_s": B * N / t_cma, "mean_candidates_per_feature": float(ncand.float().mean().item()),
+         "optimizePoint_problems_per_s": B * N / t_b1, "optimizeTriangulation_problems_per_s": M2 / t_b2})
+
+
+def config_match(torch, ctx, out):
+    """searchByProjection on synthetic ORB-like frames: 1 200 features x 1 500 projected
+    map points (a local map), th = 3."""
+    import gmmloc_amd
+    from gmmloc_amd import api, synth
+    from tests import oracle_lib
+    from tests.test_gpu_match import KEYS
+    orc = oracle_lib.load()
+    NF, NP, B = 1200, 1500, 2048
+    uniq = [synth.synth_match_frame(NF, NP, 500 + b) for b in range(64)]
+    frames = [uniq[b % 64] for b in range(B)]
+    cam = api.Camera()
+    cam.width, cam.height = 752, 480
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in frames]))).cuda()
+    a = {k: T(k) for k in KEYS}
+    a["mp_level"] = a["mp_level"].to(torch.int32)
+    args = [a[k] for k in KEYS]
+    t = ev_time(torch, lambda: api.search_by_projection(ctx, cam, *args, th=3.0), 5, ctx.stream)
+    t1 = ev_time(torch, lambda: api.search_by_projection(ctx, cam, *[x[:1] for x in args], th=3.0), 50, ctx.stream)
+    t0 = time.perf_counter()
+    for f in uniq:
+        orc.search_by_projection(th=3.0, **f)
+    tc = (time.perf_counter() - t0) / len(uniq)
+    bytes_frame = NF * (16 + 4 + 4 + 32 + 1 + 4) + NP * (24 + 4 + 8 + 1 + 32)
+    out({"config": "searchByProjection: %d frames x %d features x %d map points, th=3" % (B, NF, NP),
+         "frames_per_s": B / t, "single_frame_latency_us": 1e6 * t1, "algorithmic_bytes_per_frame": bytes_frame,
+         "algorithmic_GBs": B * bytes_frame / t / 1e9, "cpu_oracle_1thread_frames_per_s": 1.0 / tc})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4,5")
@@ -227,7 +305,8 @@ def main():
     for c in a.configs.split(","):
         {"2": lambda: config2(torch, ctx, out), "3": lambda: config3(torch, ctx, out, a.frames_cap),
          "4": lambda: config4(torch, ctx, out, a.frames_cap), "5": lambda: config5(torch, ctx, out),
-         "ba": lambda: config_ba(torch, ctx, out)}[c]()
+         "ba": lambda: config_ba(torch, ctx, out), "kf": lambda: config_kf(torch, ctx, out),
+         "match": lambda: config_match(torch, ctx, out)}[c]()
 
 
 if __name__ == "__main__":
