@@ -379,3 +379,24 @@ def search_by_projection(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_t
                                            float(nn_ratio), _ptr(match), _ptr(nm)))
     ctx._exit()
     return match, nm
+
+
+def search_by_projection_frame(ctx, cam, pose_cw, pose_lw, feat_uv, feat_ur, feat_oct, feat_angle, feat_desc, feat_taken,
+                               last_pt, last_valid, last_oct, last_angle, last_desc, th=7.0, mono=False,
+                               check_orientation=True, scale_factor=1.2):
+    """ORBmatcher::searchByProjection(CurrentFrame, LastFrame, th, bMono) (orb_matcher.cpp:410-542) for B frame
+    pairs -> (feat_match int32 (B,NF): index of the last-frame feature, nmatches int32 (B,))."""
+    import torch
+    B, NF = feat_oct.shape
+    NL = last_oct.shape[1]
+    match = torch.empty((B, NF), dtype=torch.int32, device=feat_oct.device)
+    nm = torch.empty(B, dtype=torch.int32, device=feat_oct.device)
+    ctx._enter()
+    _check(ctx.lib.gl_search_by_projection_frame(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NL, _ptr(pose_cw),
+                                                 _ptr(pose_lw), _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
+                                                 _ptr(feat_angle), _ptr(feat_desc), _ptr(feat_taken), _ptr(last_pt),
+                                                 _ptr(last_valid), _ptr(last_oct), _ptr(last_angle), _ptr(last_desc),
+                                                 float(th), int(bool(mono)), int(bool(check_orientation)), _ptr(match),
+                                                 _ptr(nm)))
+    ctx._exit()
+    return match, nm

@@ -30,7 +30,34 @@ struct MatchP {
   int NF, NP;
   float col_inv, row_inv, th, nn_ratio;
   float sf[8];
+  // frame-to-frame mode (orb_matcher.cpp:410-542)
+  double fx, fy, cx, cy;
+  float mbf, mb;
+  int width, height, mono, check_orientation;
 };
+
+// what one query point (a projected map point) asks of the feature grid
+struct Query {
+  bool valid;
+  float x, y, rr;          // window centre / half size (float, as the reference passes them)
+  int minLevel, maxLevel;  // getFeaturesInArea level filter
+  bool ratio_test;         // best / second-best test of the local-map overload
+  double ur_d;             // predicted u_right: compared in double (overload 1) ...
+  float ur_f;              // ... or in float (overload 2)
+  bool ur_float;
+};
+
+// Eigen Quaternion * Vector3:  uv = 2 q.vec x v;  v + w uv + q.vec x uv   (g2o SE3Quat::map)
+__device__ __forceinline__ void quat_rot(const double* q, const double* v, double* o) {
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  double uv[3] = {qy * v[2] - qz * v[1], qz * v[0] - qx * v[2], qx * v[1] - qy * v[0]};
+  uv[0] += uv[0];
+  uv[1] += uv[1];
+  uv[2] += uv[2];
+  o[0] = v[0] + qw * uv[0] + (qy * uv[2] - qz * uv[1]);
+  o[1] = v[1] + qw * uv[1] + (qz * uv[0] - qx * uv[2]);
+  o[2] = v[2] + qw * uv[2] + (qx * uv[1] - qy * uv[0]);
+}
 
 __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* __restrict__ b) {
   int d = 0;
@@ -39,13 +66,21 @@ __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* __r
   return d;
 }
 
+// MODE 0: searchByProjection(Frame&, mappts, stats, th): query points = projected local map points
+//         (mp_uvr = ProjStat::uvr, mp_level = scale_pred, mp_viewcos).
+// MODE 1: searchByProjection(CurrentFrame, LastFrame, th, bMono): query points = the last frame's map
+//         points (mp_uvr = world position, mp_level = octave of the last frame's feature), projected here
+//         with the current pose; rotation-consistency histogram at the end (feat_angle / mp_angle).
+template <int MODE>
 __global__ __launch_bounds__(T_M) void k_search_by_projection(
     MatchP P, int B, const double* __restrict__ feat_uv_all, const float* __restrict__ feat_ur_all,
     const int32_t* __restrict__ feat_oct_all, const uint8_t* __restrict__ feat_desc_all,
     const uint8_t* __restrict__ feat_taken_all, const double* __restrict__ mp_uvr_all,
     const int32_t* __restrict__ mp_level_all, const double* __restrict__ mp_viewcos_all,
     const uint8_t* __restrict__ mp_valid_all, const uint8_t* __restrict__ mp_desc_all,
-    int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all) {
+    int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all,
+    const double* __restrict__ pose_cw_all, const double* __restrict__ pose_lw_all,
+    const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* cell_ptr = lds;                   // NCELL + 1
   int32_t* cursor = cell_ptr + NCELL + 1;    // NCELL (grid build only)
@@ -56,7 +91,9 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
   // per CSR entry, so that the window walk touches LDS only: {u, v} double, {u_right bits, octave}
   double2* rec_uv = (double2*)(lds + ((2 * NCELL + 1 + 3 * P.NF + P.NP + 3) & ~3));  // 16-byte aligned
   int2* rec_ro = (int2*)(rec_uv + P.NF);
-  __shared__ int s_changed, s_scan[T_M];
+  __shared__ int s_changed, s_scan[T_M], s_hist[32], s_keep[4];
+  __shared__ double s_pose[8];
+  __shared__ int s_dir;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
   const int NF = P.NF, NP = P.NP;
@@ -67,7 +104,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
   const uint8_t* feat_taken = feat_taken_all + (size_t)f * NF;
   const double* mp_uvr = mp_uvr_all + (size_t)f * NP * 3;
   const int32_t* mp_level = mp_level_all + (size_t)f * NP;
-  const double* mp_viewcos = mp_viewcos_all + (size_t)f * NP;
+  const double* mp_viewcos = MODE == 0 ? mp_viewcos_all + (size_t)f * NP : nullptr;
   const uint8_t* mp_valid = mp_valid_all + (size_t)f * NP;
   const uint32_t* mp_desc = (const uint32_t*)(mp_desc_all + (size_t)f * NP * 32);
 
@@ -142,7 +179,76 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
   for (int i = tid; i < NF; i += T_M) owner[i] = feat_taken[i] ? -1 : INT_MAX;
   __syncthreads();
 
+  if (MODE == 1 && tid == 0) {  // current pose, direction of motion (orb_matcher.cpp:421-428)
+    const double* pc = pose_cw_all + (size_t)f * 7;
+    const double* pl = pose_lw_all + (size_t)f * 7;
+    const double qi[4] = {-pc[0], -pc[1], -pc[2], pc[3]};
+    const double mt[3] = {pc[4] * -1., pc[5] * -1., pc[6] * -1.};
+    double twc[3], tlc[3];
+    quat_rot(qi, mt, twc);  // Twc = Tcw.inverse()
+    quat_rot(pl, twc, tlc);
+    const double tz = tlc[2] + pl[6];
+    s_dir = (tz > P.mb && !P.mono) ? 1 : ((-tz > P.mb && !P.mono) ? 2 : 0);
+    for (int i = 0; i < 7; ++i) s_pose[i] = pc[i];
+  }
+  __syncthreads();
+
   const bool bFactor = P.th != 1.0;
+  auto make_query = [&](int m) -> Query {
+    Query q;
+    q.valid = mp_valid[m] != 0;
+    q.ratio_test = MODE == 0;
+    q.ur_float = MODE == 1;
+    q.ur_d = 0.0;
+    q.ur_f = 0.f;
+    q.x = q.y = q.rr = 0.f;
+    q.minLevel = q.maxLevel = -1;
+    if (!q.valid) return q;
+    if (MODE == 0) {
+      const int lvl = mp_level[m];
+      float r = ((float)mp_viewcos[m] > 0.998) ? 2.5f : 4.0f;
+      if (bFactor) r *= P.th;
+      q.rr = r * P.sf[lvl & 7];
+      q.x = (float)mp_uvr[3 * m];
+      q.y = (float)mp_uvr[3 * m + 1];
+      q.ur_d = mp_uvr[3 * m + 2];
+      q.minLevel = lvl - 1;
+      q.maxLevel = lvl;
+    } else {
+      double ptc[3];
+      quat_rot(s_pose, mp_uvr + 3 * m, ptc);
+      ptc[0] += s_pose[4];
+      ptc[1] += s_pose[5];
+      ptc[2] += s_pose[6];
+      const float xc = (float)ptc[0], yc = (float)ptc[1], invzc = (float)(1.0 / ptc[2]);
+      if (invzc < 0) {
+        q.valid = false;
+        return q;
+      }
+      const float u = (float)(P.fx * xc * invzc + P.cx), v = (float)(P.fy * yc * invzc + P.cy);
+      if (u < 0 || u > P.width || v < 0 || v > P.height) {
+        q.valid = false;
+        return q;
+      }
+      const int oct = mp_level[m];
+      q.rr = P.th * P.sf[oct & 7];
+      q.x = u;
+      q.y = v;
+      q.ur_f = u - P.mbf * invzc;
+      if (s_dir == 1) {
+        q.minLevel = oct;
+        q.maxLevel = -1;
+      } else if (s_dir == 2) {
+        q.minLevel = 0;
+        q.maxLevel = oct;
+      } else {
+        q.minLevel = oct - 1;
+        q.maxLevel = oct + 1;
+      }
+    }
+    return q;
+  };
+
   int rounds = 0;
   while (true) {
     for (int i = tid; i < NF; i += T_M) owner_n[i] = feat_taken[i] ? -1 : INT_MAX;
@@ -150,18 +256,15 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     __syncthreads();
     for (int m = tid; m < NP; m += T_M) {
       int bestIdx = -1;
-      if (mp_valid[m]) {
-        const int lvl = mp_level[m];
-        float r = ((float)mp_viewcos[m] > 0.998) ? 2.5f : 4.0f;
-        if (bFactor) r *= P.th;
-        const float rr = r * P.sf[lvl & 7];
-        const float x = (float)mp_uvr[3 * m], y = (float)mp_uvr[3 * m + 1];
+      const Query q = make_query(m);
+      if (q.valid) {
+        const float rr = q.rr, x = q.x, y = q.y;
         const int x0 = max(0, (int)floorf((x - 0.0f - rr) * P.col_inv));
         const int x1 = min(GC - 1, (int)ceilf((x - 0.0f + rr) * P.col_inv));
         const int y0 = max(0, (int)floorf((y - 0.0f - rr) * P.row_inv));
         const int y1 = min(GR - 1, (int)ceilf((y - 0.0f + rr) * P.row_inv));
         if (x0 < GC && x1 >= 0 && y0 < GR && y1 >= 0) {
-          const int minLevel = lvl - 1, maxLevel = lvl;
+          const int minLevel = q.minLevel, maxLevel = q.maxLevel;
           const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
           uint32_t dm[8];
 #pragma unroll
@@ -184,7 +287,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
               if (owner[idx] < m) continue;  // taken on entry (-1) or by an earlier map point
               const float ur = __int_as_float(ro.x);
               if (ur > 0) {
-                const float er = (float)fabs(mp_uvr[3 * m + 2] - (double)ur);
+                const float er = q.ur_float ? fabsf(q.ur_f - ur) : (float)fabs(q.ur_d - (double)ur);
                 if (er > rr) continue;
               }
               const int dist = hamming256(dm, feat_desc + (size_t)idx * 8);
@@ -201,7 +304,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
             }
           }
           if (!(bestDist <= 100)) bestIdx = -1;  // TH_HIGH
-          else if (bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2) bestIdx = -1;
+          else if (q.ratio_test && bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2) bestIdx = -1;
         }
       }
       choice[m] = bestIdx;
@@ -221,14 +324,79 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     __syncthreads();
   }
 
+  // ---- rotation consistency (orb_matcher.cpp:498-539, computeThreeMaxima :544-578) ---------------------
+  if (MODE == 1 && P.check_orientation) {
+    const float* feat_angle = feat_angle_all + (size_t)f * NF;
+    const float* mp_angle = mp_angle_all + (size_t)f * NP;
+    const float factor = 30 / 360.0f;
+    auto bin_of = [&](int i) -> int {  // i: matched feature, owner[i]: its last-frame feature
+      float rot = mp_angle[owner[i]] - feat_angle[i];
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == 30) bin = 0;
+      return bin;
+    };
+    if (tid < 32) s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < NF; i += T_M) {
+      const int o = owner[i];
+      if (o >= 0 && o != INT_MAX) {
+        const int b = bin_of(i);
+        if (b >= 0 && b < 30) atomicAdd(&s_hist[b], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+      for (int i = 0; i < 30; i++) {
+        const int sz = s_hist[i];
+        if (sz > max1) {
+          max3 = max2;
+          max2 = max1;
+          max1 = sz;
+          ind3 = ind2;
+          ind2 = ind1;
+          ind1 = i;
+        } else if (sz > max2) {
+          max3 = max2;
+          max2 = sz;
+          ind3 = ind2;
+          ind2 = i;
+        } else if (sz > max3) {
+          max3 = sz;
+          ind3 = i;
+        }
+      }
+      if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+      } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+      }
+      s_keep[0] = ind1;
+      s_keep[1] = ind2;
+      s_keep[2] = ind3;
+    }
+    __syncthreads();
+    for (int i = tid; i < NF; i += T_M) {
+      const int o = owner[i];
+      if (o >= 0 && o != INT_MAX) {
+        const int b = bin_of(i);
+        if (b >= 0 && b < 30 && b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) owner[i] = INT_MAX;
+      }
+    }
+    __syncthreads();
+  }
+
   // ---- outputs ------------------------------------------------------------------------------------------
   int32_t* feat_match = feat_match_all + (size_t)f * NF;
+  int cnt = 0;
   for (int i = tid; i < NF; i += T_M) {
     const int o = owner[i];
-    feat_match[i] = (o >= 0 && o != INT_MAX) ? o : -1;
+    const bool matched = o >= 0 && o != INT_MAX;
+    feat_match[i] = matched ? o : -1;
+    cnt += matched ? 1 : 0;
   }
-  int cnt = 0;
-  for (int m = tid; m < NP; m += T_M) cnt += (choice[m] >= 0) ? 1 : 0;
   s_scan[tid] = cnt;
   __syncthreads();
   if (tid == 0) {
@@ -236,6 +404,48 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     for (int t = 0; t < T_M; ++t) tot += s_scan[t];
     nmatches_all[f] = tot;
   }
+}
+
+}  // namespace
+
+namespace {
+
+int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NP,
+                 const double* feat_uv, const float* feat_ur, const int32_t* feat_oct, const uint8_t* feat_desc,
+                 const uint8_t* feat_taken, const double* mp_uvr, const int32_t* mp_level, const double* mp_viewcos,
+                 const uint8_t* mp_valid, const uint8_t* mp_desc, float th, float nn_ratio, int32_t* feat_match,
+                 int32_t* nmatches, const double* pose_cw, const double* pose_lw, const float* feat_angle,
+                 const float* mp_angle, int mono, int check_orientation) {
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  MatchP P;
+  P.NF = NF;
+  P.NP = NP;
+  P.col_inv = static_cast<float>(GC) / cam->width;  // init_config.hpp:50-54
+  P.row_inv = static_cast<float>(GR) / cam->height;
+  P.th = th;
+  P.nn_ratio = nn_ratio;
+  P.sf[0] = 1.0f;  // init_config.hpp:63-79
+  for (int i = 1; i < 8; ++i) P.sf[i] = P.sf[i - 1] * scale_factor;
+  // camera::fx ... are float config scalars (config.h:38-48); PinholeCamera::fx() returns them as double
+  const float cfx = (float)cam->fx, cfy = (float)cam->fy, ccx = (float)cam->cx, ccy = (float)cam->cy, cbf = (float)cam->bf;
+  P.fx = cfx;
+  P.fy = cfy;
+  P.cx = ccx;
+  P.cy = ccy;
+  P.mbf = cbf;        // frame.cpp:23
+  P.mb = cbf / cfx;   // frame.cpp:24
+  P.width = cam->width;
+  P.height = cam->height;
+  P.mono = mono;
+  P.check_orientation = check_orientation;
+  const size_t lds = (((size_t)2 * NCELL + 1 + 3 * (size_t)NF + NP + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 24;
+  auto kern = mode == 0 ? k_search_by_projection<0> : k_search_by_projection<1>;
+  GL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<B, T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
+                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
 }
 
 }  // namespace
@@ -255,22 +465,31 @@ extern "C" int gl_search_by_projection(gl_ctx_t* ctx, const gl_camera* cam, floa
   GL_REQUIRE(feat_uv_dev && feat_ur_dev && feat_oct_dev && feat_desc_dev && feat_taken_dev && mp_uvr_dev &&
                  mp_level_dev && mp_viewcos_dev && mp_valid_dev && mp_desc_dev && feat_match_dev && nmatches_dev,
              "null buffer");
-  gl::Ctx* c = gl::C(ctx);
-  GL_HIP(hipSetDevice(c->device));
-  MatchP P;
-  P.NF = NF;
-  P.NP = NP;
-  P.col_inv = static_cast<float>(GC) / cam->width;   // init_config.hpp:50-54
-  P.row_inv = static_cast<float>(GR) / cam->height;
-  P.th = th;
-  P.nn_ratio = nn_ratio;
-  P.sf[0] = 1.0f;  // init_config.hpp:63-79
-  for (int i = 1; i < 8; ++i) P.sf[i] = P.sf[i - 1] * scale_factor;
-  const size_t lds = (((size_t)2 * NCELL + 1 + 3 * (size_t)NF + NP + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 24;
-  GL_HIP(hipFuncSetAttribute((const void*)k_search_by_projection, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_search_by_projection<<<B, T_M, lds, c->stream>>>(P, B, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev,
-                                                     feat_taken_dev, mp_uvr_dev, mp_level_dev, mp_viewcos_dev,
-                                                     mp_valid_dev, mp_desc_dev, feat_match_dev, nmatches_dev);
-  GL_HIP(hipGetLastError());
-  return GL_OK;
+  return launch_match(0, ctx, cam, scale_factor, B, NF, NP, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev,
+                      feat_taken_dev, mp_uvr_dev, mp_level_dev, mp_viewcos_dev, mp_valid_dev, mp_desc_dev, th, nn_ratio,
+                      feat_match_dev, nmatches_dev, nullptr, nullptr, nullptr, nullptr, 0, 0);
+}
+
+extern "C" int gl_search_by_projection_frame(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF,
+                                             int NL, const double* pose_cw_dev, const double* pose_lw_dev,
+                                             const double* feat_uv_dev, const float* feat_ur_dev,
+                                             const int32_t* feat_oct_dev, const float* feat_angle_dev,
+                                             const uint8_t* feat_desc_dev, const uint8_t* feat_taken_dev,
+                                             const double* last_pt_dev, const uint8_t* last_valid_dev,
+                                             const int32_t* last_oct_dev, const float* last_angle_dev,
+                                             const uint8_t* last_desc_dev, float th, int mono, int check_orientation,
+                                             int32_t* feat_match_dev, int32_t* nmatches_dev) {
+  GL_REQUIRE(ctx && cam, "null argument");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && NF >= 1 && NL >= 1, "bad B / NF / NL");
+  GL_REQUIRE(NF <= 3072 && NL <= 4096, "NF / NL above the on-chip capacity (3072 features, 4096 map points)");
+  GL_REQUIRE(cam->width > 0 && cam->height > 0, "camera width / height not set");
+  GL_REQUIRE(pose_cw_dev && pose_lw_dev && feat_uv_dev && feat_ur_dev && feat_oct_dev && feat_angle_dev &&
+                 feat_desc_dev && feat_taken_dev && last_pt_dev && last_valid_dev && last_oct_dev && last_angle_dev &&
+                 last_desc_dev && feat_match_dev && nmatches_dev,
+             "null buffer");
+  return launch_match(1, ctx, cam, scale_factor, B, NF, NL, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev,
+                      feat_taken_dev, last_pt_dev, last_oct_dev, nullptr, last_valid_dev, last_desc_dev, th, 0.f,
+                      feat_match_dev, nmatches_dev, pose_cw_dev, pose_lw_dev, feat_angle_dev, last_angle_dev, mono,
+                      check_orientation);
 }

@@ -183,3 +183,52 @@ def synth_match_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2, dup
             mp_desc[m] = rng.integers(0, 256, 32, dtype=np.uint8)
     return dict(width=width, height=height, feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_desc=desc, feat_taken=taken,
                 mp_uvr=mp_uvr, mp_level=level, mp_viewcos=viewcos, mp_valid=valid, mp_desc=mp_desc)
+
+
+def synth_motion_frames(NF, NL, seed, cam, motion="none", rot_deg=8.0):
+    """Inputs of ORBmatcher::searchByProjection(CurrentFrame, LastFrame, th, bMono): a last frame with NL
+    features carrying map points and a current frame with NF features that re-observes ~70 % of them
+    (pixel noise, descriptor bit flips, in-plane rotation `rot_deg` so that the orientation histogram has a
+    dominant bin plus outliers).  motion: "none" | "forward" | "backward" selects the level window."""
+    rng = np.random.default_rng(seed)
+    W, H = cam.width, cam.height
+    pose_lw = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    dz = {"none": 0.0, "forward": -0.4, "backward": 0.4}[motion]  # t_cw.z of the current frame
+    ang = np.deg2rad(1.5)
+    pose_cw = np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2), 0.02, -0.01, dz])
+    depth = rng.uniform(1.5, 8.0, NL)
+    u_l, v_l = rng.uniform(20, W - 20, NL), rng.uniform(20, H - 20, NL)
+    last_pt = np.stack([(u_l - cam.cx) / cam.fx * depth, (v_l - cam.cy) / cam.fy * depth, depth], 1)
+    last_valid = (rng.uniform(size=NL) < 0.85).astype(np.uint8)
+    last_oct = rng.integers(0, 8, NL).astype(np.int32)
+    last_angle = rng.uniform(0, 360, NL).astype(np.float32)
+    last_desc = rng.integers(0, 256, (NL, 32), dtype=np.uint8)
+    R = quat_to_R(pose_cw[:4])
+    pc = last_pt @ R.T + pose_cw[4:]
+    u_c = cam.fx * pc[:, 0] / pc[:, 2] + cam.cx
+    v_c = cam.fy * pc[:, 1] / pc[:, 2] + cam.cy
+    src = rng.integers(0, NL, NF)
+    reobs = rng.uniform(size=NF) < 0.7
+    sf = 1.2 ** np.arange(8)
+    noise = rng.uniform(-1.1, 1.1, (NF, 2)) * (7.0 * sf[last_oct[src]])[:, None]
+    uv = np.where(reobs[:, None], np.stack([u_c[src], v_c[src]], 1) + noise,
+                  np.stack([rng.uniform(-5, W + 5, NF), rng.uniform(-5, H + 5, NF)], 1))
+    octv = np.clip(last_oct[src] + rng.integers(-1, 2, NF), 0, 7).astype(np.int32)
+    octv[rng.uniform(size=NF) < 0.03] = -1
+    ur_true = uv[:, 0] - cam.bf / np.maximum(pc[src, 2], 0.1)
+    ur = np.where(rng.uniform(size=NF) < 0.7, ur_true + rng.uniform(-1.1, 1.1, NF) * 7.0 * sf[last_oct[src]], -1.0)
+    ur = ur.astype(np.float32)
+    out_rot = rng.uniform(size=NF) < 0.15
+    angle = np.where(out_rot, rng.uniform(0, 360, NF), (last_angle[src] - rot_deg + rng.normal(0, 3, NF)) % 360.0)
+    desc = last_desc[src].copy()
+    nflip = rng.integers(0, 71, NF)
+    for i in range(NF):
+        if reobs[i]:
+            bits = rng.choice(256, nflip[i], replace=False)
+            np.bitwise_xor.at(desc[i], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+        else:
+            desc[i] = rng.integers(0, 256, 32, dtype=np.uint8)
+    taken = (rng.uniform(size=NF) < 0.05).astype(np.uint8)
+    return dict(pose_cw=pose_cw, pose_lw=pose_lw, feat_uv=uv, feat_ur=ur, feat_oct=octv,
+                feat_angle=angle.astype(np.float32), feat_desc=desc, feat_taken=taken, last_pt=last_pt,
+                last_valid=last_valid, last_oct=last_oct, last_angle=last_angle, last_desc=last_desc)

@@ -190,6 +190,24 @@ int gl_search_by_projection(gl_ctx_t* ctx, const gl_camera* cam, float scale_fac
                             const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
                             int32_t* nmatches_dev);
 
+/* ORBmatcher::searchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (orb_matcher.cpp:410-542) + computeThreeMaxima (:544-578): the matcher of
+ * Tracking::trackWithMotionModel (tracking.cpp:334-350).  Per frame pair: pose_cw / pose_lw = getTcw() of the
+ * current / last frame (B x 7); the current frame's features as above plus feat_angle B x NF float
+ * (cv::KeyPoint::angle); the last frame's NL features: last_pt B x NL x 3 (position of its map point),
+ * last_valid B x NL uint8 (mappoints_[i] && !is_outlier_[i]), last_oct B x NL int32, last_angle B x NL float,
+ * last_desc B x NL x 32 (the map point's descriptor).  th = 7 or 14; mono = bMono; check_orientation =
+ * ORBmatcher::check_orientation_.  cam supplies fx fy cx cy bf (as the float config scalars) and width /
+ * height.  out: feat_match B x NF int32 = index i of the last-frame feature whose map point the feature
+ * received, -1 none (after the rotation-consistency filter); nmatches B int32. */
+int gl_search_by_projection_frame(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NL,
+                                  const double* pose_cw_dev, const double* pose_lw_dev, const double* feat_uv_dev,
+                                  const float* feat_ur_dev, const int32_t* feat_oct_dev, const float* feat_angle_dev,
+                                  const uint8_t* feat_desc_dev, const uint8_t* feat_taken_dev, const double* last_pt_dev,
+                                  const uint8_t* last_valid_dev, const int32_t* last_oct_dev,
+                                  const float* last_angle_dev, const uint8_t* last_desc_dev, float th, int mono,
+                                  int check_orientation, int32_t* feat_match_dev, int32_t* nmatches_dev);
+
 /* ---- point refinement ----------------------------------------------------- */
 /* GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N independent problems.
  * pts N x 3, uvr N x 3 (u, v, u_right), octave N, pose N x 7, comp N, proj_z2 N.

@@ -1056,6 +1056,178 @@ int orc_search_by_projection(int width, int height, float scale_factor, int NF, 
   return nmatches;
 }
 
+// ---- ORBmatcher::searchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+//      (orb_matcher.cpp:410-542) + computeThreeMaxima (:544-578), one frame pair.
+//  pose_cw / pose_lw: (qx qy qz qw tx ty tz) = getTcw() of the current / last frame.
+//  Eigen's Quaternion * Vector3 (uv = 2 q.vec x v; v + w uv + q.vec x uv) is restated literally.
+//  last_valid[i] != 0  <=>  LastFrame.mappoints_[i] && !LastFrame.is_outlier_[i];  last_pt = its position.
+//  out feat_match[idx] = i (index in the last frame) or -1; returns nmatches after the rotation check.
+static void quat_rot(const double* q, const double* v, double* out) {
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  double uv[3] = {qy * v[2] - qz * v[1], qz * v[0] - qx * v[2], qx * v[1] - qy * v[0]};
+  uv[0] += uv[0];
+  uv[1] += uv[1];
+  uv[2] += uv[2];
+  out[0] = v[0] + qw * uv[0] + (qy * uv[2] - qz * uv[1]);
+  out[1] = v[1] + qw * uv[1] + (qz * uv[0] - qx * uv[2]);
+  out[2] = v[2] + qw * uv[2] + (qx * uv[1] - qy * uv[0]);
+}
+
+int orc_search_by_projection_frame(const orc_camera* cam, float scale_factor, const double* pose_cw,
+                                   const double* pose_lw, int NF, const double* feat_uv, const float* feat_ur,
+                                   const int32_t* feat_oct, const float* feat_angle, const uint8_t* feat_desc,
+                                   const uint8_t* feat_taken, int NL, const double* last_pt, const uint8_t* last_valid,
+                                   const int32_t* last_oct, const float* last_angle, const uint8_t* last_desc, float th,
+                                   int mono, int check_orientation, int32_t* feat_match) {
+  const int grid_cols = 64, grid_rows = 48, HISTO_LENGTH = 30;
+  const int width = cam->width, height = cam->height;
+  const float col_inv = static_cast<float>(grid_cols) / width, row_inv = static_cast<float>(grid_rows) / height;
+  const float cfx = (float)cam->fx, cfy = (float)cam->fy, ccx = (float)cam->cx, ccy = (float)cam->cy,
+              cbf = (float)cam->bf;                     // config.h:38-48: float scalars
+  const double fx = cfx, fy = cfy, cx = ccx, cy = ccy;  // PinholeCamera::fx() returns double
+  const float mbf = cbf, mb = cbf / cfx;                // frame.cpp:23-24
+  float sf[8];
+  sf[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) sf[i] = sf[i - 1] * scale_factor;
+  std::vector<std::vector<int>> grid((size_t)grid_cols * grid_rows);
+  for (int i = 0; i < NF; ++i) {
+    if (feat_oct[i] < 0) continue;
+    const int px = (int)round((feat_uv[2 * i] - 0.0f) * col_inv), py = (int)round((feat_uv[2 * i + 1] - 0.0f) * row_inv);
+    if (px < 0 || px >= grid_cols || py < 0 || py >= grid_rows) continue;
+    grid[(size_t)px * grid_rows + py].push_back(i);
+  }
+  std::vector<uint8_t> taken(feat_taken, feat_taken + NF);
+  for (int i = 0; i < NF; ++i) feat_match[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = HISTO_LENGTH / 360.0f;
+  // Twc = Tcw.inverse(): r = conj(q), t = r * (-t);  tlc = Rlw * twc + tlw
+  const double qc_inv[4] = {-pose_cw[0], -pose_cw[1], -pose_cw[2], pose_cw[3]};
+  const double mt[3] = {pose_cw[4] * -1., pose_cw[5] * -1., pose_cw[6] * -1.};
+  double twc[3], tlc[3];
+  quat_rot(qc_inv, mt, twc);
+  quat_rot(pose_lw, twc, tlc);
+  tlc[0] += pose_lw[4];
+  tlc[1] += pose_lw[5];
+  tlc[2] += pose_lw[6];
+  const bool bForward = tlc[2] > mb && !mono;
+  const bool bBackward = -tlc[2] > mb && !mono;
+  int nmatches = 0;
+  for (int i = 0; i < NL; ++i) {
+    if (!last_valid[i]) continue;
+    double ptc[3];
+    quat_rot(pose_cw, last_pt + 3 * i, ptc);
+    ptc[0] += pose_cw[4];
+    ptc[1] += pose_cw[5];
+    ptc[2] += pose_cw[6];
+    const float xc = ptc[0], yc = ptc[1], invzc = 1.0 / ptc[2];
+    if (invzc < 0) continue;
+    const float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+    if (u < 0 || u > width) continue;
+    if (v < 0 || v > height) continue;
+    const int oct = last_oct[i];
+    const float radius = th * sf[oct];
+    int minLevel, maxLevel;
+    if (bForward) {
+      minLevel = oct;
+      maxLevel = -1;
+    } else if (bBackward) {
+      minLevel = 0;
+      maxLevel = oct;
+    } else {
+      minLevel = oct - 1;
+      maxLevel = oct + 1;
+    }
+    const float x = u, y = v, rr = radius;
+    const int x0 = std::max(0, (int)floor((x - 0.0f - rr) * col_inv));
+    if (x0 >= grid_cols) continue;
+    const int x1 = std::min(grid_cols - 1, (int)ceil((x - 0.0f + rr) * col_inv));
+    if (x1 < 0) continue;
+    const int y0 = std::max(0, (int)floor((y - 0.0f - rr) * row_inv));
+    if (y0 >= grid_rows) continue;
+    const int y1 = std::min(grid_rows - 1, (int)ceil((y - 0.0f + rr) * row_inv));
+    if (y1 < 0) continue;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    int bestDist = 256, bestIdx2 = -1;
+    for (int ix = x0; ix <= x1; ++ix)
+      for (int iy = y0; iy <= y1; ++iy)
+        for (int i2 : grid[(size_t)ix * grid_rows + iy]) {
+          const int oc = feat_oct[i2];
+          if (bCheckLevels) {
+            if (oc < minLevel) continue;
+            if (maxLevel >= 0 && oc > maxLevel) continue;
+          }
+          const float distx = feat_uv[2 * i2] - x, disty = feat_uv[2 * i2 + 1] - y;
+          if (!(fabs(distx) < rr && fabs(disty) < rr)) continue;
+          if (taken[i2]) continue;
+          if (feat_ur[i2] > 0) {
+            const float ur = u - mbf * invzc;
+            const float er = fabs(ur - feat_ur[i2]);
+            if (er > radius) continue;
+          }
+          const int32_t* pa = (const int32_t*)(last_desc + (size_t)i * 32);
+          const int32_t* pb = (const int32_t*)(feat_desc + (size_t)i2 * 32);
+          int dist = 0;
+          for (int w = 0; w < 8; ++w) {
+            unsigned int vv = pa[w] ^ pb[w];
+            vv = vv - ((vv >> 1) & 0x55555555);
+            vv = (vv & 0x33333333) + ((vv >> 2) & 0x33333333);
+            dist += (((vv + (vv >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+          }
+          if (dist < bestDist) {
+            bestDist = dist;
+            bestIdx2 = i2;
+          }
+        }
+    if (bestDist <= 100) {
+      feat_match[bestIdx2] = i;
+      taken[bestIdx2] = 1;
+      nmatches++;
+      if (check_orientation) {
+        float rot = last_angle[i] - feat_angle[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);  // (assert in the reference)
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int sz = rotHist[i].size();
+      if (sz > max1) {
+        max3 = max2;
+        max2 = max1;
+        max1 = sz;
+        ind3 = ind2;
+        ind2 = ind1;
+        ind1 = i;
+      } else if (sz > max2) {
+        max3 = max2;
+        max2 = sz;
+        ind3 = ind2;
+        ind2 = i;
+      } else if (sz > max3) {
+        max3 = sz;
+        ind3 = i;
+      }
+    }
+    if (max2 < 0.1f * (float)max1) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+      ind3 = -1;
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) {
+          feat_match[idx] = -1;
+          nmatches--;
+        }
+  }
+  return nmatches;
+}
+
 void orc_se3_exp(const double* u, double* pose) { from_se3(se3_exp(u), pose); }
 void orc_se3_log(const double* pose, double* u) { se3_log(to_se3(pose), u); }
 void orc_se3_mul(const double* a, const double* b, double* out) { from_se3(se3_mul(to_se3(a), to_se3(b)), out); }

@@ -616,3 +616,116 @@ def search_by_projection(width, height, feat_uv, feat_ur, feat_oct, feat_desc, f
             taken[bidx] = True
             n += 1
     return match, n
+
+
+def _qrot(q, v):
+    """Eigen Quaternion * Vector3 (uv = 2 q.vec x v; v + w uv + q.vec x uv)."""
+    qv, w = np.asarray(q[:3], float), float(q[3])
+    uv = np.cross(qv, v)
+    uv = uv + uv
+    return v + w * uv + np.cross(qv, uv)
+
+
+def search_by_projection_frame(cam, pose_cw, pose_lw, feat_uv, feat_ur, feat_oct, feat_angle, feat_desc, feat_taken,
+                               last_pt, last_valid, last_oct, last_angle, last_desc, th=7.0, mono=False,
+                               check_orientation=True, scale_factor=1.2):
+    """ORBmatcher::searchByProjection(CurrentFrame, LastFrame, th, bMono) (orb_matcher.cpp:410-542),
+    independent restatement: brute force over all features in grid order, table popcount, histogram by
+    np.bincount."""
+    f32 = np.float32
+    W, H = int(cam.width), int(cam.height)
+    col_inv, row_inv = f32(64) / f32(W), f32(48) / f32(H)
+    sf = [f32(1.0)]
+    for _ in range(7):
+        sf.append(f32(sf[-1] * f32(scale_factor)))
+    fx, fy, cx, cy = (np.float64(f32(v)) for v in (cam.fx, cam.fy, cam.cx, cam.cy))
+    mbf = f32(cam.bf)
+    mb = f32(mbf / f32(cam.fx))
+    NF, NL = len(feat_oct), len(last_valid)
+    rnd = lambda v: np.where(v >= 0, np.floor(v + 0.5), np.ceil(v - 0.5)).astype(np.int64)
+    px = rnd(feat_uv[:, 0] * np.float64(col_inv))
+    py = rnd(feat_uv[:, 1] * np.float64(row_inv))
+    in_grid = (feat_oct >= 0) & (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    order = np.lexsort((np.arange(NF), py, px))
+    order = order[in_grid[order]]
+    qc, tc = pose_cw[:4], pose_cw[4:]
+    twc = _qrot(np.array([-qc[0], -qc[1], -qc[2], qc[3]]), tc * -1.0)
+    tlc = _qrot(pose_lw[:4], twc) + pose_lw[4:]
+    fwd = bool(tlc[2] > np.float64(mb)) and not mono
+    bwd = bool(-tlc[2] > np.float64(mb)) and not mono
+    taken = np.array(feat_taken, bool).copy()
+    match = -np.ones(NF, np.int32)
+    bins = {}
+    th = f32(th)
+    for i in range(NL):
+        if not last_valid[i]:
+            continue
+        ptc = _qrot(qc, last_pt[i]) + tc
+        xc, yc, invzc = f32(ptc[0]), f32(ptc[1]), f32(1.0 / ptc[2])
+        if invzc < 0:
+            continue
+        u = f32(fx * np.float64(xc) * np.float64(invzc) + cx)
+        v = f32(fy * np.float64(yc) * np.float64(invzc) + cy)
+        if u < 0 or u > f32(W) or v < 0 or v > f32(H):
+            continue
+        oc0 = int(last_oct[i])
+        rr = f32(th * sf[oc0])
+        if fwd:
+            lo, hi = oc0, -1
+        elif bwd:
+            lo, hi = 0, oc0
+        else:
+            lo, hi = oc0 - 1, oc0 + 1
+        check = lo > 0 or hi >= 0
+        if int(np.floor(f32(f32(u - rr) * col_inv))) >= 64 or int(np.ceil(f32(f32(u + rr) * col_inv))) < 0:
+            continue
+        if int(np.floor(f32(f32(v - rr) * row_inv))) >= 48 or int(np.ceil(f32(f32(v + rr) * row_inv))) < 0:
+            continue
+        best, bidx = 256, -1
+        for idx in order:
+            oc = int(feat_oct[idx])
+            if check and (oc < lo or (hi >= 0 and oc > hi)):
+                continue
+            dx, dy = f32(feat_uv[idx, 0] - np.float64(u)), f32(feat_uv[idx, 1] - np.float64(v))
+            if not (abs(dx) < rr and abs(dy) < rr):
+                continue
+            if taken[idx]:
+                continue
+            if feat_ur[idx] > 0:
+                ur = f32(u - f32(mbf * invzc))
+                if abs(f32(ur - f32(feat_ur[idx]))) > rr:
+                    continue
+            d = int(_POP8[np.bitwise_xor(last_desc[i], feat_desc[idx])].sum())
+            if d < best:
+                best, bidx = d, idx
+        if best <= 100:
+            match[bidx] = i
+            taken[bidx] = True
+            if check_orientation:
+                rot = f32(f32(last_angle[i]) - f32(feat_angle[bidx]))
+                if rot < 0.0:
+                    rot = f32(rot + f32(360.0))
+                b = int(rnd(np.float64(f32(rot * f32(f32(30) / f32(360.0))))))
+                if b == 30:
+                    b = 0
+                bins[bidx] = b
+    if check_orientation and bins:
+        cnt = np.bincount(np.array(list(bins.values())), minlength=30)
+        m1 = m2 = m3 = 0
+        i1 = i2 = i3 = -1
+        for b in range(30):
+            c = int(cnt[b])
+            if c > m1:
+                m3, m2, m1, i3, i2, i1 = m2, m1, c, i2, i1, b
+            elif c > m2:
+                m3, m2, i3, i2 = m2, c, i2, b
+            elif c > m3:
+                m3, i3 = c, b
+        if m2 < f32(0.1) * f32(m1):
+            i2 = i3 = -1
+        elif m3 < f32(0.1) * f32(m1):
+            i3 = -1
+        for idx, b in bins.items():
+            if b not in (i1, i2, i3):
+                match[idx] = -1
+    return match, int((match >= 0).sum())

@@ -188,6 +188,27 @@ class Oracle:
                                               C.c_float(nn_ratio), _p(out))
         return out, int(n)
 
+    def search_by_projection_frame(self, cam, pose_cw, pose_lw, feat_uv, feat_ur, feat_oct, feat_angle, feat_desc,
+                                   feat_taken, last_pt, last_valid, last_oct, last_angle, last_desc, th=7.0, mono=False,
+                                   check_orientation=True, scale_factor=1.2):
+        """ORBmatcher::searchByProjection(CurrentFrame, LastFrame, th, bMono) -> (feat_match [NF], nmatches)."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        feat_uv, last_pt, pose_cw, pose_lw = _f64(feat_uv), _f64(last_pt), _f64(pose_cw), _f64(pose_lw)
+        feat_ur, feat_angle, last_angle = f32(feat_ur), f32(feat_angle), f32(last_angle)
+        feat_oct, last_oct = _i32(feat_oct), _i32(last_oct)
+        feat_desc, feat_taken, last_valid, last_desc = u8(feat_desc), u8(feat_taken), u8(last_valid), u8(last_desc)
+        NF, NL = feat_uv.shape[0], last_pt.shape[0]
+        out = np.zeros(NF, np.int32)
+        c = self.camera(cam)
+        self.lib.orc_search_by_projection_frame.restype = C.c_int
+        n = self.lib.orc_search_by_projection_frame(C.byref(c), C.c_float(scale_factor), _p(pose_cw), _p(pose_lw), NF,
+                                                    _p(feat_uv), _p(feat_ur), _p(feat_oct), _p(feat_angle), _p(feat_desc),
+                                                    _p(feat_taken), NL, _p(last_pt), _p(last_valid), _p(last_oct),
+                                                    _p(last_angle), _p(last_desc), C.c_float(th), int(bool(mono)),
+                                                    int(bool(check_orientation)), _p(out))
+        return out, int(n)
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

@@ -78,3 +78,44 @@ def test_search_by_projection_degenerate_inputs(gpu, oracle):
         m_ref, n_ref = oracle.search_by_projection(th=3.0, **fr)
         assert n[b] == n_ref and np.array_equal(m[b], m_ref), b
     assert n[0] > 0 and (n[1:] == 0).all()
+
+
+FKEYS = ("pose_cw", "pose_lw", "feat_uv", "feat_ur", "feat_oct", "feat_angle", "feat_desc", "feat_taken", "last_pt",
+         "last_valid", "last_oct", "last_angle", "last_desc")
+
+
+class CamF:  # cfg/v1.yaml intrinsics as the float config scalars (config.h:38-48)
+    f32 = staticmethod(lambda x: float(np.float32(x)))
+    fx = fy = f32.__func__(435.2046959714599)
+    cx = f32.__func__(367.4517211914062)
+    cy = f32.__func__(252.2008514404297)
+    bf = f32.__func__(47.90639384423901)
+    width, height = 752, 480
+
+
+def run_gpu_frame(torch, ctx, frames, th, mono=False, chk=True):
+    cam = api.Camera()
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in frames]))).cuda()
+    a = [T(k) for k in FKEYS]
+    m, n = api.search_by_projection_frame(ctx, cam, *a, th=th, mono=mono, check_orientation=chk)
+    torch.cuda.synchronize()
+    return m.cpu().numpy(), n.cpu().numpy()
+
+
+@pytest.mark.parametrize("NF,NL,th,motion,mono,chk", [(300, 250, 7.0, "none", False, True), (1200, 900, 7.0, "forward", False, True),
+                                                     (1500, 1200, 14.0, "backward", False, True),
+                                                     (1000, 1000, 7.0, "forward", True, True),
+                                                     (800, 800, 7.0, "none", False, False), (2000, 3000, 14.0, "none", False, True)])
+def test_search_by_projection_frame_matches_oracle(gpu, oracle, NF, NL, th, motion, mono, chk):
+    torch, ctx = gpu
+    c = api.Camera()
+    assert (c.fx, c.cx, c.bf, c.width, c.height) == (CamF.fx, CamF.cx, CamF.bf, CamF.width, CamF.height)
+    frames = [synth.synth_motion_frames(NF, NL, 77 * NF + b, CamF, motion) for b in range(4)]
+    m, n = run_gpu_frame(torch, ctx, frames, th, mono, chk)
+    tot = 0
+    for b, f in enumerate(frames):
+        m_ref, n_ref = oracle.search_by_projection_frame(CamF, th=th, mono=mono, check_orientation=chk, **f)
+        assert n[b] == n_ref, (b, int(n[b]), n_ref)
+        assert np.array_equal(m[b], m_ref), (b, int((m[b] != m_ref).sum()))
+        tot += n_ref
+    assert tot > 50

@@ -169,6 +169,19 @@ def main():
         out["m%d_args" % i] = np.array([NF, NP, seed, th])
         out["m%d_match" % i] = m
         out["m%d_n" % i] = np.array(n)
+    class CamF:  # cfg/v1.yaml intrinsics as the float config scalars
+        pass
+    c0 = cam_v1()
+    for k in ("fx", "fy", "cx", "cy", "bf"):
+        setattr(CamF, k, float(np.float32(getattr(c0, k))))
+    CamF.width, CamF.height = 752, 480
+    for i, (NF, NL, seed, th, motion, chk) in enumerate(((260, 220, 111, 7.0, "none", 1), (500, 420, 112, 7.0, "forward", 1),
+                                                          (450, 500, 113, 14.0, "backward", 1), (300, 300, 114, 7.0, "none", 0))):
+        fr = synth.synth_motion_frames(NF, NL, seed, CamF, motion)
+        m, n = nr.search_by_projection_frame(CamF, th=th, check_orientation=bool(chk), **fr)
+        out["f%d_args" % i] = np.array([NF, NL, seed, th, {"none": 0, "forward": 1, "backward": 2}[motion], chk])
+        out["f%d_match" % i] = m
+        out["f%d_n" % i] = np.array(n)
     np.savez_compressed(os.path.join(G, "golden_match.npz"), **out)
     print("golden vectors written to", G)
 

@@ -288,6 +288,19 @@ def config_match(torch, ctx, out):
         orc.search_by_projection(th=3.0, **f)
     tc = (time.perf_counter() - t0) / len(uniq)
     bytes_frame = NF * (16 + 4 + 4 + 32 + 1 + 4) + NP * (24 + 4 + 8 + 1 + 32)
+    # frame-to-frame overload (trackWithMotionModel): 1 200 features vs the 1 000 map points of the last frame
+    from tests.test_gpu_match import FKEYS, CamF
+    NL = 1000
+    uq = [synth.synth_motion_frames(NF, NL, 900 + b, CamF, "none") for b in range(64)]
+    fr2 = [uq[b % 64] for b in range(B)]
+    a2 = [torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in fr2]))).cuda() for k in FKEYS]
+    t2 = ev_time(torch, lambda: api.search_by_projection_frame(ctx, api.Camera(), *a2, th=7.0), 5, ctx.stream)
+    t0 = time.perf_counter()
+    for f in uq:
+        orc.search_by_projection_frame(CamF, th=7.0, **f)
+    tc2 = (time.perf_counter() - t0) / len(uq)
+    out({"config": "searchByProjection(CurrentFrame, LastFrame): %d frame pairs x %d features x %d last-frame map points, th=7" % (B, NF, NL),
+         "frames_per_s": B / t2, "cpu_oracle_1thread_frames_per_s": 1.0 / tc2})
     out({"config": "searchByProjection: %d frames x %d features x %d map points, th=3" % (B, NF, NP),
          "frames_per_s": B / t, "single_frame_latency_us": 1e6 * t1, "algorithmic_bytes_per_frame": bytes_frame,
          "algorithmic_GBs": B * bytes_frame / t / 1e9, "cpu_oracle_1thread_frames_per_s": 1.0 / tc})
