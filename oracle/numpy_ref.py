@@ -300,6 +300,92 @@ def optimize_point(pt, uvr, octave, pose7, normal, mu, proj_z2, cam, prm):
     return res, chi2_proj, chi2_str, x
 
 
+# ------------------------------------------------------------------ A8
+def check_map_association(pt, uvr, octave, pose7, cands, comps, mean, nbs, cam, prm):
+    """GMMLoc::checkMapAssociation (gmmloc_opt.cpp:156-258).  cands: parent component indices of the feature
+    (kf->comps_[idx]); comps: build_components() dict; nbs: list of neighbour index lists (nbs_).
+    Returns (component or -1, point) -- the point is moved exactly where the reference writes it."""
+    pt0 = np.array(pt, float)
+    cands = [int(c) for c in cands if c >= 0]
+    if not cands:
+        return -1, pt0
+    T = SE3.from7(pose7)
+    z = min(1.0, T.map(pt0)[2])
+    pz2 = z * z
+    run = lambda k: optimize_point(pt0, uvr, octave, pose7, comps["axis"][k][:, 0], mean[k], pz2, cam, prm)
+    chi2 = lambda k, x: float((x - mean[k]) @ comps["cov_inv"][k] @ (x - mean[k]))
+    best, best_v, best_x = -1, np.inf, None
+    for k in cands:
+        ok, c2p, _, x = run(k)
+        if ok and c2p < best_v:
+            best, best_v, best_x = k, c2p, x
+    if best >= 0:
+        ll, sel = chi2(best, best_x), best
+        for n in nbs[best]:
+            ln = chi2(n, best_x)
+            if ln < ll:
+                ll, sel = ln, n
+        if sel != best:
+            ok, _, _, x = run(sel)
+            if ok:
+                best_x = x
+            else:
+                sel, ll = best, chi2(best, best_x)
+        if ll > 9.0:
+            return -1, pt0
+        return sel, best_x
+    # fallback: nearest mean of the 5-NN (queryPoint); only a degenerate component is tried, and the
+    # association is NOT returned even when the point is moved (:237-256)
+    k = int(np.argmin(((mean - pt0) ** 2).sum(1)))
+    if not comps["is_deg"][k]:
+        return -1, pt0
+    ok, _, _, x = run(k)
+    return -1, (x if ok else pt0)
+
+
+# ------------------------------------------------------------------ B2
+def optimize_triangulation(x3d, pose1, uvr1, oct1, pose2, uvr2, cands1, cands2, comps, mean, cam, prm):
+    """Localization::optimizeTriangulationVec (localization_opt.cpp:27-204): for every DEGENERATE candidate
+    (comps1 then comps2, de-duplicated) 20 Gauss-Newton steps from the initial point on two fixed-pose
+    reprojection edges (both weighted with kp1's 1/sigma^2, :132,135) + the point-to-plane edge
+    (tri_lambda2); chi2 values are those of the last computeActiveErrors (before the 20th update)."""
+    x0 = np.array(x3d, float)
+    T1, T2 = SE3.from7(pose1), SE3.from7(pose2)
+    st1, st2 = not (uvr1[2] < 0), not (uvr2[2] < 0)
+    s = float(prm.sigma2_inv[oct1])
+    lam = float(prm.tri_lambda2)
+    th1, th2 = (7.8 if st1 else 5.991), (7.8 if st2 else 5.991)
+    order = []
+    for c in list(cands1) + list(cands2):
+        if c >= 0 and int(c) not in order:
+            order.append(int(c))
+    best, best_v, best_x = -1, np.inf, None
+    for k in order:
+        if not comps["is_deg"][k]:
+            continue
+        n, mu = comps["axis"][k][:, 0], mean[k]
+        x = x0.copy()
+        for _ in range(20):
+            H, b = lam * np.outer(n, n), -lam * n * (n @ (x - mu))
+            errs = []
+            for T, uvr, st in ((T1, uvr1, st1), (T2, uvr2, st2)):
+                pc = T.map(x)
+                d = 3 if st else 2
+                e = uvr[:d] - proj_stereo(pc, cam)[:d]
+                J = -dproj(pc, cam, st) @ T.R
+                H = H + s * J.T @ J
+                b = b - s * J.T @ e
+                errs.append(s * e @ e)
+            es = lam * (n @ (x - mu)) ** 2
+            x = x + np.linalg.solve(H, b)
+        ok = not (prm.tri_check_str_chi2 and es > float(F32(prm.tri_str_thresh * prm.tri_lambda2)))
+        if errs[0] > th1 or errs[1] > th2:
+            ok = False
+        if ok and errs[0] + errs[1] < best_v:
+            best, best_v, best_x = k, errs[0] + errs[1], x
+    return best, (best_x if best >= 0 else x0)
+
+
 # ------------------------------------------------------------------ generic dense LM (B3 / B4)
 class Problem:
     """Un-reduced dense Levenberg-Marquardt over free poses (6) and free points (3) with the

@@ -100,6 +100,44 @@ def main():
     np.savez_compressed(os.path.join(G, "golden_optpoint.npz"), pose=pose, pts=X0, uvr=f["obs"], octave=f["octave"],
                         comp=comp.astype(np.int32), proj_z2=pz, res=np.array(res, np.uint8), chi2_proj=np.array(c2p),
                         chi2_str=np.array(c2s), pt_est=np.stack(est))
+    # --- A8: checkMapAssociation / B2: optimizeTriangulationVec (independent restatements) -------------
+    rng8 = np.random.default_rng(8)
+    K = mean.shape[0]
+    cands = -np.ones((N, 5), np.int32)
+    for i in range(N):
+        n = int(rng8.integers(0, 5))
+        c = [int(f["comp"][i])] + [int(x) for x in rng8.integers(0, K, 4)]
+        rng8.shuffle(c)
+        cands[i, :n] = c[:n]
+    need = sorted(set(int(c) for c in cands.ravel() if c >= 0))
+    nb_rows = dict(zip(need, [j for j, _ in nr.neighbour_rows(mean, cov, comps["det"], need)]))
+    nbs = [nb_rows.get(k, np.zeros(0, int)) for k in range(K)]
+    a_comp, a_pt = [], []
+    for i in range(N):
+        c, x = nr.check_map_association(X0[i], f["obs"][i], int(f["octave"][i]), pose, cands[i], comps, mean, nbs, cam, prm)
+        a_comp.append(c); a_pt.append(x)
+    np.savez_compressed(os.path.join(G, "golden_cma.npz"), pose=pose, pts=X0, uvr=f["obs"], octave=f["octave"], cand=cands,
+                        ncand=(cands >= 0).sum(1).astype(np.int32), out_comp=np.array(a_comp, np.int32), out_pt=np.array(a_pt))
+    pose2 = poses[1]
+    T2 = nr.SE3.from7(pose2)
+    pc2 = np.array([T2.map(x) for x in f["Xw"]])
+    u2 = cam.fx * pc2[:, 0] / pc2[:, 2] + cam.cx + rng8.standard_normal(N) * 0.7
+    v2 = cam.fy * pc2[:, 1] / pc2[:, 2] + cam.cy + rng8.standard_normal(N) * 0.7
+    uvr2 = np.stack([u2, v2, np.where(rng8.uniform(size=N) < 0.5, -1.0, u2 - cam.bf / pc2[:, 2])], 1)
+    uvr1 = f["obs"].copy()
+    uvr1[rng8.uniform(size=N) < 0.4, 2] = -1.0
+    cands2 = -np.ones((N, 5), np.int32)
+    for i in range(N):
+        n = int(rng8.integers(0, 4))
+        cands2[i, :n] = rng8.integers(0, K, n)
+    t_comp, t_pt = [], []
+    for i in range(N):
+        c, x = nr.optimize_triangulation(X0[i], pose, uvr1[i], int(f["octave"][i]), pose2, uvr2[i], cands[i], cands2[i],
+                                         comps, mean, cam, prm)
+        t_comp.append(c); t_pt.append(x)
+    np.savez_compressed(os.path.join(G, "golden_tri.npz"), pose1=pose, pose2=pose2, x3d=X0, uvr1=uvr1, uvr2=uvr2,
+                        oct1=f["octave"], cand1=cands, cand2=cands2, out_comp=np.array(t_comp, np.int32),
+                        out_pt=np.array(t_pt))
 
     # --- B3: optimizeCurrentPose ---------------------------------------------------------------
     out = {}
