@@ -14,6 +14,15 @@
 //   solve  in-place right-looking LDL^T of the 6P x 6P system by the whole workgroup.
 //   P3  back-substitution per point, trial state, new errors, rho test.
 // Control flow and gating as in gl_ba.hip (g2o Levenberg, 5 / 5 / 40 schedule).
+//
+// A problem is worked on by NB co-resident workgroups (cooperative launch): the point / observation
+// loops and the (j1, j2) blocks are strided over all of them, phases are separated by a
+// per-problem barrier (atomic counter + device-scope fences), sums go through per-workgroup
+// partials that every workgroup adds up in the same order, so all workgroups take identical
+// branches and the result does not depend on NB.  NB = 1 (large batches) needs no global barrier.
+#include <algorithm>
+#include <cstdlib>
+
 #include "gl_ba_common.hpp"
 
 using namespace gld;
@@ -54,7 +63,61 @@ struct GenP {
   uint8_t* pfree;  // P + F
   uint8_t* pact;   // P
   uint8_t* lact;   // L  point active this optimize()
+  // multi-workgroup execution
+  int NB, pb;          // workgroups per problem, index of this one
+  unsigned* bar;       // {arrivals, generation}
+  double* part;        // NB x 4 partial sums
+  double* Sw;          // n x n work copy for the solve when NB > 1 and it does not fit in LDS
+  int* flagg;          // solve status
 };
+
+// barrier over the NB workgroups of one problem (all co-resident: cooperative launch)
+GL_DEV void prob_sync(const GenP& G) {
+  __syncthreads();
+  if (G.NB > 1) {
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned gen = atomicAdd(&G.bar[1], 0u);
+      if (atomicAdd(&G.bar[0], 1u) == (unsigned)G.NB - 1u) {
+        G.bar[0] = 0u;
+        __threadfence();
+        atomicAdd(&G.bar[1], 1u);
+      } else {
+        while (atomicAdd(&G.bar[1], 0u) == gen) __builtin_amdgcn_s_sleep(2);
+      }
+      __threadfence();
+    }
+    __syncthreads();
+  }
+}
+// problem-wide sum of NV (<= 4) per-thread values: workgroup reduction, partials to global memory,
+// every workgroup adds the NB partials in index order (identical result everywhere)
+template <int NV>
+GL_DEV void prob_reduce(const GenP& G, double* acc, double* red) {
+  block_reduce<NV, NW_BA>(acc, red);
+  if (G.NB == 1) return;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < NV; ++i) G.part[G.pb * 4 + i] = acc[i];
+  prob_sync(G);
+  for (int i = 0; i < NV; ++i) {
+    double s = 0.0;
+    for (int b = 0; b < G.NB; ++b) s += G.part[b * 4 + i];
+    acc[i] = s;
+  }
+  prob_sync(G);  // partials may be overwritten by the next reduction
+}
+GL_DEV double prob_max(const GenP& G, double v, double* red) {
+  v = block_max(v, red);
+  if (G.NB == 1) return v;
+  if (threadIdx.x == 0) G.part[G.pb * 4] = v;
+  prob_sync(G);
+  double m = G.part[0];
+  for (int b = 1; b < G.NB; ++b) m = fmax(m, G.part[b * 4]);
+  prob_sync(G);
+  return m;
+}
+#define GSTART (G.pb * T_BA + (int)threadIdx.x)
+#define GSTRIDE (G.NB * T_BA)
 
 GL_DEV void load_Rt(const double* Rt, double* R, double* t) {
 #pragma unroll
@@ -169,7 +232,7 @@ GL_DEV void gmg(const double* q1, const double* M, const double* q2, double* blk
 // returns (per-thread partial) robust chi2; mdiag = max landmark diagonal (world frame)
 GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
   double chi = 0.0;
-  for (int l = threadIdx.x; l < G.L; l += T_BA) {
+  for (int l = GSTART; l < G.L; l += GSTRIDE) {
     if (!G.lact[l]) continue;
     const double p[3] = {G.pts[(size_t)l * 3], G.pts[(size_t)l * 3 + 1], G.pts[(size_t)l * 3 + 2]};
     double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
@@ -255,7 +318,7 @@ GL_DEV void pass_blocks(const GenP& G, bool schur) {
   const int P = G.P, n = 6 * P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = P * (P + 1) / 2;
-  for (int b = wave; b < nblk; b += NW_BA) {
+  for (int b = G.pb * NW_BA + wave; b < nblk; b += G.NB * NW_BA) {
     // decode (j1 <= j2)
     int j1 = 0, rem = b;
     while (rem >= P - j1) {
@@ -402,15 +465,16 @@ GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag) {
   return *s_flag != 0;
 }
 
-GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag) {
+GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag,
+                        double* s_lds) {
   const int P = G.P, n = 6 * P, tid = threadIdx.x;
   double acc[32];
   // ---- initializeOptimization(0): active poses / points -----------------------------------
-  for (int j = tid; j < P; j += T_BA) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
-  __syncthreads();
+  for (int j = GSTART; j < P; j += GSTRIDE) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
+  prob_sync(G);
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  for (int l = tid; l < G.L; l += T_BA) {
+  for (int l = GSTART; l < G.L; l += GSTRIDE) {
     bool any = G.assoc[l] >= 0 && !G.lev_g[l];
     for (int o = G.optr[l]; o < G.optr[l + 1]; ++o)
       if (!G.lev_o[o]) {
@@ -421,12 +485,13 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
     G.lact[l] = any ? 1 : 0;
     if (any) acc[0] += 1.0;
   }
-  __syncthreads();
-  for (int j = tid; j < P; j += T_BA)
+  prob_sync(G);
+  for (int j = GSTART; j < P; j += GSTRIDE)
     if (G.pact[j]) acc[1] += 1.0;
-  block_reduce<2, NW_BA>(acc, red);
+  prob_reduce<2>(G, acc, red);
   const bool any_point = acc[0] > 0.0, any_pose = acc[1] > 0.0;
   if (!any_point && !any_pose) return -1;
+  double* S = G.S;  // where P2 / priors assemble the reduced system (global when NB > 1)
 
   double lambda = 0.0, ni = 2.0;
   int cj = 0;
@@ -434,11 +499,11 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
       pass_points(k, gm, G, robust, 0.0, md);
-      for (int i = tid; i < n * n; i += T_BA) G.S[i] = 0.0;
-      __syncthreads();
+      for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
+      prob_sync(G);
       pass_blocks(G, false);
-      __syncthreads();
-      for (int j = tid; j < P; j += T_BA) {
+      prob_sync(G);
+      for (int j = GSTART; j < P; j += GSTRIDE) {
         if (!G.pact[j]) continue;
         double H[36], b[6] = {0, 0, 0, 0, 0, 0};
         for (int r = 0; r < 36; ++r) H[r] = 0.0;
@@ -446,9 +511,9 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
           const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
           prior_terms(Pi, T, true, H, b);
         }
-        for (int r = 0; r < 6; ++r) md = fmax(md, fabs(G.S[(size_t)(6 * j + r) * n + 6 * j + r] + H[r * 6 + r]));
+        for (int r = 0; r < 6; ++r) md = fmax(md, fabs(S[(size_t)(6 * j + r) * n + 6 * j + r] + H[r * 6 + r]));
       }
-      md = block_max(md, red);
+      md = prob_max(G, md, red);
       lambda = 1e-5 * md;
       ni = 2.0;
     }
@@ -460,20 +525,21 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
       acc[0] = pass_points(k, gm, G, robust, lambda, md_unused);
-      for (int i = tid; i < n * n; i += T_BA) G.S[i] = 0.0;
-      for (int i = tid; i < n; i += T_BA) {
+      for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
+      for (int i = GSTART; i < n; i += GSTRIDE) {
         G.gv[i] = 0.0;
         G.bp[i] = 0.0;
       }
-      block_reduce<1, NW_BA>(acc, red);
+      prob_reduce<1>(G, acc, red);  // (its barriers also publish P1's per-point results)
       double chiA = acc[0];
+      if (G.NB == 1) __syncthreads();
       pass_blocks(G, true);
-      __syncthreads();
+      prob_sync(G);
       // priors and inactive poses
-      for (int j = tid; j < P; j += T_BA) {
+      for (int j = GSTART; j < P; j += GSTRIDE) {
         G.pchi[j] = 0.0;
         if (!G.pact[j]) {
-          for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * n + 6 * j + r] = 1.0;
+          for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] = 1.0;
           continue;
         }
         if (G.prior[j] && k.first_as_prior) {
@@ -484,21 +550,36 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
           for (int r = 0; r < 6; ++r) {
             G.gv[6 * j + r] += b[r];
             G.bp[6 * j + r] += b[r];
-            for (int c = 0; c < 6; ++c) G.S[(size_t)(6 * j + r) * n + 6 * j + c] += H[r * 6 + c];
+            for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * n + 6 * j + c] += H[r * 6 + c];
           }
         }
-        for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
+        for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
       }
-      __syncthreads();
+      prob_sync(G);
       for (int j = 0; j < P; ++j) chiA += G.pchi[j];
       if (qmax == 0) currentChi = chiA;
-      for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
-      __syncthreads();
+      // ---- solve: one workgroup; with NB > 1 it works on a private copy (LDS when it fits) ----------
       bool ok2 = true;
-      if (any_pose) ok2 = block_ldlt_solve(G.S, G.dxv, n, s_flag);
-      __syncthreads();
+      if (G.NB == 1) {
+        for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
+        __syncthreads();
+        if (any_pose) ok2 = block_ldlt_solve(S, G.dxv, n, s_flag);
+        __syncthreads();
+      } else {
+        if (G.pb == 0) {
+          double* W = s_lds ? s_lds : G.Sw;
+          for (int i = tid; i < n * n; i += T_BA) W[i] = S[i];
+          for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
+          __syncthreads();
+          bool ok = true;
+          if (any_pose) ok = block_ldlt_solve(W, G.dxv, n, s_flag);
+          if (tid == 0) *G.flagg = ok ? 1 : 0;
+        }
+        prob_sync(G);
+        ok2 = *G.flagg != 0;
+      }
       // ---- P3: trial poses -----------------------------------------------------------------------
-      for (int j = tid; j < P; j += T_BA) {
+      for (int j = GSTART; j < P; j += GSTRIDE) {
         const SE3 T = se3_load(G.poses + (size_t)j * 7);
         SE3 Tn = T;
         if (G.pact[j] && ok2) {
@@ -514,10 +595,10 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
                         ? prior_terms(se3_load(G.pinv + (size_t)j * 7), Tn, false, nullptr, nullptr)
                         : 0.0;
       }
-      __syncthreads();
+      prob_sync(G);
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      for (int l = tid; l < G.L; l += T_BA) {
+      for (int l = GSTART; l < G.L; l += GSTRIDE) {
         if (!G.lact[l]) continue;
         const double* pw = G.ptw + (size_t)l * 12;
         double rhs[3] = {pw[9], pw[10], pw[11]};
@@ -564,14 +645,14 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
           acc[1] += gmm_chi2(k, g, pn);
         }
       }
-      block_reduce<2, NW_BA>(acc, red);
+      prob_reduce<2>(G, acc, red);
       double scale = acc[0], tempChi = acc[1];
       for (int j = 0; j < P; ++j) tempChi += G.pchi[j];
       for (int i = 0; i < n; ++i) scale += G.dxv[i] * (lambda * G.dxv[i] + G.bp[i]);
       if (!ok2) tempChi = 1.7976931348623157e308;
       scale += 1e-3;
       rho = (currentChi - tempChi) / scale;
-      __syncthreads();
+      prob_sync(G);
       if (rho > 0 && isfinite(tempChi)) {
         const double uu = 2 * rho - 1;
         double alpha = 1. - uu * uu * uu;
@@ -579,12 +660,12 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         lambda *= fmax(1. / 3., alpha);
         ni = 2;
         currentChi = tempChi;
-        for (int j = tid; j < P; j += T_BA) {
+        for (int j = GSTART; j < P; j += GSTRIDE) {
           if (!G.pact[j]) continue;
           for (int r = 0; r < 7; ++r) G.poses[(size_t)j * 7 + r] = G.qN[(size_t)j * 7 + r];
           for (int r = 0; r < 12; ++r) G.Rt[(size_t)j * 12 + r] = G.RtN[(size_t)j * 12 + r];
         }
-        for (int l = tid; l < G.L; l += T_BA) {
+        for (int l = GSTART; l < G.L; l += GSTRIDE) {
           if (!G.lact[l]) continue;
 #pragma unroll
           for (int i = 0; i < 3; ++i) G.pts[(size_t)l * 3 + i] = G.pn[(size_t)l * 3 + i];
@@ -593,7 +674,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         lambda *= ni;
         ni *= 2;
       }
-      __syncthreads();
+      prob_sync(G);
       qmax++;
     } while (rho < 0 && qmax < 10);
     ++cj;
@@ -602,7 +683,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
   return cj;
 }
 
-__global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P, int F, int L, int NOBS,
+__global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB, int P, int F, int L, int NOBS,
                                                  double* __restrict__ poses_all, const uint8_t* __restrict__ prior_all,
                                                  double* __restrict__ pts_all, const int32_t* __restrict__ assoc_all,
                                                  const int32_t* __restrict__ optr_all,
@@ -615,9 +696,11 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // reduced camera system when it fits
   __shared__ double red[NW_BA * 32];
   __shared__ int s_flag;
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = blockIdx.x / NB, tid = threadIdx.x;
   if (f >= B) return;
   GenP G;
+  G.NB = NB;
+  G.pb = blockIdx.x % NB;
   G.P = P;
   G.F = F;
   G.L = L;
@@ -631,8 +714,11 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
   G.ooct = ooct_all + (size_t)f * NOBS;
   G.nobs = G.optr[L];
   const int nobs = G.nobs, n = 6 * P;
-  // carve the scratch (doubles first, then ints, then bytes)
-  char* s = scratch + (size_t)f * scratch_per_problem;
+  // scratch = | B x 64 B headers {barrier arrivals, generation, solve flag} (zeroed by the host) | per-problem areas |
+  G.bar = (unsigned*)(scratch + (size_t)f * 64);
+  G.flagg = (int*)(G.bar + 2);
+  // carve the problem's area (doubles first, then ints, then bytes)
+  char* s = scratch + (size_t)B * 64 + (size_t)f * scratch_per_problem;
   auto takeD = [&](size_t cnt) {
     double* p = (double*)s;
     s += cnt * 8;
@@ -647,7 +733,10 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
   G.ptw = takeD((size_t)L * 12);
   G.chi_o = takeD((size_t)NOBS);
   G.S = takeD((size_t)n * n);
-  if (s_in_lds) G.S = dyn_lds;  // the in-place LDL^T does ~4n barriers: keep S next to the CU (6P <= 120)
+  G.Sw = takeD((size_t)n * n);
+  G.part = takeD((size_t)64 * 4);
+  // one workgroup: the in-place LDL^T does ~4n barriers, keep S next to the CU (6P <= 120)
+  if (s_in_lds && NB == 1) G.S = dyn_lds;
   G.gv = takeD(n);
   G.bp = takeD(n);
   G.dxv = takeD(n);
@@ -673,7 +762,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
   G.lact = takeB(L);
 
   // ---- setup --------------------------------------------------------------------------------------
-  for (int j = tid; j < P + F; j += T_BA) {
+  for (int j = GSTART; j < P + F; j += GSTRIDE) {
     const SE3 T = se3_load(G.poses + (size_t)j * 7);
     store_pose_Rt(T, G.Rt + (size_t)j * 12);
     bool fr = j < P;
@@ -681,7 +770,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
     G.pfree[j] = fr ? 1 : 0;
     if (j < P) se3_store(se3_inverse(T), G.pinv + (size_t)j * 7);  // e->setMeasurement(kf->getTcw())
   }
-  for (int l = tid; l < L; l += T_BA) {
+  for (int l = GSTART; l < L; l += GSTRIDE) {
     G.lev_g[l] = 0;
     for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
       G.opoint[o] = l;
@@ -689,9 +778,9 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
       G.chi_o[o] = 0.0;
     }
   }
-  for (size_t i = tid; i < (size_t)nobs * P; i += T_BA) G.match[i] = -1;
-  __syncthreads();
-  for (int l = tid; l < L; l += T_BA)
+  for (size_t i = GSTART; i < (size_t)nobs * P; i += GSTRIDE) G.match[i] = -1;
+  prob_sync(G);
+  for (int l = GSTART; l < L; l += GSTRIDE)
     for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1)
       for (int o2 = G.optr[l]; o2 < G.optr[l + 1]; ++o2) {
         const int j2 = G.opose[o2];
@@ -699,8 +788,8 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
       }
   // pose-major CSR: wave-per-pose ordered compaction (two sweeps: count, fill)
   {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int j = wave; j < P; j += NW_BA) {
+    const int lane = tid & 63, gw = G.pb * NW_BA + (tid >> 6), gnw = G.NB * NW_BA;
+    for (int j = gw; j < P; j += gnw) {
       int cnt = 0;
       for (int o0 = 0; o0 < nobs; o0 += 64) {
         const int o = o0 + lane;
@@ -709,13 +798,13 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
       }
       if (lane == 0) G.pl_ptr[j + 1] = cnt;
     }
-    __syncthreads();
-    if (tid == 0) {
+    prob_sync(G);
+    if (G.pb == 0 && tid == 0) {
       G.pl_ptr[0] = 0;
       for (int j = 0; j < P; ++j) G.pl_ptr[j + 1] += G.pl_ptr[j];
     }
-    __syncthreads();
-    for (int j = wave; j < P; j += NW_BA) {
+    prob_sync(G);
+    for (int j = gw; j < P; j += gnw) {
       int base = G.pl_ptr[j];
       for (int o0 = 0; o0 < nobs; o0 += 64) {
         const int o = o0 + lane;
@@ -726,20 +815,21 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
       }
     }
   }
-  __syncthreads();
+  prob_sync(G);
+  double* s_lds = s_in_lds ? dyn_lds : nullptr;
 
   // ---- schedule (:770-828) ---------------------------------------------------------------------------
-  gen_optimize(k, gm, G, true, 5, red, &s_flag);
-  __syncthreads();
-  for (int l = tid; l < L; l += T_BA) {
+  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds);
+  prob_sync(G);
+  for (int l = GSTART; l < L; l += GSTRIDE) {
     GmmRef g;
     load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
     if (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) G.lev_g[l] = 1;
   }
-  __syncthreads();
-  gen_optimize(k, gm, G, true, 5, red, &s_flag);
-  __syncthreads();
-  for (int l = tid; l < L; l += T_BA)
+  prob_sync(G);
+  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds);
+  prob_sync(G);
+  for (int l = GSTART; l < L; l += GSTRIDE)
     for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
       const double* Rt = G.Rt + (size_t)G.opose[o] * 12;
       const double* p = G.pts + (size_t)l * 3;
@@ -747,11 +837,11 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
       const bool stereo = !(G.ouvr[(size_t)o * 3 + 2] < 0);
       if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
     }
-  __syncthreads();
-  const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag);
-  __syncthreads();
+  prob_sync(G);
+  const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds);
+  prob_sync(G);
   // ---- outputs (:837-879) ---------------------------------------------------------------------------
-  for (int l = tid; l < L; l += T_BA) {
+  for (int l = GSTART; l < L; l += GSTRIDE) {
     GmmRef g;
     load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
     const double* p = G.pts + (size_t)l * 3;
@@ -763,14 +853,14 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int P,
       erase_all[(size_t)f * NOBS + o] = (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) ? 1 : 0;
     }
   }
-  if (tid == 0 && iters_all) iters_all[f] = it3;
+  if (G.pb == 0 && tid == 0 && iters_all) iters_all[f] = it3;
 }
 
 size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
   const size_t n = 6 * (size_t)P;
   size_t d = (size_t)(P + F) * 12 + (size_t)P * 12 + (size_t)P * 7 * 2 + (size_t)L * 3 + (size_t)NOBS * 12 +
-             (size_t)L * 12 + NOBS + n * n + 3 * n + P;
-  size_t i = (size_t)NOBS * 2 + (P + 1) + (size_t)NOBS * P + 16;
+             (size_t)L * 12 + NOBS + 2 * n * n + 256 + 3 * n + P;
+  size_t i = (size_t)NOBS * 2 + (P + 1) + (size_t)NOBS * P + 32;
   size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
   return d * 8 + i * 4 + b + 256;
 }
@@ -794,20 +884,47 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   GL_HIP(hipSetDevice(c->device));
   const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
   void* scratch = nullptr;
-  int rc = gl::ctx_scratch(c, per * B, &scratch);
+  int rc = gl::ctx_scratch(c, (size_t)B * 64 + per * B, &scratch);
   if (rc != GL_OK) return rc;
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
+  const size_t n = 6 * (size_t)P;
+  const size_t s_bytes = n * n * sizeof(double);
+  int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;
+  const size_t lds = s_in_lds ? s_bytes : 0;
+  if (s_in_lds)
+    GL_HIP(hipFuncSetAttribute((const void*)k_ba_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_bytes));
+  // workgroups per problem: as many as stay co-resident (the per-problem barrier needs that; the
+  // cooperative launch enforces it), at most 32; large batches run one workgroup per problem
+  int NB = 1;
+  {
+    int occ = 0, ncu = 0;
+    GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ba_gen, T_BA, lds));
+    GL_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+    const long cap = (long)occ * ncu;
+    NB = (int)std::min<long>(32, cap / B);
+    if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = std::min(NB, atoi(e));  // knob (tests: 1 = single workgroup)
+    if (NB < 2) NB = 1;
+  }
   {
     gl::TimerScope ts(c, GL_TIMER_BA);
-    const size_t n = 6 * (size_t)P;
-    const size_t s_bytes = n * n * sizeof(double);
-    const int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;
-    if (s_in_lds)
-      GL_HIP(hipFuncSetAttribute((const void*)k_ba_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_bytes));
-    k_ba_gen<<<B, T_BA, s_in_lds ? s_bytes : 0, c->stream>>>(make_bak(cam, prm, -1.0), gm, B, P, F, L, NOBS, poses_dev,
-                                                             prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
-                                                             obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev,
-                                                             iters_dev, (char*)scratch, per, s_in_lds);
+    GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 64, c->stream));
+    BaK kk = make_bak(cam, prm, -1.0);
+    char* scr = (char*)scratch;
+    size_t per_v = per;
+    if (NB > 1) {
+      void* args[] = {&kk, &gm, &B, &NB, &P, &F, &L, &NOBS, &poses_dev, &prior_dev, &points_dev, &assoc_dev, &obs_ptr_dev,
+                      &obs_pose_dev, &obs_uvr_dev, &obs_oct_dev, &assoc_dropped_dev, &obs_erase_dev, &iters_dev, &scr, &per_v,
+                      &s_in_lds};
+      hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(B * NB), dim3(T_BA), args, lds, c->stream);
+      if (e != hipSuccess) {  // not co-resident after all: one workgroup per problem
+        (void)hipGetLastError();
+        NB = 1;
+      }
+    }
+    if (NB == 1)
+      k_ba_gen<<<B, T_BA, lds, c->stream>>>(kk, gm, B, 1, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev,
+                                            obs_pose_dev, obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev,
+                                            scr, per_v, s_in_lds);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;
