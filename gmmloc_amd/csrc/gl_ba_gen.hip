@@ -30,6 +30,15 @@ using namespace glba;
 
 namespace {
 
+#ifdef GL_BAGEN_PROF  // phase cycles of workgroup 0 (tools/prof_bagen.py)
+__device__ unsigned long long g_gprof[8];
+#define GP_T(v) const long long v = clock64()
+#define GP_ADD(slot, a, b) if (blockIdx.x == 0 && threadIdx.x == 0) g_gprof[slot] += (unsigned long long)((b) - (a))
+#else
+#define GP_T(v)
+#define GP_ADD(slot, a, b)
+#endif
+
 struct GenP {
   int P, F, L, nobs;
   double* poses;
@@ -53,7 +62,8 @@ struct GenP {
   double* gv;      // n
   double* bp;      // n
   double* dxv;     // n
-  double* pchi;    // P prior chi2 (current / trial)
+  double* pchi;    // P prior chi2 at the current state
+  double* pchi2;   // P prior chi2 at the trial state
   int32_t* opoint; // nobs
   int32_t* pl_ptr; // P + 1
   int32_t* pl_obs; // nobs
@@ -65,6 +75,7 @@ struct GenP {
   uint8_t* lact;   // L  point active this optimize()
   // multi-workgroup execution
   int NB, pb;          // workgroups per problem, index of this one
+  int toggle;          // which partial-sum buffer the next reduction uses
   unsigned* bar;       // {arrivals, generation}
   double* part;        // NB x 4 partial sums
   double* Sw;          // n x n work copy for the solve when NB > 1 and it does not fit in LDS
@@ -93,27 +104,31 @@ GL_DEV void prob_sync(const GenP& G) {
 // problem-wide sum of NV (<= 4) per-thread values: workgroup reduction, partials to global memory,
 // every workgroup adds the NB partials in index order (identical result everywhere)
 template <int NV>
-GL_DEV void prob_reduce(const GenP& G, double* acc, double* red) {
+GL_DEV void prob_reduce(GenP& G, double* acc, double* red) {
   block_reduce<NV, NW_BA>(acc, red);
   if (G.NB == 1) return;
+  // two partial buffers used alternately: the barrier of the NEXT reduction separates the readers of a
+  // buffer from its next writers, so one barrier per reduction is enough
+  double* part = G.part + (G.toggle ? 64 * 4 : 0);
+  G.toggle ^= 1;
   if (threadIdx.x == 0)
-    for (int i = 0; i < NV; ++i) G.part[G.pb * 4 + i] = acc[i];
+    for (int i = 0; i < NV; ++i) part[G.pb * 4 + i] = acc[i];
   prob_sync(G);
   for (int i = 0; i < NV; ++i) {
     double s = 0.0;
-    for (int b = 0; b < G.NB; ++b) s += G.part[b * 4 + i];
+    for (int b = 0; b < G.NB; ++b) s += part[b * 4 + i];
     acc[i] = s;
   }
-  prob_sync(G);  // partials may be overwritten by the next reduction
 }
-GL_DEV double prob_max(const GenP& G, double v, double* red) {
+GL_DEV double prob_max(GenP& G, double v, double* red) {
   v = block_max(v, red);
   if (G.NB == 1) return v;
-  if (threadIdx.x == 0) G.part[G.pb * 4] = v;
+  double* part = G.part + (G.toggle ? 64 * 4 : 0);
+  G.toggle ^= 1;
+  if (threadIdx.x == 0) part[G.pb * 4] = v;
   prob_sync(G);
-  double m = G.part[0];
-  for (int b = 1; b < G.NB; ++b) m = fmax(m, G.part[b * 4]);
-  prob_sync(G);
+  double m = part[0];
+  for (int b = 1; b < G.NB; ++b) m = fmax(m, part[b * 4]);
   return m;
 }
 #define GSTART (G.pb * T_BA + (int)threadIdx.x)
@@ -428,8 +443,22 @@ GL_DEV void pass_blocks(const GenP& G, bool schur) {
   }
 }
 
-// in-place LDL^T solve of S x = g (lower triangle), whole workgroup; returns ok
-GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag) {
+// in-place LDL^T solve of S x = g (lower triangle), whole workgroup; returns ok.
+// Right-looking with ONE barrier per pivot (the columns stay un-scaled, l_ik = S[i][k] / S[k][k] is
+// applied on the fly); the two triangular solves run on wave 0 with the vector in registers (two rows
+// per lane, n <= 128) and v_readlane broadcasts -- no barriers, the LDS reads of L pipeline.
+// idg: n doubles of LDS work space (reciprocal pivots).
+GL_DEV double lane_bcast(double v, int src) {  // src wave-uniform
+  union {
+    double d;
+    int i[2];
+  } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag, double* idg) {
   const int tid = threadIdx.x;
   if (tid == 0) *s_flag = 1;
   __syncthreads();
@@ -438,30 +467,50 @@ GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag) {
     if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
     // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
     const double id = 1.0 / d;
+    if (tid == 0 && kk < 128) idg[kk] = id;
     for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
       const double ci = S[(size_t)i * n + kk] * id;
       for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * n + j] -= ci * S[(size_t)j * n + kk];
     }
     __syncthreads();
-    for (int i = kk + 1 + tid; i < n; i += T_BA) S[(size_t)i * n + kk] *= id;  // l_ik
-    __syncthreads();
   }
-  // forward: L y = g
-  for (int kk = 0; kk < n; ++kk) {
-    const double yk = g[kk];
+  if (n > 128) {  // more than 21 free poses: barrier-per-row substitution on the un-scaled columns
+    for (int kk = 0; kk < n; ++kk) {
+      const double yk = g[kk] / S[(size_t)kk * n + kk];
+      __syncthreads();
+      for (int i = kk + 1 + tid; i < n; i += T_BA) g[i] -= S[(size_t)i * n + kk] * yk;
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += T_BA) g[i] /= S[(size_t)i * n + i];
     __syncthreads();
-    for (int i = kk + 1 + tid; i < n; i += T_BA) g[i] -= S[(size_t)i * n + kk] * yk;
-    __syncthreads();
+    for (int kk = n - 1; kk >= 0; --kk) {
+      const double xk = g[kk];
+      __syncthreads();
+      for (int i = tid; i < kk; i += T_BA) g[i] -= S[(size_t)kk * n + i] / S[(size_t)i * n + i] * xk;
+      __syncthreads();
+    }
+  } else if (tid < 64) {
+    const int lane = tid, r0 = lane, r1 = lane + 64;
+    double y0 = r0 < n ? g[r0] : 0.0, y1 = r1 < n ? g[r1] : 0.0;
+    // forward: L y = g,  l_rk = S[r][k] * idg[k]
+    for (int kk = 0; kk < n; ++kk) {
+      const double yk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
+      const double ik = idg[kk];
+      if (r0 > kk && r0 < n) y0 -= S[(size_t)r0 * n + kk] * ik * yk;
+      if (r1 > kk && r1 < n) y1 -= S[(size_t)r1 * n + kk] * ik * yk;
+    }
+    if (r0 < n) y0 /= S[(size_t)r0 * n + r0];  // division, like the reference LDL^T (multiplying by the
+    if (r1 < n) y1 /= S[(size_t)r1 * n + r1];  // reciprocal shifts the last bit and the LM path at convergence)
+    // backward: L^T x = z,  (L^T)_rk = l_kr = S[k][r] * idg[r]
+    for (int kk = n - 1; kk >= 0; --kk) {
+      const double xk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
+      if (r0 < kk) y0 -= S[(size_t)kk * n + r0] * idg[r0] * xk;
+      if (r1 < kk && r1 < n) y1 -= S[(size_t)kk * n + r1] * idg[r1] * xk;
+    }
+    if (r0 < n) g[r0] = y0;
+    if (r1 < n) g[r1] = y1;
   }
-  for (int i = tid; i < n; i += T_BA) g[i] /= S[(size_t)i * n + i];
   __syncthreads();
-  // backward: L^T x = z
-  for (int kk = n - 1; kk >= 0; --kk) {
-    const double xk = g[kk];
-    __syncthreads();
-    for (int i = tid; i < kk; i += T_BA) g[i] -= S[(size_t)kk * n + i] * xk;
-    __syncthreads();
-  }
   return *s_flag != 0;
 }
 
@@ -522,6 +571,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
     do {
       // ---- P1 + P2 at the current state -------------------------------------------------------
       double md_unused = 0.0;
+      GP_T(t0);
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
       acc[0] = pass_points(k, gm, G, robust, lambda, md_unused);
@@ -533,69 +583,69 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       prob_reduce<1>(G, acc, red);  // (its barriers also publish P1's per-point results)
       double chiA = acc[0];
       if (G.NB == 1) __syncthreads();
+      GP_T(t1);
       pass_blocks(G, true);
       prob_sync(G);
-      // priors and inactive poses
-      for (int j = GSTART; j < P; j += GSTRIDE) {
-        G.pchi[j] = 0.0;
-        if (!G.pact[j]) {
-          for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] = 1.0;
-          continue;
-        }
-        if (G.prior[j] && k.first_as_prior) {
-          double H[36], b[6] = {0, 0, 0, 0, 0, 0};
-          for (int r = 0; r < 36; ++r) H[r] = 0.0;
-          const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
-          G.pchi[j] = prior_terms(Pi, T, true, H, b);
-          for (int r = 0; r < 6; ++r) {
-            G.gv[6 * j + r] += b[r];
-            G.bp[6 * j + r] += b[r];
-            for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * n + 6 * j + c] += H[r * 6 + c];
-          }
-        }
-        for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
-      }
-      prob_sync(G);
-      for (int j = 0; j < P; ++j) chiA += G.pchi[j];
-      if (qmax == 0) currentChi = chiA;
-      // ---- solve: one workgroup; with NB > 1 it works on a private copy (LDS when it fits) ----------
+      GP_T(t2);
+      // ---- workgroup 0: priors / inactive poses, solve, trial poses (P <= ~20 poses: not worth a barrier each)
       bool ok2 = true;
-      if (G.NB == 1) {
+      GP_T(t3);
+      if (G.pb == 0) {
+        for (int j = tid; j < P; j += T_BA) {
+          G.pchi[j] = 0.0;
+          if (!G.pact[j]) {
+            for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] = 1.0;
+            continue;
+          }
+          if (G.prior[j] && k.first_as_prior) {
+            double H[36], b[6] = {0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < 36; ++r) H[r] = 0.0;
+            const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
+            G.pchi[j] = prior_terms(Pi, T, true, H, b);
+            for (int r = 0; r < 6; ++r) {
+              G.gv[6 * j + r] += b[r];
+              G.bp[6 * j + r] += b[r];
+              for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * n + 6 * j + c] += H[r * 6 + c];
+            }
+          }
+          for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
+        }
+        __syncthreads();
+        // the solve works in place when S is this workgroup's LDS (NB == 1), else on a copy (LDS when it fits)
+        double* W = S;
+        if (G.NB > 1) {
+          W = s_lds ? s_lds : G.Sw;
+          for (int i = tid; i < n * n; i += T_BA) W[i] = S[i];
+        }
         for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
         __syncthreads();
-        if (any_pose) ok2 = block_ldlt_solve(S, G.dxv, n, s_flag);
+        bool ok = true;
+        if (any_pose) ok = block_ldlt_solve(W, G.dxv, n, s_flag, red);
+        if (tid == 0) *G.flagg = ok ? 1 : 0;
         __syncthreads();
-      } else {
-        if (G.pb == 0) {
-          double* W = s_lds ? s_lds : G.Sw;
-          for (int i = tid; i < n * n; i += T_BA) W[i] = S[i];
-          for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
-          __syncthreads();
-          bool ok = true;
-          if (any_pose) ok = block_ldlt_solve(W, G.dxv, n, s_flag);
-          if (tid == 0) *G.flagg = ok ? 1 : 0;
+        // trial poses
+        for (int j = tid; j < P; j += T_BA) {
+          const SE3 T = se3_load(G.poses + (size_t)j * 7);
+          SE3 Tn = T;
+          if (G.pact[j] && ok) {
+            double dx[6];
+            for (int r = 0; r < 6; ++r) dx[r] = G.dxv[6 * j + r];
+            Tn = se3_mul(se3_exp(dx), T);
+          } else {
+            for (int r = 0; r < 6; ++r) G.dxv[6 * j + r] = 0.0;
+          }
+          se3_store(Tn, G.qN + (size_t)j * 7);
+          store_pose_Rt(Tn, G.RtN + (size_t)j * 12);
+          G.pchi2[j] = (G.pact[j] && G.prior[j] && k.first_as_prior)
+                           ? prior_terms(se3_load(G.pinv + (size_t)j * 7), Tn, false, nullptr, nullptr)
+                           : 0.0;
         }
-        prob_sync(G);
-        ok2 = *G.flagg != 0;
-      }
-      // ---- P3: trial poses -----------------------------------------------------------------------
-      for (int j = GSTART; j < P; j += GSTRIDE) {
-        const SE3 T = se3_load(G.poses + (size_t)j * 7);
-        SE3 Tn = T;
-        if (G.pact[j] && ok2) {
-          double dx[6];
-          for (int r = 0; r < 6; ++r) dx[r] = G.dxv[6 * j + r];
-          Tn = se3_mul(se3_exp(dx), T);
-        } else {
-          for (int r = 0; r < 6; ++r) G.dxv[6 * j + r] = 0.0;
-        }
-        se3_store(Tn, G.qN + (size_t)j * 7);
-        store_pose_Rt(Tn, G.RtN + (size_t)j * 12);
-        G.pchi[j] = (G.pact[j] && G.prior[j] && k.first_as_prior)
-                        ? prior_terms(se3_load(G.pinv + (size_t)j * 7), Tn, false, nullptr, nullptr)
-                        : 0.0;
       }
       prob_sync(G);
+      ok2 = *G.flagg != 0;
+      for (int j = 0; j < P; ++j) chiA += G.pchi[j];
+      if (qmax == 0) currentChi = chiA;
+      GP_T(t4);
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
       for (int l = GSTART; l < G.L; l += GSTRIDE) {
@@ -647,12 +697,11 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       }
       prob_reduce<2>(G, acc, red);
       double scale = acc[0], tempChi = acc[1];
-      for (int j = 0; j < P; ++j) tempChi += G.pchi[j];
+      for (int j = 0; j < P; ++j) tempChi += G.pchi2[j];
       for (int i = 0; i < n; ++i) scale += G.dxv[i] * (lambda * G.dxv[i] + G.bp[i]);
       if (!ok2) tempChi = 1.7976931348623157e308;
       scale += 1e-3;
       rho = (currentChi - tempChi) / scale;
-      prob_sync(G);
       if (rho > 0 && isfinite(tempChi)) {
         const double uu = 2 * rho - 1;
         double alpha = 1. - uu * uu * uu;
@@ -676,6 +725,8 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       }
       prob_sync(G);
       qmax++;
+      GP_T(t5);
+      GP_ADD(0, t0, t1); GP_ADD(1, t1, t2); GP_ADD(2, t2, t3); GP_ADD(3, t3, t4); GP_ADD(4, t4, t5); GP_ADD(5, 0, 1);
     } while (rho < 0 && qmax < 10);
     ++cj;
     if (qmax == 10 || rho == 0) break;
@@ -734,13 +785,15 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.chi_o = takeD((size_t)NOBS);
   G.S = takeD((size_t)n * n);
   G.Sw = takeD((size_t)n * n);
-  G.part = takeD((size_t)64 * 4);
+  G.part = takeD((size_t)2 * 64 * 4);
+  G.toggle = 0;
   // one workgroup: the in-place LDL^T does ~4n barriers, keep S next to the CU (6P <= 120)
   if (s_in_lds && NB == 1) G.S = dyn_lds;
   G.gv = takeD(n);
   G.bp = takeD(n);
   G.dxv = takeD(n);
   G.pchi = takeD(P);
+  G.pchi2 = takeD(P);
   auto takeI = [&](size_t cnt) {
     int32_t* p = (int32_t*)s;
     s += ((cnt * 4 + 7) / 8) * 8;
@@ -854,12 +907,16 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
     }
   }
   if (G.pb == 0 && tid == 0 && iters_all) iters_all[f] = it3;
+#ifdef GL_BAGEN_PROF
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 6; ++i) G.poses[i] = (double)g_gprof[i];  // debug build: phase cycles instead of pose 0
+#endif
 }
 
 size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
   const size_t n = 6 * (size_t)P;
   size_t d = (size_t)(P + F) * 12 + (size_t)P * 12 + (size_t)P * 7 * 2 + (size_t)L * 3 + (size_t)NOBS * 12 +
-             (size_t)L * 12 + NOBS + 2 * n * n + 256 + 3 * n + P;
+             (size_t)L * 12 + NOBS + 2 * n * n + 512 + 3 * n + 2 * P;
   size_t i = (size_t)NOBS * 2 + (P + 1) + (size_t)NOBS * P + 32;
   size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
   return d * 8 + i * 4 + b + 256;
