@@ -31,7 +31,7 @@ using namespace glba;
 namespace {
 
 #ifdef GL_BAGEN_PROF  // phase cycles of workgroup 0 (tools/prof_bagen.py)
-__device__ unsigned long long g_gprof[8];
+__device__ unsigned long long g_gprof[12];
 #define GP_T(v) const long long v = clock64()
 #define GP_ADD(slot, a, b) if (blockIdx.x == 0 && threadIdx.x == 0) g_gprof[slot] += (unsigned long long)((b) - (a))
 #else
@@ -462,17 +462,79 @@ GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag, double* i
   const int tid = threadIdx.x;
   if (tid == 0) *s_flag = 1;
   __syncthreads();
-  for (int kk = 0; kk < n; ++kk) {
-    const double d = S[(size_t)kk * n + kk];
-    if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
-    // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
-    const double id = 1.0 / d;
-    if (tid == 0 && kk < 128) idg[kk] = id;
-    for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
-      const double ci = S[(size_t)i * n + kk] * id;
-      for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * n + j] -= ci * S[(size_t)j * n + kk];
+  if (n <= 128 && n % 6 == 0) {
+    // Blocked by the 6 x 6 pose blocks: diagonal block (one thread, registers) -> panel (one row per
+    // thread) -> trailing update (six pivots per element).  Every element still receives exactly the
+    // updates of the un-blocked loop below, in the same order and with the same operands, so the factor
+    // is bit-identical; there are 3 barriers per pose instead of one per scalar pivot, and six
+    // independent multiply-subtracts per trailing element hide the LDS latency.
+    for (int base = 0; base < n; base += 6) {
+      if (tid == 0) {
+        double a[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) a[r][c] = S[(size_t)(base + r) * n + base + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double d = a[c][c];
+          if (d == 0.0 || !isfinite(d)) *s_flag = 0;
+          const double id = 1.0 / d;
+          idg[base + c] = id;
+#pragma unroll
+          for (int r = c + 1; r < 6; ++r) {
+            const double ci = a[r][c] * id;
+#pragma unroll
+            for (int j = c + 1; j <= r; ++j) a[r][j] -= ci * a[j][c];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) S[(size_t)(base + r) * n + base + c] = a[r][c];
+      }
+      __syncthreads();
+      const int m0 = base + 6;
+      for (int i = m0 + tid; i < n; i += T_BA) {  // panel: finish the block's columns of row i
+        double a[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[c] = S[(size_t)i * n + base + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double ci = a[c] * idg[base + c];
+#pragma unroll
+          for (int j = c + 1; j < 6; ++j) a[j] -= ci * S[(size_t)(base + j) * n + base + c];
+        }
+#pragma unroll
+        for (int c = 1; c < 6; ++c) S[(size_t)i * n + base + c] = a[c];
+      }
+      __syncthreads();
+      for (int i = m0 + (tid >> 4); i < n; i += T_BA / 16) {  // trailing update
+        double ci[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ci[c] = S[(size_t)i * n + base + c] * idg[base + c];
+        for (int j = m0 + (tid & 15); j <= i; j += 16) {
+          double v = S[(size_t)i * n + j];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v -= ci[c] * S[(size_t)j * n + base + c];
+          S[(size_t)i * n + j] = v;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    for (int kk = 0; kk < n; ++kk) {
+      const double d = S[(size_t)kk * n + kk];
+      if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
+      // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
+      const double id = 1.0 / d;
+      if (tid == 0 && kk < 128) idg[kk] = id;
+      for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
+        const double ci = S[(size_t)i * n + kk] * id;
+        for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * n + j] -= ci * S[(size_t)j * n + kk];
+      }
+      __syncthreads();
+    }
   }
   if (n > 128) {  // more than 21 free poses: barrier-per-row substitution on the un-scaled columns
     for (int kk = 0; kk < n; ++kk) {
@@ -492,20 +554,51 @@ GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag, double* i
   } else if (tid < 64) {
     const int lane = tid, r0 = lane, r1 = lane + 64;
     double y0 = r0 < n ? g[r0] : 0.0, y1 = r1 < n ? g[r1] : 0.0;
-    // forward: L y = g,  l_rk = S[r][k] * idg[k]
-    for (int kk = 0; kk < n; ++kk) {
-      const double yk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
-      const double ik = idg[kk];
-      if (r0 > kk && r0 < n) y0 -= S[(size_t)r0 * n + kk] * ik * yk;
-      if (r1 > kk && r1 < n) y1 -= S[(size_t)r1 * n + kk] * ik * yk;
+    // forward: L y = g,  l_rk = S[r][k] * idg[k].  The only serial chain is y_k -> y_r; the LDS operands
+    // of four pivots are fetched together so that their latency is paid once per four steps.
+    const double* row0 = S + (size_t)(r0 < n ? r0 : 0) * n;
+    const double* row1 = S + (size_t)(r1 < n ? r1 : 0) * n;
+    for (int k0 = 0; k0 < n; k0 += 4) {
+      double a0[4], a1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = min(k0 + u, n - 1);
+        const double ik = idg[kk];
+        a0[u] = row0[kk] * ik;
+        a1[u] = row1[kk] * ik;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k0 + u;
+        if (kk < n) {
+          const double yk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
+          if (r0 > kk && r0 < n) y0 -= a0[u] * yk;
+          if (r1 > kk && r1 < n) y1 -= a1[u] * yk;
+        }
+      }
     }
     if (r0 < n) y0 /= S[(size_t)r0 * n + r0];  // division, like the reference LDL^T (multiplying by the
     if (r1 < n) y1 /= S[(size_t)r1 * n + r1];  // reciprocal shifts the last bit and the LM path at convergence)
     // backward: L^T x = z,  (L^T)_rk = l_kr = S[k][r] * idg[r]
-    for (int kk = n - 1; kk >= 0; --kk) {
-      const double xk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
-      if (r0 < kk) y0 -= S[(size_t)kk * n + r0] * idg[r0] * xk;
-      if (r1 < kk && r1 < n) y1 -= S[(size_t)kk * n + r1] * idg[r1] * xk;
+    const double i0 = r0 < n ? idg[r0] : 0.0, i1 = r1 < n ? idg[r1] : 0.0;
+    const int c0 = r0 < n ? r0 : 0, c1 = r1 < n ? r1 : 0;
+    for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
+      double a0[4], a1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = max(k0 - u, 0);
+        a0[u] = S[(size_t)kk * n + c0] * i0;
+        a1[u] = S[(size_t)kk * n + c1] * i1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k0 - u;
+        if (kk >= 0) {
+          const double xk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
+          if (r0 < kk) y0 -= a0[u] * xk;
+          if (r1 < kk && r1 < n) y1 -= a1[u] * xk;
+        }
+      }
     }
     if (r0 < n) g[r0] = y0;
     if (r1 < n) g[r1] = y1;
@@ -611,6 +704,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
           for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
         }
         __syncthreads();
+        GP_T(u0);
         // the solve works in place when S is this workgroup's LDS (NB == 1), else on a copy (LDS when it fits)
         double* W = S;
         if (G.NB > 1) {
@@ -619,10 +713,13 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         }
         for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
         __syncthreads();
+        GP_T(u1);
         bool ok = true;
         if (any_pose) ok = block_ldlt_solve(W, G.dxv, n, s_flag, red);
         if (tid == 0) *G.flagg = ok ? 1 : 0;
         __syncthreads();
+        GP_T(u2);
+        GP_ADD(6, t3, u0); GP_ADD(7, u0, u1); GP_ADD(8, u1, u2);
         // trial poses
         for (int j = tid; j < P; j += T_BA) {
           const SE3 T = se3_load(G.poses + (size_t)j * 7);
@@ -909,7 +1006,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   if (G.pb == 0 && tid == 0 && iters_all) iters_all[f] = it3;
 #ifdef GL_BAGEN_PROF
   if (blockIdx.x == 0 && tid == 0)
-    for (int i = 0; i < 6; ++i) G.poses[i] = (double)g_gprof[i];  // debug build: phase cycles instead of pose 0
+    for (int i = 0; i < 9; ++i) G.poses[i] = (double)g_gprof[i];  // debug build: phase cycles instead of poses 0-1
 #endif
 }
 
@@ -951,14 +1048,16 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   if (s_in_lds)
     GL_HIP(hipFuncSetAttribute((const void*)k_ba_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_bytes));
   // workgroups per problem: as many as stay co-resident (the per-problem barrier needs that; the
-  // cooperative launch enforces it), at most 32; large batches run one workgroup per problem
+  // cooperative launch enforces it), at most 64; large batches run one workgroup per problem
   int NB = 1;
   {
     int occ = 0, ncu = 0;
     GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ba_gen, T_BA, lds));
     GL_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     const long cap = (long)occ * ncu;
-    NB = (int)std::min<long>(32, cap / B);
+    // measured: 32 workgroups are best up to ~15 free poses (more only adds barrier time), 64 beyond
+    // (the P (P + 1) / 2 reduced-camera blocks then fill 256 waves)
+    NB = (int)std::min<long>(P >= 16 ? 64 : 32, cap / B);
     if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = std::min(NB, atoi(e));  // knob (tests: 1 = single workgroup)
     if (NB < 2) NB = 1;
   }
