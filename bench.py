@@ -52,7 +52,7 @@ def measured_traffic(kernel, frames_per_launch):
     WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
     frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
     None when the summary is missing: bench.py itself cannot run under two profilers."""
-    for name in ("r1h_traffic.json", "r1g_traffic.json"):
+    for name in ("r1j_traffic.json", "r1h_traffic.json", "r1g_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
