@@ -24,7 +24,7 @@ def oracle_track(oracle, h, cam, f):
     return keep, poses[0], pts, final, idx, d2
 
 
-@pytest.mark.parametrize("mapname,M,seed", [("v1", 400, 10), ("v1", 2000, 20), ("synth", 1000, 30)])
+@pytest.mark.parametrize("mapname,M,seed", [("v1", 400, 10), ("v1", 2000, 20), ("synth", 1000, 30), ("v1", 2100, 40)])
 def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, mapname, M, seed):
     torch, ctx = gpu
     mean, cov = map_v1 if mapname == "v1" else synth.synth_gmm(4096, 1)
