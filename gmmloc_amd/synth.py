@@ -232,3 +232,50 @@ def synth_motion_frames(NF, NL, seed, cam, motion="none", rot_deg=8.0):
     return dict(pose_cw=pose_cw, pose_lw=pose_lw, feat_uv=uv, feat_ur=ur, feat_oct=octv,
                 feat_angle=angle.astype(np.float32), feat_desc=desc, feat_taken=taken, last_pt=last_pt,
                 last_valid=last_valid, last_oct=last_oct, last_angle=last_angle, last_desc=last_desc)
+
+
+def synth_tri_matches(mean, cov, pose1, pose2, cam, N, seed, K_cand=5, allowed=None):
+    """Epipolar matches between two key-frames for Localization::createMapPoints: points drawn from map
+    components seen by both, observed with pixel noise; a random mix of stereo (u_right, depth) and mono
+    (u_right = depth = -1) key-points, 10 % gross mismatches, candidate component lists (restricted to
+    `allowed` components when given: needle-like components have no unique plane normal, so two eigen-solvers
+    legitimately disagree on them)."""
+    rng = np.random.default_rng(seed)
+    f1 = synth_frame(mean, cov, pose1, cam, N, seed, outlier_frac=0.0, mono_frac=0.0)
+    X = f1["Xw"]
+    R2, t2 = quat_to_R(pose2[:4]), pose2[4:]
+    pc2 = X @ R2.T + t2
+    R1, t1 = quat_to_R(pose1[:4]), pose1[4:]
+    pc1 = X @ R1.T + t1
+
+    def kps(pc):
+        u = cam.fx * pc[:, 0] / pc[:, 2] + cam.cx + rng.standard_normal(N) * 0.6
+        v = cam.fy * pc[:, 1] / pc[:, 2] + cam.cy + rng.standard_normal(N) * 0.6
+        st = rng.uniform(size=N) < 0.5
+        depth = np.where(st, pc[:, 2] * (1 + rng.standard_normal(N) * 0.01), -1.0).astype(np.float32)
+        ur = np.where(st, u - cam.bf / np.maximum(pc[:, 2], 0.05) + rng.standard_normal(N) * 0.6, -1.0)
+        lost = st & (ur < 0)  # a real stereo match has u_right >= 0; otherwise the key-point is monocular
+        ur[lost] = -1.0
+        depth[lost] = -1.0
+        return np.stack([u, v, ur], 1), depth
+    k1, d1 = kps(pc1)
+    k2, d2 = kps(pc2)
+    bad = rng.uniform(size=N) < 0.1
+    k2[bad, :2] += rng.uniform(-12, 12, (int(bad.sum()), 2))
+    o1 = rng.integers(0, 8, N).astype(np.int32)
+    o2 = np.clip(o1 + rng.integers(-1, 2, N), 0, 7).astype(np.int32)
+    pool = np.arange(mean.shape[0]) if allowed is None else np.nonzero(allowed)[0]
+    c1 = -np.ones((N, K_cand), np.int32)
+    c2 = -np.ones((N, K_cand), np.int32)
+    for i in range(N):
+        n = int(rng.integers(0, K_cand))
+        own = int(f1["comp"][i])
+        c = ([own] if allowed is None or allowed[own] else []) + [int(x) for x in rng.choice(pool, K_cand - 1)]
+        rng.shuffle(c)
+        n = min(n, len(c))
+        c1[i, :n] = c[:n]
+        m = int(rng.integers(0, K_cand - 1))
+        c2[i, :m] = rng.choice(pool, m)
+    return dict(pose1=np.tile(pose1, (N, 1)), uvr1=k1, depth1=d1, oct1=o1, pose2=np.tile(pose2, (N, 1)), uvr2=k2,
+                depth2=d2, oct2=o2, cand1=c1, n1=(c1 >= 0).sum(1).astype(np.int32), cand2=c2,
+                n2=(c2 >= 0).sum(1).astype(np.int32))

@@ -943,6 +943,174 @@ void orc_optimize_triangulation(void* h, const orc_camera* cam, const orc_params
                                          n2[n], c, p);
 }
 
+// ---- Localization::createMapPoints, the per-match block (localization_opt.cpp:286-420):
+// parallax test -> linear triangulation (JacobiSVD<Matrix4d>, smallest right singular vector) or
+// stereo unprojection -> optimizeTriangulationVec (B2) -> reprojection / scale-consistency checks.
+// Smallest right singular vector by one-sided Jacobi (Eigen: two-sided Jacobi with QR preconditioner;
+// the vector is defined up to sign and only vt[0..2] / vt[3] is consumed).
+static void smallest_right_singular_vector4(const double* A /*4x4 row-major*/, double* v) {
+  double U[16], V[16];
+  for (int i = 0; i < 16; ++i) {
+    U[i] = A[i];
+    V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < 4; ++k) {
+          al += U[k * 4 + p] * U[k * 4 + p];
+          be += U[k * 4 + q] * U[k * 4 + q];
+          ga += U[k * 4 + p] * U[k * 4 + q];
+        }
+        if (ga == 0.0) continue;
+        off = std::max(off, std::fabs(ga) / std::sqrt(al * be));
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int k = 0; k < 4; ++k) {
+          const double up = U[k * 4 + p], uq = U[k * 4 + q];
+          U[k * 4 + p] = c * up - sn * uq;
+          U[k * 4 + q] = sn * up + c * uq;
+          const double vp = V[k * 4 + p], vq = V[k * 4 + q];
+          V[k * 4 + p] = c * vp - sn * vq;
+          V[k * 4 + q] = sn * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  int best = 0;
+  double bn = 1e300;
+  for (int j = 0; j < 4; ++j) {
+    double nn = 0;
+    for (int k = 0; k < 4; ++k) nn += U[k * 4 + j] * U[k * 4 + j];
+    if (nn < bn) {
+      bn = nn;
+      best = j;
+    }
+  }
+  for (int k = 0; k < 4; ++k) v[k] = V[k * 4 + best];
+}
+
+// type_out: 0 = no map point, 1 FromTriMono, 2 FromTriMonoGMM, 3 FromTriStereo, 4 FromTriStereoGMM (mappoint.h)
+void orc_create_map_points(void* h, const orc_camera* cam, const orc_params* prm, float scale_factor, int N,
+                           const double* pose1, const double* uvr1, const float* depth1, const int32_t* oct1,
+                           const double* pose2, const double* uvr2, const float* depth2, const int32_t* oct2,
+                           const int32_t* cand1, const int32_t* n1, const int32_t* cand2, const int32_t* n2, int k,
+                           double* x3d_out, int32_t* type_out, int32_t* comp_out) {
+  OGmm* g = (OGmm*)h;
+  const Camera c = to_cam(cam);
+  const Params p = to_prm(prm);
+  float sf[8], sigma2[8];
+  sf[0] = 1.0f;
+  sigma2[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) {
+    sf[i] = sf[i - 1] * scale_factor;
+    sigma2[i] = sf[i] * sf[i];
+  }
+  const float fx = (float)c.fx, fy = (float)c.fy, cx = (float)c.cx, cy = (float)c.cy;  // const float fx1 = camera_->fx()
+  const float invfx = 1.0f / fx, invfy = 1.0f / fy;
+  const float mbf = (float)c.bf, mb = mbf / fx;  // frame.cpp:23-24
+  const float ratio_factor = 1.5f * scale_factor;
+  for (int n = 0; n < N; ++n) {
+    type_out[n] = 0;
+    comp_out[n] = -1;
+    for (int i = 0; i < 3; ++i) x3d_out[3 * n + i] = 0.0;
+    const SE3 Tcw1 = to_se3(pose1 + 7 * n), Tcw2 = to_se3(pose2 + 7 * n);
+    const SE3 Twc1 = se3_inverse(Tcw1), Twc2 = se3_inverse(Tcw2);
+    const double* k1 = uvr1 + 3 * n;
+    const double* k2 = uvr2 + 3 * n;
+    const float ur1 = (float)k1[2], ur2 = (float)k2[2];
+    const bool bStereo1 = ur1 >= 0, bStereo2 = ur2 >= 0;
+    const double xn1[3] = {(k1[0] - cx) * invfx, (k1[1] - cy) * invfy, 1.0};
+    const double xn2[3] = {(k2[0] - cx) * invfx, (k2[1] - cy) * invfy, 1.0};
+    double ray1[3], ray2[3];
+    qrot(Twc1.r, xn1, ray1);
+    qrot(Twc2.r, xn2, ray2);
+    const double dot = ray1[0] * ray2[0] + ray1[1] * ray2[1] + ray1[2] * ray2[2];
+    const double nr1 = std::sqrt(ray1[0] * ray1[0] + ray1[1] * ray1[1] + ray1[2] * ray1[2]);
+    const double nr2 = std::sqrt(ray2[0] * ray2[0] + ray2[1] * ray2[1] + ray2[2] * ray2[2]);
+    const float cosParallaxRays = dot / (nr1 * nr2);
+    float cosParallaxStereo = cosParallaxRays + 1;
+    float cps1 = cosParallaxStereo, cps2 = cosParallaxStereo;
+    if (bStereo1)
+      cps1 = std::cos(2 * std::atan2(mb / 2, depth1[n]));
+    else if (bStereo2)
+      cps2 = std::cos(2 * std::atan2(mb / 2, depth2[n]));
+    cosParallaxStereo = std::min(cps1, cps2);
+    double pt[3];
+    bool from_mono = false;
+    if (cosParallaxRays < cosParallaxStereo && cosParallaxRays > 0 && (bStereo1 || bStereo2 || cosParallaxRays < 0.9998)) {
+      double R1[9], R2[9], A[16];
+      qtoR(Tcw1.r, R1);
+      qtoR(Tcw2.r, R2);
+      for (int j = 0; j < 4; ++j) {
+        const double r1[3] = {j < 3 ? R1[0 * 3 + j] : Tcw1.t[0], j < 3 ? R1[1 * 3 + j] : Tcw1.t[1],
+                              j < 3 ? R1[2 * 3 + j] : Tcw1.t[2]};
+        const double r2[3] = {j < 3 ? R2[0 * 3 + j] : Tcw2.t[0], j < 3 ? R2[1 * 3 + j] : Tcw2.t[1],
+                              j < 3 ? R2[2 * 3 + j] : Tcw2.t[2]};
+        A[0 * 4 + j] = xn1[0] * r1[2] - r1[0];
+        A[1 * 4 + j] = xn1[1] * r1[2] - r1[1];
+        A[2 * 4 + j] = xn2[0] * r2[2] - r2[0];
+        A[3 * 4 + j] = xn2[1] * r2[2] - r2[1];
+      }
+      double vt[4];
+      smallest_right_singular_vector4(A, vt);
+      for (int i = 0; i < 3; ++i) pt[i] = vt[i] / vt[3];
+      from_mono = true;
+    } else if (bStereo1 && cps1 < cps2) {
+      const double z = depth1[n];
+      const double ptc[3] = {z * (k1[0] - c.cx) / c.fx, z * (k1[1] - c.cy) / c.fy, z};
+      se3_map(Twc1, ptc, pt);
+    } else if (bStereo2 && cps2 < cps1) {
+      const double z = depth2[n];
+      const double ptc[3] = {z * (k2[0] - c.cx) / c.fx, z * (k2[1] - c.cy) / c.fy, z};
+      se3_map(Twc2, ptc, pt);
+    } else {
+      continue;  // no stereo and very low parallax
+    }
+    // optimizeTriangulationVec decides mono / stereo edges by kp.depth > 0 (:116-137)
+    double b1[3] = {k1[0], k1[1], depth1[n] > 0 ? k1[2] : -1.0}, b2[3] = {k2[0], k2[1], depth2[n] > 0 ? k2[2] : -1.0};
+    const int comp = optimize_triangulation(*g, pt, Tcw1, b1, oct1[n], depth1[n] > 0, Tcw2, b2, oct2[n], depth2[n] > 0,
+                                            cand1 + (size_t)n * k, n1[n], cand2 + (size_t)n * k, n2[n], c, p);
+    for (int i = 0; i < 3; ++i) x3d_out[3 * n + i] = pt[i];
+    comp_out[n] = comp;
+    // project3 into both key-frames
+    auto project = [&](const SE3& Tcw, double* uvr) {
+      double pc[3];
+      se3_map(Tcw, pt, pc);
+      if (pc[2] < 0.0) return false;
+      const double rz = 1.0 / pc[2];
+      const double u = c.fx * (pc[0] * rz) + c.cx, v = c.fy * (pc[1] * rz) + c.cy;
+      if (!(u >= 0.0 && v >= 0.0 && u < (double)c.width && v < (double)c.height && pc[2] > 0.0)) return false;
+      uvr[0] = u;
+      uvr[1] = v;
+      uvr[2] = u - mbf / pc[2];
+      return true;
+    };
+    double p1[3], p2[3];
+    if (!project(Tcw1, p1) || !project(Tcw2, p2)) continue;
+    auto kp_error = [](const double* kp, float ur, const double* o) {  // Feature::error (feature.h:17-28)
+      if (ur < 0.0f) return (kp[0] - o[0]) * (kp[0] - o[0]) + (kp[1] - o[1]) * (kp[1] - o[1]);
+      const double d2 = (double)ur - o[2];
+      return (kp[0] - o[0]) * (kp[0] - o[0]) + (kp[1] - o[1]) * (kp[1] - o[1]) + d2 * d2;
+    };
+    const float s2 = sigma2[oct1[n]];  // both checks use kp1's octave (:370-391)
+    if (kp_error(k1, ur1, p1) > (bStereo1 ? 7.8 : 5.991) * s2) continue;
+    if (kp_error(k2, ur2, p2) > (bStereo2 ? 7.8 : 5.991) * s2) continue;
+    const double d1v[3] = {pt[0] - Twc1.t[0], pt[1] - Twc1.t[1], pt[2] - Twc1.t[2]};
+    const double d2v[3] = {pt[0] - Twc2.t[0], pt[1] - Twc2.t[1], pt[2] - Twc2.t[2]};
+    const float dist1 = std::sqrt(d1v[0] * d1v[0] + d1v[1] * d1v[1] + d1v[2] * d1v[2]);
+    const float dist2 = std::sqrt(d2v[0] * d2v[0] + d2v[1] * d2v[1] + d2v[2] * d2v[2]);
+    if (dist1 <= std::numeric_limits<float>::epsilon() || dist2 <= std::numeric_limits<float>::epsilon()) continue;
+    const float ratio_dist = dist2 / dist1;
+    const float ratio_octave = sf[oct1[n]] / sf[oct2[n]];
+    if (ratio_dist * ratio_factor < ratio_octave || ratio_dist > ratio_octave * ratio_factor) continue;
+    type_out[n] = from_mono ? (comp >= 0 ? 2 : 1) : (comp >= 0 ? 4 : 3);
+  }
+}
+
 // optimizeCurrentPose for one frame; pose in/out; returns #inliers
 int orc_optimize_current_pose(const orc_camera* cam, const orc_params* prm, double* pose, int N, const double* Xw,
                               const double* obs, const int32_t* octave, const uint8_t* has_pt,

@@ -377,13 +377,90 @@ def optimize_triangulation(x3d, pose1, uvr1, oct1, pose2, uvr2, cands1, cands2, 
                 b = b - s * J.T @ e
                 errs.append(s * e @ e)
             es = lam * (n @ (x - mu)) ** 2
-            x = x + np.linalg.solve(H, b)
+            try:
+                x = x + np.linalg.solve(H, b)
+            except np.linalg.LinAlgError:  # solver failure ends optimize(); the errors above stay
+                break
         ok = not (prm.tri_check_str_chi2 and es > float(F32(prm.tri_str_thresh * prm.tri_lambda2)))
         if errs[0] > th1 or errs[1] > th2:
             ok = False
         if ok and errs[0] + errs[1] < best_v:
             best, best_v, best_x = k, errs[0] + errs[1], x
     return best, (best_x if best >= 0 else x0)
+
+
+# ------------------------------------------------------------------ createMapPoints (per match)
+def create_map_point(pose1, kp1, depth1, oct1, pose2, kp2, depth2, oct2, cands1, cands2, comps, mean, cam, prm,
+                     scale_factor=1.2):
+    """Localization::createMapPoints, one epipolar match (localization_opt.cpp:286-420): parallax test,
+    np.linalg.svd triangulation or stereo unprojection, B2, reprojection and scale checks.
+    Returns (point or None, type 0..4, component)."""
+    f32 = np.float32
+    sf = [f32(1.0)]
+    for _ in range(7):
+        sf.append(f32(sf[-1] * f32(scale_factor)))
+    fx, fy, cx, cy = f32(cam.fx), f32(cam.fy), f32(cam.cx), f32(cam.cy)
+    ifx, ify = f32(1.0) / fx, f32(1.0) / fy
+    mbf = f32(cam.bf)
+    mb = f32(mbf / fx)
+    T1, T2 = SE3.from7(pose1), SE3.from7(pose2)
+    W1, W2 = T1.inv(), T2.inv()
+    ur1, ur2 = f32(kp1[2]), f32(kp2[2])
+    st1, st2 = bool(ur1 >= 0), bool(ur2 >= 0)
+    xn1 = np.array([(kp1[0] - np.float64(cx)) * np.float64(ifx), (kp1[1] - np.float64(cy)) * np.float64(ify), 1.0])
+    xn2 = np.array([(kp2[0] - np.float64(cx)) * np.float64(ifx), (kp2[1] - np.float64(cy)) * np.float64(ify), 1.0])
+    r1, r2 = W1.R @ xn1, W2.R @ xn2
+    cos_rays = f32(r1 @ r2 / (np.linalg.norm(r1) * np.linalg.norm(r2)))
+    c1 = c2 = f32(cos_rays + f32(1))
+    if st1:
+        c1 = f32(np.cos(f32(f32(2) * np.arctan2(f32(mb / f32(2)), f32(depth1)))))
+    elif st2:
+        c2 = f32(np.cos(f32(f32(2) * np.arctan2(f32(mb / f32(2)), f32(depth2)))))
+    cs = min(c1, c2)
+    from_mono = False
+    if cos_rays < cs and cos_rays > 0 and (st1 or st2 or np.float64(cos_rays) < 0.9998):
+        M1 = np.hstack([T1.R, T1.t[:, None]])
+        M2 = np.hstack([T2.R, T2.t[:, None]])
+        A = np.stack([xn1[0] * M1[2] - M1[0], xn1[1] * M1[2] - M1[1], xn2[0] * M2[2] - M2[0], xn2[1] * M2[2] - M2[1]])
+        vt = np.linalg.svd(A)[2][3]
+        pt = vt[:3] / vt[3]
+        from_mono = True
+    elif st1 and c1 < c2:
+        z = np.float64(f32(depth1))
+        pt = W1.map(np.array([z * (kp1[0] - cam.cx) / cam.fx, z * (kp1[1] - cam.cy) / cam.fy, z]))
+    elif st2 and c2 < c1:
+        z = np.float64(f32(depth2))
+        pt = W2.map(np.array([z * (kp2[0] - cam.cx) / cam.fx, z * (kp2[1] - cam.cy) / cam.fy, z]))
+    else:
+        return None, 0, -1
+    b1 = np.array([kp1[0], kp1[1], kp1[2] if depth1 > 0 else -1.0])
+    b2 = np.array([kp2[0], kp2[1], kp2[2] if depth2 > 0 else -1.0])
+    comp, pt = optimize_triangulation(pt, pose1, b1, oct1, pose2, b2, cands1, cands2, comps, mean, cam, prm)
+
+    def proj(T):
+        pc = T.map(pt)
+        if pc[2] < 0.0:
+            return None
+        u, v = cam.fx * (pc[0] / pc[2]) + cam.cx, cam.fy * (pc[1] / pc[2]) + cam.cy
+        if not (0.0 <= u < cam.width and 0.0 <= v < cam.height and pc[2] > 0.0):
+            return None
+        return np.array([u, v, u - np.float64(mbf) / pc[2]])
+
+    p1, p2 = proj(T1), proj(T2)
+    if p1 is None or p2 is None:
+        return pt, 0, comp
+    err = lambda kp, ur, o: ((kp[:2] - o[:2]) ** 2).sum() + (0.0 if ur < 0 else (np.float64(ur) - o[2]) ** 2)
+    s2 = np.float64(f32(sf[oct1] * sf[oct1]))
+    if err(kp1, ur1, p1) > (7.8 if st1 else 5.991) * s2 or err(kp2, ur2, p2) > (7.8 if st2 else 5.991) * s2:
+        return pt, 0, comp
+    d1, d2 = f32(np.linalg.norm(pt - W1.t)), f32(np.linalg.norm(pt - W2.t))
+    eps = np.finfo(np.float32).eps
+    if d1 <= eps or d2 <= eps:
+        return pt, 0, comp
+    ratio_d, ratio_o, rf = f32(d2 / d1), f32(sf[oct1] / sf[oct2]), f32(f32(1.5) * f32(scale_factor))
+    if f32(ratio_d * rf) < ratio_o or ratio_d > f32(ratio_o * rf):
+        return pt, 0, comp
+    return pt, (2 if comp >= 0 else 1) if from_mono else (4 if comp >= 0 else 3), comp
 
 
 # ------------------------------------------------------------------ generic dense LM (B3 / B4)

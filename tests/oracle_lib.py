@@ -142,6 +142,21 @@ class Oracle:
                                             _p(n2), k, _p(out))
         return out, x3d
 
+    def create_map_points(self, h, cam, pose1, uvr1, depth1, oct1, pose2, uvr2, depth2, oct2, cand1, n1, cand2, n2,
+                          scale_factor=1.2, prm=None):
+        """Localization::createMapPoints per-match block -> (x3d [N,3], type [N], comp [N])."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        pose1, uvr1, pose2, uvr2 = _f64(pose1), _f64(uvr1), _f64(pose2), _f64(uvr2)
+        depth1, depth2 = f32(depth1), f32(depth2)
+        oct1, oct2, cand1, n1, cand2, n2 = _i32(oct1), _i32(oct2), _i32(cand1), _i32(n1), _i32(cand2), _i32(n2)
+        N, k = cand1.shape
+        x3d, typ, comp = np.zeros((N, 3)), np.zeros(N, np.int32), np.zeros(N, np.int32)
+        c = self.camera(cam)
+        self.lib.orc_create_map_points(h, C.byref(c), C.byref(prm or self.prm), C.c_float(scale_factor), N, _p(pose1),
+                                       _p(uvr1), _p(depth1), _p(oct1), _p(pose2), _p(uvr2), _p(depth2), _p(oct2),
+                                       _p(cand1), _p(n1), _p(cand2), _p(n2), k, _p(x3d), _p(typ), _p(comp))
+        return x3d, typ, comp
+
     def optimize_current_pose(self, cam, pose, Xw, obs, octave, prm=None):
         pose = _f64(pose).copy()
         Xw, obs = _f64(Xw), _f64(obs)

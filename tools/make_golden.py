@@ -138,6 +138,19 @@ def main():
     np.savez_compressed(os.path.join(G, "golden_tri.npz"), pose1=pose, pose2=pose2, x3d=X0, uvr1=uvr1, uvr2=uvr2,
                         oct1=f["octave"], cand1=cands, cand2=cands2, out_comp=np.array(t_comp, np.int32),
                         out_pt=np.array(t_pt))
+    # --- createMapPoints per-match block: parallax test, SVD triangulation / stereo unprojection, B2, checks
+    unique_normal = comps["scale"][:, 1] > 10.0 * comps["scale"][:, 0]
+    NT = 150
+    pA, pB = synth.gt_row_to_Tcw(seq[900]), synth.gt_row_to_Tcw(seq[915])  # neighbouring key-frames
+    mt = synth.synth_tri_matches(mean, cov, pA, pB, CamLike(cam), NT, 91, allowed=unique_normal)
+    c_pt, c_type, c_comp = [], [], []
+    for i in range(NT):
+        pt_i, ty, co = nr.create_map_point(pA, mt["uvr1"][i], mt["depth1"][i], int(mt["oct1"][i]), pB,
+                                           mt["uvr2"][i], mt["depth2"][i], int(mt["oct2"][i]), mt["cand1"][i],
+                                           mt["cand2"][i], comps, mean, cam, prm)
+        c_pt.append(np.zeros(3) if pt_i is None else pt_i); c_type.append(ty); c_comp.append(co)
+    np.savez_compressed(os.path.join(G, "golden_cmp.npz"), out_pt=np.array(c_pt), out_type=np.array(c_type, np.int32),
+                        out_comp=np.array(c_comp, np.int32), **mt)
 
     # --- B3: optimizeCurrentPose ---------------------------------------------------------------
     out = {}
