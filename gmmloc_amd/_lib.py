@@ -67,6 +67,7 @@ def load():
         "gl_optimize_point": (i32, [vp, vp, P(gl_camera), P(gl_params), i32] + [vp] * 10),
         "gl_check_map_association": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32] + [vp] * 6 + [i32, vp]),
         "gl_optimize_triangulation": (i32, [vp, vp, P(gl_camera), P(gl_params), i32] + [vp] * 11 + [i32, vp]),
+        "gl_create_map_points": (i32, [vp, vp, P(gl_camera), P(gl_params), C.c_float, i32] + [vp] * 12 + [i32, vp, vp, vp]),
         "gl_optimize_current_pose": (i32, [vp, P(gl_camera), P(gl_params), i32, i32, vp, vp, vp, vp, vp, vp]),
         "gl_joint_optimization": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32, i32, i32, i32] + [vp] * 11),
         "gl_track_frames": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -400,3 +400,22 @@ def search_by_projection_frame(ctx, cam, pose_cw, pose_lw, feat_uv, feat_ur, fea
                                                  _ptr(nm)))
     ctx._exit()
     return match, nm
+
+
+def create_map_points(ctx, gmm, cam, prm, pose1, uvr1, depth1, oct1, pose2, uvr2, depth2, oct2, cand1, n1, cand2, n2,
+                      scale_factor=1.2):
+    """Localization::createMapPoints per-match block (localization_opt.cpp:286-420), N matches ->
+    (x3d float64 (N,3), type int32 (N,), comp int32 (N,))."""
+    import torch
+    N, k = cand1.shape
+    dev = pose1.device
+    x3d = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    typ = torch.empty(N, dtype=torch.int32, device=dev)
+    comp = torch.empty(N, dtype=torch.int32, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_create_map_points(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), N,
+                                        _ptr(pose1), _ptr(uvr1), _ptr(depth1), _ptr(oct1), _ptr(pose2), _ptr(uvr2),
+                                        _ptr(depth2), _ptr(oct2), _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k,
+                                        _ptr(x3d), _ptr(typ), _ptr(comp)))
+    ctx._exit()
+    return x3d, typ, comp

@@ -341,6 +341,208 @@ __global__ void k_optimize_triangulation(PtK k, int N, const double* __restrict_
   out_comp[n] = min_comp;
 }
 
+// ---- Localization::createMapPoints, per-match block (localization_opt.cpp:286-420) ---------------------
+struct TriK {
+  double fx, fy, cx, cy;                 // PinholeCamera intrinsics (double)
+  float ffx, ffy, fcx, fcy, invfx, invfy;  // `const float fx1 = camera_->fx()` ... (:227-232)
+  float mbf, mb, ratio_factor;
+  float sf[8], sigma2[8];
+  int width, height;
+};
+
+// smallest right singular vector of a 4 x 4 matrix by one-sided Jacobi (the reference: JacobiSVD, V.col(3))
+__device__ void smallest_rsv4(const double* A, double* v) {
+  double U[16], V[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    U[i] = A[i];
+    V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        double al = 0, be = 0, ga = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          al += U[k * 4 + p] * U[k * 4 + p];
+          be += U[k * 4 + q] * U[k * 4 + q];
+          ga += U[k * 4 + p] * U[k * 4 + q];
+        }
+        if (ga != 0.0) {
+          off = fmax(off, fabs(ga) / sqrt(al * be));
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double up = U[k * 4 + p], uq = U[k * 4 + q];
+            U[k * 4 + p] = c * up - sn * uq;
+            U[k * 4 + q] = sn * up + c * uq;
+            const double vp = V[k * 4 + p], vq = V[k * 4 + q];
+            V[k * 4 + p] = c * vp - sn * vq;
+            V[k * 4 + q] = sn * vp + c * vq;
+          }
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double nn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    nn[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nn[j] += U[k * 4 + j] * U[k * 4 + j];
+  }
+  int best = 0;
+  double bn = nn[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (nn[j] < bn) {
+      bn = nn[j];
+      best = j;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = best == 0 ? V[k * 4] : (best == 1 ? V[k * 4 + 1] : (best == 2 ? V[k * 4 + 2] : V[k * 4 + 3]));
+}
+
+// stage 1: parallax test, triangulation / unprojection.  stage[n]: 0 = no point, 1 = from two views, 2 = from stereo.
+// b1 / b2: the key-points as optimizeTriangulationVec reads them (u_right = -1 unless depth > 0, :116-137).
+__global__ void k_tri_pre(TriK k, int N, const double* __restrict__ pose1, const double* __restrict__ uvr1,
+                          const float* __restrict__ depth1, const double* __restrict__ pose2,
+                          const double* __restrict__ uvr2, const float* __restrict__ depth2, double* __restrict__ x3d,
+                          int32_t* __restrict__ stage, double* __restrict__ b1, double* __restrict__ b2) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const SE3 Tcw1 = se3_load(pose1 + (size_t)n * 7), Tcw2 = se3_load(pose2 + (size_t)n * 7);
+  const SE3 Twc1 = se3_inverse(Tcw1), Twc2 = se3_inverse(Tcw2);
+  const double* k1 = uvr1 + (size_t)n * 3;
+  const double* k2 = uvr2 + (size_t)n * 3;
+  const float ur1 = (float)k1[2], ur2 = (float)k2[2], dp1 = depth1[n], dp2 = depth2[n];
+  const bool bStereo1 = ur1 >= 0, bStereo2 = ur2 >= 0;
+  const double xn1[3] = {(k1[0] - k.fcx) * k.invfx, (k1[1] - k.fcy) * k.invfy, 1.0};
+  const double xn2[3] = {(k2[0] - k.fcx) * k.invfx, (k2[1] - k.fcy) * k.invfy, 1.0};
+  double ray1[3], ray2[3];
+  qrot(Twc1.r, xn1, ray1);
+  qrot(Twc2.r, xn2, ray2);
+  const double dot = ray1[0] * ray2[0] + ray1[1] * ray2[1] + ray1[2] * ray2[2];
+  const double nr1 = sqrt(ray1[0] * ray1[0] + ray1[1] * ray1[1] + ray1[2] * ray1[2]);
+  const double nr2 = sqrt(ray2[0] * ray2[0] + ray2[1] * ray2[1] + ray2[2] * ray2[2]);
+  const float cosRays = (float)(dot / (nr1 * nr2));
+  float cps = cosRays + 1;
+  float cps1 = cps, cps2 = cps;
+  if (bStereo1)
+    cps1 = cosf(2 * atan2f(k.mb / 2, dp1));
+  else if (bStereo2)
+    cps2 = cosf(2 * atan2f(k.mb / 2, dp2));
+  cps = fminf(cps1, cps2);
+  double pt[3] = {0, 0, 0};
+  int st = 0;
+  if (cosRays < cps && cosRays > 0 && (bStereo1 || bStereo2 || cosRays < 0.9998)) {
+    double R1[9], R2[9], A[16];
+    qtoR(Tcw1.r, R1);
+    qtoR(Tcw2.r, R2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double r1[3] = {j < 3 ? R1[0 * 3 + j] : Tcw1.t[0], j < 3 ? R1[1 * 3 + j] : Tcw1.t[1], j < 3 ? R1[2 * 3 + j] : Tcw1.t[2]};
+      const double r2[3] = {j < 3 ? R2[0 * 3 + j] : Tcw2.t[0], j < 3 ? R2[1 * 3 + j] : Tcw2.t[1], j < 3 ? R2[2 * 3 + j] : Tcw2.t[2]};
+      A[0 * 4 + j] = xn1[0] * r1[2] - r1[0];
+      A[1 * 4 + j] = xn1[1] * r1[2] - r1[1];
+      A[2 * 4 + j] = xn2[0] * r2[2] - r2[0];
+      A[3 * 4 + j] = xn2[1] * r2[2] - r2[1];
+    }
+    double vt[4];
+    smallest_rsv4(A, vt);
+    for (int i = 0; i < 3; ++i) pt[i] = vt[i] / vt[3];
+    st = 1;
+  } else if (bStereo1 && cps1 < cps2) {
+    const double z = dp1;
+    const double ptc[3] = {z * (k1[0] - k.cx) / k.fx, z * (k1[1] - k.cy) / k.fy, z};
+    double r[3];
+    qrot(Twc1.r, ptc, r);
+    for (int i = 0; i < 3; ++i) pt[i] = r[i] + Twc1.t[i];
+    st = 2;
+  } else if (bStereo2 && cps2 < cps1) {
+    const double z = dp2;
+    const double ptc[3] = {z * (k2[0] - k.cx) / k.fx, z * (k2[1] - k.cy) / k.fy, z};
+    double r[3];
+    qrot(Twc2.r, ptc, r);
+    for (int i = 0; i < 3; ++i) pt[i] = r[i] + Twc2.t[i];
+    st = 2;
+  }
+  stage[n] = st;
+  for (int i = 0; i < 3; ++i) x3d[(size_t)n * 3 + i] = pt[i];
+  b1[(size_t)n * 3] = k1[0];
+  b1[(size_t)n * 3 + 1] = k1[1];
+  b1[(size_t)n * 3 + 2] = dp1 > 0 ? k1[2] : -1.0;
+  b2[(size_t)n * 3] = k2[0];
+  b2[(size_t)n * 3 + 1] = k2[1];
+  b2[(size_t)n * 3 + 2] = dp2 > 0 ? k2[2] : -1.0;
+}
+
+// stage 3: reprojection and scale-consistency checks (:366-404) -> MapPoint type
+__global__ void k_tri_post(TriK k, int N, const double* __restrict__ pose1, const double* __restrict__ uvr1,
+                           const int32_t* __restrict__ oct1, const double* __restrict__ pose2,
+                           const double* __restrict__ uvr2, const int32_t* __restrict__ oct2,
+                           const int32_t* __restrict__ stage, double* __restrict__ x3d, int32_t* __restrict__ comp,
+                           int32_t* __restrict__ type) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int st = stage[n];
+  if (st == 0) {
+    type[n] = 0;
+    comp[n] = -1;
+    for (int i = 0; i < 3; ++i) x3d[(size_t)n * 3 + i] = 0.0;
+    return;
+  }
+  const SE3 Tcw1 = se3_load(pose1 + (size_t)n * 7), Tcw2 = se3_load(pose2 + (size_t)n * 7);
+  const SE3 Twc1 = se3_inverse(Tcw1), Twc2 = se3_inverse(Tcw2);
+  const double pt[3] = {x3d[(size_t)n * 3], x3d[(size_t)n * 3 + 1], x3d[(size_t)n * 3 + 2]};
+  const double* k1 = uvr1 + (size_t)n * 3;
+  const double* k2 = uvr2 + (size_t)n * 3;
+  const float ur1 = (float)k1[2], ur2 = (float)k2[2];
+  const bool bStereo1 = ur1 >= 0, bStereo2 = ur2 >= 0;
+  auto project = [&](const SE3& T, double* o) {
+    double r[3];
+    qrot(T.r, pt, r);
+    const double pc[3] = {r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2]};
+    if (pc[2] < 0.0) return false;
+    const double rz = 1.0 / pc[2];
+    const double u = k.fx * (pc[0] * rz) + k.cx, v = k.fy * (pc[1] * rz) + k.cy;
+    if (!(u >= 0.0 && v >= 0.0 && u < (double)k.width && v < (double)k.height && pc[2] > 0.0)) return false;
+    o[0] = u;
+    o[1] = v;
+    o[2] = u - k.mbf / pc[2];
+    return true;
+  };
+  auto kp_error = [](const double* kp, float ur, const double* o) {
+    const double e2 = (kp[0] - o[0]) * (kp[0] - o[0]) + (kp[1] - o[1]) * (kp[1] - o[1]);
+    if (ur < 0.0f) return e2;
+    const double d2 = (double)ur - o[2];
+    return e2 + d2 * d2;
+  };
+  int ty = 0;
+  double p1[3], p2[3];
+  if (project(Tcw1, p1) && project(Tcw2, p2)) {
+    const float s2 = k.sigma2[oct1[n] & 7];  // both checks use kp1's octave (:370-391)
+    if (!(kp_error(k1, ur1, p1) > (bStereo1 ? 7.8 : 5.991) * s2) && !(kp_error(k2, ur2, p2) > (bStereo2 ? 7.8 : 5.991) * s2)) {
+      const double a[3] = {pt[0] - Twc1.t[0], pt[1] - Twc1.t[1], pt[2] - Twc1.t[2]};
+      const double b[3] = {pt[0] - Twc2.t[0], pt[1] - Twc2.t[1], pt[2] - Twc2.t[2]};
+      const float dist1 = (float)sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      const float dist2 = (float)sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+      if (!(dist1 <= 1.1920929e-07f || dist2 <= 1.1920929e-07f)) {
+        const float ratio_dist = dist2 / dist1;
+        const float ratio_octave = k.sf[oct1[n] & 7] / k.sf[oct2[n] & 7];
+        if (!(ratio_dist * k.ratio_factor < ratio_octave || ratio_dist > ratio_octave * k.ratio_factor))
+          ty = st == 1 ? (comp[n] >= 0 ? 2 : 1) : (comp[n] >= 0 ? 4 : 3);
+      }
+    }
+  }
+  type[n] = ty;
+}
+
 PtK make_ptk(const gl_camera* cam, const gl_params* prm) {
   PtK k;
   k.fx = cam->fx;
@@ -417,6 +619,65 @@ int gl_optimize_triangulation(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camer
                                                                 x3d_dev, pose1_dev, uvr1_dev, oct1_dev, pose2_dev,
                                                                 uvr2_dev, cand1_dev, n1_dev, cand2_dev, n2_dev, k,
                                                                 out_comp_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+
+int gl_create_map_points(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, float scale_factor,
+                         int N, const double* pose1_dev, const double* uvr1_dev, const float* depth1_dev,
+                         const int32_t* oct1_dev, const double* pose2_dev, const double* uvr2_dev,
+                         const float* depth2_dev, const int32_t* oct2_dev, const int32_t* cand1_dev,
+                         const int32_t* n1_dev, const int32_t* cand2_dev, const int32_t* n2_dev, int k, double* x3d_dev,
+                         int32_t* type_dev, int32_t* comp_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (N == 0) return GL_OK;
+  GL_REQUIRE(N > 0 && k >= 1 && k <= 8, "bad N / k");
+  GL_REQUIRE(cam->width > 0 && cam->height > 0, "camera width / height not set");
+  GL_REQUIRE(pose1_dev && uvr1_dev && depth1_dev && oct1_dev && pose2_dev && uvr2_dev && depth2_dev && oct2_dev &&
+                 cand1_dev && n1_dev && cand2_dev && n2_dev && x3d_dev && type_dev && comp_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  void* scratch = nullptr;
+  int rc = gl::ctx_scratch(c, (size_t)N * (2 * 24 + 4) + 64, &scratch);
+  if (rc != GL_OK) return rc;
+  double* b1 = (double*)scratch;
+  double* b2 = b1 + (size_t)N * 3;
+  int32_t* stage = (int32_t*)(b2 + (size_t)N * 3);
+  TriK t;
+  t.fx = cam->fx;
+  t.fy = cam->fy;
+  t.cx = cam->cx;
+  t.cy = cam->cy;
+  t.ffx = (float)cam->fx;
+  t.ffy = (float)cam->fy;
+  t.fcx = (float)cam->cx;
+  t.fcy = (float)cam->cy;
+  t.invfx = 1.0f / t.ffx;
+  t.invfy = 1.0f / t.ffy;
+  t.mbf = (float)cam->bf;
+  t.mb = t.mbf / t.ffx;
+  t.ratio_factor = 1.5f * scale_factor;
+  t.sf[0] = 1.0f;
+  t.sigma2[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) {
+    t.sf[i] = t.sf[i - 1] * scale_factor;
+    t.sigma2[i] = t.sf[i] * t.sf[i];
+  }
+  t.width = cam->width;
+  t.height = cam->height;
+  const int grid = (N + 63) / 64;
+  k_tri_pre<<<grid, 64, 0, c->stream>>>(t, N, pose1_dev, uvr1_dev, depth1_dev, pose2_dev, uvr2_dev, depth2_dev, x3d_dev, stage,
+                                        b1, b2);
+  GL_HIP(hipGetLastError());
+  k_optimize_triangulation<<<grid, 64, 0, c->stream>>>(make_ptk(cam, prm), N, g->rec12, g->axis, g->flags, x3d_dev, pose1_dev,
+                                                       b1, oct1_dev, pose2_dev, b2, cand1_dev, n1_dev, cand2_dev, n2_dev, k,
+                                                       comp_dev);
+  GL_HIP(hipGetLastError());
+  k_tri_post<<<grid, 64, 0, c->stream>>>(t, N, pose1_dev, uvr1_dev, oct1_dev, pose2_dev, uvr2_dev, oct2_dev, stage, x3d_dev,
+                                         comp_dev, type_dev);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

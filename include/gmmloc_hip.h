@@ -235,6 +235,24 @@ int gl_optimize_triangulation(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camer
                               const int32_t* oct2_dev, const int32_t* cand1_dev, const int32_t* n1_dev,
                               const int32_t* cand2_dev, const int32_t* n2_dev, int k, int32_t* out_comp_dev);
 
+/* Localization::createMapPoints, the per-match block (localization_opt.cpp:286-420), for
+ * N epipolar matches: parallax test -> linear triangulation (smallest right singular vector of the 4 x 4
+ * system, the reference's JacobiSVD) or stereo unprojection (frame.cpp:27-35) -> optimizeTriangulationVec
+ * (= gl_optimize_triangulation, with u_right taken as -1 unless depth > 0, :116-137) -> project3 into both
+ * key-frames, reprojection checks (both with kp1's sigma^2, :370-391) and scale consistency (:393-404).
+ *  pose1 / pose2 N x 7 (getTcw of the two key-frames); uvr1 / uvr2 N x 3 (u, v, u_right; < 0 = monocular);
+ *  depth1 / depth2 N float (Feature::depth, -1 = none); oct1 / oct2 N; candidate tables as in
+ *  gl_optimize_triangulation; scale_factor = frame::scale_factor (1.2).
+ *  out: x3d N x 3 (the point after the structure optimisation; zeros when no point was formed),
+ *  type N int32: 0 = rejected, 1 FromTriMono, 2 FromTriMonoGMM, 3 FromTriStereo, 4 FromTriStereoGMM
+ *  (MapPoint::type_, :407-419), comp N int32 (str_ptr as component index, -1 = none). */
+int gl_create_map_points(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, float scale_factor,
+                         int N, const double* pose1_dev, const double* uvr1_dev, const float* depth1_dev,
+                         const int32_t* oct1_dev, const double* pose2_dev, const double* uvr2_dev,
+                         const float* depth2_dev, const int32_t* oct2_dev, const int32_t* cand1_dev,
+                         const int32_t* n1_dev, const int32_t* cand2_dev, const int32_t* n2_dev, int k, double* x3d_dev,
+                         int32_t* type_dev, int32_t* comp_dev);
+
 /* ---- pose refinement ------------------------------------------------------ */
 /* Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217) for B frames.
  *  pose_dev B x 7 in/out; Xw_dev B x M x 3; obs_dev B x M x 3 (u, v, u_right; u_right < 0

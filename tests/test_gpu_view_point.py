@@ -155,3 +155,31 @@ def test_optimize_triangulation_matches_oracle(gpu, oracle, map_v1, gt_sync):
     np.testing.assert_allclose(xd.cpu().numpy(), x_ref, rtol=0, atol=1e-9)
     assert (o_ref >= 0).sum() > 20
     oracle.gmm_destroy(h)
+
+
+@pytest.mark.parametrize("ia,ib,seed", [(900, 915, 5), (300, 306, 6), (1500, 1530, 7), (2000, 2012, 8)])
+def test_create_map_points_matches_oracle(gpu, oracle, map_v1, gt_sync, ia, ib, seed):
+    """createMapPoints per-match block (parallax test, SVD triangulation / stereo unprojection, B2, checks)."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    gt = gt_sync["V1_01_easy"]
+    N = 600
+    m = synth.synth_tri_matches(mean, cov, synth.gt_row_to_Tcw(gt[ia]), synth.gt_row_to_Tcw(gt[ib]), cam, N, seed)
+    x_ref, t_ref, c_ref = oracle.create_map_points(h, cam, **m)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    keys = ("pose1", "uvr1", "depth1", "oct1", "pose2", "uvr2", "depth2", "oct2", "cand1", "n1", "cand2", "n2")
+    x, t, c = gmmloc_amd.api.create_map_points(ctx, g, cam, prm, *[T(m[k]) for k in keys])
+    torch.cuda.synchronize()
+    x, t, c = x.cpu().numpy(), t.cpu().numpy(), c.cpu().numpy()
+    assert np.array_equal(t, t_ref), int((t != t_ref).sum())
+    assert np.array_equal(c, c_ref), int((c != c_ref).sum())
+    # a handful of matches triangulate to points kilometres away (parallel rays that still pass every
+    # check): Gauss-Newton is chaotic there and only the decision, not the coordinates, is comparable
+    sane = np.linalg.norm(x_ref, axis=1) < 100.0
+    assert sane.mean() > 0.98
+    np.testing.assert_allclose(x[sane], x_ref[sane], rtol=0, atol=1e-8)
+    assert (t_ref > 0).sum() > 50 and (t_ref == 0).sum() > 20 and len(set(t_ref.tolist())) >= 4
+    oracle.gmm_destroy(h)
