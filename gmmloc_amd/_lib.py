@@ -55,6 +55,7 @@ def load():
         "gl_gmm_count": (i32, [vp]),
         "gl_gmm_file_read": (i32, [C.c_char_p, vp, vp, i32, P(i32)]),
         "gl_gmm_file_write": (i32, [C.c_char_p, vp, vp, vp, i32]),
+        "gl_write_tum_trajectory": (i32, [C.c_char_p, vp, vp, i32]),
         "gl_gmm_get": (i32, [vp, i32, vp, C.c_size_t]),
         "gl_gmm_nbs_count": (i32, [vp]),
         "gl_associate3d": (i32, [vp, vp, vp, i32, i32, vp, vp]),

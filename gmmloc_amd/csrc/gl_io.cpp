@@ -175,4 +175,21 @@ int gl_gmm_file_write(const char* path, const double* mean, const double* cov, c
   return gl::write_gmm_file(path, mean, cov, flags, K);
 }
 
+// Map::summarize (map.cpp:162-188): one line per frame, `timestamp tx ty tz qx qy qz qw` of T_wc in TUM
+// format -- std::fixed, 6 digits for the stamp, 9 for the pose, single spaces, '\n'.
+int gl_write_tum_trajectory(const char* path, const double* stamps, const double* pose_wc, int N) {
+  GL_REQUIRE(path && (N == 0 || (stamps && pose_wc)) && N >= 0, "bad argument");
+  FILE* f = fopen(path, "w");
+  if (!f) {
+    gl::set_error("gl_write_tum_trajectory: cannot open %s", path);
+    return GL_ERR_IO;
+  }
+  for (int i = 0; i < N; ++i) {
+    const double* p = pose_wc + (size_t)i * 7;  // qx qy qz qw tx ty tz
+    fprintf(f, "%.6f %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", stamps[i], p[4], p[5], p[6], p[0], p[1], p[2], p[3]);
+  }
+  fclose(f);
+  return GL_OK;
+}
+
 }  // extern "C"

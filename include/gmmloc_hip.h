@@ -109,6 +109,10 @@ int gl_gmm_count(const gl_gmm_t* gmm);
 int gl_gmm_file_read(const char* path, double* mean, double* cov, int cap, int* K_out);
 int gl_gmm_file_write(const char* path, const double* mean, const double* cov, const uint8_t* flags, int K);
 
+/* Map::summarize (map.cpp:162-188), host only: writes `timestamp tx ty tz qx qy qz qw` (T_wc, TUM format,
+ * fixed notation, 6 / 9 digits) for N frames; pose_wc N x 7 in the library's (qx qy qz qw tx ty tz) order. */
+int gl_write_tum_trajectory(const char* path, const double* stamps, const double* pose_wc, int N);
+
 enum gl_gmm_field {
   GL_F_MEAN = 0,      /* K x 3 double */
   GL_F_COV = 1,       /* K x 9 double */
