@@ -290,6 +290,21 @@ int build_cell_index(Ctx* c, Gmm* g) {
     std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
     for (size_t i = 0; i < e_k.size(); ++i) idx[fill[e_cell[i]]++] = e_k[i];
   }
+  {  // the index must actually prune: the mean list length seen at the component means (where the map points
+     // are) has to stay well below K, otherwise the plain sweep with scalar-operand records is faster
+    double sum = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < K; ++k) {
+      if (!ok[k]) continue;
+      const double* mu = &g->h_mean[(size_t)k * 3];
+      int ci[3];
+      for (int a3 = 0; a3 < 3; ++a3) ci[a3] = std::min(dim[a3] - 1, std::max(0, (int)std::floor((mu[a3] - lo[a3]) / h)));
+      const size_t cell = ((size_t)ci[2] * dim[1] + ci[1]) * dim[0] + ci[0];
+      sum += (double)(ptr[cell + 1] - ptr[cell]);
+      ++cnt;
+    }
+    if (cnt > 0 && sum / cnt + (double)glob.size() > 0.25 * K) return GL_OK;
+  }
   CellIndex& G = g->grid;
   GL_HIP(hipSetDevice(g->device));
   GL_HIP(hipMalloc((void**)&G.ptr, (ncell + 1) * 4));
