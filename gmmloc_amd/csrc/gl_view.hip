@@ -24,6 +24,7 @@ namespace {
 
 constexpr int T_VIEW = 256;
 constexpr int NW_VIEW = T_VIEW / 64;
+constexpr int SLOT_LDS = 640;  // accepted 2-D components kept in LDS (40 KB); V is 100-300 on the EuRoC maps
 constexpr int REC = 8;  // m0 m1 c00 c01 c10 c11 det depth
 
 struct ViewK {
@@ -58,7 +59,6 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
   __shared__ int s_wcount[NW_VIEW];
   __shared__ double s_rd[NW_VIEW];
   __shared__ int s_ri[NW_VIEW];
-  __shared__ double s_cand[REC];
   const int f = blockIdx.x;
   if (f >= B) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,6 +70,9 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
   int32_t* slot_id = cand_id + K;
   int32_t* sorted_id = slot_id + K;  // (K*2 doubles hold 4K int32: ids use 3K)
 
+#ifdef GL_VIEW_PROF
+  const long long tp0 = clock64();
+#endif
   const SE3 T = se3_load(pose_all + (size_t)f * 7);
   double R[9];
   qtoR(T.r, R);
@@ -190,14 +193,33 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
     __syncthreads();
   }
 
+#ifdef GL_VIEW_PROF
+  const long long tp1 = clock64();
+#endif
   // ---- phase 2: sequential occlusion merge (:328-355) -------------------------------------
+  // The accepted list lives in LDS (spilled to the global scratch only beyond SLOT_LDS entries), the
+  // candidate record is fetched one iteration ahead by every thread (same address: one transaction), and
+  // a candidate costs two barriers: argmin exchange, and publication of the slot it writes.
+  extern __shared__ __attribute__((aligned(16))) double lds_slot[];  // SLOT_LDS x REC
+  double* slotp = lds_slot;
   int nslots = 0;
+  double cn[REC];
+  int idn = 0;
+  if (C > 0) {
+#pragma unroll
+    for (int i = 0; i < REC; ++i) cn[i] = cand[i];
+    idn = cand_id[0];
+  }
   for (int c = 0; c < C; ++c) {
-    if (tid < REC) s_cand[tid] = cand[(size_t)c * REC + tid];
-    __syncthreads();
     double cr[REC];
 #pragma unroll
-    for (int i = 0; i < REC; ++i) cr[i] = s_cand[i];
+    for (int i = 0; i < REC; ++i) cr[i] = cn[i];
+    const int idc = idn;
+    if (c + 1 < C) {
+#pragma unroll
+      for (int i = 0; i < REC; ++i) cn[i] = cand[(size_t)(c + 1) * REC + i];
+      idn = cand_id[c + 1];
+    }
     int action_slot;  // -2 discard, -1 append, >= 0 replace that slot
     if (nslots == 0) {
       action_slot = -1;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
       for (int j = tid; j < nslots; j += T_VIEW) {
         double sr[REC];
 #pragma unroll
-        for (int i = 0; i < REC; ++i) sr[i] = slot[(size_t)j * REC + i];
+        for (int i = 0; i < REC; ++i) sr[i] = slotp[(size_t)j * REC + i];
         const double d = bh2(sr, cr);
         if (d < best) {
           best = d;
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
         s_rd[wave] = best;
         s_ri[wave] = bj;
       }
-      __syncthreads();
+      __syncthreads();  // also: every read of the slot list is done before it changes
       best = s_rd[0];
       bj = s_ri[0];
 #pragma unroll
@@ -239,22 +261,35 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
         }
       if (bj == 0x7fffffff) bj = 0;  // every distance NaN: min_idx stays at its initial value
       if (best < 0.8) {
-        action_slot = (cr[7] < slot[(size_t)bj * REC + 7]) ? bj : -2;
+        action_slot = (cr[7] < slotp[(size_t)bj * REC + 7]) ? bj : -2;
       } else {
         action_slot = -1;
       }
+      if (action_slot == -2) __syncthreads();  // s_rd / s_ri are rewritten by the next candidate
     }
-    __syncthreads();  // all reads of the slot list done before it changes
     if (action_slot != -2) {
+      if (nslots > 0) __syncthreads();  // the depth read above precedes the overwrite
       const int dst = action_slot == -1 ? nslots : action_slot;
-      if (tid < REC) slot[(size_t)dst * REC + tid] = cr[tid];
-      if (tid == REC) slot_id[dst] = cand_id[c];
-      if (action_slot == -1) ++nslots;
+      if (tid < REC) slotp[(size_t)dst * REC + tid] = cr[tid];
+      if (tid == REC) slot_id[dst] = idc;
+      if (action_slot == -1) {
+        ++nslots;
+        if (nslots == SLOT_LDS && slotp == lds_slot) {  // rare: continue in the global scratch
+          __syncthreads();
+          for (int i = tid; i < SLOT_LDS * REC; i += T_VIEW) slot[i] = lds_slot[i];
+          slotp = slot;
+          __threadfence_block();
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
     }
-    __threadfence_block();
-    __syncthreads();
   }
+  slot = slotp;
   const int V = nslots;
+#ifdef GL_VIEW_PROF
+  const long long tp2 = clock64();
+#endif
 
   // ---- phase 3: stable sort by depth descending --------------------------------------------
   for (int j = tid; j < V; j += T_VIEW) {
@@ -279,24 +314,47 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
   }
   if (nview_out && tid == 0) nview_out[f] = V;
 
+#ifdef GL_VIEW_PROF
+  const long long tp3 = clock64();
+#endif
   // ---- phase 4: searchCorrespondence ----------------------------------------------------------
   const int nf = nfeat_all ? min(nfeat_all[f], N) : N;
-  for (int n = tid; n < N; n += T_VIEW) {
-    int32_t* co = cand_out + ((size_t)f * N + n) * knn;
-    int m = 0;
-    if (n < nf && V > 0) {
-      const double u = uv_all[((size_t)f * N + n) * 2], v = uv_all[((size_t)f * N + n) * 2 + 1];
-      double dist[8];
-      int idx[8];
+  // The kNN loop reads the mean of every rendered component for every feature: the means are staged in LDS
+  // (the slot list is dead by now) in chunks of MCH - one chunk, staged once, for any realistic view - and an
+  // entry that is not nearer than the current knn-th neighbour skips the insertion network.
+  double2* s_mean = reinterpret_cast<double2*>(lds_slot);
+  constexpr int MCH = SLOT_LDS * REC / 2;
+  bool staged = false;
+  for (int n0 = 0; n0 < N; n0 += T_VIEW) {  // uniform trip count: the staging barriers sit inside
+    const int n = n0 + tid;
+    const bool live = n < nf && V > 0;
+    double dist[8], worst = __builtin_inf(), fu = 0.0, fv = 0.0;
+    int idx[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        dist[i] = __builtin_inf();
-        idx[i] = -1;
+    for (int i = 0; i < 8; ++i) {
+      dist[i] = __builtin_inf();
+      idx[i] = -1;
+    }
+    if (live) {
+      fu = uv_all[((size_t)f * N + n) * 2];
+      fv = uv_all[((size_t)f * N + n) * 2 + 1];
+    }
+    for (int j0 = 0; j0 < V; j0 += MCH) {
+      const int jn = min(MCH, V - j0);
+      if (!staged) {
+        __syncthreads();
+        for (int j = tid; j < jn; j += T_VIEW)
+          s_mean[j] = make_double2(sorted[(size_t)(j0 + j) * REC], sorted[(size_t)(j0 + j) * REC + 1]);
+        __syncthreads();
+        staged = V <= MCH;
       }
-      for (int j = 0; j < V; ++j) {
-        const double d0 = u - sorted[(size_t)j * REC], d1 = v - sorted[(size_t)j * REC + 1];
+      if (!live) continue;
+      for (int j = 0; j < jn; ++j) {
+        const double2 mj = s_mean[j];
+        const double d0 = fu - mj.x, d1 = fv - mj.y;
         double cd = d0 * d0 + d1 * d1;  // kdtree_distance (gaussian_mixture.h:71-76)
-        int ci = j;
+        if (!(cd < worst)) continue;
+        int ci = j0 + j;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           if (i < knn) {
@@ -309,18 +367,37 @@ __global__ __launch_bounds__(T_VIEW) void k_search2d(ViewK vk, int B, int K, con
             ci = ti;
           }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) worst = (i == knn - 1) ? dist[i] : worst;
       }
+    }
+    if (n >= N) continue;
+    int32_t* co = cand_out + ((size_t)f * N + n) * knn;
+    int m = 0;
+    if (live) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i < knn && idx[i] >= 0) {
-          const double* s = &sorted[(size_t)idx[i] * REC];
-          if (mdist2_2d(s, s + 2, u, v) < 9.0) co[m++] = sorted_id[idx[i]];  // check_mdist2 (:521-527)
+          const double* sr = &sorted[(size_t)idx[i] * REC];
+          if (mdist2_2d(sr, sr + 2, fu, fv) < 9.0) co[m++] = sorted_id[idx[i]];  // check_mdist2 (:521-527)
         }
       }
     }
     ncand_out[(size_t)f * N + n] = m;
     for (; m < knn; ++m) co[m] = -1;
   }
+#ifdef GL_VIEW_PROF
+  __syncthreads();
+  if (tid == 0 && nview_out) {  // debug build: cycles of phases 1..4, C and V instead of the view list
+    const long long tp4 = clock64();
+    view_ids_out[(size_t)f * view_cap + 0] = (int)((tp1 - tp0) >> 4);
+    view_ids_out[(size_t)f * view_cap + 1] = (int)((tp2 - tp1) >> 4);
+    view_ids_out[(size_t)f * view_cap + 2] = (int)((tp3 - tp2) >> 4);
+    view_ids_out[(size_t)f * view_cap + 3] = (int)((tp4 - tp3) >> 4);
+    view_ids_out[(size_t)f * view_cap + 4] = C;
+    view_ids_out[(size_t)f * view_cap + 5] = V;
+  }
+#endif
 }
 
 }  // namespace
@@ -341,7 +418,7 @@ extern "C" int gl_search2d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* 
   int rc = gl::ctx_scratch(c, per_view * B + 64, &scratch);
   if (rc != GL_OK) return rc;
   ViewK vk{cam->fx, cam->fy, cam->cx, cam->cy, cam->width, cam->height};
-  k_search2d<<<B, T_VIEW, 0, c->stream>>>(vk, B, g->K, g->rec12, g->cov, g->axis, g->flags, pose_dev, N, uv_dev,
+  k_search2d<<<B, T_VIEW, (size_t)SLOT_LDS * REC * sizeof(double), c->stream>>>(vk, B, g->K, g->rec12, g->cov, g->axis, g->flags, pose_dev, N, uv_dev,
                                           nfeat_dev, k, cand_dev, ncand_dev, view_cap, view_ids_dev, nview_dev,
                                           (double*)scratch);
   GL_HIP(hipGetLastError());
