@@ -241,6 +241,21 @@ def main():
             sweep_ms = ms / max(nn, 1)
             idx_pairs = gmm.index_work(flat)
         torch.cuda.synchronize()
+        # single-frame latency (the north star also quotes a latency target): one frame per call,
+        # host call -> result synchronised, on the first frame of the batch
+        p1, x1, o1, c1 = pose0[:1].contiguous(), Xw0[:1].contiguous(), obs[:1].contiguous(), octv[:1].contiguous()
+        pl, xl = p1.clone(), x1.clone()
+        lat = []
+        with torch.cuda.stream(ctx.stream):
+            for it in range(25):
+                pl.copy_(p1)
+                xl.copy_(x1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                gmmloc_amd.track_frames(ctx, gmm, cam, prm, pl, xl, o1, c1, want_d2=False)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+        latency_ms = 1e3 * float(np.median(lat[5:]))
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -323,8 +338,11 @@ def main():
             },
             "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine": ba_ms / max(args.steps, 1)},
         }
+        out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(20200901 + 100000 * rank)
+            out["latency"]["cpu_1thread_ms_per_frame"] = 1e3 / out["cpu_baseline"]["value"]
+            out["latency"]["speedup_vs_cpu_1thread"] = out["latency"]["cpu_1thread_ms_per_frame"] / latency_ms
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

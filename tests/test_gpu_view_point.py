@@ -45,6 +45,80 @@ def test_search2d_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, mapname, 
     oracle.gmm_destroy(h)
 
 
+def _check_search2d(torch, ctx, oracle, mean, cov, poses, uv, k):
+    cam = api.Camera()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    B = poses.shape[0]
+    cand, ncand, vids, nview = g.search2d(cam, torch.from_numpy(poses).cuda(), torch.from_numpy(uv).cuda(), None, k=k,
+                                          view_cap=4096)
+    torch.cuda.synchronize()
+    cand, ncand, vids, nview = cand.cpu().numpy(), ncand.cpu().numpy(), vids.cpu().numpy(), nview.cpu().numpy()
+    tot = 0
+    for b in range(B):
+        ids, m2, c2, dep = oracle.render_view(h, cam, poses[b])
+        assert nview[b] == len(ids), (b, nview[b], len(ids))
+        assert np.array_equal(vids[b][:len(ids)], ids)
+        c_ref, n_ref = oracle.search_correspondence(h, uv[b], k)
+        assert np.array_equal(ncand[b], n_ref)
+        assert np.array_equal(cand[b], c_ref)
+        tot += len(ids)
+    oracle.gmm_destroy(h)
+    return tot / B
+
+
+@pytest.mark.parametrize("k", [1, 3, 8])
+def test_search2d_knn_sizes(gpu, oracle, map_v1, gt_sync, k):
+    """searchCorrespondence with k != 5 (the run-time-k instance of the selection network)."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    poses = _poses(gt_sync["V1_02_medium"], 4, step=97)
+    rng = np.random.default_rng(10 + k)
+    uv = np.stack([rng.uniform(0, 752, (4, 333)), rng.uniform(0, 480, (4, 333))], 2)
+    assert _check_search2d(torch, ctx, oracle, mean, cov, poses, uv, k) > 50
+
+
+@pytest.mark.parametrize("threads,slot_lds", [("256", None), ("1024", None), ("256", "24"), ("1024", "24")])
+def test_search2d_interacting_candidates(gpu, oracle, map_v1, gt_sync, monkeypatch, threads, slot_lds):
+    """Every component followed by a jittered copy: consecutive candidates fall below the merge threshold of each
+    other, replace each other's slots and share old argmins - the ordered part of the merge rounds, in both
+    block shapes, with the accepted list in LDS and spilled to the global scratch."""
+    torch, ctx = gpu
+    monkeypatch.setenv("GMMLOC_VIEW_THREADS", threads)
+    if slot_lds:
+        monkeypatch.setenv("GMMLOC_VIEW_SLOT_LDS", slot_lds)
+    mean, cov = map_v1
+    rng = np.random.default_rng(77)
+    K = mean.shape[0]
+    cov = cov.reshape(K, 3, 3)
+    m2 = np.empty((3 * K, 3)); c2 = np.empty((3 * K, 3, 3))
+    m2[0::3] = mean; m2[1::3] = mean + rng.normal(0, 0.02, (K, 3)); m2[2::3] = mean + rng.normal(0, 0.05, (K, 3))
+    c2[0::3] = cov; c2[1::3] = cov * rng.uniform(0.7, 1.4, (K, 1, 1)); c2[2::3] = cov * rng.uniform(0.5, 2.0, (K, 1, 1))
+    poses = _poses(gt_sync["V1_01_easy"], 5, step=131)
+    uv = np.stack([rng.uniform(0, 752, (5, 200)), rng.uniform(0, 480, (5, 200))], 2)
+    assert _check_search2d(torch, ctx, oracle, m2, c2, poses, uv, 5) > 50
+
+
+@pytest.mark.parametrize("threads", ["256", "1024"])
+def test_search2d_needle_fan(gpu, oracle, monkeypatch, threads):
+    """160 thin components fanned around one centre: every pair has Mahalanobis part 0 (nothing is screened
+    out, the pair list of a round overflows and the exhaustive path runs) while the log part keeps most of
+    them apart."""
+    torch, ctx = gpu
+    monkeypatch.setenv("GMMLOC_VIEW_THREADS", threads)
+    n = 160
+    mean = np.tile(np.array([[0.0, 0.0, 3.0]]), (n, 1)) + np.random.default_rng(5).normal(0, 1e-4, (n, 3))
+    cov = np.empty((n, 3, 3))
+    for i in range(n):
+        a = np.pi * i / n
+        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+        cov[i] = R @ np.diag([0.5 ** 2, 0.002 ** 2, 0.0005 ** 2]) @ R.T
+    poses = np.array([[0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0.1, -0.05, 0.2]], np.float64)  # qx qy qz qw tx ty tz (Tcw)
+    rng = np.random.default_rng(6)
+    uv = np.stack([rng.uniform(250, 500, (2, 300)), rng.uniform(150, 330, (2, 300))], 2)
+    assert _check_search2d(torch, ctx, oracle, mean, cov, poses, uv, 5) > 100
+
+
 def _frames(mean, cov, gt, cam, B, M, seed, **kw):
     return [synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(gt[(11 + i * 43) % gt.shape[0]]), cam, M, seed + i, **kw)
             for i in range(B)]
