@@ -667,7 +667,10 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   if (rc != GL_OK) return rc;
   {
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
-    static const bool block_version = getenv("GMMLOC_POSE_BLOCK") != nullptr;  // A/B knob: the workgroup-per-frame kernel
+    // one wave per frame is the throughput shape (12 frames per CU); with fewer frames than CUs a frame gets a
+    // whole workgroup instead (GMMLOC_POSE_BLOCK=0 / 1 forces the wave / workgroup kernel)
+    bool block_version = B <= 512;
+    if (const char* e = getenv("GMMLOC_POSE_BLOCK")) block_version = atoi(e) != 0;
     if (block_version)
       k_optimize_current_pose_block<<<B, T_POSE, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev,
                                                                  outlier_dev, ninlier_dev, (double*)scratch);

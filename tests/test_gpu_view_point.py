@@ -13,9 +13,11 @@ def _poses(gt, n, step=61):
     return np.stack([synth.gt_row_to_Tcw(gt[(7 + i * step) % gt.shape[0]]) for i in range(n)])
 
 
+@pytest.mark.parametrize("threads", ["256", "1024"])  # the batch / the few-views block shape
 @pytest.mark.parametrize("mapname,seq", [("v1", "V1_01_easy"), ("v1", "V1_03_difficult"), ("v2", "V2_02_medium")])
-def test_search2d_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, mapname, seq):
+def test_search2d_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, monkeypatch, mapname, seq, threads):
     torch, ctx = gpu
+    monkeypatch.setenv("GMMLOC_VIEW_THREADS", threads)
     mean, cov = map_v1 if mapname == "v1" else map_v2
     cam = api.Camera()
     g = api.GMM(ctx, mean, cov)
