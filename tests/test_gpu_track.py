@@ -64,3 +64,40 @@ def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, mapname, M, s
         gdt, gdr = pose_err(pose[i], f["pose_gt"])
         assert gdt < 0.1 and gdr < 0.05
     oracle.gmm_destroy(h)
+
+
+def test_track_frames_edge_cases(gpu, oracle, map_v1, gt_sync):
+    """Frames the tracker can hand over: no map point at all, a handful of points, nothing near the map (no GMM
+    edge survives the gate: plain reprojection refinement), every observation monocular, one frame of many sizes
+    sharing a padded batch."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    gt = gt_sync["V1_01_easy"]
+    M = 300
+    frames = make_frames(mean, cov, gt, cam, 6, M, 500, outlier_frac=0.02)
+    frames[0]["octave"][:] = -1                       # nothing to optimise: pose must come back unchanged
+    frames[1]["octave"][5:] = -1                      # 5 points
+    frames[2]["Xw"] += np.array([40.0, -35.0, 20.0])  # far from every component; consistent observations are kept
+    frames[3]["obs"][:, 2] = -1.0                     # monocular only
+    frames[4]["octave"][100:] = -1                    # padded short frame
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
+    pose, Xw, obs, octv = T("pose_init"), T("Xw"), T("obs"), T("octave")
+    assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, obs, octv)
+    torch.cuda.synchronize()
+    pose, Xw, assoc = pose.cpu().numpy(), Xw.cpu().numpy(), assoc.cpu().numpy()
+    assert np.array_equal(pose[0], frames[0]["pose_init"]) and (assoc[0] == -1).all()
+    assert np.array_equal(Xw[0], frames[0]["Xw"])
+    assert (assoc[2] == -1).all()
+    for i in range(1, 6):
+        f = frames[i]
+        keep, p_ref, pts_ref, a_ref, idx0, d20 = oracle_track(oracle, h, cam, f)
+        dt, dr = pose_err(pose[i], p_ref)
+        assert np.isfinite(pose[i]).all() and dt < 1e-6 and dr < 1e-6, (i, dt, dr)
+        assert np.array_equal(assoc[i][keep], a_ref), i
+        assert (assoc[i][f["octave"] < 0] == -1).all()
+        untouched = f["octave"] < 0
+        assert np.array_equal(Xw[i][untouched], f["Xw"][untouched])  # padding rows are not written
+    oracle.gmm_destroy(h)
