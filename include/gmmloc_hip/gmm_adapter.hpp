@@ -8,6 +8,7 @@
 //   GMMLoc::optimizePoint / checkMapAssociation     (gmmloc_opt.cpp:156-342)
 //   Tracking::optimizeCurrentPose                   (tracking_opt.cpp:21-217)
 //   Localization::jointOptimization                 (localization_opt.cpp:456-925)
+//   north-star per-frame path: associate + structure-constrained refinement of one frame (trackFrame)
 // Host buffers in, host buffers out: each call stages through device memory owned by the
 // adapter (gl_malloc / gl_memcpy_*), so the host code never sees a HIP type.
 #pragma once
@@ -133,6 +134,82 @@ class GMM {
     int32_t n[2];
     dn.download(n);
     return n[0];
+  }
+
+  // North-star per-frame path for ONE frame (gl_track_frames, B = 1): exact Mahalanobis association of the
+  // frame's M map points (kept iff chi2 <= 9, gmmloc_opt.cpp:230-232) + jointOptimization restricted to the
+  // frame (1 free pose, M marginalised points, 5 / 5 / 40 Levenberg schedule).  Tcw and Xw are updated;
+  // assoc[i] = component after the final gates or -1; octave[i] < 0 = no map point.
+  void trackFrame(Pose& Tcw, std::vector<double>& Xw, const std::vector<double>& obs, const std::vector<int32_t>& octave,
+                  std::vector<int32_t>& assoc) {
+    const int M = (int)octave.size();
+    assoc.assign(M, -1);
+    if (!M) return;
+    DevBuf dpose(ctx_, 56), dX(ctx_, (size_t)M * 24), dO(ctx_, (size_t)M * 24), doc(ctx_, (size_t)M * 4), da(ctx_, (size_t)M * 4);
+    dpose.upload(&Tcw);
+    dX.upload(Xw.data());
+    dO.upload(obs.data());
+    doc.upload(octave.data());
+    check(gl_track_frames(ctx_, gmm_, &cam_, &prm_, 1, M, dpose.as<double>(), dX.as<double>(), dO.as<double>(),
+                          doc.as<int32_t>(), da.as<int32_t>(), nullptr),
+          "gl_track_frames");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    dpose.download(&Tcw);
+    dX.download(Xw.data());
+    da.download(assoc.data());
+  }
+
+  // Localization::jointOptimization on one flattened local window (layout: gmmloc_hip.h, gl_joint_optimization):
+  // poses [0,P) free, [P,P+F) fixed; observations in CSR order by point.
+  struct LocalWindow {
+    int P = 0, F = 0;
+    std::vector<Pose> poses;            // P + F, in/out for [0,P)
+    std::vector<uint8_t> prior;         // P: key-frame idx_ 0 (prior edge)
+    std::vector<double> points;         // L x 3, in/out
+    std::vector<int32_t> assoc;         // L: component or -1
+    std::vector<int32_t> obs_ptr;       // L + 1
+    std::vector<int32_t> obs_pose;      // NOBS
+    std::vector<double> obs_uvr;        // NOBS x 3
+    std::vector<int32_t> obs_oct;       // NOBS
+    std::vector<uint8_t> assoc_dropped; // out, L   (:837-853)
+    std::vector<uint8_t> obs_erase;     // out, NOBS (:855-879)
+    int iters = 0;                      // out: actual_iter of the last optimize(40)
+  };
+  void jointOptimization(LocalWindow& w) {
+    const int L = (int)w.assoc.size(), NOBS = (int)w.obs_pose.size(), NP = w.P + w.F;
+    w.assoc_dropped.assign(L, 0);
+    w.obs_erase.assign(NOBS, 0);
+    w.iters = 0;
+    if (!L || !NOBS || !w.P) return;
+    DevBuf dposes(ctx_, (size_t)NP * 56), dprior(ctx_, (size_t)w.P + 8), dpts(ctx_, (size_t)L * 24), dassoc(ctx_, (size_t)L * 4),
+        dptr(ctx_, (size_t)(L + 1) * 4), dop(ctx_, (size_t)NOBS * 4), duvr(ctx_, (size_t)NOBS * 24), doct(ctx_, (size_t)NOBS * 4),
+        ddrop(ctx_, (size_t)L + 8), derase(ctx_, (size_t)NOBS + 8), dit(ctx_, 8);
+    std::vector<uint8_t> pr(w.P + 8, 0);
+    std::memcpy(pr.data(), w.prior.data(), w.P);
+    dposes.upload(w.poses.data());
+    dprior.upload(pr.data());
+    dpts.upload(w.points.data());
+    dassoc.upload(w.assoc.data());
+    dptr.upload(w.obs_ptr.data());
+    dop.upload(w.obs_pose.data());
+    duvr.upload(w.obs_uvr.data());
+    doct.upload(w.obs_oct.data());
+    check(gl_joint_optimization(ctx_, gmm_, &cam_, &prm_, 1, w.P, w.F, L, NOBS, dposes.as<double>(), dprior.as<uint8_t>(),
+                                dpts.as<double>(), dassoc.as<int32_t>(), dptr.as<int32_t>(), dop.as<int32_t>(),
+                                duvr.as<double>(), doct.as<int32_t>(), ddrop.as<uint8_t>(), derase.as<uint8_t>(),
+                                dit.as<int32_t>()),
+          "gl_joint_optimization");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    dposes.download(w.poses.data());
+    dpts.download(w.points.data());
+    std::vector<uint8_t> t1(L + 8), t2(NOBS + 8);
+    ddrop.download(t1.data());
+    derase.download(t2.data());
+    std::memcpy(w.assoc_dropped.data(), t1.data(), L);
+    std::memcpy(w.obs_erase.data(), t2.data(), NOBS);
+    int32_t it[2];
+    dit.download(it);
+    w.iters = it[0];
   }
 
   gl_ctx_t* ctx() { return ctx_; }

@@ -1,0 +1,97 @@
+// Drives include/gmmloc_hip/gmm_adapter.hpp (the C++ host mirror a gmmloc maintainer links) on one frame dumped
+// by tests/test_gpu_adapter.py and writes the results back for comparison with the Python host.
+//   adapter_check <map.gmm> <frame.bin> <out.bin>
+// frame.bin: int32 M, N, width, height; double fx fy cx cy bf; pose[7]; Xw[M*3]; obs[M*3]; int32 octave[M]; double uv[N*2]
+// out.bin:   track: double pose[7], Xw[M*3], int32 assoc[M];  pose-only: double pose[7], int32 ninlier, uint8 outl[M];
+//            associate: int32 idx[M], double d2[M];  search: int32 n[N], cand[N*5] (-1 padded);  int32 queryPoint
+#include <cstdio>
+#include <vector>
+
+#include "gmmloc_hip/gmm_adapter.hpp"
+
+template <class T>
+static void rd(FILE* f, T* p, size_t n) {
+  if (n && fread(p, sizeof(T), n, f) != n) throw std::runtime_error("short read");
+}
+template <class T>
+static void wr(FILE* f, const T* p, size_t n) {
+  if (n && fwrite(p, sizeof(T), n, f) != n) throw std::runtime_error("short write");
+}
+
+int main(int argc, char** argv) {
+  if (argc != 4) return 2;
+  try {
+    gmmloc_hip::GMM gmm;
+    if (!gmmloc_hip::GMM::loadGMMModel(argv[1], gmm)) {
+      fprintf(stderr, "loadGMMModel: %s\n", gmmloc_hip::GMM::last_error());
+      return 1;
+    }
+    FILE* f = fopen(argv[2], "rb");
+    if (!f) return 1;
+    int32_t MN[4];
+    double intr[5];
+    rd(f, MN, 4);
+    rd(f, intr, 5);
+    const int M = MN[0], N = MN[1];
+    gl_camera cam{intr[0], intr[1], intr[2], intr[3], intr[4], MN[2], MN[3]};
+    gmm.setCamera(cam);
+    gmmloc_hip::Pose pose0;
+    std::vector<double> Xw(M * 3), obs(M * 3), uv(N * 2);
+    std::vector<int32_t> oct(M);
+    rd(f, reinterpret_cast<double*>(&pose0), 7);
+    rd(f, Xw.data(), Xw.size());
+    rd(f, obs.data(), obs.size());
+    rd(f, oct.data(), oct.size());
+    rd(f, uv.data(), uv.size());
+    fclose(f);
+    FILE* o = fopen(argv[3], "wb");
+    if (!o) return 1;
+    {  // north-star path
+      gmmloc_hip::Pose p = pose0;
+      std::vector<double> X = Xw;
+      std::vector<int32_t> assoc;
+      gmm.trackFrame(p, X, obs, oct, assoc);
+      wr(o, reinterpret_cast<double*>(&p), 7);
+      wr(o, X.data(), X.size());
+      wr(o, assoc.data(), assoc.size());
+    }
+    {
+      gmmloc_hip::Pose p = pose0;
+      std::vector<uint8_t> outl;
+      const int32_t nin = gmm.optimizeCurrentPose(p, Xw, obs, oct, outl);
+      wr(o, reinterpret_cast<double*>(&p), 7);
+      wr(o, &nin, 1);
+      wr(o, outl.data(), outl.size());
+    }
+    {
+      std::vector<int32_t> idx;
+      std::vector<double> d2;
+      gmm.associate(Xw, idx, d2);
+      wr(o, idx.data(), idx.size());
+      wr(o, d2.data(), d2.size());
+    }
+    {
+      std::vector<std::vector<int32_t>> comps;
+      gmm.renderViewAndSearch(pose0, uv, comps, 5);
+      std::vector<int32_t> n(N), cand((size_t)N * 5, -1);
+      for (int i = 0; i < N; ++i) {
+        n[i] = (int32_t)comps[i].size();
+        for (size_t j = 0; j < comps[i].size(); ++j) cand[(size_t)i * 5 + j] = comps[i][j];
+      }
+      wr(o, n.data(), n.size());
+      wr(o, cand.data(), cand.size());
+    }
+    {
+      std::vector<int> res;
+      gmm.queryPoint(Xw.data(), res);
+      const int32_t q = res.empty() ? -1 : res[0];
+      wr(o, &q, 1);
+    }
+    fclose(o);
+    printf("components %zu\n", gmm.countComponents());
+  } catch (const std::exception& e) {
+    fprintf(stderr, "adapter_check: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -100,3 +100,29 @@ def test_reader_on_the_shipped_maps(lib, name):
     d = np.load(os.path.join(GOLDEN, "map_%s.npz" % name))
     assert np.array_equal(m, d["mean"]) and np.array_equal(c, d["cov"])
     assert m.shape[0] == {"v1": 3299, "v2": 5096}[name]
+
+
+def build_adapter_check(out_dir):
+    """g++-build tests/cpp/adapter_check.cpp against include/gmmloc_hip/gmm_adapter.hpp and the in-tree library."""
+    import subprocess
+    from gmmloc_amd import _lib
+    exe = os.path.join(str(out_dir), "adapter_check")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "adapter_check.cpp"), "-L" + libdir, "-lgmmloc_hip",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_adapter_compiles_and_reports_errors(lib, tmp_path):
+    """The C++ host mirror is plain C++17 over the C-ABI: it builds with g++ (no HIP headers), and without a model
+    file loadGMMModel returns false like the reference's loader instead of throwing or crashing."""
+    import subprocess
+    exe = build_adapter_check(tmp_path)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe, str(tmp_path / "missing.gmm"), str(tmp_path / "f.bin"), str(tmp_path / "o.bin")],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 1 and "loadGMMModel" in r.stderr
