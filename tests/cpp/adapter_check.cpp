@@ -4,6 +4,9 @@
 // frame.bin: int32 M, N, width, height; double fx fy cx cy bf; pose[7]; Xw[M*3]; obs[M*3]; int32 octave[M]; double uv[N*2]
 // out.bin:   track: double pose[7], Xw[M*3], int32 assoc[M];  pose-only: double pose[7], int32 ninlier, uint8 outl[M];
 //            associate: int32 idx[M], double d2[M];  search: int32 n[N], cand[N*5] (-1 padded);  int32 queryPoint
+// then (optional) a local window: int32 P, F, L, NOBS; double poses[(P+F)*7]; uint8 prior[P]; double points[L*3];
+//   int32 assoc[L], obs_ptr[L+1], obs_pose[NOBS]; double obs_uvr[NOBS*3]; int32 obs_oct[NOBS]
+//   -> out: double poses[(P+F)*7], points[L*3]; uint8 dropped[L], erase[NOBS]; int32 iters
 #include <cstdio>
 #include <vector>
 
@@ -43,6 +46,30 @@ int main(int argc, char** argv) {
     rd(f, obs.data(), obs.size());
     rd(f, oct.data(), oct.size());
     rd(f, uv.data(), uv.size());
+    gmmloc_hip::GMM::LocalWindow w;
+    int32_t hdr[4] = {0, 0, 0, 0};
+    const bool has_window = fread(hdr, sizeof(int32_t), 4, f) == 4;
+    if (has_window) {
+      w.P = hdr[0];
+      w.F = hdr[1];
+      const int L = hdr[2], NOBS = hdr[3];
+      w.poses.resize(w.P + w.F);
+      w.prior.resize(w.P);
+      w.points.resize((size_t)L * 3);
+      w.assoc.resize(L);
+      w.obs_ptr.resize(L + 1);
+      w.obs_pose.resize(NOBS);
+      w.obs_uvr.resize((size_t)NOBS * 3);
+      w.obs_oct.resize(NOBS);
+      rd(f, reinterpret_cast<double*>(w.poses.data()), (size_t)(w.P + w.F) * 7);
+      rd(f, w.prior.data(), w.prior.size());
+      rd(f, w.points.data(), w.points.size());
+      rd(f, w.assoc.data(), w.assoc.size());
+      rd(f, w.obs_ptr.data(), w.obs_ptr.size());
+      rd(f, w.obs_pose.data(), w.obs_pose.size());
+      rd(f, w.obs_uvr.data(), w.obs_uvr.size());
+      rd(f, w.obs_oct.data(), w.obs_oct.size());
+    }
     fclose(f);
     FILE* o = fopen(argv[3], "wb");
     if (!o) return 1;
@@ -86,6 +113,15 @@ int main(int argc, char** argv) {
       gmm.queryPoint(Xw.data(), res);
       const int32_t q = res.empty() ? -1 : res[0];
       wr(o, &q, 1);
+    }
+    if (has_window) {  // Localization::jointOptimization on one local window
+      gmm.jointOptimization(w);
+      wr(o, reinterpret_cast<double*>(w.poses.data()), w.poses.size() * 7);
+      wr(o, w.points.data(), w.points.size());
+      wr(o, w.assoc_dropped.data(), w.assoc_dropped.size());
+      wr(o, w.obs_erase.data(), w.obs_erase.size());
+      const int32_t it = w.iters;
+      wr(o, &it, 1);
     }
     fclose(o);
     printf("components %zu\n", gmm.countComponents());

@@ -11,6 +11,7 @@ import pytest
 import gmmloc_amd
 from gmmloc_amd import api
 from tests.test_gpu_pose import make_frames
+from tests.test_gpu_ba import make_ba_problem, run_gpu
 from tests.test_host_cabi import build_adapter_check
 
 pytestmark = pytest.mark.gpu
@@ -35,6 +36,16 @@ def test_cpp_adapter_matches_python_host(gpu, map_v1, gt_sync, tmp_path):
             np.ascontiguousarray(a, np.float64).tofile(fh)
         np.ascontiguousarray(f["octave"], np.int32).tofile(fh)
         uv.tofile(fh)
+        # one local window for jointOptimization: 3 free + 2 fixed key-frames, 150 points
+        pb = make_ba_problem(mean, cov, gt_sync["V1_01_easy"], cam, 3, 2, 150, 31)
+        idx0, d20 = g.associate3d(torch.from_numpy(pb["points"]).cuda(), api.ASSOC_BRUTE)
+        pb_assoc = np.where(d20.cpu().numpy() <= 9.0, idx0.cpu().numpy(), -1).astype(np.int32)
+        np.array([3, 2, 150, len(pb["obs_pose"])], np.int32).tofile(fh)
+        for key, dt in (("poses", np.float64), ("prior", np.uint8), ("points", np.float64)):
+            np.ascontiguousarray(pb[key], dt).tofile(fh)
+        pb_assoc.tofile(fh)
+        for key, dt in (("obs_ptr", np.int32), ("obs_pose", np.int32), ("obs_uvr", np.float64), ("obs_oct", np.int32)):
+            np.ascontiguousarray(pb[key], dt).tofile(fh)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.dirname(gmmloc_amd._lib.LIB_PATH) + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([exe, str(tmp_path / "m.gmm"), str(tmp_path / "frame.bin"), str(tmp_path / "out.bin")], env=env,
@@ -69,4 +80,12 @@ def test_cpp_adapter_matches_python_host(gpu, map_v1, gt_sync, tmp_path):
     # queryPoint
     q = g.queryPoint(T(f["Xw"][:1]))
     assert rd(np.int32, 1)[0] == int(q.cpu().numpy().ravel()[0])
+    # jointOptimization
+    poses, points, dropped, erase, iters = run_gpu(gpu, g, cam, prm, [pb], [pb_assoc])
+    nobs = len(pb["obs_pose"])
+    assert np.array_equal(rd(np.float64, 5 * 7).reshape(5, 7), poses[0])
+    assert np.array_equal(rd(np.float64, 150 * 3).reshape(150, 3), points[0])
+    assert np.array_equal(rd(np.uint8, 150), dropped[0])
+    assert np.array_equal(rd(np.uint8, nobs), erase[0][:nobs])
+    assert rd(np.int32, 1)[0] == int(iters[0])
     assert out.read() == b""
