@@ -1,19 +1,21 @@
-// Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217) as one persistent
-// workgroup per frame: 6-DoF Levenberg-Marquardt over pose-only reprojection
-// edges (g2o EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose, Huber),
-// 4 gating rounds x optimize(10), entirely on-chip:
-//   * every thread owns the edges e = tid, tid+T, ...; one pass computes the
-//     residual, chi2, Huber weight, the 2|3 x 6 Jacobian and accumulates the 21
-//     unique entries of J^T W J, the 6 of b and the robust chi2 in registers;
-//   * one deterministic wave reduce-scatter + LDS step (gld::block_reduce) gives
-//     all 28 sums to every thread, which then solve the 6x6 (LDL^T) and apply
-//     exp(delta) redundantly -- no single-lane section, no global round trip;
-//   * the evaluation at the trial pose also builds the next system, so an
-//     accepted LM step costs ONE pass over the edges.
-// g2o control flow restated: OptimizationAlgorithmLevenberg::solve (lambda init
-// 1e-5 max diag, rho test with +1e-3, x1/3..2/3 / x nu schedule, 10 trials),
-// SparseOptimizer::optimize, levels via initializeOptimization(0), stale per-edge
-// errors read by e->chi2() after the last trial.
+// Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217): 6-DoF Levenberg-Marquardt over pose-only
+// reprojection edges (g2o EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose, Huber), 4 gating rounds
+// x optimize(10), one persistent group of NW waves per frame, entirely on-chip:
+//   * thread t of the group owns the edges t, t + 64 NW, ...; one pass computes the residual, chi2, Huber
+//     weight, the 2|3 x 6 Jacobian and accumulates the 21 unique entries of J^T W J, the 6 of b and the
+//     robust chi2 in registers;
+//   * a wave reduce-scatter (permlane swaps + DPP) + one LDS step give the 28 sums; the current and the trial
+//     system live in LDS (224 B each), not in registers;
+//   * every wave solves the 6x6 (LDL^T on the packed triangle, reciprocal pivots) and applies exp(delta) on
+//     its own - pose as (R, t) in SGPRs, Rodrigues with a short series below |theta| = 0.01 - so nothing is
+//     broadcast;
+//   * the evaluation at the trial pose also builds the next system: an accepted LM step costs ONE pass.
+// NW = 1 (no barrier at all, GL_POSE_WPS frames per SIMD) is the shape for large batches, NW = 4 / 8 the one
+// for the frame-at-a-time caller: 0.34 ms instead of 0.90 ms for one frame of 1 000 edges.
+// g2o control flow restated: OptimizationAlgorithmLevenberg::solve (lambda init 1e-5 max diag, rho test with
+// +1e-3, x1/3..2/3 / x nu schedule, 10 trials), SparseOptimizer::optimize, levels via
+// initializeOptimization(0), stale per-edge errors read by e->chi2() after the last trial (SURVEY.md
+// Appendix A).
 #include <cstdlib>
 
 #include "gl_device.hpp"
@@ -31,73 +33,6 @@ struct PoseKParams {
   double delta_mono, delta_stereo;
 };
 
-constexpr int T_POSE = 256;
-constexpr int NW_POSE = T_POSE / 64;
-
-// one pass over the frame's active edges at pose (R, t)
-//  acc[0..20] H upper triangle (row-major), acc[21..26] b, acc[27] robust chi2
-GL_DEV void pose_eval(const PoseKParams& kp, const double* R, const double* t, bool robust, int M,
-                      const double* __restrict__ Xw, const double* __restrict__ obs,
-                      const int32_t* __restrict__ octave, const uint8_t* __restrict__ level,
-                      double* __restrict__ chi2_e, double* acc) {
-#pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  for (int e = threadIdx.x; e < M; e += T_POSE) {
-    const int oc = octave[e];
-    if (oc < 0 || level[e] != 0) continue;
-    const double X = Xw[(size_t)e * 3 + 0], Y = Xw[(size_t)e * 3 + 1], Z = Xw[(size_t)e * 3 + 2];
-    const double ou = obs[(size_t)e * 3 + 0], ov = obs[(size_t)e * 3 + 1], our = obs[(size_t)e * 3 + 2];
-    const bool stereo = !(our < 0);
-    const double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
-    const double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
-    const double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
-    const double invz = 1.0 / z, invz2 = invz * invz;
-    const double pu = x * invz * kp.fx + kp.cx;
-    const double pv = y * invz * kp.fy + kp.cy;
-    const double e0 = ou - pu, e1 = ov - pv;
-    const double e2 = stereo ? (our - (pu - kp.bf * invz)) : 0.0;
-    const double s = kp.s2inv[oc];
-    const double chi2 = e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2);
-    chi2_e[e] = chi2;
-    double rho0 = chi2, rho1 = 1.0;
-    if (robust) huber(chi2, stereo ? kp.delta_stereo : kp.delta_mono, rho0, rho1);
-    const double w = rho1 * s;
-    // Jacobian rows (g2o types_six_dof_expmap.cpp, EdgeSE3ProjectXYZOnlyPose::linearizeOplus)
-    double J0[6], J1[6], J2[6];
-    J0[0] = x * y * invz2 * kp.fx;
-    J0[1] = -(1 + (x * x * invz2)) * kp.fx;
-    J0[2] = y * invz * kp.fx;
-    J0[3] = -invz * kp.fx;
-    J0[4] = 0;
-    J0[5] = x * invz2 * kp.fx;
-    J1[0] = (1 + y * y * invz2) * kp.fy;
-    J1[1] = -x * y * invz2 * kp.fy;
-    J1[2] = -x * invz * kp.fy;
-    J1[3] = 0;
-    J1[4] = -invz * kp.fy;
-    J1[5] = y * invz2 * kp.fy;
-    const double sb = stereo ? 1.0 : 0.0;
-    J2[0] = sb * (J0[0] - kp.bf * y * invz2);
-    J2[1] = sb * (J0[1] + kp.bf * x * invz2);
-    J2[2] = sb * J0[2];
-    J2[3] = sb * J0[3];
-    J2[4] = 0;
-    J2[5] = sb * (J0[5] - kp.bf * invz2);
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) {
-        acc[q] += w * (J0[i] * J0[j] + J1[i] * J1[j] + J2[i] * J2[j]);
-        ++q;
-      }
-    // b += J^T * (-rho1 * Omega * err)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[21 + i] -= w * (J0[i] * e0 + J1[i] * e1 + J2[i] * e2);
-    acc[27] += rho0;
-  }
-}
-
 // un-robustified chi2 of one edge at pose (R,t) (e->computeError(); e->chi2())
 GL_DEV double pose_edge_chi2(const PoseKParams& kp, const double* R, const double* t, const double* Xw,
                              const double* obs, int oc) {
@@ -113,197 +48,6 @@ GL_DEV double pose_edge_chi2(const PoseKParams& kp, const double* R, const doubl
   return e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2);
 }
 
-GL_DEV void unpack_sym6(const double* acc, double* H) {
-  int q = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = i; j < 6; ++j) {
-      H[i * 6 + j] = acc[q];
-      H[j * 6 + i] = acc[q];
-      ++q;
-    }
-}
-
-__global__ __launch_bounds__(T_POSE) void k_optimize_current_pose_block(PoseKParams kp, int B, int M,
-                                                                  double* __restrict__ pose_io,
-                                                                  const double* __restrict__ Xw_all,
-                                                                  const double* __restrict__ obs_all,
-                                                                  const int32_t* __restrict__ oct_all,
-                                                                  uint8_t* __restrict__ outlier_all,
-                                                                  int32_t* __restrict__ ninlier,
-                                                                  double* __restrict__ chi2_all) {
-  __shared__ double red[NW_POSE * 32];
-  const int f = blockIdx.x;
-  if (f >= B) return;
-  const double* Xw = Xw_all + (size_t)f * M * 3;
-  const double* obs = obs_all + (size_t)f * M * 3;
-  const int32_t* octave = oct_all + (size_t)f * M;
-  uint8_t* level = outlier_all + (size_t)f * M;  // is_outlier_ <=> level 1
-  double* chi2_e = chi2_all + (size_t)f * M;
-
-  const SE3 T0 = se3_load(pose_io + (size_t)f * 7);
-  double acc[32];
-
-  // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
-  {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    for (int e = threadIdx.x; e < M; e += T_POSE) {
-      level[e] = 0;
-      if (octave[e] >= 0) acc[0] += 1.0;
-    }
-    block_reduce<1, NW_POSE>(acc, red);
-  }
-  const int n_init = (int)acc[0];
-  if (n_init < 3) {  // :139-140
-    if (threadIdx.x == 0) ninlier[f] = 0;
-    return;
-  }
-
-  SE3 T = T0;
-  bool robust = true;
-  int nbad = 0;
-  for (int round = 0; round < 4; ++round) {
-    T = T0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
-    // initializeOptimization(0): active = level-0 edges
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    for (int e = threadIdx.x; e < M; e += T_POSE)
-      if (octave[e] >= 0 && level[e] == 0) acc[0] += 1.0;
-    block_reduce<1, NW_POSE>(acc, red);
-    const int nactive = (int)acc[0];
-
-    if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
-      double R[9], H[36], b[6];
-      qtoR(T.r, R);
-      pose_eval(kp, R, T.t, robust, M, Xw, obs, octave, level, chi2_e, acc);
-      block_reduce<28, NW_POSE>(acc, red);
-      unpack_sym6(acc, H);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) b[i] = acc[21 + i];
-      double currentChi = acc[27];
-      bool sys_valid = true;
-      double lambda = 0.0, ni = 2.0;
-      for (int it = 0; it < 10; ++it) {
-        if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
-          qtoR(T.r, R);
-          pose_eval(kp, R, T.t, robust, M, Xw, obs, octave, level, chi2_e, acc);
-          block_reduce<28, NW_POSE>(acc, red);
-          unpack_sym6(acc, H);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) b[i] = acc[21 + i];
-          currentChi = acc[27];
-          sys_valid = true;
-        }
-        if (it == 0) {  // computeLambdaInit: tau * max |diag|
-          double md = 0.0;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) md = fmax(fabs(H[i * 6 + i]), md);
-          lambda = 1e-5 * md;
-          ni = 2.0;
-        }
-        double rho = 0.0;
-        int qmax = 0;
-        do {
-          double Hl[36], dx[6];
-#pragma unroll
-          for (int i = 0; i < 36; ++i) Hl[i] = H[i];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) Hl[i * 6 + i] += lambda;
-          const bool ok2 = ldlt_solve<6>(Hl, b, dx, true);
-          SE3 Tn = T;
-          double tempChi;
-          double Hn[36], bn[6];
-          if (ok2) {
-            Tn = se3_mul(se3_exp(dx), T);
-            double Rn[9];
-            qtoR(Tn.r, Rn);
-            pose_eval(kp, Rn, Tn.t, robust, M, Xw, obs, octave, level, chi2_e, acc);
-            block_reduce<28, NW_POSE>(acc, red);
-            unpack_sym6(acc, Hn);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) bn[i] = acc[21 + i];
-            tempChi = acc[27];
-          } else {
-            tempChi = 1.7976931348623157e308;
-          }
-          double scale = 0.0;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) scale += dx[j] * (lambda * dx[j] + b[j]);
-          scale += 1e-3;
-          rho = (currentChi - tempChi) / scale;
-          if (rho > 0 && isfinite(tempChi)) {
-            const double u = 2 * rho - 1;
-            double alpha = 1. - u * u * u;
-            alpha = fmin(alpha, 2. / 3.);
-            const double sf = fmax(1. / 3., alpha);
-            lambda *= sf;
-            ni = 2;
-            currentChi = tempChi;
-            T = Tn;
-#pragma unroll
-            for (int i = 0; i < 36; ++i) H[i] = Hn[i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b[i] = bn[i];
-          } else {
-            lambda *= ni;
-            ni *= 2;
-            // estimate restored (pop); H, b stay; per-edge errors stay those of the
-            // rejected trial until the next computeActiveErrors
-            if (!(rho < 0)) sys_valid = false;
-          }
-          qmax++;
-        } while (rho < 0 && qmax < 10);
-        if (qmax == 10 || rho == 0) break;  // Terminate
-      }
-    }
-
-    // gating (:156-203): outliers are re-evaluated at the current estimate, inliers
-    // use the error of the last computeActiveErrors; chi2 compared as float.
-    double Rg[9];
-    qtoR(T.r, Rg);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    for (int e = threadIdx.x; e < M; e += T_POSE) {
-      const int oc = octave[e];
-      if (oc < 0) continue;
-      double c2;
-      if (level[e] != 0)
-        c2 = pose_edge_chi2(kp, Rg, T.t, Xw + (size_t)e * 3, obs + (size_t)e * 3, oc);
-      else
-        c2 = chi2_e[e];
-      const bool stereo = !(obs[(size_t)e * 3 + 2] < 0);
-      const float thr = stereo ? 7.815f : 5.991f;
-      const bool bad = (float)c2 > thr;
-      level[e] = bad ? 1 : 0;
-      if (bad) acc[0] += 1.0;
-    }
-    block_reduce<1, NW_POSE>(acc, red);
-    nbad = (int)acc[0];
-    if (round == 2) robust = false;  // e->setRobustKernel(0) at it == 2
-    if (n_init < 10) break;          // optimizer.edges().size() < 10
-  }
-  if (threadIdx.x == 0) {
-    se3_store(T, pose_io + (size_t)f * 7);
-    ninlier[f] = n_init - nbad;
-  }
-}
-
-
-// =============================================================================================
-// One WAVE per frame (the default path).  The workgroup version above spends its time in the
-// serial 6x6 solve + exp() that every LM trial needs (all 256 threads repeat it, 1 frame per CU at
-// 256 VGPRs); a frame's edges (<= 1200) are little work per pass, so the frame fits one wave:
-//   * lane l owns the edges l, l+64, ...; no workgroup barrier and no LDS anywhere;
-//   * the 28 sums are reduced with the wave reduce-scatter into 28 LDS words; the current and the
-//     trial system live there (224 B each), not in registers;
-//   * 6x6 LDL^T on the packed triangle with reciprocal pivots, pose kept as (R, t) in SGPRs and
-//     updated by Rodrigues (short series below |theta| = 0.01);
-//   * <= 128 VGPRs: 4 waves per SIMD = 16 frames per CU in flight, so the serial sections of
-//     different frames overlap.
-// Same control flow as above (g2o Levenberg restated, 4 gating rounds x optimize(10)).
-// =============================================================================================
 GL_DEV double rcp_nr(double a) {
   double x = __builtin_amdgcn_rcp(a);
   x = fma(fma(-a, x, 1.0), x, x);
@@ -320,21 +64,43 @@ GL_DEV double uni(double v) {  // wave-uniform value -> SGPR pair
   u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.d;
 }
-// the 28 wave totals of acc[] -> dst[0..27] in LDS (one wave per workgroup: the barrier is a no-op
-// that orders the LDS write before the broadcast reads)
-GL_DEV void wave_totals28(double* acc, double* dst) {
+// the 28 totals of acc[] over the NW waves of the workgroup -> dst[0..27] in LDS.  Per wave a reduce-scatter
+// (permlane swaps + DPP) leaves total s on lane wave_slot^-1(s); the owners park them in part[wave][], and lane
+// s of every wave adds the NW partials in wave order (the same bits in every wave) - with one wave the barriers
+// are no-ops that order the LDS write before the broadcast reads.
+template <int NW>
+GL_DEV void block_totals28(double* acc, double* part, double* dst) {
 #pragma unroll
   for (int i = 28; i < 32; ++i) acc[i] = 0.0;
   const double r = wave_reduce_scatter32(acc);
-  const int lane = threadIdx.x & 63;
-  __syncthreads();
-  if (wave_slot_owner(lane)) dst[wave_slot(lane)] = r;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // dst / part may still be read by slower waves
+  if (NW == 1) {
+    if (wave_slot_owner(lane)) dst[wave_slot(lane)] = r;
+  } else {
+    if (wave_slot_owner(lane)) part[wave * 32 + wave_slot(lane)] = r;
+    __syncthreads();
+    if (wave == 0 && lane < 28) {
+      double s = part[lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) s += part[w * 32 + lane];
+      dst[lane] = s;
+    }
+  }
   __syncthreads();
 }
-GL_DEV double wave_total1(double v) {
+template <int NW>
+GL_DEV double block_total1(double v, double* part) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v += shfl_xor_f64(v, o);
-  return uni(v);
+  if (NW == 1) return uni(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = part[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) s += part[w];
+  return uni(s);
 }
 
 struct PoseRt {
@@ -427,13 +193,14 @@ GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, do
 }
 
 // one pass over the lane's edges at pose P: acc[0..20] H upper triangle, acc[21..26] b, acc[27] robust chi2
+template <int NW>
 GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int M,
                            const double* __restrict__ Xw, const double* __restrict__ obs,
                            const int32_t* __restrict__ octave, const uint8_t* __restrict__ level,
                            double* __restrict__ chi2_e, double* acc) {
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  for (int e = threadIdx.x & 63; e < M; e += 64) {
+  for (int e = threadIdx.x; e < M; e += 64 * NW) {
     const int oc = octave[e];
     if (oc < 0 || level[e] != 0) continue;
     const double X = Xw[(size_t)e * 3 + 0], Y = Xw[(size_t)e * 3 + 1], Z = Xw[(size_t)e * 3 + 2];
@@ -491,7 +258,11 @@ GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2t
 #ifndef GL_POSE_WPS
 #define GL_POSE_WPS 3  // waves per SIMD the register budget is capped for (measured: 3 > 2 > 4, tools/pose_ab.py)
 #endif
-__global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseKParams kp, int B, int M,
+// NW waves per frame: 1 for batches (GL_POSE_WPS frames per SIMD), 4 / 8 when the frames are fewer than the
+// SIMDs - the edges are dealt round the NW x 64 threads, the 28 sums meet in LDS, and every wave repeats the
+// serial part (solve, pose update) on its own so that no broadcast is needed.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M,
                                                                  double* __restrict__ pose_io,
                                                                  const double* __restrict__ Xw_all,
                                                                  const double* __restrict__ obs_all,
@@ -501,7 +272,8 @@ __global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseK
                                                                  double* __restrict__ chi2_all) {
   __shared__ double s2tab[8];
   __shared__ double H[32], Hn[32];  // current / trial system {H upper (21), b (6), chi2}
-  const int f = blockIdx.x, lane = threadIdx.x;
+  __shared__ double part[NW * 32];  // per-wave partial sums
+  const int f = blockIdx.x, lane = threadIdx.x;  // "lane" = thread of the frame's NW waves
   if (f >= B) return;
   if (lane == 0) {
 #pragma unroll
@@ -516,11 +288,11 @@ __global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseK
 
   // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
   double cnt = 0.0;
-  for (int e = lane; e < M; e += 64) {
+  for (int e = lane; e < M; e += 64 * NW) {
     level[e] = 0;
     if (octave[e] >= 0) cnt += 1.0;
   }
-  const int n_init = (int)wave_total1(cnt);
+  const int n_init = (int)block_total1<NW>(cnt, part);
   if (n_init < 3) {  // :139-140
     if (lane == 0) ninlier[f] = 0;
     return;
@@ -542,20 +314,20 @@ __global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseK
   for (int round = 0; round < 4; ++round) {
     P = P0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
     cnt = 0.0;
-    for (int e = lane; e < M; e += 64)
+    for (int e = lane; e < M; e += 64 * NW)
       if (octave[e] >= 0 && level[e] == 0) cnt += 1.0;
-    const int nactive = (int)wave_total1(cnt);
+    const int nactive = (int)block_total1<NW>(cnt, part);
     if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
-      wave_pose_eval(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
-      wave_totals28(acc, H);
+      wave_pose_eval<NW>(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
+      block_totals28<NW>(acc, part, H);
       double currentChi = uni(H[27]);
       bool sys_valid = true;
       double lambda = 0.0, ni = 2.0;
 #pragma unroll 1
       for (int it = 0; it < 10; ++it) {
         if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
-          wave_pose_eval(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
-          wave_totals28(acc, H);
+          wave_pose_eval<NW>(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
+          block_totals28<NW>(acc, part, H);
           currentChi = uni(H[27]);
           sys_valid = true;
         }
@@ -575,8 +347,8 @@ __global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseK
           double tempChi;
           if (ok2) {
             Pn = rt_update(P, dx);
-            wave_pose_eval(kp, s2tab, Pn, robust, M, Xw, obs, octave, level, chi2_e, acc);
-            wave_totals28(acc, Hn);
+            wave_pose_eval<NW>(kp, s2tab, Pn, robust, M, Xw, obs, octave, level, chi2_e, acc);
+            block_totals28<NW>(acc, part, Hn);
             tempChi = uni(Hn[27]);
           } else {
             tempChi = 1.7976931348623157e308;
@@ -612,7 +384,7 @@ __global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseK
     // gating (:156-203): outliers are re-evaluated at the current estimate, inliers use the error of
     // the last computeActiveErrors; chi2 compared as float.
     cnt = 0.0;
-    for (int e = lane; e < M; e += 64) {
+    for (int e = lane; e < M; e += 64 * NW) {
       const int oc = octave[e];
       if (oc < 0) continue;
       double c2;
@@ -626,7 +398,7 @@ __global__ __launch_bounds__(64, GL_POSE_WPS) void k_optimize_current_pose(PoseK
       level[e] = bad ? 1 : 0;
       if (bad) cnt += 1.0;
     }
-    nbad = (int)wave_total1(cnt);
+    nbad = (int)block_total1<NW>(cnt, part);
     if (round == 2) robust = false;  // e->setRobustKernel(0) at it == 2
     if (n_init < 10) break;          // optimizer.edges().size() < 10
   }
@@ -667,16 +439,22 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   if (rc != GL_OK) return rc;
   {
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
-    // one wave per frame is the throughput shape (12 frames per CU); with fewer frames than CUs a frame gets a
-    // whole workgroup instead (GMMLOC_POSE_BLOCK=0 / 1 forces the wave / workgroup kernel)
-    bool block_version = B <= 512;
-    if (const char* e = getenv("GMMLOC_POSE_BLOCK")) block_version = atoi(e) != 0;
-    if (block_version)
-      k_optimize_current_pose_block<<<B, T_POSE, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev,
-                                                                 outlier_dev, ninlier_dev, (double*)scratch);
+    // waves per frame: 4 is never slower than 1 up to ~2 000 frames (0.34 vs 0.90 ms for one frame of 1 000
+    // edges, 1.26 vs 1.80 ms for 1 024), 8 is the best between 32 and 256 frames; one wave per frame is the shape
+    // for large batches (12 frames per CU, no barriers).  Never more waves than the frame has 64-edge slices.
+    // GMMLOC_POSE_WAVES=1|4|8 forces a shape.
+    int nw = B > 1536 ? 1 : (B > 32 && B <= 256) ? 8 : 4;
+    while (nw > 1 && nw * 64 > M + 63) nw = nw == 8 ? 4 : 1;
+    if (const char* e = getenv("GMMLOC_POSE_WAVES")) nw = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : 1;
+    if (nw == 8)
+      k_optimize_current_pose<8><<<B, 512, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                          ninlier_dev, (double*)scratch);
+    else if (nw == 4)
+      k_optimize_current_pose<4><<<B, 256, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                          ninlier_dev, (double*)scratch);
     else
-      k_optimize_current_pose<<<B, 64, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                       ninlier_dev, (double*)scratch);
+      k_optimize_current_pose<1><<<B, 64, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                         ninlier_dev, (double*)scratch);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

@@ -37,10 +37,10 @@ def run_gpu(gpu, cam, prm, frames):
     return pose.cpu().numpy(), outl.cpu().numpy(), nin.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["0", "1"])  # wave per frame (batches) / workgroup per frame (few frames)
+@pytest.mark.parametrize("kernel", ["1", "4", "8"])  # waves per frame: 1 = large batches, 4 / 8 = few frames
 @pytest.mark.parametrize("M,seed", [(300, 100), (1200, 200), (2000, 300), (37, 400)])
 def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, monkeypatch, M, seed, kernel):
-    monkeypatch.setenv("GMMLOC_POSE_BLOCK", kernel)
+    monkeypatch.setenv("GMMLOC_POSE_WAVES", kernel)
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
     frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 6, M, seed)
@@ -57,9 +57,9 @@ def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, monk
             assert gt_dt < 0.05 and gt_dr < 0.02
 
 
-@pytest.mark.parametrize("kernel", ["0", "1"])
+@pytest.mark.parametrize("kernel", ["1", "4", "8"])
 def test_optimize_current_pose_edge_cases(gpu, oracle, map_v1, gt_sync, monkeypatch, kernel):
-    monkeypatch.setenv("GMMLOC_POSE_BLOCK", kernel)
+    monkeypatch.setenv("GMMLOC_POSE_WAVES", kernel)
     """< 3 correspondences -> returns 0 and leaves the pose; < 10 -> single round; features
     without map point (octave < 0) are skipped; noise-free input recovers the pose."""
     mean, cov = map_v1

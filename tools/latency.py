@@ -37,7 +37,7 @@ d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz")); mean1, cov1 = 
 gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_02_medium"]
 g1 = gmmloc_amd.GMM(ctx, mean1, cov1, prm)
 fr = [synth.synth_frame(mean1, cov1, synth.gt_row_to_Tcw(gt[(100 + 17 * i) % gt.shape[0]]), cam, 1000, 50 + i) for i in range(64)]
-fr = fr * 16
+fr = fr * 64
 T1 = lambda k: torch.from_numpy(np.stack([f[k] for f in fr])).to(dev)
 p0, x0, o, oc = T1("pose_init"), T1("Xw"), T1("obs"), T1("octave")
 uv = o[:, :, :2].contiguous()
@@ -54,13 +54,13 @@ def timed(name, fn, reps=30):
 
 
 with torch.cuda.stream(ctx.stream):
-    for B in (1, 4, 64, 256, 1024):
+    for B in (1, 1024, 2048, 4096):
         pb, xb, ob, ocb, uvb = p0[:B].contiguous(), x0[:B].contiguous(), o[:B].contiguous(), oc[:B].contiguous(), uv[:B].contiguous()
-        for env in ("0", "1"):
-            os.environ["GMMLOC_POSE_BLOCK"] = env
-            timed("optimizeCurrentPose B=%d M=1000 %s" % (B, "(workgroup per frame)" if env == "1" else "(wave per frame)"),
+        for env in ("1", "4", "8"):
+            os.environ["GMMLOC_POSE_WAVES"] = env
+            timed("optimizeCurrentPose B=%d M=1000 (%s waves per frame)" % (B, env),
                   lambda: api.optimize_current_pose(ctx, cam, prm, pb.clone(), xb, ob, ocb))
-        os.environ.pop("GMMLOC_POSE_BLOCK", None)
+        os.environ.pop("GMMLOC_POSE_WAVES", None)
         timed("track_frames B=%d M=1000 K=%d" % (B, mean1.shape[0]),
               lambda: gmmloc_amd.track_frames(ctx, g1, cam, prm, pb.clone(), xb.clone(), ob, ocb, want_d2=False))
         timed("search2d B=%d N=1000" % B, lambda: g1.search2d(cam, pb, uvb, None, k=5))
