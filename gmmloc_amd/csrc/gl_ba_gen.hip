@@ -1055,9 +1055,12 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ba_gen, T_BA, lds));
     GL_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     const long cap = (long)occ * ncu;
-    // measured: 32 workgroups are best up to ~15 free poses (more only adds barrier time), 64 beyond
-    // (the P (P + 1) / 2 reduced-camera blocks then fill 256 waves)
-    NB = (int)std::min<long>(P >= 16 ? 64 : 32, cap / B);
+    // measured optimum on single problems (tools/ba_nb.py): one workgroup up to ~2 000
+    // observations (1.1 vs 2.0 ms: no cross-workgroup barrier at all), 4 up to 6 000, 16 up to 16 000, 32 up to
+    // 40 000, 64 above (the P (P + 1) / 2 reduced-camera blocks then fill 256 waves); NOBS (the stride) stands
+    // in for the observation count
+    const int want = NOBS <= 2000 ? 1 : NOBS <= 6000 ? 4 : NOBS <= 16000 ? 16 : NOBS <= 40000 ? 32 : 64;
+    NB = (int)std::min<long>(want, cap / B);
     if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = std::min(NB, atoi(e));  // knob (tests: 1 = single workgroup)
     if (NB < 2) NB = 1;
   }
