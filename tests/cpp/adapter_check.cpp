@@ -7,6 +7,7 @@
 // then (optional) a local window: int32 P, F, L, NOBS; double poses[(P+F)*7]; uint8 prior[P]; double points[L*3];
 //   int32 assoc[L], obs_ptr[L+1], obs_pose[NOBS]; double obs_uvr[NOBS*3]; int32 obs_oct[NOBS]
 //   -> out: double poses[(P+F)*7], points[L*3]; uint8 dropped[L], erase[NOBS]; int32 iters
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -122,6 +123,21 @@ int main(int argc, char** argv) {
       wr(o, w.obs_erase.data(), w.obs_erase.size());
       const int32_t it = w.iters;
       wr(o, &it, 1);
+    }
+    {  // host-buffer call time of the frame-at-a-time path (staging included)
+      gmmloc_hip::Pose p = pose0;
+      std::vector<double> X = Xw;
+      std::vector<int32_t> assoc;
+      gmm.trackFrame(p, X, obs, oct, assoc);
+      const auto t0 = std::chrono::steady_clock::now();
+      const int reps = 20;
+      for (int r = 0; r < reps; ++r) {
+        p = pose0;
+        X = Xw;
+        gmm.trackFrame(p, X, obs, oct, assoc);
+      }
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+      printf("trackFrame host-to-host %.3f ms per call (M = %d)\n", ms, M);
     }
     fclose(o);
     printf("components %zu\n", gmm.countComponents());

@@ -52,6 +52,7 @@ def test_cpp_adapter_matches_python_host(gpu, map_v1, gt_sync, tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "components %d" % mean.shape[0] in r.stdout
+    print(r.stdout)
     out = open(tmp_path / "out.bin", "rb")
     rd = lambda dt, n: np.fromfile(out, dt, n)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
