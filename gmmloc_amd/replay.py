@@ -64,3 +64,38 @@ def replay(frames, compute, rank=0, world=1, dist=None, device="cpu", batch=256)
     if local.shape[0] == 0:
         local = np.zeros((0, D))
     return gather_results(idx, local, len(frames), world, dist, device), float(t[0].item())
+
+
+# ---- K-sharded association (the stress shape: 50 000 points x 65 536 Gaussians) --------------
+# Rank r holds the Gaussians [k_offset, k_offset + K_r) and evaluates the exact chi2 argmin of every point over
+# its shard (gl_associate3d: the per-pair chi2 does not depend on which other Gaussians are present, so the
+# values are bit-identical to the unsharded sweep).  The exchange step is the argmin merge: one all_reduce(MIN)
+# on the N fp64 chi2 values, then one all_reduce(MIN) on the N global indices of the ranks that hold the
+# minimum -- the lowest index wins ties, exactly like the sequential sweep.  (fp64 chi2 + index do not fit the
+# packed 64-bit key of the fp32 variant sketched in SURVEY 8e, hence two collectives of N x 8 bytes.)
+INDEX_NONE = np.iinfo(np.int64).max
+
+
+def shard_components(K, rank, world):
+    """Contiguous K-shard of rank: (k_offset, K_r); the first K % world ranks hold one more."""
+    base, extra = divmod(K, world)
+    k0 = rank * base + min(rank, extra)
+    return k0, base + (1 if rank < extra else 0)
+
+
+def merge_sharded_association(d2_local, idx_local, k_offset, dist=None, world=1):
+    """d2_local (N,) float64 and idx_local (N,) int (index inside the shard, < 0 = none) as torch tensors on the
+    collective's device.  Returns (global idx int64 with -1 = none, d2) on every rank."""
+    import torch
+    d2 = d2_local.clone()
+    valid = idx_local >= 0
+    d2 = torch.where(valid, d2, torch.full_like(d2, float("inf")))
+    mine = d2.clone()
+    if dist is not None and world > 1:
+        dist.all_reduce(d2, op=dist.ReduceOp.MIN)
+    gi = torch.where(valid & (mine == d2), idx_local.to(torch.int64) + int(k_offset),
+                     torch.full_like(idx_local, INDEX_NONE, dtype=torch.int64))
+    if dist is not None and world > 1:
+        dist.all_reduce(gi, op=dist.ReduceOp.MIN)
+    gi = torch.where(gi == INDEX_NONE, torch.full_like(gi, -1), gi)
+    return gi, d2

@@ -211,3 +211,31 @@ def test_cell_index_single_component_and_tiny_maps(gpu):
         pts = np.concatenate([synth.synth_points(mean, cov, 500, K), np.random.default_rng(K).uniform(-9, 9, (500, 3))])
         (i1, d1), (i2, d2) = _both(torch, g, pts)
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+
+
+def test_kshard_association_is_bit_identical(gpu, map_v2):
+    """K-sharding: the chi2 of a (point, Gaussian) pair does not depend on the rest of the map, so
+    associating against the shards and merging (value, then lowest global index) reproduces the unsharded
+    result exactly - through the cell index of each shard as well as through the sweep."""
+    torch, ctx = gpu
+    from gmmloc_amd import replay
+    mean, cov = map_v2
+    rng = np.random.default_rng(21)
+    pts = mean[rng.integers(0, mean.shape[0], 5000)] + rng.normal(0, 0.08, (5000, 3))
+    t = torch.from_numpy(pts).cuda()
+    full = api.GMM(ctx, mean, cov)
+    for mode in (api.ASSOC_BRUTE, api.ASSOC_EXHAUSTIVE):
+        idx_f, d2_f = full.associate3d(t, mode)
+        world = 3
+        parts = []
+        for r in range(world):
+            k0, kr = replay.shard_components(mean.shape[0], r, world)
+            g = api.GMM(ctx, mean[k0:k0 + kr], cov[k0:k0 + kr])
+            idx, d2 = g.associate3d(t, mode)
+            parts.append((idx.to(torch.int64) + k0, d2))
+        d2m = torch.stack([p[1] for p in parts]).min(0).values
+        gi = torch.stack([torch.where(p[1] == d2m, p[0], torch.full_like(p[0], replay.INDEX_NONE)) for p in parts]).min(0).values
+        assert torch.equal(d2m, d2_f) and torch.equal(gi, idx_f.to(torch.int64))
+        # the library-side merge on one rank is the identity
+        gi1, d21 = replay.merge_sharded_association(d2_f, idx_f, 0)
+        assert torch.equal(gi1, idx_f.to(torch.int64)) and torch.equal(d21, d2_f)

@@ -60,6 +60,63 @@ def test_replay_world2_gloo(n_frames):
     assert out[0][2] == out[1][2]                                     # MAX over ranks agreed
 
 
+def _kshard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gmmloc_amd import replay
+    from tests import oracle_lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz"))
+    mean, cov = d["mean"][:601], d["cov"][:601]
+    mean = np.concatenate([mean, mean[:7]])  # duplicated components across the shard boundary: ties by index
+    cov = np.concatenate([cov, cov[:7]])
+    rng = np.random.default_rng(5)
+    pts = mean[rng.integers(0, mean.shape[0], 400)] + rng.normal(0, 0.05, (400, 3))
+    orc = oracle_lib.load()
+    k0, kr = replay.shard_components(mean.shape[0], rank, world)
+    h = orc.gmm_create(mean[k0:k0 + kr], cov[k0:k0 + kr])
+    idx, d2 = orc.associate3d(h, pts)
+    gi, gd = replay.merge_sharded_association(torch.from_numpy(d2), torch.from_numpy(idx), k0, dist, world)
+    hf = orc.gmm_create(mean, cov)
+    idx_f, d2_f = orc.associate3d(hf, pts)
+    q.put((rank, bool(np.array_equal(gi.numpy(), idx_f)), bool(np.array_equal(gd.numpy(), d2_f)),
+           int((idx_f >= 601).sum()), k0, kr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_kshard_association_merge_world2_gloo():
+    """SURVEY 8e K-sharding: each rank associates against its slice of the map, two MIN all-reduces merge the
+    argmin; result = the unsharded association, bit for bit, ties resolved to the lowest global index."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kshard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_idx, same_d2, n_dup, k0, kr in out:
+        assert same_idx and same_d2, rank
+        assert n_dup == 0  # a duplicate in the upper shard never beats its lower-index original
+    assert sorted((o[4], o[5]) for o in out) == [(0, 304), (304, 304)]
+
+
+def test_shard_components_cover_the_map():
+    from gmmloc_amd import replay
+    for K in (1, 7, 3299, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [replay.shard_components(K, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(n for _, n in spans) == K
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
 def test_shard_indices():
     from gmmloc_amd import replay
     for world in (1, 2, 4, 8):
