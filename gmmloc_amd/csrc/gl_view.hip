@@ -1,16 +1,16 @@
 // GMMLoc::associateMapElements (gmmloc_opt.cpp:115-135) for B key-frames:
 //   GMM::renderView            (gaussian_mixture.cpp:271-371)   A3 + A4
 //   GMM::searchCorrespondence  (gaussian_mixture.cpp:484-534)   A5
-// One workgroup per key-frame.
+// One workgroup per key-frame (256 threads in batches, 1 024 when the views are fewer than the CUs).
 //   phase 1  all K components in parallel: view-cosine cull (degenerate planes), projection
 //            J R Sigma R^T J^T (GMMUtility::projectGaussian, gmm_utils.cpp:121-146 with
 //            PinholeCamera::project3, pinhole_camera.cpp:68-150), 2-D eigenvalue cull; ordered
 //            compaction (ballot / popcount prefix) keeps the reference's k = 0..K-1 order.
-//   phase 2  the order-dependent occlusion merge: candidates are visited in order; the
-//            argmin Bhattacharyya distance over the list accepted SO FAR is evaluated by
-//            the whole workgroup (one slot per thread, strided) and reduced with a
-//            (distance, index) argmin that prefers the lower index on ties, exactly like
-//            the sequential `dist < min_dist` scan; replace-in-place / append as :341-355.
+//   phase 2  the order-dependent occlusion merge (:328-355), in rounds of MG candidates: the
+//            Bhattacharyya distances are evaluated in parallel (exact screen, then the reference's
+//            expression for the surviving pairs), the (distance, index) argmin prefers the lower
+//            index on ties exactly like the sequential `dist < min_dist` scan, and one wave replays
+//            the replace-in-place / append decisions in order (details at the phase).
 //   phase 3  stable rank sort by depth, descending (:362-364).
 //   phase 4  per feature exact 5-NN on the 2-D means (nanoflann's result order: ascending,
 //            ties by lower index) + MDist2 < 9 gate, in kNN order.
@@ -22,17 +22,14 @@ using namespace gld;
 
 namespace {
 
-#ifdef GL_VIEW_PROF
+#ifdef GL_VIEW_PROF  // debug build (tools/prof_view.py): phase cycles are returned in place of the view list
 #define VPROF(x) const long long x = clock64()
-#else
-#define VPROF(x)
-#endif
-
-#ifdef GL_VIEW_PROF
 #define GL_VIEW_PROF_ARG (view_ids_out + (size_t)f * view_cap)
 #else
+#define VPROF(x)
 #define GL_VIEW_PROF_ARG nullptr
 #endif
+
 constexpr int SLOT_LDS = 640;  // accepted 2-D components kept in LDS (40 KB); V is 100-300 on the EuRoC maps
 constexpr int REC = 8;  // m0 m1 c00 c01 c10 c11 det depth
 constexpr int MG = 16;  // candidates per merge round (one DPP row)
