@@ -239,3 +239,38 @@ def test_kshard_association_is_bit_identical(gpu, map_v2):
         # the library-side merge on one rank is the identity
         gi1, d21 = replay.merge_sharded_association(d2_f, idx_f, 0)
         assert torch.equal(gi1, idx_f.to(torch.int64)) and torch.equal(d21, d2_f)
+
+
+def test_association_full_stress_size_properties(gpu):
+    """BASELINE configs[4] shape, 50 000 points x 65 536 Gaussians (3.3 G pairs; the oracle would need minutes):
+    (1) the cell index and the plain sweep agree bit for bit; (2) known answer: a point on a component's mean has
+    chi2 exactly 0 there, so the argmin is that component (or a lower-index one that also gives 0); (3) permuting
+    the points permutes the result; (4) every reported chi2 is the canonical expression of its own pair."""
+    torch, ctx = gpu
+    K, N = 65536, 50000
+    mean, cov = synth.synth_gmm(K, 7)
+    g = api.GMM(ctx, mean, cov)
+    assert g.index_info()["enabled"]
+    rng = np.random.default_rng(8)
+    comp = rng.integers(0, K, N)
+    pts = synth.synth_points(mean, cov, N, seed=9)
+    pts[: N // 5] = mean[comp[: N // 5]]  # a fifth of the points exactly on a mean
+    t = torch.from_numpy(pts).cuda()
+    idx_i, d2_i = g.associate3d(t, api.ASSOC_BRUTE)
+    idx_x, d2_x = g.associate3d(t, api.ASSOC_EXHAUSTIVE)
+    assert torch.equal(idx_i, idx_x) and torch.equal(d2_i, d2_x)
+    ii, dd = idx_x.cpu().numpy(), d2_x.cpu().numpy()
+    on = slice(0, N // 5)
+    assert (dd[on] == 0.0).all() and (ii[on] <= comp[on]).all()
+    perm = torch.from_numpy(rng.permutation(N)).cuda()
+    idx_p, d2_p = g.associate3d(t[perm].contiguous(), api.ASSOC_BRUTE)
+    assert torch.equal(idx_p, idx_x[perm]) and torch.equal(d2_p, d2_x[perm])
+    # (4) re-evaluate the winning pair of 4 096 points on the host with the library's own records:
+    #     r = (x - mu)^T L, chi2 = r.r in extended precision (agreement to the cancellation level of r, not to the ulp)
+    sub = rng.integers(0, N, 4096)
+    A = g.get(api.F_SQRT_INFO).reshape(K, 3, 3)[ii[sub]] if hasattr(api, "F_SQRT_INFO") else None
+    if A is not None:
+        d = (pts[sub] - mean[ii[sub]]).astype(np.longdouble)
+        r = np.einsum("ni,nij->nj", d, A.astype(np.longdouble))
+        ref = (r * r).sum(1).astype(np.float64)
+        assert np.allclose(dd[sub], ref, rtol=1e-7, atol=1e-9)
