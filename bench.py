@@ -52,11 +52,13 @@ def measured_traffic(kernel, frames_per_launch):
     WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
     frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
     None when the summary is missing: bench.py itself cannot run under two profilers."""
-    for name in ("r1j_traffic.json", "r1h_traffic.json", "r1g_traffic.json"):
+    for name in ("r1k_traffic.json", "r1j_traffic.json", "r1h_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
                 t = json.load(f).get(kernel)
+            if t and "bench" in t:  # per-shape entry (the sweep: k_assoc_brute + its merge kernel)
+                t = t["bench"]
             if t:
                 return t["hbm_bytes_per_frame"] * frames_per_launch, "profiles/" + name
     return None, None
@@ -277,6 +279,7 @@ def main():
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
         ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8) + 56)  # Xw, obs, octave, assoc, d2 in; pose in/out (points rewritten: +24)
         ba_traffic, ba_traffic_src = measured_traffic("k_ba1_fast", B)
+        sw_traffic, sw_traffic_src = measured_traffic("k_assoc_brute", B)
         out = {
             "metric": "frames/sec (associate+pose-refine), 2k pts x 4k GMM",
             "value": frames_total / dt,
@@ -330,7 +333,8 @@ def main():
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach_tflops / PEAK_FP64_VALU_TFLOPS,
-                "traffic": None,
+                "traffic": sw_traffic,  # incl. the partial minima of the K-split written and merged (k_assoc_merge)
+                "traffic_source": sw_traffic_src,
                 "avg_launch_ms": 1e3 * sweep_s,
                 "flop_per_launch": FLOP_PER_PAIR * pairs,
                 "hbm": {"achieved_GBs": alg_bytes / sweep_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
