@@ -259,3 +259,30 @@ def test_create_map_points_matches_oracle(gpu, oracle, map_v1, gt_sync, ia, ib, 
     np.testing.assert_allclose(x[sane], x_ref[sane], rtol=0, atol=1e-8)
     assert (t_ref > 0).sum() > 50 and (t_ref == 0).sum() > 20 and len(set(t_ref.tolist())) >= 4
     oracle.gmm_destroy(h)
+
+
+@pytest.mark.parametrize("K", [1, 2, 5, 17])
+def test_search2d_tiny_maps(gpu, oracle, K):
+    """Fewer components than a merge round holds, views with zero or one rendered component, features = 0."""
+    torch, ctx = gpu
+    rng = np.random.default_rng(40 + K)
+    mean = np.array([0.0, 0.0, 3.0]) + rng.normal(0, 0.6, (K, 3))
+    cov = np.empty((K, 3, 3))
+    for i in range(K):
+        A = rng.normal(0, 1, (3, 3))
+        Q, _ = np.linalg.qr(A)
+        cov[i] = Q @ np.diag([rng.uniform(1e-6, 1e-4), rng.uniform(0.01, 0.2), rng.uniform(0.01, 0.5)]) @ Q.T
+        cov[i] = 0.5 * (cov[i] + cov[i].T)
+    poses = np.array([[0, 0, 0, 1, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0.3, 0.2, -0.5]], np.float64)  # 2nd looks away
+    uv = np.stack([rng.uniform(0, 752, (3, 50)), rng.uniform(0, 480, (3, 50))], 2)
+    _check_search2d(torch, ctx, oracle, mean, cov, poses, uv, 5)
+    # no features at all: only the rendered list is produced
+    g = api.GMM(ctx, mean, cov)
+    cand, ncand, vids, nview = g.search2d(api.Camera(), torch.from_numpy(poses).cuda(),
+                                          torch.zeros((3, 0, 2), dtype=torch.float64).cuda(), None, k=5, view_cap=32)
+    torch.cuda.synchronize()
+    h = oracle.gmm_create(mean, cov)
+    for b in range(3):
+        ids, _, _, _ = oracle.render_view(h, api.Camera(), poses[b])
+        assert int(nview[b]) == len(ids) and np.array_equal(vids[b].cpu().numpy()[:len(ids)], ids)
+    oracle.gmm_destroy(h)
