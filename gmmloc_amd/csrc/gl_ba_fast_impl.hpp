@@ -374,9 +374,72 @@ GL_DEV void schur_C(const double* A, const double* AD, double* C) {
   }
 }
 
+// ---- latency shape (GL_BAF_COOPERATIVE): the points of ONE frame are dealt to NB workgroups -------------------
+// Every reduction of the optimiser then has a second level across the NB workgroups (all co-resident:
+// cooperative launch).  There is no barrier and no fence: a workgroup publishes its 32 partial sums as 64-bit
+// words {32 bits of the value | sequence number of the reduction} with device-scope atomic stores, and reads
+// everybody's words (its own included) with device-scope atomic loads until both halves of a value carry the
+// current sequence number - one memory round trip when the others are already there, against three dependent
+// ones (generation read, arrival, poll) + two fences for a counter barrier.  The partials are added in
+// workgroup order, so every workgroup holds the same bits: the Levenberg control flow (accept / reject, lambda,
+// termination) is identical in all of them and each repeats the 6x6 solve on its own.  Two buffers are used
+// alternately: a workgroup can only be one reduction ahead of the slowest one (it needs that one's partial), so
+// what it overwrites has been read by everybody.
+#ifdef GL_BAF_COOPERATIVE
+constexpr bool kCoop = true;
+#else
+constexpr bool kCoop = false;
+#endif
+struct Coop {
+  unsigned long long* part;  // 2 buffers x NB workgroups x 32 values x 2 words, zero before the launch
+  int NB, pb;
+  unsigned seq;              // reductions so far (the same in every workgroup)
+};
+// tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead)
+template <bool MAXIMUM>
+GL_DEV void coop_totals(Coop& C, double* tot) {
+  const unsigned seq = ++C.seq;
+  unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[t]);
+    unsigned long long* mine = buf + ((size_t)C.pb * 32 + t) * 2;
+    __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // all NB partials are requested at once (one round trip when the others are already there)
+    constexpr int NBMAX = 4;
+    unsigned long long w0[NBMAX], w1[NBMAX];
+    bool all;
+    do {
+      all = true;
+#pragma unroll
+      for (int p = 0; p < NBMAX; ++p) {
+        if (p < C.NB) {
+          const unsigned long long* w = buf + ((size_t)p * 32 + t) * 2;
+          w0[p] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1[p] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NBMAX; ++p)
+        if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
+    } while (!all);
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < NBMAX; ++p) {
+      if (p < C.NB) {
+        const double v = __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32)));
+        s = p == 0 ? v : (MAXIMUM ? fmax(s, v) : s + v);
+      }
+    }
+    tot[t] = s;
+  }
+  __syncthreads();
+}
+
 // two-level deterministic workgroup reduction (all threads get the NV totals)
 template <int NV>
-GL_DEV void reduce2(double* v, double* red, double* tot) {
+GL_DEV void reduce2(double* v, double* red, double* tot, Coop& C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = NV; i < 32; ++i) v[i] = 0.0;
@@ -392,12 +455,13 @@ GL_DEV void reduce2(double* v, double* red, double* tot) {
     tot[threadIdx.x] = s;
   }
   __syncthreads();
+  if (kCoop && C.NB > 1) coop_totals<false>(C, tot);
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = uni(tot[i]);
 }
 // same, but only wave 0 (the one that solves the reduced system) reads the totals back
 template <int NV>
-GL_DEV void reduce2_w0(double* v, double* red, double* tot) {
+GL_DEV void reduce2_w0(double* v, double* red, double* tot, Coop& C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = NV; i < 32; ++i) v[i] = 0.0;
@@ -411,12 +475,13 @@ GL_DEV void reduce2_w0(double* v, double* red, double* tot) {
     tot[threadIdx.x] = s;
   }
   __syncthreads();
+  if (kCoop && C.NB > 1) coop_totals<false>(C, tot);
   if (threadIdx.x < 64) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = uni(tot[i]);
   }
 }
-GL_DEV double reduce_max(double v, double* red) {
+GL_DEV double reduce_max(double v, double* red, double* tot, Coop& C) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v = fmax(v, shfl_xor_f64(v, o));
   __syncthreads();
@@ -425,6 +490,13 @@ GL_DEV double reduce_max(double v, double* red) {
   double m = red[0];
 #pragma unroll
   for (int w = 1; w < NWF; ++w) m = fmax(m, red[w]);
+  if (kCoop && C.NB > 1) {
+    __syncthreads();  // tot may still be read from the previous reduction
+    if (threadIdx.x < 32) tot[threadIdx.x] = m;
+    __syncthreads();
+    coop_totals<true>(C, tot);
+    m = uni(tot[0]);
+  }
   return m;
 }
 
@@ -510,7 +582,7 @@ GL_DEV bool load_pt(const Lds& D, FlagW fw, const double* __restrict__ gobs, con
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw, Pose& P, int L, const double* __restrict__ gobs,
                          const int32_t* __restrict__ gassoc, const double* __restrict__ gnd, bool robust, int iters,
-                         double* red, double* tot, int& trials) {
+                         double* red, double* tot, int& trials, Coop& C) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -524,7 +596,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
     if (ar) acc[0] += 1.0;
     if (ar || ag) acc[1] += 1.0;
   }
-  reduce2<2>(acc, red, tot);
+  reduce2<2>(acc, red, tot, C);
   const bool pose_active = acc[0] > 0.0;
   if (!pose_active && !(acc[1] > 0.0)) return -1;
 
@@ -558,12 +630,12 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
           accum_pose_sym(o.q, o.A, zero, acc);
         }
       }
-      reduce2<21>(acc, red, tot);
+      reduce2<21>(acc, red, tot, C);
       if (pose_active) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) md = fmax(md, fabs(acc[GL_U(i, i)]));
       }
-      md = reduce_max(md, red);
+      md = reduce_max(md, red, tot, C);
       lambda = uni(1e-5 * md);
       ni = 2.0;
     }
@@ -601,7 +673,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         }
       }
       PROF_T(tA1);
-      reduce2_w0<29>(acc, red, tot);
+      reduce2_w0<29>(acc, red, tot, C);
       PROF_T(tA2);
       if (qmax == 0) currentChi = uni(tot[27]);
       // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
@@ -685,7 +757,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         if (c.ag) acc[1] += gmm_chi2_fast(k, gm, c.nd, c.fl, c.asc, pn);
       }
       PROF_T(tB1);
-      reduce2<2>(acc, red, tot);
+      reduce2<2>(acc, red, tot, C);
       PROF_T(tB2);
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
       // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
@@ -738,7 +810,12 @@ __global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int
                                                  const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
                                                  const double* __restrict__ d2_all, uint8_t* __restrict__ dropped_all,
                                                  uint8_t* __restrict__ erase_all, int32_t* __restrict__ iters_out,
-                                                 double* __restrict__ pn_all, int32_t* __restrict__ trials_out) {
+                                                 double* __restrict__ pn_all, int32_t* __restrict__ trials_out
+#ifdef GL_BAF_COOPERATIVE
+                                                 ,
+                                                 int NB, unsigned long long* parts
+#endif
+) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                          // 3 * MCAP
@@ -748,16 +825,30 @@ __global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int
   double* tot = red + NWF * 32;         // 32 (+ 32 broadcast slots)
   D.stab = tot + 64;                    // 8
   FlagW fw = 0;
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+#ifdef GL_BAF_COOPERATIVE
+  // workgroup pb of the NB that share frame f owns the points [l0, l0 + L) of the frame's Lf
+  const int f = blockIdx.x / NB;
   if (f >= B) return;
-  double* gnd = pn_all + (size_t)f * L * 4;  // per-point plane record {n, n.mu} (written once, then read-only)
-  const double* gobs = obs_all + (size_t)f * L * 3;
-  int32_t* gassoc = assoc_all + (size_t)f * L;
+  Coop C{parts + (size_t)f * 2 * NB * 64, NB, (int)(blockIdx.x % NB), 0u};
+  const int Lf = L, Lp = (Lf + NB - 1) / NB;
+  const int l0 = min(C.pb * Lp, Lf);
+  L = min(Lp, Lf - l0);
+  const size_t gbase = (size_t)f * Lf + l0;
+#else
+  const int f = blockIdx.x;
+  if (f >= B) return;
+  Coop C{nullptr, 1, 0, 0u};
+  const size_t gbase = (size_t)f * L;
+#endif
+  double* gnd = pn_all + gbase * 4;  // per-point plane record {n, n.mu} (written once, then read-only)
+  const double* gobs = obs_all + gbase * 3;
+  int32_t* gassoc = assoc_all + gbase;
 #pragma unroll 1
   for (int i = 0; i < PPTF; ++i) {
     const int l = tid + i * TF;
     if (l >= L) break;
-    const size_t g = (size_t)f * L + l;
+    const size_t g = gbase + l;
     const int oc = oct_all[g];
     int a = assoc_all[g];
     // association gate chi2 <= 9 (checkMapAssociation, gmmloc_opt.cpp:230-232)
@@ -797,7 +888,7 @@ __global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int
   int it3 = 0, trials = 0;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(k, gm, D, fw, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot, trials);
+    it3 = optimize_fast(k, gm, D, fw, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot, trials, C);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < PPTF; ++i) {
@@ -823,7 +914,7 @@ __global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int
   for (int i = 0; i < PPTF; ++i) {  // outputs (:837-879, :898-922)
     const int l = tid + i * TF;
     if (l >= L) break;
-    const size_t g = (size_t)f * L + l;
+    const size_t g = gbase + l;
     const int fl = fw_get(fw, i);
     uint8_t dr = 0, er = 0;
     int a = gassoc[l];
@@ -843,7 +934,7 @@ __global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int
     if (!dropped_all && dr) a = -1;
     gassoc[l] = a;
   }
-  if (tid == 0) {
+  if (tid == 0 && C.pb == 0) {
     SE3 T;
     T.r = qfromR(P.R);
     T.t[0] = P.t[0];

@@ -24,9 +24,12 @@ def oracle_track(oracle, h, cam, f):
     return keep, poses[0], pts, final, idx, d2
 
 
+@pytest.mark.parametrize("coop", ["0", "auto", "3"])  # workgroups per frame: never split / by batch size / forced 3
 @pytest.mark.parametrize("mapname,M,seed", [("v1", 400, 10), ("v1", 2000, 20), ("synth", 1000, 30), ("v1", 2100, 40)])
-def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, mapname, M, seed):
+def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, monkeypatch, mapname, M, seed, coop):
     torch, ctx = gpu
+    if coop != "auto":
+        monkeypatch.setenv("GMMLOC_BA_COOP", coop)
     mean, cov = map_v1 if mapname == "v1" else synth.synth_gmm(4096, 1)
     cam, prm = api.Camera(), api.Params()
     gt = gt_sync["V1_03_difficult"]

@@ -12,7 +12,7 @@ prm = api.Params(); ctx = gmmloc_amd.Context(0); gmm = gmmloc_amd.GMM(ctx, mean,
 dev = torch.device("cuda", 0)
 T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).to(dev)
 pose0, Xw0, obs, octv = T("pose_init"), T("Xw"), T("obs"), T("octave")
-for B in [1, 2, 4, 8, 16, 64, 256]:
+for B in [1, 2, 4, 8, 16, 32, 64, 256]:
     p0, x0, o, oc = pose0[:B].contiguous(), Xw0[:B].contiguous(), obs[:B].contiguous(), octv[:B].contiguous()
     pose, Xw = p0.clone(), x0.clone()
     with torch.cuda.stream(ctx.stream):

@@ -7,7 +7,8 @@ import numpy as np, torch
 import gmmloc_amd
 from gmmloc_amd import api
 import bench
-mean, cov, cam, frames = bench.make_workload(256)
+NF = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+mean, cov, cam, frames = bench.make_workload(NF)
 ctx = gmmloc_amd.Context(0); prm = api.Params(); g = gmmloc_amd.GMM(ctx, mean, cov, prm)
 T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
 pose, Xw, obs, octv = T("pose_init"), T("Xw"), T("obs"), T("octave")
