@@ -167,3 +167,33 @@ def test_track_frames_full_size_known_answer(gpu):
     for b in range(B):
         dt, dr = pose_err(pose2.cpu().numpy()[b], p_np[b])
         assert dt < 1e-9 and dr < 1e-9, (b, dt, dr)
+
+
+def test_track_frames_latency_shape_equals_batch_shape(gpu, map_v1, gt_sync, monkeypatch):
+    """The frame-at-a-time shape (a frame dealt to 2..4 workgroups, reductions exchanged between them) against the
+    one-workgroup-per-frame shape on odd sizes: uneven splits (M = 513: 257 + 256 points), a last workgroup with
+    very few points, padding rows; same associations, poses within the north-star tolerance of each other."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    rng = np.random.default_rng(77)
+    for M, B in [(513, 3), (1025, 2), (1537, 5), (1999, 1), (777, 7)]:
+        frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, B, M, 1000 + M, outlier_frac=0.05)
+        for f in frames:
+            f["octave"][rng.uniform(size=M) < 0.1] = -1
+        T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
+        res = {}
+        for mode in ("0", "4" if M > 1536 else "3" if M > 1024 else "2"):
+            monkeypatch.setenv("GMMLOC_BA_COOP", mode)
+            pose, Xw = T("pose_init"), T("Xw")
+            assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T("obs"), T("octave"))
+            torch.cuda.synchronize()
+            res[mode] = (pose.cpu().numpy(), Xw.cpu().numpy(), assoc.cpu().numpy(), d2.cpu().numpy())
+        (p0, x0, a0, d0), (p1, x1, a1, d1) = res.values()
+        assert np.array_equal(d0, d1) and np.array_equal(a0, a1), (M, B)
+        for b in range(B):
+            dt, dr = pose_err(p0[b], p1[b])
+            assert dt < 1e-6 and dr < 1e-6, (M, b, dt, dr)
+            pad = frames[b]["octave"] < 0
+            assert np.array_equal(x0[b][pad], x1[b][pad])
