@@ -197,3 +197,28 @@ def test_track_frames_latency_shape_equals_batch_shape(gpu, map_v1, gt_sync, mon
             assert dt < 1e-6 and dr < 1e-6, (M, b, dt, dr)
             pad = frames[b]["octave"] < 0
             assert np.array_equal(x0[b][pad], x1[b][pad])
+
+
+@pytest.mark.parametrize("threads,M", [("128", 450), ("256", 900), ("512", 450)])
+def test_track_frames_block_shapes(gpu, oracle, map_v1, gt_sync, monkeypatch, threads, M):
+    """The batch shapes (128 / 256 threads per frame: 4 / 2 frames per CU) are what large batches of small frames
+    run on; small test batches default to 512 threads, so the small shapes are forced here."""
+    torch, ctx = gpu
+    monkeypatch.setenv("GMMLOC_BA_THREADS", threads)
+    monkeypatch.setenv("GMMLOC_BA_COOP", "0")
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 3, M, 3000 + M, outlier_frac=0.05)
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
+    pose, Xw = T("pose_init"), T("Xw")
+    assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T("obs"), T("octave"))
+    torch.cuda.synchronize()
+    pose, assoc = pose.cpu().numpy(), assoc.cpu().numpy()
+    for i, f in enumerate(frames):
+        keep, p_ref, pts_ref, a_ref, idx0, d20 = oracle_track(oracle, h, cam, f)
+        dt, dr = pose_err(pose[i], p_ref)
+        assert dt < 1e-6 and dr < 1e-6, (i, dt, dr)
+        assert np.array_equal(assoc[i][keep], a_ref)
+    oracle.gmm_destroy(h)
