@@ -549,4 +549,60 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
   }
 }
 
+// ---- exchange of 32 partial sums between the NB co-resident workgroups that share one problem ---------------
+// (latency shapes of the refine and pose kernels: cooperative launch).  No barrier and no fence: a workgroup
+// publishes its 32 sums as 64-bit words {32 bits of the value | sequence number of the reduction} with
+// device-scope atomic stores, and reads everybody's words (its own included) with device-scope atomic loads until
+// both halves of every value carry the current sequence number - one memory round trip when the others are
+// already there, against three dependent ones (generation read, arrival, poll) + two fences for a counter
+// barrier.  The partials are added in workgroup order, so every workgroup ends with the same bits.  Two buffers
+// are used alternately: a workgroup can only be one reduction ahead of the slowest one (it needs that one's
+// partial), so what it overwrites has been read by everybody.
+struct Coop {
+  unsigned long long* part;  // 2 buffers x NB workgroups x 32 values x 2 words, zero before the launch
+  int NB, pb;
+  unsigned seq;              // reductions so far (the same in every workgroup)
+};
+// tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead)
+template <bool MAXIMUM>
+GL_DEV void coop_totals(Coop& C, double* tot) {
+  const unsigned seq = ++C.seq;
+  unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
+  const int t = threadIdx.x;
+  if (t < 32) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[t]);
+    unsigned long long* mine = buf + ((size_t)C.pb * 32 + t) * 2;
+    __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // all NB partials are requested at once (one round trip when the others are already there)
+    constexpr int NBMAX = 4;
+    unsigned long long w0[NBMAX], w1[NBMAX];
+    bool all;
+    do {
+      all = true;
+#pragma unroll
+      for (int p = 0; p < NBMAX; ++p) {
+        if (p < C.NB) {
+          const unsigned long long* w = buf + ((size_t)p * 32 + t) * 2;
+          w0[p] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1[p] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NBMAX; ++p)
+        if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
+    } while (!all);
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < NBMAX; ++p) {
+      if (p < C.NB) {
+        const double v = __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32)));
+        s = p == 0 ? v : (MAXIMUM ? fmax(s, v) : s + v);
+      }
+    }
+    tot[t] = s;
+  }
+  __syncthreads();
+}
+
 }  // namespace gld

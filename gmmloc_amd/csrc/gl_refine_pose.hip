@@ -16,6 +16,7 @@
 // +1e-3, x1/3..2/3 / x nu schedule, 10 trials), SparseOptimizer::optimize, levels via
 // initializeOptimization(0), stale per-edge errors read by e->chi2() after the last trial (SURVEY.md
 // Appendix A).
+#include <algorithm>
 #include <cstdlib>
 
 #include "gl_device.hpp"
@@ -69,7 +70,7 @@ GL_DEV double uni(double v) {  // wave-uniform value -> SGPR pair
 // s of every wave adds the NW partials in wave order (the same bits in every wave) - with one wave the barriers
 // are no-ops that order the LDS write before the broadcast reads.
 template <int NW>
-GL_DEV void block_totals28(double* acc, double* part, double* dst) {
+GL_DEV void block_totals28(double* acc, double* part, double* dst, Coop& C) {
 #pragma unroll
   for (int i = 28; i < 32; ++i) acc[i] = 0.0;
   const double r = wave_reduce_scatter32(acc);
@@ -80,7 +81,7 @@ GL_DEV void block_totals28(double* acc, double* part, double* dst) {
   } else {
     if (wave_slot_owner(lane)) part[wave * 32 + wave_slot(lane)] = r;
     __syncthreads();
-    if (wave == 0 && lane < 28) {
+    if (wave == 0 && lane < 32) {
       double s = part[lane];
 #pragma unroll
       for (int w = 1; w < NW; ++w) s += part[w * 32 + lane];
@@ -88,18 +89,26 @@ GL_DEV void block_totals28(double* acc, double* part, double* dst) {
     }
   }
   __syncthreads();
+  if (C.NB > 1) coop_totals<false>(C, dst);  // second level: the workgroups that share the frame
 }
 template <int NW>
-GL_DEV double block_total1(double v, double* part) {
+GL_DEV double block_total1(double v, double* part, double* xs, Coop& C) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v += shfl_xor_f64(v, o);
-  if (NW == 1) return uni(v);
+  if (NW == 1 && C.NB == 1) return uni(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = part[0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) s += part[w];
+  if (C.NB > 1) {
+    __syncthreads();
+    if (threadIdx.x < 32) xs[threadIdx.x] = threadIdx.x == 0 ? s : 0.0;
+    __syncthreads();
+    coop_totals<false>(C, xs);
+    s = xs[0];
+  }
   return uni(s);
 }
 
@@ -194,13 +203,13 @@ GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, do
 
 // one pass over the lane's edges at pose P: acc[0..20] H upper triangle, acc[21..26] b, acc[27] robust chi2
 template <int NW>
-GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int M,
+GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int e0, int es, int M,
                            const double* __restrict__ Xw, const double* __restrict__ obs,
                            const int32_t* __restrict__ octave, const uint8_t* __restrict__ level,
                            double* __restrict__ chi2_e, double* acc) {
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  for (int e = threadIdx.x; e < M; e += 64 * NW) {
+  for (int e = e0; e < M; e += es) {
     const int oc = octave[e];
     if (oc < 0 || level[e] != 0) continue;
     const double X = Xw[(size_t)e * 3 + 0], Y = Xw[(size_t)e * 3 + 1], Z = Xw[(size_t)e * 3 + 2];
@@ -269,12 +278,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
                                                                  const int32_t* __restrict__ oct_all,
                                                                  uint8_t* __restrict__ outlier_all,
                                                                  int32_t* __restrict__ ninlier,
-                                                                 double* __restrict__ chi2_all) {
+                                                                 double* __restrict__ chi2_all, int NB,
+                                                                 unsigned long long* parts) {
   __shared__ double s2tab[8];
   __shared__ double H[32], Hn[32];  // current / trial system {H upper (21), b (6), chi2}
   __shared__ double part[NW * 32];  // per-wave partial sums
-  const int f = blockIdx.x, lane = threadIdx.x;  // "lane" = thread of the frame's NW waves
+  __shared__ double xs[32];         // scalar exchanges between the workgroups of a frame
+  // NB > 1 (cooperative launch, few frames): workgroup pb of the NB that share frame f; the edges are dealt
+  // round all NB x NW x 64 threads and every sum has a second level across the workgroups (gld::coop_totals)
+  const int f = blockIdx.x / NB, lane = threadIdx.x;  // "lane" = thread of the workgroup's NW waves
   if (f >= B) return;
+  Coop C{parts ? parts + (size_t)f * 2 * NB * 64 : nullptr, NB, (int)(blockIdx.x % NB), 0u};
+  const int e0 = C.pb * 64 * NW + lane, es = 64 * NW * NB;
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s2tab[j] = kp.s2inv[j];
@@ -288,13 +303,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
 
   // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
   double cnt = 0.0;
-  for (int e = lane; e < M; e += 64 * NW) {
+  for (int e = e0; e < M; e += es) {
     level[e] = 0;
     if (octave[e] >= 0) cnt += 1.0;
   }
-  const int n_init = (int)block_total1<NW>(cnt, part);
+  const int n_init = (int)block_total1<NW>(cnt, part, xs, C);
   if (n_init < 3) {  // :139-140
-    if (lane == 0) ninlier[f] = 0;
+    if (lane == 0 && C.pb == 0) ninlier[f] = 0;
     return;
   }
   PoseRt P0;
@@ -314,20 +329,20 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
   for (int round = 0; round < 4; ++round) {
     P = P0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
     cnt = 0.0;
-    for (int e = lane; e < M; e += 64 * NW)
+    for (int e = e0; e < M; e += es)
       if (octave[e] >= 0 && level[e] == 0) cnt += 1.0;
-    const int nactive = (int)block_total1<NW>(cnt, part);
+    const int nactive = (int)block_total1<NW>(cnt, part, xs, C);
     if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
-      wave_pose_eval<NW>(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
-      block_totals28<NW>(acc, part, H);
+      wave_pose_eval<NW>(kp, s2tab, P, robust, e0, es, M, Xw, obs, octave, level, chi2_e, acc);
+      block_totals28<NW>(acc, part, H, C);
       double currentChi = uni(H[27]);
       bool sys_valid = true;
       double lambda = 0.0, ni = 2.0;
 #pragma unroll 1
       for (int it = 0; it < 10; ++it) {
         if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
-          wave_pose_eval<NW>(kp, s2tab, P, robust, M, Xw, obs, octave, level, chi2_e, acc);
-          block_totals28<NW>(acc, part, H);
+          wave_pose_eval<NW>(kp, s2tab, P, robust, e0, es, M, Xw, obs, octave, level, chi2_e, acc);
+          block_totals28<NW>(acc, part, H, C);
           currentChi = uni(H[27]);
           sys_valid = true;
         }
@@ -347,8 +362,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
           double tempChi;
           if (ok2) {
             Pn = rt_update(P, dx);
-            wave_pose_eval<NW>(kp, s2tab, Pn, robust, M, Xw, obs, octave, level, chi2_e, acc);
-            block_totals28<NW>(acc, part, Hn);
+            wave_pose_eval<NW>(kp, s2tab, Pn, robust, e0, es, M, Xw, obs, octave, level, chi2_e, acc);
+            block_totals28<NW>(acc, part, Hn, C);
             tempChi = uni(Hn[27]);
           } else {
             tempChi = 1.7976931348623157e308;
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
     // gating (:156-203): outliers are re-evaluated at the current estimate, inliers use the error of
     // the last computeActiveErrors; chi2 compared as float.
     cnt = 0.0;
-    for (int e = lane; e < M; e += 64 * NW) {
+    for (int e = e0; e < M; e += es) {
       const int oc = octave[e];
       if (oc < 0) continue;
       double c2;
@@ -398,11 +413,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
       level[e] = bad ? 1 : 0;
       if (bad) cnt += 1.0;
     }
-    nbad = (int)block_total1<NW>(cnt, part);
+    nbad = (int)block_total1<NW>(cnt, part, xs, C);
     if (round == 2) robust = false;  // e->setRobustKernel(0) at it == 2
     if (n_init < 10) break;          // optimizer.edges().size() < 10
   }
-  if (lane == 0) {
+  if (lane == 0 && C.pb == 0) {
     SE3 T;
     T.r = qfromR(P.R);
     T.t[0] = P.t[0];
@@ -435,7 +450,8 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   kp.delta_mono = (double)(float)sqrt(5.991);    // const float delta_mono = sqrt(5.991)   (:57)
   kp.delta_stereo = (double)(float)sqrt(7.815);  // const float delta_stereo = sqrt(7.815) (:58)
   void* scratch = nullptr;
-  int rc = gl::ctx_scratch(c, (size_t)B * (M > 0 ? M : 1) * sizeof(double), &scratch);
+  const size_t chi_bytes = (((size_t)B * (M > 0 ? M : 1) * sizeof(double) + 63) / 64) * 64;
+  int rc = gl::ctx_scratch(c, chi_bytes + (size_t)B * 4096, &scratch);  // + the exchange words of the latency shape
   if (rc != GL_OK) return rc;
   {
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
@@ -446,15 +462,40 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     int nw = B > 1536 ? 1 : (B > 32 && B <= 256) ? 8 : 4;
     while (nw > 1 && nw * 64 > M + 63) nw = nw == 8 ? 4 : 1;
     if (const char* e = getenv("GMMLOC_POSE_WAVES")) nw = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : 1;
-    if (nw == 8)
+    // very few frames: a frame's edges are dealt to NB <= 4 workgroups of 4 waves on as many CUs (one edge per
+    // thread from 1 024 edges), sums exchanged between them (cooperative launch; GMMLOC_POSE_COOP=0 | 2..4)
+    int nb = std::min(4, (M + 255) / 256);
+    while (nb > 1 && B * nb > 256) --nb;  // one frame 0.35 -> 0.28 ms, 64 frames 0.42 -> 0.35 ms (1 000 edges)
+    bool coop = nb > 1;
+    if (const char* e = getenv("GMMLOC_POSE_COOP")) {
+      const int v = atoi(e);
+      coop = v >= 2 && B * v <= 512;
+      if (coop) nb = std::min(v, 4);
+    }
+    int one = 1;
+    unsigned long long* none = nullptr;
+    bool done = false;
+    if (coop) {
+      unsigned long long* parts = (unsigned long long*)((char*)scratch + chi_bytes);
+      double* chi = (double*)scratch;
+      GL_HIP(hipMemsetAsync(parts, 0, (size_t)B * 2 * nb * 64 * sizeof(unsigned long long), c->stream));
+      void* args[] = {&kp, &B, &M, &pose_dev, &Xw_dev, &obs_dev, &octave_dev, &outlier_dev, &ninlier_dev, &chi, &nb, &parts};
+      if (hipLaunchCooperativeKernel((const void*)k_optimize_current_pose<4>, dim3(B * nb), dim3(256), args, 0, c->stream) ==
+          hipSuccess)
+        done = true;
+      else
+        (void)hipGetLastError();  // not co-resident: the ordinary shapes below
+    }
+    if (done) {
+    } else if (nw == 8)
       k_optimize_current_pose<8><<<B, 512, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                          ninlier_dev, (double*)scratch);
+                                                          ninlier_dev, (double*)scratch, one, none);
     else if (nw == 4)
       k_optimize_current_pose<4><<<B, 256, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                          ninlier_dev, (double*)scratch);
+                                                          ninlier_dev, (double*)scratch, one, none);
     else
       k_optimize_current_pose<1><<<B, 64, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                         ninlier_dev, (double*)scratch);
+                                                         ninlier_dev, (double*)scratch, one, none);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

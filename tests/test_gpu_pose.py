@@ -41,6 +41,7 @@ def run_gpu(gpu, cam, prm, frames):
 @pytest.mark.parametrize("M,seed", [(300, 100), (1200, 200), (2000, 300), (37, 400)])
 def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, monkeypatch, M, seed, kernel):
     monkeypatch.setenv("GMMLOC_POSE_WAVES", kernel)
+    monkeypatch.setenv("GMMLOC_POSE_COOP", "0" if kernel != "4" else "3")  # "4": also the frame dealt to 3 workgroups
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
     frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 6, M, seed)
