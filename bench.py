@@ -142,6 +142,9 @@ def cpu_baseline_worker(seed0, budget_s):
                       "sample": "%d frames of the same workload (oracle = CPU port of the reference algorithm: all-pairs "
                                 "associate3d + joint_optimization, 1 thread); association alone %.1f ms/frame"
                                 % (n, 1e3 * t_assoc / n),
+                      "note": "the timed association is the same-math exhaustive sweep the GPU path answers exactly; the reference's "
+                              "own nearest-5 kd-tree lookup (queryPoint) costs 1.4 ms/frame on this CPU "
+                              "(profiles/r1k_configs.jsonl, config 2) and does not return the argmin over all Gaussians",
                       "cpu_model": model, "host_cores": ncore,
                       "host_hw_threads": os.cpu_count(), "all_cores": allc}))
 
