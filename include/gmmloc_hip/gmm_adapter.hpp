@@ -14,6 +14,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -37,6 +38,9 @@ class DevBuf {
   T* as() { return static_cast<T*>(p_); }
   void upload(const void* src) { check(gl_memcpy_h2d(ctx_, p_, src, bytes_), "h2d"); }
   void download(void* dst) { check(gl_memcpy_d2h(ctx_, dst, p_, bytes_), "d2h"); }
+  void upload(const void* src, size_t n) { check(gl_memcpy_h2d(ctx_, p_, src, n), "h2d"); }
+  void download(void* dst, size_t n) { check(gl_memcpy_d2h(ctx_, dst, p_, n), "d2h"); }
+  size_t bytes() const { return bytes_; }
 
  private:
   gl_ctx_t* ctx_;
@@ -145,18 +149,26 @@ class GMM {
     const int M = (int)octave.size();
     assoc.assign(M, -1);
     if (!M) return;
-    DevBuf dpose(ctx_, 56), dX(ctx_, (size_t)M * 24), dO(ctx_, (size_t)M * 24), doc(ctx_, (size_t)M * 4), da(ctx_, (size_t)M * 4);
-    dpose.upload(&Tcw);
-    dX.upload(Xw.data());
-    dO.upload(obs.data());
-    doc.upload(octave.data());
-    check(gl_track_frames(ctx_, gmm_, &cam_, &prm_, 1, M, dpose.as<double>(), dX.as<double>(), dO.as<double>(),
-                          doc.as<int32_t>(), da.as<int32_t>(), nullptr),
+    // the per-frame caller: one device buffer kept (and only grown) between calls - hipMalloc / hipFree per call
+    // cost more than the kernels - and one transfer each way:  pose | Xw | assoc || obs | octave
+    const size_t oX = 64, oA = oX + (size_t)M * 24, oO = oA + (((size_t)M * 4 + 7) / 8) * 8, oC = oO + (size_t)M * 24,
+                 total = oC + (size_t)M * 4;
+    DevBuf& d = pooled(0, total);
+    stage_.resize(total);
+    std::memcpy(stage_.data(), &Tcw, 56);
+    std::memcpy(stage_.data() + oX, Xw.data(), (size_t)M * 24);
+    std::memcpy(stage_.data() + oO, obs.data(), (size_t)M * 24);
+    std::memcpy(stage_.data() + oC, octave.data(), (size_t)M * 4);
+    d.upload(stage_.data(), total);
+    char* base = d.as<char>();
+    check(gl_track_frames(ctx_, gmm_, &cam_, &prm_, 1, M, reinterpret_cast<double*>(base), reinterpret_cast<double*>(base + oX),
+                          reinterpret_cast<const double*>(base + oO), reinterpret_cast<const int32_t*>(base + oC),
+                          reinterpret_cast<int32_t*>(base + oA), nullptr),
           "gl_track_frames");
-    check(gl_ctx_synchronize(ctx_), "sync");
-    dpose.download(&Tcw);
-    dX.download(Xw.data());
-    da.download(assoc.data());
+    d.download(stage_.data(), oO);  // synchronous on the context's stream: also waits for the kernels
+    std::memcpy(&Tcw, stage_.data(), 56);
+    std::memcpy(Xw.data(), stage_.data() + oX, (size_t)M * 24);
+    std::memcpy(assoc.data(), stage_.data() + oA, (size_t)M * 4);
   }
 
   // Localization::jointOptimization on one flattened local window (layout: gmmloc_hip.h, gl_joint_optimization):
@@ -219,11 +231,19 @@ class GMM {
 
  private:
   void release() {
+    pool_.clear();
     if (gmm_) gl_gmm_destroy(gmm_);
     if (ctx_) gl_ctx_destroy(ctx_);
     gmm_ = nullptr;
     ctx_ = nullptr;
   }
+  DevBuf& pooled(size_t slot, size_t bytes) {
+    if (pool_.size() <= slot) pool_.resize(slot + 1);
+    if (!pool_[slot] || pool_[slot]->bytes() < bytes) pool_[slot].reset(new DevBuf(ctx_, bytes + bytes / 4 + 64));
+    return *pool_[slot];
+  }
+  std::vector<std::unique_ptr<DevBuf>> pool_;
+  std::vector<char> stage_;
   gl_ctx_t* ctx_ = nullptr;
   gl_gmm_t* gmm_ = nullptr;
   gl_params prm_;
