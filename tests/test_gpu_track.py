@@ -83,7 +83,10 @@ def test_track_frames_edge_cases(gpu, oracle, map_v1, gt_sync):
     frames[1]["octave"][5:] = -1                      # 5 points
     frames[2]["Xw"] += np.array([40.0, -35.0, 20.0])  # far from every component; consistent observations are kept
     frames[3]["obs"][:, 2] = -1.0                     # monocular only
-    frames[4]["octave"][100:] = -1                    # padded short frame
+    frames[4]["octave"][100:] = -1                    # padded short frame ...
+    frames[4]["Xw"][100:200] = np.nan                 # ... whose padding rows hold garbage
+    frames[4]["Xw"][200:] = np.inf
+    frames[4]["obs"][100:] = -np.inf
     g = api.GMM(ctx, mean, cov)
     h = oracle.gmm_create(mean, cov)
     T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
@@ -102,7 +105,7 @@ def test_track_frames_edge_cases(gpu, oracle, map_v1, gt_sync):
         assert np.array_equal(assoc[i][keep], a_ref), i
         assert (assoc[i][f["octave"] < 0] == -1).all()
         untouched = f["octave"] < 0
-        assert np.array_equal(Xw[i][untouched], f["Xw"][untouched])  # padding rows are not written
+        assert np.array_equal(Xw[i][untouched], f["Xw"][untouched], equal_nan=True)  # padding rows are not written
     oracle.gmm_destroy(h)
 
 
