@@ -111,6 +111,7 @@ int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out) {
   GL_HIP(hipSetDevice(device));
   gl::Ctx* c = new gl::Ctx();
   c->device = device;
+  if (hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->ncu <= 0) c->ncu = 256;
   c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
   *out = (gl_ctx_t*)c;
   return GL_OK;

@@ -100,10 +100,10 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
                     uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
   {
     int NB = (L + 511) / 512;  // <= 4
-    bool coop = NB > 1 && B * NB <= 256;  // one 160-KB workgroup per CU (measured: 64 frames 0.84 vs 1.15 ms)
+    bool coop = NB > 1 && B * NB <= c->ncu;  // one 160-KB workgroup per CU (measured: 64 frames 0.84 vs 1.15 ms)
     if (const char* e = getenv("GMMLOC_BA_COOP")) {  // 0 = never; n >= 2 = that many workgroups per frame (tests)
       const int v = atoi(e);
-      coop = v >= 2 && B * v <= 256;
+      coop = v >= 2 && B * v <= c->ncu;
       if (coop) NB = std::min(v, 4);
     }
     if (coop) {
@@ -113,7 +113,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   }
   // small shapes put several frames on a CU; with no more frames than CUs a frame takes the 512 threads instead
   // (300 points, one frame: 0.51 -> 0.30 ms; 64 frames: 0.80 -> 0.66 ms)
-  int shape = B <= 256 ? 512 : (L <= 500 ? 128 : (L <= 1000 ? 256 : 512));
+  int shape = B <= c->ncu ? 512 : (L <= 500 ? 128 : (L <= 1000 ? 256 : 512));
   if (const char* e = getenv("GMMLOC_BA_THREADS")) {  // tuning knob: force a block shape that fits
     const int t = atoi(e);
     if ((t == 128 && L <= 500) || (t == 256 && L <= 1000) || t == 512) shape = t;

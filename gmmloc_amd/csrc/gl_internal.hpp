@@ -76,6 +76,7 @@ struct Gmm {
 
 struct Ctx {
   int device = 0;
+  int ncu = 256;  // compute units of the device (shape decisions: frames vs CUs)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // scratch (grown on demand)

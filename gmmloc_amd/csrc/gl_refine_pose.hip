@@ -465,7 +465,7 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     // very few frames: a frame's edges are dealt to NB <= 4 workgroups of 4 waves on as many CUs (one edge per
     // thread from 1 024 edges), sums exchanged between them (cooperative launch; GMMLOC_POSE_COOP=0 | 2..4)
     int nb = std::min(4, (M + 255) / 256);
-    while (nb > 1 && B * nb > 256) --nb;  // one frame 0.35 -> 0.28 ms, 64 frames 0.42 -> 0.35 ms (1 000 edges)
+    while (nb > 1 && B * nb > c->ncu) --nb;  // one frame 0.35 -> 0.28 ms, 64 frames 0.42 -> 0.35 ms (1 000 edges)
     bool coop = nb > 1;
     if (const char* e = getenv("GMMLOC_POSE_COOP")) {
       const int v = atoi(e);

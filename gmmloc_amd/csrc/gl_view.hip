@@ -798,7 +798,7 @@ extern "C" int gl_search2d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* 
   int slot_lds = SLOT_LDS;
   if (const char* e = getenv("GMMLOC_VIEW_SLOT_LDS")) slot_lds = std::max(1, std::min(SLOT_LDS, atoi(e)));  // tests: the spill path
   // latency shape up to one view per CU, throughput shape above (GMMLOC_VIEW_THREADS forces one)
-  int threads = B <= 256 ? 1024 : 256;
+  int threads = B <= c->ncu ? 1024 : 256;
   if (const char* e = getenv("GMMLOC_VIEW_THREADS")) threads = atoi(e) == 1024 ? 1024 : 256;
   const size_t lds = (size_t)SLOT_LDS * REC * sizeof(double);
   if (threads == 1024)
