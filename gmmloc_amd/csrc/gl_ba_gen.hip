@@ -245,13 +245,24 @@ GL_DEV void gmg(const double* q1, const double* M, const double* q2, double* blk
 
 // ---- P1 -------------------------------------------------------------------------------------
 // returns (per-thread partial) robust chi2; mdiag = max landmark diagonal (world frame)
+// sum over the LPP adjacent lanes that share one point (every lane gets it)
+template <int LPP>
+GL_DEV double group_sum(double v) {
+  if (LPP >= 2) v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+  if (LPP >= 4) v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+// LPP adjacent lanes per point (1, 2 or 4: as many as the problem's workgroups have threads for): the
+// observations of the point are dealt round them, the 3x3 point block and its rhs are summed over the group
+template <int LPP>
 GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
   double chi = 0.0;
-  for (int l = GSTART; l < G.L; l += GSTRIDE) {
-    if (!G.lact[l]) continue;
+  const int sub = (int)threadIdx.x & (LPP - 1);
+  for (int l = GSTART / LPP; l < G.L; l += GSTRIDE / LPP) {
+    if (!G.lact[l]) continue;  // the same for the LPP lanes of the group
     const double p[3] = {G.pts[(size_t)l * 3], G.pts[(size_t)l * 3 + 1], G.pts[(size_t)l * 3 + 2]};
     double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+    for (int o = G.optr[l] + sub; o < G.optr[l + 1]; o += LPP) {
       if (G.lev_o[o]) continue;
       const int j = G.opose[o];
       double R[9], t[3], q[3], A[6], a[3], c2, r0;
@@ -279,7 +290,7 @@ GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool ro
 #pragma unroll
       for (int i = 0; i < 3; ++i) bl[i] += R[i] * a[0] + R[3 + i] * a[1] + R[6 + i] * a[2];
     }
-    if (G.assoc[l] >= 0 && !G.lev_g[l]) {
+    if (sub == 0 && G.assoc[l] >= 0 && !G.lev_g[l]) {
       GmmRef g;
       load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
       const double d[3] = {p[0] - g.mu[0], p[1] - g.mu[1], p[2] - g.mu[2]};
@@ -312,20 +323,102 @@ GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool ro
         for (int i = 0; i < 3; ++i) bl[i] -= g.L[i * 3] * e[0] + g.L[i * 3 + 1] * e[1] + g.L[i * 3 + 2] * e[2];
       }
     }
+    if (LPP > 1) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) H[i] = group_sum<LPP>(H[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bl[i] = group_sum<LPP>(bl[i]);
+    }
     mdiag = fmax(mdiag, fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))));
     double D[6] = {H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda}, Dinv[6], u[3];
     sym3_inv(D, Dinv);
     sym3_mul_vec(Dinv, bl, u);
-    double* pw = G.ptw + (size_t)l * 12;
+    if (sub == 0) {
+      double* pw = G.ptw + (size_t)l * 12;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pw[i] = Dinv[i];
+      for (int i = 0; i < 6; ++i) pw[i] = Dinv[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      pw[6 + i] = u[i];
-      pw[9 + i] = bl[i];
+      for (int i = 0; i < 3; ++i) {
+        pw[6 + i] = u[i];
+        pw[9 + i] = bl[i];
+      }
     }
   }
   return chi;
+}
+GL_DEV double pass_points_lpp(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
+  if (lpp == 4) return pass_points<4>(k, gm, G, robust, lambda, mdiag);
+  if (lpp == 2) return pass_points<2>(k, gm, G, robust, lambda, mdiag);
+  return pass_points<1>(k, gm, G, robust, lambda, mdiag);
+}
+
+// ---- P3: back-substitution of the points, trial points, their chi2 (LPP lanes per point like P1) ------------
+template <int LPP>
+GL_DEV void pass_trial(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, int P, double* acc) {
+  const int sub = (int)threadIdx.x & (LPP - 1);
+  for (int l = GSTART / LPP; l < G.L; l += GSTRIDE / LPP) {
+    if (!G.lact[l]) continue;
+    const double* pw = G.ptw + (size_t)l * 12;
+    double rhs[3] = {0.0, 0.0, 0.0};
+    if (sub == 0) {
+      rhs[0] = pw[9];
+      rhs[1] = pw[10];
+      rhs[2] = pw[11];
+    }
+    for (int o = G.optr[l] + sub; o < G.optr[l + 1]; o += LPP) {
+      if (G.lev_o[o]) continue;
+      const int j = G.opose[o];
+      if (j >= P || !G.pact[j]) continue;
+      const double* lo = G.lin + (size_t)o * 12;
+      const double* dx = G.dxv + 6 * j;
+      double gd[3], Ag[3];
+      cross(dx, lo, gd);
+      gd[0] += dx[3];
+      gd[1] += dx[4];
+      gd[2] += dx[5];
+      sym3_mul_vec(lo + 3, gd, Ag);
+      const double* R = G.Rt + (size_t)j * 12;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rhs[i] -= R[i] * Ag[0] + R[3 + i] * Ag[1] + R[6 + i] * Ag[2];
+    }
+    if (LPP > 1) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rhs[i] = group_sum<LPP>(rhs[i]);
+    }
+    double dl[3];
+    sym3_mul_vec(pw, rhs, dl);
+    const double pn[3] = {G.pts[(size_t)l * 3] + dl[0], G.pts[(size_t)l * 3 + 1] + dl[1], G.pts[(size_t)l * 3 + 2] + dl[2]};
+    if (sub == 0) {
+      acc[0] += dl[0] * (lambda * dl[0] + pw[9]) + dl[1] * (lambda * dl[1] + pw[10]) + dl[2] * (lambda * dl[2] + pw[11]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) G.pn[(size_t)l * 3 + i] = pn[i];
+    }
+    for (int o = G.optr[l] + sub; o < G.optr[l + 1]; o += LPP) {
+      if (G.lev_o[o]) continue;
+      const int j = G.opose[o];
+      const double* Rt = (j < P) ? G.RtN + (size_t)j * 12 : G.Rt + (size_t)j * 12;
+      double q[3], e[3], iz;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q[i] = Rt[i * 3] * pn[0] + Rt[i * 3 + 1] * pn[1] + Rt[i * 3 + 2] * pn[2] + Rt[9 + i];
+      const double* ob = G.ouvr + (size_t)o * 3;
+      const bool stereo = !(ob[2] < 0);
+      const double c2 = reproj_err(k, q, ob, stereo, k.s2inv[G.ooct[o]], e, iz);
+      G.chi_o[o] = c2;
+      double r0 = c2, r1;
+      if (robust) huber(c2, stereo ? k.delta_stereo : k.delta_mono, r0, r1);
+      acc[1] += r0;
+    }
+    if (sub == 0 && G.assoc[l] >= 0 && !G.lev_g[l]) {
+      GmmRef g;
+      load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
+      acc[1] += gmm_chi2(k, g, pn);
+    }
+  }
+}
+GL_DEV void pass_trial_lpp(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, int P, double* acc) {
+  if (lpp == 4) return pass_trial<4>(k, gm, G, robust, lambda, P, acc);
+  if (lpp == 2) return pass_trial<2>(k, gm, G, robust, lambda, P, acc);
+  return pass_trial<1>(k, gm, G, robust, lambda, P, acc);
 }
 
 // ---- P2 -------------------------------------------------------------------------------------
@@ -610,6 +703,8 @@ GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag, double* i
 GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag,
                         double* s_lds) {
   const int P = G.P, n = 6 * P, tid = threadIdx.x;
+  // lanes per point in the point passes: as many (1, 2, 4) as the problem's threads allow in one round
+  const int lpp = (G.NB * T_BA >= 4 * G.L) ? 4 : (G.NB * T_BA >= 2 * G.L) ? 2 : 1;
   double acc[32];
   // ---- initializeOptimization(0): active poses / points -----------------------------------
   for (int j = GSTART; j < P; j += GSTRIDE) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
@@ -640,7 +735,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
   for (int it = 0; it < iters; ++it) {
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
-      pass_points(k, gm, G, robust, 0.0, md);
+      pass_points_lpp(lpp, k, gm, G, robust, 0.0, md);
       for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
       prob_sync(G);
       pass_blocks(G, false);
@@ -667,7 +762,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       GP_T(t0);
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      acc[0] = pass_points(k, gm, G, robust, lambda, md_unused);
+      acc[0] = pass_points_lpp(lpp, k, gm, G, robust, lambda, md_unused);
       for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
       for (int i = GSTART; i < n; i += GSTRIDE) {
         G.gv[i] = 0.0;
@@ -745,53 +840,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       GP_T(t4);
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      for (int l = GSTART; l < G.L; l += GSTRIDE) {
-        if (!G.lact[l]) continue;
-        const double* pw = G.ptw + (size_t)l * 12;
-        double rhs[3] = {pw[9], pw[10], pw[11]};
-        for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
-          if (G.lev_o[o]) continue;
-          const int j = G.opose[o];
-          if (j >= P || !G.pact[j]) continue;
-          const double* lo = G.lin + (size_t)o * 12;
-          const double* dx = G.dxv + 6 * j;
-          double gd[3], Ag[3];
-          cross(dx, lo, gd);
-          gd[0] += dx[3];
-          gd[1] += dx[4];
-          gd[2] += dx[5];
-          sym3_mul_vec(lo + 3, gd, Ag);
-          const double* R = G.Rt + (size_t)j * 12;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) rhs[i] -= R[i] * Ag[0] + R[3 + i] * Ag[1] + R[6 + i] * Ag[2];
-        }
-        double dl[3];
-        sym3_mul_vec(pw, rhs, dl);
-        acc[0] += dl[0] * (lambda * dl[0] + pw[9]) + dl[1] * (lambda * dl[1] + pw[10]) + dl[2] * (lambda * dl[2] + pw[11]);
-        const double pn[3] = {G.pts[(size_t)l * 3] + dl[0], G.pts[(size_t)l * 3 + 1] + dl[1], G.pts[(size_t)l * 3 + 2] + dl[2]};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) G.pn[(size_t)l * 3 + i] = pn[i];
-        for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
-          if (G.lev_o[o]) continue;
-          const int j = G.opose[o];
-          const double* Rt = (j < P) ? G.RtN + (size_t)j * 12 : G.Rt + (size_t)j * 12;
-          double q[3], e[3], iz;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) q[i] = Rt[i * 3] * pn[0] + Rt[i * 3 + 1] * pn[1] + Rt[i * 3 + 2] * pn[2] + Rt[9 + i];
-          const double* ob = G.ouvr + (size_t)o * 3;
-          const bool stereo = !(ob[2] < 0);
-          const double c2 = reproj_err(k, q, ob, stereo, k.s2inv[G.ooct[o]], e, iz);
-          G.chi_o[o] = c2;
-          double r0 = c2, r1;
-          if (robust) huber(c2, stereo ? k.delta_stereo : k.delta_mono, r0, r1);
-          acc[1] += r0;
-        }
-        if (G.assoc[l] >= 0 && !G.lev_g[l]) {
-          GmmRef g;
-          load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
-          acc[1] += gmm_chi2(k, g, pn);
-        }
-      }
+      pass_trial_lpp(lpp, k, gm, G, robust, lambda, P, acc);
       prob_reduce<2>(G, acc, red);
       double scale = acc[0], tempChi = acc[1];
       for (int j = 0; j < P; ++j) tempChi += G.pchi2[j];
@@ -1055,13 +1104,13 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ba_gen, T_BA, lds));
     GL_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     const long cap = (long)occ * ncu;
-    // measured optimum on single problems (tools/ba_nb.py): one workgroup up to ~2 000
-    // observations (1.1 vs 2.0 ms: no cross-workgroup barrier at all), 4 up to 6 000, 16 up to 16 000, 32 up to
-    // 40 000, 64 above (the P (P + 1) / 2 reduced-camera blocks then fill 256 waves); NOBS (the stride) stands
-    // in for the observation count
-    const int want = NOBS <= 2000 ? 1 : NOBS <= 6000 ? 4 : NOBS <= 16000 ? 16 : NOBS <= 40000 ? 32 : 64;
+    // measured optimum on single problems (tools/ba_nb.py), with up to 4 lanes per point in the
+    // point passes: one workgroup up to ~600 observations (no cross-workgroup barrier at all), 4 up to 2 000,
+    // 8 up to 6 000, 32 up to 40 000, 64 above (the P (P + 1) / 2 reduced-camera blocks then fill 256 waves);
+    // NOBS (the stride) stands in for the observation count
+    const int want = NOBS <= 600 ? 1 : NOBS <= 2000 ? 4 : NOBS <= 6000 ? 8 : NOBS <= 40000 ? 32 : 64;
     NB = (int)std::min<long>(want, cap / B);
-    if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = std::min(NB, atoi(e));  // knob (tests: 1 = single workgroup)
+    if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = (int)std::min<long>(std::max(1, atoi(e)), cap / B);  // knob: that many workgroups per problem (tests: 1)
     if (NB < 2) NB = 1;
   }
   {
