@@ -422,20 +422,28 @@ GL_DEV void pass_trial_lpp(int lpp, const BaK& k, const GmmDev& gm, const GenP& 
 }
 
 // ---- P2 -------------------------------------------------------------------------------------
-GL_DEV void pass_blocks(const GenP& G, bool schur) {
+// One wave per block (j1 <= j2) of the reduced camera system, its lanes over the observations of pose j1; when
+// the problem's workgroups have at least 2 (4) waves per block, 2 (4) waves of a workgroup share a block (the
+// observation list dealt round them, their 48 sums met in LDS).
+GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
   const int P = G.P, n = 6 * P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = P * (P + 1) / 2;
-  for (int b = G.pb * NW_BA + wave; b < nblk; b += G.NB * NW_BA) {
+  const int tw = G.NB * NW_BA;
+  const int W = (tw >= 4 * nblk) ? 4 : (tw >= 2 * nblk) ? 2 : 1;
+  const int grp = wave / W, sub = wave % W, gpw = NW_BA / W;
+  const int rounds = (nblk + G.NB * gpw - 1) / (G.NB * gpw);
+  for (int it = 0; it < rounds; ++it) {  // uniform trip count over the workgroup: barriers inside
+    const int b = (it * G.NB + G.pb) * gpw + grp;
+    bool act = b < nblk;
     // decode (j1 <= j2)
-    int j1 = 0, rem = b;
+    int j1 = 0, rem = act ? b : 0;
     while (rem >= P - j1) {
       rem -= P - j1;
       ++j1;
     }
     const int j2 = j1 + rem;
-    if (!G.pact[j1] || !G.pact[j2]) continue;
-    if (!schur && j1 != j2) continue;
+    act = act && G.pact[j1] && G.pact[j2] && (schur || j1 == j2);
     double v1[32], v2[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -445,7 +453,7 @@ GL_DEV void pass_blocks(const GenP& G, bool schur) {
     double R1[9], t1[3], R2[9], t2[3];
     load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
     load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
-    for (int e = G.pl_ptr[j1] + lane; e < G.pl_ptr[j1 + 1]; e += 64) {
+    for (int e = G.pl_ptr[j1] + sub * 64 + lane; act && e < G.pl_ptr[j1 + 1]; e += 64 * W) {
       const int o1 = G.pl_obs[e];
       if (G.lev_o[o1]) continue;
       const int o2 = (j1 == j2) ? o1 : G.match[(size_t)o1 * P + j2];
@@ -514,9 +522,23 @@ GL_DEV void pass_blocks(const GenP& G, bool schur) {
         v2[10 + i] += bq[i];
       }
     }
-    const double r1 = wave_reduce_scatter32(v1);
-    const double r2 = wave_reduce_scatter32(v2);
-    if (wave_slot_owner(lane)) {
+    double r1 = wave_reduce_scatter32(v1);
+    double r2 = wave_reduce_scatter32(v2);
+    if (W > 1) {
+      if (wave_slot_owner(lane)) {
+        p2part[wave * 64 + wave_slot(lane)] = r1;
+        p2part[wave * 64 + 32 + wave_slot(lane)] = r2;
+      }
+      __syncthreads();
+      if (sub == 0 && wave_slot_owner(lane)) {
+        for (int w = 1; w < W; ++w) {
+          r1 += p2part[(wave + w) * 64 + wave_slot(lane)];
+          r2 += p2part[(wave + w) * 64 + 32 + wave_slot(lane)];
+        }
+      }
+      __syncthreads();
+    }
+    if (act && sub == 0 && wave_slot_owner(lane)) {
       const int s = wave_slot(lane);
       {
         const int r = s / 6, c = s % 6;
@@ -701,7 +723,7 @@ GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag, double* i
 }
 
 GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag,
-                        double* s_lds) {
+                        double* s_lds, double* p2part) {
   const int P = G.P, n = 6 * P, tid = threadIdx.x;
   // lanes per point in the point passes: as many (1, 2, 4) as the problem's threads allow in one round
   const int lpp = (G.NB * T_BA >= 4 * G.L) ? 4 : (G.NB * T_BA >= 2 * G.L) ? 2 : 1;
@@ -738,7 +760,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       pass_points_lpp(lpp, k, gm, G, robust, 0.0, md);
       for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
       prob_sync(G);
-      pass_blocks(G, false);
+      pass_blocks(G, false, p2part);
       prob_sync(G);
       for (int j = GSTART; j < P; j += GSTRIDE) {
         if (!G.pact[j]) continue;
@@ -772,7 +794,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       double chiA = acc[0];
       if (G.NB == 1) __syncthreads();
       GP_T(t1);
-      pass_blocks(G, true);
+      pass_blocks(G, true, p2part);
       prob_sync(G);
       GP_T(t2);
       // ---- workgroup 0: priors / inactive poses, solve, trial poses (P <= ~20 poses: not worth a barrier each)
@@ -892,6 +914,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
                                                  size_t scratch_per_problem, int s_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // reduced camera system when it fits
   __shared__ double red[NW_BA * 32];
+  __shared__ double p2part[NW_BA * 64];  // pass_blocks: sums of the waves that share a block
   __shared__ int s_flag;
   const int f = blockIdx.x / NB, tid = threadIdx.x;
   if (f >= B) return;
@@ -1018,7 +1041,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   double* s_lds = s_in_lds ? dyn_lds : nullptr;
 
   // ---- schedule (:770-828) ---------------------------------------------------------------------------
-  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds);
+  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds, p2part);
   prob_sync(G);
   for (int l = GSTART; l < L; l += GSTRIDE) {
     GmmRef g;
@@ -1026,7 +1049,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
     if (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) G.lev_g[l] = 1;
   }
   prob_sync(G);
-  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds);
+  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds, p2part);
   prob_sync(G);
   for (int l = GSTART; l < L; l += GSTRIDE)
     for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
@@ -1037,7 +1060,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
       if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
     }
   prob_sync(G);
-  const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds);
+  const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds, p2part);
   prob_sync(G);
   // ---- outputs (:837-879) ---------------------------------------------------------------------------
   for (int l = GSTART; l < L; l += GSTRIDE) {
@@ -1105,10 +1128,10 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     GL_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     const long cap = (long)occ * ncu;
     // measured optimum on single problems (tools/ba_nb.py), with up to 4 lanes per point in the
-    // point passes: one workgroup up to ~600 observations (no cross-workgroup barrier at all), 4 up to 2 000,
-    // 8 up to 6 000, 32 up to 40 000, 64 above (the P (P + 1) / 2 reduced-camera blocks then fill 256 waves);
-    // NOBS (the stride) stands in for the observation count
-    const int want = NOBS <= 600 ? 1 : NOBS <= 2000 ? 4 : NOBS <= 6000 ? 8 : NOBS <= 40000 ? 32 : 64;
+    // point passes and up to 4 waves per reduced-camera block: one workgroup up to ~600 observations (no
+    // cross-workgroup barrier at all), 8 up to 2 000, 16 up to 6 000, 32 up to 16 000, 64 above; NOBS (the
+    // stride) stands in for the observation count
+    const int want = NOBS <= 600 ? 1 : NOBS <= 2000 ? 8 : NOBS <= 6000 ? 16 : NOBS <= 16000 ? 32 : 64;
     NB = (int)std::min<long>(want, cap / B);
     if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = (int)std::min<long>(std::max(1, atoi(e)), cap / B);  // knob: that many workgroups per problem (tests: 1)
     if (NB < 2) NB = 1;
