@@ -258,7 +258,16 @@ def config_kf(torch, ctx, out):
                                                              octv[1::2].reshape(-1).contiguous(), cand[0::2].reshape(M2, 5).contiguous(),
                                                              ncand[0::2].reshape(-1).contiguous(), cand[1::2].reshape(M2, 5).contiguous(),
                                                              ncand[1::2].reshape(-1).contiguous()), 3, ctx.stream)
+    # one key-frame at a time (the reference's caller)
+    p1k, x1k, u1k, o1k = poses[:1].contiguous(), pts0[:1].contiguous(), uvr[:1].contiguous(), octv[:1].contiguous()
+    c1k, n1k = g.search2d(cam, p1k, uv[:1].contiguous(), None, k=5)[:2]
+    t_cma1 = ev_time(torch, lambda: api.check_map_association(ctx, g, cam, prm, p1k, x1k.clone(), u1k, o1k, c1k, n1k), 5, ctx.stream)
+    t_b21 = ev_time(torch, lambda: api.optimize_triangulation(ctx, g, cam, prm, x3[:N].clone(), p1[:N].contiguous(), uvr[0].contiguous(),
+                                                              octv[0].contiguous(), p2[:N].contiguous(), uvr[1].contiguous(), octv[1].contiguous(),
+                                                              cand[0].contiguous(), ncand[0].contiguous(), cand[1].contiguous(),
+                                                              ncand[1].contiguous()), 5, ctx.stream)
     out({"config": "key-frame chain on v1.gmm: %d key-frames x %d features" % (B, N),
+         "single_keyframe_checkMapAssociation_us": 1e6 * t_cma1, "single_keyframe_optimizeTriangulation_1000_matches_us": 1e6 * t_b21,
          "search2d_keyframes_per_s": B / t_s2d, "checkMapAssociation_keyframes_per_s": B / t_cma,
          "checkMapAssociation_features_per_s": B * N / t_cma, "mean_candidates_per_feature": float(ncand.float().mean().item()),
          "optimizePoint_problems_per_s": B * N / t_b1, "optimizeTriangulation_problems_per_s": M2 / t_b2})
