@@ -68,9 +68,19 @@ for mapname, seqs in (("map_v1", ["V1_01_easy", "V1_02_medium", "V1_03_difficult
             keep, p_ref, pts_ref, a_ref, idx0, d20 = oracle_track(orc, h, cam, ft)
             dt, dr = pose_err(pose.cpu().numpy()[0], p_ref)
             ok3 = dt < 1e-6 and dr < 1e-6 and np.array_equal(assoc.cpu().numpy()[0][keep], a_ref) and np.array_equal(d2.cpu().numpy()[0][keep], d20)
+        # ---- optimizeCurrentPose (random size: every launch shape of the kernel over the rounds)
+        Mp = int(rng.integers(5, 1300))
+        fp = synth.synth_frame(mean, cov, p1, cam, Mp, 13000 + r, outlier_frac=0.08)
+        fp["octave"][rng.uniform(size=Mp) < 0.1] = -1
+        pose = T(fp["pose_init"][None])
+        outl, nin = api.optimize_current_pose(ctx, cam, prm, pose, T(fp["Xw"][None]), T(fp["obs"][None]), T(fp["octave"][None]))
+        torch.cuda.synchronize()
+        pr, orf, nr_ = orc.optimize_current_pose(cam, fp["pose_init"], fp["Xw"], fp["obs"], fp["octave"])
+        dt, dr = pose_err(pose.cpu().numpy()[0], pr)
+        ok3 = ok3 and dt < 1e-6 and dr < 1e-6 and np.array_equal(outl.cpu().numpy()[0], orf) and int(nin[0]) == nr_
         if not (ok and ok2 and ok3):
             bad += 1
-            print("MISMATCH", mapname, "round", r, "frames", ia, ib, "N", N, "chain", ok, "createMapPoints", ok2, "track", ok3, flush=True)
+            print("MISMATCH", mapname, "round", r, "frames", ia, ib, "N", N, "chain", ok, "createMapPoints", ok2, "track+pose", ok3, flush=True)
     orc.gmm_destroy(h)
 print("soak: %d rounds per map, %d mismatches, %.0f s" % (rounds, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
