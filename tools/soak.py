@@ -1,5 +1,5 @@
 """Randomised parity soak on the GPU box: many seeds of the key-frame chain (search2d -> checkMapAssociation,
-createMapPoints) and of the per-frame path against the oracle; prints the first mismatch and a summary.
+createMapPoints), of the per-frame path and of the local BA against the oracle; prints the first mismatch and a summary.
     python tools/soak.py [rounds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -82,5 +82,27 @@ for mapname, seqs in (("map_v1", ["V1_01_easy", "V1_02_medium", "V1_03_difficult
             bad += 1
             print("MISMATCH", mapname, "round", r, "frames", ia, ib, "N", N, "chain", ok, "createMapPoints", ok2, "track+pose", ok3, flush=True)
     orc.gmm_destroy(h)
+# ---- local BA: random window sizes and forced workgroup counts (lanes per point / waves per block combinations)
+from tests.test_gpu_ba import make_ba_problem, run_gpu, check
+d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz")); mean, cov = d["mean"], d["cov"]
+g = gmmloc_amd.GMM(ctx, mean, cov, prm); h = orc.gmm_create(mean, cov)
+rng = np.random.default_rng(5)
+for r in range(max(10, rounds // 4)):
+    P, F, L = int(rng.integers(1, 8)), int(rng.integers(0, 4)), int(rng.integers(20, 400))
+    nb = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
+    if nb:
+        os.environ["GMMLOC_BAGEN_NB"] = str(nb)
+    else:
+        os.environ.pop("GMMLOC_BAGEN_NB", None)
+    p = make_ba_problem(mean, cov, gts["V1_01_easy"], cam, P, F, L, 500 + r, bool(rng.integers(0, 2)))
+    idx, d2 = orc.associate3d(h, p["points"])
+    a = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
+    try:
+        check([p], [a], run_gpu((torch, ctx), g, cam, prm, [p], [a]), orc, h, cam)
+    except AssertionError as e:
+        bad += 1
+        print("MISMATCH local BA round", r, "P F L NB", P, F, L, nb, str(e)[:200], flush=True)
+os.environ.pop("GMMLOC_BAGEN_NB", None)
+orc.gmm_destroy(h)
 print("soak: %d rounds per map, %d mismatches, %.0f s" % (rounds, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
