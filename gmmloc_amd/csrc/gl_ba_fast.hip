@@ -56,7 +56,8 @@ static int launch_shape(KernelT kern, int TF_, int MCAP_, Ctx* c, const Gmm* g, 
                         int B, int L, double* pose, double* pts, const double* obs, const int32_t* oct, int32_t* assoc,
                         const double* d2, double gate, uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
   const size_t lds = (size_t)(10 * MCAP_ + (TF_ / 64) * 32 + 64 + 8) * sizeof(double);
-  GL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static size_t lds_set[3] = {0, 0, 0};  // per block shape
+  GL_HIP(ensure_dynamic_lds((const void*)kern, lds, &lds_set[TF_ == 128 ? 0 : TF_ == 256 ? 1 : 2]));
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   {
     TimerScope ts(c, GL_TIMER_BA);
@@ -75,7 +76,8 @@ static int launch_coop(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_para
                        double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
                        uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
   const size_t lds = (size_t)(10 * 2000 + (512 / 64) * 32 + 64 + 8) * sizeof(double);
-  GL_HIP(hipFuncSetAttribute((const void*)baf512c::k_ba1_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static size_t lds_set = 0;
+  GL_HIP(ensure_dynamic_lds((const void*)baf512c::k_ba1_fast, lds, &lds_set));
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
   BaK kk = make_bak(cam, prm, gate);
   // the exchange words of the frames sit behind the plane records

@@ -1118,14 +1118,21 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;
   const size_t lds = s_in_lds ? s_bytes : 0;
   if (s_in_lds)
-    GL_HIP(hipFuncSetAttribute((const void*)k_ba_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_bytes));
+  {
+    static size_t lds_set = 0;
+    GL_HIP(gl::ensure_dynamic_lds((const void*)k_ba_gen, s_bytes, &lds_set));
+  }
   // workgroups per problem: as many as stay co-resident (the per-problem barrier needs that; the
   // cooperative launch enforces it), at most 64; large batches run one workgroup per problem
   int NB = 1;
   {
-    int occ = 0, ncu = 0;
-    GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ba_gen, T_BA, lds));
-    GL_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+    static size_t occ_lds = (size_t)-1;  // the occupancy query is a driver call: remembered per LDS size
+    static int occ_val = 0;
+    if (occ_lds != lds) {
+      GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_val, (const void*)k_ba_gen, T_BA, lds));
+      occ_lds = lds;
+    }
+    const int occ = occ_val, ncu = c->ncu;
     const long cap = (long)occ * ncu;
     // measured optimum on single problems (tools/ba_nb.py), with up to 4 lanes per point in the
     // point passes and up to 4 waves per reduced-camera block: one workgroup up to ~600 observations (no

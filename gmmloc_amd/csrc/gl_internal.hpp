@@ -94,6 +94,15 @@ struct Ctx {
 };
 
 int ctx_scratch(Ctx* c, size_t bytes, void** out);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs a driver call: raise a kernel's limit only when it grows.
+// `slot` is a per-call-site static (one per kernel instantiation and device would be stricter; the limit only
+// ever grows, and every device of a process runs the same kernels with the same sizes).
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, size_t* slot) {
+  if (bytes <= *slot) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) *slot = bytes;
+  return e;
+}
 // bracket a launch region with events when timing is enabled
 struct TimerScope {
   Ctx* c;

@@ -71,8 +71,8 @@ __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* __r
 // MODE 1: searchByProjection(CurrentFrame, LastFrame, th, bMono): query points = the last frame's map
 //         points (mp_uvr = world position, mp_level = octave of the last frame's feature), projected here
 //         with the current pose; rotation-consistency histogram at the end (feat_angle / mp_angle).
-template <int MODE>
-__global__ __launch_bounds__(T_M) void k_search_by_projection(
+template <int MODE, bool DL>
+__global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     MatchP P, int B, const double* __restrict__ feat_uv_all, const float* __restrict__ feat_ur_all,
     const int32_t* __restrict__ feat_oct_all, const uint8_t* __restrict__ feat_desc_all,
     const uint8_t* __restrict__ feat_taken_all, const double* __restrict__ mp_uvr_all,
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all,
     const double* __restrict__ pose_cw_all, const double* __restrict__ pose_lw_all,
     const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all) {
+  constexpr int TM = DL ? 1024 : T_M;  // threads per frame: the latency shape doubles them
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* cell_ptr = lds;                   // NCELL + 1
   int32_t* cursor = cell_ptr + NCELL + 1;    // NCELL (grid build only)
@@ -91,11 +92,18 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
   // per CSR entry, so that the window walk touches LDS only: {u, v} double, {u_right bits, octave}
   double2* rec_uv = (double2*)(lds + ((2 * NCELL + 1 + 3 * P.NF + P.NP + 3) & ~3));  // 16-byte aligned
   int2* rec_ro = (int2*)(rec_uv + P.NF);
-  __shared__ int s_changed, s_scan[T_M], s_hist[32], s_keep[4];
+  // DL (few frames: one workgroup per CU anyway): the 256-bit descriptors too, in CSR order - a candidate that
+  // survives the window test otherwise costs a dependent global load of 32 bytes
+  uint4* rec_desc = (uint4*)(rec_ro + ((P.NF + 1) & ~1));  // 2 x uint4 per entry, 16-byte aligned
+  __shared__ int s_changed, s_scan[TM], s_hist[32], s_keep[4];
   __shared__ double s_pose[8];
   __shared__ int s_dir;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
+#ifdef GL_MATCH_PROF
+  const long long tp0 = clock64();
+  long long tp_round = 0;
+#endif
   const int NF = P.NF, NP = P.NP;
   const double* feat_uv = feat_uv_all + (size_t)f * NF * 2;
   const float* feat_ur = feat_ur_all + (size_t)f * NF;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
   const uint32_t* mp_desc = (const uint32_t*)(mp_desc_all + (size_t)f * NP * 32);
 
   // ---- assignFeaturesToGrid: CSR by cell (ix * GR + iy), ascending feature index inside a cell ----
-  for (int c = tid; c <= NCELL; c += T_M) cell_ptr[c] = 0;
+  for (int c = tid; c <= NCELL; c += TM) cell_ptr[c] = 0;
   __syncthreads();
   auto cell_of = [&](int i) -> int {
     if (feat_oct[i] < 0) return -1;  // padding slot
@@ -117,28 +125,28 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     if (!(px >= 0 && px < GC && py >= 0 && py < GR)) return -1;  // also rejects NaN
     return (int)px * GR + (int)py;
   };
-  for (int i = tid; i < NF; i += T_M) {
+  for (int i = tid; i < NF; i += TM) {
     const int c = cell_of(i);
     if (c >= 0) atomicAdd(&cell_ptr[c + 1], 1);
   }
   __syncthreads();
   {  // exclusive scan of NCELL counts: each thread scans a contiguous chunk, then the chunk sums
-    constexpr int CH = (NCELL + T_M - 1) / T_M;
+    constexpr int CH = (NCELL + TM - 1) / TM;
     const int c0 = tid * CH, c1 = min(NCELL, c0 + CH);
     int s = 0;
     for (int c = c0; c < c1; ++c) s += cell_ptr[c + 1];
-    s_scan[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-      int run = 0;
-      for (int t = 0; t < T_M; ++t) {
-        const int v = s_scan[t];
-        s_scan[t] = run;
-        run += v;
-      }
+    // exclusive scan of the TM chunk sums: shuffle scan inside each wave, then the wave totals
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if ((tid & 63) >= o) inc += up;
     }
+    if ((tid & 63) == 63) s_scan[tid >> 6] = inc;
     __syncthreads();
-    int run = s_scan[tid];
+    int run = inc - s;
+    for (int w = 0; w < (tid >> 6); ++w) run += s_scan[w];
+    __syncthreads();  // s_scan is reused below
     for (int c = c0; c < c1; ++c) {
       const int v = cell_ptr[c + 1];
       cell_ptr[c + 1] = run + v;  // inclusive end; cell_ptr[c] (= end of c-1) is its start
@@ -148,14 +156,14 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
   }
   // fill through a per-cell cursor, then put every (short) cell list in ascending feature order: that
   // is the push_back order of the reference and decides ties between equal Hamming distances
-  for (int c = tid; c < NCELL; c += T_M) cursor[c] = 0;
+  for (int c = tid; c < NCELL; c += TM) cursor[c] = 0;
   __syncthreads();
-  for (int i = tid; i < NF; i += T_M) {
+  for (int i = tid; i < NF; i += TM) {
     const int c = cell_of(i);
     if (c >= 0) cell_idx[cell_ptr[c] + atomicAdd(&cursor[c], 1)] = i;
   }
   __syncthreads();
-  for (int c = tid; c < NCELL; c += T_M) {
+  for (int c = tid; c < NCELL; c += TM) {
     const int e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
     for (int e = e0 + 1; e < e1; ++e) {  // insertion sort
       const int v = cell_idx[e];
@@ -168,15 +176,20 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     }
   }
   __syncthreads();
-  for (int e = tid; e < cell_ptr[NCELL]; e += T_M) {
+  for (int e = tid; e < cell_ptr[NCELL]; e += TM) {
     const int i = cell_idx[e];
     rec_uv[e] = make_double2(feat_uv[2 * i], feat_uv[2 * i + 1]);
     rec_ro[e] = make_int2(__float_as_int(feat_ur[i]), feat_oct[i]);
+    if (DL) {
+      const uint4* src = (const uint4*)(feat_desc + (size_t)i * 8);
+      rec_desc[2 * e] = src[0];
+      rec_desc[2 * e + 1] = src[1];
+    }
   }
   __syncthreads();
 
   // ---- owners on entry -------------------------------------------------------------------------------
-  for (int i = tid; i < NF; i += T_M) owner[i] = feat_taken[i] ? -1 : INT_MAX;
+  for (int i = tid; i < NF; i += TM) owner[i] = feat_taken[i] ? -1 : INT_MAX;
   __syncthreads();
 
   if (MODE == 1 && tid == 0) {  // current pose, direction of motion (orb_matcher.cpp:421-428)
@@ -249,12 +262,15 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     return q;
   };
 
+#ifdef GL_MATCH_PROF
+  const long long tp1 = clock64();
+#endif
   int rounds = 0;
   while (true) {
-    for (int i = tid; i < NF; i += T_M) owner_n[i] = feat_taken[i] ? -1 : INT_MAX;
+    for (int i = tid; i < NF; i += TM) owner_n[i] = feat_taken[i] ? -1 : INT_MAX;
     if (tid == 0) s_changed = 0;
     __syncthreads();
-    for (int m = tid; m < NP; m += T_M) {
+    for (int m = tid; m < NP; m += TM) {
       int bestIdx = -1;
       const Query q = make_query(m);
       if (q.valid) {
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
                 const float er = q.ur_float ? fabsf(q.ur_f - ur) : (float)fabs(q.ur_d - (double)ur);
                 if (er > rr) continue;
               }
-              const int dist = hamming256(dm, feat_desc + (size_t)idx * 8);
+              const int dist = DL ? hamming256(dm, (const uint32_t*)(rec_desc + 2 * e)) : hamming256(dm, feat_desc + (size_t)idx * 8);
               if (dist < bestDist) {
                 bestDist2 = bestDist;
                 bestDist = dist;
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     }
     __syncthreads();
     int ch = 0;
-    for (int i = tid; i < NF; i += T_M) {
+    for (int i = tid; i < NF; i += TM) {
       const int o = owner_n[i];
       if (o != owner[i]) ch = 1;
       owner[i] = o;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     };
     if (tid < 32) s_hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < NF; i += T_M) {
+    for (int i = tid; i < NF; i += TM) {
       const int o = owner[i];
       if (o >= 0 && o != INT_MAX) {
         const int b = bin_of(i);
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
       s_keep[2] = ind3;
     }
     __syncthreads();
-    for (int i = tid; i < NF; i += T_M) {
+    for (int i = tid; i < NF; i += TM) {
       const int o = owner[i];
       if (o >= 0 && o != INT_MAX) {
         const int b = bin_of(i);
@@ -388,21 +404,32 @@ __global__ __launch_bounds__(T_M) void k_search_by_projection(
     __syncthreads();
   }
 
+#ifdef GL_MATCH_PROF
+  const long long tp2 = clock64();
+#endif
   // ---- outputs ------------------------------------------------------------------------------------------
   int32_t* feat_match = feat_match_all + (size_t)f * NF;
   int cnt = 0;
-  for (int i = tid; i < NF; i += T_M) {
+  for (int i = tid; i < NF; i += TM) {
     const int o = owner[i];
     const bool matched = o >= 0 && o != INT_MAX;
     feat_match[i] = matched ? o : -1;
     cnt += matched ? 1 : 0;
   }
-  s_scan[tid] = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((tid & 63) == 0) s_scan[tid >> 6] = cnt;
   __syncthreads();
   if (tid == 0) {
     int tot = 0;
-    for (int t = 0; t < T_M; ++t) tot += s_scan[t];
+    for (int w = 0; w < TM / 64; ++w) tot += s_scan[w];
     nmatches_all[f] = tot;
+#ifdef GL_MATCH_PROF
+    feat_match[0] = (int)((tp1 - tp0) >> 4);
+    feat_match[1] = (int)((tp2 - tp1) >> 4);
+    feat_match[2] = (int)((clock64() - tp2) >> 4);
+    feat_match[3] = rounds;
+#endif
   }
 }
 
@@ -439,10 +466,17 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
   P.height = cam->height;
   P.mono = mono;
   P.check_orientation = check_orientation;
-  const size_t lds = (((size_t)2 * NCELL + 1 + 3 * (size_t)NF + NP + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 24;
-  auto kern = mode == 0 ? k_search_by_projection<0> : k_search_by_projection<1>;
-  GL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  kern<<<B, T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
+  size_t lds = (((size_t)2 * NCELL + 1 + 3 * (size_t)NF + NP + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 24;
+  // latency shape (no more frames than CUs): descriptors in LDS as well, if they fit
+  const size_t lds_dl = lds + 8 + (size_t)NF * 32;
+  bool dl = B <= c->ncu && lds_dl <= 160 * 1024 - 8 * 1024;
+  if (const char* e = getenv("GMMLOC_MATCH_DESC_LDS")) dl = atoi(e) != 0 && lds_dl <= 160 * 1024 - 8 * 1024;
+  if (dl) lds = lds_dl;
+  auto kern = mode == 0 ? (dl ? k_search_by_projection<0, true> : k_search_by_projection<0, false>)
+                        : (dl ? k_search_by_projection<1, true> : k_search_by_projection<1, false>);
+  static size_t lds_set[4] = {0, 0, 0, 0};  // per instantiation
+  GL_HIP(gl::ensure_dynamic_lds((const void*)kern, lds, &lds_set[(mode ? 2 : 0) + (dl ? 1 : 0)]));
+  kern<<<B, dl ? 1024 : T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
                                    mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle);
   GL_HIP(hipGetLastError());
   return GL_OK;
