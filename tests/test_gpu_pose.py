@@ -14,7 +14,9 @@ TOL_T, TOL_R = 1e-6, 1e-6
 def pose_err(a, b):
     Ra, Rb = synth.quat_to_R(a[:4]), synth.quat_to_R(b[:4])
     dR = Ra @ Rb.T
-    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
+    # rotation angle from the skew part (|sin| ~ angle): arccos of the trace has a 1e-8 noise floor at zero
+    sk = 0.5 * np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]])
+    ang = np.arctan2(np.linalg.norm(sk), (np.trace(dR) - 1) / 2)
     return np.linalg.norm(a[4:] - b[4:]), ang
 
 
