@@ -117,6 +117,13 @@ def test_knn3d_and_query_point(gpu, oracle, map_v1, map_v2, which):
         assert np.array_equal(gi.cpu().numpy(), ni)
     q = g.queryPoint(torch.from_numpy(pts).cuda())
     assert np.array_equal(q.cpu().numpy(), ki[:, 0])
+    # few queries run a wave per query, many a thread per query: both kernels, other k, ties through duplicated means
+    big = np.concatenate([synth.synth_points(mean, cov, 9000, 10), mean[:200], 0.5 * (mean[:100] + mean[1:101])])
+    for k in (1, 3, 8):
+        ki2, kd2, _ = oracle.knn3d(h, big, k)
+        for sl in (slice(0, 9300), slice(9000, 9300), slice(9299, 9300)):  # 9 300 -> thread kernel, 300 / 1 -> wave kernel
+            gi2, gd2 = g.knn3d(torch.from_numpy(big[sl]).cuda(), k)
+            assert np.array_equal(gi2.cpu().numpy(), ki2[sl]) and np.array_equal(gd2.cpu().numpy(), kd2[sl])
     oracle.gmm_destroy(h)
 
 
