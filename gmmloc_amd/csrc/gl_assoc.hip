@@ -16,7 +16,8 @@
 //
 //  k_knn3d       : exact k-NN (k <= 8) on the means, ascending squared L2,
 //                  ties by lower index (GMM::queryPoint's knnSearch,
-//                  gaussian_mixture.cpp:553-558).
+//                  gaussian_mixture.cpp:553-558); a thread per query, or a wave per
+//                  query (k_knn3d_wave) when the queries are few.
 //
 // Compiled with -ffp-contract=off; the only fused ops are the explicit fma()
 // of the canonical chi2 (gl_device.hpp) -> bit-identical to the fp64 CPU order.

@@ -13,7 +13,8 @@
 // is rebuilt with LDS atomics; by induction the choices of map points 0..r-1 are final after round
 // r, and the iteration stops when the owner table repeats (2-5 rounds on realistic frames).
 //
-// One workgroup per frame; grid CSR, owner tables and choices live in LDS.  Every float / double
+// One workgroup per frame (512 threads in batches; 1 024 and the descriptors in LDS as well when there are no more
+// frames than CUs); grid CSR, owner tables and choices live in LDS.  Every float / double
 // conversion of the reference (float window, float grid scale, double feature coordinates) is kept
 // so that the candidate sets, their visiting order (cell column, cell row, feature index) and hence
 // the ties are identical.

@@ -1,7 +1,8 @@
-// Point refinement against the GMM, one thread per independent problem:
-//   k_optimize_point        GMMLoc::optimizePoint              (gmmloc_opt.cpp:260-342)   B1
-//   k_check_map_association GMMLoc::checkMapAssociation        (gmmloc_opt.cpp:156-258)   A8
-//   k_optimize_triangulation Localization::optimizeTriangulationVec (localization_opt.cpp:27-204) B2
+// Point refinement against the GMM:
+//   k_optimize_point        GMMLoc::optimizePoint              (gmmloc_opt.cpp:260-342)   B1   a thread per problem
+//   k_check_map_association GMMLoc::checkMapAssociation        (gmmloc_opt.cpp:156-258)   A8   a DPP row (16 lanes) per feature
+//   k_optimize_triangulation Localization::optimizeTriangulationVec (localization_opt.cpp:27-204) B2   a DPP row per match
+// (A8 / B2: one candidate component per lane, the ordered choices of the reference as lexicographic row argmins.)
 // Each problem is a 3-DoF Gauss-Newton (g2o OptimizationAlgorithmGaussNewton, BlockSolverX +
 // LinearSolverEigen on one 3x3 block) over EdgeProjectXYZOnly{,Stereo} + EdgePt2GaussianDeg
 // (factors.cpp:55-168).  The reference pays a g2o graph construction (heap allocations,
