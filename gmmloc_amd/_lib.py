@@ -45,6 +45,8 @@ def load():
         "gl_ctx_destroy": (i32, [vp]),
         "gl_ctx_synchronize": (i32, [vp]),
         "gl_ctx_stream": (vp, [vp]),
+        "gl_ctx_set_option": (i32, [vp, C.c_char_p, C.c_double]),
+        "gl_ctx_get_option": (i32, [vp, C.c_char_p, P(C.c_double)]),
         "gl_ctx_timing_enable": (i32, [vp, i32]),
         "gl_ctx_timing_read": (i32, [vp, i32, P(C.c_double), P(i64), i32]),
         "gl_ctx_set_stats_buffer": (i32, [vp, vp, i32]),

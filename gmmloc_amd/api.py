@@ -105,6 +105,15 @@ class Context:
     def synchronize(self):
         _check(self.lib.gl_ctx_synchronize(self.h))
 
+    def set_option(self, name, value):
+        """gl_ctx_set_option: tuning / test knob of this context (see include/gmmloc_hip.h)."""
+        _check(self.lib.gl_ctx_set_option(self.h, name.encode(), float(value)))
+
+    def get_option(self, name):
+        v = C.c_double()
+        _check(self.lib.gl_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def timing(self, on):
         _check(self.lib.gl_ctx_timing_enable(self.h, 1 if on else 0))
 

@@ -1,6 +1,7 @@
 // Context management, error strings, params, device-memory helpers.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gl_internal.hpp"
@@ -14,6 +15,30 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// option table: name as in gl_ctx_set_option; the environment variable is GMMLOC_<NAME IN CAPITALS>
+#define GL_OPTION_LIST(X) \
+  X(ba_shape) X(ba_step32) X(ba_slow) X(pose_waves) X(pose_coop) X(bagen_nb) X(view_slot_lds) X(view_threads) \
+  X(assoc_index_min) X(match_desc_lds)
+double* option_slot(Options& o, const char* name) {
+#define X(n) \
+  if (strcmp(name, #n) == 0) return &o.n;
+  GL_OPTION_LIST(X)
+#undef X
+  return nullptr;
+}
+static void options_from_env(Options& o) {
+#define X(n)                                          \
+  {                                                   \
+    char var[64] = "GMMLOC_";                         \
+    size_t k = strlen(var);                           \
+    for (const char* p = #n; *p && k + 1 < sizeof(var); ++p) var[k++] = (char)((*p >= 'a' && *p <= 'z') ? *p - 32 : *p); \
+    var[k] = 0;                                       \
+    if (const char* e = getenv(var)) o.n = atof(e);   \
+  }
+  GL_OPTION_LIST(X)
+#undef X
 }
 
 int ctx_scratch(Ctx* c, size_t bytes, void** out) {
@@ -113,6 +138,7 @@ int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out) {
   c->device = device;
   if (hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->ncu <= 0) c->ncu = 256;
   c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
+  gl::options_from_env(c->opt);         // the only place the knobs are read from the environment
   *out = (gl_ctx_t*)c;
   return GL_OK;
 }
@@ -133,9 +159,33 @@ int gl_ctx_destroy(gl_ctx_t* ctx) {
   return GL_OK;
 }
 
+// (the null stream belongs to the calling thread's CURRENT device: every entry point that touches the stream
+// makes the context's device current first)
 int gl_ctx_synchronize(gl_ctx_t* ctx) {
   GL_REQUIRE(ctx, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
   GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
+  return GL_OK;
+}
+
+int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value) {
+  GL_REQUIRE(ctx && name, "null argument");
+  double* slot = gl::option_slot(gl::C(ctx)->opt, name);
+  if (!slot) {
+    gl::set_error("gl_ctx_set_option: unknown option '%s'", name);
+    return GL_ERR_ARG;
+  }
+  *slot = value;
+  return GL_OK;
+}
+int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value) {
+  GL_REQUIRE(ctx && name && value, "null argument");
+  const double* slot = gl::option_slot(gl::C(ctx)->opt, name);
+  if (!slot) {
+    gl::set_error("gl_ctx_get_option: unknown option '%s'", name);
+    return GL_ERR_ARG;
+  }
+  *value = *slot;
   return GL_OK;
 }
 
@@ -178,17 +228,20 @@ int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out) {
 }
 int gl_free(gl_ctx_t* ctx, void* dev) {
   GL_REQUIRE(ctx, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
   if (dev) GL_HIP(hipFree(dev));
   return GL_OK;
 }
 int gl_memcpy_h2d(gl_ctx_t* ctx, void* dst_dev, const void* src, size_t bytes) {
   GL_REQUIRE(ctx && dst_dev && src, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
   GL_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, gl::C(ctx)->stream));
   GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
   return GL_OK;
 }
 int gl_memcpy_d2h(gl_ctx_t* ctx, void* dst, const void* src_dev, size_t bytes) {
   GL_REQUIRE(ctx && dst && src_dev, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
   GL_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, gl::C(ctx)->stream));
   GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
   return GL_OK;

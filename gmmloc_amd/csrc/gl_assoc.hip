@@ -281,23 +281,35 @@ namespace gl {
 //  * points per thread: 4 amortises the broadcast LDS reads best once there are enough points;
 //  * K splits: aim for ~4096 workgroups so the tail is short; a single 2 000-point frame still
 //    gets 8 x 64 workgroups.
-static int assoc_minchunk() {
-  if (const char* e = getenv("GMMLOC_ASSOC_CHUNK")) return atoi(e) == 16 ? 16 : 8;  // tuning knob
-  return 8;
+// launch-shape tuning knobs of tools/tune_assoc.py (GMMLOC_ASSOC_CHUNK / _PPT / _NSPLIT): process-wide, read from
+// the environment ONCE (first use), never on the call path
+struct AssocTune {
+  int chunk = 8, ppt = 0, nsplit = 0;
+};
+static const AssocTune& assoc_tune() {
+  static const AssocTune t = [] {
+    AssocTune a;
+    if (const char* e = getenv("GMMLOC_ASSOC_CHUNK")) a.chunk = atoi(e) == 16 ? 16 : 8;
+    if (const char* e = getenv("GMMLOC_ASSOC_PPT")) a.ppt = atoi(e);
+    if (const char* e = getenv("GMMLOC_ASSOC_NSPLIT")) a.nsplit = atoi(e);
+    return a;
+  }();
+  return t;
 }
+static int assoc_minchunk() { return assoc_tune().chunk; }
 static void assoc_shape(int K, int N, int* ppt_o, int* ptiles_o, int* nsplit_o, int* kchunk_o) {
   const int kChunk = assoc_minchunk();
   int ppt = 1;
   if (N >= 8192) ppt = 2;
   if (N >= 16384) ppt = 4;
-  if (const char* e = getenv("GMMLOC_ASSOC_PPT")) ppt = atoi(e);  // tuning knob (1, 2 or 4)
+  if (assoc_tune().ppt > 0) ppt = assoc_tune().ppt;  // tuning knob (1, 2 or 4)
   const int ptiles = (N + 256 * ppt - 1) / (256 * ppt);
   const int target_blocks = (N >= 8192) ? 4096 : 512;
   int nsplit = (target_blocks + ptiles - 1) / ptiles;
   const int max_split = (K + 63) / 64;  // >= 64 Gaussians per split
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
-  if (const char* e = getenv("GMMLOC_ASSOC_NSPLIT")) nsplit = atoi(e);  // tuning knob
+  if (assoc_tune().nsplit > 0) nsplit = assoc_tune().nsplit;  // tuning knob
   int kchunk = (K + nsplit - 1) / nsplit;
   kchunk = (kchunk + kChunk - 1) / kChunk * kChunk;  // whole min-chunks per split
   nsplit = (K + kchunk - 1) / kchunk;
@@ -416,7 +428,7 @@ int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, in
   GL_HIP(hipSetDevice(c->device));
   // small problems are launch-bound: the sweep's two launches beat index + list + sweep of the rest
   double min_pairs = 6.7e7;
-  if (const char* e = getenv("GMMLOC_ASSOC_INDEX_MIN")) min_pairs = atof(e);  // knob (tests force the index with 0)
+  if (c->opt.assoc_index_min >= 0) min_pairs = c->opt.assoc_index_min;  // option (tests force the index with 0)
   const bool small = (double)N * g->K < min_pairs;
   if (mode == GL_ASSOC_EXHAUSTIVE || (mode == GL_ASSOC_BRUTE && (!g->grid.enabled || small)))
     return gl::launch_assoc_brute(c, g, pts_dev, N, idx_dev, d2_dev);

@@ -502,9 +502,8 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   else
     rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
   if (rc != GL_OK) return rc;
-  // on-chip fast path (gl_ba_fast.hip) for M <= 2048; GMMLOC_BA_SLOW=1 forces the general kernel
-  static const bool force_slow = getenv("GMMLOC_BA_SLOW") != nullptr;
-  if (!force_slow && gl::ba1_fast_supported(M))
+  // on-chip fast path (gl_ba_fast.hip) for M <= 2000; option ba_slow forces the general kernel
+  if (c->opt.ba_slow == 0 && gl::ba1_fast_supported(M))
     return gl::launch_ba1_fast(c, g, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
                                nullptr, nullptr, nullptr, scratch);
   return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, nullptr, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,

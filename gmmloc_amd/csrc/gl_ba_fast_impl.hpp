@@ -1,43 +1,53 @@
-// (included by gl_ba_fast.hip once per block shape: GL_BAF_NS / GL_BAF_TF / GL_BAF_MCAP)
-// On-chip fast path of the single-pose structure-constrained refinement (same algorithm and
-// control flow as k_ba1 in gl_ba.hip, which stays as the general / large-M path and as the
-// A/B reference).  For M <= 2000 points per frame:
-//   * 512 threads (8 waves, 2 per SIMD) per frame; the frame's mutable state lives in LDS as
-//     SoA for the whole 5/5/40 schedule: current point (3 fp64), stale chi2 (1 fp64) and a
-//     12-word slot with two lifetimes -- between the two passes of a Levenberg trial it caches
-//     the per-point solve in fp32 {u = D^-1 b, A D^-1}, so pass B computes the point step
-//     eps = u - (A D^-1)^T (omega x q + upsilon) without re-linearising (the step only needs
-//     ~1e-7 relative accuracy, the trial state is then evaluated exactly in fp64; D^-1 itself
-//     is NOT cached: its 1/lambda eigenvalue along an unconstrained ray would swamp fp32);
-//     after pass B it holds the backup of the point while the trial point sits in place
-//     (nothing to copy on acceptance).  80 B/point = 160 000 B + 2.6 KB of reduction scratch
-//     of the CU's 160 KB.  Flag / level / octave bits of a thread's 4 points are a 64-bit
-//     register word.  A trial touches global memory only for the read-only observations and
-//     plane records (56 B/point per pass, coalesced); measured (cache-hot substitute) their
-//     latency is fully hidden by the second wave of the SIMD;
-//   * computeScale is evaluated as  lambda (sum|eps|^2 + |dx|^2) + sum u.b + dx.g  (the b-terms
-//     of the point blocks collapse onto the reduced rhs g), so pass B needs neither b nor A;
-//   * the pose is kept as (R, t) in SGPRs (v_readfirstlane after the solve: there is no scalar
-//     fp64 ALU, uniform results otherwise occupy VGPRs) and updated by Rodrigues directly
-//     (short series for |theta| < 0.01); reciprocals / inverse square roots use v_rcp_f64 /
-//     v_rsq_f64 + two Newton steps instead of the IEEE division sequence; Huber is branch-free;
-//   * fp64 needs 2 VGPRs per value, so the per-point working set (not the data) is what limits
-//     occupancy: one point at a time per thread in rolled loops, no spills in the trial loop;
-//   * two-level deterministic reduction: wave reduce-scatter (v_permlane32/16_swap + DPP) ->
-//     LDS -> 32 lanes sum the 8 wave partials -> only the solving wave reads the totals back;
-//     the 6x6 LDL^T + exp() run on wave 0 and are broadcast through LDS.
-// The kernel is VALU-issue bound (every wave64 instruction holds its SIMD for 4 cycles; ~3100
-// instructions per wave and trial at 2 waves/SIMD + ~450 on the serial solve).  Measured and
-// dropped: software prefetch (spills), alternating s_setprio between the two waves of a SIMD
-// (-1.4 %), trial pose through LDS, 256-thread blocks; see DESIGN.md section 8.
-// Results agree with k_ba1 / the oracle to the north-star tolerance (tests/test_gpu_track.py).
+// (included by gl_ba_fast.hip once per instance: GL_BAF_NS / GL_BAF_MCAP / GL_BAF_NW / GL_BAF_SPREAD / GL_BAF_STEP32)
+// On-chip fast path of the single-pose structure-constrained refinement (same algorithm and control flow as
+// k_ba1 in gl_ba.hip, which stays as the general / large-M path and as the A/B reference), M <= 2000 points.
+//
+// ONE summation order for every launch shape.  The result of a frame must not depend on how many frames ride
+// in the call, so the order in which the per-point terms of every sum are added is a function of the frame's
+// stride L alone (the "canonical order"):
+//     chunks   c = l / 64 (64 consecutive points), nch = ceil(L / 64)
+//     groups   G = ceil(nch / 4) groups of S = ceil(nch / G) <= 4 consecutive chunks
+//     level 1  lane j of group g adds the terms of its points (g S + i) 64 + j, i = 0 .. S-1, in that order
+//     level 2  the 64 lane sums of a group meet in the butterfly tree of gld::wave_reduce_scatter32
+//              (partners 32, 16, 1, 2, 4, 8 lanes apart)
+//     level 3  blocks of two groups, B_k = g_2k + g_2k+1, then ((B_0 + B_1) + B_2) + B_3.
+// Two kernels realise it, with the SAME per-point code (pt_lin / pt_pass_a / pt_pass_b below, every term is
+// rounded on its own before it enters a sum: add_nc):
+//   * DENSE  (batches): one workgroup of G waves per frame, wave g = group g, a thread owns the S points of its
+//     lane and keeps level 1 in registers; 1 / 2 / 4 frames per CU by LDS class (MCAP 2000 / 1000 / 496);
+//   * SPREAD (few frames, the frame-at-a-time caller): one point per thread, 512 threads per workgroup =
+//     one block of two groups, ceil(G / 2) co-resident workgroups per frame (cooperative launch when > 1);
+//     level 1 runs through an LDS transpose (term [value][wave][lane]): the S waves of a group share its
+//     values, add the S terms of each lane in slot order and finish with the same butterfly
+//     (wave_reduce_scatter8); level 3 crosses the workgroups through gld::coop_totals in block order.
+// tests/test_gpu_track.py::test_track_frames_bit_identical_across_shapes holds the two to equal bits.
+//
+// Per-frame state in LDS, SoA over the points, for the whole 5/5/40 schedule: current point (3 fp64), stale
+// chi2 (1 fp64) and a 48-byte slot with two lifetimes: between the two passes of a Levenberg trial it holds
+// the damped point block inverse D^-1 (6 fp64) of pass A, so that pass B computes the point step
+//     eps = D^-1 (b - A (omega x q + upsilon)) = D^-1 (Jpi^T W (e - Jpi gd) + b_gmm)
+// exactly in fp64 from the re-evaluated residual (no fp32 anywhere; GL_BAF_STEP32 instead caches the fp32
+// pair {u = D^-1 b, A D^-1} of round 1: ~8 % faster, but its 1e-7 step error is amplified by badly conditioned
+// frames - off by default, gl_ctx_set_option("ba_step32", 1)); after pass B the slot holds the backup of the
+// point while the trial point sits in place (nothing to copy on acceptance).  80 B/point.
+// computeScale is  lambda (sum|eps|^2 + |dx|^2) + sum u.b + dx.g ; the pose is (R, t) in SGPRs; rcp / rsq +
+// two Newton steps; branch-free Huber; the 6x6 LDL^T + exp() run on wave 0 and are broadcast through LDS.
 namespace {
 namespace GL_BAF_NS {
 
-constexpr int TF = GL_BAF_TF;      // threads per frame
-constexpr int NWF = TF / 64;
-constexpr int PPTF = 4;            // point slots per thread (rolled loop)
-constexpr int MCAP = GL_BAF_MCAP;  // LDS capacity in points: 80 B/point (+ 2.6 KB reduction / broadcast)
+constexpr int MCAP = GL_BAF_MCAP;  // LDS capacity in points
+#if GL_BAF_SPREAD
+constexpr bool kSpread = true;
+#else
+constexpr bool kSpread = false;
+#endif
+#if GL_BAF_STEP32
+constexpr bool kStep32 = true;
+#else
+constexpr bool kStep32 = false;
+#endif
+constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of this LDS class has at most
+constexpr int NRED = kSpread ? 2 : NWC;    // group totals kept in LDS (a SPREAD workgroup is one block of two groups)
 
 #ifdef GL_BA_PROF
 __device__ unsigned long long g_prof[16];
@@ -53,6 +63,13 @@ __device__ unsigned long long g_prof[16];
 #endif
 
 enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32 };
+
+// a + b that is never contracted with a multiplication feeding it: every term of a canonical sum is rounded on
+// its own, whichever kernel adds it (this file is compiled with contraction allowed)
+GL_DEV double add_nc(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 
 GL_DEV double rcp_nr(double a) {
   double x = __builtin_amdgcn_rcp(a);
@@ -146,25 +163,27 @@ GL_DEV Pose pose_update(const Pose& P, const double* u) {
   return N;
 }
 
-struct Lds {      // per-frame state, SoA over MCAP points
+struct Lds {      // per-frame state, SoA over MCAP points (index = local point index)
   double* sp;     // 3 x MCAP  current point (world)
   double* chir;   // MCAP      stale chi2 of the reprojection edge (e->chi2())
-  // 12 x MCAP 32-bit words, two lifetimes sharing one slot per point:
-  //   pass A -> pass B : fp32 {u = D^-1 b (3), A D^-1 (3x3)} -- the per-point solve, so pass B does not
-  //                      re-linearise: eps = u - (A D^-1)^T gd.  Both are O(1)-conditioned (unlike D^-1
-  //                      itself, whose 1/lambda eigenvalue along an unconstrained ray would swamp fp32),
-  //                      and the step only needs ~1e-7 relative accuracy: the trial state it produces is
-  //                      evaluated exactly in fp64;
-  //   pass B -> accept : backup of the point (3 x {lo, hi} words, exact fp64) while the trial point sits
-  //                      in `sp`; restored only when the trial is rejected.
-  int* un;
+  // 6 x MCAP doubles, two lifetimes sharing one slot per point:
+  //   pass A -> pass B : D^-1 (sym6, fp64)   [GL_BAF_STEP32: 12 fp32 words {u = D^-1 b (3), A D^-1 (3x3)}]
+  //   pass B -> accept : backup of the point (3 fp64) while the trial point sits in `sp`; restored only
+  //                      when the trial is rejected.
+  double* un;
   double* stab;   // 8: 1/sigma^2 per pyramid octave
 };
-// per-point flag bits + octave (bits 8..10) live in REGISTERS: thread t owns points t + i*TF, i < 4,
-// 16 bits each in one 64-bit word
+// per-point flag bits + octave (bits 8..10) live in REGISTERS: 16 bits per point slot of the thread
 typedef unsigned long long FlagW;
 GL_DEV int fw_get(FlagW fw, int i) { return (int)((fw >> (16 * i)) & 0xffffull); }
 GL_DEV void fw_or(FlagW& fw, int i, int bits) { fw |= (FlagW)bits << (16 * i); }
+
+// the canonical order of a frame of stride L and this thread's place in it
+struct Map {
+  int S;      // point slots of this thread (DENSE: chunks per group; SPREAD: 1)
+  int base;   // frame-local index of the thread's first point; slot i is base + 64 i
+  int lbase;  // LDS index of the first point (DENSE: = base; SPREAD: threadIdx.x)
+};
 
 struct Lin {
   double q[3];
@@ -197,8 +216,12 @@ GL_DEV double gmm_nondeg(const GmmDev& gm, int a, const double* R, const double*
   double Hd[3];
   sym3_mul_vec(Hg, d, Hd);
   const double chi = d[0] * Hd[0] + d[1] * Hd[1] + d[2] * Hd[2];
+  if (bc) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bc[i] = -(R[i * 3] * Hd[0] + R[i * 3 + 1] * Hd[1] + R[i * 3 + 2] * Hd[2]);
+  }
   if (Hc) {
-    // Hc = R Hg R^T, bc = -R Hg d
+    // Hc = R Hg R^T
     double RH[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -212,10 +235,23 @@ GL_DEV double gmm_nondeg(const GmmDev& gm, int a, const double* R, const double*
     Hc[3] = RH[3] * R[3] + RH[4] * R[4] + RH[5] * R[5];
     Hc[4] = RH[3] * R[6] + RH[4] * R[7] + RH[5] * R[8];
     Hc[5] = RH[6] * R[6] + RH[7] * R[7] + RH[8] * R[8];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) bc[i] = -(R[i * 3] * Hd[0] + R[i * 3 + 1] * Hd[1] + R[i * 3 + 2] * Hd[2]);
   }
   return chi;
+}
+
+// Jpi of the (stereo) projection at camera point q: rows (al, 0, b0), (0, ga, b1) and, stereo only, (al, 0, b2)
+struct Jpi {
+  double al, ga, b0, b1, b2;
+};
+GL_DEV Jpi jpi_at(const BaK& k, const double* q, double iz) {
+  Jpi J;
+  const double iz2 = iz * iz;
+  J.al = k.fx * iz;
+  J.ga = k.fy * iz;
+  J.b0 = -k.fx * q[0] * iz2;
+  J.b1 = -k.fy * q[1] * iz2;
+  J.b2 = fma(k.bf, iz2, J.b0);
+  return J;
 }
 
 // linearise point l at pose P and world point p; returns the un-robustified chi2_r
@@ -241,22 +277,19 @@ GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const doub
       const double dl = stereo ? k.delta_stereo : k.delta_mono;
       huber_bf(chi_r, dl, dl * dl, o.rho0_r, rho1);
     }
-    // rows of Jpi: (al, 0, b0), (0, ga, b1) and, stereo only, (al, 0, b2); t = w on the stereo row, else 0
+    // t = w on the stereo row, else 0
     const double w = rho1 * s;
     const double t = stereo ? w : 0.0;
-    const double iz2 = iz * iz;
-    const double al = k.fx * iz, ga = k.fy * iz;
-    const double b0 = -k.fx * o.q[0] * iz2, b1 = -k.fy * o.q[1] * iz2;
-    const double b2 = fma(k.bf, iz2, b0);
-    const double wga = w * ga, tb2 = t * b2;
-    o.A[0] = (w + t) * al * al;
-    o.A[2] = al * fma(t, b2, w * b0);
-    o.A[3] = wga * ga;
-    o.A[4] = wga * b1;
-    o.A[5] = fma(tb2, b2, w * fma(b1, b1, b0 * b0));
-    o.a[0] = al * fma(t, e[2], w * e[0]);
+    const Jpi J = jpi_at(k, o.q, iz);
+    const double wga = w * J.ga, tb2 = t * J.b2;
+    o.A[0] = (w + t) * J.al * J.al;
+    o.A[2] = J.al * fma(t, J.b2, w * J.b0);
+    o.A[3] = wga * J.ga;
+    o.A[4] = wga * J.b1;
+    o.A[5] = fma(tb2, J.b2, w * fma(J.b1, J.b1, J.b0 * J.b0));
+    o.a[0] = J.al * fma(t, e[2], w * e[0]);
     o.a[1] = wga * e[1];
-    o.a[2] = fma(tb2, e[2], w * fma(b1, e[1], b0 * e[0]));
+    o.a[2] = fma(tb2, e[2], w * fma(J.b1, e[1], J.b0 * e[0]));
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) o.D[c] = o.A[c];
@@ -322,10 +355,21 @@ GL_DEV void point_solve_fast(const Lin& o, double lambda, double* Dinv, double* 
   sym3_mul_vec(Dinv, o.b, u);
 }
 
-// acc[0..20] += upper(G^T C G), acc[21..26] += G^T c,  C symmetric (sym6)  (callers pass a zeroed v)
-GL_DEV void accum_pose_sym(const double* q, const double* C, const double* c, double* acc) {
-  // M = [q]x C (row r, column j) = (q x C[:, j])[r];  TL = [q]x C [q]x^T accumulated straight into acc
-  // with two FMAs per entry (explicit: contraction alone would leave mul + fma + add)
+// The terms of a point enter the sums through a sink: DENSE adds them to the thread's registers (level 1 of the
+// canonical order), SPREAD just keeps them (they go to the LDS transpose).  Each index is written once per point.
+struct SinkAcc {
+  double* a;
+  GL_DEV void put(int i, double v) const { a[i] = add_nc(a[i], v); }
+};
+struct SinkSet {
+  double* a;
+  GL_DEV void put(int i, double v) const { a[i] = v; }
+};
+
+// terms 0..20 <- upper(G^T C G), 21..26 <- G^T c,  G = [-[q]x | I], C symmetric (sym6)
+template <class Sink>
+GL_DEV void pose_terms(const double* q, const double* C, const double* c, bool with_rhs, const Sink& sk) {
+  // M = [q]x C (row r, column j) = (q x C[:, j])[r];  TL = [q]x C [q]x^T
   const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
   double M[9];
 #pragma unroll
@@ -334,33 +378,35 @@ GL_DEV void accum_pose_sym(const double* q, const double* C, const double* c, do
     M[3 + j] = fma(q[2], Cf[j], -q[0] * Cf[6 + j]);
     M[6 + j] = fma(q[0], Cf[3 + j], -q[1] * Cf[j]);
   }
-  acc[0] = fma(q[1], M[2], fma(-q[2], M[1], acc[0]));
-  acc[1] = fma(q[2], M[0], fma(-q[0], M[2], acc[1]));
-  acc[2] = fma(q[0], M[1], fma(-q[1], M[0], acc[2]));
-  acc[3] += M[0];
-  acc[4] += M[1];
-  acc[5] += M[2];
-  acc[6] = fma(q[2], M[3], fma(-q[0], M[5], acc[6]));
-  acc[7] = fma(q[0], M[4], fma(-q[1], M[3], acc[7]));
-  acc[8] += M[3];
-  acc[9] += M[4];
-  acc[10] += M[5];
-  acc[11] = fma(q[0], M[7], fma(-q[1], M[6], acc[11]));
-  acc[12] += M[6];
-  acc[13] += M[7];
-  acc[14] += M[8];
-  acc[15] += C[0];
-  acc[16] += C[1];
-  acc[17] += C[2];
-  acc[18] += C[3];
-  acc[19] += C[4];
-  acc[20] += C[5];
-  acc[21] = fma(q[1], c[2], fma(-q[2], c[1], acc[21]));
-  acc[22] = fma(q[2], c[0], fma(-q[0], c[2], acc[22]));
-  acc[23] = fma(q[0], c[1], fma(-q[1], c[0], acc[23]));
-  acc[24] += c[0];
-  acc[25] += c[1];
-  acc[26] += c[2];
+  sk.put(0, fma(q[1], M[2], -q[2] * M[1]));
+  sk.put(1, fma(q[2], M[0], -q[0] * M[2]));
+  sk.put(2, fma(q[0], M[1], -q[1] * M[0]));
+  sk.put(3, M[0]);
+  sk.put(4, M[1]);
+  sk.put(5, M[2]);
+  sk.put(6, fma(q[2], M[3], -q[0] * M[5]));
+  sk.put(7, fma(q[0], M[4], -q[1] * M[3]));
+  sk.put(8, M[3]);
+  sk.put(9, M[4]);
+  sk.put(10, M[5]);
+  sk.put(11, fma(q[0], M[7], -q[1] * M[6]));
+  sk.put(12, M[6]);
+  sk.put(13, M[7]);
+  sk.put(14, M[8]);
+  sk.put(15, C[0]);
+  sk.put(16, C[1]);
+  sk.put(17, C[2]);
+  sk.put(18, C[3]);
+  sk.put(19, C[4]);
+  sk.put(20, C[5]);
+  if (with_rhs) {
+    sk.put(21, fma(q[1], c[2], -q[2] * c[1]));
+    sk.put(22, fma(q[2], c[0], -q[0] * c[2]));
+    sk.put(23, fma(q[0], c[1], -q[1] * c[0]));
+    sk.put(24, c[0]);
+    sk.put(25, c[1]);
+    sk.put(26, c[2]);
+  }
 }
 
 // C = A - (A Dinv) A (symmetric sym6), AD = A Dinv (3x3)
@@ -374,75 +420,111 @@ GL_DEV void schur_C(const double* A, const double* AD, double* C) {
   }
 }
 
-// ---- latency shape (GL_BAF_COOPERATIVE): the points of ONE frame are dealt to NB workgroups -------------------
-// Every reduction of the optimiser then has a second level across the NB workgroups (gld::coop_totals: tagged
-// words, no barrier); all workgroups hold the same totals, so the Levenberg control flow (accept / reject,
-// lambda, termination) is identical in all of them and each repeats the 6x6 solve on its own.
-#ifdef GL_BAF_COOPERATIVE
-constexpr bool kCoop = true;
-#else
-constexpr bool kCoop = false;
-#endif
-// two-level deterministic workgroup reduction (all threads get the NV totals)
+// ---- reductions in the canonical order ---------------------------------------------------------------------
+// 8-value variant of gld::wave_reduce_scatter32 with the same lane pairings in the same order (32, 16, 1, 2, 4, 8):
+// in: v[0..7] per lane; out: every lane holds the wave total of value ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + (l0^l2)
+GL_DEV double wave_reduce_scatter8(double* v) {
+  const int lane = threadIdx.x & 63;
+  const int l0 = lane & 1, l2 = (lane >> 2) & 1;
+  rs_swap_stage<4, 32>(v);
+  rs_swap_stage<2, 16>(v);
+  rs_stage<1, 0>(v, l0 ^ l2);
+  double r = v[0];
+  r = r + dpp_f64<0x4E>(r);   // quad_perm [2,3,0,1]: lane ^ 2
+  r = r + dpp_f64<0x141>(r);  // row_half_mirror:     lane ^ 7
+  r = r + dpp_f64<0x140>(r);  // row_mirror:          lane ^ 15
+  return r;
+}
+
+struct Red {
+  double* red;   // NRED x 32: per group (DENSE: wave) totals
+  double* tot;   // 32 totals (+ 32 broadcast slots)
+  double* tb;    // SPREAD: transpose buffer [value][512]
+  int S;         // chunks per group
+};
+
+// totals of NV values over the frame -> tot[0..NV-1] (LDS), valid after the call for every thread.
+// DENSE: v[] holds the lane sums (level 1 done in registers).  SPREAD: v[] holds this thread's terms.
 template <int NV>
-GL_DEV void reduce2(double* v, double* red, double* tot, Coop& C) {
+GL_DEV void reduce_to_tot(double* v, const Red& R, Coop& C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!kSpread) {
 #pragma unroll
-  for (int i = NV; i < 32; ++i) v[i] = 0.0;
-  const double r = wave_reduce_scatter32(v);
-  // no barrier needed before writing `red`: its last readers (threads < 32) finished before the
-  // closing barrier of the previous reduction, which every thread has passed
-  if (wave_slot_owner(lane)) red[wave * 32 + wave_slot(lane)] = r;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    double s = red[threadIdx.x];
+    for (int i = NV; i < 32; ++i) v[i] = 0.0;
+    const double r = wave_reduce_scatter32(v);
+    // no barrier needed before writing `red`: its last readers (threads < 32) finished before the
+    // closing barrier of the previous reduction, which every thread has passed
+    if (wave_slot_owner(lane)) R.red[wave * 32 + wave_slot(lane)] = r;
+    __syncthreads();
+    if (threadIdx.x < 32) {  // absent groups hold zeros (never written after the initial clear); a class
+      // with fewer groups than 8 just has no further (all-zero) blocks to add
+      double s = NWC > 1 ? add_nc(R.red[threadIdx.x], R.red[32 + threadIdx.x]) : R.red[threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < NWF; ++w) s += red[w * 32 + threadIdx.x];
-    tot[threadIdx.x] = s;
+      for (int b = 1; b < NWC / 2; ++b) s = add_nc(s, add_nc(R.red[(2 * b) * 32 + threadIdx.x], R.red[(2 * b + 1) * 32 + threadIdx.x]));
+      R.tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+  } else {
+    // level 1 through LDS: term [value][wave][lane]
+#pragma unroll
+    for (int i = 0; i < NV; ++i) R.tb[i * 512 + threadIdx.x] = v[i];
+    __syncthreads();
+    const int S = R.S, gi = wave / S, slot = wave - gi * S;  // group of the block (0 / 1; >= 2: idle wave), slot in it
+    if (gi < 2) {
+      // the S waves of a group share its values in rounds of 8: wave `slot` takes rounds slot, slot + S, ...
+      for (int r8 = slot; r8 * 8 < NV; r8 += S) {
+        double y[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int val = r8 * 8 + kk;
+          double s = 0.0;
+          if (val < NV) {
+            for (int j = 0; j < S; ++j) s = add_nc(s, R.tb[val * 512 + (gi * S + j) * 64 + lane]);
+          }
+          y[kk] = s;
+        }
+        const double t8 = wave_reduce_scatter8(y);
+        if ((lane & 0xE) == 0) R.red[gi * 32 + r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1)] = t8;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) R.tot[threadIdx.x] = threadIdx.x < NV ? add_nc(R.red[threadIdx.x], R.red[32 + threadIdx.x]) : 0.0;
+    __syncthreads();
+    if (C.NB > 1) coop_totals<false>(C, R.tot);  // level 3 across the frame's workgroups, in block order
   }
-  __syncthreads();
-  if (kCoop && C.NB > 1) coop_totals<false>(C, tot);
+}
+template <int NV>
+GL_DEV void reduce2(double* v, const Red& R, Coop& C) {
+  reduce_to_tot<NV>(v, R, C);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = uni(tot[i]);
+  for (int i = 0; i < NV; ++i) v[i] = uni(R.tot[i]);
 }
 // same, but only wave 0 (the one that solves the reduced system) reads the totals back
 template <int NV>
-GL_DEV void reduce2_w0(double* v, double* red, double* tot, Coop& C) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = NV; i < 32; ++i) v[i] = 0.0;
-  const double r = wave_reduce_scatter32(v);
-  if (wave_slot_owner(lane)) red[wave * 32 + wave_slot(lane)] = r;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    double s = red[threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < NWF; ++w) s += red[w * 32 + threadIdx.x];
-    tot[threadIdx.x] = s;
-  }
-  __syncthreads();
-  if (kCoop && C.NB > 1) coop_totals<false>(C, tot);
+GL_DEV void reduce2_w0(double* v, const Red& R, Coop& C) {
+  reduce_to_tot<NV>(v, R, C);
   if (threadIdx.x < 64) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = uni(tot[i]);
+    for (int i = 0; i < NV; ++i) v[i] = uni(R.tot[i]);
   }
 }
-GL_DEV double reduce_max(double v, double* red, double* tot, Coop& C) {
+GL_DEV double reduce_max(double v, const Red& R, Coop& C) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v = fmax(v, shfl_xor_f64(v, o));
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) R.red[threadIdx.x >> 6] = v;
   __syncthreads();
-  double m = red[0];
-#pragma unroll
-  for (int w = 1; w < NWF; ++w) m = fmax(m, red[w]);
-  if (kCoop && C.NB > 1) {
+  const int nw = blockDim.x >> 6;
+  double m = R.red[0];
+  for (int w = 1; w < nw; ++w) m = fmax(m, R.red[w]);
+  if (kSpread && C.NB > 1) {
     __syncthreads();  // tot may still be read from the previous reduction
-    if (threadIdx.x < 32) tot[threadIdx.x] = m;
+    if (threadIdx.x < 32) R.tot[threadIdx.x] = m;
     __syncthreads();
-    coop_totals<true>(C, tot);
-    m = uni(tot[0]);
+    coop_totals<true>(C, R.tot);
+    m = uni(R.tot[0]);
   }
+  __syncthreads();  // red[0..7] are rewritten by the next sum (group 0 owns them)
   return m;
 }
 
@@ -492,9 +574,36 @@ GL_DEV bool ldlt6_packed(double* a, const double* b, double lambda, double* x) {
   return ok;
 }
 
+// backup of the current point in the slot (pass B) / restore on a rejected trial.  The fp32 cache of
+// GL_BAF_STEP32 is read by its owner just before, but planes of OTHER points alias a double-indexed slot,
+// so that variant keeps the {lo, hi} words in the owner's own 32-bit entries.
+GL_DEV void backup_point(const Lds& D, int ll, const double* p) {
+  if (kStep32) {
+    int* un = (int*)D.un;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      un[(2 * j) * MCAP + ll] = __double2loint(p[j]);
+      un[(2 * j + 1) * MCAP + ll] = __double2hiint(p[j]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) D.un[j * MCAP + ll] = p[j];
+  }
+}
+GL_DEV void restore_point(const Lds& D, int ll) {
+  if (kStep32) {
+    const int* un = (const int*)D.un;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = __hiloint2double(un[(2 * j + 1) * MCAP + ll], un[(2 * j) * MCAP + ll]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = D.un[j * MCAP + ll];
+  }
+}
+
 // per-point context loaded at the top of a loop iteration
 struct PtCtx {
-  int l, fl, asc;
+  int l, ll, fl, asc;  // frame-local point index, LDS index, flags, non-degenerate component (or -1)
   double s;
   double ob[3], nd[4], p[3];
   bool ar, ag;
@@ -502,9 +611,10 @@ struct PtCtx {
 // observations and plane records come from global memory (read-only, coalesced, L2-resident).
 // (Software-prefetching slot i+1 was measured: it costs 14 VGPRs -> 6 spilled registers and
 // ~1 GB of scratch writes per launch for no gain; the second wave of the SIMD hides the latency.)
-GL_DEV bool load_pt(const Lds& D, FlagW fw, const double* __restrict__ gobs, const double* __restrict__ gnd,
+GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gobs, const double* __restrict__ gnd,
                     const int32_t* __restrict__ gassoc, int L, int i, PtCtx& c) {
-  c.l = threadIdx.x + i * TF;
+  c.l = mp.base + 64 * i;
+  c.ll = mp.lbase + 64 * i;
   {  // issue the observation loads first (clamped index): they overlap the LDS reads / flag tests below
     const int lc = min(c.l, L - 1);
 #pragma unroll
@@ -521,28 +631,195 @@ GL_DEV bool load_pt(const Lds& D, FlagW fw, const double* __restrict__ gobs, con
   c.s = D.stab[(c.fl >> 8) & 7];
   c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? gassoc[c.l] : -1;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.l];
+  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
   return true;
 }
 
+// ---- per-point bodies of the passes (shared by both kernels) -------------------------------------------------
+// computeLambdaInit: pose-block terms 0..20 of the undamped reprojection Hessian, and the largest diagonal of the
+// point block (world frame) into md
+template <class Sink>
+GL_DEV void pt_lambda_init(const BaK& k, const GmmDev& gm, const Pose& P, const PtCtx& c, bool robust, double& md, const Sink& sk) {
+  Lin o;
+  lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+  const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s += P.R[a * 3 + j] * Hf[a * 3 + b] * P.R[b * 3 + j];
+    md = fmax(md, fabs(s));
+  }
+  if (c.ar) {
+    const double zero[3] = {0, 0, 0};
+    pose_terms(o.q, o.A, zero, false, sk);
+  }
+}
+// pass A: linearise, point solve, Schur terms 0..26, robust chi2 (27), sum u.b (28); leaves D^-1 in the slot
+template <class Sink>
+GL_DEV void pt_pass_a(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double lambda,
+                      const Sink& sk) {
+  Lin o;
+  lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+  sk.put(27, o.rho0_r + o.chi_g);
+  double Dinv[6], u[3];
+  point_solve_fast(o, lambda, Dinv, u);
+  sk.put(28, fma(u[0], o.b[0], fma(u[1], o.b[1], u[2] * o.b[2])));
+  if (kStep32) {
+    int* un = (int*)D.un;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) un[j * MCAP + c.ll] = __float_as_int((float)u[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) D.un[j * MCAP + c.ll] = Dinv[j];
+  }
+  if (c.ar) {
+    double C[6], cc[3], AD[9];
+    sym3_mul(o.A, Dinv, AD);
+    if (kStep32) {
+      int* un = (int*)D.un;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) un[(3 + j) * MCAP + c.ll] = __float_as_int((float)AD[j]);
+    }
+    schur_C(o.A, AD, C);
+    cc[0] = fma(-o.A[0], u[0], fma(-o.A[1], u[1], fma(-o.A[2], u[2], o.a[0])));
+    cc[1] = fma(-o.A[1], u[0], fma(-o.A[3], u[1], fma(-o.A[4], u[2], o.a[1])));
+    cc[2] = fma(-o.A[2], u[0], fma(-o.A[4], u[1], fma(-o.A[5], u[2], o.a[2])));
+    pose_terms(o.q, C, cc, true, sk);
+  } else if (kStep32) {
+    int* un = (int*)D.un;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) un[(3 + j) * MCAP + c.ll] = 0;
+  }
+}
+// pass B: point step, trial point (in place, old point backed up in the slot), chi2 at the trial state.
+// terms: 0 = |eps|^2, 1 = robust chi2 of the point's edges at the trial state
+template <class Sink>
+GL_DEV void pt_pass_b(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& P, const Pose& Pn, const double* dx, const PtCtx& c,
+                      bool robust, const Sink& sk) {
+  // eps = D^-1 (b - A gd),  gd = omega x q + upsilon
+  double q[3], gd[3], eps[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) q[j] = P.R[j * 3] * c.p[0] + P.R[j * 3 + 1] * c.p[1] + P.R[j * 3 + 2] * c.p[2] + P.t[j];
+  cross(dx, q, gd);
+  gd[0] += dx[3];
+  gd[1] += dx[4];
+  gd[2] += dx[5];
+  const bool stereo = c.fl & F_STEREO;
+  if (kStep32) {  // = u - (A D^-1)^T gd from the fp32 cache of pass A
+    const int* un = (const int*)D.un;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double e = (double)__int_as_float(un[j * MCAP + c.ll]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) e -= (double)__int_as_float(un[(3 + a * 3 + j) * MCAP + c.ll]) * gd[a];
+      eps[j] = e;
+    }
+  } else {  // exact: b - A gd = Jpi^T W (e - Jpi gd) + b_gmm from the re-evaluated residual, times the cached D^-1
+    double rhs[3] = {0.0, 0.0, 0.0};
+    if (c.ar) {
+      double e[3], iz;
+      const double chi_r = reproj_chi2(k, q, c.ob, stereo, c.s, e, iz);
+      double rho0 = chi_r, rho1 = 1.0;
+      if (robust) {
+        const double dl = stereo ? k.delta_stereo : k.delta_mono;
+        huber_bf(chi_r, dl, dl * dl, rho0, rho1);
+      }
+      const double w = rho1 * c.s;
+      const double t = stereo ? w : 0.0;
+      const Jpi J = jpi_at(k, q, iz);
+      const double f0 = w * (e[0] - fma(J.al, gd[0], J.b0 * gd[2]));
+      const double f1 = w * (e[1] - fma(J.ga, gd[1], J.b1 * gd[2]));
+      const double f2 = t * (e[2] - fma(J.al, gd[0], J.b2 * gd[2]));
+      rhs[0] = J.al * (f0 + f2);
+      rhs[1] = J.ga * f1;
+      rhs[2] = fma(J.b2, f2, fma(J.b1, f1, J.b0 * f0));
+    }
+    if (c.ag) {
+      if (c.fl & F_DEG) {
+        const double nx = c.nd[0], ny = c.nd[1], nz = c.nd[2];
+        const double eg = fma(nz, c.p[2], fma(ny, c.p[1], nx * c.p[0])) - c.nd[3];
+        const double m = -k.ba_lambda2 * eg;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rhs[j] = fma(m, fma(P.R[j * 3 + 2], nz, fma(P.R[j * 3 + 1], ny, P.R[j * 3] * nx)), rhs[j]);
+      } else {
+        double bc[3];
+        gmm_nondeg(gm, c.asc, P.R, c.p, nullptr, bc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rhs[j] += bc[j];
+      }
+    }
+    double Dinv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Dinv[j] = D.un[j * MCAP + c.ll];
+    sym3_mul_vec(Dinv, rhs, eps);
+  }
+  sk.put(0, eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2]);
+  double pn[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) pn[j] = c.p[j] + (P.R[j] * eps[0] + P.R[3 + j] * eps[1] + P.R[6 + j] * eps[2]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) D.sp[j * MCAP + c.ll] = pn[j];  // the trial point goes in place,
+  backup_point(D, c.ll, c.p);                                  // the old point into the slot
+  double chi = 0.0;
+  if (c.ar) {
+    double qn[3], e[3], iz;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) qn[j] = Pn.R[j * 3] * pn[0] + Pn.R[j * 3 + 1] * pn[1] + Pn.R[j * 3 + 2] * pn[2] + Pn.t[j];
+    const double c2 = reproj_chi2(k, qn, c.ob, stereo, c.s, e, iz);
+    D.chir[c.ll] = c2;
+    double r0 = c2, r1;
+    if (robust) {
+      const double dl = stereo ? k.delta_stereo : k.delta_mono;
+      huber_bf(c2, dl, dl * dl, r0, r1);
+    }
+    chi = r0;
+  }
+  if (c.ag) chi += gmm_chi2_fast(k, gm, c.nd, c.fl, c.asc, pn);
+  sk.put(1, chi);
+}
+
+// one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
+// point's terms there (zeros when the thread has no active point)
+#define GL_BAF_PASS(BODY)                                                     \
+  {                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) acc[i_] = 0.0;          \
+    if (kSpread) {                                                            \
+      const SinkSet sk{acc};                                                  \
+      PtCtx c;                                                                \
+      if (load_pt(D, mp, fw, gobs, gnd, gassoc, L, 0, c)) { BODY; }           \
+    } else {                                                                  \
+      const SinkAcc sk{acc};                                                  \
+      _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
+        PtCtx c;                                                              \
+        if (!load_pt(D, mp, fw, gobs, gnd, gassoc, L, i, c)) continue;        \
+        BODY;                                                                 \
+      }                                                                       \
+    }                                                                         \
+  }
+
 // SparseOptimizer::optimize(iters), Levenberg
-GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw, Pose& P, int L, const double* __restrict__ gobs,
-                         const int32_t* __restrict__ gassoc, const double* __restrict__ gnd, bool robust, int iters,
-                         double* red, double* tot, int& trials, Coop& C) {
+GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P, int L,
+                         const double* __restrict__ gobs, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
+                         bool robust, int iters, const Red& R, int& trials, Coop& C) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  {
+    const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
-  for (int i = 0; i < PPTF; ++i) {
-    const int l = threadIdx.x + i * TF;
-    if (l >= L) break;
-    const int fl = fw_get(fw, i);
-    if (!(fl & F_EXISTS)) continue;
-    const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
-    if (ar) acc[0] += 1.0;
-    if (ar || ag) acc[1] += 1.0;
+    for (int i = 0; i < ns; ++i) {
+      if (mp.base + 64 * i >= L) break;
+      const int fl = fw_get(fw, i);
+      if (!(fl & F_EXISTS)) continue;
+      const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
+      if (ar) acc[0] += 1.0;
+      if (ar || ag) acc[1] += 1.0;
+    }
   }
-  reduce2<2>(acc, red, tot, C);
+  reduce2<2>(acc, R, C);
   const bool pose_active = acc[0] > 0.0;
   if (!pose_active && !(acc[1] > 0.0)) return -1;
 
@@ -553,77 +830,26 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
     int qmax = 0;
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-#pragma unroll 1
-      for (int i = 0; i < PPTF; ++i) {
-        PtCtx c;
-        if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
-        Lin o;
-        lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
-        const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double s = 0.0;
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) s += P.R[a * 3 + j] * Hf[a * 3 + b] * P.R[b * 3 + j];
-          md = fmax(md, fabs(s));
-        }
-        if (c.ar) {
-          const double zero[3] = {0, 0, 0};
-          accum_pose_sym(o.q, o.A, zero, acc);
-        }
-      }
-      reduce2<21>(acc, red, tot, C);
+      GL_BAF_PASS(pt_lambda_init(k, gm, P, c, robust, md, sk));
+      reduce2<21>(acc, R, C);
       if (pose_active) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) md = fmax(md, fabs(acc[GL_U(i, i)]));
       }
-      md = reduce_max(md, red, tot, C);
+      md = reduce_max(md, R, C);
       lambda = uni(1e-5 * md);
       ni = 2.0;
     }
     do {
       PROF_T(tA0);
       // ---- pass A ---------------------------------------------------------------------------
-#pragma unroll
-      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-#pragma unroll 1
-      for (int i = 0; i < PPTF; ++i) {
-        PtCtx c;
-        if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
-        Lin o;
-        const double c2 = lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
-        if (c.ar) D.chir[c.l] = c2;  // computeActiveErrors
-        acc[27] += o.rho0_r + o.chi_g;
-        double Dinv[6], u[3];
-        point_solve_fast(o, lambda, Dinv, u);
-        acc[28] = fma(u[0], o.b[0], fma(u[1], o.b[1], fma(u[2], o.b[2], acc[28])));
-#pragma unroll
-        for (int j = 0; j < 3; ++j) D.un[j * MCAP + c.l] = __float_as_int((float)u[j]);
-        if (c.ar) {
-          double C[6], cc[3], AD[9];
-          sym3_mul(o.A, Dinv, AD);
-#pragma unroll
-          for (int j = 0; j < 9; ++j) D.un[(3 + j) * MCAP + c.l] = __float_as_int((float)AD[j]);
-          schur_C(o.A, AD, C);
-          cc[0] = fma(-o.A[0], u[0], fma(-o.A[1], u[1], fma(-o.A[2], u[2], o.a[0])));
-          cc[1] = fma(-o.A[1], u[0], fma(-o.A[3], u[1], fma(-o.A[4], u[2], o.a[1])));
-          cc[2] = fma(-o.A[2], u[0], fma(-o.A[4], u[1], fma(-o.A[5], u[2], o.a[2])));
-          accum_pose_sym(o.q, C, cc, acc);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 9; ++j) D.un[(3 + j) * MCAP + c.l] = 0;
-        }
-      }
+      GL_BAF_PASS(pt_pass_a(k, gm, D, P, c, robust, lambda, sk));
       PROF_T(tA1);
-      reduce2_w0<29>(acc, red, tot, C);
+      reduce2_w0<29>(acc, R, C);
       PROF_T(tA2);
-      if (qmax == 0) currentChi = uni(tot[27]);
+      if (qmax == 0) currentChi = uni(R.tot[27]);
       // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
-      double* bc = tot + 32;  // 20 doubles: dx[6] R[9] t[3] ok pad
+      double* bc = R.tot + 32;  // 26 doubles: dx[6] R[9] t[3] ok g[6] sum u.b
       if (threadIdx.x < 64) {
         double dxs[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
@@ -655,55 +881,9 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
       const bool ok2 = uni(bc[18]) != 0.0;
       PROF_T(tS);
       // ---- pass B ---------------------------------------------------------------------------
-#pragma unroll
-      for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-#pragma unroll 1
-      for (int i = 0; i < PPTF; ++i) {
-        PtCtx c;
-        if (!load_pt(D, fw, gobs, gnd, gassoc, L, i, c)) continue;
-        // eps = D^-1 (b - A gd) = u - (A D^-1)^T gd,  gd = omega x q + upsilon  (u, A D^-1: pass-A cache)
-        double q[3], gd[3], eps[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) q[j] = P.R[j * 3] * c.p[0] + P.R[j * 3 + 1] * c.p[1] + P.R[j * 3 + 2] * c.p[2] + P.t[j];
-        cross(dx, q, gd);
-        gd[0] += dx[3];
-        gd[1] += dx[4];
-        gd[2] += dx[5];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double e = (double)__int_as_float(D.un[j * MCAP + c.l]);
-#pragma unroll
-          for (int a = 0; a < 3; ++a) e -= (double)__int_as_float(D.un[(3 + a * 3 + j) * MCAP + c.l]) * gd[a];
-          eps[j] = e;
-        }
-        acc[0] += eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2];
-        double pn[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) pn[j] = c.p[j] + (P.R[j] * eps[0] + P.R[3 + j] * eps[1] + P.R[6 + j] * eps[2]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {  // the trial point goes in place; the old point is backed up in the cache slot
-          D.sp[j * MCAP + c.l] = pn[j];
-          D.un[(2 * j) * MCAP + c.l] = __double2loint(c.p[j]);
-          D.un[(2 * j + 1) * MCAP + c.l] = __double2hiint(c.p[j]);
-        }
-        if (c.ar) {
-          double qn[3], e[3], iz;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) qn[j] = Pn.R[j * 3] * pn[0] + Pn.R[j * 3 + 1] * pn[1] + Pn.R[j * 3 + 2] * pn[2] + Pn.t[j];
-          const bool stereo = c.fl & F_STEREO;
-          const double c2 = reproj_chi2(k, qn, c.ob, stereo, c.s, e, iz);
-          D.chir[c.l] = c2;
-          double r0 = c2, r1;
-          if (robust) {
-            const double dl = stereo ? k.delta_stereo : k.delta_mono;
-            huber_bf(c2, dl, dl * dl, r0, r1);
-          }
-          acc[1] += r0;
-        }
-        if (c.ag) acc[1] += gmm_chi2_fast(k, gm, c.nd, c.fl, c.asc, pn);
-      }
+      GL_BAF_PASS(pt_pass_b(k, gm, D, P, Pn, dx, c, robust, sk));
       PROF_T(tB1);
-      reduce2<2>(acc, red, tot, C);
+      reduce2<2>(acc, R, C);
       PROF_T(tB2);
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
       // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
@@ -727,17 +907,16 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
         lambda *= ni;
         ni *= 2;
         PROF_ADD(7, 0, 1);  // rejected trials
+        const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
-        for (int i = 0; i < PPTF; ++i) {  // discardTop: restore the backed-up points
-          const int l = threadIdx.x + i * TF;
-          if (l >= L) break;
+        for (int i = 0; i < ns; ++i) {  // discardTop: restore the backed-up points
+          if (mp.base + 64 * i >= L) break;
+          const int ll = mp.lbase + 64 * i;
           const int fl = fw_get(fw, i);
           if (!(fl & F_EXISTS)) continue;
           const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
           if (!(ar || ag)) continue;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            D.sp[j * MCAP + l] = __hiloint2double(D.un[(2 * j + 1) * MCAP + l], D.un[(2 * j) * MCAP + l]);
+          restore_point(D, ll);
         }
       }
       qmax++;
@@ -751,76 +930,81 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, FlagW fw,
   return cj;
 }
 
-__global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int L, double* __restrict__ pose_io,
-                                                 double* __restrict__ pts_io, const double* __restrict__ obs_all,
-                                                 const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
-                                                 const double* __restrict__ d2_all, uint8_t* __restrict__ dropped_all,
-                                                 uint8_t* __restrict__ erase_all, int32_t* __restrict__ iters_out,
-                                                 double* __restrict__ pn_all, int32_t* __restrict__ trials_out
-#ifdef GL_BAF_COOPERATIVE
-                                                 ,
-                                                 int NB, unsigned long long* parts
-#endif
-) {
+// DENSE: <<<B, 64 G>>>, one workgroup per frame.  SPREAD: <<<B NB, 512>>>, NB = ceil(G / 2) workgroups per frame
+// (cooperative launch when NB > 1).  G, S: the canonical order of stride L (launcher: canon_order()).
+__global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int L, int G, int S, double* __restrict__ pose_io,
+                                                  double* __restrict__ pts_io, const double* __restrict__ obs_all,
+                                                  const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
+                                                  const double* __restrict__ d2_all, uint8_t* __restrict__ dropped_all,
+                                                  uint8_t* __restrict__ erase_all, int32_t* __restrict__ iters_out,
+                                                  double* __restrict__ pn_all, int32_t* __restrict__ trials_out, int NB,
+                                                  unsigned long long* parts) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
-  D.sp = smem;                          // 3 * MCAP
-  D.chir = D.sp + 3 * MCAP;             // MCAP
-  D.un = (int*)(D.chir + MCAP);         // 12 * MCAP words = 6 * MCAP doubles
-  double* red = D.chir + 7 * MCAP;      // NWF * 32
-  double* tot = red + NWF * 32;         // 32 (+ 32 broadcast slots)
-  D.stab = tot + 64;                    // 8
+  D.sp = smem;                      // 3 * MCAP
+  D.chir = D.sp + 3 * MCAP;         // MCAP
+  D.un = D.chir + MCAP;             // 6 * MCAP
+  Red R;
+  R.red = D.chir + 7 * MCAP;        // NRED * 32
+  R.tot = R.red + NRED * 32;        // 32 (+ 32 broadcast slots)
+  D.stab = R.tot + 64;              // 8
+  R.tb = D.stab + 8;                // SPREAD: 29 x 512
+  R.S = S;
   FlagW fw = 0;
-  const int tid = threadIdx.x;
-#ifdef GL_BAF_COOPERATIVE
-  // workgroup pb of the NB that share frame f owns the points [l0, l0 + L) of the frame's Lf
-  const int f = blockIdx.x / NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = kSpread ? blockIdx.x / NB : blockIdx.x;
   if (f >= B) return;
-  Coop C{parts + (size_t)f * 2 * NB * 64, NB, (int)(blockIdx.x % NB), 0u};
-  const int Lf = L, Lp = (Lf + NB - 1) / NB;
-  const int l0 = min(C.pb * Lp, Lf);
-  L = min(Lp, Lf - l0);
-  const size_t gbase = (size_t)f * Lf + l0;
-#else
-  const int f = blockIdx.x;
-  if (f >= B) return;
-  Coop C{nullptr, 1, 0, 0u};
+  Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, kSpread ? (int)(blockIdx.x % NB) : 0, 0u};
+  Map mp;
+  if (kSpread) {  // block pb = groups 2 pb, 2 pb + 1; wave = (group of the block) * S + slot; idle waves beyond 2 S
+    const int gi = wave / S, slot = wave - gi * S;
+    mp.S = 1;
+    mp.base = gi < 2 ? ((2 * C.pb + gi) * S + slot) * 64 + lane : L;
+    mp.lbase = tid;
+  } else {
+    mp.S = S;
+    mp.base = wave * S * 64 + lane;
+    mp.lbase = mp.base;
+  }
   const size_t gbase = (size_t)f * L;
-#endif
   double* gnd = pn_all + gbase * 4;  // per-point plane record {n, n.mu} (written once, then read-only)
   const double* gobs = obs_all + gbase * 3;
   int32_t* gassoc = assoc_all + gbase;
+  for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
+  {
+    const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
-  for (int i = 0; i < PPTF; ++i) {
-    const int l = tid + i * TF;
-    if (l >= L) break;
-    const size_t g = gbase + l;
-    const int oc = oct_all[g];
-    int a = assoc_all[g];
-    // association gate chi2 <= 9 (checkMapAssociation, gmmloc_opt.cpp:230-232)
-    if (d2_all && k.gate_chi2 >= 0 && !(d2_all[g] <= k.gate_chi2)) a = -1;
-    if (oc < 0) a = -1;
-    int fl = 0;
+    for (int i = 0; i < ns; ++i) {
+      const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
+      if (l >= L) break;
+      const size_t g = gbase + l;
+      const int oc = oct_all[g];
+      int a = assoc_all[g];
+      // association gate chi2 <= 9 (checkMapAssociation, gmmloc_opt.cpp:230-232)
+      if (d2_all && k.gate_chi2 >= 0 && !(d2_all[g] <= k.gate_chi2)) a = -1;
+      if (oc < 0) a = -1;
+      int fl = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) D.sp[j * MCAP + l] = pts_io[g * 3 + j];
-    if (oc >= 0) {
-      fl = F_EXISTS | ((oc & 7) << 8);
-      if (!(gobs[(size_t)l * 3 + 2] < 0)) fl |= F_STEREO;
-      if (a >= 0) {
-        fl |= F_ASSOC;
-        if (gm.flags[a] & 1) {
-          fl |= F_DEG;
-          const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
-          gnd[(size_t)l * 4] = nx;
-          gnd[(size_t)l * 4 + 1] = ny;
-          gnd[(size_t)l * 4 + 2] = nz;
-          gnd[(size_t)l * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
+      for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = pts_io[g * 3 + j];
+      if (oc >= 0) {
+        fl = F_EXISTS | ((oc & 7) << 8);
+        if (!(gobs[(size_t)l * 3 + 2] < 0)) fl |= F_STEREO;
+        if (a >= 0) {
+          fl |= F_ASSOC;
+          if (gm.flags[a] & 1) {
+            fl |= F_DEG;
+            const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
+            gnd[(size_t)l * 4] = nx;
+            gnd[(size_t)l * 4 + 1] = ny;
+            gnd[(size_t)l * 4 + 2] = nz;
+            gnd[(size_t)l * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
+          }
         }
       }
+      gassoc[l] = a;
+      D.chir[ll] = 0.0;
+      fw_or(fw, i, fl);
     }
-    gassoc[l] = a;
-    D.chir[l] = 0.0;
-    fw_or(fw, i, fl);
   }
   if (tid == 0) {
 #pragma unroll
@@ -832,46 +1016,47 @@ __global__ __launch_bounds__(TF, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int
   // schedule (:770-828): optimize(5) -> gate degenerate GMM edges -> optimize(5) -> gate reprojection
   // edges, robust kernels off -> optimize(40).  One rolled phase loop = one copy of the optimiser code.
   int it3 = 0, trials = 0;
+  const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(k, gm, D, fw, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, red, tot, trials, C);
+    it3 = optimize_fast(k, gm, D, mp, fw, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, R, trials, C);
     if (phase == 2) break;
 #pragma unroll 1
-    for (int i = 0; i < PPTF; ++i) {
-      const int l = tid + i * TF;
+    for (int i = 0; i < ns; ++i) {
+      const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
       if (l >= L) break;
       const int fl = fw_get(fw, i);
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
         if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
-          const double p[3] = {D.sp[l], D.sp[MCAP + l], D.sp[2 * MCAP + l]};
+          const double p[3] = {D.sp[ll], D.sp[MCAP + ll], D.sp[2 * MCAP + ll]};
           const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
           if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) fw_or(fw, i, F_LEVG);
         }
       } else {  // STALE chi2 of the reprojection edges, fresh depth test (:799-825)
         if (!(fl & F_EXISTS)) continue;
-        const double z = P.R[6] * D.sp[l] + P.R[7] * D.sp[MCAP + l] + P.R[8] * D.sp[2 * MCAP + l] + P.t[2];
-        if (D.chir[l] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) fw_or(fw, i, F_LEVR);
+        const double z = P.R[6] * D.sp[ll] + P.R[7] * D.sp[MCAP + ll] + P.R[8] * D.sp[2 * MCAP + ll] + P.t[2];
+        if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) fw_or(fw, i, F_LEVR);
       }
     }
     __syncthreads();
   }
 
 #pragma unroll 1
-  for (int i = 0; i < PPTF; ++i) {  // outputs (:837-879, :898-922)
-    const int l = tid + i * TF;
+  for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
+    const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
     if (l >= L) break;
     const size_t g = gbase + l;
     const int fl = fw_get(fw, i);
     uint8_t dr = 0, er = 0;
     int a = gassoc[l];
     if (fl & F_EXISTS) {
-      const double p[3] = {D.sp[l], D.sp[MCAP + l], D.sp[2 * MCAP + l]};
+      const double p[3] = {D.sp[ll], D.sp[MCAP + ll], D.sp[2 * MCAP + ll]};
       if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
         const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
         if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) dr = 1;
       }
       const double z = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];
-      if (D.chir[l] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
+      if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
 #pragma unroll
       for (int j = 0; j < 3; ++j) pts_io[g * 3 + j] = p[j];
     }

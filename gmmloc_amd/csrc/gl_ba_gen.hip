@@ -1118,21 +1118,20 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;
   const size_t lds = s_in_lds ? s_bytes : 0;
   if (s_in_lds)
-  {
-    static size_t lds_set = 0;
-    GL_HIP(gl::ensure_dynamic_lds((const void*)k_ba_gen, s_bytes, &lds_set));
-  }
+    GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_ba_gen, s_bytes));
   // workgroups per problem: as many as stay co-resident (the per-problem barrier needs that; the
   // cooperative launch enforces it), at most 64; large batches run one workgroup per problem
   int NB = 1;
   {
-    static size_t occ_lds = (size_t)-1;  // the occupancy query is a driver call: remembered per LDS size
-    static int occ_val = 0;
-    if (occ_lds != lds) {
+    // the occupancy query is a driver call: the context (one device, one host thread) remembers it per LDS size
+    auto key = std::make_pair((const void*)k_ba_gen, lds);
+    auto hit = c->occupancy.find(key);
+    if (hit == c->occupancy.end()) {
+      int occ_val = 0;
       GL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_val, (const void*)k_ba_gen, T_BA, lds));
-      occ_lds = lds;
+      hit = c->occupancy.emplace(key, occ_val).first;
     }
-    const int occ = occ_val, ncu = c->ncu;
+    const int occ = hit->second, ncu = c->ncu;
     const long cap = (long)occ * ncu;
     // measured optimum on single problems (tools/ba_nb.py), with up to 4 lanes per point in the
     // point passes and up to 4 waves per reduced-camera block: one workgroup up to ~600 observations (no
@@ -1140,7 +1139,7 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     // stride) stands in for the observation count
     const int want = NOBS <= 600 ? 1 : NOBS <= 2000 ? 8 : NOBS <= 6000 ? 16 : NOBS <= 16000 ? 32 : 64;
     NB = (int)std::min<long>(want, cap / B);
-    if (const char* e = getenv("GMMLOC_BAGEN_NB")) NB = (int)std::min<long>(std::max(1, atoi(e)), cap / B);  // knob: that many workgroups per problem (tests: 1)
+    if (c->opt.bagen_nb > 0) NB = (int)std::min<long>(std::max(1, (int)c->opt.bagen_nb), cap / B);  // knob: that many workgroups per problem (tests: 1)
     if (NB < 2) NB = 1;
   }
   {

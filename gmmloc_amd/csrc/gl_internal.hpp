@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -74,9 +75,31 @@ struct Gmm {
   gl_params prm;
 };
 
+// Tuning / test knobs of a context.  Read ONCE from the environment (GMMLOC_<NAME>) at gl_ctx_create and
+// changed afterwards only through gl_ctx_set_option: no libc environment scan on the call paths.
+struct Options {
+  double ba_shape = -1;         // gl_track_frames refine: -1 auto, 0 one workgroup per frame, 1 one point per thread
+  double ba_step32 = 0;         // 1: point step from an fp32 cache of the pass-A solve (faster, not the default)
+  double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
+  double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame
+  double pose_coop = -1;        //   -1 auto, 0 never, 2..4 workgroups per frame
+  double bagen_nb = 0;          // gl_joint_optimization: 0 auto, n workgroups per problem
+  double view_slot_lds = 0;     // gl_search2d: accepted-list records kept in LDS (0 = all that fit)
+  double view_threads = 0;      //   0 auto, 256 / 1024
+  double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
+  double match_desc_lds = -1;   // gl_search_by_projection: descriptors in LDS (-1 auto, 0 / 1)
+};
+// name -> member; nullptr if unknown
+double* option_slot(Options& o, const char* name);
+
 struct Ctx {
   int device = 0;
   int ncu = 256;  // compute units of the device (shape decisions: frames vs CUs)
+  Options opt;
+  // per-context (= per device, per host thread) caches of driver queries: the dynamic-LDS limit already set
+  // for a kernel (hipFuncSetAttribute is per device) and occupancy answers
+  std::map<const void*, size_t> lds_limit;
+  std::map<std::pair<const void*, size_t>, int> occupancy;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // scratch (grown on demand)
@@ -94,13 +117,14 @@ struct Ctx {
 };
 
 int ctx_scratch(Ctx* c, size_t bytes, void** out);
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs a driver call: raise a kernel's limit only when it grows.
-// `slot` is a per-call-site static (one per kernel instantiation and device would be stricter; the limit only
-// ever grows, and every device of a process runs the same kernels with the same sizes).
-inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, size_t* slot) {
-  if (bytes <= *slot) return hipSuccess;
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE and costs a driver call: a context (one device,
+// one host thread) remembers the limit it has set for each kernel and raises it only when it grows.  The caller
+// has made the context's device current.
+inline hipError_t ensure_dynamic_lds(Ctx* c, const void* kernel, size_t bytes) {
+  size_t& have = c->lds_limit[kernel];
+  if (bytes <= have) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) *slot = bytes;
+  if (e == hipSuccess) have = bytes;
   return e;
 }
 // bracket a launch region with events when timing is enabled

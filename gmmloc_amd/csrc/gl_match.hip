@@ -471,12 +471,11 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
   // latency shape (no more frames than CUs): descriptors in LDS as well, if they fit
   const size_t lds_dl = lds + 8 + (size_t)NF * 32;
   bool dl = B <= c->ncu && lds_dl <= 160 * 1024 - 8 * 1024;
-  if (const char* e = getenv("GMMLOC_MATCH_DESC_LDS")) dl = atoi(e) != 0 && lds_dl <= 160 * 1024 - 8 * 1024;
+  if (c->opt.match_desc_lds >= 0) dl = c->opt.match_desc_lds != 0 && lds_dl <= 160 * 1024 - 8 * 1024;
   if (dl) lds = lds_dl;
   auto kern = mode == 0 ? (dl ? k_search_by_projection<0, true> : k_search_by_projection<0, false>)
                         : (dl ? k_search_by_projection<1, true> : k_search_by_projection<1, false>);
-  static size_t lds_set[4] = {0, 0, 0, 0};  // per instantiation
-  GL_HIP(gl::ensure_dynamic_lds((const void*)kern, lds, &lds_set[(mode ? 2 : 0) + (dl ? 1 : 0)]));
+  GL_HIP(gl::ensure_dynamic_lds(c, (const void*)kern, lds));
   kern<<<B, dl ? 1024 : T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
                                    mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle);
   GL_HIP(hipGetLastError());

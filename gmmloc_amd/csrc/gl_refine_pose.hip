@@ -461,14 +461,14 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     // GMMLOC_POSE_WAVES=1|4|8 forces a shape.
     int nw = B > 1536 ? 1 : (B > 32 && B <= 256) ? 8 : 4;
     while (nw > 1 && nw * 64 > M + 63) nw = nw == 8 ? 4 : 1;
-    if (const char* e = getenv("GMMLOC_POSE_WAVES")) nw = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : 1;
+    if (c->opt.pose_waves > 0) nw = (int)c->opt.pose_waves == 8 ? 8 : (int)c->opt.pose_waves == 4 ? 4 : 1;
     // very few frames: a frame's edges are dealt to NB <= 4 workgroups of 4 waves on as many CUs (one edge per
     // thread from 1 024 edges), sums exchanged between them (cooperative launch; GMMLOC_POSE_COOP=0 | 2..4)
     int nb = std::min(4, (M + 255) / 256);
     while (nb > 1 && B * nb > c->ncu) --nb;  // one frame 0.35 -> 0.28 ms, 64 frames 0.42 -> 0.35 ms (1 000 edges)
     bool coop = nb > 1;
-    if (const char* e = getenv("GMMLOC_POSE_COOP")) {
-      const int v = atoi(e);
+    if (c->opt.pose_coop >= 0) {
+      const int v = (int)c->opt.pose_coop;
       coop = v >= 2 && B * v <= 512;
       if (coop) nb = std::min(v, 4);
     }

@@ -796,10 +796,10 @@ extern "C" int gl_search2d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* 
   if (rc != GL_OK) return rc;
   ViewK vk{cam->fx, cam->fy, cam->cx, cam->cy, cam->width, cam->height};
   int slot_lds = SLOT_LDS;
-  if (const char* e = getenv("GMMLOC_VIEW_SLOT_LDS")) slot_lds = std::max(1, std::min(SLOT_LDS, atoi(e)));  // tests: the spill path
-  // latency shape up to one view per CU, throughput shape above (GMMLOC_VIEW_THREADS forces one)
+  if (c->opt.view_slot_lds > 0) slot_lds = std::max(1, std::min(SLOT_LDS, (int)c->opt.view_slot_lds));  // tests: the spill path
+  // latency shape up to one view per CU, throughput shape above (option view_threads forces one)
   int threads = B <= c->ncu ? 1024 : 256;
-  if (const char* e = getenv("GMMLOC_VIEW_THREADS")) threads = atoi(e) == 1024 ? 1024 : 256;
+  if (c->opt.view_threads > 0) threads = (int)c->opt.view_threads == 1024 ? 1024 : 256;
   const size_t lds = (size_t)SLOT_LDS * REC * sizeof(double);
   if (threads == 1024)
     k_search2d<1024><<<B, 1024, lds, c->stream>>>(vk, B, g->K, slot_lds, g->rec12, g->cov, g->axis, g->flags, pose_dev, N,

@@ -77,6 +77,14 @@ int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out);
 int gl_ctx_destroy(gl_ctx_t* ctx);
 int gl_ctx_synchronize(gl_ctx_t* ctx);
 void* gl_ctx_stream(gl_ctx_t* ctx);
+/* Tuning / test options of a context (launch shapes, A/B switches; never the results' meaning).  Each option is
+ * initialised ONCE at gl_ctx_create from the environment variable GMMLOC_<NAME IN CAPITALS> and changed only by
+ * this call afterwards - no entry point reads the environment.  Names:
+ *   ba_shape (-1 auto | 0 one workgroup per frame | 1 one point per thread; same bits either way),
+ *   ba_step32 (1: fp32-cached point step in gl_track_frames, faster, NOT bit-compatible with the default),
+ *   ba_slow, pose_waves, pose_coop, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
+int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
+int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
 /* Kernel timing with HIP events on the context's stream: while enabled, every
  * launch of the named hot kernel class is bracketed by events.  Returns the
  * accumulated milliseconds / launch count since the last reset. */

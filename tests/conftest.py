@@ -38,6 +38,20 @@ def gt_sync():
     return np.load(os.path.join(GOLDEN, "gt_sync.npz"))
 
 
+@pytest.fixture
+def opt(gpu):
+    """opt(name, value): set a context option (gl_ctx_set_option) for this test only."""
+    ctx = gpu[1]
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, ctx.get_option(name))
+        ctx.set_option(name, value)
+    yield set_
+    for k, v in saved.items():
+        ctx.set_option(k, v)
+
+
 @pytest.fixture(scope="session")
 def gpu():
     """(torch, Context) on cuda:0 -- GPU tests fail loudly if the HIP library is absent."""

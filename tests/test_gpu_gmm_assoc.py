@@ -148,12 +148,13 @@ def test_gmm_file_roundtrip(gpu, map_v1, tmp_path):
 # ---- the exact cell index behind ASSOC_BRUTE vs the plain N x K sweep (ASSOC_EXHAUSTIVE) -------
 
 def _both(torch, g, pts):
+    ctx = g.ctx
     t = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
-    os.environ["GMMLOC_ASSOC_INDEX_MIN"] = "0"  # small problems default to the sweep; force the index
+    ctx.set_option("assoc_index_min", 0)  # small problems default to the sweep; force the index
     try:
         a = g.associate3d(t, api.ASSOC_BRUTE)
     finally:
-        del os.environ["GMMLOC_ASSOC_INDEX_MIN"]
+        ctx.set_option("assoc_index_min", -1)
     b = g.associate3d(t, api.ASSOC_EXHAUSTIVE)
     return [x.cpu().numpy() for x in a], [x.cpu().numpy() for x in b]
 

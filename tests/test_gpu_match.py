@@ -27,9 +27,9 @@ def run_gpu(torch, ctx, frames, th, nn_ratio=0.8):
 @pytest.mark.parametrize("NF,NP,th,dup", [(300, 200, 3.0, 0.25), (1200, 800, 3.0, 0.25), (2000, 2500, 5.0, 0.5),
                                           (64, 4000, 3.0, 0.9), (1000, 1000, 1.0, 0.3), (1, 1, 3.0, 0.0)])
 @pytest.mark.parametrize("shape", ["0", "1"])  # batch shape (512 threads) / few-frames shape (1 024, descriptors in LDS)
-def test_search_by_projection_matches_oracle(gpu, oracle, monkeypatch, NF, NP, th, dup, shape):
+def test_search_by_projection_matches_oracle(gpu, oracle, opt, NF, NP, th, dup, shape):
     torch, ctx = gpu
-    monkeypatch.setenv("GMMLOC_MATCH_DESC_LDS", shape)
+    opt("match_desc_lds", int(shape))
     frames = [synth.synth_match_frame(NF, NP, 1000 * NF + 7 * b, dup_frac=dup) for b in range(5)]
     m, n = run_gpu(torch, ctx, frames, th)
     tot = 0

@@ -41,9 +41,9 @@ def run_gpu(gpu, cam, prm, frames):
 
 @pytest.mark.parametrize("kernel", ["1", "4", "8"])  # waves per frame: 1 = large batches, 4 / 8 = few frames
 @pytest.mark.parametrize("M,seed", [(300, 100), (1200, 200), (2000, 300), (37, 400)])
-def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, monkeypatch, M, seed, kernel):
-    monkeypatch.setenv("GMMLOC_POSE_WAVES", kernel)
-    monkeypatch.setenv("GMMLOC_POSE_COOP", "0" if kernel != "4" else "3")  # "4": also the frame dealt to 3 workgroups
+def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, opt, M, seed, kernel):
+    opt("pose_waves", int(kernel))
+    opt("pose_coop", 0 if kernel != "4" else 3)  # "4": also the frame dealt to 3 workgroups
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
     frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 6, M, seed)
@@ -61,8 +61,8 @@ def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, monk
 
 
 @pytest.mark.parametrize("kernel", ["1", "4", "8"])
-def test_optimize_current_pose_edge_cases(gpu, oracle, map_v1, gt_sync, monkeypatch, kernel):
-    monkeypatch.setenv("GMMLOC_POSE_WAVES", kernel)
+def test_optimize_current_pose_edge_cases(gpu, oracle, map_v1, gt_sync, opt, kernel):
+    opt("pose_waves", int(kernel))
     """< 3 correspondences -> returns 0 and leaves the pose; < 10 -> single round; features
     without map point (octave < 0) are skipped; noise-free input recovers the pose."""
     mean, cov = map_v1

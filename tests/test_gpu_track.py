@@ -24,12 +24,11 @@ def oracle_track(oracle, h, cam, f):
     return keep, poses[0], pts, final, idx, d2
 
 
-@pytest.mark.parametrize("coop", ["0", "auto", "3"])  # workgroups per frame: never split / by batch size / forced 3
+@pytest.mark.parametrize("shape", [0, -1, 1])  # one workgroup per frame / by batch size / one point per thread
 @pytest.mark.parametrize("mapname,M,seed", [("v1", 400, 10), ("v1", 2000, 20), ("synth", 1000, 30), ("v1", 2100, 40)])
-def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, monkeypatch, mapname, M, seed, coop):
+def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, opt, mapname, M, seed, shape):
     torch, ctx = gpu
-    if coop != "auto":
-        monkeypatch.setenv("GMMLOC_BA_COOP", coop)
+    opt("ba_shape", shape)
     mean, cov = map_v1 if mapname == "v1" else synth.synth_gmm(4096, 1)
     cam, prm = api.Camera(), api.Params()
     gt = gt_sync["V1_03_difficult"]
@@ -172,53 +171,97 @@ def test_track_frames_full_size_known_answer(gpu):
         assert dt < 1e-9 and dr < 1e-9, (b, dt, dr)
 
 
-def test_track_frames_latency_shape_equals_batch_shape(gpu, map_v1, gt_sync, monkeypatch):
-    """The frame-at-a-time shape (a frame dealt to 2..4 workgroups, reductions exchanged between them) against the
-    one-workgroup-per-frame shape on odd sizes: uneven splits (M = 513: 257 + 256 points), a last workgroup with
-    very few points, padding rows; same associations, poses within the north-star tolerance of each other."""
+def _run_track(torch, ctx, g, cam, prm, frames, sel=None):
+    fr = frames if sel is None else [frames[i] for i in sel]
+    T = lambda k: torch.from_numpy(np.stack([f[k] for f in fr])).cuda()
+    pose, Xw = T("pose_init"), T("Xw")
+    assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T("obs"), T("octave"))
+    torch.cuda.synchronize()
+    return pose.cpu().numpy(), Xw.cpu().numpy(), assoc.cpu().numpy(), d2.cpu().numpy()
+
+
+def test_track_frames_bit_identical_across_shapes(gpu, map_v1, gt_sync, opt):
+    """ONE summation order (gl_ba_fast_impl.hpp): the frame-at-a-time shape (one point per thread, a frame dealt to
+    1..4 co-resident workgroups, sums exchanged between them) and the batch shape (one workgroup of G waves per
+    frame) must return the same BITS - poses, points, associations - on odd sizes: every chunks-per-group count,
+    last groups with one chunk or a few points, padding rows, all three LDS classes."""
     torch, ctx = gpu
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
     g = api.GMM(ctx, mean, cov)
     rng = np.random.default_rng(77)
-    for M, B in [(513, 3), (1025, 2), (1537, 5), (1999, 1), (777, 7)]:
+    for M, B in [(37, 3), (64, 2), (130, 4), (300, 5), (496, 2), (513, 3), (640, 2), (777, 7), (1000, 2), (1025, 2),
+                 (1537, 5), (1999, 1), (2000, 3)]:
         frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, B, M, 1000 + M, outlier_frac=0.05)
         for f in frames:
             f["octave"][rng.uniform(size=M) < 0.1] = -1
-        T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
         res = {}
-        for mode in ("0", "4" if M > 1536 else "3" if M > 1024 else "2"):
-            monkeypatch.setenv("GMMLOC_BA_COOP", mode)
-            pose, Xw = T("pose_init"), T("Xw")
-            assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T("obs"), T("octave"))
-            torch.cuda.synchronize()
-            res[mode] = (pose.cpu().numpy(), Xw.cpu().numpy(), assoc.cpu().numpy(), d2.cpu().numpy())
-        (p0, x0, a0, d0), (p1, x1, a1, d1) = res.values()
-        assert np.array_equal(d0, d1) and np.array_equal(a0, a1), (M, B)
-        for b in range(B):
-            dt, dr = pose_err(p0[b], p1[b])
-            assert dt < 1e-6 and dr < 1e-6, (M, b, dt, dr)
-            pad = frames[b]["octave"] < 0
-            assert np.array_equal(x0[b][pad], x1[b][pad])
+        for shape in (0, 1):
+            opt("ba_shape", shape)
+            res[shape] = _run_track(torch, ctx, g, cam, prm, frames)
+        for a, b, what in zip(res[0], res[1], ("pose", "points", "assoc", "chi2")):
+            assert np.array_equal(a, b, equal_nan=True), (M, B, what, np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("threads,M", [("128", 450), ("256", 900), ("512", 450)])
-def test_track_frames_block_shapes(gpu, oracle, map_v1, gt_sync, monkeypatch, threads, M):
-    """The batch shapes (128 / 256 threads per frame: 4 / 2 frames per CU) are what large batches of small frames
-    run on; small test batches default to 512 threads, so the small shapes are forced here."""
+def test_track_frames_result_independent_of_batch(gpu, map_v1, gt_sync, opt):
+    """A drop-in caller gets the same bits for a frame whatever rides with it: alone (B = 1: latency shape), in a
+    handful, and inside a batch larger than the chip (B > CUs: batch shape)."""
     torch, ctx = gpu
-    monkeypatch.setenv("GMMLOC_BA_THREADS", threads)
-    monkeypatch.setenv("GMMLOC_BA_COOP", "0")
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    opt("ba_shape", -1)
+    for M, B in [(300, 700), (1200, 300), (2000, 280)]:
+        frames = make_frames(mean, cov, gt_sync["V1_03_difficult"], cam, 6, M, 5000 + M, outlier_frac=0.08)
+        frames = [frames[i % 6] for i in range(B)]
+        big = _run_track(torch, ctx, g, cam, prm, frames)
+        for sel in ([0], [1], [0, 1, 2, 3, 4, 5], list(range(40))):
+            small = _run_track(torch, ctx, g, cam, prm, frames, sel)
+            for a, b, what in zip(big, small, ("pose", "points", "assoc", "chi2")):
+                assert np.array_equal(a[sel], b, equal_nan=True), (M, len(sel), what)
+
+
+def test_track_frames_step32_option(gpu, oracle, opt):
+    """The refine's point step: exact fp64 (default, what bench.py times) against the fp32-cached step of round 1
+    (option ba_step32) on 8 of the actual bench frames (bench.py seeds, 4 096-Gaussian synthetic map, M = 2 000,
+    noisy observations, 10 % outliers), both against the oracle.  The default must hold the north-star tolerance
+    with margin; the fp32 variant is only required to stay close (it is an opt-in speed switch)."""
+    import bench
+    torch, ctx = gpu
+    mean, cov, cam, frames = bench.make_workload(8)
+    prm = api.Params()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    ref = [oracle_track(oracle, h, cam, f) for f in frames]
+    worst = {}
+    for s32 in (0, 1):
+        opt("ba_step32", s32)
+        pose, Xw, assoc, d2 = _run_track(torch, ctx, g, cam, prm, frames)
+        w = (0.0, 0.0)
+        for i, (keep, p_ref, pts_ref, a_ref, idx0, d20) in enumerate(ref):
+            dt, dr = pose_err(pose[i], p_ref)
+            w = (max(w[0], dt), max(w[1], dr))
+            assert np.array_equal(d2[i][keep], d20)
+            if s32 == 0:
+                assert np.array_equal(assoc[i][keep], a_ref), i
+        worst[s32] = w
+    oracle.gmm_destroy(h)
+    assert worst[0][0] < 1e-6 and worst[0][1] < 1e-6, worst   # exact step: the north-star tolerance (measured 7e-8)
+    assert worst[1][0] < 1e-4 and worst[1][1] < 1e-4, worst   # fp32-cached step: close, not bound to 1e-6
+
+
+@pytest.mark.parametrize("M", [450, 900, 1500])
+def test_track_frames_lds_classes(gpu, oracle, map_v1, gt_sync, opt, M):
+    """The batch shape on the three LDS classes (496 / 1 000 / 2 000 points: 4 / 2 / 1 frames per CU); small test
+    batches would default to the latency shape, so the batch shape is forced here."""
+    torch, ctx = gpu
+    opt("ba_shape", 0)
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
     frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 3, M, 3000 + M, outlier_frac=0.05)
     g = api.GMM(ctx, mean, cov)
     h = oracle.gmm_create(mean, cov)
-    T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
-    pose, Xw = T("pose_init"), T("Xw")
-    assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T("obs"), T("octave"))
-    torch.cuda.synchronize()
-    pose, assoc = pose.cpu().numpy(), assoc.cpu().numpy()
+    pose, Xw, assoc, d2 = _run_track(torch, ctx, g, cam, prm, frames)
     for i, f in enumerate(frames):
         keep, p_ref, pts_ref, a_ref, idx0, d20 = oracle_track(oracle, h, cam, f)
         dt, dr = pose_err(pose[i], p_ref)

@@ -15,9 +15,9 @@ def _poses(gt, n, step=61):
 
 @pytest.mark.parametrize("threads", ["256", "1024"])  # the batch / the few-views block shape
 @pytest.mark.parametrize("mapname,seq", [("v1", "V1_01_easy"), ("v1", "V1_03_difficult"), ("v2", "V2_02_medium")])
-def test_search2d_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, monkeypatch, mapname, seq, threads):
+def test_search2d_matches_oracle(gpu, oracle, map_v1, map_v2, gt_sync, opt, mapname, seq, threads):
     torch, ctx = gpu
-    monkeypatch.setenv("GMMLOC_VIEW_THREADS", threads)
+    opt("view_threads", int(threads))
     mean, cov = map_v1 if mapname == "v1" else map_v2
     cam = api.Camera()
     g = api.GMM(ctx, mean, cov)
@@ -81,14 +81,14 @@ def test_search2d_knn_sizes(gpu, oracle, map_v1, gt_sync, k):
 
 
 @pytest.mark.parametrize("threads,slot_lds", [("256", None), ("1024", None), ("256", "24"), ("1024", "24")])
-def test_search2d_interacting_candidates(gpu, oracle, map_v1, gt_sync, monkeypatch, threads, slot_lds):
+def test_search2d_interacting_candidates(gpu, oracle, map_v1, gt_sync, opt, threads, slot_lds):
     """Every component followed by a jittered copy: consecutive candidates fall below the merge threshold of each
     other, replace each other's slots and share old argmins - the ordered part of the merge rounds, in both
     block shapes, with the accepted list in LDS and spilled to the global scratch."""
     torch, ctx = gpu
-    monkeypatch.setenv("GMMLOC_VIEW_THREADS", threads)
+    opt("view_threads", int(threads))
     if slot_lds:
-        monkeypatch.setenv("GMMLOC_VIEW_SLOT_LDS", slot_lds)
+        opt("view_slot_lds", int(slot_lds))
     mean, cov = map_v1
     rng = np.random.default_rng(77)
     K = mean.shape[0]
@@ -102,12 +102,12 @@ def test_search2d_interacting_candidates(gpu, oracle, map_v1, gt_sync, monkeypat
 
 
 @pytest.mark.parametrize("threads", ["256", "1024"])
-def test_search2d_needle_fan(gpu, oracle, monkeypatch, threads):
+def test_search2d_needle_fan(gpu, oracle, opt, threads):
     """160 thin components fanned around one centre: every pair has Mahalanobis part 0 (nothing is screened
     out, the pair list of a round overflows and the exhaustive path runs) while the log part keeps most of
     them apart."""
     torch, ctx = gpu
-    monkeypatch.setenv("GMMLOC_VIEW_THREADS", threads)
+    opt("view_threads", int(threads))
     n = 160
     mean = np.tile(np.array([[0.0, 0.0, 3.0]]), (n, 1)) + np.random.default_rng(5).normal(0, 1e-4, (n, 3))
     cov = np.empty((n, 3, 3))

@@ -1,4 +1,4 @@
-"""Single-problem time of gl_joint_optimization against the workgroups per problem (GMMLOC_BAGEN_NB; 0 = the library default)."""
+"""Single-problem time of gl_joint_optimization against the workgroups per problem (context option bagen_nb; 0 = the library default)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gmmloc_amd
@@ -16,7 +16,7 @@ for (P, F, L) in [(1, 1, 200), (2, 2, 400), (4, 2, 800), (8, 4, 1500), (12, 4, 2
     args = [T(p["prior"][None]), None, assoc, T(p["obs_ptr"][None]), T(p["obs_pose"][None]), T(p["obs_uvr"][None]), T(p["obs_oct"][None])]
     line = "P%d F%d L%d obs %d:" % (P, F, L, len(p["obs_pose"]))
     for nb in ("0", "1", "2", "4", "8", "16", "32", "64"):
-        os.environ.pop("GMMLOC_BAGEN_NB", None) if nb == "0" else os.environ.__setitem__("GMMLOC_BAGEN_NB", nb)
+        ctx.set_option("bagen_nb", int(nb))
         def run():
             poses = T(p["poses"][None]); pts = T(p["points"][None])
             return api.joint_optimization(ctx, g, cam, prm, P, F, poses, args[0], pts, assoc, *args[3:])

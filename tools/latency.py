@@ -57,17 +57,17 @@ with torch.cuda.stream(ctx.stream):
     for B in (1, 16, 64, 128, 1024, 4096):
         pb, xb, ob, ocb, uvb = p0[:B].contiguous(), x0[:B].contiguous(), o[:B].contiguous(), oc[:B].contiguous(), uv[:B].contiguous()
         for env in ("1", "4", "8"):
-            os.environ["GMMLOC_POSE_WAVES"] = env
+            ctx.set_option("pose_waves", int(env))
             timed("optimizeCurrentPose B=%d M=1000 (%s waves per frame)" % (B, env),
                   lambda: api.optimize_current_pose(ctx, cam, prm, pb.clone(), xb, ob, ocb))
-        os.environ.pop("GMMLOC_POSE_WAVES", None)
+        ctx.set_option("pose_waves", 0)
         for env in ("0", "2", "4"):
             if B * int(env) > 512:
                 continue
-            os.environ["GMMLOC_POSE_COOP"] = env
+            ctx.set_option("pose_coop", int(env))
             timed("optimizeCurrentPose B=%d M=1000 (coop %s workgroups per frame)" % (B, env),
                   lambda: api.optimize_current_pose(ctx, cam, prm, pb.clone(), xb, ob, ocb))
-        os.environ.pop("GMMLOC_POSE_COOP", None)
+        ctx.set_option("pose_coop", -1)
         timed("track_frames B=%d M=1000 K=%d" % (B, mean1.shape[0]),
               lambda: gmmloc_amd.track_frames(ctx, g1, cam, prm, pb.clone(), xb.clone(), ob, ocb, want_d2=False))
         timed("search2d B=%d N=1000" % B, lambda: g1.search2d(cam, pb, uvb, None, k=5))

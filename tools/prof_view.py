@@ -27,7 +27,7 @@ for Bt in (1, 16, 64, 128, 512, 2048):
     ub = uv[:1].repeat(Bt, 1, 1).contiguous() if Bt > B else uv[:Bt].contiguous()
     line = "B=%5d:" % Bt
     for th in ("256", "1024"):
-        os.environ["GMMLOC_VIEW_THREADS"] = th
+        ctx.set_option("view_threads", int(th))
         for _ in range(3):
             g.search2d(cam, pb, ub, None, k=5, view_cap=64)
         torch.cuda.synchronize(); t0 = time.perf_counter()

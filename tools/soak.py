@@ -1,119 +1,148 @@
 """Randomised parity soak on the GPU box: many seeds of the key-frame chain (search2d -> checkMapAssociation,
-createMapPoints), of the per-frame path and of the local BA against the oracle; prints the first mismatch and a summary.
-    python tools/soak.py [rounds]"""
-import os, sys, time
+createMapPoints), of the per-frame path (gl_track_frames), of optimizeCurrentPose and of the local BA against the
+oracle, at the STRICT tolerances of the parity tests (decisions equal, pose 1e-6 m / 1e-6 rad, associated points
+1e-9, triangulated points 1e-8).  Every deviation is printed with its (map, round) label - tools/soak_cases.py
+regenerates the inputs from the label - and its inputs + GPU outputs are saved for the three-way comparison
+HIP / C++ oracle / numpy restatement of tools/soak_classify.py.
+    python tools/soak.py [rounds] [--dump DIR]"""
+import argparse
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch, gmmloc_amd
-from gmmloc_amd import api, synth
+import numpy as np
+import torch
+
+import gmmloc_amd
+from gmmloc_amd import api
 from tests import oracle_lib
 from tests.test_gpu_pose import pose_err
-from tests.test_gpu_track import oracle_track
+from tools import soak_cases as sc
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ap = argparse.ArgumentParser()
+ap.add_argument("rounds", nargs="?", type=int, default=40)
+ap.add_argument("--dump", default=None, help="directory for the inputs / GPU outputs of every deviation")
+ap.add_argument("--maps", default="map_v1,map_v2")
+args = ap.parse_args()
+rounds = args.rounds
+if args.dump:
+    os.makedirs(args.dump, exist_ok=True)
+
 orc = oracle_lib.load()
 ctx = gmmloc_amd.Context(0)
 cam, prm = api.Camera(), api.Params()
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-gts = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))
-bad = 0
-soft = 0  # numerical deviations on ill-conditioned inputs (reported, not failures)
+gts = sc.load_gt()
+count = dict(chain=0, chain_fallback=0, tri=0, tri_far=0, track=0, pose=0, ba=0)
+checked = dict(chain=0, tri=0, track=0, pose=0, ba=0)
 t0 = time.time()
-for mapname, seqs in (("map_v1", ["V1_01_easy", "V1_02_medium", "V1_03_difficult"]), ("map_v2", ["V2_01_easy", "V2_02_medium"])):
-    d = np.load(os.path.join(ROOT, "tests", "golden", mapname + ".npz")); mean, cov = d["mean"], d["cov"]
-    g = gmmloc_amd.GMM(ctx, mean, cov, prm); h = orc.gmm_create(mean, cov)
+
+
+def report(kind, mapname, r, detail, **arrays):
+    count[kind] += 1
+    print("DEVIATION %-14s %s round %d  %s" % (kind, mapname, r, detail), flush=True)
+    if args.dump:
+        np.savez_compressed(os.path.join(args.dump, "%s_%s_r%d.npz" % (kind, mapname, r)), **arrays)
+
+
+for mapname in args.maps.split(","):
+    mean, cov = sc.load_map(mapname)
+    g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+    h = orc.gmm_create(mean, cov)
     for r in range(rounds):
-        rng = np.random.default_rng(1000 * len(mapname) + r)
-        gt = gts[seqs[r % len(seqs)]]
-        while True:  # a key-frame pair with a baseline: the caller of createMapPoints skips the others (the sequences
-            ia = int(rng.integers(0, gt.shape[0] - 40)); ib = ia + int(rng.integers(3, 30))  # start with a standing robot)
-            if np.linalg.norm(gt[ia][1:4] - gt[ib][1:4]) > 0.05:
-                break
-        p1, p2 = synth.gt_row_to_Tcw(gt[ia]), synth.gt_row_to_Tcw(gt[ib])
-        N = int(rng.integers(50, 900))
-        # ---- key-frame association chain
-        f = synth.synth_frame(mean, cov, p1, cam, N, 7000 + r, mono_frac=0.0, outlier_frac=0.1)
-        pts = f["Xw"] + rng.standard_normal((N, 3)) * 0.02
-        octv = f["octave"].copy(); octv[rng.uniform(size=N) < 0.05] = -1
-        cand, ncand, vids, nview = g.search2d(cam, T(p1[None]), T(f["obs"][None, :, :2].copy()), None, k=5, view_cap=4096)
-        pd = T(pts[None])
-        out = api.check_map_association(ctx, g, cam, prm, T(p1[None]), pd, T(f["obs"][None]), T(octv[None]), cand, ncand)
+        c = sc.gen(mapname, r, mean, cov, gts, cam)
+        # ---- key-frame association chain: renderView + searchCorrespondence, then checkMapAssociation
+        ch = c["chain"]
+        cand, ncand, vids, nview = g.search2d(cam, T(ch["pose"][None]), T(ch["obs"][None, :, :2].copy()), None, k=5, view_cap=4096)
+        pd = T(ch["pts"][None])
+        out = api.check_map_association(ctx, g, cam, prm, T(ch["pose"][None]), pd, T(ch["obs"][None]), T(ch["octave"][None]), cand, ncand)
         torch.cuda.synchronize()
-        ids, _, _, _ = orc.render_view(h, cam, p1)
-        c_ref, n_ref = orc.search_correspondence(h, f["obs"][:, :2].copy(), 5)
-        ok = int(nview[0]) == len(ids) and np.array_equal(vids[0].cpu().numpy()[:len(ids)], ids) and \
+        ids, _, _, _ = orc.render_view(h, cam, ch["pose"])
+        c_ref, n_ref = orc.search_correspondence(h, ch["obs"][:, :2].copy(), 5)
+        view_ok = int(nview[0]) == len(ids) and np.array_equal(vids[0].cpu().numpy()[:len(ids)], ids) and \
             np.array_equal(cand[0].cpu().numpy(), c_ref) and np.array_equal(ncand[0].cpu().numpy(), n_ref)
-        keep = octv >= 0
-        o_ref, p_ref = orc.check_map_association(h, cam, p1, pts[keep], f["obs"][keep], octv[keep], c_ref[keep], n_ref[keep])
-        pg = pd[0].cpu().numpy()[keep]
-        hit = o_ref >= 0  # associated points to 1e-9; the fallback branch (no association, point moved towards the nearest
-        ok = ok and np.array_equal(out[0].cpu().numpy()[keep], o_ref) and np.allclose(pg[hit], p_ref[hit], rtol=0, atol=1e-9)
-            # mean) also runs on inconsistent outliers (u < 0, negative disparity): 5 GN steps on garbage, reported only
-        soft += int((np.abs(pg[~hit] - p_ref[~hit]).max(1) > 1e-4).sum()) if (~hit).any() else 0
+        keep = ch["octave"] >= 0
+        o_ref, p_ref = orc.check_map_association(h, cam, ch["pose"], ch["pts"][keep], ch["obs"][keep], ch["octave"][keep], c_ref[keep], n_ref[keep])
+        og, pg = out[0].cpu().numpy()[keep], pd[0].cpu().numpy()[keep]
+        hit = o_ref >= 0
+        checked["chain"] += 1
+        if not (view_ok and np.array_equal(og, o_ref) and np.allclose(pg[hit], p_ref[hit], rtol=0, atol=1e-9)):
+            report("chain", mapname, r, "view/candidates equal %s, %d association(s) differ, associated points max |d| %.3g"
+                   % (view_ok, int((og != o_ref).sum()), np.abs(pg[hit] - p_ref[hit]).max() if hit.any() else 0.0),
+                   assoc_gpu=og, pts_gpu=pg)
+        # the no-association fallback (gmmloc_opt.cpp:237-256) moves the point towards the nearest mean with a
+        # 5-step Gauss-Newton that also runs on inconsistent outliers: strict 1e-9 here too, counted separately
+        dfb = np.abs(pg[~hit] - p_ref[~hit]).max(1) if (~hit).any() else np.zeros(0)
+        if (dfb > 1e-9).any():
+            report("chain_fallback", mapname, r, "%d of %d unassociated points moved differently, max |d| %.3g"
+                   % (int((dfb > 1e-9).sum()), int((~hit).sum()), dfb.max()), assoc_gpu=og, pts_gpu=pg)
         # ---- createMapPoints
-        m = synth.synth_tri_matches(mean, cov, p1, p2, cam, int(rng.integers(20, 500)), 9000 + r)
+        m = c["tri"]
         x_ref, t_ref, cc_ref = orc.create_map_points(h, cam, **m)
-        keys = ("pose1", "uvr1", "depth1", "oct1", "pose2", "uvr2", "depth2", "oct2", "cand1", "n1", "cand2", "n2")
-        x, t, c = api.create_map_points(ctx, g, cam, prm, *[T(m[k]) for k in keys])
+        x, t, cg = api.create_map_points(ctx, g, cam, prm, *[T(m[k]) for k in sc.TRI_KEYS])
         torch.cuda.synchronize()
-        # near-parallel rays triangulate to points 10^3 .. 10^8 m away where Gauss-Newton is chaotic (the numpy
-        # restatement disagrees with both there): neither the coordinates nor the sign-dependent checks compare
-        xg = x.cpu().numpy()
+        xg, tg, cg = x.cpu().numpy(), t.cpu().numpy(), cg.cpu().numpy()
         with np.errstate(invalid="ignore"):
-            sane = (np.linalg.norm(x_ref, axis=1) < 100.0) & (np.linalg.norm(np.nan_to_num(xg, nan=1e9), axis=1) < 100.0)
+            far = ~((np.linalg.norm(x_ref, axis=1) < 100.0) & (np.linalg.norm(np.nan_to_num(xg, nan=1e9), axis=1) < 100.0))
         acc = t_ref > 0
-        ok2 = np.array_equal(t.cpu().numpy()[sane], t_ref[sane]) and np.array_equal(c.cpu().numpy()[sane], cc_ref[sane]) and \
-            np.allclose(xg[sane & acc], x_ref[sane & acc], rtol=0, atol=1e-8)
-        soft += int((~sane).sum())
-        # ---- per-frame path (every 4th round: the oracle's joint_optimization is slow)
-        ok3 = True
-        if r % 4 == 0:
-            M = int(rng.integers(30, 700))
-            ft = synth.synth_frame(mean, cov, p1, cam, M, 11000 + r, outlier_frac=0.05)
+        checked["tri"] += 1
+        dec = (tg != t_ref) | (cg != cc_ref)
+        with np.errstate(invalid="ignore"):
+            num = acc & (tg == t_ref) & ~(np.abs(xg - x_ref).max(1) <= 1e-8)
+        if (dec | num)[~far].any():
+            report("tri", mapname, r, "%d decision(s), %d point(s) differ among the %d matches within 100 m"
+                   % (int(dec[~far].sum()), int(num[~far].sum()), int((~far).sum())), x_gpu=xg, type_gpu=tg, comp_gpu=cg)
+        if (dec | num)[far].any():
+            report("tri_far", mapname, r, "%d match(es) triangulated beyond 100 m differ" % int((dec | num)[far].sum()),
+                   x_gpu=xg, type_gpu=tg, comp_gpu=cg)
+        # ---- per-frame path
+        ft = c["track"]
+        if ft is not None:
             pose, Xw = T(ft["pose_init"][None]), T(ft["Xw"][None])
             assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T(ft["obs"][None]), T(ft["octave"][None]))
             torch.cuda.synchronize()
-            keep, p_ref, pts_ref, a_ref, idx0, d20 = oracle_track(orc, h, cam, ft)
+            keepf, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(orc, h, cam, ft)
             dt, dr = pose_err(pose.cpu().numpy()[0], p_ref)
-            # the Levenberg schedule (5 / 5 / 40 iterations) can stop before convergence on small, outlier-ridden frames:
-            # the end point then depends on the summation order (it does between the library's own launch shapes): reported
-            ok3 = dt < 1e-2 and dr < 1e-2 and np.array_equal(assoc.cpu().numpy()[0][keep], a_ref) and np.array_equal(d2.cpu().numpy()[0][keep], d20)
-            soft += 0 if (dt < 1e-6 and dr < 1e-6) else 1
-        # ---- optimizeCurrentPose (random size: every launch shape of the kernel over the rounds)
-        Mp = int(rng.integers(5, 1300))
-        fp = synth.synth_frame(mean, cov, p1, cam, Mp, 13000 + r, outlier_frac=0.08)
-        fp["octave"][rng.uniform(size=Mp) < 0.1] = -1
+            checked["track"] += 1
+            a_ok = np.array_equal(assoc.cpu().numpy()[0][keepf], a_ref)
+            d_ok = np.array_equal(d2.cpu().numpy()[0][keepf], d20)
+            if not (dt < 1e-6 and dr < 1e-6 and a_ok and d_ok):
+                report("track", mapname, r, "M %d pose |dt| %.3g m |dr| %.3g rad, associations equal %s, chi2 equal %s"
+                       % (len(ft["octave"]), dt, dr, a_ok, d_ok), pose_gpu=pose.cpu().numpy()[0], Xw_gpu=Xw.cpu().numpy()[0],
+                       assoc_gpu=assoc.cpu().numpy()[0])
+        # ---- optimizeCurrentPose
+        fp = c["pose"]
         pose = T(fp["pose_init"][None])
         outl, nin = api.optimize_current_pose(ctx, cam, prm, pose, T(fp["Xw"][None]), T(fp["obs"][None]), T(fp["octave"][None]))
         torch.cuda.synchronize()
         pr, orf, nr_ = orc.optimize_current_pose(cam, fp["pose_init"], fp["Xw"], fp["obs"], fp["octave"])
         dt, dr = pose_err(pose.cpu().numpy()[0], pr)
-        ok3 = ok3 and dt < 1e-6 and dr < 1e-6 and np.array_equal(outl.cpu().numpy()[0], orf) and int(nin[0]) == nr_
-        if not (ok and ok2 and ok3):
-            bad += 1
-            print("MISMATCH", mapname, "round", r, "frames", ia, ib, "N", N, "chain", ok, "createMapPoints", ok2, "track+pose", ok3, flush=True)
+        checked["pose"] += 1
+        m_ok = np.array_equal(outl.cpu().numpy()[0], orf) and int(nin[0]) == nr_
+        if not (dt < 1e-6 and dr < 1e-6 and m_ok):
+            report("pose", mapname, r, "M %d pose |dt| %.3g |dr| %.3g, masks equal %s" % (len(fp["octave"]), dt, dr, m_ok),
+                   pose_gpu=pose.cpu().numpy()[0], outl_gpu=outl.cpu().numpy()[0])
     orc.gmm_destroy(h)
+
 # ---- local BA: random window sizes and forced workgroup counts (lanes per point / waves per block combinations)
-from tests.test_gpu_ba import make_ba_problem, run_gpu, check
-d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz")); mean, cov = d["mean"], d["cov"]
-g = gmmloc_amd.GMM(ctx, mean, cov, prm); h = orc.gmm_create(mean, cov)
-rng = np.random.default_rng(5)
-for r in range(max(10, rounds // 4)):
-    P, F, L = int(rng.integers(1, 8)), int(rng.integers(0, 4)), int(rng.integers(20, 400))
-    nb = int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64]))
-    if nb:
-        os.environ["GMMLOC_BAGEN_NB"] = str(nb)
-    else:
-        os.environ.pop("GMMLOC_BAGEN_NB", None)
-    p = make_ba_problem(mean, cov, gts["V1_01_easy"], cam, P, F, L, 500 + r, bool(rng.integers(0, 2)))
+from tests.test_gpu_ba import run_gpu, check  # noqa: E402
+mean, cov = sc.load_map("map_v1")
+g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+h = orc.gmm_create(mean, cov)
+for b in sc.gen_ba(max(10, rounds // 4), mean, cov, gts, cam):
+    ctx.set_option("bagen_nb", b["nb"])
+    p = b["problem"]
     idx, d2 = orc.associate3d(h, p["points"])
     a = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
+    checked["ba"] += 1
+    res = run_gpu((torch, ctx), g, cam, prm, [p], [a])
     try:
-        check([p], [a], run_gpu((torch, ctx), g, cam, prm, [p], [a]), orc, h, cam)
-    except AssertionError as e:  # windows without a fixed pose or prior have gauge freedom; small ones stop unconverged
-        soft += 1
-        print("deviation local BA round", r, "P F L NB", P, F, L, nb, str(e)[:120], flush=True)
-os.environ.pop("GMMLOC_BAGEN_NB", None)
+        check([p], [a], res, orc, h, cam)
+    except AssertionError as e:
+        report("ba", "map_v1", b["r"], "P %d F %d L %d NB %d prior %s: %s" % (b["P"], b["F"], b["L"], b["nb"], b["prior"], str(e)[:100]),
+               poses_gpu=res[0][0], points_gpu=res[1][0], dropped_gpu=res[2][0], erase_gpu=res[3][0], iters_gpu=res[4][0])
+ctx.set_option("bagen_nb", 0)
 orc.gmm_destroy(h)
-print("soak: %d rounds per map, %d decision mismatches, %d numerical deviations on ill-conditioned inputs, %.0f s" % (rounds, bad, soft, time.time() - t0))
-sys.exit(1 if bad else 0)
+print("soak: %d rounds per map; checked %s; deviations %s; %.0f s" % (rounds, checked, count, time.time() - t0))
+sys.exit(1 if sum(count.values()) else 0)

@@ -18,7 +18,7 @@ def haar(rng, K):
 def main():
     ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     ctx = gmmloc_amd.Context(0)
-    os.environ["GMMLOC_ASSOC_INDEX_MIN"] = "0"
+    ctx.set_option("assoc_index_min", 0)
     bad = 0
     for case in range(ncase):
         rng = np.random.default_rng(1000 + case)
