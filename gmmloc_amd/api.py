@@ -239,13 +239,15 @@ class GMM:
             pass
 
 
-def optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octave):
+def optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octave, outlier=None):
     """Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217) for B frames.
-    pose (B,7) in/out, Xw (B,M,3), obs (B,M,3), octave (B,M) int32 (<0: no map point).
+    pose (B,7) in/out, Xw (B,M,3), obs (B,M,3), octave (B,M) int32 (<0: no map point); outlier (B,M) uint8
+    in/out (is_outlier_: rewritten where a map point exists, untouched elsewhere; default: zeros).
     Returns (outlier uint8 (B,M), ninlier int32 (B,))."""
     import torch
     B, M = octave.shape
-    outlier = torch.zeros((B, M), dtype=torch.uint8, device=pose.device)
+    if outlier is None:
+        outlier = torch.zeros((B, M), dtype=torch.uint8, device=pose.device)
     nin = torch.zeros(B, dtype=torch.int32, device=pose.device)
     ctx._enter()
     _check(ctx.lib.gl_optimize_current_pose(ctx.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),

@@ -158,7 +158,7 @@ GL_DEV Plane load_plane(const double* __restrict__ rec12, const double* __restri
   return pl;
 }
 
-__global__ void k_optimize_point(PtK k, int N, const double* __restrict__ rec12, const double* __restrict__ axis,
+__global__ void k_optimize_point(PtK k, int N, int K, const double* __restrict__ rec12, const double* __restrict__ axis,
                                  const double* __restrict__ pts, const double* __restrict__ uvr,
                                  const int32_t* __restrict__ octave, const double* __restrict__ pose,
                                  const int32_t* __restrict__ comp, const double* __restrict__ proj_z2,
@@ -166,6 +166,16 @@ __global__ void k_optimize_point(PtK k, int N, const double* __restrict__ rec12,
                                  double* __restrict__ chi2_str, double* __restrict__ pt_est) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  // "no component" (-1, the marker used everywhere in this API) / an octave outside the pyramid: no problem to
+  // solve - failure with the point untouched, never an out-of-range read of the component / sigma tables
+  if (comp[n] < 0 || comp[n] >= K || octave[n] < 0 || octave[n] > 7) {
+    res[n] = 0;
+    chi2_proj[n] = 0.0;
+    chi2_str[n] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt_est[(size_t)n * 3 + i] = pts[(size_t)n * 3 + i];
+    return;
+  }
   const FixedPose P = load_pose(pose + (size_t)n * 7);
   const Plane pl = load_plane(rec12, axis, comp[n]);
   const StrOptStat r = optimize_point(k, P, pts + (size_t)n * 3, uvr + (size_t)n * 3, octave[n], pl, proj_z2[n]);
@@ -343,6 +353,10 @@ __global__ __launch_bounds__(256) void k_optimize_triangulation(PtK k, int N, co
   const double* u2 = uvr2 + (size_t)n * 3;
   const bool st1 = !(u1[2] < 0), st2 = !(u2[2] < 0);  // kp.depth > 0 <=> u_right >= 0
   const double th1 = st1 ? 7.8 : 5.991, th2 = st2 ? 7.8 : 5.991;  // :120-136
+  if (oct1[n] < 0 || oct1[n] > 7) {  // octave outside the pyramid: nothing to weigh the edges with -> no association
+    if (ci == 0) out_comp[n] = -1;
+    return;
+  }
   const double s1 = k.s2inv[oct1[n]];  // both edges use kp1's sigma2_inv (:132,135)
   double* x3d = x3d_all + (size_t)n * 3;
   const double pt_init[3] = {x3d[0], x3d[1], x3d[2]};
@@ -628,7 +642,7 @@ int gl_optimize_point(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, 
   gl::Ctx* c = gl::C(ctx);
   gl::Gmm* g = gl::G(gmm);
   GL_HIP(hipSetDevice(c->device));
-  k_optimize_point<<<(N + 127) / 128, 128, 0, c->stream>>>(make_ptk(cam, prm), N, g->rec12, g->axis, pts_dev, uvr_dev,
+  k_optimize_point<<<(N + 127) / 128, 128, 0, c->stream>>>(make_ptk(cam, prm), N, g->K, g->rec12, g->axis, pts_dev, uvr_dev,
                                                            octave_dev, pose_dev, comp_dev, proj_z2_dev, res_dev,
                                                            chi2_proj_dev, chi2_str_dev, pt_est_dev);
   GL_HIP(hipGetLastError());

@@ -304,8 +304,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
   // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
   double cnt = 0.0;
   for (int e = e0; e < M; e += es) {
-    level[e] = 0;
-    if (octave[e] >= 0) cnt += 1.0;
+    if (octave[e] >= 0) {  // is_outlier_[i] is reset only where mappoints_[i] exists (:63-69); the flags of the
+      level[e] = 0;        // other features stay the caller's
+      cnt += 1.0;
+    }
   }
   const int n_init = (int)block_total1<NW>(cnt, part, xs, C);
   if (n_init < 3) {  // :139-140

@@ -223,7 +223,8 @@ int gl_search_by_projection_frame(gl_ctx_t* ctx, const gl_camera* cam, float sca
 /* ---- point refinement ----------------------------------------------------- */
 /* GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N independent problems.
  * pts N x 3, uvr N x 3 (u, v, u_right), octave N, pose N x 7, comp N, proj_z2 N.
- * out: res N uint8, chi2_proj N, chi2_str N, pt_est N x 3. */
+ * out: res N uint8, chi2_proj N, chi2_str N, pt_est N x 3.  A problem without a component (comp < 0 or
+ * >= K) or with an octave outside 0..7 is not solved: res = 0, chi2 = 0, pt_est = pts. */
 int gl_optimize_point(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int N,
                       const double* pts_dev, const double* uvr_dev, const int32_t* octave_dev,
                       const double* pose_dev, const int32_t* comp_dev, const double* proj_z2_dev,
@@ -240,7 +241,7 @@ int gl_check_map_association(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera
 
 /* Localization::optimizeTriangulationVec (localization_opt.cpp:27-204), N problems.
  * x3d N x 3 in/out; pose1/pose2 N x 7; uvr1/uvr2 N x 3 (u_right < 0 => mono edge);
- * oct1/oct2 N; cand1/cand2 N x k with n1/n2 N; out_comp N. */
+ * oct1/oct2 N; cand1/cand2 N x k with n1/n2 N; out_comp N (an octave outside 0..7: -1, x3d untouched). */
 int gl_optimize_triangulation(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
                               int N, double* x3d_dev, const double* pose1_dev, const double* uvr1_dev,
                               const int32_t* oct1_dev, const double* pose2_dev, const double* uvr2_dev,
@@ -269,7 +270,9 @@ int gl_create_map_points(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* ca
 /* Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217) for B frames.
  *  pose_dev B x 7 in/out; Xw_dev B x M x 3; obs_dev B x M x 3 (u, v, u_right; u_right < 0
  *  => monocular edge); octave_dev B x M int32 (< 0 => feature has no map point);
- *  outlier_dev B x M uint8 (is_outlier_); ninlier_dev B int32 (return value). */
+ *  outlier_dev B x M uint8 (is_outlier_), in/out: rewritten for the features with a map point, left untouched
+ *  for the others (the reference resets is_outlier_[i] only where mappoints_[i] exists, :63-69);
+ *  ninlier_dev B int32 (return value). */
 int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M,
                              double* pose_dev, const double* Xw_dev, const double* obs_dev,
                              const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev);

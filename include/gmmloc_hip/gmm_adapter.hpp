@@ -114,11 +114,12 @@ class GMM {
   }
 
   // Tracking::optimizeCurrentPose for one frame: Xw / obs are M x 3, octave[i] < 0 = no map point.
-  // Returns the inlier count; pose and is_outlier are updated like the reference does.
+  // Returns the inlier count; pose and is_outlier are updated like the reference does: the flag of a feature WITH a
+  // map point is rewritten, the flags of the others are left as the host had them (tracking_opt.cpp:63-69).
   int optimizeCurrentPose(Pose& Tcw, const std::vector<double>& Xw, const std::vector<double>& obs,
                           const std::vector<int32_t>& octave, std::vector<uint8_t>& is_outlier) {
     const int M = (int)octave.size();
-    is_outlier.assign(M, 0);
+    is_outlier.resize(M, 0);
     DevBuf dpose(ctx_, 56), dX(ctx_, (size_t)M * 24 + 8), dO(ctx_, (size_t)M * 24 + 8), doc(ctx_, (size_t)M * 4 + 4),
         dout(ctx_, (size_t)M + 8), dn(ctx_, 8);
     dpose.upload(&Tcw);
@@ -126,6 +127,9 @@ class GMM {
       dX.upload(Xw.data());
       dO.upload(obs.data());
       doc.upload(octave.data());
+      std::vector<uint8_t> cur(M + 8, 0);
+      std::memcpy(cur.data(), is_outlier.data(), M);
+      dout.upload(cur.data());
     }
     check(gl_optimize_current_pose(ctx_, &cam_, &prm_, 1, M, dpose.as<double>(), dX.as<double>(), dO.as<double>(),
                                    doc.as<int32_t>(), dout.as<uint8_t>(), dn.as<int32_t>()),

@@ -88,3 +88,21 @@ def test_optimize_current_pose_edge_cases(gpu, oracle, map_v1, gt_sync, opt, ker
     assert nin[0] == 0 and np.allclose(pose[0], frames[0]["pose_init"] / np.r_[np.ones(4) * np.linalg.norm(frames[0]["pose_init"][:4]), 1, 1, 1])
     dt, dr = pose_err(pose[3], frames[3]["pose_gt"])
     assert dt < 1e-8 and dr < 1e-8
+
+
+def test_optimize_current_pose_keeps_flags_without_map_point(gpu, oracle, map_v1, gt_sync):
+    """is_outlier_[i] is reset only where mappoints_[i] exists (tracking_opt.cpp:63-69): the flags the host holds
+    for the other features must survive the call; the flags of the features with a map point are rewritten."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    f = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 1, 400, 900)[0]
+    f["octave"][::3] = -1
+    preset = np.random.default_rng(1).integers(0, 2, 400).astype(np.uint8)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a[None])).cuda()
+    pose, outl = T(f["pose_init"]), T(preset)
+    _, nin = gmmloc_amd.optimize_current_pose(ctx, cam, prm, pose, T(f["Xw"]), T(f["obs"]), T(f["octave"]), outlier=outl)
+    torch.cuda.synchronize()
+    p_ref, o_ref, n_ref = oracle.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
+    got, none = outl.cpu().numpy()[0], f["octave"] < 0
+    assert np.array_equal(got[none], preset[none]) and np.array_equal(got[~none], o_ref[~none]) and int(nin[0]) == n_ref

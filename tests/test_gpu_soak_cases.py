@@ -1,0 +1,195 @@
+"""The deviations the strict randomised soak found (tools/soak.py, 2 000 rounds per map; profiles/r2_soak_*.txt),
+each held as a three-way test: HIP vs the C++ oracle vs the independent numpy restatement
+(tests/golden/soak_numpy_ref.npz, tools/make_soak_golden.py), together with the oracle's OWN sensitivity to changes
+that leave the mathematics untouched (inputs moved by an ulp, points re-ordered).  A case counts as ill-conditioned
+only because the ORACLE ITSELF moves by more than the parity tolerance under such a change - and the HIP result must
+then still lie within the spread the oracle and the numpy restatement show among themselves; everything else in the
+same problem (the other features / matches, every decision) is held to the strict tolerance.
+Inputs are regenerated from the (map, round) label by tools/soak_cases.py."""
+import os
+
+import numpy as np
+import pytest
+
+import gmmloc_amd
+from gmmloc_amd import api
+from tests.conftest import GOLDEN
+from tests.test_gpu_pose import pose_err
+from tools import soak_cases as sc
+from tools.make_soak_golden import BA, FALLBACK, TRACK, TRI
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def env(gpu, oracle):
+    torch, ctx = gpu
+    cam, prm, gts = api.Camera(), api.Params(), sc.load_gt()
+    maps = {}
+    for name in ("map_v1", "map_v2"):
+        mean, cov = sc.load_map(name)
+        maps[name] = (mean, cov, api.GMM(ctx, mean, cov, prm), oracle.gmm_create(mean, cov))
+    ref = np.load(os.path.join(GOLDEN, "soak_numpy_ref.npz"))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return dict(torch=torch, ctx=ctx, cam=cam, prm=prm, gts=gts, maps=maps, ref=ref, T=T)
+
+
+def ulp_variants(x, n, rng):
+    out = []
+    for _ in range(n):
+        y = np.array(x, float).ravel().copy()
+        j = int(rng.integers(0, y.size))
+        y[j] = np.nextafter(y[j], np.inf if rng.integers(0, 2) else -np.inf)
+        out.append(y.reshape(np.shape(x)))
+    return out
+
+
+@pytest.mark.parametrize("mapname,r", TRACK)
+def test_soak_track_bifurcation(env, oracle, opt, mapname, r):
+    """gl_track_frames on a small, outlier-ridden frame (124 points, optimum 14 cm off the generating pose): the
+    5 / 5 / 40 Levenberg schedule stops before convergence next to an accept / reject flip.  Moving the observations
+    by <= 1 ulp makes the ORACLE jump by up to a millimetre in a few probes out of dozens (and not at all in the
+    others); HIP lands on one of the two branches.  Associations, chi2 and the bits across launch shapes are exact."""
+    e = env
+    mean, cov, g, h = e["maps"][mapname]
+    f = sc.gen(mapname, r, mean, cov, e["gts"], e["cam"])["track"]
+    keep, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(oracle, h, e["cam"], f)
+    res = {}
+    for shape in (0, 1):
+        opt("ba_shape", shape)
+        pose, Xw = e["T"](f["pose_init"][None]), e["T"](f["Xw"][None])
+        assoc, d2 = gmmloc_amd.track_frames(e["ctx"], g, e["cam"], e["prm"], pose, Xw, e["T"](f["obs"][None]), e["T"](f["octave"][None]))
+        e["torch"].cuda.synchronize()
+        res[shape] = (pose.cpu().numpy()[0], Xw.cpu().numpy()[0], assoc.cpu().numpy()[0], d2.cpu().numpy()[0])
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)  # one summation order: the same bits whatever the launch shape
+    pose_hip, _, assoc, d2 = res[0]
+    assert np.array_equal(d2[keep], d20) and np.array_equal(assoc[keep], a_ref)  # decisions are exact
+    hip = max(pose_err(pose_hip, p_ref))
+    # the oracle's own sensitivity: points re-ordered / observations moved by <= 1 ulp
+    rng = np.random.default_rng(0)
+    probes = []
+    for _ in range(12):
+        _, p1, _, _, _, _ = sc.track_oracle(oracle, h, e["cam"], f, rng.permutation(len(keep)))
+        probes.append(max(pose_err(p1, p_ref)))
+    for _ in range(36):
+        gobs = f["obs"] * (1 + 3e-16 * rng.standard_normal(f["obs"].shape))
+        gobs[f["obs"] < 0] = f["obs"][f["obs"] < 0]
+        _, p1, _, _, _, _ = sc.track_oracle(oracle, h, e["cam"], dict(f, obs=gobs))
+        probes.append(max(pose_err(p1, p_ref)))
+    probes = np.array(probes)
+    numpy_vs_oracle = max(pose_err(e["ref"]["track_%s_r%d_pose" % (mapname, r)], p_ref))
+    spread = max(probes.max(), numpy_vs_oracle)
+    assert (probes > TOL).sum() >= 1, "the oracle no longer jumps: this frame must then pass the strict tolerance"
+    assert np.median(probes) < 1e-8   # ... and is perfectly stable in the other probes: a flip, not noise
+    assert hip < TOL or hip < 10 * spread, (hip, spread, numpy_vs_oracle)
+
+
+@pytest.mark.parametrize("r", BA)
+def test_soak_ba_gauge_free_window(env, oracle, r):
+    """gl_joint_optimization on a window with ONE free key-frame, no fixed one and no prior: the gauge is free, the
+    normal equations are singular up to the damping, and the oracle's own answer moves by 0.4 mm when its points are
+    re-ordered.  Decisions (dropped associations, erased observations) are exact."""
+    from tests.test_gpu_ba import run_gpu
+    e = env
+    mean, cov, g, h = e["maps"]["map_v1"]
+    b = sc.gen_ba(r + 1, mean, cov, e["gts"], e["cam"])[r]
+    p = b["problem"]
+    assert p["P"] == 1 and p["F"] == 0 and not b["prior"]
+    idx, d2 = oracle.associate3d(h, p["points"])
+    a = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
+    e["ctx"].set_option("bagen_nb", b["nb"])
+    try:
+        out = run_gpu((e["torch"], e["ctx"]), g, e["cam"], e["prm"], [p], [a])
+    finally:
+        e["ctx"].set_option("bagen_nb", 0)
+    args = (p["obs_ptr"], p["obs_pose"], p["obs_uvr"], p["obs_oct"])
+    ref = oracle.joint_optimization(h, e["cam"], 1, 0, p["poses"], p["prior"], p["points"], a, *args)
+    nobs = len(p["obs_pose"])
+    assert np.array_equal(out[2][0], ref[2]) and np.array_equal(out[3][0][:nobs], ref[3])
+    hip = max(pose_err(out[0][0][0], ref[0][0]))
+    rng = np.random.default_rng(0)
+    L = len(p["points"])
+    spread = 0.0
+    for _ in range(6):
+        perm = rng.permutation(L)
+        optr = np.concatenate([[0], np.cumsum(np.diff(p["obs_ptr"])[perm])]).astype(np.int32)
+        sel = np.concatenate([np.arange(p["obs_ptr"][l], p["obs_ptr"][l + 1]) for l in perm]).astype(int)
+        r2 = oracle.joint_optimization(h, e["cam"], 1, 0, p["poses"], p["prior"], p["points"][perm], a[perm], optr, p["obs_pose"][sel],
+                                       p["obs_uvr"][sel], p["obs_oct"][sel])
+        spread = max(spread, max(pose_err(r2[0][0], ref[0][0])))
+    numpy_vs_oracle = max(pose_err(e["ref"]["ba_r%d_poses" % r][0], ref[0][0]))
+    assert spread > TOL, "the oracle is stable under re-ordering: this window must then pass the strict tolerance"
+    assert hip < 10 * max(spread, numpy_vs_oracle), (hip, spread, numpy_vs_oracle)
+
+
+@pytest.mark.parametrize("mapname,r,j", FALLBACK)
+def test_soak_check_map_association_fallback(env, oracle, mapname, r, j):
+    """checkMapAssociation's no-association fallback (gmmloc_opt.cpp:237-256) also "refines" features whose
+    observation is inconsistent (u < 0, negative disparity): five Gauss-Newton steps that throw the point tens of metres
+    to kilometres away - a result that the oracle itself changes in the same digits when the point moves by one ulp.
+    The association decisions of ALL features and every other point of the key-frame are exact / within 1e-9."""
+    e = env
+    mean, cov, g, h = e["maps"][mapname]
+    ch = sc.gen(mapname, r, mean, cov, e["gts"], e["cam"])["chain"]
+    T = e["T"]
+    cand, ncand, vids, nview = g.search2d(e["cam"], T(ch["pose"][None]), T(ch["obs"][None, :, :2].copy()), None, k=5, view_cap=4096)
+    pd = T(ch["pts"][None])
+    out = api.check_map_association(e["ctx"], g, e["cam"], e["prm"], T(ch["pose"][None]), pd, T(ch["obs"][None]), T(ch["octave"][None]), cand, ncand)
+    e["torch"].cuda.synchronize()
+    ids, _, _, _ = oracle.render_view(h, e["cam"], ch["pose"])
+    c_ref, n_ref = oracle.search_correspondence(h, ch["obs"][:, :2].copy(), 5)
+    assert np.array_equal(vids[0].cpu().numpy()[:len(ids)], ids) and np.array_equal(cand[0].cpu().numpy(), c_ref)
+    keep = ch["octave"] >= 0
+    pts, obs, octv, c_k, n_k = ch["pts"][keep], ch["obs"][keep], ch["octave"][keep], c_ref[keep], n_ref[keep]
+    o_ref, p_ref = oracle.check_map_association(h, e["cam"], ch["pose"], pts, obs, octv, c_k, n_k)
+    og, pg = out[0].cpu().numpy()[keep], pd[0].cpu().numpy()[keep]
+    assert np.array_equal(og, o_ref)
+    dev = np.abs(pg - p_ref).max(1)
+    others = np.arange(len(dev)) != j
+    assert dev[others].max() <= 1e-9
+    assert o_ref[j] == -1 and np.linalg.norm(p_ref[j] - pts[j]) > 10.0  # unassociated, thrown > 10 m away
+    spread = 0.0
+    for v in ulp_variants(pts[j], 12, np.random.default_rng(0)):
+        _, pv = oracle.check_map_association(h, e["cam"], ch["pose"], v[None], obs[j][None], octv[j][None], c_k[j][None], n_k[j][None])
+        spread = max(spread, np.abs(pv[0] - p_ref[j]).max())
+    rec = e["ref"]["fallback_%s_r%d_f%d" % (mapname, r, j)]
+    numpy_vs_oracle = np.abs(rec[1:] - p_ref[j]).max()
+    assert int(rec[0]) == -1
+    assert dev[j] <= 1e-9 or (spread > 1e-9 and dev[j] < 10 * max(spread, numpy_vs_oracle)), (dev[j], spread, numpy_vs_oracle)
+
+
+@pytest.mark.parametrize("mapname,r,j", TRI)
+def test_soak_create_map_points_far(env, oracle, mapname, r, j):
+    """createMapPoints on an epipolar match with near-parallel rays: the linear triangulation lands 10^4 .. 10^9 m
+    away, where 20 Gauss-Newton steps are chaotic - one ulp on a key-point moves the oracle's point by as much as HIP
+    and the numpy restatement differ from it, and flips its sign-dependent checks.  All other matches are exact."""
+    e = env
+    mean, cov, g, h = e["maps"][mapname]
+    m = sc.gen(mapname, r, mean, cov, e["gts"], e["cam"])["tri"]
+    x_ref, t_ref, c_ref = oracle.create_map_points(h, e["cam"], **m)
+    x, t, c = api.create_map_points(e["ctx"], g, e["cam"], e["prm"], *[e["T"](m[k]) for k in sc.TRI_KEYS])
+    e["torch"].cuda.synchronize()
+    xg, tg, cg = x.cpu().numpy(), t.cpu().numpy(), c.cpu().numpy()
+    others = np.arange(len(t_ref)) != j
+    with np.errstate(invalid="ignore"):
+        sane = others & (np.linalg.norm(x_ref, axis=1) < 100.0)
+    assert np.array_equal(tg[sane], t_ref[sane]) and np.array_equal(cg[sane], c_ref[sane])
+    acc = sane & (t_ref > 0)
+    assert np.abs(xg[acc] - x_ref[acc]).max() <= 1e-8
+    assert np.linalg.norm(x_ref[j]) > 1e3  # the match in question: far beyond the 10 m room
+    one = {k: m[k][j:j + 1] for k in m}
+    spread, flips = 0.0, 0
+    for v in ulp_variants(m["uvr1"][j], 12, np.random.default_rng(0)):
+        xv, tv, cv = oracle.create_map_points(h, e["cam"], **dict(one, uvr1=v[None]))
+        flips += int(tv[0] != t_ref[j] or cv[0] != c_ref[j])
+        with np.errstate(invalid="ignore"):
+            spread = max(spread, np.nanmax(np.abs(xv[0] - x_ref[j])))
+    rec = e["ref"]["tri_%s_r%d_m%d" % (mapname, r, j)]
+    numpy_vs_oracle = np.nanmax(np.abs(rec[2:] - x_ref[j]))
+    dev = np.nanmax(np.abs(xg[j] - x_ref[j]))
+    decision_equal = tg[j] == t_ref[j] and cg[j] == c_ref[j]
+    assert spread > 1e-8, "the oracle is stable under an ulp: this match must then pass the strict tolerance"
+    assert dev < 10 * max(spread, numpy_vs_oracle), (dev, spread, numpy_vs_oracle)
+    assert decision_equal or flips > 0 or int(rec[0]) != t_ref[j], (tg[j], t_ref[j], rec[0], flips)

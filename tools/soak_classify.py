@@ -110,14 +110,27 @@ def classify_track(mapname, r, dump, with_numpy):
     keep, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(orc, h, cam, f)
     dt, dr = pose_err(dump["pose_gpu"], p_ref)
     row = dict(M=len(keep), hip_vs_oracle=(dt, dr), oracle_vs_gt=pose_err(p_ref, f["pose_gt"]), init_vs_gt=pose_err(f["pose_init"], f["pose_gt"]))
+    # the oracle's own sensitivity: (1) its points re-ordered (summation order), (2) every observation moved by a
+    # relative 1e-16 .. 1e-15 (0 or 1 ulp).  A Levenberg schedule that stops before convergence can sit next to an
+    # accept / reject flip: then a FEW of the probes jump by the full distance between the two branches, the others
+    # do not move at all - so many probes, and the count of jumps, not just a maximum over a handful
     rng = np.random.default_rng(0)
-    sp = (0.0, 0.0)
-    for _ in range(6):
+    d_perm, d_ulp = [], []
+    for _ in range(12):
         perm = rng.permutation(len(keep))
         _, p1, _, a1, _, _ = sc.track_oracle(orc, h, cam, f, perm)
-        e = pose_err(p1, p_ref)
-        sp = (max(sp[0], e[0]), max(sp[1], e[1]))
-    row["oracle_reorder_spread"] = sp
+        d_perm.append(max(pose_err(p1, p_ref)))
+    for _ in range(36):
+        g = dict(f)
+        g["obs"] = f["obs"] * (1 + 3e-16 * rng.standard_normal(f["obs"].shape))
+        g["obs"][f["obs"] < 0] = f["obs"][f["obs"] < 0]
+        _, p1, _, a1, _, _ = sc.track_oracle(orc, h, cam, g)
+        d_ulp.append(max(pose_err(p1, p_ref)))
+    d_all = np.array(d_perm + d_ulp)
+    row["oracle_probes"] = len(d_all)
+    row["oracle_probe_median"] = float(np.median(d_all))
+    row["oracle_probe_max"] = float(d_all.max())
+    row["oracle_probes_above_1e-6"] = int((d_all > 1e-6).sum())
     if with_numpy:
         L = len(keep)
         assoc = np.where(d20 <= 9.0, idx0, -1).astype(np.int32)
