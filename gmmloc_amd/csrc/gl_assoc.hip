@@ -430,7 +430,7 @@ int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, in
   double min_pairs = 6.7e7;
   if (c->opt.assoc_index_min >= 0) min_pairs = c->opt.assoc_index_min;  // option (tests force the index with 0)
   const bool small = (double)N * g->K < min_pairs;
-  if (mode == GL_ASSOC_EXHAUSTIVE || (mode == GL_ASSOC_BRUTE && (!g->grid.enabled || small)))
+  if (mode == GL_ASSOC_EXHAUSTIVE || (mode == GL_ASSOC_BRUTE && (!g->grid.enabled || c->opt.assoc_grid == 0 || small)))
     return gl::launch_assoc_brute(c, g, pts_dev, N, idx_dev, d2_dev);
   void* scratch = nullptr;
   if (mode == GL_ASSOC_BRUTE) {  // same result through the exact cell index (gl_grid.hip)

@@ -489,15 +489,16 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   // Layout: | assoc partials (used first, dead afterwards) ... reused by ba1 | d2 |
   void* scratch = nullptr;
   const size_t ba_bytes = gl::ba1_scratch_bytes(B, M);
+  const bool use_grid = g->grid.enabled && c->opt.assoc_grid != 0;
   const size_t assoc_bytes =
-      g->grid.enabled ? gl::assoc_index_scratch_bytes(g->K, (int)n, d2_dev != nullptr) : gl::assoc_scratch_bytes(g->K, (int)n);
+      use_grid ? gl::assoc_index_scratch_bytes(g->K, (int)n, d2_dev != nullptr) : gl::assoc_scratch_bytes(g->K, (int)n);
   const size_t work = ba_bytes > assoc_bytes ? ba_bytes : assoc_bytes;
   int rc = gl::ctx_scratch(c, work + n * 8 + 64, &scratch);
   if (rc != GL_OK) return rc;
   double* d2 = d2_dev ? d2_dev : (double*)((char*)scratch + ((work + 63) / 64) * 64);
   // Only chi2 <= 9 survives the gate below, so the points the cell index cannot resolve (minimum
   // above 9) need their exact argmin only when the caller asked for the chi2 values.
-  if (g->grid.enabled)
+  if (use_grid)
     rc = gl::launch_assoc_index(c, g, Xw_dev, (int)n, assoc_dev, d2, d2_dev != nullptr, scratch);
   else
     rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);

@@ -87,6 +87,7 @@ struct Options {
   double view_slot_lds = 0;     // gl_search2d: accepted-list records kept in LDS (0 = all that fit)
   double view_threads = 0;      //   0 auto, 256 / 1024
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
+  double assoc_grid = -1;       // 0: never use the cell index (every association is the N x K sweep); A/B and bench
   double match_desc_lds = -1;   // gl_search_by_projection: descriptors in LDS (-1 auto, 0 / 1)
 };
 // name -> member; nullptr if unknown

@@ -15,12 +15,13 @@ def shard_indices(n_frames, rank, world):
     return np.arange(rank, n_frames, world, dtype=np.int64)
 
 
-def gather_results(local_idx, local_vals, n_frames, world, dist=None, device="cpu"):
+def gather_results(local_idx, local_vals, n_frames, world, dist=None, device="cpu", always_collective=False):
     """All-gather per-frame rows (local_vals: (len(local_idx), D) float64) into a (n_frames, D) array
-    in frame order on every rank.  Shards are padded to the common maximum length."""
+    in frame order on every rank.  Shards are padded to the common maximum length.  always_collective runs the
+    collective at world == 1 too (the RCCL path on a one-GPU box)."""
     import torch
     D = local_vals.shape[1]
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not always_collective):
         out = np.zeros((n_frames, D))
         out[local_idx] = local_vals
         return out
@@ -39,31 +40,28 @@ def gather_results(local_idx, local_vals, n_frames, world, dist=None, device="cp
     return out
 
 
-def replay(frames, compute, rank=0, world=1, dist=None, device="cpu", batch=256):
+def replay(frames, compute, rank=0, world=1, dist=None, device="cpu", batch=256, always_collective=False):
     """frames: list of frame problems; compute(list_of_frames) -> (len, D) float64 rows.
     Returns (results (n_frames, D) on every rank, elapsed seconds = max over ranks)."""
     import time
     import torch
     idx = shard_indices(len(frames), rank, world)
     rows = []
-    if dist is not None and world > 1:
+    coll = dist is not None and (world > 1 or always_collective)
+    if coll:
         dist.barrier()
     t0 = time.perf_counter()
     for s in range(0, len(idx), batch):
         rows.append(compute([frames[i] for i in idx[s:s + batch]]))
     dt = time.perf_counter() - t0
-    local = np.concatenate(rows) if rows else np.zeros((0, 1))
-    if local.shape[0] == 0:  # a rank may own no frames
-        D = 1
-        probe = torch.tensor([0], dtype=torch.int64, device=device)
-        local = np.zeros((0, D))
+    local = np.concatenate(rows) if rows else np.zeros((0, 0))  # a rank may own no frames: it learns the row width below
     t = torch.tensor([dt, float(local.shape[1])], dtype=torch.float64, device=device)
-    if dist is not None and world > 1:
+    if coll:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     D = int(t[1].item())
     if local.shape[0] == 0:
         local = np.zeros((0, D))
-    return gather_results(idx, local, len(frames), world, dist, device), float(t[0].item())
+    return gather_results(idx, local, len(frames), world, dist, device, always_collective), float(t[0].item())
 
 
 # ---- K-sharded association (SURVEY.md 8e, the stress shape: 50 000 points x 65 536 Gaussians) --------------
@@ -99,3 +97,119 @@ def merge_sharded_association(d2_local, idx_local, k_offset, dist=None, world=1)
         dist.all_reduce(gi, op=dist.ReduceOp.MIN)
     gi = torch.where(gi == INDEX_NONE, torch.full_like(gi, -1), gi)
     return gi, d2
+
+
+# ---- BASELINE configs[3]: batch replay of the EuRoC V1 / V2 sequences through the HIP path -----------------------
+# The reference's only end-to-end check is replay -> traj_est.txt -> APE (gmmloc_ros/scripts/evaluate_euroc.sh:65-103,
+# Map::summarize map.cpp:162-188, scripts/evo_euroc.py:28-57).  Its front end (images, ORB) is out of scope, so the
+# frame problems are pre-materialised "synthetic-from-real-map" (SURVEY 8d configs 1 / 4): poses = the lines of
+# data/gt_sync/<sequence>.txt, map = the shipped v1.gmm / v2.gmm, per frame M stereo observations of points drawn from
+# the visible components with pixel noise 1.2^octave, 10 % gross outliers, initial pose = ground truth o exp(xi).
+# Every frame then goes through gl_track_frames (exact association + structure-constrained refine); the refined poses
+# are written in TUM format by the library's writer and scored against gt_sync with the APE of traj.py.
+EUROC_SEQUENCES = (("V1_01_easy", "map_v1"), ("V1_02_medium", "map_v1"), ("V1_03_difficult", "map_v1"),
+                   ("V2_01_easy", "map_v2"), ("V2_02_medium", "map_v2"), ("V2_03_difficult", "map_v2"))
+# per-frame result row: T_cw after optimizeCurrentPose (7), T_cw after the structure refine (7), inliers of the pose
+# refinement, associated points, points with an octave, ms of the batch per frame
+ROW_D = 18
+
+
+def materialise_euroc(golden_dir, cam, M=300, limit=None, seed0=20200901, sequences=EUROC_SEQUENCES):
+    """-> (maps {name: (mean, cov)}, frames [dict + seq / map / stamp / row], in sequence order); limit = frames per
+    sequence (evenly spaced over it)."""
+    import os
+    from . import synth
+    gt = np.load(os.path.join(golden_dir, "gt_sync.npz"))
+    maps, frames = {}, []
+    for seq, mapname in sequences:
+        if mapname not in maps:
+            d = np.load(os.path.join(golden_dir, mapname + ".npz"))
+            maps[mapname] = (d["mean"], d["cov"])
+        mean, cov = maps[mapname]
+        take = np.arange(len(gt[seq])) if limit is None else np.arange(len(gt[seq]))[::max(1, len(gt[seq]) // limit)][:limit]
+        for i in take:  # a limit takes evenly spaced frames of the whole sequence
+            row = gt[seq][i]
+            f = synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(row), cam, M, seed0 + len(frames))
+            f.update(seq=seq, map=mapname, stamp=float(row[0]), row=int(i))
+            frames.append(f)
+    return maps, frames
+
+
+class TrackCompute:
+    """compute callback of replay(): a batch of frame problems -> ROW_D result rows, the per-frame sequence of the
+    reference's tracker on the HIP path: Tracking::optimizeCurrentPose on the frame's correspondences
+    (gl_optimize_current_pose: the pose of the trajectory), then the north-star association + structure-constrained
+    refinement from that pose (gl_track_frames: one free pose and free points, held by the map's Gaussians only -
+    no prior or fixed key-frame anchors its gauge, so its pose is reported next to the tracker's, not instead)."""
+
+    def __init__(self, ctx, gmms, cam, prm):
+        self.ctx, self.gmms, self.cam, self.prm = ctx, gmms, cam, prm
+
+    def __call__(self, frames):
+        import time
+        import torch
+        from . import api
+        out = np.zeros((len(frames), ROW_D))
+        for mapname in sorted({f["map"] for f in frames}):
+            sel = [i for i, f in enumerate(frames) if f["map"] == mapname]
+            dev = torch.device("cuda", self.ctx.device)
+            T = lambda k: torch.from_numpy(np.stack([frames[i][k] for i in sel])).to(dev)
+            pose, Xw, obs, octv = T("pose_init"), T("Xw"), T("obs"), T("octave")
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            outl, nin = api.optimize_current_pose(self.ctx, self.cam, self.prm, pose, Xw, obs, octv)
+            pose_track = pose.clone()
+            assoc, _ = api.track_frames(self.ctx, self.gmms[mapname], self.cam, self.prm, pose, Xw, obs, octv, want_d2=False)
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t0) / len(sel)
+            out[sel, :7] = pose_track.cpu().numpy()
+            out[sel, 7:14] = pose.cpu().numpy()
+            out[sel, 14] = nin.cpu().numpy()
+            out[sel, 15] = (assoc >= 0).sum(1).cpu().numpy()
+            out[sel, 16] = (octv >= 0).sum(1).cpu().numpy()
+            out[sel, 17] = ms
+        return out
+
+
+def pose_cw_to_wc(pose_cw):
+    """(N,7) T_cw -> (N,7) T_wc, (qx qy qz qw tx ty tz)."""
+    from . import synth
+    out = np.zeros_like(pose_cw)
+    for i, p in enumerate(pose_cw):
+        R = synth.quat_to_R(p[:4])
+        out[i, :4] = synth.R_to_quat(R.T)
+        out[i, 4:] = -R.T @ p[4:]
+    return out
+
+
+def score_euroc(frames, results, out_dir=None):
+    """Per sequence: TUM trajectory of the refined poses (gl_write_tum_trajectory) and its translation APE against the
+    gt_sync poses the frames were generated from (traj.ape_translation = scripts/evo_euroc.py)."""
+    import os
+    import tempfile
+    from . import synth, traj
+    report = {}
+    tmp = out_dir or tempfile.mkdtemp(prefix="gmmloc_replay_")
+    os.makedirs(tmp, exist_ok=True)
+    for seq in dict.fromkeys(f["seq"] for f in frames):
+        sel = [i for i, f in enumerate(frames) if f["seq"] == seq]
+        stamps = np.array([frames[i]["stamp"] for i in sel])
+        est_wc = pose_cw_to_wc(results[sel, :7])       # the tracker's poses (optimizeCurrentPose)
+        str_wc = pose_cw_to_wc(results[sel, 7:14])     # after the structure-constrained refine
+        gt_wc = pose_cw_to_wc(np.stack([frames[i]["pose_gt"] for i in sel]))
+        init_wc = pose_cw_to_wc(np.stack([frames[i]["pose_init"] for i in sel]))
+        path = os.path.join(tmp, seq + "_traj_est.txt")
+        # gt_sync repeats its first stamp while the robot stands still: TUM files keep one line per stamp
+        _, first = np.unique(stamps, return_index=True)
+        first.sort()
+        traj.write_tum(path, stamps[first], est_wc[first])
+        st, xyz, _ = traj.read_tum(path)
+        ape = traj.ape_translation(stamps[first], gt_wc[first, 4:], st, xyz)
+        ape0 = traj.ape_translation(stamps[first], gt_wc[first, 4:], stamps[first], init_wc[first, 4:])
+        path2 = os.path.join(tmp, seq + "_traj_structure.txt")
+        traj.write_tum(path2, stamps[first], str_wc[first])
+        ape2 = traj.ape_translation(stamps[first], gt_wc[first, 4:], stamps[first], str_wc[first, 4:])
+        report[seq] = {"frames": len(sel), "tum": path, "ape_rmse_m": ape["rmse"], "ape_max_m": ape["max"],
+                       "ape_rmse_initial_m": ape0["rmse"], "tum_structure": path2, "ape_rmse_structure_m": ape2["rmse"],
+                       "inliers_per_frame": float(results[sel, 14].mean()), "associated_per_frame": float(results[sel, 15].mean())}
+    return report

@@ -62,4 +62,29 @@ void nfref_knn2d(const double* pts, int n, const double* q, int nq, int k, int32
 void nfref_knn3d(const double* pts, int n, const double* q, int nq, int k, int32_t* idx, double* dist, int32_t* cnt) {
   knn<3>(pts, n, q, nq, k, idx, dist, cnt);
 }
+// Persistent 3-D tree, as the reference keeps it (built once in the GMM constructor, gaussian_mixture.cpp:43-59;
+// queried per point by GMM::queryPoint, :545-576): lets the CPU baseline time the queries without the build.
+struct NfTree3 {
+  Cloud<3> cloud;
+  nanoflann::KDTreeSingleIndexAdaptor<nanoflann::L2_Simple_Adaptor<double, Cloud<3>>, Cloud<3>, 3> tree;
+  std::vector<double> copy;
+  NfTree3(const double* pts, int n) : cloud{nullptr, (size_t)n}, tree(3, cloud, nanoflann::KDTreeSingleIndexAdaptorParams(5)), copy(pts, pts + (size_t)n * 3) {
+    cloud.pts = copy.data();
+    tree.buildIndex();
+  }
+};
+void* nfref_tree3d_create(const double* pts, int n) { return new NfTree3(pts, n); }
+void nfref_tree3d_destroy(void* h) { delete (NfTree3*)h; }
+void nfref_tree3d_knn(void* h, const double* q, int nq, int k, int32_t* idx, double* dist) {
+  NfTree3* t = (NfTree3*)h;
+  std::vector<size_t> ri(k);
+  std::vector<double> rd(k);
+  for (int i = 0; i < nq; ++i) {
+    const size_t m = t->tree.knnSearch(q + (size_t)i * 3, (size_t)k, ri.data(), rd.data());
+    for (int j = 0; j < k; ++j) {
+      idx[(size_t)i * k + j] = j < (int)m ? (int32_t)ri[j] : -1;
+      dist[(size_t)i * k + j] = j < (int)m ? rd[j] : 0.0;
+    }
+  }
+}
 }

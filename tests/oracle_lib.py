@@ -235,6 +235,22 @@ class Oracle:
         return out
 
     # ---- real nanoflann (oracle/_ref) ----
+    def nanoflann_tree3d(self, pts):
+        """Persistent kd-tree over 3-D points (as the reference builds once per map) -> handle for nanoflann_tree_knn."""
+        assert self.nf is not None, "oracle/_ref/libnanoflann_ref.so missing"
+        self.nf.nfref_tree3d_create.restype = C.c_void_p
+        pts = _f64(pts)
+        return C.c_void_p(self.nf.nfref_tree3d_create(_p(pts), pts.shape[0]))
+
+    def nanoflann_tree_knn(self, tree, q, k):
+        q = _f64(q)
+        idx, dist = np.zeros((q.shape[0], k), np.int32), np.zeros((q.shape[0], k))
+        self.nf.nfref_tree3d_knn(tree, _p(q), q.shape[0], k, _p(idx), _p(dist))
+        return idx, dist
+
+    def nanoflann_tree_destroy(self, tree):
+        self.nf.nfref_tree3d_destroy(tree)
+
     def nanoflann_knn(self, pts, q, k):
         assert self.nf is not None, "oracle/_ref/libnanoflann_ref.so missing"
         pts, q = _f64(pts), _f64(q)
@@ -251,6 +267,19 @@ _cached = None
 
 def build():
     subprocess.check_call(["make", "-s", "-C", ODIR])
+
+
+def load_native():
+    """The same oracle source built on THIS machine with the reference's flags (-O3 -march=native,
+    gmmloc/CMakeLists.txt:7) for the CPU-baseline timing of bench.py; None when it cannot be built here."""
+    so = os.path.join(ODIR, "_native", "liboracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", ODIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+    except (subprocess.CalledProcessError, OSError):
+        return None
+    nfp = os.path.join(ODIR, "_ref", "libnanoflann_ref.so")
+    return Oracle(lib, C.CDLL(nfp) if os.path.exists(nfp) else None)
 
 
 def load():

@@ -122,3 +122,57 @@ def test_shard_indices():
     for world in (1, 2, 4, 8):
         allidx = np.sort(np.concatenate([replay.shard_indices(13735, r, world) for r in range(world)]))
         assert np.array_equal(allidx, np.arange(13735))  # BASELINE configs[3]: all V1/V2 frames covered once
+
+
+def _euroc_worker(rank, world, port, q, out_dir):
+    """configs[3] plumbing on CPU: materialise -> replay (world 2, gloo) -> TUM + APE, with the ORACLE as the per-frame
+    compute (the product's compute is the HIP path: tests/test_gpu_replay.py)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from gmmloc_amd import api, replay
+    from tests import oracle_lib
+    from tools import soak_cases as sc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cam = api.Camera()
+    maps, frames = replay.materialise_euroc(os.path.join(ROOT, "tests", "golden"), cam, M=60, limit=7)
+    orc = oracle_lib.load()
+    hs = {name: orc.gmm_create(mean, cov) for name, (mean, cov) in maps.items()}
+
+    def compute(fs):
+        rows = np.zeros((len(fs), replay.ROW_D))
+        for i, f in enumerate(fs):
+            p1, outl, nin = orc.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
+            keep, p2, pts, final, idx, d2 = sc.track_oracle(orc, hs[f["map"]], cam, dict(f, pose_init=p1))
+            rows[i, :7], rows[i, 7:14], rows[i, 14], rows[i, 15], rows[i, 16] = p1, p2, nin, (final >= 0).sum(), len(keep)
+        return rows
+
+    res, dt = replay.replay(frames, compute, rank, world, dist, "cpu", batch=4)
+    rep = replay.score_euroc(frames, res, os.path.join(out_dir, "rank%d" % rank)) if rank == 0 else None
+    q.put((rank, res, rep))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replay_euroc_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    from gmmloc_amd import replay
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_euroc_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict((r, (res, rep)) for r, res, rep in [q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][0].shape == (42, replay.ROW_D)  # every rank holds all rows
+    rep = out[0][1]
+    assert set(rep) == {s for s, _ in replay.EUROC_SEQUENCES}
+    for seq, r in rep.items():
+        assert os.path.exists(r["tum"]) and r["frames"] == 7
+        # 60-point frames: the tracker's poses within 2 cm of the generating trajectory, from 3-5 cm at the start
+        assert r["ape_rmse_m"] < 0.02 and r["ape_rmse_m"] < r["ape_rmse_initial_m"], (seq, r)
+        assert os.path.exists(r["tum_structure"]) and np.isfinite(r["ape_rmse_structure_m"])
