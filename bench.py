@@ -52,7 +52,7 @@ def measured_traffic(kernel, frames_per_launch):
     WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
     frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
     None when the summary is missing: bench.py itself cannot run under two profilers."""
-    for name in ("r1k_traffic.json", "r1j_traffic.json", "r1h_traffic.json"):
+    for name in ("r2_traffic.json", "r1k_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -68,14 +68,33 @@ _W = {}
 
 
 def _cpu_one(i):
-    """One frame through the oracle (CPU port of the reference algorithm): all-pairs association,
-    chi2 <= 9 gate, joint_optimization with one free pose."""
+    """One frame through the oracle, SAME-MATH baseline: exhaustive all-pairs association (what the GPU path answers
+    exactly), chi2 <= 9 gate, joint_optimization with one free pose.  -> seconds spent in the association."""
     orc, h, cam, frames = _W["orc"], _W["h"], _W["cam"], _W["frames"]
     f = frames[i]
     ta = time.perf_counter()
     idx, d2 = orc.associate3d(h, f["Xw"])
     ta = time.perf_counter() - ta
     assoc = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
+    L = f["Xw"].shape[0]
+    orc.joint_optimization(h, cam, 1, 0, f["pose_init"][None].copy(), np.zeros(1, np.uint8), f["Xw"].copy(), assoc,
+                           np.arange(L + 1, dtype=np.int32), np.zeros(L, np.int32), f["obs"], f["octave"])
+    return ta
+
+
+def _cpu_one_reference(i):
+    """One frame the way the REFERENCE ALGORITHM associates (GMM::queryPoint, gaussian_mixture.cpp:545-576): exact 5-NN on
+    the component means through the reference's own nanoflann kd-tree (built once per map, as the GMM constructor does)
+    + chi2 of those five, best one gated at 9; then the same g2o-semantic LM (joint_optimization, one free pose)."""
+    orc, h, cam, frames, tree = _W["orc"], _W["h"], _W["cam"], _W["frames"], _W["tree"]
+    f = frames[i]
+    ta = time.perf_counter()
+    knn, _ = orc.nanoflann_tree_knn(tree, f["Xw"], 5)
+    c2 = np.stack([orc.chi2(h, knn[:, j], f["Xw"]) for j in range(5)], 1)
+    j = np.argmin(c2, 1)
+    rows = np.arange(len(j))
+    assoc = np.where(c2[rows, j] <= 9.0, knn[rows, j], -1).astype(np.int32)
+    ta = time.perf_counter() - ta
     L = f["Xw"].shape[0]
     orc.joint_optimization(h, cam, 1, 0, f["pose_init"][None].copy(), np.zeros(1, np.uint8), f["Xw"].copy(), assoc,
                            np.arange(L + 1, dtype=np.int32), np.zeros(L, np.int32), f["obs"], f["octave"])
@@ -106,21 +125,42 @@ def host_cores():
 
 
 def cpu_baseline_worker(seed0, budget_s):
-    """Runs in a fresh process (no HIP state, so forking a pool is safe): the oracle on the first
-    frames of the same workload, 1 thread, then one frame per worker process on all host cores."""
+    """Runs in a fresh process (no HIP state, so forking a pool is safe): the oracle on the first frames of the same
+    workload, 1 thread - BOTH baselines of SURVEY 8d in the same run, never mixed: (i) the reference algorithm
+    (nanoflann 5-NN + chi2, then LM), (ii) same-math brute force (exhaustive argmin, then LM) - then (ii) with one
+    frame per worker process on all host cores.  The oracle is rebuilt on this machine with the reference's own
+    flags (-O3 -march=native, gmmloc/CMakeLists.txt:7); the real reference binary cannot be built here (ROS, g2o)."""
     import multiprocessing as mp
     from tests import oracle_lib
     ncore = host_cores()
     n_all = 4 * ncore if ncore > 1 else 0
     mean, cov, cam, frames = make_workload(max(n_all, 400), seed0)
-    orc = oracle_lib.load()
-    _W.update(orc=orc, h=orc.gmm_create(mean, cov), cam=cam, frames=frames)
-    t0 = time.perf_counter()
-    n, t_assoc = 0, 0.0
-    while n < len(frames) and time.perf_counter() - t0 < budget_s:
-        t_assoc += _cpu_one(n)
-        n += 1
-    dt = time.perf_counter() - t0
+    orc = oracle_lib.load_native()
+    flags = "-O3 -march=native (built on this host)"
+    if orc is None:
+        orc, flags = oracle_lib.load(), "-O2 -mavx2 -mfma (portable checker build: the native build failed on this host)"
+    h = orc.gmm_create(mean, cov)
+    _W.update(orc=orc, h=h, cam=cam, frames=frames, tree=orc.nanoflann_tree3d(mean) if orc.nf is not None else None)
+
+    def timed(fn, budget):
+        t0 = time.perf_counter()
+        n, t_assoc = 0, 0.0
+        while n < len(frames) and time.perf_counter() - t0 < budget:
+            t_assoc += fn(n)
+            n += 1
+        return n, time.perf_counter() - t0, t_assoc
+
+    n, dt, t_assoc = timed(_cpu_one, 0.6 * budget_s)
+    ref = None
+    if _W["tree"] is not None:
+        nr_, dtr, tr_assoc = timed(_cpu_one_reference, 0.4 * budget_s)
+        ref = {"value": nr_ / dtr, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d frames of the same workload: the reference's own nanoflann kd-tree (5-NN on the means, tree built once) "
+                         "+ chi2 of the five + chi2 <= 9 gate (GMM::queryPoint), then joint_optimization (g2o-semantic LM, 1 free pose), "
+                         "1 thread; association alone %.2f ms/frame" % (nr_, 1e3 * tr_assoc / nr_),
+               "ms_per_frame": 1e3 * dtr / nr_, "assoc_ms_per_frame": 1e3 * tr_assoc / nr_,
+               "note": "nanoflann wrapper built -O2 -mavx2 from the reference's header in the build container (the header does not "
+                       "travel); it returns the best of the 5 nearest means, NOT the argmin over all Gaussians"}
     allc = None
     if n_all:
         with mp.get_context("fork").Pool(ncore) as pool:
@@ -128,7 +168,7 @@ def cpu_baseline_worker(seed0, budget_s):
             ta = time.perf_counter()
             pool.map(_cpu_one, range(n_all), chunksize=1)
             allc = {"value": n_all / (time.perf_counter() - ta), "unit": "frames/s", "cores": ncore, "frames": n_all,
-                    "how": "one frame per forked worker process"}
+                    "how": "same-math brute force, one frame per forked worker process"}
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -138,18 +178,17 @@ def cpu_baseline_worker(seed0, budget_s):
                     break
     except OSError:
         pass
-    print(json.dumps({"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-                      "sample": "%d frames of the same workload (oracle = CPU port of the reference algorithm: all-pairs "
-                                "associate3d + joint_optimization, 1 thread); association alone %.1f ms/frame"
-                                % (n, 1e3 * t_assoc / n),
-                      "note": "the timed association is the same-math exhaustive sweep the GPU path answers exactly; the reference's "
-                              "own nearest-5 kd-tree lookup (queryPoint) costs 1.4 ms/frame on this CPU "
-                              "(profiles/r1k_configs.jsonl, config 2) and does not return the argmin over all Gaussians",
-                      "cpu_model": model, "host_cores": ncore,
-                      "host_hw_threads": os.cpu_count(), "all_cores": allc}))
+    brute = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+             "sample": "%d frames of the same workload (oracle = CPU port of the reference's arithmetic: all-pairs associate3d + "
+                       "joint_optimization, 1 thread); association alone %.1f ms/frame" % (n, 1e3 * t_assoc / n),
+             "ms_per_frame": 1e3 * dt / n, "assoc_ms_per_frame": 1e3 * t_assoc / n}
+    out = dict(brute)  # the contract's cpu_baseline = the same-math baseline (what the GPU path computes, pair for pair)
+    out.update({"build": flags, "cpu_model": model, "host_cores": ncore, "host_hw_threads": os.cpu_count(),
+                "same_math_brute": brute, "reference_algorithm": ref, "all_cores": allc})
+    print(json.dumps(out))
 
 
-def cpu_baseline(seed0, budget_s=15.0):
+def cpu_baseline(seed0, budget_s=24.0):
     import subprocess
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(seed0), str(budget_s)],
                        capture_output=True, text=True, cwd=ROOT)
@@ -228,6 +267,20 @@ def main():
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
     ctx.timing(False)
 
+    # the same step with the association forced to the plain N x K sweep (option assoc_grid = 0): same results
+    # (tests/test_gpu_track.py), the arithmetic of the same-math CPU baseline pair for pair
+    sweep_steps = max(2, args.steps // 4)
+    ctx.set_option("assoc_grid", 0)
+    with torch.cuda.stream(ctx.stream):
+        step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(sweep_steps):
+            step()
+        barrier()
+        dt_sweep = (time.perf_counter() - t0) / sweep_steps
+    ctx.set_option("assoc_grid", -1)
+
     # outside the timed region: the plain N x K sweep on the same points (its roofline record), and
     # the number of chi2 evaluations the cell index needed for them
     sweep_ms = None
@@ -294,7 +347,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if ctx.get_option("ba_step32") == 0 else "f64 (fp32-cached point step: option ba_step32)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 2000 map points x 4096 Gaussians per frame "
                                    "(95% planar map, SURVEY 8d), exact chi2 argmin over all Gaussians + structure-constrained "
@@ -345,11 +398,24 @@ def main():
             },
             "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine": ba_ms / max(args.steps, 1)},
         }
+        out["step_with_exhaustive_sweep"] = {
+            "value": B * world / dt_sweep, "unit": "frames/s", "ms_per_step": 1e3 * dt_sweep, "steps": sweep_steps,
+            "what": "the same step with GL_ASSOC_EXHAUSTIVE-style association (all 2000 x 4096 pairs per frame swept, option "
+                    "assoc_grid = 0) instead of the exact cell index; rank 0's clock"}
         out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(20200901 + 100000 * rank)
-            out["latency"]["cpu_1thread_ms_per_frame"] = 1e3 / out["cpu_baseline"]["value"]
-            out["latency"]["speedup_vs_cpu_1thread"] = out["latency"]["cpu_1thread_ms_per_frame"] / latency_ms
+            cb = cpu_baseline(20200901 + 100000 * rank)
+            out["cpu_baseline"] = cb
+            lat = out["latency"]
+            lat["cpu_same_math_brute_ms_per_frame"] = cb["same_math_brute"]["ms_per_frame"]
+            lat["speedup_vs_cpu_same_math_brute"] = cb["same_math_brute"]["ms_per_frame"] / latency_ms
+            if cb.get("reference_algorithm"):
+                lat["cpu_reference_algorithm_ms_per_frame"] = cb["reference_algorithm"]["ms_per_frame"]
+                lat["speedup_vs_cpu_reference_algorithm"] = cb["reference_algorithm"]["ms_per_frame"] / latency_ms
+            out["speedup_batched"] = {
+                "vs_cpu_same_math_brute_1thread": out["step_with_exhaustive_sweep"]["value"] / cb["same_math_brute"]["value"],
+                "vs_cpu_reference_algorithm_1thread": (out["value"] / cb["reference_algorithm"]["value"]) if cb.get("reference_algorithm") else None,
+                "note": "like with like: the sweep step against the brute-force CPU path, the indexed step against the kd-tree CPU path"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -1,17 +1,18 @@
 // Tracking::optimizeCurrentPose (tracking_opt.cpp:21-217): 6-DoF Levenberg-Marquardt over pose-only
 // reprojection edges (g2o EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose, Huber), 4 gating rounds
 // x optimize(10), one persistent group of NW waves per frame, entirely on-chip:
-//   * thread t of the group owns the edges t, t + 64 NW, ...; one pass computes the residual, chi2, Huber
+//   * a wave owns groups of <= 4 chunks of 64 consecutive edges; one pass computes the residual, chi2, Huber
 //     weight, the 2|3 x 6 Jacobian and accumulates the 21 unique entries of J^T W J, the 6 of b and the
-//     robust chi2 in registers;
+//     robust chi2 of a group in registers;
 //   * a wave reduce-scatter (permlane swaps + DPP) + one LDS step give the 28 sums; the current and the trial
 //     system live in LDS (224 B each), not in registers;
 //   * every wave solves the 6x6 (LDL^T on the packed triangle, reciprocal pivots) and applies exp(delta) on
 //     its own - pose as (R, t) in SGPRs, Rodrigues with a short series below |theta| = 0.01 - so nothing is
 //     broadcast;
 //   * the evaluation at the trial pose also builds the next system: an accepted LM step costs ONE pass.
-// NW = 1 (no barrier at all, GL_POSE_WPS frames per SIMD) is the shape for large batches, NW = 4 / 8 the one
-// for the frame-at-a-time caller: 0.34 ms instead of 0.90 ms for one frame of 1 000 edges.
+// One wave per frame (no barrier at all, GL_POSE_WPS frames per SIMD) is the shape for large batches, a wave per
+// group of <= 256 edges (up to 8) the one for the frame-at-a-time caller: 0.34 ms instead of 0.90 ms for one frame of
+// 1 000 edges.  Every shape adds in the same canonical order (group_totals28): same bits whatever the batch.
 // g2o control flow restated: OptimizationAlgorithmLevenberg::solve (lambda init 1e-5 max diag, rho test with
 // +1e-3, x1/3..2/3 / x nu schedule, 10 trials), SparseOptimizer::optimize, levels via
 // initializeOptimization(0), stale per-edge errors read by e->chi2() after the last trial (SURVEY.md
@@ -65,50 +66,48 @@ GL_DEV double uni(double v) {  // wave-uniform value -> SGPR pair
   u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.d;
 }
-// the 28 totals of acc[] over the NW waves of the workgroup -> dst[0..27] in LDS.  Per wave a reduce-scatter
-// (permlane swaps + DPP) leaves total s on lane wave_slot^-1(s); the owners park them in part[wave][], and lane
-// s of every wave adds the NW partials in wave order (the same bits in every wave) - with one wave the barriers
-// are no-ops that order the LDS write before the broadcast reads.
-template <int NW>
-GL_DEV void block_totals28(double* acc, double* part, double* dst, Coop& C) {
+// ---- ONE summation order for every launch shape (the same canonical order as the structure refine,
+// gl_ba_fast_impl.hpp): chunks of 64 consecutive edges, nch = ceil(M / 64); G = ceil(nch / 4) groups of
+// S = ceil(nch / G) <= 4 consecutive chunks; lane j of group g adds the terms of its edges (g S + i) 64 + j in slot
+// order; the 64 lane sums of a group meet in the butterfly of gld::wave_reduce_scatter32; blocks of two groups,
+// B_k = g_2k + g_2k+1, are added in order.  A frame runs on NW waves (1 for large batches - no barrier at all -, up to
+// 8 for few frames); wave w owns the groups w, w + NW, ...: whatever NW, every sum is built from the same terms in the
+// same order, so the refined pose does not depend on how many frames ride in the call.
+GL_DEV double add_nc(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+// group g's 28 lane sums (acc) -> its totals in red[g][0..31]
+GL_DEV void group_totals28(double* acc, double* red, int g) {
 #pragma unroll
   for (int i = 28; i < 32; ++i) acc[i] = 0.0;
   const double r = wave_reduce_scatter32(acc);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();  // dst / part may still be read by slower waves
-  if (NW == 1) {
-    if (wave_slot_owner(lane)) dst[wave_slot(lane)] = r;
-  } else {
-    if (wave_slot_owner(lane)) part[wave * 32 + wave_slot(lane)] = r;
-    __syncthreads();
-    if (wave == 0 && lane < 32) {
-      double s = part[lane];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) s += part[w * 32 + lane];
-      dst[lane] = s;
-    }
-  }
-  __syncthreads();
-  if (C.NB > 1) coop_totals<false>(C, dst);  // second level: the workgroups that share the frame
+  const int lane = threadIdx.x & 63;
+  if (wave_slot_owner(lane)) red[g * 32 + wave_slot(lane)] = r;
 }
-template <int NW>
-GL_DEV double block_total1(double v, double* part, double* xs, Coop& C) {
+// red[0..G-1][32] -> dst[0..27]: blocks of two groups in order (wave 0; the caller brackets it with barriers)
+GL_DEV void frame_totals28(const double* red, double* dst, int G) {
+  const int lane = threadIdx.x;
+  if (lane < 32) {
+    double s = G > 1 ? add_nc(red[lane], red[32 + lane]) : red[lane];
+    for (int b = 1; 2 * b < G; ++b) {
+      const double blk = 2 * b + 1 < G ? add_nc(red[(2 * b) * 32 + lane], red[(2 * b + 1) * 32 + lane]) : red[(2 * b) * 32 + lane];
+      s = add_nc(s, blk);
+    }
+    dst[lane] = s;
+  }
+}
+// a count per thread -> the frame's total (integers: exact in any order)
+GL_DEV double block_total1(double v, double* part) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v += shfl_xor_f64(v, o);
-  if (NW == 1 && C.NB == 1) return uni(v);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return uni(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = part[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) s += part[w];
-  if (C.NB > 1) {
-    __syncthreads();
-    if (threadIdx.x < 32) xs[threadIdx.x] = threadIdx.x == 0 ? s : 0.0;
-    __syncthreads();
-    coop_totals<false>(C, xs);
-    s = xs[0];
-  }
+  for (int w = 1; w < nw; ++w) s += part[w];
   return uni(s);
 }
 
@@ -201,17 +200,13 @@ GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, do
   return ok;
 }
 
-// one pass over the lane's edges at pose P: acc[0..20] H upper triangle, acc[21..26] b, acc[27] robust chi2
-template <int NW>
-GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int e0, int es, int M,
-                           const double* __restrict__ Xw, const double* __restrict__ obs,
-                           const int32_t* __restrict__ octave, const uint8_t* __restrict__ level,
-                           double* __restrict__ chi2_e, double* acc) {
-#pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  for (int e = e0; e < M; e += es) {
+// one edge: residual, chi2, Huber weight, Jacobian; accumulates into acc[0..27]
+GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int e,
+                      const double* __restrict__ Xw, const double* __restrict__ obs, const int32_t* __restrict__ octave,
+                      const uint8_t* __restrict__ level, double* __restrict__ chi2_e, double* acc) {
+  {
     const int oc = octave[e];
-    if (oc < 0 || level[e] != 0) continue;
+    if (oc < 0 || level[e] != 0) return;
     const double X = Xw[(size_t)e * 3 + 0], Y = Xw[(size_t)e * 3 + 1], Z = Xw[(size_t)e * 3 + 2];
     const double ou = obs[(size_t)e * 3 + 0], ov = obs[(size_t)e * 3 + 1], our = obs[(size_t)e * 3 + 2];
     const bool stereo = !(our < 0);
@@ -264,32 +259,52 @@ GL_DEV void wave_pose_eval(const PoseKParams& kp, const double* __restrict__ s2t
   }
 }
 
+// one pass over the frame's edges at pose P -> dst[0..27] (LDS): H upper triangle (21), b (6), robust chi2.
+// Wave w walks the groups w, w + NW, ...: lane sums of the group's S chunks in registers, tree, red[g]; then the blocks.
+GL_DEV void pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int G, int S, int M,
+                      const double* __restrict__ Xw, const double* __restrict__ obs, const int32_t* __restrict__ octave,
+                      const uint8_t* __restrict__ level, double* __restrict__ chi2_e, double* red, double* dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double acc[32];
+  __syncthreads();  // red / dst may still be read by slower waves (no-op ordering for a single wave)
+  for (int g = wave; g < G; g += nw) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    for (int i = 0; i < S; ++i) {
+      const int e = (g * S + i) * 64 + lane;
+      if (e >= M) break;
+      pose_edge(kp, s2tab, P, robust, e, Xw, obs, octave, level, chi2_e, acc);
+    }
+    group_totals28(acc, red, g);
+  }
+  __syncthreads();
+  if (wave == 0) frame_totals28(red, dst, G);
+  __syncthreads();
+}
+
 #ifndef GL_POSE_WPS
 #define GL_POSE_WPS 3  // waves per SIMD the register budget is capped for (measured: 3 > 2 > 4, tools/pose_ab.py)
 #endif
-// NW waves per frame: 1 for batches (GL_POSE_WPS frames per SIMD), 4 / 8 when the frames are fewer than the
-// SIMDs - the edges are dealt round the NW x 64 threads, the 28 sums meet in LDS, and every wave repeats the
-// serial part (solve, pose update) on its own so that no broadcast is needed.
+// NW = waves per frame the instance is compiled for (register budget): 1 for large batches (GL_POSE_WPS frames per
+// SIMD, no barrier does anything), 4 / 8 when the frames are fewer than the SIMDs; launched with nw <= NW waves
+// (never more than the frame has groups).  Every wave repeats the serial part (solve, pose update) on its own so that
+// no broadcast is needed.
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M,
+__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M, int G, int S,
                                                                  double* __restrict__ pose_io,
                                                                  const double* __restrict__ Xw_all,
                                                                  const double* __restrict__ obs_all,
                                                                  const int32_t* __restrict__ oct_all,
                                                                  uint8_t* __restrict__ outlier_all,
                                                                  int32_t* __restrict__ ninlier,
-                                                                 double* __restrict__ chi2_all, int NB,
-                                                                 unsigned long long* parts) {
+                                                                 double* __restrict__ chi2_all) {
   __shared__ double s2tab[8];
   __shared__ double H[32], Hn[32];  // current / trial system {H upper (21), b (6), chi2}
-  __shared__ double part[NW * 32];  // per-wave partial sums
-  __shared__ double xs[32];         // scalar exchanges between the workgroups of a frame
-  // NB > 1 (cooperative launch, few frames): workgroup pb of the NB that share frame f; the edges are dealt
-  // round all NB x NW x 64 threads and every sum has a second level across the workgroups (gld::coop_totals)
-  const int f = blockIdx.x / NB, lane = threadIdx.x;  // "lane" = thread of the workgroup's NW waves
+  __shared__ double part[NW];       // per-wave counts
+  extern __shared__ double red[];   // G x 32 group totals
+  const int f = blockIdx.x, lane = threadIdx.x;  // "lane" = thread of the workgroup's waves
   if (f >= B) return;
-  Coop C{parts ? parts + (size_t)f * 2 * NB * 64 : nullptr, NB, (int)(blockIdx.x % NB), 0u};
-  const int e0 = C.pb * 64 * NW + lane, es = 64 * NW * NB;
+  const int e0 = lane, es = blockDim.x;  // counting / gating loops: any order (integers, per-edge decisions)
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s2tab[j] = kp.s2inv[j];
@@ -309,9 +324,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
       cnt += 1.0;
     }
   }
-  const int n_init = (int)block_total1<NW>(cnt, part, xs, C);
+  const int n_init = (int)block_total1(cnt, part);
   if (n_init < 3) {  // :139-140
-    if (lane == 0 && C.pb == 0) ninlier[f] = 0;
+    if (lane == 0) ninlier[f] = 0;
     return;
   }
   PoseRt P0;
@@ -324,27 +339,25 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
     P0 = rt_uni(P0);
   }
   PoseRt P = P0;
-  double acc[32];
   bool robust = true;
   int nbad = 0;
 #pragma unroll 1
   for (int round = 0; round < 4; ++round) {
     P = P0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
     cnt = 0.0;
+    __syncthreads();  // level[] of the previous round's gating is read by other threads below
     for (int e = e0; e < M; e += es)
       if (octave[e] >= 0 && level[e] == 0) cnt += 1.0;
-    const int nactive = (int)block_total1<NW>(cnt, part, xs, C);
+    const int nactive = (int)block_total1(cnt, part);
     if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
-      wave_pose_eval<NW>(kp, s2tab, P, robust, e0, es, M, Xw, obs, octave, level, chi2_e, acc);
-      block_totals28<NW>(acc, part, H, C);
+      pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
       double currentChi = uni(H[27]);
       bool sys_valid = true;
       double lambda = 0.0, ni = 2.0;
 #pragma unroll 1
       for (int it = 0; it < 10; ++it) {
         if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
-          wave_pose_eval<NW>(kp, s2tab, P, robust, e0, es, M, Xw, obs, octave, level, chi2_e, acc);
-          block_totals28<NW>(acc, part, H, C);
+          pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
           currentChi = uni(H[27]);
           sys_valid = true;
         }
@@ -364,8 +377,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
           double tempChi;
           if (ok2) {
             Pn = rt_update(P, dx);
-            wave_pose_eval<NW>(kp, s2tab, Pn, robust, e0, es, M, Xw, obs, octave, level, chi2_e, acc);
-            block_totals28<NW>(acc, part, Hn, C);
+            pose_eval(kp, s2tab, Pn, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, Hn);
             tempChi = uni(Hn[27]);
           } else {
             tempChi = 1.7976931348623157e308;
@@ -401,6 +413,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
     // gating (:156-203): outliers are re-evaluated at the current estimate, inliers use the error of
     // the last computeActiveErrors; chi2 compared as float.
     cnt = 0.0;
+    __syncthreads();  // chi2_e[] of the last evaluation was written by other threads (edge -> thread maps differ)
     for (int e = e0; e < M; e += es) {
       const int oc = octave[e];
       if (oc < 0) continue;
@@ -415,11 +428,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
       level[e] = bad ? 1 : 0;
       if (bad) cnt += 1.0;
     }
-    nbad = (int)block_total1<NW>(cnt, part, xs, C);
+    nbad = (int)block_total1(cnt, part);
     if (round == 2) robust = false;  // e->setRobustKernel(0) at it == 2
     if (n_init < 10) break;          // optimizer.edges().size() < 10
   }
-  if (lane == 0 && C.pb == 0) {
+  if (lane == 0) {
     SE3 T;
     T.r = qfromR(P.R);
     T.t[0] = P.t[0];
@@ -451,53 +464,30 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   for (int i = 0; i < 8; ++i) kp.s2inv[i] = (double)prm->sigma2_inv[i];
   kp.delta_mono = (double)(float)sqrt(5.991);    // const float delta_mono = sqrt(5.991)   (:57)
   kp.delta_stereo = (double)(float)sqrt(7.815);  // const float delta_stereo = sqrt(7.815) (:58)
+  GL_REQUIRE(M <= 64 * 4 * 512, "M above 131 072 edges per frame");
   void* scratch = nullptr;
   const size_t chi_bytes = (((size_t)B * (M > 0 ? M : 1) * sizeof(double) + 63) / 64) * 64;
-  int rc = gl::ctx_scratch(c, chi_bytes + (size_t)B * 4096, &scratch);  // + the exchange words of the latency shape
+  int rc = gl::ctx_scratch(c, chi_bytes, &scratch);
   if (rc != GL_OK) return rc;
   {
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
-    // waves per frame: 4 is never slower than 1 up to ~2 000 frames (0.34 vs 0.90 ms for one frame of 1 000
-    // edges, 1.26 vs 1.80 ms for 1 024), 8 is the best between 32 and 256 frames; one wave per frame is the shape
-    // for large batches (12 frames per CU, no barriers).  Never more waves than the frame has 64-edge slices.
-    // GMMLOC_POSE_WAVES=1|4|8 forces a shape.
-    int nw = B > 1536 ? 1 : (B > 32 && B <= 256) ? 8 : 4;
-    while (nw > 1 && nw * 64 > M + 63) nw = nw == 8 ? 4 : 1;
-    if (c->opt.pose_waves > 0) nw = (int)c->opt.pose_waves == 8 ? 8 : (int)c->opt.pose_waves == 4 ? 4 : 1;
-    // very few frames: a frame's edges are dealt to NB <= 4 workgroups of 4 waves on as many CUs (one edge per
-    // thread from 1 024 edges), sums exchanged between them (cooperative launch; GMMLOC_POSE_COOP=0 | 2..4)
-    int nb = std::min(4, (M + 255) / 256);
-    while (nb > 1 && B * nb > c->ncu) --nb;  // one frame 0.35 -> 0.28 ms, 64 frames 0.42 -> 0.35 ms (1 000 edges)
-    bool coop = nb > 1;
-    if (c->opt.pose_coop >= 0) {
-      const int v = (int)c->opt.pose_coop;
-      coop = v >= 2 && B * v <= 512;
-      if (coop) nb = std::min(v, 4);
-    }
-    int one = 1;
-    unsigned long long* none = nullptr;
-    bool done = false;
-    if (coop) {
-      unsigned long long* parts = (unsigned long long*)((char*)scratch + chi_bytes);
-      double* chi = (double*)scratch;
-      GL_HIP(hipMemsetAsync(parts, 0, (size_t)B * 2 * nb * 64 * sizeof(unsigned long long), c->stream));
-      void* args[] = {&kp, &B, &M, &pose_dev, &Xw_dev, &obs_dev, &octave_dev, &outlier_dev, &ninlier_dev, &chi, &nb, &parts};
-      if (hipLaunchCooperativeKernel((const void*)k_optimize_current_pose<4>, dim3(B * nb), dim3(256), args, 0, c->stream) ==
-          hipSuccess)
-        done = true;
-      else
-        (void)hipGetLastError();  // not co-resident: the ordinary shapes below
-    }
-    if (done) {
-    } else if (nw == 8)
-      k_optimize_current_pose<8><<<B, 512, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                          ninlier_dev, (double*)scratch, one, none);
-    else if (nw == 4)
-      k_optimize_current_pose<4><<<B, 256, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                          ninlier_dev, (double*)scratch, one, none);
+    // the canonical summation order of a frame of stride M (see group_totals28): G groups of S <= 4 chunks of 64 edges
+    const int nch = std::max(1, (M + 63) / 64), G = (nch + 3) / 4, S = (nch + G - 1) / G;
+    // waves per frame: one wave for large batches (12 frames per CU, no barriers); for fewer frames a wave per group, up to
+    // 8 (one frame of 1 000 edges: 0.34 ms on 4 waves against 0.90 ms on one).  The sums are built in the same order
+    // whatever the count: the shape never shows in the results.  Option pose_waves (1 | 4 | 8) forces the cap.
+    int nw = B > 1536 ? 1 : std::min(G, 8);
+    if (c->opt.pose_waves > 0) nw = std::min(G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
+    const size_t lds = (size_t)G * 32 * sizeof(double);
+    if (nw > 4)
+      k_optimize_current_pose<8><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                               ninlier_dev, (double*)scratch);
+    else if (nw > 1)
+      k_optimize_current_pose<4><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                               ninlier_dev, (double*)scratch);
     else
-      k_optimize_current_pose<1><<<B, 64, 0, c->stream>>>(kp, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                         ninlier_dev, (double*)scratch, one, none);
+      k_optimize_current_pose<1><<<B, 64, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
+                                                           ninlier_dev, (double*)scratch);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

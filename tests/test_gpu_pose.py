@@ -43,7 +43,6 @@ def run_gpu(gpu, cam, prm, frames):
 @pytest.mark.parametrize("M,seed", [(300, 100), (1200, 200), (2000, 300), (37, 400)])
 def test_optimize_current_pose_matches_oracle(gpu, oracle, map_v1, gt_sync, opt, M, seed, kernel):
     opt("pose_waves", int(kernel))
-    opt("pose_coop", 0 if kernel != "4" else 3)  # "4": also the frame dealt to 3 workgroups
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
     frames = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 6, M, seed)
@@ -106,3 +105,26 @@ def test_optimize_current_pose_keeps_flags_without_map_point(gpu, oracle, map_v1
     p_ref, o_ref, n_ref = oracle.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
     got, none = outl.cpu().numpy()[0], f["octave"] < 0
     assert np.array_equal(got[none], preset[none]) and np.array_equal(got[~none], o_ref[~none]) and int(nin[0]) == n_ref
+
+
+def test_optimize_current_pose_bit_identical_across_shapes_and_batches(gpu, map_v1, gt_sync, opt):
+    """One canonical summation order (gl_refine_pose.hip): the refined pose, the outlier mask and the inlier count of a
+    frame are the same BITS on one wave (batch shape), on a wave per group (few frames), and whatever rides in the call."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    for M in (37, 64, 300, 513, 1000, 1200, 1999, 2500):
+        frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, 6, M, 7000 + M)
+        frames[1]["octave"][::5] = -1
+        res = {}
+        for nw in (1, 4, 8):
+            opt("pose_waves", nw)
+            res[nw] = run_gpu(gpu, cam, prm, frames)
+        for nw in (4, 8):
+            for a, b in zip(res[1], res[nw]):
+                assert np.array_equal(a, b), (M, nw)
+        opt("pose_waves", 0)
+        big = run_gpu(gpu, cam, prm, [frames[i % 6] for i in range(1700)])  # > 1536 frames: the one-wave shape
+        one = run_gpu(gpu, cam, prm, frames[:1])                             # the frame-at-a-time shape
+        for a, b, c in zip(res[1], big, one):
+            assert np.array_equal(a, b[:6]) and np.array_equal(a[:1], c), M

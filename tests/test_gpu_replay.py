@@ -53,6 +53,6 @@ def test_replay_cli_with_rccl_collectives_at_world_1():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay_euroc.py"), "--limit", "40", "--batch", "64",
                           "--collective-at-world-1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
-    d = json.loads(out.stdout.strip().split("\n")[-1])
+    d = json.loads([l for l in out.stdout.split("\n") if l.startswith("{")][-1])  # RCCL prints its banner on stdout too
     assert d["frames"] == 240 and d["backend"] == "nccl" and d["frames_per_s"] > 0
     assert all(v["ape_rmse_m"] < 0.01 for v in d["sequences"].values())
