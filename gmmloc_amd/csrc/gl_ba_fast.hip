@@ -118,7 +118,7 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   const bool s32 = c->opt.ba_step32 != 0;
   const int cap = s32 ? 2000 : (a.L <= 496 ? 496 : a.L <= 1000 ? 1000 : 2000);
   const BafKernel kern = s32 ? bafd2000s32::k_ba1_fast : cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast;
-  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap == 1000 ? 4 : 8) * 32 + 64 + 8) * sizeof(double);
+  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap == 1000 ? 4 : 8) * 32 + 64 + 40) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;
@@ -137,11 +137,11 @@ static int launch_dense(Ctx* c, BafArgs& a) {
 // Returns 1 when the cooperative launch is refused (the caller falls back to DENSE).
 static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   const BafKernel kern = c->opt.ba_step32 != 0 ? bafs32::k_ba1_fast : bafs::k_ba1_fast;
-  const size_t lds = (size_t)(10 * 512 + 2 * 32 + 64 + 8 + 29 * 512) * sizeof(double);
+  const size_t lds = (size_t)(10 * 512 + 2 * 32 + 64 + 40 + 29 * 512) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = (a.G + 1) / 2;
   // the exchange words of the frames sit behind the plane records
-  a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 32 + 63) / 64) * 64);
+  a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 56 + 63) / 64) * 64);
   TimerScope ts(c, GL_TIMER_BA);
   if (a.NB == 1) {
     kern<<<a.B, 512, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.obs, a.oct, a.assoc, a.d2, a.dropped, a.erase, a.iters,

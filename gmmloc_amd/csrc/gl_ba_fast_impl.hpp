@@ -51,6 +51,11 @@ constexpr int NRED = kSpread ? 2 : NWC;    // group totals kept in LDS (a SPREAD
 
 #ifdef GL_BA_PROF
 __device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof_w[64 * 8 * 4];  // [trial < 64][wave][marker]: clock64 at pass-A end, after reduce A, pass-B start, pass-B end
+#define PROF_W(trial, marker) \
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (trial) < 64) g_prof_w[((trial)*8 + (threadIdx.x >> 6)) * 4 + (marker)] = (unsigned long long)clock64()
+#else
+#define PROF_W(trial, marker)
 #endif
 #ifndef PROF_T
 #ifdef GL_BA_PROF
@@ -62,7 +67,9 @@ __device__ unsigned long long g_prof[16];
 #endif
 #endif
 
-enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32 };
+// F_AR / F_AG: the point's reprojection / GMM edge is ACTIVE (exists, level 0) - derived bits, refreshed whenever the
+// levels change (fw_activity), so that a pass tests one mask instead of re-deriving them per point and trial
+enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32, F_AR = 64, F_AG = 128 };
 
 // a + b that is never contracted with a multiplication feeding it: every term of a canonical sum is rounded on
 // its own, whichever kernel adds it (this file is compiled with contraction allowed)
@@ -171,12 +178,21 @@ struct Lds {      // per-frame state, SoA over MCAP points (index = local point 
   //   pass B -> accept : backup of the point (3 fp64) while the trial point sits in `sp`; restored only
   //                      when the trial is rejected.
   double* un;
-  double* stab;   // 8: 1/sigma^2 per pyramid octave
+  // 24 uniform constants: [0..7] sx = fx^2 / sigma^2 and [8..15] sy = fy^2 / sigma^2 per pyramid octave (the residuals
+  // are kept in NORMALISED image coordinates, see reproj_n), [16..19] Huber {delta, delta^2} mono / stereo
+  double* stab;
 };
 // per-point flag bits + octave (bits 8..10) live in REGISTERS: 16 bits per point slot of the thread
 typedef unsigned long long FlagW;
 GL_DEV int fw_get(FlagW fw, int i) { return (int)((fw >> (16 * i)) & 0xffffull); }
 GL_DEV void fw_or(FlagW& fw, int i, int bits) { fw |= (FlagW)bits << (16 * i); }
+GL_DEV void fw_activity(FlagW& fw, int i) {
+  const int fl = fw_get(fw, i);
+  int act = 0;
+  if ((fl & F_EXISTS) && !(fl & F_LEVR)) act |= F_AR;
+  if ((fl & F_EXISTS) && (fl & F_ASSOC) && !(fl & F_LEVG)) act |= F_AG;
+  fw = (fw & ~((FlagW)(F_AR | F_AG) << (16 * i))) | ((FlagW)act << (16 * i));
+}
 
 // the canonical order of a frame of stride L and this thread's place in it
 struct Map {
@@ -187,22 +203,42 @@ struct Map {
 
 struct Lin {
   double q[3];
-  double A[6];   // reprojection block w Jpi^T Jpi (camera frame, sym6; A[1] == 0)
+  double A[6];   // reprojection block sum_r w_r j_r^T j_r (camera frame, sym6; A[1] == 0)
   double a[3];   // its rhs
   double D[6];   // A + GMM block (no damping yet)
   double b[3];   // a + GMM rhs
-  double rho0_r, chi_g;
+  double rho0_r, rho1, chi_g;
 };
 
-GL_DEV double reproj_chi2(const BaK& k, const double* q, const double* ob, bool stereo, double s, double* e,
-                          double& iz) {
-  const double ou = ob[0], ov = ob[1], our = ob[2];
+// uniform camera / weight constants of a launch (SGPRs)
+struct Uni {
+  double bn;    // bf / fx: baseline in normalised image units
+  double lm;    // ba_lambda2
+};
+
+// Reprojection residual in NORMALISED image coordinates: the observations are stored once per launch as
+// ((u - cx) / fx, (v - cy) / fy, (u_right - cx) / fx), so e_n = obs_n - (x/z, y/z, x/z - bn/z) needs no intrinsics and
+// chi2 = sx (e0^2 + e2^2) + sy e1^2 with sx = fx^2 / sigma^2, sy = fy^2 / sigma^2 (per octave, LDS table) - the same
+// quadratic form as s |obs - K pi(q)|^2 of EdgeStereoSE3ProjectXYZ / factors.cpp:66-168.
+GL_DEV double reproj_n(const double* q, const double* ob, bool stereo, double bn, double sx, double sy, double* e, double& iz) {
   iz = rcp_nr(q[2]);
-  const double pu = q[0] * iz * k.fx + k.cx, pv = q[1] * iz * k.fy + k.cy;
-  e[0] = ou - pu;
-  e[1] = ov - pv;
-  e[2] = stereo ? (our - (pu - k.bf * iz)) : 0.0;
-  return s * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const double xz = q[0] * iz, yz = q[1] * iz;
+  e[0] = ob[0] - xz;
+  e[1] = ob[1] - yz;
+  e[2] = stereo ? (ob[2] - fma(-bn, iz, xz)) : 0.0;
+  return fma(sy * e[1], e[1], sx * fma(e[2], e[2], e[0] * e[0]));
+}
+// rows of the projection Jacobian in normalised coordinates: (iz, 0, c0), (0, iz, c1) and, stereo only, (iz, 0, c2)
+struct Jpi {
+  double c0, c1, c2;
+};
+GL_DEV Jpi jpi_n(const double* q, double iz, double bn) {
+  Jpi J;
+  const double iz2 = iz * iz;
+  J.c0 = -q[0] * iz2;
+  J.c1 = -q[1] * iz2;
+  J.c2 = fma(bn, iz2, J.c0);
+  return J;
 }
 
 // GMM edge of a NON-degenerate component (rare): EdgePt2Gaussian, e = L^T d, J = L^T, so
@@ -239,73 +275,69 @@ GL_DEV double gmm_nondeg(const GmmDev& gm, int a, const double* R, const double*
   return chi;
 }
 
-// Jpi of the (stereo) projection at camera point q: rows (al, 0, b0), (0, ga, b1) and, stereo only, (al, 0, b2)
-struct Jpi {
-  double al, ga, b0, b1, b2;
+// per-point context loaded at the top of a loop iteration
+struct PtCtx {
+  int l, ll, fl, asc;  // frame-local point index, LDS index, flags, non-degenerate component (or -1)
+  double sx, sy;       // fx^2 / sigma^2, fy^2 / sigma^2 of the point's octave
+  double ob[3], nd[4], p[3];
+  bool ar, ag;
 };
-GL_DEV Jpi jpi_at(const BaK& k, const double* q, double iz) {
-  Jpi J;
-  const double iz2 = iz * iz;
-  J.al = k.fx * iz;
-  J.ga = k.fy * iz;
-  J.b0 = -k.fx * q[0] * iz2;
-  J.b1 = -k.fy * q[1] * iz2;
-  J.b2 = fma(k.bf, iz2, J.b0);
-  return J;
+
+// Huber weight of the point's reprojection edge from its un-robustified chi2 (delta by edge type, LDS table)
+GL_DEV void huber_pt(const Lds& D, bool stereo, double chi, double& rho0, double& rho1) {
+  const double dl = D.stab[stereo ? 18 : 16], dsqr = D.stab[stereo ? 19 : 17];
+  huber_bf(chi, dl, dsqr, rho0, rho1);
 }
 
-// linearise point l at pose P and world point p; returns the un-robustified chi2_r
-GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const double* nd, int fl, int asc, double s,
-                       const double* ob, const double* p, bool robust, Lin& o) {
-  const bool act_r = !(fl & F_LEVR), act_g = (fl & F_ASSOC) && !(fl & F_LEVG);
+// linearise the point of context c at pose P; returns the un-robustified chi2_r
+GL_DEV double lin_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, Lin& o) {
+  const double* p = c.p;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o.q[c] = P.R[c * 3] * p[0] + P.R[c * 3 + 1] * p[1] + P.R[c * 3 + 2] * p[2] + P.t[c];
+  for (int k = 0; k < 3; ++k) o.q[k] = P.R[k * 3] * p[0] + P.R[k * 3 + 1] * p[1] + P.R[k * 3 + 2] * p[2] + P.t[k];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) o.A[c] = 0.0;
+  for (int k = 0; k < 6; ++k) o.A[k] = 0.0;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o.a[c] = 0.0;
+  for (int k = 0; k < 3; ++k) o.a[k] = 0.0;
   o.rho0_r = 0.0;
+  o.rho1 = 1.0;
   o.chi_g = 0.0;
   double chi_r = 0.0;
-  if (act_r) {
-    const bool stereo = fl & F_STEREO;
+  if (c.ar) {
+    const bool stereo = c.fl & F_STEREO;
     double e[3], iz;
-    chi_r = reproj_chi2(k, o.q, ob, stereo, s, e, iz);
-    double rho1 = 1.0;
+    chi_r = reproj_n(o.q, c.ob, stereo, U.bn, c.sx, c.sy, e, iz);
     o.rho0_r = chi_r;
-    if (robust) {
-      const double dl = stereo ? k.delta_stereo : k.delta_mono;
-      huber_bf(chi_r, dl, dl * dl, o.rho0_r, rho1);
-    }
-    // t = w on the stereo row, else 0
-    const double w = rho1 * s;
-    const double t = stereo ? w : 0.0;
-    const Jpi J = jpi_at(k, o.q, iz);
-    const double wga = w * J.ga, tb2 = t * J.b2;
-    o.A[0] = (w + t) * J.al * J.al;
-    o.A[2] = J.al * fma(t, J.b2, w * J.b0);
-    o.A[3] = wga * J.ga;
-    o.A[4] = wga * J.b1;
-    o.A[5] = fma(tb2, J.b2, w * fma(J.b1, J.b1, J.b0 * J.b0));
-    o.a[0] = J.al * fma(t, e[2], w * e[0]);
-    o.a[1] = wga * e[1];
-    o.a[2] = fma(tb2, e[2], w * fma(J.b1, e[1], J.b0 * e[0]));
+    if (robust) huber_pt(D, stereo, chi_r, o.rho0_r, o.rho1);
+    // weights of the u / v rows and (t) of the stereo row
+    const double wx = o.rho1 * c.sx, wy = o.rho1 * c.sy;
+    const double t = stereo ? wx : 0.0;
+    const Jpi J = jpi_n(o.q, iz, U.bn);
+    const double iz2 = iz * iz;
+    const double wxc0 = wx * J.c0, wyc1 = wy * J.c1, tc2 = t * J.c2, wyiz = wy * iz;
+    o.A[0] = (wx + t) * iz2;
+    o.A[2] = iz * (wxc0 + tc2);
+    o.A[3] = wy * iz2;
+    o.A[4] = wyiz * J.c1;
+    o.A[5] = fma(tc2, J.c2, fma(wyc1, J.c1, wxc0 * J.c0));
+    o.a[0] = iz * fma(t, e[2], wx * e[0]);
+    o.a[1] = wyiz * e[1];
+    o.a[2] = fma(tc2, e[2], fma(wyc1, e[1], wxc0 * e[0]));
   }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) o.D[c] = o.A[c];
+  for (int k = 0; k < 6; ++k) o.D[k] = o.A[k];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o.b[c] = o.a[c];
-  if (act_g) {
-    if (fl & F_DEG) {  // EdgePt2GaussianDeg x ba_lambda2: D += lm n' n'^T, b -= lm eg n'  (n' = R n)
-      const double nx = nd[0], ny = nd[1], nz = nd[2];
-      const double eg = fma(nz, p[2], fma(ny, p[1], nx * p[0])) - nd[3];
-      const double lm = k.ba_lambda2;
+  for (int k = 0; k < 3; ++k) o.b[k] = o.a[k];
+  if (c.ag) {
+    if (c.fl & F_DEG) {  // EdgePt2GaussianDeg x ba_lambda2: D += lm n' n'^T, b -= lm eg n'  (n' = R n)
+      const double nx = c.nd[0], ny = c.nd[1], nz = c.nd[2];
+      const double eg = fma(nz, p[2], fma(ny, p[1], nx * p[0])) - c.nd[3];
+      const double lm = U.lm;
       o.chi_g = eg * (lm * eg);
       double nc[3], tn[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        nc[c] = fma(P.R[c * 3 + 2], nz, fma(P.R[c * 3 + 1], ny, P.R[c * 3] * nx));
-        tn[c] = lm * nc[c];
+      for (int k = 0; k < 3; ++k) {
+        nc[k] = fma(P.R[k * 3 + 2], nz, fma(P.R[k * 3 + 1], ny, P.R[k * 3] * nx));
+        tn[k] = lm * nc[k];
       }
       o.D[0] = fma(tn[0], nc[0], o.D[0]);
       o.D[1] = fma(tn[0], nc[1], o.D[1]);
@@ -314,23 +346,23 @@ GL_DEV double lin_fast(const BaK& k, const GmmDev& gm, const Pose& P, const doub
       o.D[4] = fma(tn[1], nc[2], o.D[4]);
       o.D[5] = fma(tn[2], nc[2], o.D[5]);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o.b[c] = fma(-eg, tn[c], o.b[c]);
+      for (int k = 0; k < 3; ++k) o.b[k] = fma(-eg, tn[k], o.b[k]);
     } else {
       double Hc[6], bc[3];
-      o.chi_g = gmm_nondeg(gm, asc, P.R, p, Hc, bc);
+      o.chi_g = gmm_nondeg(gm, c.asc, P.R, p, Hc, bc);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) o.D[c] += Hc[c];
+      for (int k = 0; k < 6; ++k) o.D[k] += Hc[k];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o.b[c] += bc[c];
+      for (int k = 0; k < 3; ++k) o.b[k] += bc[k];
     }
   }
   return chi_r;
 }
 
-GL_DEV double gmm_chi2_fast(const BaK& k, const GmmDev& gm, const double* nd, int fl, int asc, const double* p) {
+GL_DEV double gmm_chi2_fast(double lm, const GmmDev& gm, const double* nd, int fl, int asc, const double* p) {
   if (fl & F_DEG) {
     const double eg = (nd[0] * p[0] + nd[1] * p[1] + nd[2] * p[2]) - nd[3];
-    return eg * (k.ba_lambda2 * eg);
+    return eg * (lm * eg);
   }
   return gmm_nondeg(gm, asc, nullptr, p, nullptr, nullptr);
 }
@@ -439,6 +471,7 @@ GL_DEV double wave_reduce_scatter8(double* v) {
 struct Red {
   double* red;   // NRED x 32: per group (DENSE: wave) totals
   double* tot;   // 32 totals (+ 32 broadcast slots)
+  double* red2;  // DENSE: NWC x 2 wave totals of pass B (zero where a wave is absent)
   double* tb;    // SPREAD: transpose buffer [value][512]
   int S;         // chunks per group
 };
@@ -508,6 +541,83 @@ GL_DEV void reduce2_w0(double* v, const Red& R, Coop& C) {
     for (int i = 0; i < NV; ++i) v[i] = uni(R.tot[i]);
   }
 }
+// ---- DENSE shortcuts for the two reductions of every Levenberg trial (same canonical order, fewer barriers) ----
+// pass A (29 values, read by the solving wave only): group totals to red[], ONE barrier, then wave 0 adds the blocks
+// itself and hands the totals round its lanes with v_readlane - no `tot` round trip, no second barrier.  The next
+// writer of red[] is the next trial's pass A, two barriers later.
+GL_DEV void reduce29_w0_dense(double* v, const Red& R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 29; i < 32; ++i) v[i] = 0.0;
+  const double r = wave_reduce_scatter32(v);
+  if (wave_slot_owner(lane)) R.red[wave * 32 + wave_slot(lane)] = r;
+  __syncthreads();
+  if (wave == 0) {
+    const int t = lane & 31;
+    double s = NWC > 1 ? add_nc(R.red[t], R.red[32 + t]) : R.red[t];
+#pragma unroll
+    for (int b = 1; b < NWC / 2; ++b) s = add_nc(s, add_nc(R.red[(2 * b) * 32 + t], R.red[(2 * b + 1) * 32 + t]));
+    union {
+      double d;
+      int i[2];
+    } u, w;
+    u.d = s;
+#pragma unroll
+    for (int i = 0; i < 29; ++i) {
+      w.i[0] = __builtin_amdgcn_readlane(u.i[0], i);
+      w.i[1] = __builtin_amdgcn_readlane(u.i[1], i);
+      v[i] = w.d;
+    }
+  }
+}
+// one value summed over the wave in the canonical butterfly (partners 32, 16, 1, 2, 4, 8 lanes apart, every lane ends
+// with the total): with a = b = x the lane swaps return own and partner value, whichever half the lane is in
+GL_DEV double wave_allreduce_canon(double x) {
+  union {
+    double d;
+    unsigned u[2];
+  } a, b;
+  a.d = x;
+  gl_v2u lo = __builtin_amdgcn_permlane32_swap(a.u[0], a.u[0], false, false);
+  gl_v2u hi = __builtin_amdgcn_permlane32_swap(a.u[1], a.u[1], false, false);
+  a.u[0] = lo.x;
+  b.u[0] = lo.y;
+  a.u[1] = hi.x;
+  b.u[1] = hi.y;
+  x = a.d + b.d;
+  a.d = x;
+  lo = __builtin_amdgcn_permlane16_swap(a.u[0], a.u[0], false, false);
+  hi = __builtin_amdgcn_permlane16_swap(a.u[1], a.u[1], false, false);
+  a.u[0] = lo.x;
+  b.u[0] = lo.y;
+  a.u[1] = hi.x;
+  b.u[1] = hi.y;
+  x = a.d + b.d;
+  x = x + dpp_f64<0xB1>(x);   // lane ^ 1
+  x = x + dpp_f64<0x4E>(x);   // lane ^ 2
+  x = x + dpp_f64<0x141>(x);  // lane ^ 7
+  x = x + dpp_f64<0x140>(x);  // lane ^ 15
+  return x;
+}
+// pass B (2 values, needed by every thread): wave totals to the small buffer red2, ONE barrier, every thread
+// adds the blocks itself.  The buffer is rewritten one trial later, with the barriers of pass A in between.
+GL_DEV void reduce2_dense(double* v, const Red& R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double s0 = wave_allreduce_canon(v[0]), s1 = wave_allreduce_canon(v[1]);
+  if (lane == 0) {
+    R.red2[wave * 2] = s0;
+    R.red2[wave * 2 + 1] = s1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    double s = NWC > 1 ? add_nc(R.red2[j], R.red2[2 + j]) : R.red2[j];
+#pragma unroll
+    for (int b = 1; b < NWC / 2; ++b) s = add_nc(s, add_nc(R.red2[(2 * b) * 2 + j], R.red2[(2 * b + 1) * 2 + j]));
+    v[j] = uni(s);
+  }
+}
+
 GL_DEV double reduce_max(double v, const Red& R, Coop& C) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) v = fmax(v, shfl_xor_f64(v, o));
@@ -601,34 +711,26 @@ GL_DEV void restore_point(const Lds& D, int ll) {
   }
 }
 
-// per-point context loaded at the top of a loop iteration
-struct PtCtx {
-  int l, ll, fl, asc;  // frame-local point index, LDS index, flags, non-degenerate component (or -1)
-  double s;
-  double ob[3], nd[4], p[3];
-  bool ar, ag;
-};
-// observations and plane records come from global memory (read-only, coalesced, L2-resident).
+// The normalised observations and the plane records come from the launch's scratch in global memory (read-only after
+// the set-up, coalesced, L2-resident).  A point takes part in a pass iff one of its edges is active: one mask test
+// (slots beyond the frame never get a flag).
 // (Software-prefetching slot i+1 was measured: it costs 14 VGPRs -> 6 spilled registers and
 // ~1 GB of scratch writes per launch for no gain; the second wave of the SIMD hides the latency.)
-GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gobs, const double* __restrict__ gnd,
-                    const int32_t* __restrict__ gassoc, int L, int i, PtCtx& c) {
+GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gobn, const double* __restrict__ gnd,
+                    const int32_t* __restrict__ gassoc, int i, PtCtx& c) {
+  c.fl = fw_get(fw, i);
+  if (!(c.fl & (F_AR | F_AG))) return false;
   c.l = mp.base + 64 * i;
   c.ll = mp.lbase + 64 * i;
-  {  // issue the observation loads first (clamped index): they overlap the LDS reads / flag tests below
-    const int lc = min(c.l, L - 1);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) c.ob[j] = gobs[(size_t)lc * 3 + j];
-  }
-  if (c.l >= L) return false;
+  for (int j = 0; j < 3; ++j) c.ob[j] = gobn[(size_t)c.l * 3 + j];
 #pragma unroll
   for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)c.l * 4 + j];  // plane normal n and n . mean
-  c.fl = fw_get(fw, i);
-  if (!(c.fl & F_EXISTS)) return false;
-  c.ar = !(c.fl & F_LEVR);
-  c.ag = (c.fl & F_ASSOC) && !(c.fl & F_LEVG);
-  if (!(c.ar || c.ag)) return false;
-  c.s = D.stab[(c.fl >> 8) & 7];
+  c.ar = c.fl & F_AR;
+  c.ag = c.fl & F_AG;
+  const int oc = (c.fl >> 8) & 7;
+  c.sx = D.stab[oc];
+  c.sy = D.stab[8 + oc];
   c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? gassoc[c.l] : -1;
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
@@ -639,9 +741,9 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
 // computeLambdaInit: pose-block terms 0..20 of the undamped reprojection Hessian, and the largest diagonal of the
 // point block (world frame) into md
 template <class Sink>
-GL_DEV void pt_lambda_init(const BaK& k, const GmmDev& gm, const Pose& P, const PtCtx& c, bool robust, double& md, const Sink& sk) {
+GL_DEV void pt_lambda_init(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double& md, const Sink& sk) {
   Lin o;
-  lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+  lin_fast(U, gm, D, P, c, robust, o);
   const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -657,12 +759,13 @@ GL_DEV void pt_lambda_init(const BaK& k, const GmmDev& gm, const Pose& P, const 
     pose_terms(o.q, o.A, zero, false, sk);
   }
 }
-// pass A: linearise, point solve, Schur terms 0..26, robust chi2 (27), sum u.b (28); leaves D^-1 in the slot
+// pass A: linearise, point solve, Schur terms 0..26, robust chi2 (27), sum u.b (28); leaves D^-1 in the slot and the
+// Huber weight rho' of the reprojection edge in the stale-chi2 cell (dead until pass B rewrites it)
 template <class Sink>
-GL_DEV void pt_pass_a(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double lambda,
+GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double lambda,
                       const Sink& sk) {
   Lin o;
-  lin_fast(k, gm, P, c.nd, c.fl, c.asc, c.s, c.ob, c.p, robust, o);
+  lin_fast(U, gm, D, P, c, robust, o);
   sk.put(27, o.rho0_r + o.chi_g);
   double Dinv[6], u[3];
   point_solve_fast(o, lambda, Dinv, u);
@@ -676,6 +779,7 @@ GL_DEV void pt_pass_a(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& 
     for (int j = 0; j < 6; ++j) D.un[j * MCAP + c.ll] = Dinv[j];
   }
   if (c.ar) {
+    if (!kStep32) D.chir[c.ll] = o.rho1;
     double C[6], cc[3], AD[9];
     sym3_mul(o.A, Dinv, AD);
     if (kStep32) {
@@ -697,7 +801,7 @@ GL_DEV void pt_pass_a(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& 
 // pass B: point step, trial point (in place, old point backed up in the slot), chi2 at the trial state.
 // terms: 0 = |eps|^2, 1 = robust chi2 of the point's edges at the trial state
 template <class Sink>
-GL_DEV void pt_pass_b(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& P, const Pose& Pn, const double* dx, const PtCtx& c,
+GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const Pose& Pn, const double* dx, const PtCtx& c,
                       bool robust, const Sink& sk) {
   // eps = D^-1 (b - A gd),  gd = omega x q + upsilon
   double q[3], gd[3], eps[3];
@@ -720,28 +824,24 @@ GL_DEV void pt_pass_b(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& 
   } else {  // exact: b - A gd = Jpi^T W (e - Jpi gd) + b_gmm from the re-evaluated residual, times the cached D^-1
     double rhs[3] = {0.0, 0.0, 0.0};
     if (c.ar) {
-      double e[3], iz;
-      const double chi_r = reproj_chi2(k, q, c.ob, stereo, c.s, e, iz);
-      double rho0 = chi_r, rho1 = 1.0;
-      if (robust) {
-        const double dl = stereo ? k.delta_stereo : k.delta_mono;
-        huber_bf(chi_r, dl, dl * dl, rho0, rho1);
-      }
-      const double w = rho1 * c.s;
-      const double t = stereo ? w : 0.0;
-      const Jpi J = jpi_at(k, q, iz);
-      const double f0 = w * (e[0] - fma(J.al, gd[0], J.b0 * gd[2]));
-      const double f1 = w * (e[1] - fma(J.ga, gd[1], J.b1 * gd[2]));
-      const double f2 = t * (e[2] - fma(J.al, gd[0], J.b2 * gd[2]));
-      rhs[0] = J.al * (f0 + f2);
-      rhs[1] = J.ga * f1;
-      rhs[2] = fma(J.b2, f2, fma(J.b1, f1, J.b0 * f0));
+      const double rho1 = D.chir[c.ll];  // the edge's Huber weight, left there by pass A
+      const double iz = rcp_nr(q[2]);
+      const double xz = q[0] * iz, yz = q[1] * iz;
+      const Jpi J = jpi_n(q, iz, U.bn);
+      const double wx = rho1 * c.sx, wy = rho1 * c.sy;
+      // f_r = w_r (e_r - j_r . gd)
+      const double f0 = wx * ((c.ob[0] - xz) - fma(iz, gd[0], J.c0 * gd[2]));
+      const double f1 = wy * ((c.ob[1] - yz) - fma(iz, gd[1], J.c1 * gd[2]));
+      const double f2 = stereo ? wx * ((c.ob[2] - fma(-U.bn, iz, xz)) - fma(iz, gd[0], J.c2 * gd[2])) : 0.0;
+      rhs[0] = iz * (f0 + f2);
+      rhs[1] = iz * f1;
+      rhs[2] = fma(J.c2, f2, fma(J.c1, f1, J.c0 * f0));
     }
     if (c.ag) {
       if (c.fl & F_DEG) {
         const double nx = c.nd[0], ny = c.nd[1], nz = c.nd[2];
         const double eg = fma(nz, c.p[2], fma(ny, c.p[1], nx * c.p[0])) - c.nd[3];
-        const double m = -k.ba_lambda2 * eg;
+        const double m = -U.lm * eg;
 #pragma unroll
         for (int j = 0; j < 3; ++j) rhs[j] = fma(m, fma(P.R[j * 3 + 2], nz, fma(P.R[j * 3 + 1], ny, P.R[j * 3] * nx)), rhs[j]);
       } else {
@@ -768,16 +868,13 @@ GL_DEV void pt_pass_b(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& 
     double qn[3], e[3], iz;
 #pragma unroll
     for (int j = 0; j < 3; ++j) qn[j] = Pn.R[j * 3] * pn[0] + Pn.R[j * 3 + 1] * pn[1] + Pn.R[j * 3 + 2] * pn[2] + Pn.t[j];
-    const double c2 = reproj_chi2(k, qn, c.ob, stereo, c.s, e, iz);
+    const double c2 = reproj_n(qn, c.ob, stereo, U.bn, c.sx, c.sy, e, iz);
     D.chir[c.ll] = c2;
     double r0 = c2, r1;
-    if (robust) {
-      const double dl = stereo ? k.delta_stereo : k.delta_mono;
-      huber_bf(c2, dl, dl * dl, r0, r1);
-    }
+    if (robust) huber_pt(D, stereo, c2, r0, r1);
     chi = r0;
   }
-  if (c.ag) chi += gmm_chi2_fast(k, gm, c.nd, c.fl, c.asc, pn);
+  if (c.ag) chi += gmm_chi2_fast(U.lm, gm, c.nd, c.fl, c.asc, pn);
   sk.put(1, chi);
 }
 
@@ -789,20 +886,20 @@ GL_DEV void pt_pass_b(const BaK& k, const GmmDev& gm, const Lds& D, const Pose& 
     if (kSpread) {                                                            \
       const SinkSet sk{acc};                                                  \
       PtCtx c;                                                                \
-      if (load_pt(D, mp, fw, gobs, gnd, gassoc, L, 0, c)) { BODY; }           \
+      if (load_pt(D, mp, fw, gobn, gnd, gassoc, 0, c)) { BODY; }              \
     } else {                                                                  \
       const SinkAcc sk{acc};                                                  \
       _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
         PtCtx c;                                                              \
-        if (!load_pt(D, mp, fw, gobs, gnd, gassoc, L, i, c)) continue;        \
+        if (!load_pt(D, mp, fw, gobn, gnd, gassoc, i, c)) continue;           \
         BODY;                                                                 \
       }                                                                       \
     }                                                                         \
   }
 
 // SparseOptimizer::optimize(iters), Levenberg
-GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P, int L,
-                         const double* __restrict__ gobs, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
+GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
+                         const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
                          bool robust, int iters, const Red& R, int& trials, Coop& C) {
   double acc[32];
 #pragma unroll
@@ -811,12 +908,9 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map
     const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
-      if (mp.base + 64 * i >= L) break;
       const int fl = fw_get(fw, i);
-      if (!(fl & F_EXISTS)) continue;
-      const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
-      if (ar) acc[0] += 1.0;
-      if (ar || ag) acc[1] += 1.0;
+      if (fl & F_AR) acc[0] += 1.0;
+      if (fl & (F_AR | F_AG)) acc[1] += 1.0;
     }
   }
   reduce2<2>(acc, R, C);
@@ -830,7 +924,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map
     int qmax = 0;
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
-      GL_BAF_PASS(pt_lambda_init(k, gm, P, c, robust, md, sk));
+      GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
       if (pose_active) {
 #pragma unroll
@@ -843,13 +937,15 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map
     do {
       PROF_T(tA0);
       // ---- pass A ---------------------------------------------------------------------------
-      GL_BAF_PASS(pt_pass_a(k, gm, D, P, c, robust, lambda, sk));
+      GL_BAF_PASS(pt_pass_a(U, gm, D, P, c, robust, lambda, sk));
       PROF_T(tA1);
-      reduce2_w0<29>(acc, R, C);
+      PROF_W(trials, 0);
+      if (kSpread) reduce2_w0<29>(acc, R, C);
+      else reduce29_w0_dense(acc, R);
+      PROF_W(trials, 1);
       PROF_T(tA2);
-      if (qmax == 0) currentChi = uni(R.tot[27]);
       // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
-      double* bc = R.tot + 32;  // 26 doubles: dx[6] R[9] t[3] ok g[6] sum u.b
+      double* bc = R.tot + 32;  // 27 doubles: dx[6] R[9] t[3] ok g[6] sum u.b chi2
       if (threadIdx.x < 64) {
         double dxs[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
@@ -867,9 +963,11 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map
 #pragma unroll
           for (int i = 0; i < 6; ++i) bc[19 + i] = acc[21 + i];  // reduced rhs g and sum u.b, for computeScale
           bc[25] = acc[28];
+          bc[26] = acc[27];  // robust chi2 at the linearisation point
         }
       }
       __syncthreads();
+      if (qmax == 0) currentChi = uni(bc[26]);
       double dx[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) dx[i] = uni(bc[i]);
@@ -880,10 +978,13 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map
       for (int i = 0; i < 3; ++i) Pn.t[i] = uni(bc[15 + i]);
       const bool ok2 = uni(bc[18]) != 0.0;
       PROF_T(tS);
+      PROF_W(trials, 2);
       // ---- pass B ---------------------------------------------------------------------------
-      GL_BAF_PASS(pt_pass_b(k, gm, D, P, Pn, dx, c, robust, sk));
+      GL_BAF_PASS(pt_pass_b(U, gm, D, P, Pn, dx, c, robust, sk));
       PROF_T(tB1);
-      reduce2<2>(acc, R, C);
+      PROF_W(trials, 3);
+      if (kSpread) reduce2<2>(acc, R, C);
+      else reduce2_dense(acc, R);
       PROF_T(tB2);
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
       // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
@@ -910,13 +1011,7 @@ GL_DEV int optimize_fast(const BaK& k, const GmmDev& gm, const Lds& D, const Map
         const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
         for (int i = 0; i < ns; ++i) {  // discardTop: restore the backed-up points
-          if (mp.base + 64 * i >= L) break;
-          const int ll = mp.lbase + 64 * i;
-          const int fl = fw_get(fw, i);
-          if (!(fl & F_EXISTS)) continue;
-          const bool ar = !(fl & F_LEVR), ag = (fl & F_ASSOC) && !(fl & F_LEVG);
-          if (!(ar || ag)) continue;
-          restore_point(D, ll);
+          if (fw_get(fw, i) & (F_AR | F_AG)) restore_point(D, mp.lbase + 64 * i);
         }
       }
       qmax++;
@@ -947,8 +1042,9 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   Red R;
   R.red = D.chir + 7 * MCAP;        // NRED * 32
   R.tot = R.red + NRED * 32;        // 32 (+ 32 broadcast slots)
-  D.stab = R.tot + 64;              // 8
-  R.tb = D.stab + 8;                // SPREAD: 29 x 512
+  D.stab = R.tot + 64;              // 24
+  R.red2 = D.stab + 24;             // 16
+  R.tb = R.red2 + 16;               // SPREAD: 29 x 512
   R.S = S;
   FlagW fw = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -967,10 +1063,16 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     mp.lbase = mp.base;
   }
   const size_t gbase = (size_t)f * L;
-  double* gnd = pn_all + gbase * 4;  // per-point plane record {n, n.mu} (written once, then read-only)
+  // launch scratch, written once here and read-only afterwards: per-point plane record {n, n.mu} and the observation
+  // in normalised image coordinates
+  double* gnd = pn_all + gbase * 4;
+  double* gobn = pn_all + (size_t)B * L * 4 + gbase * 3;
   const double* gobs = obs_all + gbase * 3;
+  const Uni U{uni(k.bf / k.fx), uni(k.ba_lambda2)};
+  const double ifx = 1.0 / k.fx, ify = 1.0 / k.fy;
   int32_t* gassoc = assoc_all + gbase;
   for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
+  if (tid < 16) R.red2[tid] = 0.0;
   {
     const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
@@ -988,7 +1090,11 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
       for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = pts_io[g * 3 + j];
       if (oc >= 0) {
         fl = F_EXISTS | ((oc & 7) << 8);
-        if (!(gobs[(size_t)l * 3 + 2] < 0)) fl |= F_STEREO;
+        const double ou = gobs[(size_t)l * 3], ov = gobs[(size_t)l * 3 + 1], our = gobs[(size_t)l * 3 + 2];
+        if (!(our < 0)) fl |= F_STEREO;
+        gobn[(size_t)l * 3] = (ou - k.cx) * ifx;
+        gobn[(size_t)l * 3 + 1] = (ov - k.cy) * ify;
+        gobn[(size_t)l * 3 + 2] = (our - k.cx) * ifx;
         if (a >= 0) {
           fl |= F_ASSOC;
           if (gm.flags[a] & 1) {
@@ -1004,11 +1110,19 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
       gassoc[l] = a;
       D.chir[ll] = 0.0;
       fw_or(fw, i, fl);
+      fw_activity(fw, i);
     }
   }
   if (tid == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) D.stab[j] = k.s2inv[j];  // static indices: a lane-indexed kernarg array would go through scratch
+    for (int j = 0; j < 8; ++j) {  // static indices: a lane-indexed kernarg array would go through scratch
+      D.stab[j] = k.s2inv[j] * (k.fx * k.fx);
+      D.stab[8 + j] = k.s2inv[j] * (k.fy * k.fy);
+    }
+    D.stab[16] = k.delta_mono;
+    D.stab[17] = k.delta_mono * k.delta_mono;
+    D.stab[18] = k.delta_stereo;
+    D.stab[19] = k.delta_stereo * k.delta_stereo;
   }
   Pose P = pose_from_se3(se3_load(pose_io + (size_t)f * 7));
   __syncthreads();
@@ -1019,7 +1133,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(k, gm, D, mp, fw, P, L, gobs, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, R, trials, C);
+    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, R, trials, C);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
@@ -1030,13 +1144,14 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
         if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
           const double p[3] = {D.sp[ll], D.sp[MCAP + ll], D.sp[2 * MCAP + ll]};
           const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
-          if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) fw_or(fw, i, F_LEVG);
+          if (gmm_chi2_fast(U.lm, gm, nd, fl, -1, p) > k.str_thresh) fw_or(fw, i, F_LEVG);
         }
       } else {  // STALE chi2 of the reprojection edges, fresh depth test (:799-825)
         if (!(fl & F_EXISTS)) continue;
         const double z = P.R[6] * D.sp[ll] + P.R[7] * D.sp[MCAP + ll] + P.R[8] * D.sp[2 * MCAP + ll] + P.t[2];
         if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) fw_or(fw, i, F_LEVR);
       }
+      fw_activity(fw, i);
     }
     __syncthreads();
   }
@@ -1053,7 +1168,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
       const double p[3] = {D.sp[ll], D.sp[MCAP + ll], D.sp[2 * MCAP + ll]};
       if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
         const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
-        if (gmm_chi2_fast(k, gm, nd, fl, -1, p) > k.str_thresh) dr = 1;
+        if (gmm_chi2_fast(U.lm, gm, nd, fl, -1, p) > k.str_thresh) dr = 1;
       }
       const double z = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];
       if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
@@ -1076,8 +1191,10 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
 #ifdef GL_BA_PROF
-    if (f == 0)
-      for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections  // debug build only: phase cycles instead of pose 0
+    if (f == 0) {  // debug build only: phase cycles instead of pose 0, per-wave markers instead of the points of frame 0
+      for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections
+      for (int i = 0; i < 64 * 8 * 4 && i < L * 3; ++i) pts_io[i] = (double)g_prof_w[i];
+    }
 #endif
   }
 }
