@@ -878,6 +878,23 @@ GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
   sk.put(1, chi);
 }
 
+// Issue priority inside a pass (DENSE, 8-wave frames).  The two waves of a SIMD (w and w + 4) run the same code; the
+// arbiter favours the older one, which then finishes its 4 slots a third of the pass early and leaves the younger
+// one alone on the SIMD at single-wave speed (measured: 11.6 k vs 18.3 k cycles).  Waves 4..7 sit at priority 1; waves
+// 0..3 start a pass at 2 and drop to 0 for their last slot, so that the pair ends the pass together.
+#ifdef GL_BAF_NO_PRIO
+#define GL_BAF_PRIO_PASS_BEGIN()
+#define GL_BAF_PRIO_SLOT(i)
+#else
+#define GL_BAF_PRIO_PASS_BEGIN() \
+  if (NWC == 8 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(2)
+#define GL_BAF_PRIO_SLOT(i) \
+  if (NWC == 8 && (threadIdx.x >> 6) < 4 && (i) == GL_BAF_PRIO_DROP) __builtin_amdgcn_s_setprio(0)
+#endif
+#ifndef GL_BAF_PRIO_DROP
+#define GL_BAF_PRIO_DROP 3
+#endif
+
 // one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
 // point's terms there (zeros when the thread has no active point)
 #define GL_BAF_PASS(BODY)                                                     \
@@ -889,7 +906,9 @@ GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
       if (load_pt(D, mp, fw, gobn, gnd, gassoc, 0, c)) { BODY; }              \
     } else {                                                                  \
       const SinkAcc sk{acc};                                                  \
+      GL_BAF_PRIO_PASS_BEGIN();                                               \
       _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
+        GL_BAF_PRIO_SLOT(i);                                                  \
         PtCtx c;                                                              \
         if (!load_pt(D, mp, fw, gobn, gnd, gassoc, i, c)) continue;           \
         BODY;                                                                 \
@@ -1125,6 +1144,9 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     D.stab[19] = k.delta_stereo * k.delta_stereo;
   }
   Pose P = pose_from_se3(se3_load(pose_io + (size_t)f * 7));
+#ifndef GL_BAF_NO_PRIO
+  if (!kSpread && NWC == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   __syncthreads();
 
   // schedule (:770-828): optimize(5) -> gate degenerate GMM edges -> optimize(5) -> gate reprojection
