@@ -8,6 +8,114 @@
 using namespace gld;
 using namespace glba;
 
+// ---- launch scratch and its producer ------------------------------------------------------------------------------
+// Per point of the launch, in the PERMUTED order of its frame: the plane record {n, n.mu} (32 B), the observation in
+// normalised image coordinates (24 B), the original index (perm), the flag word, the gated association: 68 B.
+namespace {
+struct PrepView {
+  double* gnd;
+  double* gobn;
+  int32_t* perm;
+  int32_t* pfl;
+  int32_t* assoc_p;
+};
+__host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
+  PrepView v;
+  const size_t n = (size_t)B * L;
+  v.gnd = scratch;
+  v.gobn = scratch + n * 4;
+  v.perm = (int32_t*)(scratch + n * 7);
+  v.pfl = v.perm + n;
+  v.assoc_p = v.pfl + n;
+  return v;
+}
+
+// Set-up of a refine launch, one workgroup per frame: the association gate chi2 <= 9 (checkMapAssociation,
+// gmmloc_opt.cpp:230-232), the flag word of every point, its plane record and normalised observation - and the ORDER the
+// refine walks the frame in: a stable partition that puts the points associated with a NON-degenerate component (the
+// volumetric ~5 % of a map, whose EdgePt2Gaussian needs the full 3x3 block R L L^T R^T instead of a rank-1 plane term)
+// behind all the others.  A wave of 64 consecutive points then takes the expensive branch only in the last chunk or two of
+// a frame instead of in 96 % of its slots (one such lane was enough to make the wave issue ~100 extra instructions per
+// point and pass).  The order is a function of the frame's data alone, so the canonical summation order built on it stays
+// independent of the launch shape and of the batch.
+constexpr int PREP_T = 256, PREP_C = 8;  // 8 consecutive points per thread: frames up to 2 048 points
+__global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, int L, const double* __restrict__ obs_all,
+                                                    const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
+                                                    const double* __restrict__ d2_all, double* __restrict__ scratch) {
+  __shared__ int wsum[PREP_T / 64];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= B) return;
+  const size_t gbase = (size_t)f * L;
+  const PrepView pv = prep_view(scratch, B, L);
+  const int c = (L + PREP_T - 1) / PREP_T, l0 = tid * c;
+  int a_[PREP_C], fl_[PREP_C];
+  int nd = 0;  // points of this thread that sit on a non-degenerate component
+#pragma unroll
+  for (int j = 0; j < PREP_C; ++j) {
+    const int l = l0 + j;
+    a_[j] = -1;
+    fl_[j] = 0;
+    if (j < c && l < L) {
+      const size_t g = gbase + l;
+      const int oc = oct_all[g];
+      int a = assoc_all[g];
+      if (d2_all && k.gate_chi2 >= 0 && !(d2_all[g] <= k.gate_chi2)) a = -1;
+      if (oc < 0) a = -1;
+      assoc_all[g] = a;  // the gated association, in the caller's order (the refine writes the final one)
+      int fl = 0;
+      if (oc >= 0) {
+        fl = 1 | ((oc & 7) << 8);                              // F_EXISTS, octave
+        if (!(obs_all[g * 3 + 2] < 0)) fl |= 2;                // F_STEREO
+        if (a >= 0) fl |= 4 | ((gm.flags[a] & 1) ? 8 : 0);     // F_ASSOC, F_DEG
+      }
+      a_[j] = a;
+      fl_[j] = fl;
+      nd += (fl & 12) == 4;  // associated and not degenerate
+    }
+  }
+  // exclusive scan of nd over the threads (= over the points in index order: each thread owns a contiguous run)
+  int inc = nd;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if ((tid & 63) >= o) inc += v;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  int before = inc - nd, total = 0;
+#pragma unroll
+  for (int w = 0; w < PREP_T / 64; ++w) {
+    if (w < (tid >> 6)) before += wsum[w];
+    total += wsum[w];
+  }
+  const int n_others = L - total;
+  const double ifx = 1.0 / k.fx, ify = 1.0 / k.fy;
+#pragma unroll
+  for (int j = 0; j < PREP_C; ++j) {
+    const int l = l0 + j;
+    if (!(j < c && l < L)) continue;
+    const bool isnd = (fl_[j] & 12) == 4;
+    const int lp = isnd ? n_others + before : l - before;  // stable on both sides
+    before += isnd;
+    const size_t g = gbase + l, gp = gbase + lp;
+    pv.perm[gp] = l;
+    pv.pfl[gp] = fl_[j];
+    pv.assoc_p[gp] = a_[j];
+    pv.gobn[gp * 3] = (obs_all[g * 3] - k.cx) * ifx;
+    pv.gobn[gp * 3 + 1] = (obs_all[g * 3 + 1] - k.cy) * ify;
+    pv.gobn[gp * 3 + 2] = (obs_all[g * 3 + 2] - k.cx) * ifx;
+    if ((fl_[j] & 12) == 12) {  // degenerate component: plane normal (axis_.col(0)) and n . mean
+      const int a = a_[j];
+      const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
+      pv.gnd[gp * 4] = nx;
+      pv.gnd[gp * 4 + 1] = ny;
+      pv.gnd[gp * 4 + 2] = nz;
+      pv.gnd[gp * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
+    }
+  }
+}
+}  // namespace
+
 // (namespace, LDS capacity in points, waves at most, SPREAD, fp32-cached step)
 #define GL_BAF_NS bafd496   // DENSE, exact step: 4 frames per CU
 #define GL_BAF_MCAP 496
@@ -93,8 +201,8 @@ static void canon_order(int L, int* G, int* S) {
   *S = (nch + *G - 1) / *G;
 }
 
-typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, const double*, const int32_t*, int32_t*, const double*,
-                          uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int, unsigned long long*);
+typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
+                          unsigned long long*);
 
 struct BafArgs {
   BaK k;
@@ -122,11 +230,8 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;
-  {
-    TimerScope ts(c, GL_TIMER_BA);
-    kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.obs, a.oct, a.assoc, a.d2, a.dropped, a.erase,
-                                            a.iters, a.pn, a.stats, a.NB, a.parts);
-  }
+  kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
+                                          a.NB, a.parts);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -141,17 +246,15 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = (a.G + 1) / 2;
   // the exchange words of the frames sit behind the plane records
-  a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 56 + 63) / 64) * 64);
-  TimerScope ts(c, GL_TIMER_BA);
+  a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 68 + 63) / 64) * 64);
   if (a.NB == 1) {
-    kern<<<a.B, 512, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.obs, a.oct, a.assoc, a.d2, a.dropped, a.erase, a.iters,
-                                       a.pn, a.stats, a.NB, a.parts);
+    kern<<<a.B, 512, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
+                                       a.parts);
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
   GL_HIP(hipMemsetAsync(a.parts, 0, (size_t)a.B * 2 * a.NB * 64 * sizeof(unsigned long long), c->stream));
-  void* args[] = {&a.k, &a.gm, &a.B, &a.L, &a.G, &a.S, &a.pose, &a.pts, &a.obs, &a.oct, &a.assoc, &a.d2, &a.dropped, &a.erase, &a.iters, &a.pn,
-                  &a.stats, &a.NB, &a.parts};
+  void* args[] = {&a.k, &a.gm, &a.B, &a.L, &a.G, &a.S, &a.pose, &a.pts, &a.assoc, &a.dropped, &a.erase, &a.iters, &a.pn, &a.stats, &a.NB, &a.parts};
   if (hipLaunchCooperativeKernel((const void*)kern, dim3(a.B * a.NB), dim3(512), args, lds, c->stream) != hipSuccess) {
     (void)hipGetLastError();  // not co-resident on this device
     return 1;
@@ -182,6 +285,10 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   a.iters = iters;
   a.pn = (double*)scratch;
   a.stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
+  TimerScope ts(c, GL_TIMER_BA);  // one timed region per call: set-up + refine
+  // set-up: gate, flags, plane records, normalised observations, and the order the refine walks each frame in
+  k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch);
+  GL_HIP(hipGetLastError());
   const int NB = (a.G + 1) / 2;
   bool spread = (long)B * NB <= c->ncu;
   if (c->opt.ba_shape == 0) spread = false;

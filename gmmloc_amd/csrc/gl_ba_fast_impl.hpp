@@ -69,6 +69,7 @@ __device__ unsigned long long g_prof_w[64 * 8 * 4];  // [trial < 64][wave][marke
 
 // F_AR / F_AG: the point's reprojection / GMM edge is ACTIVE (exists, level 0) - derived bits, refreshed whenever the
 // levels change (fw_activity), so that a pass tests one mask instead of re-deriving them per point and trial
+// (the values of the first four and the octave at bits 8..10 are what k_ba1_prep writes: gl_ba_fast.hip)
 enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32, F_AR = 64, F_AG = 128 };
 
 // a + b that is never contracted with a multiplication feeding it: every term of a canonical sum is rounded on
@@ -222,10 +223,9 @@ struct Uni {
 // quadratic form as s |obs - K pi(q)|^2 of EdgeStereoSE3ProjectXYZ / factors.cpp:66-168.
 GL_DEV double reproj_n(const double* q, const double* ob, bool stereo, double bn, double sx, double sy, double* e, double& iz) {
   iz = rcp_nr(q[2]);
-  const double xz = q[0] * iz, yz = q[1] * iz;
-  e[0] = ob[0] - xz;
-  e[1] = ob[1] - yz;
-  e[2] = stereo ? (ob[2] - fma(-bn, iz, xz)) : 0.0;
+  e[0] = fma(-q[0], iz, ob[0]);
+  e[1] = fma(-q[1], iz, ob[1]);
+  e[2] = stereo ? fma(bn - q[0], iz, ob[2]) : 0.0;  // u_right - (x - b) / z
   return fma(sy * e[1], e[1], sx * fma(e[2], e[2], e[0] * e[0]));
 }
 // rows of the projection Jacobian in normalised coordinates: (iz, 0, c0), (0, iz, c1) and, stereo only, (iz, 0, c2)
@@ -293,7 +293,7 @@ GL_DEV void huber_pt(const Lds& D, bool stereo, double chi, double& rho0, double
 GL_DEV double lin_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, Lin& o) {
   const double* p = c.p;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) o.q[k] = P.R[k * 3] * p[0] + P.R[k * 3 + 1] * p[1] + P.R[k * 3 + 2] * p[2] + P.t[k];
+  for (int k = 0; k < 3; ++k) o.q[k] = fma(P.R[k * 3], p[0], fma(P.R[k * 3 + 1], p[1], fma(P.R[k * 3 + 2], p[2], P.t[k])));
 #pragma unroll
   for (int k = 0; k < 6; ++k) o.A[k] = 0.0;
 #pragma unroll
@@ -441,15 +441,26 @@ GL_DEV void pose_terms(const double* q, const double* C, const double* c, bool w
   }
 }
 
-// C = A - (A Dinv) A (symmetric sym6), AD = A Dinv (3x3)
-GL_DEV void schur_C(const double* A, const double* AD, double* C) {
-  const double Af[9] = {A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5]};
-  const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+// The reprojection block A = sum_r w_r j_r^T j_r has A(0,1) = 0 by construction (no row of Jpi touches x and y):
+// written out, the products below skip the multiplications by that zero (IEEE arithmetic may not drop them itself).
+// AD = A Dinv (3x3), A = {A0, 0, A2, A3, A4, A5} sym6, Dinv sym6
+GL_DEV void ad_product(const double* A, const double* Di, double* AD) {
+  const double y[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
 #pragma unroll
-  for (int e = 0; e < 6; ++e) {
-    const int i = ij[e][0], j = ij[e][1];
-    C[e] = fma(-AD[i * 3], Af[j], fma(-AD[i * 3 + 1], Af[3 + j], fma(-AD[i * 3 + 2], Af[6 + j], A[e])));
+  for (int j = 0; j < 3; ++j) {
+    AD[j] = fma(A[0], y[j], A[2] * y[6 + j]);
+    AD[3 + j] = fma(A[3], y[3 + j], A[4] * y[6 + j]);
+    AD[6 + j] = fma(A[2], y[j], fma(A[4], y[3 + j], A[5] * y[6 + j]));
   }
+}
+// C = A - (A Dinv) A (symmetric sym6)
+GL_DEV void schur_C(const double* A, const double* AD, double* C) {
+  C[0] = fma(-AD[0], A[0], fma(-AD[2], A[2], A[0]));
+  C[1] = fma(-AD[1], A[3], -AD[2] * A[4]);
+  C[2] = fma(-AD[0], A[2], fma(-AD[1], A[4], fma(-AD[2], A[5], A[2])));
+  C[3] = fma(-AD[4], A[3], fma(-AD[5], A[4], A[3]));
+  C[4] = fma(-AD[3], A[2], fma(-AD[4], A[4], fma(-AD[5], A[5], A[4])));
+  C[5] = fma(-AD[6], A[2], fma(-AD[7], A[4], fma(-AD[8], A[5], A[5])));
 }
 
 // ---- reductions in the canonical order ---------------------------------------------------------------------
@@ -781,15 +792,15 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
   if (c.ar) {
     if (!kStep32) D.chir[c.ll] = o.rho1;
     double C[6], cc[3], AD[9];
-    sym3_mul(o.A, Dinv, AD);
+    ad_product(o.A, Dinv, AD);
     if (kStep32) {
       int* un = (int*)D.un;
 #pragma unroll
       for (int j = 0; j < 9; ++j) un[(3 + j) * MCAP + c.ll] = __float_as_int((float)AD[j]);
     }
     schur_C(o.A, AD, C);
-    cc[0] = fma(-o.A[0], u[0], fma(-o.A[1], u[1], fma(-o.A[2], u[2], o.a[0])));
-    cc[1] = fma(-o.A[1], u[0], fma(-o.A[3], u[1], fma(-o.A[4], u[2], o.a[1])));
+    cc[0] = fma(-o.A[0], u[0], fma(-o.A[2], u[2], o.a[0]));
+    cc[1] = fma(-o.A[3], u[1], fma(-o.A[4], u[2], o.a[1]));
     cc[2] = fma(-o.A[2], u[0], fma(-o.A[4], u[1], fma(-o.A[5], u[2], o.a[2])));
     pose_terms(o.q, C, cc, true, sk);
   } else if (kStep32) {
@@ -806,7 +817,7 @@ GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
   // eps = D^-1 (b - A gd),  gd = omega x q + upsilon
   double q[3], gd[3], eps[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) q[j] = P.R[j * 3] * c.p[0] + P.R[j * 3 + 1] * c.p[1] + P.R[j * 3 + 2] * c.p[2] + P.t[j];
+  for (int j = 0; j < 3; ++j) q[j] = fma(P.R[j * 3], c.p[0], fma(P.R[j * 3 + 1], c.p[1], fma(P.R[j * 3 + 2], c.p[2], P.t[j])));
   cross(dx, q, gd);
   gd[0] += dx[3];
   gd[1] += dx[4];
@@ -826,13 +837,12 @@ GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
     if (c.ar) {
       const double rho1 = D.chir[c.ll];  // the edge's Huber weight, left there by pass A
       const double iz = rcp_nr(q[2]);
-      const double xz = q[0] * iz, yz = q[1] * iz;
       const Jpi J = jpi_n(q, iz, U.bn);
       const double wx = rho1 * c.sx, wy = rho1 * c.sy;
-      // f_r = w_r (e_r - j_r . gd)
-      const double f0 = wx * ((c.ob[0] - xz) - fma(iz, gd[0], J.c0 * gd[2]));
-      const double f1 = wy * ((c.ob[1] - yz) - fma(iz, gd[1], J.c1 * gd[2]));
-      const double f2 = stereo ? wx * ((c.ob[2] - fma(-U.bn, iz, xz)) - fma(iz, gd[0], J.c2 * gd[2])) : 0.0;
+      // f_r = w_r (e_r - j_r . gd),  e_r - j_r . gd = obs_r - iz (q_r + gd_r) - c_r gd_z
+      const double f0 = wx * fma(-J.c0, gd[2], fma(-(q[0] + gd[0]), iz, c.ob[0]));
+      const double f1 = wy * fma(-J.c1, gd[2], fma(-(q[1] + gd[1]), iz, c.ob[1]));
+      const double f2 = stereo ? wx * fma(-J.c2, gd[2], fma(U.bn - (q[0] + gd[0]), iz, c.ob[2])) : 0.0;
       rhs[0] = iz * (f0 + f2);
       rhs[1] = iz * f1;
       rhs[2] = fma(J.c2, f2, fma(J.c1, f1, J.c0 * f0));
@@ -867,7 +877,7 @@ GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
   if (c.ar) {
     double qn[3], e[3], iz;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) qn[j] = Pn.R[j * 3] * pn[0] + Pn.R[j * 3 + 1] * pn[1] + Pn.R[j * 3 + 2] * pn[2] + Pn.t[j];
+    for (int j = 0; j < 3; ++j) qn[j] = fma(Pn.R[j * 3], pn[0], fma(Pn.R[j * 3 + 1], pn[1], fma(Pn.R[j * 3 + 2], pn[2], Pn.t[j])));
     const double c2 = reproj_n(qn, c.ob, stereo, U.bn, c.sx, c.sy, e, iz);
     D.chir[c.ll] = c2;
     double r0 = c2, r1;
@@ -1045,14 +1055,14 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
 }
 
 // DENSE: <<<B, 64 G>>>, one workgroup per frame.  SPREAD: <<<B NB, 512>>>, NB = ceil(G / 2) workgroups per frame
-// (cooperative launch when NB > 1).  G, S: the canonical order of stride L (launcher: canon_order()).
+// (cooperative launch when NB > 1).  G, S: the canonical order of stride L (launcher: canon_order()).  The frame's points
+// are addressed through the permutation k_ba1_prep made (points associated with a NON-degenerate component last), so
+// "point l" below is the l-th point of that order; pts_io / assoc_all are read and written through perm.
 __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int L, int G, int S, double* __restrict__ pose_io,
-                                                  double* __restrict__ pts_io, const double* __restrict__ obs_all,
-                                                  const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
-                                                  const double* __restrict__ d2_all, uint8_t* __restrict__ dropped_all,
-                                                  uint8_t* __restrict__ erase_all, int32_t* __restrict__ iters_out,
-                                                  double* __restrict__ pn_all, int32_t* __restrict__ trials_out, int NB,
-                                                  unsigned long long* parts) {
+                                                  double* __restrict__ pts_io, int32_t* __restrict__ assoc_all,
+                                                  uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
+                                                  int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
+                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1082,14 +1092,14 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     mp.lbase = mp.base;
   }
   const size_t gbase = (size_t)f * L;
-  // launch scratch, written once here and read-only afterwards: per-point plane record {n, n.mu} and the observation
-  // in normalised image coordinates
-  double* gnd = pn_all + gbase * 4;
-  double* gobn = pn_all + (size_t)B * L * 4 + gbase * 3;
-  const double* gobs = obs_all + gbase * 3;
+  // launch scratch written by k_ba1_prep, read-only here: plane records, normalised observations, permutation, flags,
+  // gated associations (all but perm in the permuted order)
+  const PrepView pv = prep_view(pn_all, B, L);
+  const double* gnd = pv.gnd + gbase * 4;
+  const double* gobn = pv.gobn + gbase * 3;
+  const int32_t* gperm = pv.perm + gbase;
+  const int32_t* gassoc = pv.assoc_p + gbase;
   const Uni U{uni(k.bf / k.fx), uni(k.ba_lambda2)};
-  const double ifx = 1.0 / k.fx, ify = 1.0 / k.fy;
-  int32_t* gassoc = assoc_all + gbase;
   for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
   if (tid < 16) R.red2[tid] = 0.0;
   {
@@ -1098,37 +1108,11 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     for (int i = 0; i < ns; ++i) {
       const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
       if (l >= L) break;
-      const size_t g = gbase + l;
-      const int oc = oct_all[g];
-      int a = assoc_all[g];
-      // association gate chi2 <= 9 (checkMapAssociation, gmmloc_opt.cpp:230-232)
-      if (d2_all && k.gate_chi2 >= 0 && !(d2_all[g] <= k.gate_chi2)) a = -1;
-      if (oc < 0) a = -1;
-      int fl = 0;
+      const size_t g = gbase + gperm[l];
 #pragma unroll
       for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = pts_io[g * 3 + j];
-      if (oc >= 0) {
-        fl = F_EXISTS | ((oc & 7) << 8);
-        const double ou = gobs[(size_t)l * 3], ov = gobs[(size_t)l * 3 + 1], our = gobs[(size_t)l * 3 + 2];
-        if (!(our < 0)) fl |= F_STEREO;
-        gobn[(size_t)l * 3] = (ou - k.cx) * ifx;
-        gobn[(size_t)l * 3 + 1] = (ov - k.cy) * ify;
-        gobn[(size_t)l * 3 + 2] = (our - k.cx) * ifx;
-        if (a >= 0) {
-          fl |= F_ASSOC;
-          if (gm.flags[a] & 1) {
-            fl |= F_DEG;
-            const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
-            gnd[(size_t)l * 4] = nx;
-            gnd[(size_t)l * 4 + 1] = ny;
-            gnd[(size_t)l * 4 + 2] = nz;
-            gnd[(size_t)l * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
-          }
-        }
-      }
-      gassoc[l] = a;
       D.chir[ll] = 0.0;
-      fw_or(fw, i, fl);
+      fw_or(fw, i, pv.pfl[gbase + l]);
       fw_activity(fw, i);
     }
   }
@@ -1182,7 +1166,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
     const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
     if (l >= L) break;
-    const size_t g = gbase + l;
+    const size_t g = gbase + gperm[l];  // back to the caller's order
     const int fl = fw_get(fw, i);
     uint8_t dr = 0, er = 0;
     int a = gassoc[l];
@@ -1200,7 +1184,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     if (dropped_all) dropped_all[g] = dr;
     if (erase_all) erase_all[g] = er;
     if (!dropped_all && dr) a = -1;
-    gassoc[l] = a;
+    assoc_all[g] = a;
   }
   if (tid == 0 && C.pb == 0) {
     SE3 T;
