@@ -6,8 +6,10 @@
 // in the call, so the order in which the per-point terms of every sum are added is a function of the frame's
 // stride L alone (the "canonical order"):
 //     chunks   c = l / 64 (64 consecutive points), nch = ceil(L / 64)
-//     groups   G = ceil(nch / 4) groups of S = ceil(nch / G) <= 4 consecutive chunks
-//     level 1  lane j of group g adds the terms of its points (g S + i) 64 + j, i = 0 .. S-1, in that order
+//     groups   G = ceil(nch / 4) groups; group g = the chunks g, g + G, g + 2 G, ... (S = ceil(nch / G) <= 4 of them):
+//              neighbouring chunks sit in different groups, so a run of expensive points (see k_ba1_prep) spreads
+//              over the waves instead of landing on one
+//     level 1  lane j of group g adds the terms of its points (g + G i) 64 + j, i = 0 .. S-1, in that order
 //     level 2  the 64 lane sums of a group meet in the butterfly tree of gld::wave_reduce_scatter32
 //              (partners 32, 16, 1, 2, 4, 8 lanes apart)
 //     level 3  blocks of two groups, B_k = g_2k + g_2k+1, then ((B_0 + B_1) + B_2) + B_3.
@@ -197,9 +199,10 @@ GL_DEV void fw_activity(FlagW& fw, int i) {
 
 // the canonical order of a frame of stride L and this thread's place in it
 struct Map {
-  int S;      // point slots of this thread (DENSE: chunks per group; SPREAD: 1)
-  int base;   // frame-local index of the thread's first point; slot i is base + 64 i
+  int S;      // point slots of this thread (DENSE: chunks of its group; SPREAD: 1)
+  int base;   // frame-local index of the thread's first point; slot i is base + step i
   int lbase;  // LDS index of the first point (DENSE: = base; SPREAD: threadIdx.x)
+  int step;   // 64 G: the chunks of a group are G apart
 };
 
 struct Lin {
@@ -731,8 +734,8 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
                     const int32_t* __restrict__ gassoc, int i, PtCtx& c) {
   c.fl = fw_get(fw, i);
   if (!(c.fl & (F_AR | F_AG))) return false;
-  c.l = mp.base + 64 * i;
-  c.ll = mp.lbase + 64 * i;
+  c.l = mp.base + mp.step * i;
+  c.ll = mp.lbase + mp.step * i;
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.ob[j] = gobn[(size_t)c.l * 3 + j];
 #pragma unroll
@@ -1040,7 +1043,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
         for (int i = 0; i < ns; ++i) {  // discardTop: restore the backed-up points
-          if (fw_get(fw, i) & (F_AR | F_AG)) restore_point(D, mp.lbase + 64 * i);
+          if (fw_get(fw, i) & (F_AR | F_AG)) restore_point(D, mp.lbase + mp.step * i);
         }
       }
       qmax++;
@@ -1084,12 +1087,15 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   if (kSpread) {  // block pb = groups 2 pb, 2 pb + 1; wave = (group of the block) * S + slot; idle waves beyond 2 S
     const int gi = wave / S, slot = wave - gi * S;
     mp.S = 1;
-    mp.base = gi < 2 ? ((2 * C.pb + gi) * S + slot) * 64 + lane : L;
+    const int g = 2 * C.pb + gi;
+    mp.base = gi < 2 && g < G ? (g + G * slot) * 64 + lane : L;  // chunk g + G i of group g (the last block may hold one)
     mp.lbase = tid;
+    mp.step = 0;
   } else {
     mp.S = S;
-    mp.base = wave * S * 64 + lane;
+    mp.base = wave * 64 + lane;  // group = wave: chunks wave, wave + G, ...
     mp.lbase = mp.base;
+    mp.step = 64 * G;
   }
   const size_t gbase = (size_t)f * L;
   // launch scratch written by k_ba1_prep, read-only here: plane records, normalised observations, permutation, flags,
@@ -1106,7 +1112,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
-      const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
+      const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
       if (l >= L) break;
       const size_t g = gbase + gperm[l];
 #pragma unroll
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
-      const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
+      const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
       if (l >= L) break;
       const int fl = fw_get(fw, i);
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
@@ -1164,7 +1170,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
 
 #pragma unroll 1
   for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
-    const int l = mp.base + 64 * i, ll = mp.lbase + 64 * i;
+    const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
     if (l >= L) break;
     const size_t g = gbase + gperm[l];  // back to the caller's order
     const int fl = fw_get(fw, i);
