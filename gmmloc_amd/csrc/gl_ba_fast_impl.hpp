@@ -155,15 +155,30 @@ GL_DEV Pose pose_update(const Pose& P, const double* u) {
     b = (1 - ct) * it * it;
     c = (theta - st) * it * it * it;
   }
-  double Om[9], Om2[9], dR[9], V[9];
-  skew(u, Om);
-  mm3(Om, Om, Om2);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const double I = (i % 4 == 0) ? 1.0 : 0.0;
-    dR[i] = I + a * Om[i] + b * Om2[i];
-    V[i] = I + b * Om[i] + c * Om2[i];
-  }
+  // dR = I + a [w]x + b [w]x^2,  V = I + b [w]x + c [w]x^2  with  [w]x^2 = w w^T - |w|^2 I  written out (the generic
+  // 3x3 products would multiply by the zeros of the skew matrix: ~50 instructions on the serial path of every trial)
+  const double w0 = u[0], w1 = u[1], w2 = u[2];
+  const double s00 = w0 * w0 - th2, s11 = w1 * w1 - th2, s22 = w2 * w2 - th2;
+  const double s01 = w0 * w1, s02 = w0 * w2, s12 = w1 * w2;
+  double dR[9], V[9];
+  dR[0] = fma(b, s00, 1.0);
+  dR[4] = fma(b, s11, 1.0);
+  dR[8] = fma(b, s22, 1.0);
+  dR[1] = fma(b, s01, -a * w2);
+  dR[3] = fma(b, s01, a * w2);
+  dR[2] = fma(b, s02, a * w1);
+  dR[6] = fma(b, s02, -a * w1);
+  dR[5] = fma(b, s12, -a * w0);
+  dR[7] = fma(b, s12, a * w0);
+  V[0] = fma(c, s00, 1.0);
+  V[4] = fma(c, s11, 1.0);
+  V[8] = fma(c, s22, 1.0);
+  V[1] = fma(c, s01, -b * w2);
+  V[3] = fma(c, s01, b * w2);
+  V[2] = fma(c, s02, b * w1);
+  V[6] = fma(c, s02, -b * w1);
+  V[5] = fma(c, s12, -b * w0);
+  V[7] = fma(c, s12, b * w0);
   Pose N;
   mm3(dR, P.R, N.R);
 #pragma unroll
