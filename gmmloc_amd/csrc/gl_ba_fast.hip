@@ -38,24 +38,24 @@ __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
 // a frame instead of in 96 % of its slots (one such lane was enough to make the wave issue ~100 extra instructions per
 // point and pass).  The order is a function of the frame's data alone, so the canonical summation order built on it stays
 // independent of the launch shape and of the batch.
-constexpr int PREP_T = 256, PREP_C = 8;  // 8 consecutive points per thread: frames up to 2 048 points
+constexpr int PREP_T = 256, PREP_C = 8;  // rounds of 256 consecutive points: frames up to 2 048 points
 __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, int L, const double* __restrict__ obs_all,
                                                     const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
                                                     const double* __restrict__ d2_all, double* __restrict__ scratch) {
-  __shared__ int wsum[PREP_T / 64];
-  const int f = blockIdx.x, tid = threadIdx.x;
+  __shared__ int cnt[PREP_C][PREP_T / 64];  // non-degenerate-component points per (round, wave)
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (f >= B) return;
   const size_t gbase = (size_t)f * L;
   const PrepView pv = prep_view(scratch, B, L);
-  const int c = (L + PREP_T - 1) / PREP_T, l0 = tid * c;
+  const int rounds = (L + PREP_T - 1) / PREP_T;
+  // round j, thread t: point j 256 + t (coalesced); index order = (round, wave, lane)
   int a_[PREP_C], fl_[PREP_C];
-  int nd = 0;  // points of this thread that sit on a non-degenerate component
 #pragma unroll
   for (int j = 0; j < PREP_C; ++j) {
-    const int l = l0 + j;
+    const int l = j * PREP_T + tid;
     a_[j] = -1;
     fl_[j] = 0;
-    if (j < c && l < L) {
+    if (j < rounds && l < L) {
       const size_t g = gbase + l;
       const int oc = oct_all[g];
       int a = assoc_all[g];
@@ -70,48 +70,49 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
       }
       a_[j] = a;
       fl_[j] = fl;
-      nd += (fl & 12) == 4;  // associated and not degenerate
     }
+    const unsigned long long bal = __ballot((fl_[j] & 12) == 4);  // associated and not degenerate
+    if (lane == 0) cnt[j][wave] = __popcll(bal);
   }
-  // exclusive scan of nd over the threads (= over the points in index order: each thread owns a contiguous run)
-  int inc = nd;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(inc, o, 64);
-    if ((tid & 63) >= o) inc += v;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
   __syncthreads();
-  int before = inc - nd, total = 0;
+  int total = 0;
 #pragma unroll
-  for (int w = 0; w < PREP_T / 64; ++w) {
-    if (w < (tid >> 6)) before += wsum[w];
-    total += wsum[w];
-  }
+  for (int j = 0; j < PREP_C; ++j)
+#pragma unroll
+    for (int w = 0; w < PREP_T / 64; ++w) total += cnt[j][w];
   const int n_others = L - total;
   const double ifx = 1.0 / k.fx, ify = 1.0 / k.fy;
+  int base = 0;  // non-degenerate-component points before this (round, wave)
 #pragma unroll
   for (int j = 0; j < PREP_C; ++j) {
-    const int l = l0 + j;
-    if (!(j < c && l < L)) continue;
+#pragma unroll
+    for (int w = 0; w < PREP_T / 64; ++w)
+      if (w < wave) base += cnt[j][w];
+    const int l = j * PREP_T + tid;
     const bool isnd = (fl_[j] & 12) == 4;
-    const int lp = isnd ? n_others + before : l - before;  // stable on both sides
-    before += isnd;
-    const size_t g = gbase + l, gp = gbase + lp;
-    pv.perm[gp] = l;
-    pv.pfl[gp] = fl_[j];
-    pv.assoc_p[gp] = a_[j];
-    pv.gobn[gp * 3] = (obs_all[g * 3] - k.cx) * ifx;
-    pv.gobn[gp * 3 + 1] = (obs_all[g * 3 + 1] - k.cy) * ify;
-    pv.gobn[gp * 3 + 2] = (obs_all[g * 3 + 2] - k.cx) * ifx;
-    if ((fl_[j] & 12) == 12) {  // degenerate component: plane normal (axis_.col(0)) and n . mean
-      const int a = a_[j];
-      const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
-      pv.gnd[gp * 4] = nx;
-      pv.gnd[gp * 4 + 1] = ny;
-      pv.gnd[gp * 4 + 2] = nz;
-      pv.gnd[gp * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
+    const unsigned long long bal = __ballot(isnd);
+    const int before = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (j < rounds && l < L) {
+      const int lp = isnd ? n_others + before : l - before;  // stable on both sides
+      const size_t g = gbase + l, gp = gbase + lp;
+      pv.perm[gp] = l;
+      pv.pfl[gp] = fl_[j];
+      pv.assoc_p[gp] = a_[j];
+      pv.gobn[gp * 3] = (obs_all[g * 3] - k.cx) * ifx;
+      pv.gobn[gp * 3 + 1] = (obs_all[g * 3 + 1] - k.cy) * ify;
+      pv.gobn[gp * 3 + 2] = (obs_all[g * 3 + 2] - k.cx) * ifx;
+      if ((fl_[j] & 12) == 12) {  // degenerate component: plane normal (axis_.col(0)) and n . mean
+        const int a = a_[j];
+        const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
+        pv.gnd[gp * 4] = nx;
+        pv.gnd[gp * 4 + 1] = ny;
+        pv.gnd[gp * 4 + 2] = nz;
+        pv.gnd[gp * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
+      }
     }
+#pragma unroll
+    for (int w = 0; w < PREP_T / 64; ++w)
+      if (w >= wave) base += cnt[j][w];  // the rest of this round: base now counts every point before round j + 1
   }
 }
 }  // namespace
@@ -285,10 +286,12 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   a.iters = iters;
   a.pn = (double*)scratch;
   a.stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
-  TimerScope ts(c, GL_TIMER_BA);  // one timed region per call: set-up + refine
-  // set-up: gate, flags, plane records, normalised observations, and the order the refine walks each frame in
-  k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch);
+  {  // set-up: gate, flags, plane records, normalised observations, and the order the refine walks each frame in
+    TimerScope ts(c, GL_TIMER_BA_PREP);
+    k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch);
+  }
   GL_HIP(hipGetLastError());
+  TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper
   const int NB = (a.G + 1) / 2;
   bool spread = (long)B * NB <= c->ncu;
   if (c->opt.ba_shape == 0) spread = false;
