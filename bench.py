@@ -257,6 +257,7 @@ def main():
         ctx.timing(True)
         ctx.timing_read(api.TIMER_ASSOC, reset=True)
         ctx.timing_read(api.TIMER_BA, reset=True)
+        ctx.timing_read(api.TIMER_BA_PREP, reset=True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -265,6 +266,7 @@ def main():
         dt = time.perf_counter() - t0
     assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
+    prep_ms, prep_n = ctx.timing_read(api.TIMER_BA_PREP)
     ctx.timing(False)
 
     # the same step with the association forced to the plain N x K sweep (option assoc_grid = 0): same results
@@ -396,7 +398,8 @@ def main():
                 "hbm": {"achieved_GBs": alg_bytes / sweep_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
-            "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine": ba_ms / max(args.steps, 1)},
+            "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine_setup": prep_ms / max(args.steps, 1),
+                                   "refine": ba_ms / max(args.steps, 1)},
         }
         out["step_with_exhaustive_sweep"] = {
             "value": B * world / dt_sweep, "unit": "frames/s", "ms_per_step": 1e3 * dt_sweep, "steps": sweep_steps,

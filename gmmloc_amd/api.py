@@ -18,7 +18,7 @@ ASSOC_KNN5_EUCLID = 1
 ASSOC_EXHAUSTIVE = 2
 
 F_MEAN, F_COV, F_COV_INV, F_DET, F_SCALE, F_AXIS, F_SQRT_INFO, F_FLAGS, F_NBS_PTR, F_NBS_IDX, F_NBS_DIST = range(11)
-TIMER_ASSOC, TIMER_REFINE_POSE, TIMER_BA = 0, 1, 2
+TIMER_ASSOC, TIMER_REFINE_POSE, TIMER_BA, TIMER_BA_PREP = 0, 1, 2, 3
 
 
 class GLError(RuntimeError):

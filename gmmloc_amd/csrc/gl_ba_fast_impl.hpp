@@ -827,11 +827,11 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
     for (int j = 0; j < 9; ++j) un[(3 + j) * MCAP + c.ll] = 0;
   }
 }
-// pass B: point step, trial point (in place, old point backed up in the slot), chi2 at the trial state.
-// terms: 0 = |eps|^2, 1 = robust chi2 of the point's edges at the trial state
+// pass B, first half: point step and trial point (in place, old point backed up in the slot) - needs the pose STEP dx
+// only.  term 0 = |eps|^2
 template <class Sink>
-GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const Pose& Pn, const double* dx, const PtCtx& c,
-                      bool robust, const Sink& sk) {
+GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const double* dx, const PtCtx& c, double* pn,
+                           const Sink& sk) {
   // eps = D^-1 (b - A gd),  gd = omega x q + upsilon
   double q[3], gd[3], eps[3];
 #pragma unroll
@@ -885,12 +885,17 @@ GL_DEV void pt_pass_b(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
     sym3_mul_vec(Dinv, rhs, eps);
   }
   sk.put(0, eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2]);
-  double pn[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) pn[j] = c.p[j] + (P.R[j] * eps[0] + P.R[3 + j] * eps[1] + P.R[6 + j] * eps[2]);
 #pragma unroll
   for (int j = 0; j < 3; ++j) D.sp[j * MCAP + c.ll] = pn[j];  // the trial point goes in place,
   backup_point(D, c.ll, c.p);                                  // the old point into the slot
+}
+// pass B, second half: chi2 at the trial state (trial pose Pn, trial point pn).  term 1 = robust chi2 of the point's edges
+template <class Sink>
+GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& Pn, const PtCtx& c, const double* pn, bool robust,
+                           const Sink& sk) {
+  const bool stereo = c.fl & F_STEREO;
   double chi = 0.0;
   if (c.ar) {
     double qn[3], e[3], iz;
@@ -991,21 +996,18 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       else reduce29_w0_dense(acc, R);
       PROF_W(trials, 1);
       PROF_T(tA2);
-      // 6x6 solve + exp(dx) by wave 0 only; step, trial pose and status are broadcast through LDS
+      // 6x6 solve by wave 0; the step and the status are broadcast through LDS behind a barrier.  The trial pose
+      // exp(dx) P is computed by wave 0 AFTER that barrier, while the other waves are already in pass B (its first use
+      // is the evaluation of their first point, ~200 instructions in), and handed over through LDS + a sequence word.
       double* bc = R.tot + 32;  // 27 doubles: dx[6] R[9] t[3] ok g[6] sum u.b chi2
+      volatile int* pnflag = (volatile int*)(R.tot + 60);
       if (threadIdx.x < 64) {
         double dxs[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
         if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
-        Pose Pw = P;
-        if (pose_active && ok) Pw = pose_update(P, dxs);
         if (threadIdx.x == 0) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) bc[i] = dxs[i];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) bc[6 + i] = Pw.R[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) bc[15 + i] = Pw.t[i];
           bc[18] = ok ? 1.0 : 0.0;
 #pragma unroll
           for (int i = 0; i < 6; ++i) bc[19 + i] = acc[21 + i];  // reduced rhs g and sum u.b, for computeScale
@@ -1018,16 +1020,44 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       double dx[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) dx[i] = uni(bc[i]);
-      Pose Pn;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Pn.R[i] = uni(bc[6 + i]);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Pn.t[i] = uni(bc[15 + i]);
       const bool ok2 = uni(bc[18]) != 0.0;
+      const int seq = trials + 1;
+      Pose Pn = P;
+      bool have_pn = false;
+      if (threadIdx.x < 64) {
+        Pose Pw = P;
+        if (pose_active && ok2) Pw = pose_update(P, dx);
+        if (threadIdx.x == 0) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) bc[6 + i] = Pw.R[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bc[15 + i] = Pw.t[i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          *pnflag = seq;
+        }
+        Pn = pose_uni(Pw);
+        have_pn = true;
+      }
       PROF_T(tS);
       PROF_W(trials, 2);
       // ---- pass B ---------------------------------------------------------------------------
-      GL_BAF_PASS(pt_pass_b(U, gm, D, P, Pn, dx, c, robust, sk));
+      // the trial pose arrives while the step half of the first point is under way (wave 0 has it already)
+#define GL_BAF_GET_PN()                                                                          \
+  if (!have_pn) {                                                                                \
+    while (*pnflag != seq) __builtin_amdgcn_s_sleep(1);                                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) Pn.R[i_] = uni(bc[6 + i_]);                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) Pn.t[i_] = uni(bc[15 + i_]);                \
+    have_pn = true;                                                                              \
+  }
+      GL_BAF_PASS({
+        double pn[3];
+        pt_pass_b_step(U, gm, D, P, dx, c, pn, sk);
+        GL_BAF_GET_PN();
+        pt_pass_b_eval(U, gm, D, Pn, c, pn, robust, sk);
+      });
+      GL_BAF_GET_PN();  // (a wave without an active point still takes the pose: P = Pn on acceptance)
+#undef GL_BAF_GET_PN
       PROF_T(tB1);
       PROF_W(trials, 3);
       if (kSpread) reduce2<2>(acc, R, C);
@@ -1123,6 +1153,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   const Uni U{uni(k.bf / k.fx), uni(k.ba_lambda2)};
   for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
   if (tid < 16) R.red2[tid] = 0.0;
+  if (tid == 0) *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
   {
     const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1

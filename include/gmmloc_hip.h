@@ -89,7 +89,13 @@ int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
 /* Kernel timing with HIP events on the context's stream: while enabled, every
  * launch of the named hot kernel class is bracketed by events.  Returns the
  * accumulated milliseconds / launch count since the last reset. */
-enum gl_timer { GL_TIMER_ASSOC = 0, GL_TIMER_REFINE_POSE = 1, GL_TIMER_BA = 2, GL_TIMER_COUNT = 8 };
+enum gl_timer {
+  GL_TIMER_ASSOC = 0,       /* association kernels                                             */
+  GL_TIMER_REFINE_POSE = 1, /* k_optimize_current_pose                                         */
+  GL_TIMER_BA = 2,          /* the refine kernel proper (k_ba1_fast / k_ba1 / k_ba_gen)        */
+  GL_TIMER_BA_PREP = 3,     /* k_ba1_prep: set-up launch of gl_track_frames' refine            */
+  GL_TIMER_COUNT = 8
+};
 int gl_ctx_timing_enable(gl_ctx_t* ctx, int on);
 int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* launches, int reset);
 /* Optional statistics: while a device buffer of n int32 is registered, gl_track_frames writes the
