@@ -474,9 +474,11 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     // the canonical summation order of a frame of stride M (see group_totals28): G groups of S <= 4 chunks of 64 edges
     const int nch = std::max(1, (M + 63) / 64), G = (nch + 3) / 4, S = (nch + G - 1) / G;
     // waves per frame: a wave per group of <= 256 edges, up to 8 (one frame of 1 000 edges: 0.40 ms on 4 waves against
-    // 1.24 ms on one; frames of <= 256 edges are one wave: 12 frames per CU, no barriers).  The sums are built in the same
-    // order whatever the count: the shape never shows in the results.  Option pose_waves (1 | 4 | 8) forces the cap.
-    int nw = std::min(G, 8);  // (measured at 1 000 edges: 4 waves beat one even at 4 096 frames, 4.5 vs 4.8 ms)
+    // 1.24 ms on one).  The sums are built in the same order whatever the count: the shape never shows in the results.
+    // Option pose_waves (1 | 4 | 8) forces the cap.
+    // one wave per frame for large batches: 12 frames per CU in flight and no barrier (config 3, 2 149 frames of up to 1 200
+    // edges: 0.79 M frames/s against 0.56 M with a wave per group; 4 096 full frames of 1 000 edges: 4.8 vs 4.5 ms)
+    int nw = B > 1536 ? 1 : std::min(G, 8);
     if (c->opt.pose_waves > 0) nw = std::min(G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
     const size_t lds = (size_t)G * 32 * sizeof(double);
     if (nw > 4)

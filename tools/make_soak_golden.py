@@ -18,7 +18,7 @@ from tests import oracle_lib
 from tools import soak_cases as sc
 
 # (kind, map, round, index of the deviating feature / match within the round's problem)
-TRACK = [("map_v2", 736)]
+TRACK = [("map_v2", 736), ("map_v1", 1572)]
 BA = [333]
 FALLBACK = [("map_v1", 852, 33), ("map_v2", 79, 547), ("map_v2", 323, 2), ("map_v2", 903, 323)]
 TRI = [("map_v1", 693, 80), ("map_v1", 1475, 81), ("map_v1", 1533, 145), ("map_v2", 630, 267)]
