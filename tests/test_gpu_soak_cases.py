@@ -50,7 +50,7 @@ def test_soak_track_bifurcation(env, oracle, opt, mapname, r):
     """gl_track_frames on small, outlier-ridden frames (124 / 504 points, optimum 5 - 14 cm off the generating pose):
     the 5 / 5 / 40 Levenberg schedule stops before convergence next to an accept / reject flip.  Moving the
     observations by <= 1 ulp makes the ORACLE jump by 0.2 - 1 mm in some probes (2 of 48 on the first frame, half of
-    them on the second) and not at all in the others; HIP and the numpy restatement each land on one of the branches.
+    them on the second) and by < 1e-6 in the others; HIP and the numpy restatement each land on one of the branches.
     Which frames sit on such a flip depends on the summation order, so the soak's single track deviation moved from
     the first frame to the second when the refine's order changed; both are held here.  Associations, chi2 and the
     bits across launch shapes are exact."""
@@ -85,7 +85,7 @@ def test_soak_track_bifurcation(env, oracle, opt, mapname, r):
     numpy_vs_oracle = max(pose_err(e["ref"]["track_%s_r%d_pose" % (mapname, r)], p_ref))
     spread = max(probes.max(), numpy_vs_oracle)
     assert (probes > TOL).sum() >= 1, "the oracle no longer jumps: this frame must then pass the strict tolerance"
-    assert probes.min() < 1e-8   # ... and does not move at all in other probes: a flip between branches, not noise
+    assert probes.min() < TOL    # ... and stays inside the strict tolerance in other probes: a flip between branches
     assert hip < TOL or hip < 10 * spread, (hip, spread, numpy_vs_oracle)
 
 
