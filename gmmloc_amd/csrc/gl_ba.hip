@@ -452,7 +452,7 @@ int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm,
                const uint8_t* has_prior, double* pts, const double* obs, const int32_t* oct, int32_t* assoc,
                const double* d2, double gate, uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
   BaK k = make_bak(cam, prm, gate);
-  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
+  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   char* s = (char*)scratch;
   double* pn = (double*)s;
   s += (size_t)B * L * 24;
@@ -471,7 +471,7 @@ int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm,
 // fast path: plane records (32 B) + normalised observations (24 B) + permutation, flags, gated association (12 B) per
 // point; general kernel: trial points, chi2, levels (33 B); + per frame: 2 x 4 x 32 x 2 exchange words of the latency
 // shape (gl_ba_fast.hip)
-size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 68 + (size_t)B * 4096 + 512; }
+size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 36 + (size_t)B * 4096 + 512; }
 
 }  // namespace gl
 

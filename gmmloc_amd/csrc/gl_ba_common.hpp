@@ -284,6 +284,7 @@ struct GmmDev {
   const double* sqrt_info;
   const double* hgw;
   const uint8_t* flags;
+  const double* plane4;
 };
 
 inline BaK make_bak(const gl_camera* cam, const gl_params* prm, double gate) {

@@ -9,11 +9,13 @@ using namespace gld;
 using namespace glba;
 
 // ---- launch scratch and its producer ------------------------------------------------------------------------------
-// Per point of the launch, in the PERMUTED order of its frame: the plane record {n, n.mu} (32 B), the observation in
-// normalised image coordinates (24 B), the original index (perm), the flag word, the gated association: 68 B.
+// Per point of the launch, in the PERMUTED order of its frame: the observation in normalised image coordinates (24 B),
+// the original index (perm), the flag word, the gated association: 36 B.  (The plane record {n, n.mu} of a point's
+// component is NOT copied per point: the passes fetch it from the map's K x 4 table by the association - 128 KB shared
+// by every frame of an XCD instead of 64 KB per frame, which is what lets the per-pass streams of the 32 frames of an
+// XCD stay in its 4 MB L2: fabric-side reads 12.0 -> 0.6 GB per launch.)
 namespace {
 struct PrepView {
-  double* gnd;
   double* gobn;
   int32_t* perm;
   int32_t* pfl;
@@ -22,16 +24,15 @@ struct PrepView {
 __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
   PrepView v;
   const size_t n = (size_t)B * L;
-  v.gnd = scratch;
-  v.gobn = scratch + n * 4;
-  v.perm = (int32_t*)(scratch + n * 7);
+  v.gobn = scratch;
+  v.perm = (int32_t*)(scratch + n * 3);
   v.pfl = v.perm + n;
   v.assoc_p = v.pfl + n;
   return v;
 }
 
 // Set-up of a refine launch, one workgroup per frame: the association gate chi2 <= 9 (checkMapAssociation,
-// gmmloc_opt.cpp:230-232), the flag word of every point, its plane record and normalised observation - and the ORDER the
+// gmmloc_opt.cpp:230-232), the flag word of every point, its normalised observation - and the ORDER the
 // refine walks the frame in: a stable partition that puts the points associated with a NON-degenerate component (the
 // volumetric ~5 % of a map, whose EdgePt2Gaussian needs the full 3x3 block R L L^T R^T instead of a rank-1 plane term)
 // behind all the others.  A wave of 64 consecutive points then takes the expensive branch only in the last chunk or two of
@@ -101,14 +102,6 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
       pv.gobn[gp * 3] = (obs_all[g * 3] - k.cx) * ifx;
       pv.gobn[gp * 3 + 1] = (obs_all[g * 3 + 1] - k.cy) * ify;
       pv.gobn[gp * 3 + 2] = (obs_all[g * 3 + 2] - k.cx) * ifx;
-      if ((fl_[j] & 12) == 12) {  // degenerate component: plane normal (axis_.col(0)) and n . mean
-        const int a = a_[j];
-        const double nx = gm.axis[(size_t)a * 9], ny = gm.axis[(size_t)a * 9 + 3], nz = gm.axis[(size_t)a * 9 + 6];
-        pv.gnd[gp * 4] = nx;
-        pv.gnd[gp * 4 + 1] = ny;
-        pv.gnd[gp * 4 + 2] = nz;
-        pv.gnd[gp * 4 + 3] = nx * gm.rec12[(size_t)a * 12] + ny * gm.rec12[(size_t)a * 12 + 1] + nz * gm.rec12[(size_t)a * 12 + 2];
-      }
     }
 #pragma unroll
     for (int w = 0; w < PREP_T / 64; ++w)
@@ -247,7 +240,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = (a.G + 1) / 2;
   // the exchange words of the frames sit behind the plane records
-  a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 68 + 63) / 64) * 64);
+  a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 36 + 63) / 64) * 64);
   if (a.NB == 1) {
     kern<<<a.B, 512, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
                                        a.parts);
@@ -271,7 +264,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
                     uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
   BafArgs a;
   a.k = make_bak(cam, prm, gate);
-  a.gm = GmmDev{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
+  a.gm = GmmDev{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   a.B = B;
   a.L = L;
   canon_order(L, &a.G, &a.S);

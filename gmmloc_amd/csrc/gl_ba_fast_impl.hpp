@@ -753,14 +753,16 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
   c.ll = mp.lbase + mp.step * i;
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.ob[j] = gobn[(size_t)c.l * 3 + j];
+  const int a = gassoc[c.l];
+  const int ap = a > 0 ? a : 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)c.l * 4 + j];  // plane normal n and n . mean
+  for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];  // plane normal n and n . mean: the map's table, by component
   c.ar = c.fl & F_AR;
   c.ag = c.fl & F_AG;
   const int oc = (c.fl >> 8) & 7;
   c.sx = D.stab[oc];
   c.sy = D.stab[8 + oc];
-  c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? gassoc[c.l] : -1;
+  c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? a : -1;
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
   return true;
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   // launch scratch written by k_ba1_prep, read-only here: plane records, normalised observations, permutation, flags,
   // gated associations (all but perm in the permuted order)
   const PrepView pv = prep_view(pn_all, B, L);
-  const double* gnd = pv.gnd + gbase * 4;
+  const double* gnd = gm.plane4;
   const double* gobn = pv.gobn + gbase * 3;
   const int32_t* gperm = pv.perm + gbase;
   const int32_t* gassoc = pv.assoc_p + gbase;
@@ -1201,7 +1203,8 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
         if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
           const double p[3] = {D.sp[ll], D.sp[MCAP + ll], D.sp[2 * MCAP + ll]};
-          const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
+          const size_t ap = (size_t)gassoc[l];
+          const double nd[4] = {gnd[ap * 4], gnd[ap * 4 + 1], gnd[ap * 4 + 2], gnd[ap * 4 + 3]};
           if (gmm_chi2_fast(U.lm, gm, nd, fl, -1, p) > k.str_thresh) fw_or(fw, i, F_LEVG);
         }
       } else {  // STALE chi2 of the reprojection edges, fresh depth test (:799-825)
@@ -1225,7 +1228,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
     if (fl & F_EXISTS) {
       const double p[3] = {D.sp[ll], D.sp[MCAP + ll], D.sp[2 * MCAP + ll]};
       if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
-        const double nd[4] = {gnd[(size_t)l * 4], gnd[(size_t)l * 4 + 1], gnd[(size_t)l * 4 + 2], gnd[(size_t)l * 4 + 3]};
+        const double nd[4] = {gnd[(size_t)a * 4], gnd[(size_t)a * 4 + 1], gnd[(size_t)a * 4 + 2], gnd[(size_t)a * 4 + 3]};
         if (gmm_chi2_fast(U.lm, gm, nd, fl, -1, p) > k.str_thresh) dr = 1;
       }
       const double z = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];

@@ -1112,7 +1112,7 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   void* scratch = nullptr;
   int rc = gl::ctx_scratch(c, (size_t)B * 64 + per * B, &scratch);
   if (rc != GL_OK) return rc;
-  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags};
+  GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   const size_t n = 6 * (size_t)P;
   const size_t s_bytes = n * n * sizeof(double);
   int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;

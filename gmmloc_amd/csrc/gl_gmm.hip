@@ -18,7 +18,7 @@ namespace {
 __global__ void k_build_components(int K, const double* __restrict__ mean_in, const double* __restrict__ cov_in,
                                    double* __restrict__ rec12, double* __restrict__ det, double* __restrict__ scale,
                                    double* __restrict__ axis, double* __restrict__ sqrt_info,
-                                   double* __restrict__ hgw, uint8_t* __restrict__ flags) {
+                                   double* __restrict__ hgw, double* __restrict__ plane4, uint8_t* __restrict__ flags) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   double cov[9], inv[9], w[3], V[9], L[9];
@@ -48,6 +48,14 @@ __global__ void k_build_components(int K, const double* __restrict__ mean_in, co
       const int i = ii[e], j = jj[e];
       hgw[(size_t)k * 6 + e] = ok ? (L[i * 3] * L[j * 3] + L[i * 3 + 1] * L[j * 3 + 1] + L[i * 3 + 2] * L[j * 3 + 2]) : __builtin_nan("");
     }
+  }
+  {  // EdgePt2GaussianDeg's plane (factors.cpp:55-64): normal = axis_.col(0), offset n . mean
+    const double nx = V[0], ny = V[3], nz = V[6];
+    double* pl = plane4 + (size_t)k * 4;
+    pl[0] = nx;
+    pl[1] = ny;
+    pl[2] = nz;
+    pl[3] = nx * rec[0] + ny * rec[1] + nz * rec[2];
   }
   const bool deg = w[0] < 1e-4;                     // gaussian.cpp:44
   const bool salient = (w[1] > 0.2 && w[2] > 0.2);  // gaussian.cpp:51-54
@@ -125,7 +133,7 @@ int launch_build_components(Ctx* c, Gmm* g) {
   GL_HIP(hipMemcpyAsync(g->mean, g->h_mean.data(), sizeof(double) * 3 * K, hipMemcpyHostToDevice, c->stream));
   (void)d_cov;
   k_build_components<<<(K + 127) / 128, 128, 0, c->stream>>>(K, d_mean, g->cov, g->rec12, g->det, g->scale, g->axis,
-                                                             g->sqrt_info, g->hgw, g->flags);
+                                                             g->sqrt_info, g->hgw, g->plane4, g->flags);
   GL_HIP(hipGetLastError());
   GL_HIP(hipStreamSynchronize(c->stream));
   GL_HIP(hipFree(d_mean));
@@ -193,6 +201,7 @@ int gl_gmm_create(gl_ctx_t* ctx, const double* mean, const double* cov, int K, c
   alloc((void**)&g->axis, sizeof(double) * 9 * K);
   alloc((void**)&g->sqrt_info, sizeof(double) * 9 * K);
   alloc((void**)&g->hgw, sizeof(double) * 6 * K);
+  alloc((void**)&g->plane4, sizeof(double) * 4 * K);
   alloc((void**)&g->flags, K);
   if (rc == GL_OK) rc = gl::launch_build_components(c, g);
   if (rc == GL_OK) rc = gl::launch_build_neighbours(c, g);
@@ -226,7 +235,7 @@ int gl_gmm_destroy(gl_gmm_t* gmm) {
   if (!gmm) return GL_OK;
   gl::Gmm* g = gl::G(gmm);
   (void)hipSetDevice(g->device);
-  void* ptrs[] = {g->rec12, g->mean, g->cov, g->det, g->scale, g->axis, g->sqrt_info, g->hgw, g->flags, g->nbs_ptr, g->nbs_idx, g->nbs_dist};
+  void* ptrs[] = {g->rec12, g->mean, g->cov, g->det, g->scale, g->axis, g->sqrt_info, g->hgw, g->plane4, g->flags, g->nbs_ptr, g->nbs_idx, g->nbs_dist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   gl::free_cell_index(g);

@@ -66,6 +66,7 @@ struct Gmm {
   double* axis = nullptr;
   double* sqrt_info = nullptr;
   double* hgw = nullptr;  // K x 6 sym: sqrt_info * sqrt_info^T (EdgePt2Gaussian J^T J, world frame)
+  double* plane4 = nullptr;  // K x 4: axis_.col(0) and its dot product with the mean (EdgePt2GaussianDeg's plane)
   uint8_t* flags = nullptr;
   int32_t* nbs_ptr = nullptr;
   int32_t* nbs_idx = nullptr;
