@@ -316,6 +316,22 @@ def main():
                 torch.cuda.synchronize()
                 lat.append(time.perf_counter() - t1)
         latency_ms = 1e3 * float(np.median(lat[5:]))
+        # host buffers in, host buffers out (what the reference host would call once per frame through the adapter):
+        # page-locked staging, one enqueued copy each way, one synchronize; at the bench frame and at 700 points
+        h2h = {}
+        hp = api.HostFramePath(ctx, gmm, cam, prm, N_PTS)
+        from gmmloc_amd import synth
+        f700 = synth.synth_frame(mean, cov, synth.look_at_pose(np.array([-1.0, 0.5, 1.5]), np.array([1.5, 2.0, 1.4])), cam, 700, 20200901)
+        for mpts, f0 in ((N_PTS, frames[0]), (700, f700)):
+            hx, ho, hc = f0["Xw"].copy(), f0["obs"].copy(), f0["octave"].copy()
+            lat = []
+            for it in range(25):
+                hpose, hxw = f0["pose_init"].copy(), hx.copy()
+                t1 = time.perf_counter()
+                hp.track_frame(hpose, hxw, ho, hc)
+                lat.append(time.perf_counter() - t1)
+            h2h[mpts] = 1e3 * float(np.median(lat[5:]))
+        hp.close()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -405,7 +421,11 @@ def main():
             "value": B * world / dt_sweep, "unit": "frames/s", "ms_per_step": 1e3 * dt_sweep, "steps": sweep_steps,
             "what": "the same step with GL_ASSOC_EXHAUSTIVE-style association (all 2000 x 4096 pairs per frame swept, option "
                     "assoc_grid = 0) instead of the exact cell index; rank 0's clock"}
-        out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20"}
+        out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20",
+                          "host_to_host_ms": h2h[N_PTS], "host_to_host_700pts_ms": h2h[700],
+                          "host_to_host_what": "host numpy buffers -> pinned staging -> one H2D + gl_track_frames + one D2H on the "
+                                               "context's stream -> one synchronize -> host buffers (api.HostFramePath = the "
+                                               "adapter's trackFrame), ctypes caller, median of 20"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(20200901 + 100000 * rank)
             out["cpu_baseline"] = cb

@@ -78,6 +78,10 @@ def load():
         "gl_free": (i32, [vp, vp]),
         "gl_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),
         "gl_memcpy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
+        "gl_malloc_host": (i32, [vp, C.c_size_t, P(vp)]),
+        "gl_free_host": (i32, [vp, vp]),
+        "gl_memcpy_h2d_async": (i32, [vp, vp, vp, C.c_size_t]),
+        "gl_memcpy_d2h_async": (i32, [vp, vp, vp, C.c_size_t]),
     }
     missing = []
     for name, (res, args) in sig.items():

@@ -272,6 +272,56 @@ def track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octave, want_d2=True):
     return assoc, d2
 
 
+class HostFramePath:
+    """The frame-at-a-time caller with HOST buffers in and out - what include/gmmloc_hip/gmm_adapter.hpp::trackFrame
+    does for the reference host (tracking.cpp calls the path once per frame): one pooled device buffer, one
+    page-locked staging buffer (gl_malloc_host), one enqueued transfer each way and ONE synchronize per frame.
+    Layout  pose | Xw | assoc || obs | octave ; only the part before || comes back."""
+
+    def __init__(self, ctx, gmm, cam, prm, max_points):
+        self.ctx, self.gmm, self.cam, self.prm = ctx, gmm, cam.c(), prm.c()
+        self.cap = self._layout(max_points)[-1]
+        lib = ctx.lib
+        self.dev, self.host = C.c_void_p(), C.c_void_p()
+        _check(lib.gl_malloc(ctx.h, self.cap, C.byref(self.dev)))
+        _check(lib.gl_malloc_host(ctx.h, self.cap, C.byref(self.host)))
+        self.stage = np.ctypeslib.as_array(C.cast(self.host, C.POINTER(C.c_uint8)), shape=(self.cap,))
+
+    @staticmethod
+    def _layout(M):
+        oX = 64
+        oA = oX + M * 24
+        oO = oA + ((M * 4 + 7) // 8) * 8
+        oC = oO + M * 24
+        return oX, oA, oO, oC, oC + M * 4
+
+    def track_frame(self, pose, Xw, obs, octave):
+        """pose (7,), Xw (M,3) float64 are updated in place; returns assoc (M,) int32."""
+        M = octave.shape[0]
+        oX, oA, oO, oC, total = self._layout(M)
+        if total > self.cap:
+            raise ValueError("frame larger than the path was created for")
+        st, lib, h, d = self.stage, self.ctx.lib, self.ctx.h, self.dev.value
+        st[:56] = pose.view(np.uint8)
+        st[oX:oA] = Xw.reshape(-1).view(np.uint8)
+        st[oO:oC] = obs.reshape(-1).view(np.uint8)
+        st[oC:total] = octave.view(np.uint8)
+        _check(lib.gl_memcpy_h2d_async(h, self.dev, self.host, total))
+        _check(lib.gl_track_frames(h, self.gmm.h, C.byref(self.cam), C.byref(self.prm), 1, M, C.c_void_p(d), C.c_void_p(d + oX),
+                                   C.c_void_p(d + oO), C.c_void_p(d + oC), C.c_void_p(d + oA), None))
+        _check(lib.gl_memcpy_d2h_async(h, self.host, self.dev, oO))
+        _check(lib.gl_ctx_synchronize(h))
+        pose[:] = st[:56].view(np.float64)
+        Xw.reshape(-1)[:] = st[oX:oA].view(np.float64)
+        return st[oA:oA + M * 4].view(np.int32).copy()
+
+    def close(self):
+        if self.dev:
+            self.ctx.lib.gl_free(self.ctx.h, self.dev)
+            self.ctx.lib.gl_free_host(self.ctx.h, self.host)
+            self.dev = self.host = None
+
+
 def read_gmm_file(path):
     """Host-only .gmm reader (gl_gmm_file_read) -> (mean (K,3), cov (K,9))."""
     lib = _lib.load()

@@ -246,5 +246,32 @@ int gl_memcpy_d2h(gl_ctx_t* ctx, void* dst, const void* src_dev, size_t bytes) {
   GL_HIP(hipStreamSynchronize(gl::C(ctx)->stream));
   return GL_OK;
 }
+int gl_malloc_host(gl_ctx_t* ctx, size_t bytes, void** host_out) {
+  GL_REQUIRE(ctx && host_out, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
+  if (hipHostMalloc(host_out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    gl::set_error("gl_malloc_host(%zu) failed", bytes);
+    return GL_ERR_NOMEM;
+  }
+  return GL_OK;
+}
+int gl_free_host(gl_ctx_t* ctx, void* host) {
+  GL_REQUIRE(ctx, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
+  if (host) GL_HIP(hipHostFree(host));
+  return GL_OK;
+}
+int gl_memcpy_h2d_async(gl_ctx_t* ctx, void* dst_dev, const void* src_pinned, size_t bytes) {
+  GL_REQUIRE(ctx && dst_dev && src_pinned, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
+  GL_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, gl::C(ctx)->stream));
+  return GL_OK;
+}
+int gl_memcpy_d2h_async(gl_ctx_t* ctx, void* dst_pinned, const void* src_dev, size_t bytes) {
+  GL_REQUIRE(ctx && dst_pinned && src_dev, "null argument");
+  GL_HIP(hipSetDevice(gl::C(ctx)->device));
+  GL_HIP(hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, gl::C(ctx)->stream));
+  return GL_OK;
+}
 
 }  // extern "C"

@@ -321,6 +321,14 @@ int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out);
 int gl_free(gl_ctx_t* ctx, void* dev);
 int gl_memcpy_h2d(gl_ctx_t* ctx, void* dst_dev, const void* src, size_t bytes); /* synchronous */
 int gl_memcpy_d2h(gl_ctx_t* ctx, void* dst, const void* src_dev, size_t bytes); /* synchronous */
+/* The frame-at-a-time host path (tracking.cpp:274,312,356 call once per frame): page-locked staging memory and
+ * copies that are only ENQUEUED on the context's stream, so a frame costs one gl_ctx_synchronize instead of one per
+ * transfer.  The host side of an _async copy must come from gl_malloc_host and stay untouched until the
+ * synchronize. */
+int gl_malloc_host(gl_ctx_t* ctx, size_t bytes, void** host_out);
+int gl_free_host(gl_ctx_t* ctx, void* host);
+int gl_memcpy_h2d_async(gl_ctx_t* ctx, void* dst_dev, const void* src_pinned, size_t bytes);
+int gl_memcpy_d2h_async(gl_ctx_t* ctx, void* dst_pinned, const void* src_dev, size_t bytes);
 
 #ifdef __cplusplus
 }

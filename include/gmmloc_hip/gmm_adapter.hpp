@@ -120,28 +120,33 @@ class GMM {
                           const std::vector<int32_t>& octave, std::vector<uint8_t>& is_outlier) {
     const int M = (int)octave.size();
     is_outlier.resize(M, 0);
-    DevBuf dpose(ctx_, 56), dX(ctx_, (size_t)M * 24 + 8), dO(ctx_, (size_t)M * 24 + 8), doc(ctx_, (size_t)M * 4 + 4),
-        dout(ctx_, (size_t)M + 8), dn(ctx_, 8);
-    dpose.upload(&Tcw);
+    // one pooled device buffer, one page-locked staging buffer, one transfer each way, one synchronize:
+    //   pose | ninlier | is_outlier || Xw | obs | octave
+    const size_t oN = 64, oF = 72, oX = oF + (((size_t)M + 7) / 8) * 8 + 8, oO = oX + (size_t)M * 24, oC = oO + (size_t)M * 24,
+                 total = oC + (size_t)M * 4 + 8;
+    DevBuf& d = pooled(1, total);
+    char* st = stage(total);
+    std::memcpy(st, &Tcw, 56);
+    std::memset(st + oN, 0, 8);
     if (M) {
-      dX.upload(Xw.data());
-      dO.upload(obs.data());
-      doc.upload(octave.data());
-      std::vector<uint8_t> cur(M + 8, 0);
-      std::memcpy(cur.data(), is_outlier.data(), M);
-      dout.upload(cur.data());
+      std::memcpy(st + oF, is_outlier.data(), M);
+      std::memcpy(st + oX, Xw.data(), (size_t)M * 24);
+      std::memcpy(st + oO, obs.data(), (size_t)M * 24);
+      std::memcpy(st + oC, octave.data(), (size_t)M * 4);
     }
-    check(gl_optimize_current_pose(ctx_, &cam_, &prm_, 1, M, dpose.as<double>(), dX.as<double>(), dO.as<double>(),
-                                   doc.as<int32_t>(), dout.as<uint8_t>(), dn.as<int32_t>()),
+    char* base = d.as<char>();
+    check(gl_memcpy_h2d_async(ctx_, base, st, total), "h2d");
+    check(gl_optimize_current_pose(ctx_, &cam_, &prm_, 1, M, reinterpret_cast<double*>(base), reinterpret_cast<const double*>(base + oX),
+                                   reinterpret_cast<const double*>(base + oO), reinterpret_cast<const int32_t*>(base + oC),
+                                   reinterpret_cast<uint8_t*>(base + oF), reinterpret_cast<int32_t*>(base + oN)),
           "gl_optimize_current_pose");
+    check(gl_memcpy_d2h_async(ctx_, st, base, oX), "d2h");
     check(gl_ctx_synchronize(ctx_), "sync");
-    dpose.download(&Tcw);
-    std::vector<uint8_t> tmp(M + 8);
-    dout.download(tmp.data());
-    std::memcpy(is_outlier.data(), tmp.data(), M);
-    int32_t n[2];
-    dn.download(n);
-    return n[0];
+    std::memcpy(&Tcw, st, 56);
+    if (M) std::memcpy(is_outlier.data(), st + oF, M);
+    int32_t n;
+    std::memcpy(&n, st + oN, 4);
+    return n;
   }
 
   // North-star per-frame path for ONE frame (gl_track_frames, B = 1): exact Mahalanobis association of the
@@ -153,26 +158,28 @@ class GMM {
     const int M = (int)octave.size();
     assoc.assign(M, -1);
     if (!M) return;
-    // the per-frame caller: one device buffer kept (and only grown) between calls - hipMalloc / hipFree per call
-    // cost more than the kernels - and one transfer each way:  pose | Xw | assoc || obs | octave
+    // the per-frame caller: one device buffer and one page-locked staging buffer kept (and only grown) between calls -
+    // hipMalloc / hipFree per call cost more than the kernels - one transfer each way, enqueued on the context's
+    // stream, and ONE synchronize per frame:  pose | Xw | assoc || obs | octave
     const size_t oX = 64, oA = oX + (size_t)M * 24, oO = oA + (((size_t)M * 4 + 7) / 8) * 8, oC = oO + (size_t)M * 24,
                  total = oC + (size_t)M * 4;
     DevBuf& d = pooled(0, total);
-    stage_.resize(total);
-    std::memcpy(stage_.data(), &Tcw, 56);
-    std::memcpy(stage_.data() + oX, Xw.data(), (size_t)M * 24);
-    std::memcpy(stage_.data() + oO, obs.data(), (size_t)M * 24);
-    std::memcpy(stage_.data() + oC, octave.data(), (size_t)M * 4);
-    d.upload(stage_.data(), total);
+    char* st = stage(total);
+    std::memcpy(st, &Tcw, 56);
+    std::memcpy(st + oX, Xw.data(), (size_t)M * 24);
+    std::memcpy(st + oO, obs.data(), (size_t)M * 24);
+    std::memcpy(st + oC, octave.data(), (size_t)M * 4);
     char* base = d.as<char>();
+    check(gl_memcpy_h2d_async(ctx_, base, st, total), "h2d");
     check(gl_track_frames(ctx_, gmm_, &cam_, &prm_, 1, M, reinterpret_cast<double*>(base), reinterpret_cast<double*>(base + oX),
                           reinterpret_cast<const double*>(base + oO), reinterpret_cast<const int32_t*>(base + oC),
                           reinterpret_cast<int32_t*>(base + oA), nullptr),
           "gl_track_frames");
-    d.download(stage_.data(), oO);  // synchronous on the context's stream: also waits for the kernels
-    std::memcpy(&Tcw, stage_.data(), 56);
-    std::memcpy(Xw.data(), stage_.data() + oX, (size_t)M * 24);
-    std::memcpy(assoc.data(), stage_.data() + oA, (size_t)M * 4);
+    check(gl_memcpy_d2h_async(ctx_, st, base, oO), "d2h");
+    check(gl_ctx_synchronize(ctx_), "sync");
+    std::memcpy(&Tcw, st, 56);
+    std::memcpy(Xw.data(), st + oX, (size_t)M * 24);
+    std::memcpy(assoc.data(), st + oA, (size_t)M * 4);
   }
 
   // Localization::jointOptimization on one flattened local window (layout: gmmloc_hip.h, gl_joint_optimization):
@@ -236,6 +243,9 @@ class GMM {
  private:
   void release() {
     pool_.clear();
+    if (stage_ && ctx_) gl_free_host(ctx_, stage_);
+    stage_ = nullptr;
+    stage_bytes_ = 0;
     if (gmm_) gl_gmm_destroy(gmm_);
     if (ctx_) gl_ctx_destroy(ctx_);
     gmm_ = nullptr;
@@ -246,8 +256,21 @@ class GMM {
     if (!pool_[slot] || pool_[slot]->bytes() < bytes) pool_[slot].reset(new DevBuf(ctx_, bytes + bytes / 4 + 64));
     return *pool_[slot];
   }
+  char* stage(size_t bytes) {  // page-locked, grown on demand
+    if (stage_bytes_ < bytes) {
+      if (stage_) gl_free_host(ctx_, stage_);
+      stage_ = nullptr;
+      stage_bytes_ = 0;
+      void* p = nullptr;
+      check(gl_malloc_host(ctx_, bytes + bytes / 4 + 64, &p), "gl_malloc_host");
+      stage_ = static_cast<char*>(p);
+      stage_bytes_ = bytes + bytes / 4 + 64;
+    }
+    return stage_;
+  }
   std::vector<std::unique_ptr<DevBuf>> pool_;
-  std::vector<char> stage_;
+  char* stage_ = nullptr;
+  size_t stage_bytes_ = 0;
   gl_ctx_t* ctx_ = nullptr;
   gl_gmm_t* gmm_ = nullptr;
   gl_params prm_;

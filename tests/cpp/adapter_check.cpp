@@ -138,6 +138,15 @@ int main(int argc, char** argv) {
       }
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
       printf("trackFrame host-to-host %.3f ms per call (M = %d)\n", ms, M);
+      std::vector<uint8_t> outl;
+      gmm.optimizeCurrentPose(p, Xw, obs, oct, outl);
+      const auto t1 = std::chrono::steady_clock::now();
+      for (int r = 0; r < reps; ++r) {
+        p = pose0;
+        gmm.optimizeCurrentPose(p, Xw, obs, oct, outl);
+      }
+      const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() / reps;
+      printf("optimizeCurrentPose host-to-host %.3f ms per call (M = %d)\n", ms2, M);
     }
     fclose(o);
     printf("components %zu\n", gmm.countComponents());

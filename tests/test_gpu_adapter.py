@@ -63,6 +63,14 @@ def test_cpp_adapter_matches_python_host(gpu, map_v1, gt_sync, tmp_path):
     assert np.array_equal(rd(np.float64, 7), pose.cpu().numpy()[0])
     assert np.array_equal(rd(np.float64, M * 3).reshape(M, 3), Xw.cpu().numpy()[0])
     assert np.array_equal(rd(np.int32, M), assoc.cpu().numpy()[0])
+    # the same host-buffer path from Python (api.HostFramePath: pinned staging, enqueued copies, one synchronize)
+    hp = api.HostFramePath(ctx, g, cam, prm, M)
+    for _ in range(2):  # the staging buffers are reused between frames
+        hpose, hxw = f["pose_init"].copy(), np.ascontiguousarray(f["Xw"]).copy()
+        ha = hp.track_frame(hpose, hxw, np.ascontiguousarray(f["obs"]), np.ascontiguousarray(f["octave"], np.int32))
+        assert np.array_equal(hpose, pose.cpu().numpy()[0]) and np.array_equal(hxw, Xw.cpu().numpy()[0])
+        assert np.array_equal(ha, assoc.cpu().numpy()[0])
+    hp.close()
     # optimizeCurrentPose
     pose = T(f["pose_init"][None])
     outl, nin = api.optimize_current_pose(ctx, cam, prm, pose, T(f["Xw"][None]), T(f["obs"][None]), T(f["octave"][None]))
