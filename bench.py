@@ -52,7 +52,7 @@ def measured_traffic(kernel, frames_per_launch):
     WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
     frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
     None when the summary is missing: bench.py itself cannot run under two profilers."""
-    for name in ("r2_traffic.json", "r1k_traffic.json"):
+    for name in ("r2c_traffic.json", "r2_traffic.json", "r1k_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -351,7 +351,7 @@ def main():
         ba_s = ba_ms / 1e3 / max(ba_n, 1)
         ba_flop = FLOP_PER_POINT_TRIAL * N_PTS * n_trials
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
-        ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8) + 56)  # Xw, obs, octave, assoc, d2 in; pose in/out (points rewritten: +24)
+        ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8 + 24 + 4) + 2 * 56)  # Xw, obs, octave, assoc, d2 in; points, final assoc out; pose in/out
         ba_traffic, ba_traffic_src = measured_traffic("k_ba1_fast", B)
         sw_traffic, sw_traffic_src = measured_traffic("k_assoc_brute", B)
         out = {
@@ -382,6 +382,7 @@ def main():
                 "frac": (ba_tflops / PEAK_FP64_VALU_TFLOPS) if ba_tflops else None,
                 "traffic": ba_traffic,
                 "traffic_source": ba_traffic_src,
+                "traffic_setup_kernel": measured_traffic("k_ba1_prep", B)[0],  # k_ba1_prep: gate, flags, order, normalised observations
                 "avg_launch_ms": 1e3 * ba_s,
                 "flop_per_launch": ba_flop,
                 "units": "%d frames x %d points x %.1f LM trials/frame x %d flop" % (B, N_PTS, n_trials / B, FLOP_PER_POINT_TRIAL),
