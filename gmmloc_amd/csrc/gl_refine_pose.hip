@@ -201,14 +201,9 @@ GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, do
 }
 
 // one edge: residual, chi2, Huber weight, Jacobian; accumulates into acc[0..27]
-GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int e,
-                      const double* __restrict__ Xw, const double* __restrict__ obs, const int32_t* __restrict__ octave,
-                      const uint8_t* __restrict__ level, double* __restrict__ chi2_e, double* acc) {
+GL_DEV void pose_edge_v(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int oc, double X,
+                        double Y, double Z, double ou, double ov, double our, double& chi2_out, double* acc) {
   {
-    const int oc = octave[e];
-    if (oc < 0 || level[e] != 0) return;
-    const double X = Xw[(size_t)e * 3 + 0], Y = Xw[(size_t)e * 3 + 1], Z = Xw[(size_t)e * 3 + 2];
-    const double ou = obs[(size_t)e * 3 + 0], ov = obs[(size_t)e * 3 + 1], our = obs[(size_t)e * 3 + 2];
     const bool stereo = !(our < 0);
     const double x = P.R[0] * X + P.R[1] * Y + P.R[2] * Z + P.t[0];
     const double y = P.R[3] * X + P.R[4] * Y + P.R[5] * Z + P.t[1];
@@ -220,7 +215,7 @@ GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, c
     const double e2 = stereo ? (our - (pu - kp.bf * invz)) : 0.0;
     const double s = s2tab[oc];
     const double chi2 = e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2);
-    chi2_e[e] = chi2;
+    chi2_out = chi2;
     double rho0 = chi2, rho1 = 1.0;
     if (robust) huber(chi2, stereo ? kp.delta_stereo : kp.delta_mono, rho0, rho1);
     const double w = rho1 * s;
@@ -259,6 +254,59 @@ GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, c
   }
 }
 
+// the same from global memory (the shapes whose waves own more edges than registers hold)
+GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int e,
+                      const double* __restrict__ Xw, const double* __restrict__ obs, const int32_t* __restrict__ octave,
+                      const uint8_t* __restrict__ level, double* __restrict__ chi2_e, double* acc) {
+  const int oc = octave[e];
+  if (oc < 0 || level[e] != 0) return;
+  double c2;
+  pose_edge_v(kp, s2tab, P, robust, oc, Xw[(size_t)e * 3 + 0], Xw[(size_t)e * 3 + 1], Xw[(size_t)e * 3 + 2], obs[(size_t)e * 3 + 0],
+              obs[(size_t)e * 3 + 1], obs[(size_t)e * 3 + 2], c2, acc);
+  chi2_e[e] = c2;
+}
+
+// The frame-at-a-time shapes (a wave per group, G <= 8): a thread owns the <= 4 edges (wave S + i) 64 + lane of its
+// group for the whole kernel and keeps them in REGISTERS - map point, observation, octave, level, stale chi2 - so a
+// trial touches no global memory at all (two dependent L2 round trips per chunk before: most of a trial's 9 us).
+// (Eight waves = two per SIMD have 256 registers each, not enough for four edges' coordinates next to the 28 sums:
+// that instance keeps map point and observation in LDS - [slot][coordinate][thread], conflict-free - and the rest in
+// registers.)
+struct EdgeRegs {
+  double X[4][3], O[4][3], c2[4];
+  int oc[4];   // octave, < 0: no edge in the slot (no map point, or beyond the frame)
+  int lv[4];   // level = is_outlier_
+};
+template <int MODE>
+GL_DEV void edge_xo(const EdgeRegs& E, const double* xo, int i, double* X, double* O) {
+  const int T = blockDim.x, t = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    X[j] = MODE == 1 ? E.X[i][j] : xo[(i * 6 + j) * T + t];
+    O[j] = MODE == 1 ? E.O[i][j] : xo[(i * 6 + 3 + j) * T + t];
+  }
+}
+template <int MODE>
+GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int G, EdgeRegs& E,
+                           const double* xo, double* red, double* dst) {
+  const int wave = threadIdx.x >> 6;
+  double acc[32];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (E.oc[i] >= 0 && E.lv[i] == 0) {
+      double X[3], O[3];
+      edge_xo<MODE>(E, xo, i, X, O);
+      pose_edge_v(kp, s2tab, P, robust, E.oc[i], X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc);
+    }
+  group_totals28(acc, red, wave);
+  __syncthreads();
+  if (wave == 0) frame_totals28(red, dst, G);
+  __syncthreads();
+}
+
 // one pass over the frame's edges at pose P -> dst[0..27] (LDS): H upper triangle (21), b (6), robust chi2.
 // Wave w walks the groups w, w + NW, ...: lane sums of the group's S chunks in registers, tree, red[g]; then the blocks.
 GL_DEV void pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int G, int S, int M,
@@ -289,7 +337,7 @@ GL_DEV void pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, c
 // SIMD, no barrier does anything), 4 / 8 when the frames are fewer than the SIMDs; launched with nw <= NW waves
 // (never more than the frame has groups).  Every wave repeats the serial part (solve, pose update) on its own so that
 // no broadcast is needed.
-template <int NW>
+template <int NW, int REGS>  // REGS: 0 edges from global memory, 1 in registers, 2 coordinates in LDS
 __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M, int G, int S,
                                                                  double* __restrict__ pose_io,
                                                                  const double* __restrict__ Xw_all,
@@ -301,7 +349,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
   __shared__ double s2tab[8];
   __shared__ double H[32], Hn[32];  // current / trial system {H upper (21), b (6), chi2}
   __shared__ double part[NW];       // per-wave counts
-  extern __shared__ double red[];   // G x 32 group totals
+  extern __shared__ double red[];   // G x 32 group totals (then, REGS == 2: 4 slots x 6 coordinates x threads)
+  double* xo = red + G * 32;
   const int f = blockIdx.x, lane = threadIdx.x;  // "lane" = thread of the workgroup's waves
   if (f >= B) return;
   const int e0 = lane, es = blockDim.x;  // counting / gating loops: any order (integers, per-edge decisions)
@@ -318,10 +367,37 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
 
   // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
   double cnt = 0.0;
-  for (int e = e0; e < M; e += es) {
-    if (octave[e] >= 0) {  // is_outlier_[i] is reset only where mappoints_[i] exists (:63-69); the flags of the
-      level[e] = 0;        // other features stay the caller's
-      cnt += 1.0;
+  EdgeRegs E;
+  if (REGS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = ((lane >> 6) * S + i) * 64 + (lane & 63);
+      E.oc[i] = (i < S && e < M) ? octave[e] : -1;
+      E.lv[i] = 0;  // is_outlier_[i] is reset only where mappoints_[i] exists (:63-69): written back for those only
+      E.c2[i] = 0.0;
+      if (E.oc[i] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (REGS == 1) {
+            E.X[i][j] = Xw[(size_t)e * 3 + j];
+            E.O[i][j] = obs[(size_t)e * 3 + j];
+          } else {
+            xo[(i * 6 + j) * es + lane] = Xw[(size_t)e * 3 + j];
+            xo[(i * 6 + 3 + j) * es + lane] = obs[(size_t)e * 3 + j];
+          }
+        }
+        cnt += 1.0;
+      } else if (REGS == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E.X[i][j] = E.O[i][j] = 0.0;
+      }
+    }
+  } else {
+    for (int e = e0; e < M; e += es) {
+      if (octave[e] >= 0) {  // is_outlier_[i] is reset only where mappoints_[i] exists (:63-69); the flags of the
+        level[e] = 0;        // other features stay the caller's
+        cnt += 1.0;
+      }
     }
   }
   const int n_init = (int)block_total1(cnt, part);
@@ -346,18 +422,26 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
     P = P0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
     cnt = 0.0;
     __syncthreads();  // level[] of the previous round's gating is read by other threads below
-    for (int e = e0; e < M; e += es)
-      if (octave[e] >= 0 && level[e] == 0) cnt += 1.0;
+    if (REGS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (E.oc[i] >= 0 && E.lv[i] == 0) cnt += 1.0;
+    } else {
+      for (int e = e0; e < M; e += es)
+        if (octave[e] >= 0 && level[e] == 0) cnt += 1.0;
+    }
     const int nactive = (int)block_total1(cnt, part);
     if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
-      pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
+      if (REGS) pose_eval_regs<REGS>(kp, s2tab, P, robust, G, E, xo, red, H);
+      else pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
       double currentChi = uni(H[27]);
       bool sys_valid = true;
       double lambda = 0.0, ni = 2.0;
 #pragma unroll 1
       for (int it = 0; it < 10; ++it) {
         if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
-          pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
+          if (REGS) pose_eval_regs<REGS>(kp, s2tab, P, robust, G, E, xo, red, H);
+          else pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
           currentChi = uni(H[27]);
           sys_valid = true;
         }
@@ -377,7 +461,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
           double tempChi;
           if (ok2) {
             Pn = rt_update(P, dx);
-            pose_eval(kp, s2tab, Pn, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, Hn);
+            if (REGS) pose_eval_regs<REGS>(kp, s2tab, Pn, robust, G, E, xo, red, Hn);
+            else pose_eval(kp, s2tab, Pn, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, Hn);
             tempChi = uni(Hn[27]);
           } else {
             tempChi = 1.7976931348623157e308;
@@ -414,7 +499,20 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
     // the last computeActiveErrors; chi2 compared as float.
     cnt = 0.0;
     __syncthreads();  // chi2_e[] of the last evaluation was written by other threads (edge -> thread maps differ)
-    for (int e = e0; e < M; e += es) {
+    if (REGS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (E.oc[i] < 0) continue;
+        double X[3], O[3];
+        edge_xo<REGS == 2 ? 2 : 1>(E, xo, i, X, O);
+        const double c2 = E.lv[i] != 0 ? pose_edge_chi2(kp, P.R, P.t, X, O, E.oc[i]) : E.c2[i];
+        const float thr = !(O[2] < 0) ? 7.815f : 5.991f;
+        const bool bad = (float)c2 > thr;
+        E.lv[i] = bad ? 1 : 0;
+        if (bad) cnt += 1.0;
+      }
+    }
+    for (int e = e0; e < M && !REGS; e += es) {
       const int oc = octave[e];
       if (oc < 0) continue;
       double c2;
@@ -431,6 +529,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void
     nbad = (int)block_total1(cnt, part);
     if (round == 2) robust = false;  // e->setRobustKernel(0) at it == 2
     if (n_init < 10) break;          // optimizer.edges().size() < 10
+  }
+  if (REGS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (E.oc[i] >= 0) level[((lane >> 6) * S + i) * 64 + (lane & 63)] = (uint8_t)E.lv[i];
   }
   if (lane == 0) {
     SE3 T;
@@ -480,16 +583,26 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     // edges: 0.79 M frames/s against 0.56 M with a wave per group; 4 096 full frames of 1 000 edges: 4.8 vs 4.5 ms)
     int nw = B > 1536 ? 1 : std::min(G, 8);
     if (c->opt.pose_waves > 0) nw = std::min(G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
-    const size_t lds = (size_t)G * 32 * sizeof(double);
-    if (nw > 4)
-      k_optimize_current_pose<8><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                               ninlier_dev, (double*)scratch);
-    else if (nw > 1)
-      k_optimize_current_pose<4><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                               ninlier_dev, (double*)scratch);
-    else
-      k_optimize_current_pose<1><<<B, 64, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev,
-                                                           ninlier_dev, (double*)scratch);
+    size_t lds = (size_t)G * 32 * sizeof(double);
+#define GL_POSE_LAUNCH(NWC, REGS) \
+  k_optimize_current_pose<NWC, REGS><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, \
+                                                                     ninlier_dev, (double*)scratch)
+    const bool regs = nw > 1 && nw == G && c->opt.pose_regs != 0;  // a wave per group: the frame's edges stay on chip
+    if (nw > 4) {
+      if (regs) {
+        lds += (size_t)24 * 64 * nw * sizeof(double);
+        GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<8, 2>, lds));
+        GL_POSE_LAUNCH(8, 2);
+      } else {
+        GL_POSE_LAUNCH(8, 0);
+      }
+    } else if (nw > 1) {
+      if (regs) GL_POSE_LAUNCH(4, 1);
+      else GL_POSE_LAUNCH(4, 0);
+    } else {
+      GL_POSE_LAUNCH(1, 0);
+    }
+#undef GL_POSE_LAUNCH
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

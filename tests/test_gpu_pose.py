@@ -128,3 +128,7 @@ def test_optimize_current_pose_bit_identical_across_shapes_and_batches(gpu, map_
         one = run_gpu(gpu, cam, prm, frames[:1])                             # the frame-at-a-time shape
         for a, b, c in zip(res[1], big, one):
             assert np.array_equal(a, b[:6]) and np.array_equal(a[:1], c), M
+        opt("pose_regs", 0)  # the same shapes with the edges re-read from global memory every trial
+        for a, b in zip(res[1], run_gpu(gpu, cam, prm, frames)):
+            assert np.array_equal(a, b), M
+        opt("pose_regs", 1)

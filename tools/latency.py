@@ -61,13 +61,10 @@ with torch.cuda.stream(ctx.stream):
             timed("optimizeCurrentPose B=%d M=1000 (%s waves per frame)" % (B, env),
                   lambda: api.optimize_current_pose(ctx, cam, prm, pb.clone(), xb, ob, ocb))
         ctx.set_option("pose_waves", 0)
-        for env in ("0", "2", "4"):
-            if B * int(env) > 512:
-                continue
-            ctx.set_option("pose_coop", int(env))
-            timed("optimizeCurrentPose B=%d M=1000 (coop %s workgroups per frame)" % (B, env),
-                  lambda: api.optimize_current_pose(ctx, cam, prm, pb.clone(), xb, ob, ocb))
-        ctx.set_option("pose_coop", -1)
+        ctx.set_option("pose_regs", 0)
+        timed("optimizeCurrentPose B=%d M=1000 (edges re-read from global memory)" % B,
+              lambda: api.optimize_current_pose(ctx, cam, prm, pb.clone(), xb, ob, ocb))
+        ctx.set_option("pose_regs", 1)
         timed("track_frames B=%d M=1000 K=%d" % (B, mean1.shape[0]),
               lambda: gmmloc_amd.track_frames(ctx, g1, cam, prm, pb.clone(), xb.clone(), ob, ocb, want_d2=False))
         timed("search2d B=%d N=1000" % B, lambda: g1.search2d(cam, pb, uvb, None, k=5))
