@@ -580,7 +580,9 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     // 1.24 ms on one).  The sums are built in the same order whatever the count: the shape never shows in the results.
     // Option pose_waves (1 | 4 | 8) forces the cap.
     // one wave per frame for large batches: 12 frames per CU in flight and no barrier (config 3, 2 149 frames of up to 1 200
-    // edges: 0.79 M frames/s against 0.56 M with a wave per group; 4 096 full frames of 1 000 edges: 4.8 vs 4.5 ms)
+    // edges: 0.78 M frames/s against 0.74 M with a wave per group and the edges on chip; tools/pose_ab.py: the wave per
+    // group only wins on full frames of exactly four groups, 4.3 vs 4.9 ms for 4 096 x 1 000, and loses up to 1.6x elsewhere -
+    // its 424 registers leave one wave per SIMD)
     int nw = B > 1536 ? 1 : std::min(G, 8);
     if (c->opt.pose_waves > 0) nw = std::min(G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
     size_t lds = (size_t)G * 32 * sizeof(double);
