@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hipcub/hipcub.hpp>
+
 #include "gl_device.hpp"
 #include "gl_internal.hpp"
 
@@ -112,6 +114,93 @@ __global__ __launch_bounds__(256) void k_index_work(GridDev G, const double* __r
   if ((threadIdx.x & 63) == 0 && w) atomicAdd(total, w);
 }
 
+// ---- index build on the device -------------------------------------------------------------------
+// The O(K) part (eigenvalues, boxes, grid level, the three bounding forms per component) stays on the host; the
+// enumeration - every cell of every component's box against the three forms, ~10^8 tests for 65 536 Gaussians - and the
+// ordering of the entries run here: one workgroup per component appends the keys (cell << 32 | component) of the cells
+// that pass (wave-aggregated atomics), a radix sort orders them by cell then component (= the ascending lists the
+// tie rule of the sweep needs, deterministically), and the CSR pointers are read off the sorted keys.
+struct CompReg {
+  double mu[3];
+  double Minv[18];  // the three forms, sym6 each
+  int i0[3], n[3];  // first cell and cell count of the box per axis
+  int k, pad;
+};
+struct GridGeom {
+  double lo[3], h;
+  int dim[3];
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_index_register(const CompReg* __restrict__ regs, GridGeom gg, unsigned long long* __restrict__ total,
+                                                        unsigned long long* __restrict__ keys) {
+  __shared__ CompReg r;
+  if (threadIdx.x == 0) r = regs[blockIdx.x];
+  __syncthreads();
+  const int n0 = r.n[0], n01 = r.n[0] * r.n[1], ncell = n01 * r.n[2];
+  const int lane = threadIdx.x & 63;
+  unsigned long long mine = 0;
+  for (int base = 0; base < ncell; base += 256) {
+    const int t = base + (int)threadIdx.x;
+    bool in = t < ncell;
+    unsigned long long key = 0;
+    if (in) {
+      const int iz = t / n01, rem = t - iz * n01, iy = rem / n0, ix = rem - iy * n0;
+      const int cx = r.i0[0] + ix, cy = r.i0[1] + iy, cz = r.i0[2] + iz;
+      const double d[3] = {gg.lo[0] + (cx + 0.5) * gg.h - r.mu[0], gg.lo[1] + (cy + 0.5) * gg.h - r.mu[1], gg.lo[2] + (cz + 0.5) * gg.h - r.mu[2]};
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const double* I = r.Minv + b * 6;
+        const double q = d[0] * (I[0] * d[0] + I[1] * d[1] + I[2] * d[2]) + d[1] * (I[1] * d[0] + I[3] * d[1] + I[4] * d[2]) +
+                         d[2] * (I[2] * d[0] + I[4] * d[1] + I[5] * d[2]);
+        in = in && (q <= 1.0 + 1e-9);
+      }
+      key = ((unsigned long long)(unsigned)((cz * gg.dim[1] + cy) * gg.dim[0] + cx) << 32) | (unsigned)r.k;
+    }
+    const unsigned long long bal = __ballot(in);
+    if (!bal) continue;
+    if (!FILL) {
+      if (lane == 0) mine += (unsigned long long)__popcll(bal);
+    } else {
+      unsigned long long pos = 0;
+      if (lane == 0) pos = atomicAdd(total, (unsigned long long)__popcll(bal));
+      pos = __shfl(pos, 0, 64);
+      if (in) keys[pos + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    }
+  }
+  if (!FILL && lane == 0 && mine) atomicAdd(total, mine);
+}
+// idx[i] = component of the i-th sorted key;  ptr[c] = first key of a cell >= c
+__global__ void k_index_csr(const unsigned long long* __restrict__ keys, size_t nnz, size_t ncell, int32_t* __restrict__ ptr, int32_t* __restrict__ idx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) idx[i] = (int32_t)(unsigned)(keys[i] & 0xffffffffull);
+  if (i <= ncell) {
+    size_t lo = 0, hi = nnz;
+    while (lo < hi) {
+      const size_t mid = (lo + hi) >> 1;
+      if ((keys[mid] >> 32) < i) lo = mid + 1;
+      else hi = mid;
+    }
+    ptr[i] = (int32_t)lo;
+  }
+}
+// sum over the registered components of the list length at their own mean (does the index prune?)
+__global__ void k_index_mean_lists(const CompReg* __restrict__ regs, int nreg, GridGeom gg, const int32_t* __restrict__ ptr,
+                                   unsigned long long* __restrict__ sum) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long w = 0;
+  if (j < nreg) {
+    int ci[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ci[a] = min(gg.dim[a] - 1, max(0, (int)floor((regs[j].mu[a] - gg.lo[a]) / gg.h)));
+    const size_t cell = ((size_t)ci[2] * gg.dim[1] + ci[1]) * gg.dim[0] + ci[0];
+    w = (unsigned long long)(ptr[cell + 1] - ptr[cell]);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) w += __shfl_xor(w, o, 64);
+  if ((threadIdx.x & 63) == 0 && w) atomicAdd(sum, w);
+}
+
 // ---- host build ------------------------------------------------------------------------------
 // eigenvalues of a symmetric 3x3 (cyclic Jacobi), ascending
 void eig3_sym(const double* c, double* w) {
@@ -169,7 +258,6 @@ void free_cell_index(Gmm* g) {
 }
 
 int build_cell_index(Ctx* c, Gmm* g) {
-  (void)c;
   g->grid = CellIndex();
   if (const char* e = getenv("GMMLOC_ASSOC_GRID"))
     if (atoi(e) == 0) return GL_OK;  // knob: serve GL_ASSOC_BRUTE with the all-pairs sweep
@@ -241,86 +329,121 @@ int build_cell_index(Ctx* c, Gmm* g) {
   const size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
   const double eps_idx = 1e-9;
   const double rho = h * std::sqrt(3.0) * 0.5 * (1.0 + 1e-9) + 1e-9 * smax;
-  std::vector<uint32_t> e_cell;
-  std::vector<int32_t> e_k;
-  e_cell.reserve(1 << 20);
-  e_k.reserve(1 << 20);
+  std::vector<CompReg> regs;
+  regs.reserve(K);
   const double betas[3] = {0.5, 1.0, 2.0};
   for (int k = 0; k < K; ++k) {
     if (!ok[k]) continue;
     const double* cv = &g->h_cov[(size_t)k * 9];
     const double* mu = &g->h_mean[(size_t)k * 3];
-    int i0[3], i1[3];
+    CompReg r;
     double ncells_k = 1.0;
     for (int a = 0; a < 3; ++a) {
-      i0[a] = (int)std::floor((mu[a] - ext[(size_t)k * 3 + a] - lo[a]) / h - eps_idx);
-      i1[a] = (int)std::floor((mu[a] + ext[(size_t)k * 3 + a] - lo[a]) / h + eps_idx);
-      i0[a] = std::max(i0[a], 0);
-      i1[a] = std::min(i1[a], dim[a] - 1);
-      ncells_k *= (double)(i1[a] - i0[a] + 1);
+      int i0 = (int)std::floor((mu[a] - ext[(size_t)k * 3 + a] - lo[a]) / h - eps_idx);
+      int i1 = (int)std::floor((mu[a] + ext[(size_t)k * 3 + a] - lo[a]) / h + eps_idx);
+      i0 = std::max(i0, 0);
+      i1 = std::min(i1, dim[a] - 1);
+      r.i0[a] = i0;
+      r.n[a] = i1 - i0 + 1;
+      r.mu[a] = mu[a];
+      ncells_k *= (double)r.n[a];
     }
     if (ncells_k > 65536.0) {
       glob.push_back(k);
       continue;
     }
-    double Minv[3][6];
     for (int b = 0; b < 3; ++b) {
       const double s1 = (1.0 + 1.0 / betas[b]) * t_reg, s2 = (1.0 + betas[b]) * rho * rho;
       const double M[6] = {s1 * cv[0] + s2, s1 * cv[1], s1 * cv[2], s1 * cv[4] + s2, s1 * cv[5], s1 * cv[8] + s2};
-      sym3_inv_host(M, Minv[b]);
+      sym3_inv_host(M, r.Minv + b * 6);
     }
-    for (int iz = i0[2]; iz <= i1[2]; ++iz)
-      for (int iy = i0[1]; iy <= i1[1]; ++iy)
-        for (int ix = i0[0]; ix <= i1[0]; ++ix) {
-          const double d[3] = {lo[0] + (ix + 0.5) * h - mu[0], lo[1] + (iy + 0.5) * h - mu[1],
-                               lo[2] + (iz + 0.5) * h - mu[2]};
-          bool in = true;
-          for (int b = 0; b < 3 && in; ++b) {
-            const double* I = Minv[b];
-            const double q = d[0] * (I[0] * d[0] + I[1] * d[1] + I[2] * d[2]) +
-                             d[1] * (I[1] * d[0] + I[3] * d[1] + I[4] * d[2]) +
-                             d[2] * (I[2] * d[0] + I[4] * d[1] + I[5] * d[2]);
-            in = q <= 1.0 + 1e-9;
-          }
-          if (!in) continue;
-          e_cell.push_back((uint32_t)(((size_t)iz * dim[1] + iy) * dim[0] + ix));
-          e_k.push_back(k);
-        }
+    r.k = k;
+    r.pad = 0;
+    regs.push_back(r);
   }
   if ((int)glob.size() > K / 4) return GL_OK;
   std::sort(glob.begin(), glob.end());
-  // CSR by cell; the entries were generated with ascending k, a stable counting sort keeps that
-  std::vector<int32_t> ptr(ncell + 1, 0), idx(e_k.size());
-  for (uint32_t cidx : e_cell) ptr[cidx + 1]++;
-  for (size_t i = 0; i < ncell; ++i) ptr[i + 1] += ptr[i];
-  {
-    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-    for (size_t i = 0; i < e_k.size(); ++i) idx[fill[e_cell[i]]++] = e_k[i];
+  // ---- enumeration, ordering and CSR on the device
+  GL_HIP(hipSetDevice(g->device));
+  GridGeom gg;
+  for (int a = 0; a < 3; ++a) {
+    gg.lo[a] = lo[a];
+    gg.dim[a] = dim[a];
   }
-  {  // the index must actually prune: the mean list length seen at the component means (where the map points
-     // are) has to stay far below K, otherwise the plain sweep with scalar-operand records is faster
-    double sum = 0.0;
-    int cnt = 0;
-    for (int k = 0; k < K; ++k) {
-      if (!ok[k]) continue;
-      const double* mu = &g->h_mean[(size_t)k * 3];
-      int ci[3];
-      for (int a3 = 0; a3 < 3; ++a3) ci[a3] = std::min(dim[a3] - 1, std::max(0, (int)std::floor((mu[a3] - lo[a3]) / h)));
-      const size_t cell = ((size_t)ci[2] * dim[1] + ci[1]) * dim[0] + ci[0];
-      sum += (double)(ptr[cell + 1] - ptr[cell]);
-      ++cnt;
-    }
-    // per evaluated pair the gather kernel is ~20x slower than the sweep (92 G vs 1.8 T pairs/s measured)
-    if (cnt > 0 && sum / cnt + (double)glob.size() > K / 24.0) return GL_OK;
+  gg.h = h;
+  const int nreg = (int)regs.size();
+  CompReg* d_regs = nullptr;
+  unsigned long long *d_cnt = nullptr, *d_keys = nullptr, *d_sorted = nullptr;
+  void* d_tmp = nullptr;
+  int32_t *d_ptr = nullptr, *d_idx = nullptr;
+  auto cleanup = [&]() {
+    for (void* p_ : {(void*)d_regs, (void*)d_cnt, (void*)d_keys, (void*)d_sorted, d_tmp})
+      if (p_) (void)hipFree(p_);
+  };
+  auto fail = [&](hipError_t e) {
+    cleanup();
+    if (d_ptr) (void)hipFree(d_ptr);
+    if (d_idx) (void)hipFree(d_idx);
+    set_error("cell index build: %s", hipGetErrorString(e));
+    return GL_ERR_DEVICE;
+  };
+#define GL_TRY(x)                            \
+  do {                                       \
+    const hipError_t e_ = (x);               \
+    if (e_ != hipSuccess) return fail(e_);   \
+  } while (0)
+  hipStream_t st = c->stream;
+  unsigned long long nnz = 0, mean_sum = 0;
+  GL_TRY(hipMalloc((void**)&d_cnt, 16));
+  GL_TRY(hipMemsetAsync(d_cnt, 0, 16, st));
+  GL_TRY(hipMalloc((void**)&d_ptr, (ncell + 1) * 4));
+  if (nreg) {
+    GL_TRY(hipMalloc((void**)&d_regs, sizeof(CompReg) * nreg));
+    GL_TRY(hipMemcpyAsync(d_regs, regs.data(), sizeof(CompReg) * nreg, hipMemcpyHostToDevice, st));
+    k_index_register<false><<<nreg, 256, 0, st>>>(d_regs, gg, d_cnt, nullptr);
+    GL_TRY(hipGetLastError());
+    GL_TRY(hipMemcpyAsync(&nnz, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    GL_TRY(hipStreamSynchronize(st));
+  }
+  GL_TRY(hipMalloc((void**)&d_idx, std::max<size_t>(nnz, 1) * 4));
+  if (nnz) {
+    GL_TRY(hipMalloc((void**)&d_keys, nnz * 8));
+    GL_TRY(hipMalloc((void**)&d_sorted, nnz * 8));
+    GL_TRY(hipMemsetAsync(d_cnt, 0, 8, st));
+    k_index_register<true><<<nreg, 256, 0, st>>>(d_regs, gg, d_cnt, d_keys);
+    GL_TRY(hipGetLastError());
+    int cell_bits = 1;
+    while (((size_t)1 << cell_bits) < ncell) ++cell_bits;
+    size_t tmp_bytes = 0;
+    GL_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_sorted, (int)nnz, 0, 32 + cell_bits, st));
+    GL_TRY(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 1)));
+    GL_TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_sorted, (int)nnz, 0, 32 + cell_bits, st));
+  }
+  {
+    const size_t nthr = std::max<size_t>(nnz, ncell + 1);
+    k_index_csr<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(d_sorted, (size_t)nnz, ncell, d_ptr, d_idx);
+    GL_TRY(hipGetLastError());
+  }
+  if (nreg) {  // the index must actually prune: the mean list length seen at the component means (where the map points
+               // are) has to stay far below K, otherwise the plain sweep with scalar-operand records is faster
+    k_index_mean_lists<<<(nreg + 255) / 256, 256, 0, st>>>(d_regs, nreg, gg, d_ptr, d_cnt + 1);
+    GL_TRY(hipGetLastError());
+    GL_TRY(hipMemcpyAsync(&mean_sum, d_cnt + 1, 8, hipMemcpyDeviceToHost, st));
+  }
+  GL_TRY(hipStreamSynchronize(st));
+  cleanup();
+  // per evaluated pair the gather kernel is ~20x slower than the sweep (92 G vs 1.8 T pairs/s measured)
+  if (nreg > 0 && (double)mean_sum / nreg + (double)glob.size() > K / 24.0) {
+    (void)hipFree(d_ptr);
+    (void)hipFree(d_idx);
+    return GL_OK;
   }
   CellIndex& G = g->grid;
-  GL_HIP(hipSetDevice(g->device));
-  GL_HIP(hipMalloc((void**)&G.ptr, (ncell + 1) * 4));
-  GL_HIP(hipMalloc((void**)&G.idx, std::max<size_t>(idx.size(), 1) * 4));
+  G.ptr = d_ptr;
+  G.idx = d_idx;
   GL_HIP(hipMalloc((void**)&G.glob, std::max<size_t>(glob.size(), 1) * 4));
-  GL_HIP(hipMemcpy(G.ptr, ptr.data(), (ncell + 1) * 4, hipMemcpyHostToDevice));
-  if (!idx.empty()) GL_HIP(hipMemcpy(G.idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
   if (!glob.empty()) GL_HIP(hipMemcpy(G.glob, glob.data(), glob.size() * 4, hipMemcpyHostToDevice));
+#undef GL_TRY
   for (int a = 0; a < 3; ++a) {
     G.lo[a] = lo[a];
     G.dim[a] = dim[a];
@@ -329,7 +452,7 @@ int build_cell_index(Ctx* c, Gmm* g) {
   G.inv_h = 1.0 / h;
   G.t_resolve = T * (1.0 + 1e-6);
   G.nglob = (int)glob.size();
-  G.nnz = idx.size();
+  G.nnz = (size_t)nnz;
   G.ncell = ncell;
   G.enabled = true;
   return GL_OK;

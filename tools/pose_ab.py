@@ -1,14 +1,36 @@
-import os,sys,json
-sys.path.insert(0,os.getcwd())
+"""optimizeCurrentPose, large batches: one wave per frame against a wave per group (edges on chip), full frames of M edges
+and ragged ones (M_f ~ U{150..M}).   python tools/pose_ab.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gmmloc_amd
-from gmmloc_amd import api
-from tools.run_configs import v1_frames, pad_batch, ev_time
-ctx=gmmloc_amd.Context(0)
-for (seq,cap,lo,hi) in (("V1_03_difficult",100000,150,1200),("V1_01_easy",100000,300,300)):
-    mean,cov,cam,frames=v1_frames(seq,cap,lo,hi,3)
-    prm=api.Params()
-    pose,Xw,obs,octv=pad_batch(torch,frames,hi)
-    t=ev_time(torch,lambda: gmmloc_amd.optimize_current_pose(ctx,cam,prm,pose.clone(),Xw,obs,octv),3,ctx.stream)
-    big=[torch.cat([x]*8) for x in (pose,Xw,obs,octv)]
-    t8=ev_time(torch,lambda: gmmloc_amd.optimize_current_pose(ctx,cam,prm,big[0].clone(),big[1],big[2],big[3]),2,ctx.stream)
-    print(os.environ.get("GMMLOC_HIP_LIB","default").split("/")[-1], os.environ.get("GMMLOC_POSE_WAVES"), seq, len(frames), "frames/s", round(len(frames)/t), " x8 batch:", round(8*len(frames)/t8))
+from gmmloc_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz")); mean, cov = d["mean"], d["cov"]
+gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_02_medium"]
+cam, prm = api.Camera(), api.Params()
+ctx = gmmloc_amd.Context(0)
+dev = torch.device("cuda", 0)
+for M in (300, 600, 1000, 1200):
+    fr = [synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(gt[(100 + 17 * i) % gt.shape[0]]), cam, M, 50 + i) for i in range(64)]
+    for ragged in (False, True):
+        rng = np.random.default_rng(1)
+        for B in (2048, 4096):
+            fs = [fr[i % 64] for i in range(B)]
+            T = lambda k: torch.from_numpy(np.stack([f[k] for f in fs])).to(dev)
+            p0, x0, o, oc = T("pose_init"), T("Xw"), T("obs"), T("octave").clone()
+            if ragged:
+                for b in range(B):
+                    oc[b, int(rng.integers(150, M + 1)):] = -1
+            out = []
+            with torch.cuda.stream(ctx.stream):
+                for nw in (1, 0):
+                    ctx.set_option("pose_waves", nw)
+                    for _ in range(2):
+                        api.optimize_current_pose(ctx, cam, prm, p0.clone(), x0, o, oc)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(5):
+                        api.optimize_current_pose(ctx, cam, prm, p0.clone(), x0, o, oc)
+                    torch.cuda.synchronize()
+                    out.append((time.perf_counter() - t0) / 5 * 1e3)
+            print("M %4d %s B %4d: one wave per frame %.3f ms, auto %.3f ms" % (M, "ragged" if ragged else "full  ", B, out[0], out[1]), flush=True)
