@@ -297,15 +297,21 @@ static const AssocTune& assoc_tune() {
   return t;
 }
 static int assoc_minchunk() { return assoc_tune().chunk; }
-static void assoc_shape(int K, int N, int* ppt_o, int* ptiles_o, int* nsplit_o, int* kchunk_o) {
+// `listed`: the sweep of a point LIST whose length only the device knows (the points the cell index left unresolved,
+// typically 5 - 15 % of N).  The grid must cover N, but the shape is chosen for N / 16 points so that the few point
+// tiles that have work still make ~1 000 workgroups (config 5: 2 500 of 50 000 points x 65 536 Gaussians were 252
+// workgroups of 1 024 points, one per CU: 0.40 ms for a tenth of a millisecond of arithmetic).
+static void assoc_shape(int K, int N, bool listed, int* ppt_o, int* ptiles_o, int* nsplit_o, int* kchunk_o) {
   const int kChunk = assoc_minchunk();
+  const int Ne = listed ? std::max(N / 16, 256) : N;
   int ppt = 1;
-  if (N >= 8192) ppt = 2;
-  if (N >= 16384) ppt = 4;
+  if (Ne >= 8192) ppt = 2;
+  if (Ne >= 16384) ppt = 4;
   if (assoc_tune().ppt > 0) ppt = assoc_tune().ppt;  // tuning knob (1, 2 or 4)
   const int ptiles = (N + 256 * ppt - 1) / (256 * ppt);
-  const int target_blocks = (N >= 8192) ? 4096 : 512;
-  int nsplit = (target_blocks + ptiles - 1) / ptiles;
+  const int etiles = (Ne + 256 * ppt - 1) / (256 * ppt);  // tiles expected to have work
+  const int target_blocks = (Ne >= 8192) ? 4096 : (listed ? 1024 : 512);
+  int nsplit = (target_blocks + etiles - 1) / etiles;
   const int max_split = (K + 63) / 64;  // >= 64 Gaussians per split
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
@@ -319,9 +325,9 @@ static void assoc_shape(int K, int N, int* ppt_o, int* ptiles_o, int* nsplit_o, 
   *kchunk_o = kchunk;
 }
 
-size_t assoc_scratch_bytes(int K, int N) {
+size_t assoc_scratch_bytes(int K, int N, bool listed) {
   int ppt, ptiles, nsplit, kchunk;
-  assoc_shape(K, N, &ppt, &ptiles, &nsplit, &kchunk);
+  assoc_shape(K, N, listed, &ppt, &ptiles, &nsplit, &kchunk);
   return (size_t)nsplit * N * 12 + 64;
 }
 
@@ -331,12 +337,12 @@ int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
 }
 
 // all-pairs sweep of N points, or (list / count_dev given) of the listed subset; `scratch` (may be
-// NULL: taken from the context) must hold assoc_scratch_bytes(K, N)
+// NULL: taken from the context) must hold assoc_scratch_bytes(K, N, list != NULL)
 int launch_assoc_sweep(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, const int32_t* list,
                        const int32_t* count_dev, void* scratch) {
   const int K = g->K;
   int ppt, ptiles, nsplit, kchunk;
-  assoc_shape(K, N, &ppt, &ptiles, &nsplit, &kchunk);
+  assoc_shape(K, N, list != nullptr, &ppt, &ptiles, &nsplit, &kchunk);
   double* part_d2;
   int32_t* part_idx;
   if (nsplit > 1 || !d2 || list) {

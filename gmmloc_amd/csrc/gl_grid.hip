@@ -461,7 +461,7 @@ int build_cell_index(Ctx* c, Gmm* g) {
 // | count (64 B) | list N x 4 | (resolve_all: partial minima of the sweep) |
 static size_t index_list_bytes(int N) { return (((size_t)N * 4 + 64) + 63) / 64 * 64; }
 size_t assoc_index_scratch_bytes(int K, int N, bool resolve_all) {
-  return index_list_bytes(N) + (resolve_all ? assoc_scratch_bytes(K, N) : 0);
+  return index_list_bytes(N) + (resolve_all ? assoc_scratch_bytes(K, N, true) : 0);
 }
 
 static GridDev grid_dev(const CellIndex& I) {

@@ -154,7 +154,7 @@ void free_cell_index(Gmm* g);
 int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
 int launch_assoc_sweep(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, const int32_t* list,
                        const int32_t* count_dev, void* scratch);
-size_t assoc_scratch_bytes(int K, int N);
+size_t assoc_scratch_bytes(int K, int N, bool listed = false);
 int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, bool resolve_all,
                        void* scratch);
 size_t assoc_index_scratch_bytes(int K, int N, bool resolve_all);
