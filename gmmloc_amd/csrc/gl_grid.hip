@@ -13,7 +13,7 @@
 // sweep (GL_ASSOC_EXHAUSTIVE, k_assoc_brute) returns -- with ~10-20 instead of K evaluations
 // per point on the EuRoC maps and on the synthetic configs[1] map.
 //
-// Conservative registration (host, at gl_gmm_create), component k in cell C iff
+// Conservative registration (at gl_gmm_create; the O(K) set-up on the host, the enumeration on the device), component k in cell C iff
 //   (1) C overlaps the axis-aligned box  mu_k +- sqrt(T cov_ii)  (exact AABB of the ellipsoid), and
 //   (2) the cell centre c passes  (c-mu)^T ((1+1/b) T cov + (1+b) rho^2 I)^-1 (c-mu) <= 1  for
 //       b in {1/2, 1, 2}, rho = half diagonal of the cell: the outer ellipsoidal bound of
@@ -21,7 +21,7 @@
 // Rounding is covered by margins: T is inflated by 4e-6 for registration and by 1e-6 for the
 // "resolved" test, cells by 1e-9; components that are not SPD / finite, have a condition number
 // above 1e8 (where the computed chi2 may differ from the exact form by more than the margin) or
-// would cover more than 2^16 cells go to a short global list every point evaluates.
+// would cover more than 2^22 cells go to a short global list every point evaluates.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -300,7 +300,7 @@ int build_cell_index(Ctx* c, Gmm* g) {
     smax = std::max(smax, span[a]);
   }
   // finest power-of-two subdivision of the longest side within the cell / entry budgets
-  const double max_cells = 4.0e6, max_ins = 12.0e6;
+  const double max_cells = 16.0e6, max_ins = 12.0e6;
   double h = smax;
   for (int lvl = 1; lvl <= 10; ++lvl) {
     const double hc = smax / (double)(1 << lvl);
@@ -318,7 +318,7 @@ int build_cell_index(Ctx* c, Gmm* g) {
       for (int a = 0; a < 3; ++a) vol *= semi[(size_t)k * 3 + a] + rho_c;
       double box = 1.0;
       for (int a = 0; a < 3; ++a) box *= std::floor(2.0 * ext[(size_t)k * 3 + a] / hc) + 2.0;
-      ins += std::min(std::min(vol / (hc * hc * hc) + 1.0, box), 65536.0);
+      ins += std::min(std::min(vol / (hc * hc * hc) + 1.0, box), 4194304.0);
     }
     if (ins > max_ins) break;
     h = hc;
@@ -329,6 +329,8 @@ int build_cell_index(Ctx* c, Gmm* g) {
   const size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
   const double eps_idx = 1e-9;
   const double rho = h * std::sqrt(3.0) * 0.5 * (1.0 + 1e-9) + 1e-9 * smax;
+  double glob_cells = 4194304.0;  // boxes above 2^22 cells: evaluated for every point instead
+  if (const char* e = getenv("GMMLOC_ASSOC_GLOBCELLS")) glob_cells = atof(e);  // tuning knob
   std::vector<CompReg> regs;
   regs.reserve(K);
   const double betas[3] = {0.5, 1.0, 2.0};
@@ -348,7 +350,7 @@ int build_cell_index(Ctx* c, Gmm* g) {
       r.mu[a] = mu[a];
       ncells_k *= (double)r.n[a];
     }
-    if (ncells_k > 65536.0) {
+    if (ncells_k > glob_cells) {
       glob.push_back(k);
       continue;
     }
