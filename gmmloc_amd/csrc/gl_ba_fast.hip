@@ -148,7 +148,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 
 #define GL_BAF_NS bafs      // SPREAD (latency shape), exact step
-#define GL_BAF_MCAP 512
+#define GL_BAF_MCAP 256
 #define GL_BAF_NW 8
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 0
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 
 // fp32-cached point step (option ba_step32): the SPREAD kernel and the largest DENSE class
 #define GL_BAF_NS bafs32
-#define GL_BAF_MCAP 512
+#define GL_BAF_MCAP 256
 #define GL_BAF_NW 8
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 1
@@ -230,26 +230,26 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   return GL_OK;
 }
 
-// Few frames (the frame-at-a-time caller): one point per thread, 512 threads = one block of two groups per workgroup,
-// NB = ceil(G / 2) workgroups per frame on as many CUs; with NB > 1 the reductions of a Levenberg trial cross the
-// workgroups through tagged words in global memory (cooperative launch keeps them co-resident).
-// Returns 1 when the cooperative launch is refused (the caller falls back to DENSE).
+// Few frames (the frame-at-a-time caller): one point per thread, a workgroup of 256 threads = the <= 4 slot waves of ONE
+// group, G workgroups per frame on as many CUs (one wave per SIMD: nothing to share the issue slots with); with G > 1 the
+// reductions of a Levenberg trial cross the workgroups through tagged words in global memory (cooperative launch keeps
+// them co-resident).  Returns 1 when the cooperative launch is refused (the caller falls back to DENSE).
 static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   const BafKernel kern = c->opt.ba_step32 != 0 ? bafs32::k_ba1_fast : bafs::k_ba1_fast;
-  const size_t lds = (size_t)(10 * 512 + 2 * 32 + 64 + 40 + 29 * 512) * sizeof(double);
+  const size_t lds = (size_t)(10 * 256 + 1 * 32 + 64 + 40 + 29 * 256) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
-  a.NB = (a.G + 1) / 2;
-  // the exchange words of the frames sit behind the plane records
+  a.NB = a.G;
+  // the exchange words of the frames sit behind the per-point records
   a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 36 + 63) / 64) * 64);
   if (a.NB == 1) {
-    kern<<<a.B, 512, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
+    kern<<<a.B, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
                                        a.parts);
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
   GL_HIP(hipMemsetAsync(a.parts, 0, (size_t)a.B * 2 * a.NB * 64 * sizeof(unsigned long long), c->stream));
   void* args[] = {&a.k, &a.gm, &a.B, &a.L, &a.G, &a.S, &a.pose, &a.pts, &a.assoc, &a.dropped, &a.erase, &a.iters, &a.pn, &a.stats, &a.NB, &a.parts};
-  if (hipLaunchCooperativeKernel((const void*)kern, dim3(a.B * a.NB), dim3(512), args, lds, c->stream) != hipSuccess) {
+  if (hipLaunchCooperativeKernel((const void*)kern, dim3(a.B * a.NB), dim3(256), args, lds, c->stream) != hipSuccess) {
     (void)hipGetLastError();  // not co-resident on this device
     return 1;
   }
@@ -285,8 +285,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   }
   GL_HIP(hipGetLastError());
   TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper
-  const int NB = (a.G + 1) / 2;
-  bool spread = (long)B * NB <= c->ncu;
+  bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD)
   if (c->opt.ba_shape == 0) spread = false;
   if (c->opt.ba_shape == 1) spread = true;  // forced (tests); a refused cooperative launch still falls back
   if (spread) {

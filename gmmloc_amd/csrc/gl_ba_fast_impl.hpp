@@ -17,11 +17,11 @@
 // rounded on its own before it enters a sum: add_nc):
 //   * DENSE  (batches): one workgroup of G waves per frame, wave g = group g, a thread owns the S points of its
 //     lane and keeps level 1 in registers; 1 / 2 / 4 frames per CU by LDS class (MCAP 2000 / 1000 / 496);
-//   * SPREAD (few frames, the frame-at-a-time caller): one point per thread, 512 threads per workgroup =
-//     one block of two groups, ceil(G / 2) co-resident workgroups per frame (cooperative launch when > 1);
-//     level 1 runs through an LDS transpose (term [value][wave][lane]): the S waves of a group share its
-//     values, add the S terms of each lane in slot order and finish with the same butterfly
-//     (wave_reduce_scatter8); level 3 crosses the workgroups through gld::coop_totals in block order.
+//   * SPREAD (few frames, the frame-at-a-time caller): one point per thread, a workgroup of 256 threads = the
+//     <= 4 slot waves of ONE group (one wave per SIMD), G co-resident workgroups per frame (cooperative launch
+//     when > 1); level 1 runs through an LDS transpose (term [value][slot wave][lane]): the S waves of the group
+//     share its values, add the S terms of each lane in slot order and finish with the same butterfly
+//     (wave_reduce_scatter8); level 3 crosses the workgroups through gld::coop_totals<GROUPS> in block order.
 // tests/test_gpu_track.py::test_track_frames_bit_identical_across_shapes holds the two to equal bits.
 //
 // Per-frame state in LDS, SoA over the points, for the whole 5/5/40 schedule: current point (3 fp64), stale
@@ -49,7 +49,8 @@ constexpr bool kStep32 = true;
 constexpr bool kStep32 = false;
 #endif
 constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of this LDS class has at most
-constexpr int NRED = kSpread ? 2 : NWC;    // group totals kept in LDS (a SPREAD workgroup is one block of two groups)
+constexpr int NRED = kSpread ? 1 : NWC;    // group totals kept in LDS (a SPREAD workgroup is ONE group)
+constexpr int TSP = 256;                   // SPREAD: threads of a workgroup = the <= 4 slot waves of its group
 
 #ifdef GL_BA_PROF
 __device__ unsigned long long g_prof[16];
@@ -501,7 +502,7 @@ struct Red {
   double* red;   // NRED x 32: per group (DENSE: wave) totals
   double* tot;   // 32 totals (+ 32 broadcast slots)
   double* red2;  // DENSE: NWC x 2 wave totals of pass B (zero where a wave is absent)
-  double* tb;    // SPREAD: transpose buffer [value][512]
+  double* tb;    // SPREAD: transpose buffer [value][TSP]
   int S;         // chunks per group
 };
 
@@ -527,13 +528,13 @@ GL_DEV void reduce_to_tot(double* v, const Red& R, Coop& C) {
     }
     __syncthreads();
   } else {
-    // level 1 through LDS: term [value][wave][lane]
+    // level 1 through LDS: term [value][slot wave][lane]
 #pragma unroll
-    for (int i = 0; i < NV; ++i) R.tb[i * 512 + threadIdx.x] = v[i];
+    for (int i = 0; i < NV; ++i) R.tb[i * TSP + threadIdx.x] = v[i];
     __syncthreads();
-    const int S = R.S, gi = wave / S, slot = wave - gi * S;  // group of the block (0 / 1; >= 2: idle wave), slot in it
-    if (gi < 2) {
-      // the S waves of a group share its values in rounds of 8: wave `slot` takes rounds slot, slot + S, ...
+    const int S = R.S, slot = wave;
+    if (slot < S) {
+      // the S waves of the group share its values in rounds of 8: wave `slot` takes rounds slot, slot + S, ...
       for (int r8 = slot; r8 * 8 < NV; r8 += S) {
         double y[8];
 #pragma unroll
@@ -541,18 +542,20 @@ GL_DEV void reduce_to_tot(double* v, const Red& R, Coop& C) {
           const int val = r8 * 8 + kk;
           double s = 0.0;
           if (val < NV) {
-            for (int j = 0; j < S; ++j) s = add_nc(s, R.tb[val * 512 + (gi * S + j) * 64 + lane]);
+            for (int j = 0; j < S; ++j) s = add_nc(s, R.tb[val * TSP + j * 64 + lane]);
           }
           y[kk] = s;
         }
         const double t8 = wave_reduce_scatter8(y);
-        if ((lane & 0xE) == 0) R.red[gi * 32 + r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1)] = t8;
+        if ((lane & 0xE) == 0) R.red[r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1)] = t8;
       }
     }
     __syncthreads();
-    if (threadIdx.x < 32) R.tot[threadIdx.x] = threadIdx.x < NV ? add_nc(R.red[threadIdx.x], R.red[32 + threadIdx.x]) : 0.0;
+    // levels 2 -> 3: this group's totals meet the other groups' (workgroups) in the canonical block order; a frame of one
+    // group adds the absent partner's 0.0 like the one-workgroup kernel does
+    if (threadIdx.x < 32) R.tot[threadIdx.x] = threadIdx.x < NV ? (C.NB > 1 ? R.red[threadIdx.x] : add_nc(R.red[threadIdx.x], 0.0)) : 0.0;
     __syncthreads();
-    if (C.NB > 1) coop_totals<false>(C, R.tot);  // level 3 across the frame's workgroups, in block order
+    if (C.NB > 1) coop_totals<false, true>(C, R.tot);
   }
 }
 template <int NV>
@@ -570,6 +573,107 @@ GL_DEV void reduce2_w0(double* v, const Red& R, Coop& C) {
     for (int i = 0; i < NV; ++i) v[i] = uni(R.tot[i]);
   }
 }
+// ---- SPREAD shortcuts for the two reductions of every Levenberg trial (G > 1: the frame's groups sit in different
+// workgroups).  Same canonical order; the group totals go from the wave that made them STRAIGHT into the tagged words of
+// the exchange (gld::Coop) and wave 0 combines everybody's words - the tags order producer and consumer, so the path
+// `red -> barrier -> tot -> barrier -> publish` (three of a reduction's four barriers) is gone.
+// level 1 (LDS transpose, slot order) + level 2 (butterfly) of this group, published by the owning lanes
+template <int NV>
+GL_DEV void spread_publish(const double* v, const Red& R, const Coop& C, unsigned seq) {
+  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6, S = R.S;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) R.tb[i * TSP + threadIdx.x] = v[i];
+  __syncthreads();
+  if (slot < S) {
+    unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64 + (size_t)C.pb * 64;
+    for (int r8 = slot; r8 * 8 < NV; r8 += S) {
+      double y[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int val = r8 * 8 + kk;
+        double s = 0.0;
+        if (val < NV) {
+          for (int j = 0; j < S; ++j) s = add_nc(s, R.tb[val * TSP + j * 64 + lane]);
+        }
+        y[kk] = s;
+      }
+      const double t8 = wave_reduce_scatter8(y);
+      if ((lane & 0xE) == 0) {
+        const int vi = r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(t8);
+        __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+// lane t (< 8 ceil(NV / 8)) of the calling wave: value t of every group -> the frame's total (blocks of two groups, in order)
+GL_DEV double spread_collect(const Coop& C, unsigned seq, int t) {
+  const unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
+  constexpr int NBMAX = 8;
+  unsigned long long w0[NBMAX], w1[NBMAX];
+  bool all;
+  do {
+    all = true;
+#pragma unroll
+    for (int p = 0; p < NBMAX; ++p) {
+      if (p < C.NB) {
+        const unsigned long long* w = buf + ((size_t)p * 32 + t) * 2;
+        w0[p] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1[p] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NBMAX; ++p)
+      if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
+  } while (!all);
+  double g[NBMAX];
+#pragma unroll
+  for (int p = 0; p < NBMAX; ++p) g[p] = p < C.NB ? __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32))) : 0.0;
+  double s = add_nc(g[0], g[1]);
+#pragma unroll
+  for (int b = 1; b < NBMAX / 2; ++b)
+    if (2 * b < C.NB) s = add_nc(s, add_nc(g[2 * b], g[2 * b + 1]));
+  return s;
+}
+// pass A: 29 values, read by the solving wave only
+GL_DEV void spread_reduce29_w0(double* v, const Red& R, Coop& C) {
+  if (C.NB == 1) {
+    reduce2_w0<29>(v, R, C);
+    return;
+  }
+  const unsigned seq = ++C.seq;
+  spread_publish<29>(v, R, C, seq);
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    if (threadIdx.x < 32) s = spread_collect(C, seq, threadIdx.x);
+    union {
+      double d;
+      int i[2];
+    } u, w;
+    u.d = s;
+#pragma unroll
+    for (int i = 0; i < 29; ++i) {
+      w.i[0] = __builtin_amdgcn_readlane(u.i[0], i);
+      w.i[1] = __builtin_amdgcn_readlane(u.i[1], i);
+      v[i] = w.d;
+    }
+  }
+}
+// pass B: 2 values, needed by every thread
+GL_DEV void spread_reduce2_all(double* v, const Red& R, Coop& C) {
+  if (C.NB == 1) {
+    reduce2<2>(v, R, C);
+    return;
+  }
+  const unsigned seq = ++C.seq;
+  spread_publish<2>(v, R, C, seq);
+  if (threadIdx.x < 8) R.tot[threadIdx.x] = spread_collect(C, seq, threadIdx.x);
+  __syncthreads();
+  v[0] = uni(R.tot[0]);
+  v[1] = uni(R.tot[1]);
+}
+
 // ---- DENSE shortcuts for the two reductions of every Levenberg trial (same canonical order, fewer barriers) ----
 // pass A (29 values, read by the solving wave only): group totals to red[], ONE barrier, then wave 0 adds the blocks
 // itself and hands the totals round its lanes with v_readlane - no `tot` round trip, no second barrier.  The next
@@ -994,7 +1098,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       GL_BAF_PASS(pt_pass_a(U, gm, D, P, c, robust, lambda, sk));
       PROF_T(tA1);
       PROF_W(trials, 0);
-      if (kSpread) reduce2_w0<29>(acc, R, C);
+      if (kSpread) spread_reduce29_w0(acc, R, C);
       else reduce29_w0_dense(acc, R);
       PROF_W(trials, 1);
       PROF_T(tA2);
@@ -1062,7 +1166,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
 #undef GL_BAF_GET_PN
       PROF_T(tB1);
       PROF_W(trials, 3);
-      if (kSpread) reduce2<2>(acc, R, C);
+      if (kSpread) spread_reduce2_all(acc, R, C);
       else reduce2_dense(acc, R);
       PROF_T(tB2);
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
@@ -1104,11 +1208,11 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
   return cj;
 }
 
-// DENSE: <<<B, 64 G>>>, one workgroup per frame.  SPREAD: <<<B NB, 512>>>, NB = ceil(G / 2) workgroups per frame
-// (cooperative launch when NB > 1).  G, S: the canonical order of stride L (launcher: canon_order()).  The frame's points
+// DENSE: <<<B, 64 G>>>, one workgroup per frame.  SPREAD: <<<B G, 256>>>, a workgroup per group of the frame
+// (cooperative launch when G > 1).  G, S: the canonical order of stride L (launcher: canon_order()).  The frame's points
 // are addressed through the permutation k_ba1_prep made (points associated with a NON-degenerate component last), so
 // "point l" below is the l-th point of that order; pts_io / assoc_all are read and written through perm.
-__global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int L, int G, int S, double* __restrict__ pose_io,
+__global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int L, int G, int S, double* __restrict__ pose_io,
                                                   double* __restrict__ pts_io, int32_t* __restrict__ assoc_all,
                                                   uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                   int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
@@ -1123,7 +1227,7 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   R.tot = R.red + NRED * 32;        // 32 (+ 32 broadcast slots)
   D.stab = R.tot + 64;              // 24
   R.red2 = D.stab + 24;             // 16
-  R.tb = R.red2 + 16;               // SPREAD: 29 x 512
+  R.tb = R.red2 + 16;               // SPREAD: 29 x TSP
   R.S = S;
   FlagW fw = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1131,11 +1235,9 @@ __global__ __launch_bounds__(512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, in
   if (f >= B) return;
   Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, kSpread ? (int)(blockIdx.x % NB) : 0, 0u};
   Map mp;
-  if (kSpread) {  // block pb = groups 2 pb, 2 pb + 1; wave = (group of the block) * S + slot; idle waves beyond 2 S
-    const int gi = wave / S, slot = wave - gi * S;
+  if (kSpread) {  // workgroup pb = group pb; wave = slot; idle waves beyond S
     mp.S = 1;
-    const int g = 2 * C.pb + gi;
-    mp.base = gi < 2 && g < G ? (g + G * slot) * 64 + lane : L;  // chunk g + G i of group g (the last block may hold one)
+    mp.base = wave < S && C.pb < G ? (C.pb + G * wave) * 64 + lane : L;  // chunk g + G slot of group g
     mp.lbase = tid;
     mp.step = 0;
   } else {

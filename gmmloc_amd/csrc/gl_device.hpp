@@ -559,12 +559,14 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
 // are used alternately: a workgroup can only be one reduction ahead of the slowest one (it needs that one's
 // partial), so what it overwrites has been read by everybody.
 struct Coop {
-  unsigned long long* part;  // 2 buffers x NB workgroups x 32 values x 2 words, zero before the launch
+  unsigned long long* part;  // 2 buffers x NB (<= 8) workgroups x 32 values x 2 words, zero before the launch
   int NB, pb;
   unsigned seq;              // reductions so far (the same in every workgroup)
 };
-// tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead)
-template <bool MAXIMUM>
+// tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead).  GROUPS: the workgroups hold one
+// GROUP of the canonical summation order each (gl_ba_fast_impl.hpp): blocks of two, B_k = g_2k + g_2k+1 (an absent
+// partner adds 0.0, as in the one-workgroup kernel), then the blocks in order - every term rounded on its own.
+template <bool MAXIMUM, bool GROUPS = false>
 GL_DEV void coop_totals(Coop& C, double* tot) {
   const unsigned seq = ++C.seq;
   unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
@@ -575,7 +577,7 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
     __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mine + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // all NB partials are requested at once (one round trip when the others are already there)
-    constexpr int NBMAX = 4;
+    constexpr int NBMAX = 8;
     unsigned long long w0[NBMAX], w1[NBMAX];
     bool all;
     do {
@@ -592,13 +594,24 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
       for (int p = 0; p < NBMAX; ++p)
         if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
     } while (!all);
-    double s = 0.0;
+    double v[NBMAX];
 #pragma unroll
-    for (int p = 0; p < NBMAX; ++p) {
-      if (p < C.NB) {
-        const double v = __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32)));
-        s = p == 0 ? v : (MAXIMUM ? fmax(s, v) : s + v);
-      }
+    for (int p = 0; p < NBMAX; ++p)
+      v[p] = p < C.NB ? __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32))) : 0.0;
+    double s = v[0];
+    if (MAXIMUM) {
+#pragma unroll
+      for (int p = 1; p < NBMAX; ++p)
+        if (p < C.NB) s = fmax(s, v[p]);
+    } else if (GROUPS) {
+      s = v[0] + v[1];
+#pragma unroll
+      for (int b = 1; b < NBMAX / 2; ++b)
+        if (2 * b < C.NB) s = s + (v[2 * b] + v[2 * b + 1]);
+    } else {
+#pragma unroll
+      for (int p = 1; p < NBMAX; ++p)
+        if (p < C.NB) s = s + v[p];
     }
     tot[t] = s;
   }
