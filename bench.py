@@ -52,8 +52,9 @@ def measured_traffic(kernel, frames_per_launch):
     WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
     frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
     None when the summary is missing: bench.py itself cannot run under two profilers."""
-    for name in ("r2c_traffic.json", "r2_traffic.json", "r1k_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):  # the latest summary that has it
+        name = os.path.basename(path)
         if os.path.exists(path):
             with open(path) as f:
                 t = json.load(f).get(kernel)
