@@ -21,7 +21,7 @@
 //     <= 4 slot waves of ONE group (one wave per SIMD), G co-resident workgroups per frame (cooperative launch
 //     when > 1); level 1 runs through an LDS transpose (term [value][slot wave][lane]): the S waves of the group
 //     share its values, add the S terms of each lane in slot order and finish with the same butterfly
-//     (wave_reduce_scatter8); level 3 crosses the workgroups through gld::coop_totals<GROUPS> in block order.
+//     (wave_reduce_scatter8); level 3 crosses the workgroups as tagged words (gld::Coop) in block order.
 // tests/test_gpu_track.py::test_track_frames_bit_identical_across_shapes holds the two to equal bits.
 //
 // Per-frame state in LDS, SoA over the points, for the whole 5/5/40 schedule: current point (3 fp64), stale
@@ -555,7 +555,7 @@ GL_DEV void reduce_to_tot(double* v, const Red& R, Coop& C) {
     // group adds the absent partner's 0.0 like the one-workgroup kernel does
     if (threadIdx.x < 32) R.tot[threadIdx.x] = threadIdx.x < NV ? (C.NB > 1 ? R.red[threadIdx.x] : add_nc(R.red[threadIdx.x], 0.0)) : 0.0;
     __syncthreads();
-    if (C.NB > 1) coop_totals<false, true>(C, R.tot);
+    if (C.NB > 1) coop_totals<false>(C, R.tot);
   }
 }
 template <int NV>

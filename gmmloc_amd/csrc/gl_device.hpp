@@ -550,7 +550,7 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
 }
 
 // ---- exchange of 32 partial sums between the NB co-resident workgroups that share one problem ---------------
-// (latency shapes of the refine and pose kernels: cooperative launch).  No barrier and no fence: a workgroup
+// (latency shape of the structure refine: cooperative launch).  No barrier and no fence: a workgroup
 // publishes its 32 sums as 64-bit words {32 bits of the value | sequence number of the reduction} with
 // device-scope atomic stores, and reads everybody's words (its own included) with device-scope atomic loads until
 // both halves of every value carry the current sequence number - one memory round trip when the others are
@@ -563,10 +563,10 @@ struct Coop {
   int NB, pb;
   unsigned seq;              // reductions so far (the same in every workgroup)
 };
-// tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead).  GROUPS: the workgroups hold one
-// GROUP of the canonical summation order each (gl_ba_fast_impl.hpp): blocks of two, B_k = g_2k + g_2k+1 (an absent
-// partner adds 0.0, as in the one-workgroup kernel), then the blocks in order - every term rounded on its own.
-template <bool MAXIMUM, bool GROUPS = false>
+// tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead).  The workgroups hold one GROUP
+// of the canonical summation order each (gl_ba_fast_impl.hpp): blocks of two, B_k = g_2k + g_2k+1 (an absent partner
+// adds 0.0, as in the one-workgroup kernel), then the blocks in order - every term rounded on its own.
+template <bool MAXIMUM>
 GL_DEV void coop_totals(Coop& C, double* tot) {
   const unsigned seq = ++C.seq;
   unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
@@ -603,15 +603,11 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
 #pragma unroll
       for (int p = 1; p < NBMAX; ++p)
         if (p < C.NB) s = fmax(s, v[p]);
-    } else if (GROUPS) {
+    } else {
       s = v[0] + v[1];
 #pragma unroll
       for (int b = 1; b < NBMAX / 2; ++b)
         if (2 * b < C.NB) s = s + (v[2 * b] + v[2 * b + 1]);
-    } else {
-#pragma unroll
-      for (int p = 1; p < NBMAX; ++p)
-        if (p < C.NB) s = s + v[p];
     }
     tot[t] = s;
   }
