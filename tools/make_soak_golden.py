@@ -19,9 +19,12 @@ from tools import soak_cases as sc
 
 # (kind, map, round, index of the deviating feature / match within the round's problem)
 TRACK = [("map_v2", 736), ("map_v1", 1572)]
-BA = [333]
+BA = [333, 807]
 FALLBACK = [("map_v1", 852, 33), ("map_v2", 79, 547), ("map_v2", 323, 2), ("map_v2", 903, 323)]
 TRI = [("map_v1", 693, 80), ("map_v1", 1475, 81), ("map_v1", 1533, 145), ("map_v2", 630, 267)]
+# matches that every implementation REJECTS (type 0: no map point is created) but whose by-products - the last candidate
+# optimizeTriangulationVec settled on, the point it left behind - differ: found by the 6 000-round soak
+TRI_REJECTED = [("map_v1", 3986, 273), ("map_v2", 2703, 15)]
 
 
 def main():
@@ -67,7 +70,7 @@ def main():
                                               mean, nbs, ncam, nprm)
         out["fallback_%s_r%d_f%d" % (mapname, r, j)] = np.concatenate([[c_np], p_np])
         print("fallback", mapname, r, j, c_np, p_np, flush=True)
-    for mapname, r, j in TRI:
+    for mapname, r, j in TRI + TRI_REJECTED:
         mean, cov, h, comps = maps[mapname]
         m = sc.gen(mapname, r, mean, cov, gts, cam)["tri"]
         pt, t, c = nr.create_map_point(m["pose1"][j], m["uvr1"][j], m["depth1"][j], int(m["oct1"][j]), m["pose2"][j], m["uvr2"][j], m["depth2"][j],

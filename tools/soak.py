@@ -34,7 +34,7 @@ ctx = gmmloc_amd.Context(0)
 cam, prm = api.Camera(), api.Params()
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 gts = sc.load_gt()
-count = dict(chain=0, chain_fallback=0, tri=0, tri_far=0, track=0, pose=0, ba=0)
+count = dict(chain=0, chain_fallback=0, tri=0, tri_rejected=0, tri_far=0, track=0, pose=0, ba=0)
 checked = dict(chain=0, tri=0, track=0, pose=0, ba=0)
 t0 = time.time()
 
@@ -87,9 +87,15 @@ for mapname in args.maps.split(","):
             far = ~((np.linalg.norm(x_ref, axis=1) < 100.0) & (np.linalg.norm(np.nan_to_num(xg, nan=1e9), axis=1) < 100.0))
         acc = t_ref > 0
         checked["tri"] += 1
-        dec = (tg != t_ref) | (cg != cc_ref)
+        # the component is an output only where a map point is created: a match BOTH sides reject (type 0) leaves the last
+        # candidate of optimizeTriangulationVec behind, a by-product counted separately (tri_rejected)
+        rej = (tg == 0) & (t_ref == 0)
+        dec = (tg != t_ref) | ((cg != cc_ref) & ~rej)
         with np.errstate(invalid="ignore"):
             num = acc & (tg == t_ref) & ~(np.abs(xg - x_ref).max(1) <= 1e-8)
+        if (rej & (cg != cc_ref))[~far].any():
+            report("tri_rejected", mapname, r, "%d rejected match(es) within 100 m left a different candidate behind" % int((rej & (cg != cc_ref))[~far].sum()),
+                   x_gpu=xg, type_gpu=tg, comp_gpu=cg)
         if (dec | num)[~far].any():
             report("tri", mapname, r, "%d decision(s), %d point(s) differ among the %d matches within 100 m"
                    % (int(dec[~far].sum()), int(num[~far].sum()), int((~far).sum())), x_gpu=xg, type_gpu=tg, comp_gpu=cg)
