@@ -471,7 +471,7 @@ int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm,
 // fast path: plane records (32 B) + normalised observations (24 B) + permutation, flags, gated association (12 B) per
 // point; general kernel: trial points, chi2, levels (33 B); + per frame: 2 x 4 x 32 x 2 exchange words of the latency
 // shape (gl_ba_fast.hip)
-size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 36 + (size_t)B * 8192 + 512; }
+size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 36 + (size_t)B * (8192 + 8) + 512; }
 
 }  // namespace gl
 

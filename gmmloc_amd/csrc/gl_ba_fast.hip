@@ -196,7 +196,7 @@ static void canon_order(int L, int* G, int* S) {
 }
 
 typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*);
+                          unsigned long long*, int*, long long);
 
 struct BafArgs {
   BaK k;
@@ -213,6 +213,7 @@ struct BafArgs {
   int32_t* stats;
   int NB;
   unsigned long long* parts;
+  int* ctl = nullptr;  // per frame {abort, done} of a latency-shape launch (the follow-up DENSE launch skips the done ones)
 };
 
 // one workgroup of G waves per frame; LDS class by stride (4 / 2 / 1 frames per CU)
@@ -225,35 +226,44 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   a.NB = 1;
   a.parts = nullptr;
   kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts);
+                                          a.NB, a.parts, a.ctl, 0ll);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
 
 // Few frames (the frame-at-a-time caller): one point per thread, a workgroup of 256 threads = the <= 4 slot waves of ONE
 // group, G workgroups per frame on as many CUs (one wave per SIMD: nothing to share the issue slots with); with G > 1 the
-// reductions of a Levenberg trial cross the workgroups through tagged words in global memory (cooperative launch keeps
-// them co-resident).  Returns 1 when the cooperative launch is refused (the caller falls back to DENSE).
+// reductions of a Levenberg trial cross the workgroups through tagged words in global memory.  That needs the workgroups
+// of a frame co-resident.  A cooperative launch guarantees it and costs 31 us per call here (0.463 vs 0.432 ms for one
+// frame); the kernel is launched plainly instead, with the rendezvous protocol of gld::Coop: a frame whose workgroups do not
+// all show up within the time limit (another launch holds the CUs and waits for its own) gives up without writing
+// anything, and the one-workgroup kernel that follows redoes exactly those frames - same bits, so the caller never sees
+// which kernel answered.  Returns 1 when the shape does not fit the device at all (the caller goes DENSE).
 static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   const BafKernel kern = c->opt.ba_step32 != 0 ? bafs32::k_ba1_fast : bafs::k_ba1_fast;
   const size_t lds = (size_t)(10 * 256 + 1 * 32 + 64 + 40 + 29 * 256) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = a.G;
-  // the exchange words of the frames sit behind the per-point records
+  {  // all the workgroups of the launch must fit the device at once (the occupancy answer is cached per context)
+    const auto key = std::make_pair((const void*)kern, lds);
+    auto hit = c->occupancy.find(key);
+    if (hit == c->occupancy.end()) {
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds) != hipSuccess) occ = 0;
+      hit = c->occupancy.emplace(key, occ).first;
+    }
+    if ((long)a.B * a.NB > (long)hit->second * c->ncu) return 1;
+  }
+  // the exchange words of the frames sit behind the per-point records, {abort, done} per frame behind them
   a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 36 + 63) / 64) * 64);
-  if (a.NB == 1) {
-    kern<<<a.B, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                       a.parts);
-    GL_HIP(hipGetLastError());
-    return GL_OK;
-  }
-  GL_HIP(hipMemsetAsync(a.parts, 0, (size_t)a.B * 2 * a.NB * 64 * sizeof(unsigned long long), c->stream));
-  void* args[] = {&a.k, &a.gm, &a.B, &a.L, &a.G, &a.S, &a.pose, &a.pts, &a.assoc, &a.dropped, &a.erase, &a.iters, &a.pn, &a.stats, &a.NB, &a.parts};
-  if (hipLaunchCooperativeKernel((const void*)kern, dim3(a.B * a.NB), dim3(256), args, lds, c->stream) != hipSuccess) {
-    (void)hipGetLastError();  // not co-resident on this device
-    return 1;
-  }
-  return GL_OK;
+  const size_t words = (size_t)a.B * 2 * a.NB * 64;
+  a.ctl = (int*)(a.parts + words);
+  GL_HIP(hipMemsetAsync(a.parts, 0, words * sizeof(unsigned long long) + (size_t)a.B * 2 * sizeof(int), c->stream));
+  const long long limit = (long long)(c->opt.ba_rendezvous_us * 100.0);  // wall_clock64() ticks at 100 MHz
+  kern<<<a.B * a.NB, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
+                                            a.parts, a.ctl, limit);
+  GL_HIP(hipGetLastError());
+  return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }
 
 // Shape: SPREAD when every workgroup of the batch gets a CU of its own (B NB <= CUs: the frame-at-a-time
@@ -285,12 +295,13 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   }
   GL_HIP(hipGetLastError());
   TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper
-  bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD)
+  bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD; checked in launch_spread)
   if (c->opt.ba_shape == 0) spread = false;
   if (c->opt.ba_shape == 1) spread = true;  // forced (tests); a refused cooperative launch still falls back
   if (spread) {
     const int rc = launch_spread(c, a, scratch);
     if (rc <= 0) return rc;
+    if (rc == 1) a.ctl = nullptr;  // shape does not fit: every frame goes DENSE
   }
   return launch_dense(c, a);
 }

@@ -598,7 +598,7 @@ GL_DEV void spread_publish(const double* v, const Red& R, const Coop& C, unsigne
         y[kk] = s;
       }
       const double t8 = wave_reduce_scatter8(y);
-      if ((lane & 0xE) == 0) {
+      if ((lane & 0xE) == 0 && !C.failed) {
         const int vi = r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(t8);
         __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -609,10 +609,11 @@ GL_DEV void spread_publish(const double* v, const Red& R, const Coop& C, unsigne
 }
 // lane t (< 8 ceil(NV / 8)) of the calling wave: value t of every group -> the frame's total (blocks of two groups, in order)
 GL_DEV double spread_collect(const Coop& C, unsigned seq, int t) {
+  if (C.failed) return 0.0;
   const unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
   constexpr int NBMAX = 8;
   unsigned long long w0[NBMAX], w1[NBMAX];
-  bool all;
+  bool all, off = false;
   do {
     all = true;
 #pragma unroll
@@ -626,7 +627,9 @@ GL_DEV double spread_collect(const Coop& C, unsigned seq, int t) {
 #pragma unroll
     for (int p = 0; p < NBMAX; ++p)
       if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
-  } while (!all);
+    if (!all) off = coop_give_up(C, seq, 0);  // (never the first exchange of a launch: no time limit here)
+  } while (!all && !off);
+  if (off) *C.lds_fail = 1;
   double g[NBMAX];
 #pragma unroll
   for (int p = 0; p < NBMAX; ++p) g[p] = p < C.NB ? __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32))) : 0.0;
@@ -647,6 +650,7 @@ GL_DEV void spread_reduce29_w0(double* v, const Red& R, Coop& C) {
   if (threadIdx.x < 64) {
     double s = 0.0;
     if (threadIdx.x < 32) s = spread_collect(C, seq, threadIdx.x);
+    C.failed |= __builtin_amdgcn_readfirstlane(*(volatile int*)C.lds_fail);  // the other waves learn it behind pass B's barrier
     union {
       double d;
       int i[2];
@@ -670,6 +674,7 @@ GL_DEV void spread_reduce2_all(double* v, const Red& R, Coop& C) {
   spread_publish<2>(v, R, C, seq);
   if (threadIdx.x < 8) R.tot[threadIdx.x] = spread_collect(C, seq, threadIdx.x);
   __syncthreads();
+  C.failed |= *C.lds_fail;
   v[0] = uni(R.tot[0]);
   v[1] = uni(R.tot[1]);
 }
@@ -1216,7 +1221,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   double* __restrict__ pts_io, int32_t* __restrict__ assoc_all,
                                                   uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                   int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
-                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts) {
+                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1233,7 +1238,9 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = kSpread ? blockIdx.x / NB : blockIdx.x;
   if (f >= B) return;
-  Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, kSpread ? (int)(blockIdx.x % NB) : 0, 0u};
+  if (!kSpread && ctl && ctl[2 * f + 1]) return;  // follow-up of a latency-shape launch: this frame completed there
+  Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, kSpread ? (int)(blockIdx.x % NB) : 0, 0u,
+         ctl ? ctl + 2 * f : nullptr, (int*)(R.tot + 61), limit, 0};
   Map mp;
   if (kSpread) {  // workgroup pb = group pb; wave = slot; idle waves beyond S
     mp.S = 1;
@@ -1257,7 +1264,10 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   const Uni U{uni(k.bf / k.fx), uni(k.ba_lambda2)};
   for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
   if (tid < 16) R.red2[tid] = 0.0;
-  if (tid == 0) *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
+  if (tid == 0) {
+    *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
+    *(int*)(R.tot + 61) = 0;  // a poll of the exchange gave up (SPREAD)
+  }
   {
     const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
@@ -1319,6 +1329,11 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     __syncthreads();
   }
 
+  if (kSpread && C.NB > 1) {  // a frame whose workgroups did not all meet writes nothing: the follow-up launch redoes it
+    __syncthreads();
+    C.failed |= *C.lds_fail;
+    if (C.failed) return;
+  }
 #pragma unroll 1
   for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
     const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
@@ -1353,6 +1368,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     se3_store(T, pose_io + (size_t)f * 7);
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
+    if (kSpread && C.ctl) C.ctl[1] = 1;  // done
 #ifdef GL_BA_PROF
     if (f == 0) {  // debug build only: phase cycles instead of pose 0, per-wave markers instead of the points of frame 0
       for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections

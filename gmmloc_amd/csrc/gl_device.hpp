@@ -558,11 +558,31 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
 // barrier.  The partials are added in workgroup order, so every workgroup ends with the same bits.  Two buffers
 // are used alternately: a workgroup can only be one reduction ahead of the slowest one (it needs that one's
 // partial), so what it overwrites has been read by everybody.
+// The workgroups of a problem must be co-resident for this to terminate.  A cooperative launch guarantees it but costs
+// ~30 us per launch on this stack; the kernels are launched plainly and protect themselves instead: the FIRST exchange of
+// a launch is a rendezvous with a time limit - a workgroup whose siblings do not show up (they are queued behind another
+// launch that is itself waiting for ITS siblings) raises the problem's abort word and leaves; every later poll watches that
+// word, so a problem either completes in all its workgroups or in none, and nothing is written unless it completed (the
+// launcher follows up with the one-workgroup kernel for the problems whose `done` word stayed 0: same bits by construction).
+// Once all workgroups of a problem have met they stay resident until they exit, so later polls need no limit.
 struct Coop {
   unsigned long long* part;  // 2 buffers x NB (<= 8) workgroups x 32 values x 2 words, zero before the launch
   int NB, pb;
   unsigned seq;              // reductions so far (the same in every workgroup)
+  int* ctl;                  // global {abort, done} of the problem, zero before the launch
+  int* lds_fail;             // LDS word: a poll of this workgroup failed (read by everybody behind the next barrier)
+  long long limit;           // rendezvous time limit in wall_clock64() ticks (100 MHz)
+  int failed;                // this thread knows the problem is off
 };
+// poll helper of the exchange loops: true = give up (abort raised by a sibling, or the rendezvous timed out)
+GL_DEV bool coop_give_up(const Coop& C, unsigned seq, long long t0) {
+  if (__hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+  if (seq == 1u && (long long)wall_clock64() - t0 > C.limit) {
+    __hip_atomic_store(C.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return false;
+}
 // tot[0..31]: this workgroup's sums (LDS) -> the frame's sums (MAXIMUM: maxima instead).  The workgroups hold one GROUP
 // of the canonical summation order each (gl_ba_fast_impl.hpp): blocks of two, B_k = g_2k + g_2k+1 (an absent partner
 // adds 0.0, as in the one-workgroup kernel), then the blocks in order - every term rounded on its own.
@@ -571,7 +591,7 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
   const unsigned seq = ++C.seq;
   unsigned long long* buf = C.part + (size_t)(seq & 1u) * C.NB * 64;
   const int t = threadIdx.x;
-  if (t < 32) {
+  if (t < 32 && !C.failed) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[t]);
     unsigned long long* mine = buf + ((size_t)C.pb * 32 + t) * 2;
     __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -579,7 +599,8 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
     // all NB partials are requested at once (one round trip when the others are already there)
     constexpr int NBMAX = 8;
     unsigned long long w0[NBMAX], w1[NBMAX];
-    bool all;
+    bool all, off = false;
+    const long long t0 = seq == 1u ? (long long)wall_clock64() : 0;
     do {
       all = true;
 #pragma unroll
@@ -593,7 +614,9 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
 #pragma unroll
       for (int p = 0; p < NBMAX; ++p)
         if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
-    } while (!all);
+      if (!all) off = coop_give_up(C, seq, t0);
+    } while (!all && !off);
+    if (off) *C.lds_fail = 1;
     double v[NBMAX];
 #pragma unroll
     for (int p = 0; p < NBMAX; ++p)
@@ -612,6 +635,7 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
     tot[t] = s;
   }
   __syncthreads();
+  C.failed |= *C.lds_fail;
 }
 
 }  // namespace gld

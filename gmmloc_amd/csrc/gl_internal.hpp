@@ -83,6 +83,7 @@ struct Options {
   double ba_step32 = 0;         // 1: point step from an fp32 cache of the pass-A solve (faster, not the default)
   double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
   double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame
+  double ba_rendezvous_us = 50000;  // time limit of the latency shape's rendezvous (0: every frame gives up -> follow-up kernel; tests)
   double pose_regs = 1;         //   0: the frame-at-a-time shapes read their edges from global memory every trial (A/B)
   double bagen_nb = 0;          // gl_joint_optimization: 0 auto, n workgroups per problem
   double view_slot_lds = 0;     // gl_search2d: accepted-list records kept in LDS (0 = all that fit)

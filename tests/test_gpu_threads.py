@@ -63,3 +63,55 @@ def test_two_contexts_two_threads(gpu, map_v1, gt_sync):
         for r in results[name]:
             for x, y in zip(ref[0], r):
                 assert np.array_equal(x, y, equal_nan=True), name
+
+
+def test_two_contexts_oversubscribe_the_latency_shape(gpu, map_v1, gt_sync):
+    """Two host threads launch latency-shape refines that EACH want every workgroup slot of the chip (60 frames x 8
+    workgroups = 480 of 512) on their own streams, again and again: neither launch can be fully resident while the
+    other one is, which is the case a cooperative launch exists for.  The plain launches survive it through the
+    rendezvous protocol (frames whose workgroups do not meet within the limit give up untouched, the follow-up kernel
+    redoes them): no hang, and every result equals the single-context one bit for bit."""
+    torch, ctx0 = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx0, mean, cov)
+    frames = make_frames(mean, cov, gt_sync["V1_03_difficult"], cam, 6, 2000, 991, outlier_frac=0.05)
+    frames = [frames[i % 6] for i in range(60)]
+
+    def work(ctx, reps):
+        T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
+        obs, octv = T("obs"), T("octave")
+        out = []
+        for rep in range(reps):
+            pose, Xw = T("pose_init"), T("Xw")
+            assoc, _ = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, obs, octv, want_d2=False)
+            ctx.synchronize()
+            out.append([x.cpu().numpy() for x in (pose, Xw, assoc)])
+        return out
+
+    ctx0.set_option("ba_shape", 0)
+    ref = work(ctx0, 1)[0]
+    ctx0.set_option("ba_shape", -1)
+    results, errors = {}, []
+
+    def thread_main(name):
+        try:
+            ctx = gmmloc_amd.Context(0)
+            ctx.set_option("ba_shape", 1)
+            ctx.set_option("ba_rendezvous_us", 3000)  # keep the test short when the launches do collide
+            results[name] = work(ctx, 12)
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append((name, repr(e)))
+
+    ts = [threading.Thread(target=thread_main, args=(n,)) for n in ("a", "b")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors and not any(t.is_alive() for t in ts), errors
+    for name in ("a", "b"):
+        assert len(results[name]) == 12
+        for r in results[name]:
+            for x, y in zip(ref, r):
+                assert np.array_equal(x, y, equal_nan=True), name

@@ -203,6 +203,29 @@ def test_track_frames_bit_identical_across_shapes(gpu, map_v1, gt_sync, opt):
             assert np.array_equal(a, b, equal_nan=True), (M, B, what, np.abs(a - b).max())
 
 
+def test_track_frames_rendezvous_gives_up_cleanly(gpu, map_v1, gt_sync, opt):
+    """The latency shape is launched plainly (a cooperative launch costs 31 us per call): the workgroups of a frame meet
+    in a rendezvous with a time limit, a frame whose workgroups do not all show up writes NOTHING and is redone by the
+    one-workgroup kernel that follows.  With the limit at 0 (every workgroup that does not find all its siblings' words
+    at its first look gives up) most frames take that path: the results must be the same bits, and the inputs of a frame
+    that gave up must have been left alone for the follow-up."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    for M, B in [(300, 5), (1000, 2), (1999, 1), (2000, 9)]:
+        frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, B, M, 3000 + M, outlier_frac=0.05)
+        opt("ba_shape", 0)
+        ref = _run_track(torch, ctx, g, cam, prm, frames)
+        opt("ba_shape", 1)
+        for limit_us in (0, 50000):
+            opt("ba_rendezvous_us", limit_us)
+            for _ in range(3):  # the outcome of the rendezvous at limit 0 varies from launch to launch
+                res = _run_track(torch, ctx, g, cam, prm, frames)
+                for a, b, what in zip(ref, res, ("pose", "points", "assoc", "chi2")):
+                    assert np.array_equal(a, b, equal_nan=True), (M, B, limit_us, what)
+
+
 def test_track_frames_result_independent_of_batch(gpu, map_v1, gt_sync, opt):
     """A drop-in caller gets the same bits for a frame whatever rides with it: alone (B = 1: latency shape), in a
     handful, and inside a batch larger than the chip (B > CUs: batch shape)."""
