@@ -338,7 +338,7 @@ GL_DEV void pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, c
 // (never more than the frame has groups).  Every wave repeats the serial part (solve, pose update) on its own so that
 // no broadcast is needed.
 template <int NW, int REGS>  // REGS: 0 edges from global memory, 1 in registers, 2 coordinates in LDS
-__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M, int G, int S,
+__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS == 2) ? 2 : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M, int G, int S,
                                                                  double* __restrict__ pose_io,
                                                                  const double* __restrict__ Xw_all,
                                                                  const double* __restrict__ obs_all,
@@ -576,22 +576,28 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
     // the canonical summation order of a frame of stride M (see group_totals28): G groups of S <= 4 chunks of 64 edges
     const int nch = std::max(1, (M + 63) / 64), G = (nch + 3) / 4, S = (nch + G - 1) / G;
-    // waves per frame: a wave per group of <= 256 edges, up to 8 (one frame of 1 000 edges: 0.40 ms on 4 waves against
-    // 1.24 ms on one).  The sums are built in the same order whatever the count: the shape never shows in the results.
-    // Option pose_waves (1 | 4 | 8) forces the cap.
-    // one wave per frame for large batches: 12 frames per CU in flight and no barrier (config 3, 2 149 frames of up to 1 200
-    // edges: 0.78 M frames/s against 0.74 M with a wave per group and the edges on chip; tools/pose_ab.py: the wave per
-    // group only wins on full frames of exactly four groups, 4.3 vs 4.9 ms for 4 096 x 1 000, and loses up to 1.6x elsewhere -
-    // its 424 registers leave one wave per SIMD)
-    int nw = B > 1536 ? 1 : std::min(G, 8);
+    // Waves per frame and where the edges live (tools/pose_ab.py, tools/latency.py; the sums are built in the same order
+    // whatever the shape, so it never shows in the results; option pose_waves (1 | 4 | 8) forces the cap, pose_regs = 0 the
+    // global-memory variants):
+    //  * a wave per group of <= 256 edges with the frame's edges ON CHIP whenever that fills the CU's wave slots: frames of
+    //    <= 4 groups - in registers (424 VGPRs, one workgroup per CU) while every frame gets a CU of its own, coordinates in
+    //    LDS (two workgroups per CU) beyond; frames of 5 - 8 groups: coordinates in LDS, eight waves.  One frame of 1 000
+    //    edges 0.26 ms (0.40 from global memory, 1.2 ms on one wave); 4 096 full frames of 1 000 edges 3.2 ms (4.9 on one
+    //    wave each), of 2 000 edges 7.0 ms (11.4), of 300 edges 1.49 ms (1.75);
+    //  * one wave per frame, edges from global memory, 12 frames per CU in flight and no barrier, for the large batches whose
+    //    wave-per-group shape would leave wave slots empty: 3 groups (6 of 8 slots: 2.7 vs 2.5 ms ragged), 5 - 7 groups
+    //    (config 3, 2 149 frames of up to 1 200 edges: 0.78 M frames/s against 0.74 M).
+    const bool big = B > 1536;
+    int nw = std::min(G, 8);
+    if (big && !(G <= 4 && G != 3) && G != 8) nw = 1;
     if (c->opt.pose_waves > 0) nw = std::min(G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
     size_t lds = (size_t)G * 32 * sizeof(double);
 #define GL_POSE_LAUNCH(NWC, REGS) \
   k_optimize_current_pose<NWC, REGS><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, \
                                                                      ninlier_dev, (double*)scratch)
-    const bool regs = nw > 1 && nw == G && c->opt.pose_regs != 0;  // a wave per group: the frame's edges stay on chip
+    const bool on_chip = nw > 1 && nw == G && c->opt.pose_regs != 0;  // a wave per group: the frame's edges stay on chip
     if (nw > 4) {
-      if (regs) {
+      if (on_chip) {
         lds += (size_t)24 * 64 * nw * sizeof(double);
         GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<8, 2>, lds));
         GL_POSE_LAUNCH(8, 2);
@@ -599,8 +605,15 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
         GL_POSE_LAUNCH(8, 0);
       }
     } else if (nw > 1) {
-      if (regs) GL_POSE_LAUNCH(4, 1);
-      else GL_POSE_LAUNCH(4, 0);
+      if (on_chip && B > c->ncu) {
+        lds += (size_t)24 * 64 * nw * sizeof(double);
+        GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<4, 2>, lds));
+        GL_POSE_LAUNCH(4, 2);
+      } else if (on_chip) {
+        GL_POSE_LAUNCH(4, 1);
+      } else {
+        GL_POSE_LAUNCH(4, 0);
+      }
     } else {
       GL_POSE_LAUNCH(1, 0);
     }
