@@ -1,5 +1,7 @@
+"""gl_gmm_create wall time (components, neighbour graph, device-built cell index) for the bench map and the stress map.
+    python tools/time_map_build.py"""
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gmmloc_amd
 from gmmloc_amd import api, synth
 ctx = gmmloc_amd.Context(0)
