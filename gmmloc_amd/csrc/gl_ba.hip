@@ -11,6 +11,7 @@
 //       Hc = R Hg R^T,     bc = R bg                (GMM edge)
 //       D  = A + Hc + lambda I  -> D^-1 (cofactors, as g2o's Dinv = D->inverse())
 //       Schur:  S += G^T (A - A D^-1 A) G,  g += G^T (a - A D^-1 (a + bc)),  G = [-[q]x | I]
+//               (evaluated as M D^-1 A and M u - bc, M = Hc + lambda I: no cancellation)
 //     (the orthogonal change of variables eps = R dp leaves lambda I and
 //     computeScale() invariant), then ONE deterministic 28-value workgroup
 //     reduction (gld::block_reduce), 6x6 LDL^T and exp() redundantly per thread;
@@ -215,16 +216,17 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
         if (pose_active && o.act_r) {
           double Dinv[6], b[3], u[3];
           point_solve(o, lambda, Dinv, b, u);
-          double AD[9], Cf[9], Au[3], c[3];
+          // A - A D^-1 A = M D^-1 A and a - A u = M u - bc with M = D - A = Hc + lambda I: products instead of the
+          // subtraction, which loses most of its digits for a point held by its reprojection alone (gl_ba_fast_impl.hpp)
+          double AD[9], Cf[9], c[3];
           sym3_mul(o.A, Dinv, AD);  // A D^-1
-          const double Af[9] = {o.A[0], o.A[1], o.A[2], o.A[1], o.A[3], o.A[4], o.A[2], o.A[4], o.A[5]};
+          const double Mf[9] = {o.Hc[0] + lambda, o.Hc[1], o.Hc[2], o.Hc[1], o.Hc[3] + lambda, o.Hc[4], o.Hc[2], o.Hc[4], o.Hc[5] + lambda};
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Af[i * 3 + j] - (AD[i * 3] * Af[j] + AD[i * 3 + 1] * Af[3 + j] + AD[i * 3 + 2] * Af[6 + j]);
-          sym3_mul_vec(o.A, u, Au);
+            for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Mf[i * 3] * AD[j * 3] + Mf[i * 3 + 1] * AD[j * 3 + 1] + Mf[i * 3 + 2] * AD[j * 3 + 2];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) c[i] = o.a[i] - Au[i];
+          for (int i = 0; i < 3; ++i) c[i] = (Mf[i * 3] * u[0] + Mf[i * 3 + 1] * u[1] + Mf[i * 3 + 2] * u[2]) - o.bc[i];
           accum_pose(o.q, Cf, c, acc);
         }
       }

@@ -52,6 +52,19 @@ constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of
 constexpr int NRED = kSpread ? 1 : NWC;    // group totals kept in LDS (a SPREAD workgroup is ONE group)
 constexpr int TSP = 256;                   // SPREAD: threads of a workgroup = the <= 4 slot waves of its group
 
+#ifdef GL_BA_TRACE  // debug build: (currentChi, tempChi, lambda, rho) of every Levenberg trial of frame 0 -> its points
+__device__ double g_trace[10 * 128];
+#define TRACE_TRIAL(t, a, b, c_, d, dxp)                            \
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (t) < 128) {            \
+    g_trace[(t)*10] = (a);                                           \
+    g_trace[(t)*10 + 1] = (b);                                       \
+    g_trace[(t)*10 + 2] = (c_);                                      \
+    g_trace[(t)*10 + 3] = (d);                                       \
+    for (int i_ = 0; i_ < 6; ++i_) g_trace[(t)*10 + 4 + i_] = (dxp)[i_]; \
+  }
+#else
+#define TRACE_TRIAL(t, a, b, c_, d, dxp)
+#endif
 #ifdef GL_BA_PROF
 __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_prof_w[64 * 8 * 4];  // [trial < 64][wave][marker]: clock64 at pass-A end, after reduce A, pass-B start, pass-B end
@@ -471,15 +484,6 @@ GL_DEV void ad_product(const double* A, const double* Di, double* AD) {
     AD[3 + j] = fma(A[3], y[3 + j], A[4] * y[6 + j]);
     AD[6 + j] = fma(A[2], y[j], fma(A[4], y[3 + j], A[5] * y[6 + j]));
   }
-}
-// C = A - (A Dinv) A (symmetric sym6)
-GL_DEV void schur_C(const double* A, const double* AD, double* C) {
-  C[0] = fma(-AD[0], A[0], fma(-AD[2], A[2], A[0]));
-  C[1] = fma(-AD[1], A[3], -AD[2] * A[4]);
-  C[2] = fma(-AD[0], A[2], fma(-AD[1], A[4], fma(-AD[2], A[5], A[2])));
-  C[3] = fma(-AD[4], A[3], fma(-AD[5], A[4], A[3]));
-  C[4] = fma(-AD[3], A[2], fma(-AD[4], A[4], fma(-AD[5], A[5], A[4])));
-  C[5] = fma(-AD[6], A[2], fma(-AD[7], A[4], fma(-AD[8], A[5], A[5])));
 }
 
 // ---- reductions in the canonical order ---------------------------------------------------------------------
@@ -927,10 +931,27 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
 #pragma unroll
       for (int j = 0; j < 9; ++j) un[(3 + j) * MCAP + c.ll] = __float_as_int((float)AD[j]);
     }
-    schur_C(o.A, AD, C);
-    cc[0] = fma(-o.A[0], u[0], fma(-o.A[2], u[2], o.a[0]));
-    cc[1] = fma(-o.A[3], u[1], fma(-o.A[4], u[2], o.a[1]));
-    cc[2] = fma(-o.A[2], u[0], fma(-o.A[4], u[1], fma(-o.A[5], u[2], o.a[2])));
+    // Schur contribution of the point without the subtraction A - A D^-1 A.  With M = D - A = lambda I + (GMM block) the
+    // same matrix is M D^-1 A - a plain product - and the reduced right-hand side a - A u is M u - b_gmm.  For a point whose
+    // only strong constraint is its reprojection (no GMM edge, small lambda) the result is of the size of lambda while A is
+    // ~1e4: the subtracted form keeps ~5 of its 16 digits there, and on a frame whose reduced system is itself near
+    // singular (gauge direction held by lambda alone, cond ~1e11) that noise decides accept / reject steps of the
+    // Levenberg path (soak frame v1 r19656: 1.75e-5 m off an oracle that 400 perturbed runs do not move; with this form HIP
+    // follows the oracle's path step for step, profiles/r2f_track_v1_r19656_trace_*.txt).
+    {
+      const double M[9] = {(o.D[0] - o.A[0]) + lambda, o.D[1] - o.A[1], o.D[2] - o.A[2],
+                           o.D[1] - o.A[1], (o.D[3] - o.A[3]) + lambda, o.D[4] - o.A[4],
+                           o.D[2] - o.A[2], o.D[4] - o.A[4], (o.D[5] - o.A[5]) + lambda};
+      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k)
+      const int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int r = ri[e], j = ci[e];
+        C[e] = fma(M[r * 3], AD[j * 3], fma(M[r * 3 + 1], AD[j * 3 + 1], M[r * 3 + 2] * AD[j * 3 + 2]));
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) cc[r] = fma(M[r * 3], u[0], fma(M[r * 3 + 1], u[1], fma(M[r * 3 + 2], u[2], o.a[r] - o.b[r])));
+    }
     pose_terms(o.q, C, cc, true, sk);
   } else if (kStep32) {
     int* un = (int*)D.un;
@@ -1184,6 +1205,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       }
       scale += 1e-3;
       rho = (currentChi - tempChi) / scale;
+      TRACE_TRIAL(trials, currentChi, tempChi, lambda, rho, dx);
       if (rho > 0 && isfinite(tempChi)) {
         const double uu = 2 * rho - 1;
         double alpha = 1. - uu * uu * uu;
@@ -1369,6 +1391,10 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
     if (kSpread && C.ctl) C.ctl[1] = 1;  // done
+#ifdef GL_BA_TRACE
+    if (f == 0)
+      for (int i = 0; i < 10 * 128 && i < L * 3; ++i) pts_io[i] = g_trace[i];
+#endif
 #ifdef GL_BA_PROF
     if (f == 0) {  // debug build only: phase cycles instead of pose 0, per-wave markers instead of the points of frame 0
       for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections
