@@ -14,6 +14,8 @@
 // localization_opt.cpp:45-171,533-828.
 // ============================================================================
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -394,6 +396,7 @@ struct Optimizer {
   std::vector<std::vector<PL>> hpl;  // per landmark (index = hessianIndex - numPoses)
   double currentLambda = -1.0, ni = 2.0;
   int levenbergIterations = 0;
+  bool trace = std::getenv("OG_TRACE") != nullptr;  // per-trial (currentChi, tempChi, lambda, rho) on stderr (debugging aid)
 
   Vertex* addVertex(int kind) {
     vstore.emplace_back(new Vertex());
@@ -734,6 +737,11 @@ struct Optimizer {
       double scale = computeScale();
       scale += 1e-3;
       rho /= scale;
+      if (trace) {
+        std::fprintf(stderr, "OGTRACE %.17g %.17g %.17g %.17g", currentChi, tempChi, currentLambda, rho);
+        for (int i = 0; i < sizePoses && i < 6; ++i) std::fprintf(stderr, " %.17g", xvec[i]);
+        std::fprintf(stderr, "\n");
+      }
       if (rho > 0 && std::isfinite(tempChi)) {
         double alpha = 1. - std::pow((2 * rho - 1), 3);
         alpha = std::min(alpha, 2. / 3.);
