@@ -34,8 +34,8 @@ ctx = gmmloc_amd.Context(0)
 cam, prm = api.Camera(), api.Params()
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 gts = sc.load_gt()
-count = dict(chain=0, chain_fallback=0, tri=0, tri_rejected=0, tri_far=0, track=0, pose=0, ba=0)
-checked = dict(chain=0, tri=0, track=0, pose=0, ba=0)
+count = dict(chain=0, chain_fallback=0, tri=0, tri_rejected=0, tri_far=0, track=0, pose=0, ba=0, shape=0)
+checked = dict(chain=0, tri=0, track=0, pose=0, ba=0, shape=0)
 t0 = time.time()
 
 
@@ -108,6 +108,15 @@ for mapname in args.maps.split(","):
             pose, Xw = T(ft["pose_init"][None]), T(ft["Xw"][None])
             assoc, d2 = gmmloc_amd.track_frames(ctx, g, cam, prm, pose, Xw, T(ft["obs"][None]), T(ft["octave"][None]))
             torch.cuda.synchronize()
+            # the other launch shape on the same frame: one summation order, so the bits must be equal
+            ctx.set_option("ba_shape", 0)
+            pose_d, Xw_d = T(ft["pose_init"][None]), T(ft["Xw"][None])
+            assoc_d, _ = gmmloc_amd.track_frames(ctx, g, cam, prm, pose_d, Xw_d, T(ft["obs"][None]), T(ft["octave"][None]))
+            ctx.set_option("ba_shape", -1)
+            torch.cuda.synchronize()
+            checked["shape"] += 1
+            if not (torch.equal(pose, pose_d) and torch.equal(Xw, Xw_d) and torch.equal(assoc, assoc_d)):
+                report("shape", mapname, r, "gl_track_frames: batch shape and latency shape differ in bits")
             keepf, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(orc, h, cam, ft)
             dt, dr = pose_err(pose.cpu().numpy()[0], p_ref)
             checked["track"] += 1
@@ -122,6 +131,14 @@ for mapname in args.maps.split(","):
         pose = T(fp["pose_init"][None])
         outl, nin = api.optimize_current_pose(ctx, cam, prm, pose, T(fp["Xw"][None]), T(fp["obs"][None]), T(fp["octave"][None]))
         torch.cuda.synchronize()
+        ctx.set_option("pose_waves", 1)  # one wave per frame, edges from global memory: same order, same bits
+        pose_1 = T(fp["pose_init"][None])
+        outl_1, nin_1 = api.optimize_current_pose(ctx, cam, prm, pose_1, T(fp["Xw"][None]), T(fp["obs"][None]), T(fp["octave"][None]))
+        ctx.set_option("pose_waves", 0)
+        torch.cuda.synchronize()
+        checked["shape"] += 1
+        if not (torch.equal(pose, pose_1) and torch.equal(outl, outl_1) and torch.equal(nin, nin_1)):
+            report("shape", mapname, r, "gl_optimize_current_pose: wave-per-group and one-wave shapes differ in bits")
         pr, orf, nr_ = orc.optimize_current_pose(cam, fp["pose_init"], fp["Xw"], fp["obs"], fp["octave"])
         dt, dr = pose_err(pose.cpu().numpy()[0], pr)
         checked["pose"] += 1
