@@ -42,10 +42,15 @@ __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
 constexpr int PREP_T = 256, PREP_C = 8;  // rounds of 256 consecutive points: frames up to 2 048 points
 __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, int L, const double* __restrict__ obs_all,
                                                     const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
-                                                    const double* __restrict__ d2_all, double* __restrict__ scratch) {
+                                                    const double* __restrict__ d2_all, double* __restrict__ scratch,
+                                                    unsigned long long* __restrict__ xwords, int* __restrict__ xctl, int nxw) {
   __shared__ int cnt[PREP_C][PREP_T / 64];  // non-degenerate-component points per (round, wave)
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (f >= B) return;
+  if (xwords) {  // latency shape next: this frame's exchange words and {abort, done} start at zero (no separate memset)
+    for (int i = tid; i < nxw; i += PREP_T) xwords[(size_t)f * nxw + i] = 0ull;
+    if (tid < 2) xctl[2 * f + tid] = 0;
+  }
   const size_t gbase = (size_t)f * L;
   const PrepView pv = prep_view(scratch, B, L);
   const int rounds = (L + PREP_T - 1) / PREP_T;
@@ -256,9 +261,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   }
   // the exchange words of the frames sit behind the per-point records, {abort, done} per frame behind them
   a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 36 + 63) / 64) * 64);
-  const size_t words = (size_t)a.B * 2 * a.NB * 64;
-  a.ctl = (int*)(a.parts + words);
-  GL_HIP(hipMemsetAsync(a.parts, 0, words * sizeof(unsigned long long) + (size_t)a.B * 2 * sizeof(int), c->stream));
+  a.ctl = (int*)(a.parts + (size_t)a.B * 2 * a.NB * 64);  // (both zeroed by k_ba1_prep)
   const long long limit = (long long)(c->opt.ba_rendezvous_us * 100.0);  // wall_clock64() ticks at 100 MHz
   kern<<<a.B * a.NB, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
                                             a.parts, a.ctl, limit);
@@ -289,15 +292,19 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   a.iters = iters;
   a.pn = (double*)scratch;
   a.stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
-  {  // set-up: gate, flags, plane records, normalised observations, and the order the refine walks each frame in
+  bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD; checked in launch_spread)
+  if (c->opt.ba_shape == 0) spread = false;
+  if (c->opt.ba_shape == 1) spread = true;  // forced (tests); a shape that does not fit the device still goes DENSE
+  {  // set-up: gate, flags, normalised observations, the order the refine walks each frame in - and, before a latency-shape
+     // launch, the zeros its exchange words start from
     TimerScope ts(c, GL_TIMER_BA_PREP);
-    k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch);
+    unsigned long long* xw = nullptr;
+    if (spread) xw = (unsigned long long*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64);
+    const int nxw = 2 * a.G * 64;
+    k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch, xw, xw ? (int*)(xw + (size_t)B * nxw) : nullptr, nxw);
   }
   GL_HIP(hipGetLastError());
   TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper
-  bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD; checked in launch_spread)
-  if (c->opt.ba_shape == 0) spread = false;
-  if (c->opt.ba_shape == 1) spread = true;  // forced (tests); a refused cooperative launch still falls back
   if (spread) {
     const int rc = launch_spread(c, a, scratch);
     if (rc <= 0) return rc;
