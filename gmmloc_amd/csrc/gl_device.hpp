@@ -575,8 +575,8 @@ struct Coop {
   int failed;                // this thread knows the problem is off
 };
 // poll helper of the exchange loops: true = give up (abort raised by a sibling, or the rendezvous timed out)
-GL_DEV bool coop_give_up(const Coop& C, unsigned seq, long long t0) {
-  if (__hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+GL_DEV bool coop_give_up(const Coop& C, int abort_word, unsigned seq, long long t0) {
+  if (abort_word != 0) return true;
   if (seq == 1u && (long long)wall_clock64() - t0 > C.limit) {
     __hip_atomic_store(C.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
@@ -603,6 +603,7 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
     const long long t0 = seq == 1u ? (long long)wall_clock64() : 0;
     do {
       all = true;
+      const int ab = __hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // with the same batch of requests
 #pragma unroll
       for (int p = 0; p < NBMAX; ++p) {
         if (p < C.NB) {
@@ -614,7 +615,7 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
 #pragma unroll
       for (int p = 0; p < NBMAX; ++p)
         if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
-      if (!all) off = coop_give_up(C, seq, t0);
+      if (!all) off = coop_give_up(C, ab, seq, t0);
     } while (!all && !off);
     if (off) *C.lds_fail = 1;
     double v[NBMAX];
