@@ -544,10 +544,15 @@ GL_DEV void reduce_to_tot(double* v, const Red& R, Coop& C) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const int val = r8 * 8 + kk;
+          // all four slot values are fetched before the first add (absent slots add 0.0, which changes nothing: the sum
+          // starts from +0.0): with a loop over the S slots every LDS read waited for the previous add - 32 serialised
+          // LDS round trips, 3.9 k of a trial's 20 k cycles
+          double x[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[j] = (val < NV && j < S) ? R.tb[val * TSP + j * 64 + lane] : 0.0;
           double s = 0.0;
-          if (val < NV) {
-            for (int j = 0; j < S; ++j) s = add_nc(s, R.tb[val * TSP + j * 64 + lane]);
-          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s = add_nc(s, x[j]);
           y[kk] = s;
         }
         const double t8 = wave_reduce_scatter8(y);
@@ -595,10 +600,12 @@ GL_DEV void spread_publish(const double* v, const Red& R, const Coop& C, unsigne
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const int val = r8 * 8 + kk;
+        double x[4];  // all four slot values before the first add (see reduce_to_tot)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = (val < NV && j < S) ? R.tb[val * TSP + j * 64 + lane] : 0.0;
         double s = 0.0;
-        if (val < NV) {
-          for (int j = 0; j < S; ++j) s = add_nc(s, R.tb[val * TSP + j * 64 + lane]);
-        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = add_nc(s, x[j]);
         y[kk] = s;
       }
       const double t8 = wave_reduce_scatter8(y);
