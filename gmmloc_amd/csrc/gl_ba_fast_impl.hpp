@@ -893,6 +893,49 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
   return true;
 }
 
+// SPREAD: a thread owns ONE point for the whole kernel, so what load_pt fetches from global memory - normalised
+// observation, association, plane record: two dependent L2 round trips at the head of every pass, on a SIMD that has
+// nothing else to run - is fetched once and kept in registers.
+struct PtConst {
+  double ob[3], nd[4];
+  int a;
+};
+GL_DEV void load_const(const Map& mp, FlagW fw, const double* __restrict__ gobn, const double* __restrict__ gnd,
+                       const int32_t* __restrict__ gassoc, PtConst& pc) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) pc.ob[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pc.nd[j] = 0.0;
+  pc.a = -1;
+  if (!(fw_get(fw, 0) & F_EXISTS)) return;
+  const int l = mp.base;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) pc.ob[j] = gobn[(size_t)l * 3 + j];
+  pc.a = gassoc[l];
+  const int ap = pc.a > 0 ? pc.a : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pc.nd[j] = gnd[(size_t)ap * 4 + j];
+}
+GL_DEV bool load_pt_const(const Lds& D, const Map& mp, FlagW fw, const PtConst& pc, PtCtx& c) {
+  c.fl = fw_get(fw, 0);
+  if (!(c.fl & (F_AR | F_AG))) return false;
+  c.l = mp.base;
+  c.ll = mp.lbase;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.ob[j] = pc.ob[j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.nd[j] = pc.nd[j];
+  c.ar = c.fl & F_AR;
+  c.ag = c.fl & F_AG;
+  const int oc = (c.fl >> 8) & 7;
+  c.sx = D.stab[oc];
+  c.sy = D.stab[8 + oc];
+  c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? pc.a : -1;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
+  return true;
+}
+
 // ---- per-point bodies of the passes (shared by both kernels) -------------------------------------------------
 // computeLambdaInit: pose-block terms 0..20 of the undamped reprojection Hessian, and the largest diagonal of the
 // point block (world frame) into md
@@ -1080,7 +1123,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
     if (kSpread) {                                                            \
       const SinkSet sk{acc};                                                  \
       PtCtx c;                                                                \
-      if (load_pt(D, mp, fw, gobn, gnd, gassoc, 0, c)) { BODY; }              \
+      if (load_pt_const(D, mp, fw, pc, c)) { BODY; }                          \
     } else {                                                                  \
       const SinkAcc sk{acc};                                                  \
       GL_BAF_PRIO_PASS_BEGIN();                                               \
@@ -1096,7 +1139,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
                          const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
-                         bool robust, int iters, const Red& R, int& trials, Coop& C) {
+                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -1316,6 +1359,8 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
       fw_activity(fw, i);
     }
   }
+  PtConst pc;
+  if (kSpread) load_const(mp, fw, gobn, gnd, gassoc, pc);
   if (tid == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {  // static indices: a lane-indexed kernarg array would go through scratch
@@ -1339,7 +1384,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, phase < 2, phase < 2 ? 5 : 40, R, trials, C);
+    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, pc, phase < 2, phase < 2 ? 5 : 40, R, trials, C);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
