@@ -263,8 +263,10 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 36 + 63) / 64) * 64);
   a.ctl = (int*)(a.parts + (size_t)a.B * 2 * a.NB * 64);  // (both zeroed by k_ba1_prep)
   const long long limit = (long long)(c->opt.ba_rendezvous_us * 100.0);  // wall_clock64() ticks at 100 MHz
-  kern<<<a.B * a.NB, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                            a.parts, a.ctl, limit);
+  // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
+  const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
+  kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
+                                      a.parts, a.ctl, limit);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }

@@ -612,8 +612,13 @@ GL_DEV void spread_publish(const double* v, const Red& R, const Coop& C, unsigne
       if ((lane & 0xE) == 0 && !C.failed) {
         const int vi = r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(t8);
+#ifdef GL_BAF_EXPERIMENT_SAMEXCD
+        __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
         __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       }
     }
   }
@@ -1313,10 +1318,13 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   R.S = S;
   FlagW fw = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = kSpread ? blockIdx.x / NB : blockIdx.x;
-  if (f >= B) return;
+  // SPREAD: the workgroups of a frame are given block indices that are equal modulo 8, which is what puts them on ONE XCD
+  // on this hardware (observed, not promised: a matter of speed only) - block 8 k + x is group k % 8 of frame x + 8 (k / 8)
+  const int f = kSpread ? (NB > 1 ? (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 6) : (int)blockIdx.x) : (int)blockIdx.x;
+  const int pb_ = kSpread && NB > 1 ? (int)((blockIdx.x >> 3) & 7) : 0;
+  if (f >= B || pb_ >= NB) return;
   if (!kSpread && ctl && ctl[2 * f + 1]) return;  // follow-up of a latency-shape launch: this frame completed there
-  Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, kSpread ? (int)(blockIdx.x % NB) : 0, 0u,
+  Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, pb_, 0u,
          ctl ? ctl + 2 * f : nullptr, (int*)(R.tot + 61), limit, 0};
   Map mp;
   if (kSpread) {  // workgroup pb = group pb; wave = slot; idle waves beyond S
