@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 // option table: name as in gl_ctx_set_option; the environment variable is GMMLOC_<NAME IN CAPITALS>
 #define GL_OPTION_LIST(X) \
-  X(ba_shape) X(ba_step32) X(ba_slow) X(ba_rendezvous_us) X(pose_waves) X(pose_regs) X(bagen_nb) X(view_slot_lds) X(view_threads) \
+  X(ba_shape) X(ba_step32) X(ba_slow) X(ba_rendezvous_us) X(ba_same_xcd) X(pose_waves) X(pose_regs) X(bagen_nb) X(view_slot_lds) X(view_threads) \
   X(assoc_index_min) X(assoc_grid) X(match_desc_lds)
 double* option_slot(Options& o, const char* name) {
 #define X(n) \
@@ -139,6 +139,7 @@ int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out) {
   if (hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->ncu <= 0) c->ncu = 256;
   c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
   gl::options_from_env(c->opt);         // the only place the knobs are read from the environment
+  c->xcc_ids_trusted = gl::probe_xcc_ids(c);
   *out = (gl_ctx_t*)c;
   return GL_OK;
 }

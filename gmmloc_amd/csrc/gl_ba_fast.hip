@@ -189,7 +189,40 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 
+namespace {
+// HW_REG_XCC_ID (hwreg 20, 4 bits): the XCD the wave runs on
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15; }
+__global__ void k_xcc_probe(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+}  // namespace
+
 namespace gl {
+
+// The same-XCD form of the latency shape's exchange (plain stores that stay in the XCD's L2, read by L1-bypassing loads)
+// is only valid if the workgroups of a frame really share an XCD.  The kernel checks that at run time with the XCC ids
+// its workgroups report; this probe decides whether those reports can be trusted at all: 64 blocks must report ids in
+// 0..7, block b the same as block b % 8, and the eight residues eight different ones (the known placement of this
+// hardware).  Anything else - another partition mode, another device - leaves the device-scope form in place.
+bool probe_xcc_ids(Ctx* c) {
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, 64 * sizeof(int)) != hipSuccess) return false;
+  int h[64];
+  bool ok = hipMemsetAsync(d, 0xff, 64 * sizeof(int), c->stream) == hipSuccess;
+  if (ok) {
+    k_xcc_probe<<<64, 64, 0, c->stream>>>(d);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  (void)hipFree(d);
+  if (!ok) return false;
+  unsigned seen = 0;
+  for (int b = 0; b < 64; ++b) {
+    if (h[b] < 0 || h[b] > 7 || h[b] != h[b & 7]) return false;
+    seen |= 1u << h[b];
+  }
+  return seen == 0xffu;
+}
 
 bool ba1_fast_supported(int L) { return L <= 2000; }
 
@@ -201,7 +234,7 @@ static void canon_order(int L, int* G, int* S) {
 }
 
 typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*, int*, long long);
+                          unsigned long long*, int*, long long, int);
 
 struct BafArgs {
   BaK k;
@@ -231,7 +264,7 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   a.NB = 1;
   a.parts = nullptr;
   kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts, a.ctl, 0ll);
+                                          a.NB, a.parts, a.ctl, 0ll, 0);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -266,7 +299,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
   kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                      a.parts, a.ctl, limit);
+                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }

@@ -612,13 +612,13 @@ GL_DEV void spread_publish(const double* v, const Red& R, const Coop& C, unsigne
       if ((lane & 0xE) == 0 && !C.failed) {
         const int vi = r8 * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1);
         const unsigned long long bits = (unsigned long long)__double_as_longlong(t8);
-#ifdef GL_BAF_EXPERIMENT_SAMEXCD
-        __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-        __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+        if (C.same_xcd) {  // plain stores: the words stay in the XCD's L2, where the siblings' L1-bypassing loads find them
+          __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {           // device scope: written through to memory, visible from every XCD
+          __hip_atomic_store(buf + vi * 2, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(buf + vi * 2 + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   double* __restrict__ pts_io, int32_t* __restrict__ assoc_all,
                                                   uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                   int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
-                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit) {
+                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   if (f >= B || pb_ >= NB) return;
   if (!kSpread && ctl && ctl[2 * f + 1]) return;  // follow-up of a latency-shape launch: this frame completed there
   Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, pb_, 0u,
-         ctl ? ctl + 2 * f : nullptr, (int*)(R.tot + 61), limit, 0};
+         ctl ? ctl + 2 * f : nullptr, (int*)(R.tot + 61), limit, 0, 0};
   Map mp;
   if (kSpread) {  // workgroup pb = group pb; wave = slot; idle waves beyond S
     mp.S = 1;
@@ -1385,6 +1385,16 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   if (!kSpread && NWC == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   __syncthreads();
+  if (kSpread && C.NB > 1 && xcc_trusted) {
+    // do the frame's workgroups share an XCD?  Every contributing thread adds its XCC id and the id's square (through the
+    // device-scope exchange: this is also the launch's rendezvous); they are all equal iff N sum(id^2) == sum(id)^2
+    double x2[32];
+    const double id = (double)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15);
+    x2[0] = id;
+    x2[1] = id * id;
+    reduce2<2>(x2, R, C);
+    C.same_xcd = ((double)(C.NB * R.S * 64) * x2[1] == x2[0] * x2[0]) ? 1 : 0;
+  }
 
   // schedule (:770-828): optimize(5) -> gate degenerate GMM edges -> optimize(5) -> gate reprojection
   // edges, robust kernels off -> optimize(40).  One rolled phase loop = one copy of the optimiser code.

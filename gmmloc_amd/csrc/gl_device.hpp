@@ -573,6 +573,7 @@ struct Coop {
   int* lds_fail;             // LDS word: a poll of this workgroup failed (read by everybody behind the next barrier)
   long long limit;           // rendezvous time limit in wall_clock64() ticks (100 MHz)
   int failed;                // this thread knows the problem is off
+  int same_xcd;              // 1 once the workgroups have reported one and the same XCC id (and the host trusts the ids)
 };
 // poll helper of the exchange loops: true = give up (abort raised by a sibling, or the rendezvous timed out)
 GL_DEV bool coop_give_up(const Coop& C, int abort_word, unsigned seq, long long t0) {

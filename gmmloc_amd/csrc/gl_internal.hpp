@@ -83,6 +83,7 @@ struct Options {
   double ba_step32 = 0;         // 1: point step from an fp32 cache of the pass-A solve (faster, not the default)
   double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
   double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame
+  double ba_same_xcd = 1;          //   0: the latency shape never uses the same-XCD form of its exchange (A/B, tests)
   double ba_rendezvous_us = 50000;  // time limit of the latency shape's rendezvous (0: every frame gives up -> follow-up kernel; tests)
   double pose_regs = 1;         //   0: the frame-at-a-time shapes read their edges from global memory every trial (A/B)
   double bagen_nb = 0;          // gl_joint_optimization: 0 auto, n workgroups per problem
@@ -105,6 +106,9 @@ struct Ctx {
   std::map<std::pair<const void*, size_t>, int> occupancy;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // the device reports its XCC id per workgroup and places block b on XCD b % 8 (probed once at gl_ctx_create): the
+  // latency-shape kernels may then use the same-XCD form of their exchange - after checking the ids again at run time
+  bool xcc_ids_trusted = false;
   // scratch (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -120,6 +124,7 @@ struct Ctx {
 };
 
 int ctx_scratch(Ctx* c, size_t bytes, void** out);
+bool probe_xcc_ids(Ctx* c);  // gl_ba_fast.hip
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE and costs a driver call: a context (one device,
 // one host thread) remembers the limit it has set for each kernel and raises it only when it grows.  The caller
 // has made the context's device current.

@@ -83,7 +83,7 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   ba_shape (-1 auto | 0 one workgroup per frame | 1 one point per thread; same bits either way),
  *   ba_step32 (1: fp32-cached point step in gl_track_frames, faster, NOT bit-compatible with the default),
  *   assoc_grid (0: every association is the plain N x K sweep, never the cell index),
- *   ba_slow, ba_rendezvous_us, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
+ *   ba_slow, ba_rendezvous_us, ba_same_xcd, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
 /* Kernel timing with HIP events on the context's stream: while enabled, every
