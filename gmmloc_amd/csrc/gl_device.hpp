@@ -595,8 +595,13 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
   if (t < 32 && !C.failed) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[t]);
     unsigned long long* mine = buf + ((size_t)C.pb * 32 + t) * 2;
-    __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(mine + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (C.same_xcd) {  // the workgroups share an XCD (verified): plain stores stay in its L2, where the L1-bypassing polls find them
+      __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(mine + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      __hip_atomic_store(mine, (bits << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 1, (bits & 0xffffffff00000000ull) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // all NB partials are requested at once (one round trip when the others are already there)
     constexpr int NBMAX = 8;
     unsigned long long w0[NBMAX], w1[NBMAX];
