@@ -425,9 +425,9 @@ def main():
                     "assoc_grid = 0) instead of the exact cell index; rank 0's clock"}
         out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20",
                           "host_to_host_ms": h2h[N_PTS], "host_to_host_700pts_ms": h2h[700],
-                          "host_to_host_what": "host numpy buffers -> pinned staging -> one H2D + gl_track_frames + one D2H on the "
-                                               "context's stream -> one synchronize -> host buffers (api.HostFramePath = the "
-                                               "adapter's trackFrame), ctypes caller, median of 20"}
+                          "host_to_host_what": "gl_track_frame_host: host buffers -> the context's page-locked staging -> one H2D + "
+                                               "gl_track_frames + one D2H on its stream -> one synchronize -> host buffers (what the "
+                                               "adapter's trackFrame calls), ctypes caller, median of 20"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(20200901 + 100000 * rank)
             out["cpu_baseline"] = cb

@@ -78,6 +78,7 @@ def load():
         "gl_free": (i32, [vp, vp]),
         "gl_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),
         "gl_memcpy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
+        "gl_track_frame_host": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, vp, vp, vp, vp, vp]),
         "gl_malloc_host": (i32, [vp, C.c_size_t, P(vp)]),
         "gl_free_host": (i32, [vp, vp]),
         "gl_memcpy_h2d_async": (i32, [vp, vp, vp, C.c_size_t]),

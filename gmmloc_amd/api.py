@@ -273,53 +273,24 @@ def track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octave, want_d2=True):
 
 
 class HostFramePath:
-    """The frame-at-a-time caller with HOST buffers in and out - what include/gmmloc_hip/gmm_adapter.hpp::trackFrame
-    does for the reference host (tracking.cpp calls the path once per frame): one pooled device buffer, one
-    page-locked staging buffer (gl_malloc_host), one enqueued transfer each way and ONE synchronize per frame.
-    Layout  pose | Xw | assoc || obs | octave ; only the part before || comes back."""
+    """The frame-at-a-time caller with HOST buffers in and out - gl_track_frame_host, what
+    include/gmmloc_hip/gmm_adapter.hpp::trackFrame does for the reference host (tracking.cpp calls the path once per
+    frame): the context's page-locked staging buffer and its device mirror, one enqueued transfer each way and ONE
+    synchronize per frame."""
 
-    def __init__(self, ctx, gmm, cam, prm, max_points):
+    def __init__(self, ctx, gmm, cam, prm, max_points=0):
         self.ctx, self.gmm, self.cam, self.prm = ctx, gmm, cam.c(), prm.c()
-        self.cap = self._layout(max_points)[-1]
-        lib = ctx.lib
-        self.dev, self.host = C.c_void_p(), C.c_void_p()
-        _check(lib.gl_malloc(ctx.h, self.cap, C.byref(self.dev)))
-        _check(lib.gl_malloc_host(ctx.h, self.cap, C.byref(self.host)))
-        self.stage = np.ctypeslib.as_array(C.cast(self.host, C.POINTER(C.c_uint8)), shape=(self.cap,))
-
-    @staticmethod
-    def _layout(M):
-        oX = 64
-        oA = oX + M * 24
-        oO = oA + ((M * 4 + 7) // 8) * 8
-        oC = oO + M * 24
-        return oX, oA, oO, oC, oC + M * 4
 
     def track_frame(self, pose, Xw, obs, octave):
-        """pose (7,), Xw (M,3) float64 are updated in place; returns assoc (M,) int32."""
+        """pose (7,), Xw (M,3) float64 are updated in place; returns assoc (M,) int32.  All arrays C-contiguous."""
         M = octave.shape[0]
-        oX, oA, oO, oC, total = self._layout(M)
-        if total > self.cap:
-            raise ValueError("frame larger than the path was created for")
-        st, lib, h, d = self.stage, self.ctx.lib, self.ctx.h, self.dev.value
-        st[:56] = pose.view(np.uint8)
-        st[oX:oA] = Xw.reshape(-1).view(np.uint8)
-        st[oO:oC] = obs.reshape(-1).view(np.uint8)
-        st[oC:total] = octave.view(np.uint8)
-        _check(lib.gl_memcpy_h2d_async(h, self.dev, self.host, total))
-        _check(lib.gl_track_frames(h, self.gmm.h, C.byref(self.cam), C.byref(self.prm), 1, M, C.c_void_p(d), C.c_void_p(d + oX),
-                                   C.c_void_p(d + oO), C.c_void_p(d + oC), C.c_void_p(d + oA), None))
-        _check(lib.gl_memcpy_d2h_async(h, self.host, self.dev, oO))
-        _check(lib.gl_ctx_synchronize(h))
-        pose[:] = st[:56].view(np.float64)
-        Xw.reshape(-1)[:] = st[oX:oA].view(np.float64)
-        return st[oA:oA + M * 4].view(np.int32).copy()
+        assoc = np.empty(M, np.int32)
+        _check(self.ctx.lib.gl_track_frame_host(self.ctx.h, self.gmm.h, C.byref(self.cam), C.byref(self.prm), M, pose.ctypes.data,
+                                                Xw.ctypes.data, obs.ctypes.data, octave.ctypes.data, assoc.ctypes.data))
+        return assoc
 
     def close(self):
-        if self.dev:
-            self.ctx.lib.gl_free(self.ctx.h, self.dev)
-            self.ctx.lib.gl_free_host(self.ctx.h, self.host)
-            self.dev = self.host = None
+        pass
 
 
 def read_gmm_file(path):

@@ -155,6 +155,8 @@ int gl_ctx_destroy(gl_ctx_t* ctx) {
     (void)hipEventDestroy(p.second);
   }
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->dev_stage) (void)hipFree(c->dev_stage);
+  if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GL_OK;

@@ -20,6 +20,7 @@
 // optimize + the 5 / gate GMM / 5 / gate reprojection / 40 schedule
 // (localization_opt.cpp:770-828), incl. stale e->chi2() semantics.
 #include <cstdlib>
+#include <cstring>
 
 #include "gl_ba_common.hpp"
 
@@ -513,4 +514,46 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
                                nullptr, nullptr, nullptr, scratch);
   return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, nullptr, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
                         nullptr, nullptr, nullptr, scratch);
+}
+
+// One frame, host buffers in and out: | pose | Xw | assoc || obs | octave | staged through the context's page-locked
+// buffer; only the part before || comes back.
+extern "C" int gl_track_frame_host(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
+                                   double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
+                                   int32_t* assoc_host) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  GL_REQUIRE(M >= 0, "bad M");
+  if (M == 0) return GL_OK;
+  GL_REQUIRE(pose_host && Xw_host && obs_host && octave_host && assoc_host, "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  const size_t oX = 64, oA = oX + (size_t)M * 24, oO = oA + (((size_t)M * 4 + 7) / 8) * 8, oC = oO + (size_t)M * 24,
+               total = oC + (size_t)M * 4;
+  if (c->stage_bytes < total) {
+    GL_HIP(hipStreamSynchronize(c->stream));
+    if (c->dev_stage) GL_HIP(hipFree(c->dev_stage));
+    if (c->host_stage) GL_HIP(hipHostFree(c->host_stage));
+    c->dev_stage = c->host_stage = nullptr;
+    c->stage_bytes = 0;
+    const size_t want = total + total / 4 + 64;
+    GL_HIP(hipMalloc(&c->dev_stage, want));
+    GL_HIP(hipHostMalloc(&c->host_stage, want, hipHostMallocDefault));
+    c->stage_bytes = want;
+  }
+  char* st = (char*)c->host_stage;
+  char* dv = (char*)c->dev_stage;
+  memcpy(st, pose_host, 56);
+  memcpy(st + oX, Xw_host, (size_t)M * 24);
+  memcpy(st + oO, obs_host, (size_t)M * 24);
+  memcpy(st + oC, octave_host, (size_t)M * 4);
+  GL_HIP(hipMemcpyAsync(dv, st, total, hipMemcpyHostToDevice, c->stream));
+  const int rc = gl_track_frames(ctx, gmm, cam, prm, 1, M, (double*)dv, (double*)(dv + oX), (const double*)(dv + oO),
+                                 (const int32_t*)(dv + oC), (int32_t*)(dv + oA), nullptr);
+  if (rc != GL_OK) return rc;
+  GL_HIP(hipMemcpyAsync(st, dv, oO, hipMemcpyDeviceToHost, c->stream));
+  GL_HIP(hipStreamSynchronize(c->stream));
+  memcpy(pose_host, st, 56);
+  memcpy(Xw_host, st + oX, (size_t)M * 24);
+  memcpy(assoc_host, st + oA, (size_t)M * 4);
+  return GL_OK;
 }

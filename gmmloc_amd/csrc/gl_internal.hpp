@@ -112,6 +112,10 @@ struct Ctx {
   // scratch (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // staging of the frame-at-a-time host entry point (gl_track_frame_host): page-locked + device mirror, grown on demand
+  void* host_stage = nullptr;
+  void* dev_stage = nullptr;
+  size_t stage_bytes = 0;
   // optional statistics buffer (gl_ctx_set_stats_buffer)
   int32_t* stats = nullptr;
   int stats_n = 0;

@@ -315,6 +315,13 @@ int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* c
 int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
                     double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
                     int32_t* assoc_dev, double* d2_dev);
+/* The same for ONE frame with HOST buffers in and out - what the reference's tracking thread would call once per frame
+ * (tracking.cpp:274,312,356).  The context keeps a page-locked staging buffer and its device mirror (grown on demand),
+ * enqueues one copy each way around gl_track_frames(B = 1) on its stream and synchronises once; pose_host (7) and
+ * Xw_host (M x 3) are updated in place, assoc_host (M) receives the associations.  Blocking. */
+int gl_track_frame_host(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
+                        double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
+                        int32_t* assoc_host);
 
 /* ---- device memory helpers for hosts without their own HIP allocator ------ */
 int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out);

@@ -158,28 +158,11 @@ class GMM {
     const int M = (int)octave.size();
     assoc.assign(M, -1);
     if (!M) return;
-    // the per-frame caller: one device buffer and one page-locked staging buffer kept (and only grown) between calls -
-    // hipMalloc / hipFree per call cost more than the kernels - one transfer each way, enqueued on the context's
-    // stream, and ONE synchronize per frame:  pose | Xw | assoc || obs | octave
-    const size_t oX = 64, oA = oX + (size_t)M * 24, oO = oA + (((size_t)M * 4 + 7) / 8) * 8, oC = oO + (size_t)M * 24,
-                 total = oC + (size_t)M * 4;
-    DevBuf& d = pooled(0, total);
-    char* st = stage(total);
-    std::memcpy(st, &Tcw, 56);
-    std::memcpy(st + oX, Xw.data(), (size_t)M * 24);
-    std::memcpy(st + oO, obs.data(), (size_t)M * 24);
-    std::memcpy(st + oC, octave.data(), (size_t)M * 4);
-    char* base = d.as<char>();
-    check(gl_memcpy_h2d_async(ctx_, base, st, total), "h2d");
-    check(gl_track_frames(ctx_, gmm_, &cam_, &prm_, 1, M, reinterpret_cast<double*>(base), reinterpret_cast<double*>(base + oX),
-                          reinterpret_cast<const double*>(base + oO), reinterpret_cast<const int32_t*>(base + oC),
-                          reinterpret_cast<int32_t*>(base + oA), nullptr),
-          "gl_track_frames");
-    check(gl_memcpy_d2h_async(ctx_, st, base, oO), "d2h");
-    check(gl_ctx_synchronize(ctx_), "sync");
-    std::memcpy(&Tcw, st, 56);
-    std::memcpy(Xw.data(), st + oX, (size_t)M * 24);
-    std::memcpy(assoc.data(), st + oA, (size_t)M * 4);
+    // the per-frame caller: the library keeps a page-locked staging buffer and its device mirror in the context, one
+    // transfer each way on the context's stream and ONE synchronize per frame (gl_track_frame_host)
+    check(gl_track_frame_host(ctx_, gmm_, &cam_, &prm_, M, reinterpret_cast<double*>(&Tcw), Xw.data(), obs.data(), octave.data(),
+                              assoc.data()),
+          "gl_track_frame_host");
   }
 
   // Localization::jointOptimization on one flattened local window (layout: gmmloc_hip.h, gl_joint_optimization):
