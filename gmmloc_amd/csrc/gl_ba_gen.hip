@@ -64,6 +64,8 @@ struct GenP {
   double* dxv;     // n
   double* pchi;    // P prior chi2 at the current state
   double* pchi2;   // P prior chi2 at the trial state
+  double* prH;     // P x 36 + P x 6: prior information / rhs at the current state (per outer iteration)
+  double* prb;
   int32_t* opoint; // nobs
   int32_t* pl_ptr; // P + 1
   int32_t* pl_obs; // nobs
@@ -74,28 +76,27 @@ struct GenP {
   uint8_t* pact;   // P
   uint8_t* lact;   // L  point active this optimize()
   // multi-workgroup execution
+  int ld;              // row stride of S (doubles)
   int NB, pb;          // workgroups per problem, index of this one
   int toggle;          // which partial-sum buffer the next reduction uses
-  unsigned* bar;       // {arrivals, generation}
+  unsigned* bar;       // arrival counter of the problem's barrier
+  unsigned epoch;      // arrivals that complete the next barrier
   double* part;        // NB x 4 partial sums
-  double* Sw;          // n x n work copy for the solve when NB > 1 and it does not fit in LDS
   int* flagg;          // solve status
 };
 
-// barrier over the NB workgroups of one problem (all co-resident: cooperative launch)
-GL_DEV void prob_sync(const GenP& G) {
+// barrier over the NB workgroups of one problem (all co-resident: cooperative launch).  One monotonic arrival
+// counter (zeroed by the host): an arrival is one fire-and-forget add, the k-th barrier is passed when the counter
+// reaches k NB - no reset, no generation word, one fabric round trip less than the classic two-word barrier.
+GL_DEV void prob_sync(GenP& G) {
   __syncthreads();
   if (G.NB > 1) {
+    G.epoch += (unsigned)G.NB;
     if (threadIdx.x == 0) {
       __threadfence();
-      const unsigned gen = atomicAdd(&G.bar[1], 0u);
-      if (atomicAdd(&G.bar[0], 1u) == (unsigned)G.NB - 1u) {
-        G.bar[0] = 0u;
-        __threadfence();
-        atomicAdd(&G.bar[1], 1u);
-      } else {
-        while (atomicAdd(&G.bar[1], 0u) == gen) __builtin_amdgcn_s_sleep(2);
-      }
+      __hip_atomic_fetch_add(&G.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((int)(__hip_atomic_load(&G.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - G.epoch) < 0)
+        __builtin_amdgcn_s_sleep(1);
       __threadfence();
     }
     __syncthreads();
@@ -426,7 +427,7 @@ GL_DEV void pass_trial_lpp(int lpp, const BaK& k, const GmmDev& gm, const GenP& 
 // the problem's workgroups have at least 2 (4) waves per block, 2 (4) waves of a workgroup share a block (the
 // observation list dealt round them, their 48 sums met in LDS).
 GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
-  const int P = G.P, n = 6 * P;
+  const int P = G.P, ld = G.ld;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = P * (P + 1) / 2;
   const int tw = G.NB * NW_BA;
@@ -541,14 +542,12 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
     if (act && sub == 0 && wave_slot_owner(lane)) {
       const int s = wave_slot(lane);
       {
-        const int r = s / 6, c = s % 6;
-        G.S[(size_t)(6 * j1 + r) * n + 6 * j2 + c] = r1;
-        if (j1 != j2) G.S[(size_t)(6 * j2 + c) * n + 6 * j1 + r] = r1;
+        const int r = s / 6, c = s % 6;  // only the lower triangle of S is read: block (j2, j1) = block (j1, j2)^T
+        G.S[j1 == j2 ? (size_t)(6 * j1 + r) * ld + 6 * j1 + c : (size_t)(6 * j2 + c) * ld + 6 * j1 + r] = r1;
       }
       if (s < 4) {
         const int r = (32 + s) / 6, c = (32 + s) % 6;
-        G.S[(size_t)(6 * j1 + r) * n + 6 * j2 + c] = r2;
-        if (j1 != j2) G.S[(size_t)(6 * j2 + c) * n + 6 * j1 + r] = r2;
+        G.S[j1 == j2 ? (size_t)(6 * j1 + r) * ld + 6 * j1 + c : (size_t)(6 * j2 + c) * ld + 6 * j1 + r] = r2;
       } else if (s < 10 && j1 == j2) {
         G.gv[6 * j1 + (s - 4)] = r2;
       } else if (s < 16 && j1 == j2) {
@@ -558,173 +557,256 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
   }
 }
 
-// in-place LDL^T solve of S x = g (lower triangle), whole workgroup; returns ok.
-// Right-looking with ONE barrier per pivot (the columns stay un-scaled, l_ik = S[i][k] / S[k][k] is
-// applied on the fly); the two triangular solves run on wave 0 with the vector in registers (two rows
-// per lane, n <= 128) and v_readlane broadcasts -- no barriers, the LDS reads of L pipeline.
-// idg: n doubles of LDS work space (reciprocal pivots).
-GL_DEV double lane_bcast(double v, int src) {  // src wave-uniform
-  union {
-    double d;
-    int i[2];
-  } u;
-  u.d = v;
-  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
-  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
-  return u.d;
+// ---- solve: LDL^T of the reduced camera system S x = g (lower triangle), whole workgroup; returns ok ------------
+// Right-looking, blocked by the 6 x 6 pose blocks, the columns kept un-scaled (l_ik = S[i][k] / S[k][k] is applied
+// on the fly).  Every element receives exactly the updates of the scalar algorithm - S[i][j] -= l_ik S[j][k] for
+// ascending k - with the same operands, so the factor does not depend on the blocking or on who holds an element:
+//   n <= 128 (up to 21 free poses): the trailing matrix lives in REGISTERS, element (i, j) with thread
+//     (i mod 16, j mod 16) - up to 8 x 8 per thread; per pose block the six columns that become the panel go to the
+//     LDS work matrix, one thread factorises the diagonal block, one thread per row finishes the panel, and the
+//     trailing update reads 6 + 6 panel values per row / column tile of a thread and works on registers (an LDS-resident
+//     trailing matrix costs 7 LDS reads and a write per 6 multiply-adds on a workgroup with one wave per SIMD).
+//     The forward substitution rides along (see below); the backward one runs by pose blocks on the finished factor.
+//   n > 128: scalar pivots on the matrix in memory, barrier-per-row substitutions.
+// SP is `double*` (work matrix in global memory) or `lds_double*`: with the matrix known to be in LDS the accesses
+// are ds_read / ds_write; through a generic pointer every one is a FLAT access (longer latency, a wait on both
+// counters).  idg: 128 reciprocal pivots + 128 doubles for the right-hand side, in LDS.
+typedef __attribute__((address_space(3))) double lds_double;
+
+// prior information / lambda / unit diagonal of an inactive pose, for element (r, c <= r) of the assembled system
+GL_DEV double diag_terms(const GenP& G, const BaK& k, double lambda, int r, int c, double v) {
+  const int j = r / 6;
+  if (c < 6 * j) return v;
+  if (!G.pact[j]) return r == c ? 1.0 : v;
+  if (G.prior[j] && k.first_as_prior) v += G.prH[(size_t)j * 36 + (r - 6 * j) * 6 + (c - 6 * j)];
+  if (r == c) v += lambda;
+  return v;
 }
-GL_DEV bool block_ldlt_solve(double* S, double* g, int n, int* s_flag, double* idg) {
+
+// diagonal block of a pose (one thread, registers), with the block's part of the forward substitution L y = g: row r
+// receives y_r -= l_rk y_k in ascending k from the thread that has just formed l_rk
+template <class SP>
+GL_DEV void ldlt_diag_block(SP S, int ld, int base, double* idg, double* yv, int* s_flag) {
+  double a[6][6], yb[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    yb[r] = yv[base + r];
+#pragma unroll
+    for (int c = 0; c <= r; ++c) a[r][c] = S[(size_t)(base + r) * ld + base + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double d = a[c][c];
+    if (d == 0.0 || !isfinite(d)) *s_flag = 0;
+    const double id = 1.0 / d;
+    idg[base + c] = id;
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      const double ci = a[r][c] * id;
+#pragma unroll
+      for (int j = c + 1; j <= r; ++j) a[r][j] -= ci * a[j][c];
+      yb[r] = __builtin_fma(-ci, yb[c], yb[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    yv[base + r] = yb[r];
+#pragma unroll
+    for (int c = 0; c <= r; ++c) S[(size_t)(base + r) * ld + base + c] = a[r][c];
+  }
+}
+// panel: the block's six columns of row i (one thread per row), and the row's part of the forward substitution
+template <class SP>
+GL_DEV void ldlt_panel_row(SP S, int ld, int base, int i, const double* idg, double* yv) {
+  double a[6], yi = yv[i];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) a[c] = S[(size_t)i * ld + base + c];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double ci = a[c] * idg[base + c];
+#pragma unroll
+    for (int j = c + 1; j < 6; ++j) a[j] -= ci * S[(size_t)(base + j) * ld + base + c];
+    yi = __builtin_fma(-ci, yv[base + c], yi);
+  }
+#pragma unroll
+  for (int c = 1; c < 6; ++c) S[(size_t)i * ld + base + c] = a[c];
+  yv[i] = yi;
+}
+// y holds L y = g.  z = D^-1 y by division, like the reference LDL^T (multiplying by the reciprocal shifts the last
+// bit and the LM path at convergence); then L^T x = z by pose blocks from the last to the first: one thread finishes
+// the six unknowns of a block, then every row above it takes their six contributions - x_r -= l_kr x_k in descending
+// k, the order of a plain substitution, with l_kr = S[k][r] / S[r][r]; the reads S[k][r] of a step are contiguous
+// over the rows.
+template <class SP>
+GL_DEV void ldlt_backward(SP S, int ld, int n, const double* idg, double* yv, double* g) {
+  const int tid = threadIdx.x;
+  if (tid < n) yv[tid] = yv[tid] / S[(size_t)tid * ld + tid];
+  __syncthreads();
+  for (int base = n - 6; base >= 0; base -= 6) {
+    if (tid == 0) {
+      double x[6], lk[6][6], ir[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        x[r] = yv[base + r];
+        ir[r] = idg[base + r];
+#pragma unroll
+        for (int kq = r + 1; kq < 6; ++kq) lk[kq][r] = S[(size_t)(base + kq) * ld + base + r];
+      }
+#pragma unroll
+      for (int kq = 5; kq >= 1; --kq)
+#pragma unroll
+        for (int r = 0; r < kq; ++r) x[r] = __builtin_fma(-(lk[kq][r] * ir[r]), x[kq], x[r]);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) yv[base + r] = x[r];
+    }
+    __syncthreads();
+    if (tid < base) {
+      double y = yv[tid], sk[6], xk[6];
+      const double ir = idg[tid];
+#pragma unroll
+      for (int kq = 0; kq < 6; ++kq) {
+        sk[kq] = S[(size_t)(base + kq) * ld + tid];
+        xk[kq] = yv[base + kq];
+      }
+#pragma unroll
+      for (int kq = 5; kq >= 0; --kq) y = __builtin_fma(-(sk[kq] * ir), xk[kq], y);
+      yv[tid] = y;
+    }
+    __syncthreads();
+  }
+  if (tid < n) g[tid] = yv[tid];
+}
+
+// n <= 16 A <= 128, n a multiple of 6.  src (row stride lsrc): the assembled system, global memory or the work matrix
+// itself; fuse: add the diagonal terms while loading.  The right-hand side is in yv = idg + 128 (put there by the caller).
+template <int A, class SP>
+GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
+                             double* g, int n, int* s_flag, double* idg) {
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  static_assert(T_BA == 256, "thread (i mod 16, j mod 16) owns element (i, j)");
+  double* yv = idg + 128;
+  if (tid == 0) *s_flag = 1;
+  double v[A][A];
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = ti + 16 * a, j = tj + 16 * b;
+      v[a][b] = (i < n && j <= i) ? src[(size_t)i * lsrc + j] : 0.0;
+    }
+  if (fuse) {
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        const int i = ti + 16 * a, j = tj + 16 * b;
+        if (i < n && j <= i && j >= 6 * (i / 6)) v[a][b] = diag_terms(G, k, lambda, i, j, v[a][b]);
+      }
+  }
+  for (int base = 0; base < n; base += 6) {
+    GP_T(q0);
+    const int m0 = base + 6;
+    // the six columns of this pose leave the registers (elements of other threads' columns are not touched: the
+    // trailing update of the previous block reads columns base - 6 ..., so no barrier is needed before these stores)
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      const int j = tj + 16 * b;
+      if (j >= base && j < m0) {
+#pragma unroll
+        for (int a = b; a < A; ++a) {
+          const int i = ti + 16 * a;
+          if (i < n && j <= i) S[(size_t)i * ld + j] = v[a][b];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
+    __syncthreads();
+    GP_T(q1);
+    if (m0 + tid < n) ldlt_panel_row(S, ld, base, m0 + tid, idg, yv);
+    __syncthreads();
+    GP_T(q2);
+    double idc[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) idc[c] = idg[base + c];
+    double ci[A][6];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      if (16 * a + 15 < m0) continue;  // (uniform) the whole row tile is factorised
+      const int i = min(ti + 16 * a, n - 1);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) ci[a][c] = S[(size_t)i * ld + base + c] * idc[c];
+    }
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      if (16 * b + 15 < m0) continue;
+      const int j = tj + 16 * b, jc = min(j, n - 1);
+      double sj[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) sj[c] = S[(size_t)jc * ld + base + c];
+#pragma unroll
+      for (int a = b; a < A; ++a) {
+        const int i = ti + 16 * a;
+        if (j >= m0 && j <= i && i < n) {
+          double x = v[a][b];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) x -= ci[a][c] * sj[c];
+          v[a][b] = x;
+        }
+      }
+    }
+    GP_T(q3);
+    GP_ADD(9, q0, q1); GP_ADD(10, q1, q2); GP_ADD(11, q2, q3);
+  }
+  ldlt_backward(S, ld, n, idg, yv, g);
+  __syncthreads();
+  return *s_flag != 0;
+}
+template <class SP>
+GL_DEV bool ldlt_solve_small(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
+                             double* g, int n, int* s_flag, double* idg) {
+  if (n <= 32) return ldlt_solve_tiles<2>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 48) return ldlt_solve_tiles<3>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 80) return ldlt_solve_tiles<5>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  return ldlt_solve_tiles<8>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+}
+
+// n > 128 (more than 21 free poses): scalar pivots, ONE barrier per pivot, on the matrix in memory; g in, x out
+GL_DEV bool ldlt_solve_large(double* S, double* g, int n, int ld, int* s_flag) {
   const int tid = threadIdx.x;
   if (tid == 0) *s_flag = 1;
   __syncthreads();
-  if (n <= 128 && n % 6 == 0) {
-    // Blocked by the 6 x 6 pose blocks: diagonal block (one thread, registers) -> panel (one row per
-    // thread) -> trailing update (six pivots per element).  Every element still receives exactly the
-    // updates of the un-blocked loop below, in the same order and with the same operands, so the factor
-    // is bit-identical; there are 3 barriers per pose instead of one per scalar pivot, and six
-    // independent multiply-subtracts per trailing element hide the LDS latency.
-    for (int base = 0; base < n; base += 6) {
-      if (tid == 0) {
-        double a[6][6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c <= r; ++c) a[r][c] = S[(size_t)(base + r) * n + base + c];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double d = a[c][c];
-          if (d == 0.0 || !isfinite(d)) *s_flag = 0;
-          const double id = 1.0 / d;
-          idg[base + c] = id;
-#pragma unroll
-          for (int r = c + 1; r < 6; ++r) {
-            const double ci = a[r][c] * id;
-#pragma unroll
-            for (int j = c + 1; j <= r; ++j) a[r][j] -= ci * a[j][c];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c <= r; ++c) S[(size_t)(base + r) * n + base + c] = a[r][c];
-      }
-      __syncthreads();
-      const int m0 = base + 6;
-      for (int i = m0 + tid; i < n; i += T_BA) {  // panel: finish the block's columns of row i
-        double a[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) a[c] = S[(size_t)i * n + base + c];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double ci = a[c] * idg[base + c];
-#pragma unroll
-          for (int j = c + 1; j < 6; ++j) a[j] -= ci * S[(size_t)(base + j) * n + base + c];
-        }
-#pragma unroll
-        for (int c = 1; c < 6; ++c) S[(size_t)i * n + base + c] = a[c];
-      }
-      __syncthreads();
-      for (int i = m0 + (tid >> 4); i < n; i += T_BA / 16) {  // trailing update
-        double ci[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) ci[c] = S[(size_t)i * n + base + c] * idg[base + c];
-        for (int j = m0 + (tid & 15); j <= i; j += 16) {
-          double v = S[(size_t)i * n + j];
-#pragma unroll
-          for (int c = 0; c < 6; ++c) v -= ci[c] * S[(size_t)j * n + base + c];
-          S[(size_t)i * n + j] = v;
-        }
-      }
-      __syncthreads();
+  for (int kk = 0; kk < n; ++kk) {
+    const double d = S[(size_t)kk * ld + kk];
+    if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
+    // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
+    const double id = 1.0 / d;
+    for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
+      const double ci = S[(size_t)i * ld + kk] * id;
+      for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * ld + j] -= ci * S[(size_t)j * ld + kk];
     }
-  } else {
-    for (int kk = 0; kk < n; ++kk) {
-      const double d = S[(size_t)kk * n + kk];
-      if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
-      // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
-      const double id = 1.0 / d;
-      if (tid == 0 && kk < 128) idg[kk] = id;
-      for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
-        const double ci = S[(size_t)i * n + kk] * id;
-        for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * n + j] -= ci * S[(size_t)j * n + kk];
-      }
-      __syncthreads();
-    }
-  }
-  if (n > 128) {  // more than 21 free poses: barrier-per-row substitution on the un-scaled columns
-    for (int kk = 0; kk < n; ++kk) {
-      const double yk = g[kk] / S[(size_t)kk * n + kk];
-      __syncthreads();
-      for (int i = kk + 1 + tid; i < n; i += T_BA) g[i] -= S[(size_t)i * n + kk] * yk;
-      __syncthreads();
-    }
-    for (int i = tid; i < n; i += T_BA) g[i] /= S[(size_t)i * n + i];
     __syncthreads();
-    for (int kk = n - 1; kk >= 0; --kk) {
-      const double xk = g[kk];
-      __syncthreads();
-      for (int i = tid; i < kk; i += T_BA) g[i] -= S[(size_t)kk * n + i] / S[(size_t)i * n + i] * xk;
-      __syncthreads();
-    }
-  } else if (tid < 64) {
-    const int lane = tid, r0 = lane, r1 = lane + 64;
-    double y0 = r0 < n ? g[r0] : 0.0, y1 = r1 < n ? g[r1] : 0.0;
-    // forward: L y = g,  l_rk = S[r][k] * idg[k].  The only serial chain is y_k -> y_r; the LDS operands
-    // of four pivots are fetched together so that their latency is paid once per four steps.
-    const double* row0 = S + (size_t)(r0 < n ? r0 : 0) * n;
-    const double* row1 = S + (size_t)(r1 < n ? r1 : 0) * n;
-    for (int k0 = 0; k0 < n; k0 += 4) {
-      double a0[4], a1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = min(k0 + u, n - 1);
-        const double ik = idg[kk];
-        a0[u] = row0[kk] * ik;
-        a1[u] = row1[kk] * ik;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = k0 + u;
-        if (kk < n) {
-          const double yk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
-          if (r0 > kk && r0 < n) y0 -= a0[u] * yk;
-          if (r1 > kk && r1 < n) y1 -= a1[u] * yk;
-        }
-      }
-    }
-    if (r0 < n) y0 /= S[(size_t)r0 * n + r0];  // division, like the reference LDL^T (multiplying by the
-    if (r1 < n) y1 /= S[(size_t)r1 * n + r1];  // reciprocal shifts the last bit and the LM path at convergence)
-    // backward: L^T x = z,  (L^T)_rk = l_kr = S[k][r] * idg[r]
-    const double i0 = r0 < n ? idg[r0] : 0.0, i1 = r1 < n ? idg[r1] : 0.0;
-    const int c0 = r0 < n ? r0 : 0, c1 = r1 < n ? r1 : 0;
-    for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
-      double a0[4], a1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = max(k0 - u, 0);
-        a0[u] = S[(size_t)kk * n + c0] * i0;
-        a1[u] = S[(size_t)kk * n + c1] * i1;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = k0 - u;
-        if (kk >= 0) {
-          const double xk = kk < 64 ? lane_bcast(y0, kk) : lane_bcast(y1, kk - 64);
-          if (r0 < kk) y0 -= a0[u] * xk;
-          if (r1 < kk && r1 < n) y1 -= a1[u] * xk;
-        }
-      }
-    }
-    if (r0 < n) g[r0] = y0;
-    if (r1 < n) g[r1] = y1;
   }
+  for (int kk = 0; kk < n; ++kk) {
+    const double yk = g[kk] / S[(size_t)kk * ld + kk];
+    __syncthreads();
+    for (int i = kk + 1 + tid; i < n; i += T_BA) g[i] -= S[(size_t)i * ld + kk] * yk;
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += T_BA) g[i] /= S[(size_t)i * ld + i];
   __syncthreads();
+  for (int kk = n - 1; kk >= 0; --kk) {
+    const double xk = g[kk];
+    __syncthreads();
+    for (int i = tid; i < kk; i += T_BA) g[i] -= S[(size_t)kk * ld + i] / S[(size_t)i * ld + i] * xk;
+    __syncthreads();
+  }
   return *s_flag != 0;
 }
 
 GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag,
                         double* s_lds, double* p2part) {
-  const int P = G.P, n = 6 * P, tid = threadIdx.x;
+  const int P = G.P, n = 6 * P, ld = G.ld, tid = threadIdx.x;
   // lanes per point in the point passes: as many (1, 2, 4) as the problem's threads allow in one round
   const int lpp = (G.NB * T_BA >= 4 * G.L) ? 4 : (G.NB * T_BA >= 2 * G.L) ? 2 : 1;
   double acc[32];
@@ -755,22 +837,33 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
   double lambda = 0.0, ni = 2.0;
   int cj = 0;
   for (int it = 0; it < iters; ++it) {
+    // Prior edges at the current state: that state changes once per outer iteration (an accepted trial ends the
+    // inner loop), so their information / rhs / chi2 are formed here and not per trial, by the LAST threads of the
+    // problem - which have no point of the first pass when the problem's threads outnumber its points - so that the
+    // serial pose algebra overlaps the point pass; the barriers of that pass publish the result.
+    {
+      const int rev = G.NB * T_BA - 1 - (G.pb * T_BA + tid);
+      if (rev < P) {
+        const int j = rev;
+        double H[36], b[6] = {0, 0, 0, 0, 0, 0}, chi = 0.0;
+        for (int r = 0; r < 36; ++r) H[r] = 0.0;
+        if (G.pact[j] && G.prior[j] && k.first_as_prior)
+          chi = prior_terms(se3_load(G.pinv + (size_t)j * 7), se3_load(G.poses + (size_t)j * 7), true, H, b);
+        for (int r = 0; r < 36; ++r) G.prH[(size_t)j * 36 + r] = H[r];
+        for (int r = 0; r < 6; ++r) G.prb[(size_t)j * 6 + r] = b[r];
+        G.pchi[j] = chi;
+      }
+    }
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
       pass_points_lpp(lpp, k, gm, G, robust, 0.0, md);
-      for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
+      for (int i = GSTART; i < n * ld; i += GSTRIDE) S[i] = 0.0;
       prob_sync(G);
       pass_blocks(G, false, p2part);
       prob_sync(G);
       for (int j = GSTART; j < P; j += GSTRIDE) {
         if (!G.pact[j]) continue;
-        double H[36], b[6] = {0, 0, 0, 0, 0, 0};
-        for (int r = 0; r < 36; ++r) H[r] = 0.0;
-        if (G.prior[j] && k.first_as_prior) {
-          const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
-          prior_terms(Pi, T, true, H, b);
-        }
-        for (int r = 0; r < 6; ++r) md = fmax(md, fabs(S[(size_t)(6 * j + r) * n + 6 * j + r] + H[r * 6 + r]));
+        for (int r = 0; r < 6; ++r) md = fmax(md, fabs(S[(size_t)(6 * j + r) * ld + 6 * j + r] + G.prH[(size_t)j * 36 + r * 6 + r]));
       }
       md = prob_max(G, md, red);
       lambda = 1e-5 * md;
@@ -785,7 +878,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
       acc[0] = pass_points_lpp(lpp, k, gm, G, robust, lambda, md_unused);
-      for (int i = GSTART; i < n * n; i += GSTRIDE) S[i] = 0.0;
+      for (int i = GSTART; i < n * ld; i += GSTRIDE) S[i] = 0.0;
       for (int i = GSTART; i < n; i += GSTRIDE) {
         G.gv[i] = 0.0;
         G.bp[i] = 0.0;
@@ -801,42 +894,46 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       bool ok2 = true;
       GP_T(t3);
       if (G.pb == 0) {
-        for (int j = tid; j < P; j += T_BA) {
-          G.pchi[j] = 0.0;
-          if (!G.pact[j]) {
-            for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] = 1.0;
-            continue;
-          }
-          if (G.prior[j] && k.first_as_prior) {
-            double H[36], b[6] = {0, 0, 0, 0, 0, 0};
-            for (int r = 0; r < 36; ++r) H[r] = 0.0;
-            const SE3 T = se3_load(G.poses + (size_t)j * 7), Pi = se3_load(G.pinv + (size_t)j * 7);
-            G.pchi[j] = prior_terms(Pi, T, true, H, b);
-            for (int r = 0; r < 6; ++r) {
-              G.gv[6 * j + r] += b[r];
-              G.bp[6 * j + r] += b[r];
-              for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * n + 6 * j + c] += H[r * 6 + c];
+        // n <= 128: the solve loads the assembled system into registers (from global memory when the problem has
+        // several workgroups, adding the diagonal terms on the way; from this workgroup's LDS, in place, when it has
+        // one) and factorises it in the LDS work matrix; larger systems are factorised in place in global memory
+        const bool small = n <= 128 && s_lds != nullptr;
+        if (G.NB == 1 || !small) {
+          for (int j = tid; j < P; j += T_BA) {
+            if (!G.pact[j]) {
+              for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * ld + 6 * j + r] = 1.0;
+              continue;
             }
+            if (G.prior[j] && k.first_as_prior) {
+              const double* H = G.prH + (size_t)j * 36;
+              for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * ld + 6 * j + c] += H[r * 6 + c];
+            }
+            for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * ld + 6 * j + r] += lambda;
           }
-          for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * n + 6 * j + r] += lambda;
+        }
+        // right-hand side (+ the prior's), into the solve's LDS vector when the system is small enough for it
+        for (int i = tid; i < n; i += T_BA) {
+          const int j = i / 6;
+          double v = G.gv[i];
+          if (G.pact[j] && G.prior[j] && k.first_as_prior) {
+            const double b = G.prb[i];
+            v += b;
+            G.bp[i] += b;
+          }
+          G.dxv[i] = v;
+          if (n <= 128) red[128 + i] = v;
         }
         __syncthreads();
         GP_T(u0);
-        // the solve works in place when S is this workgroup's LDS (NB == 1), else on a copy (LDS when it fits)
-        double* W = S;
-        if (G.NB > 1) {
-          W = s_lds ? s_lds : G.Sw;
-          for (int i = tid; i < n * n; i += T_BA) W[i] = S[i];
-        }
-        for (int i = tid; i < n; i += T_BA) G.dxv[i] = G.gv[i];
-        __syncthreads();
-        GP_T(u1);
         bool ok = true;
-        if (any_pose) ok = block_ldlt_solve(W, G.dxv, n, s_flag, red);
+        if (any_pose)
+          ok = small ? ldlt_solve_small(G, k, lambda, S, ld, G.NB > 1, (lds_double*)s_lds, ld, G.dxv, n, s_flag, red)
+                     : ldlt_solve_large(S, G.dxv, n, ld, s_flag);
         if (tid == 0) *G.flagg = ok ? 1 : 0;
         __syncthreads();
         GP_T(u2);
-        GP_ADD(6, t3, u0); GP_ADD(7, u0, u1); GP_ADD(8, u1, u2);
+        GP_ADD(6, t3, u0); GP_ADD(8, u0, u2);
         // trial poses
         for (int j = tid; j < P; j += T_BA) {
           const SE3 T = se3_load(G.poses + (size_t)j * 7);
@@ -913,7 +1010,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
                                                  int32_t* __restrict__ iters_all, char* __restrict__ scratch,
                                                  size_t scratch_per_problem, int s_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // reduced camera system when it fits
-  __shared__ double red[NW_BA * 32];
+  __shared__ double red[NW_BA * 32 + 128];  // reductions / reciprocal pivots (128) + the right-hand side of the solve (128)
   __shared__ double p2part[NW_BA * 64];  // pass_blocks: sums of the waves that share a block
   __shared__ int s_flag;
   const int f = blockIdx.x / NB, tid = threadIdx.x;
@@ -952,10 +1049,14 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.lin = takeD((size_t)NOBS * 12);
   G.ptw = takeD((size_t)L * 12);
   G.chi_o = takeD((size_t)NOBS);
-  G.S = takeD((size_t)n * n);
-  G.Sw = takeD((size_t)n * n);
+#ifndef GL_LD_PAD
+#define GL_LD_PAD 1  // odd row stride: the column reads of the solve spread over the LDS banks
+#endif
+  G.ld = n + GL_LD_PAD;  // row stride of S
+  G.S = takeD((size_t)n * G.ld);
   G.part = takeD((size_t)2 * 64 * 4);
   G.toggle = 0;
+  G.epoch = 0u;
   // one workgroup: the in-place LDL^T does ~4n barriers, keep S next to the CU (6P <= 120)
   if (s_in_lds && NB == 1) G.S = dyn_lds;
   G.gv = takeD(n);
@@ -963,6 +1064,8 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.dxv = takeD(n);
   G.pchi = takeD(P);
   G.pchi2 = takeD(P);
+  G.prH = takeD((size_t)P * 36);
+  G.prb = takeD((size_t)P * 6);
   auto takeI = [&](size_t cnt) {
     int32_t* p = (int32_t*)s;
     s += ((cnt * 4 + 7) / 8) * 8;
@@ -1041,6 +1144,8 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   double* s_lds = s_in_lds ? dyn_lds : nullptr;
 
   // ---- schedule (:770-828) ---------------------------------------------------------------------------
+  // (three inlined copies of the optimiser, each with its constants folded: a loop over the stages gives a third of
+  // the code but other contraction decisions, i.e. other last bits than the validated build)
   gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds, p2part);
   prob_sync(G);
   for (int l = GSTART; l < L; l += GSTRIDE) {
@@ -1078,14 +1183,14 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   if (G.pb == 0 && tid == 0 && iters_all) iters_all[f] = it3;
 #ifdef GL_BAGEN_PROF
   if (blockIdx.x == 0 && tid == 0)
-    for (int i = 0; i < 9; ++i) G.poses[i] = (double)g_gprof[i];  // debug build: phase cycles instead of poses 0-1
+    for (int i = 0; i < 12; ++i) G.poses[i] = (double)g_gprof[i];  // debug build: phase cycles instead of poses 0-1
 #endif
 }
 
 size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
   const size_t n = 6 * (size_t)P;
   size_t d = (size_t)(P + F) * 12 + (size_t)P * 12 + (size_t)P * 7 * 2 + (size_t)L * 3 + (size_t)NOBS * 12 +
-             (size_t)L * 12 + NOBS + 2 * n * n + 512 + 3 * n + 2 * P;
+             (size_t)L * 12 + NOBS + n * (n + 2) + 512 + 3 * n + 2 * P + 42 * (size_t)P;
   size_t i = (size_t)NOBS * 2 + (P + 1) + (size_t)NOBS * P + 32;
   size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
   return d * 8 + i * 4 + b + 256;
@@ -1114,8 +1219,8 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   if (rc != GL_OK) return rc;
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   const size_t n = 6 * (size_t)P;
-  const size_t s_bytes = n * n * sizeof(double);
-  int s_in_lds = s_bytes <= 120 * 1024 ? 1 : 0;
+  const size_t s_bytes = n * (n + GL_LD_PAD) * sizeof(double);
+  int s_in_lds = s_bytes <= 136 * 1024 ? 1 : 0;  // 6 P <= 126: every system the register-tile solve takes
   const size_t lds = s_in_lds ? s_bytes : 0;
   if (s_in_lds)
     GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_ba_gen, s_bytes));
