@@ -68,8 +68,10 @@ struct GenP {
   double* prb;
   int32_t* opoint; // nobs
   int32_t* pl_ptr; // P + 1
-  int32_t* pl_obs; // nobs
-  int32_t* match;  // nobs x P
+  int32_t* pl_obs; // nobs: pose-major list of the free poses' observations
+  int32_t* pl_pos; // nobs: position of an observation in that list
+  int32_t* pl_pt;  // nobs: point of the e-th entry of the list
+  int32_t* plm;    // nobs x P: partner of the e-th entry in pose j2 (itself for its own pose); -1: none, or an edge at level 1
   uint8_t* lev_o;  // nobs
   uint8_t* lev_g;  // L
   uint8_t* pfree;  // P + F
@@ -79,27 +81,36 @@ struct GenP {
   int ld;              // row stride of S (doubles)
   int NB, pb;          // workgroups per problem, index of this one
   int toggle;          // which partial-sum buffer the next reduction uses
-  unsigned* bar;       // arrival counter of the problem's barrier
-  unsigned epoch;      // arrivals that complete the next barrier
+  unsigned* bar;       // 64 arrival words of the problem's barrier
+  unsigned epoch;      // barriers passed
   double* part;        // NB x 4 partial sums
   int* flagg;          // solve status
 };
 
-// barrier over the NB workgroups of one problem (all co-resident: cooperative launch).  One monotonic arrival
-// counter (zeroed by the host): an arrival is one fire-and-forget add, the k-th barrier is passed when the counter
-// reaches k NB - no reset, no generation word, one fabric round trip less than the classic two-word barrier.
+// barrier over the NB <= 64 workgroups of one problem (all co-resident: cooperative launch).  One flag word per
+// workgroup (zeroed by the host): a workgroup announces its k-th arrival by storing k into its own word and the lanes
+// of its first wave read everybody's word until all of them say k - plain stores to different words and one 256-byte
+// read per poll, where NB read-modify-writes of ONE counter would queue up behind each other at the memory side.
 GL_DEV void prob_sync(GenP& G) {
+  GP_T(b0);
   __syncthreads();
+  GP_T(b1);
+  GP_ADD(7, b0, b1);  // waiting for the own workgroup
   if (G.NB > 1) {
-    G.epoch += (unsigned)G.NB;
-    if (threadIdx.x == 0) {
-      __threadfence();
-      __hip_atomic_fetch_add(&G.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((int)(__hip_atomic_load(&G.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - G.epoch) < 0)
+    G.epoch += 1u;
+    if (threadIdx.x < 64) {
+      if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_store(&G.bar[G.pb], G.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int w = min((int)threadIdx.x, G.NB - 1);
+      while (!__all((int)(__hip_atomic_load(&G.bar[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - G.epoch) >= 0))
         __builtin_amdgcn_s_sleep(1);
       __threadfence();
     }
     __syncthreads();
+    GP_T(b2);
+    GP_ADD(10, b1, b2);  // (debug build: replaces the panel slot) the cross-workgroup part
   }
 }
 // problem-wide sum of NV (<= 4) per-thread values: workgroup reduction, partials to global memory,
@@ -247,6 +258,35 @@ GL_DEV void gmg(const double* q1, const double* M, const double* q2, double* blk
 // ---- P1 -------------------------------------------------------------------------------------
 // returns (per-thread partial) robust chi2; mdiag = max landmark diagonal (world frame)
 // sum over the LPP adjacent lanes that share one point (every lane gets it)
+// Round-trip economy of the point passes.  A thread walks the observations of its point, and every record it
+// needs (flag, pose index, key-point, then the pose) used to be fetched where the code first tests it - four to six
+// dependent global-memory latencies per observation, on a workgroup with one wave per SIMD and nothing to switch
+// to.  Now the record of an observation {flag, pose, octave, key-point} is fetched as one round BEFORE the flag is
+// tested, one observation ahead of its use, and the pose-indexed data as a second round; `pin` keeps the compiler from
+// sinking those loads back behind the tests.  The arithmetic is untouched.
+GL_DEV void pin(double x) { asm volatile("" ::"v"(x)); }
+GL_DEV void pin(int x) { asm volatile("" ::"v"(x)); }
+struct ObsRec {
+  int lv, j, oc;
+  double ob[3];
+};
+GL_DEV void fetch_obs(const GenP& G, int o, int o_end, ObsRec& r) {
+  const int oc = min(o, o_end - 1);  // (one past the end: re-reads the last record)
+  r.lv = G.lev_o[oc];
+  r.j = G.opose[oc];
+  r.oc = G.ooct[oc];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.ob[i] = G.ouvr[(size_t)oc * 3 + i];
+}
+GL_DEV void pin_obs(const ObsRec& r) {
+  pin(r.lv);
+  pin(r.j);
+  pin(r.oc);
+  pin(r.ob[0]);
+  pin(r.ob[1]);
+  pin(r.ob[2]);
+}
+
 template <int LPP>
 GL_DEV double group_sum(double v) {
   if (LPP >= 2) v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
@@ -263,12 +303,19 @@ GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool ro
     if (!G.lact[l]) continue;  // the same for the LPP lanes of the group
     const double p[3] = {G.pts[(size_t)l * 3], G.pts[(size_t)l * 3 + 1], G.pts[(size_t)l * 3 + 2]};
     double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    for (int o = G.optr[l] + sub; o < G.optr[l + 1]; o += LPP) {
-      if (G.lev_o[o]) continue;
-      const int j = G.opose[o];
+    const int o_end = G.optr[l + 1];
+    ObsRec cur;
+    if (G.optr[l] + sub < o_end) fetch_obs(G, G.optr[l] + sub, o_end, cur);
+    for (int o = G.optr[l] + sub; o < o_end; o += LPP) {
+      ObsRec nxt;
+      fetch_obs(G, o + LPP, o_end, nxt);
+      const ObsRec rec = cur;
       double R[9], t[3], q[3], A[6], a[3], c2, r0;
-      load_Rt(G.Rt + (size_t)j * 12, R, t);
-      lin_obs(k, R, t, p, G.ouvr + (size_t)o * 3, G.ooct[o], robust, q, A, a, c2, r0);
+      load_Rt(G.Rt + (size_t)rec.j * 12, R, t);
+      pin_obs(nxt);
+      cur = nxt;
+      if (rec.lv) continue;
+      lin_obs(k, R, t, p, rec.ob, rec.oc, robust, q, A, a, c2, r0);
       G.chi_o[o] = c2;
       chi += r0;
       double* lo = G.lin + (size_t)o * 12;
@@ -366,19 +413,31 @@ GL_DEV void pass_trial(const BaK& k, const GmmDev& gm, const GenP& G, bool robus
       rhs[1] = pw[10];
       rhs[2] = pw[11];
     }
-    for (int o = G.optr[l] + sub; o < G.optr[l + 1]; o += LPP) {
-      if (G.lev_o[o]) continue;
-      const int j = G.opose[o];
-      if (j >= P || !G.pact[j]) continue;
-      const double* lo = G.lin + (size_t)o * 12;
-      const double* dx = G.dxv + 6 * j;
+    const int o_beg = G.optr[l] + sub, o_end = G.optr[l + 1];
+    for (int o = o_beg; o < o_end; o += LPP) {  // (two rounds of loads, then the tests: see fetch_obs)
+      const int lv = G.lev_o[o], j = G.opose[o], jf = min(j, P - 1);
+      double lo[9], dx[6], R[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) lo[i] = G.lin[(size_t)o * 12 + i];
+      const int pa = G.pact[jf];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dx[i] = G.dxv[6 * jf + i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = G.Rt[(size_t)j * 12 + i];
+      pin(pa);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pin(lo[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pin(dx[i]);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pin(R[i]);
+      if (lv || j >= P || !pa) continue;
       double gd[3], Ag[3];
       cross(dx, lo, gd);
       gd[0] += dx[3];
       gd[1] += dx[4];
       gd[2] += dx[5];
       sym3_mul_vec(lo + 3, gd, Ag);
-      const double* R = G.Rt + (size_t)j * 12;
 #pragma unroll
       for (int i = 0; i < 3; ++i) rhs[i] -= R[i] * Ag[0] + R[3 + i] * Ag[1] + R[6 + i] * Ag[2];
     }
@@ -394,16 +453,28 @@ GL_DEV void pass_trial(const BaK& k, const GmmDev& gm, const GenP& G, bool robus
 #pragma unroll
       for (int i = 0; i < 3; ++i) G.pn[(size_t)l * 3 + i] = pn[i];
     }
-    for (int o = G.optr[l] + sub; o < G.optr[l + 1]; o += LPP) {
-      if (G.lev_o[o]) continue;
-      const int j = G.opose[o];
+    ObsRec cur;
+    if (o_beg < o_end) fetch_obs(G, o_beg, o_end, cur);
+    for (int o = o_beg; o < o_end; o += LPP) {
+      ObsRec nxt;
+      fetch_obs(G, o + LPP, o_end, nxt);
+      const ObsRec rec = cur;
+      const int j = rec.j;
       const double* Rt = (j < P) ? G.RtN + (size_t)j * 12 : G.Rt + (size_t)j * 12;
+      double Rv[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Rv[i] = Rt[i];
+      pin_obs(nxt);
+      cur = nxt;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pin(Rv[i]);
+      if (rec.lv) continue;
       double q[3], e[3], iz;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) q[i] = Rt[i * 3] * pn[0] + Rt[i * 3 + 1] * pn[1] + Rt[i * 3 + 2] * pn[2] + Rt[9 + i];
-      const double* ob = G.ouvr + (size_t)o * 3;
+      for (int i = 0; i < 3; ++i) q[i] = Rv[i * 3] * pn[0] + Rv[i * 3 + 1] * pn[1] + Rv[i * 3 + 2] * pn[2] + Rv[9 + i];
+      const double* ob = rec.ob;
       const bool stereo = !(ob[2] < 0);
-      const double c2 = reproj_err(k, q, ob, stereo, k.s2inv[G.ooct[o]], e, iz);
+      const double c2 = reproj_err(k, q, ob, stereo, k.s2inv[rec.oc], e, iz);
       G.chi_o[o] = c2;
       double r0 = c2, r1;
       if (robust) huber(c2, stereo ? k.delta_stereo : k.delta_mono, r0, r1);
@@ -455,14 +526,17 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
     load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
     load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
     for (int e = G.pl_ptr[j1] + sub * 64 + lane; act && e < G.pl_ptr[j1 + 1]; e += 64 * W) {
+      // (partner, observation and point come from position-indexed tables in one round of loads; the level flags
+      // are folded into the partner table when they change)
+      const int o2 = G.plm[(size_t)e * P + j2];
       const int o1 = G.pl_obs[e];
-      if (G.lev_o[o1]) continue;
-      const int o2 = (j1 == j2) ? o1 : G.match[(size_t)o1 * P + j2];
-      if (o2 < 0 || G.lev_o[o2]) continue;
-      const int l = G.opoint[o1];
+      const int l = G.pl_pt[e];
+      if (o2 < 0) continue;
       const double* l1 = G.lin + (size_t)o1 * 12;
       const double* l2 = G.lin + (size_t)o2 * 12;
       const double* pw = G.ptw + (size_t)l * 12;
+      // (reading the three records into local arrays first - the way to software-pipeline this loop - changes the
+      // compiler's contraction of the block products, i.e. the last bits of the validated build: measured, not done)
       double A1[9], A2[9], Dv[9];
       sym_to_full(l1 + 3, A1);
       sym_to_full(l2 + 3, A2);
@@ -756,7 +830,7 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       }
     }
     GP_T(q3);
-    GP_ADD(9, q0, q1); GP_ADD(10, q1, q2); GP_ADD(11, q2, q3);
+    GP_ADD(9, q0, q1); GP_ADD(11, q2, q3);
   }
   ldlt_backward(S, ld, n, idg, yv, g);
   __syncthreads();
@@ -1031,11 +1105,11 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.ooct = ooct_all + (size_t)f * NOBS;
   G.nobs = G.optr[L];
   const int nobs = G.nobs, n = 6 * P;
-  // scratch = | B x 64 B headers {barrier arrivals, generation, solve flag} (zeroed by the host) | per-problem areas |
-  G.bar = (unsigned*)(scratch + (size_t)f * 64);
-  G.flagg = (int*)(G.bar + 2);
+  // scratch = | B x 512 B headers {64 barrier words, solve flag} (zeroed by the host) | per-problem areas |
+  G.bar = (unsigned*)(scratch + (size_t)f * 512);
+  G.flagg = (int*)(G.bar + 64);
   // carve the problem's area (doubles first, then ints, then bytes)
-  char* s = scratch + (size_t)B * 64 + (size_t)f * scratch_per_problem;
+  char* s = scratch + (size_t)B * 512 + (size_t)f * scratch_per_problem;
   auto takeD = [&](size_t cnt) {
     double* p = (double*)s;
     s += cnt * 8;
@@ -1074,7 +1148,9 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.opoint = takeI(NOBS);
   G.pl_ptr = takeI(P + 1);
   G.pl_obs = takeI(NOBS);
-  G.match = takeI((size_t)NOBS * P);
+  G.pl_pos = takeI(NOBS);
+  G.pl_pt = takeI(NOBS);
+  G.plm = takeI((size_t)NOBS * P);
   auto takeB = [&](size_t cnt) {
     uint8_t* p = (uint8_t*)s;
     s += ((cnt + 7) / 8) * 8;
@@ -1103,14 +1179,8 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
       G.chi_o[o] = 0.0;
     }
   }
-  for (size_t i = GSTART; i < (size_t)nobs * P; i += GSTRIDE) G.match[i] = -1;
+  for (size_t i = GSTART; i < (size_t)nobs * P; i += GSTRIDE) G.plm[i] = -1;
   prob_sync(G);
-  for (int l = GSTART; l < L; l += GSTRIDE)
-    for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1)
-      for (int o2 = G.optr[l]; o2 < G.optr[l + 1]; ++o2) {
-        const int j2 = G.opose[o2];
-        if (j2 < P) G.match[(size_t)o1 * P + j2] = o2;
-      }
   // pose-major CSR: wave-per-pose ordered compaction (two sweeps: count, fill)
   {
     const int lane = tid & 63, gw = G.pb * NW_BA + (tid >> 6), gnw = G.NB * NW_BA;
@@ -1135,11 +1205,27 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
         const int o = o0 + lane;
         const bool hit = o < nobs && G.opose[o] == j;
         const unsigned long long m = __ballot(hit);
-        if (hit) G.pl_obs[base + __popcll(m & ((1ull << lane) - 1ull))] = o;
+        if (hit) {
+          const int e = base + __popcll(m & ((1ull << lane) - 1ull));
+          G.pl_obs[e] = o;
+          G.pl_pos[o] = e;
+          G.pl_pt[e] = G.opoint[o];
+        }
         base += __popcll(m);
       }
     }
   }
+  prob_sync(G);
+  // partner table, indexed by list position: entry (e, j2) = the observation of the same point in free pose j2
+  for (int l = GSTART; l < L; l += GSTRIDE)
+    for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1) {
+      if (G.opose[o1] >= P) continue;
+      const size_t row = (size_t)G.pl_pos[o1] * P;
+      for (int o2 = G.optr[l]; o2 < G.optr[l + 1]; ++o2) {
+        const int j2 = G.opose[o2];
+        if (j2 < P) G.plm[row + j2] = o2;
+      }
+    }
   prob_sync(G);
   double* s_lds = s_in_lds ? dyn_lds : nullptr;
 
@@ -1164,6 +1250,12 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
       const bool stereo = !(G.ouvr[(size_t)o * 3 + 2] < 0);
       if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
     }
+  prob_sync(G);
+  // the partner table forgets the edges that are now at level 1
+  for (size_t i = GSTART; i < (size_t)G.pl_ptr[P] * P; i += GSTRIDE) {
+    const int o2 = G.plm[i];
+    if (o2 >= 0 && (G.lev_o[o2] || G.lev_o[G.pl_obs[i / P]])) G.plm[i] = -1;
+  }
   prob_sync(G);
   const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds, p2part);
   prob_sync(G);
@@ -1191,7 +1283,7 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
   const size_t n = 6 * (size_t)P;
   size_t d = (size_t)(P + F) * 12 + (size_t)P * 12 + (size_t)P * 7 * 2 + (size_t)L * 3 + (size_t)NOBS * 12 +
              (size_t)L * 12 + NOBS + n * (n + 2) + 512 + 3 * n + 2 * P + 42 * (size_t)P;
-  size_t i = (size_t)NOBS * 2 + (P + 1) + (size_t)NOBS * P + 32;
+  size_t i = (size_t)NOBS * 4 + (P + 1) + (size_t)NOBS * P + 32;
   size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
   return d * 8 + i * 4 + b + 256;
 }
@@ -1215,7 +1307,7 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
   GL_HIP(hipSetDevice(c->device));
   const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
   void* scratch = nullptr;
-  int rc = gl::ctx_scratch(c, (size_t)B * 64 + per * B, &scratch);
+  int rc = gl::ctx_scratch(c, (size_t)B * 512 + per * B, &scratch);
   if (rc != GL_OK) return rc;
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   const size_t n = 6 * (size_t)P;
@@ -1245,11 +1337,12 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     const int want = NOBS <= 600 ? 1 : NOBS <= 2000 ? 8 : NOBS <= 6000 ? 16 : NOBS <= 16000 ? 32 : 64;
     NB = (int)std::min<long>(want, cap / B);
     if (c->opt.bagen_nb > 0) NB = (int)std::min<long>(std::max(1, (int)c->opt.bagen_nb), cap / B);  // knob: that many workgroups per problem (tests: 1)
+    NB = std::min(NB, 64);  // (the barrier has 64 arrival words)
     if (NB < 2) NB = 1;
   }
   {
     gl::TimerScope ts(c, GL_TIMER_BA);
-    GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 64, c->stream));
+    GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 512, c->stream));
     BaK kk = make_bak(cam, prm, -1.0);
     char* scr = (char*)scratch;
     size_t per_v = per;

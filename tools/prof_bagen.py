@@ -26,4 +26,5 @@ for n, v in zip(names, c):
     print("%-10s %12.0f cycles %5.1f %%" % (n, v, 100 * v / tot if n != "trials" else 0))
 print("per trial: %.0f cycles, observations %d" % (tot / max(c[5], 1), len(p["obs_pose"])))
 print("  inside solve phase, per trial: priors %.0f  copy %.0f  ldlt %.0f  (rest = trial poses + barrier)" % tuple(c[6:9] / max(c[5], 1)))
-print("  inside ldlt, per trial: diagonal block %.0f  panel %.0f  trailing %.0f" % tuple(c[9:12] / max(c[5], 1)))
+print("  inside ldlt, per trial: diagonal block %.0f  trailing %.0f" % (c[9] / max(c[5], 1), c[11] / max(c[5], 1)))
+print("  barriers of workgroup 0, per trial (all phases, setup included): own workgroup %.0f  other workgroups + fences %.0f" % (c[7] / max(c[5], 1), c[10] / max(c[5], 1)))
