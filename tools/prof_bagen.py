@@ -20,11 +20,11 @@ api.joint_optimization(ctx, g, cam, prm, P, F, poses, T(p["prior"][None]), T(p["
                        T(p["obs_pose"][None]), T(p["obs_uvr"][None]), T(p["obs_oct"][None]))
 torch.cuda.synchronize()
 c = poses[0, :2].reshape(-1).cpu().numpy()  # 14 doubles
-names = ["P1 points", "P2 blocks", "priors", "solve", "P3+accept", "trials"]
+names = ["P1 points", "P2 blocks", "(gap)", "solve", "P3+accept", "trials"]
 tot = c[:5].sum()
 for n, v in zip(names, c):
     print("%-10s %12.0f cycles %5.1f %%" % (n, v, 100 * v / tot if n != "trials" else 0))
 print("per trial: %.0f cycles, observations %d" % (tot / max(c[5], 1), len(p["obs_pose"])))
-print("  inside solve phase, per trial: priors %.0f  copy %.0f  ldlt %.0f  (rest = trial poses + barrier)" % tuple(c[6:9] / max(c[5], 1)))
-print("  inside ldlt, per trial: diagonal block %.0f  trailing %.0f" % (c[9] / max(c[5], 1), c[11] / max(c[5], 1)))
+print("  inside solve phase, per trial: diagonal terms / right-hand side %.0f  LDL^T solve %.0f  (rest = trial poses + barrier)" % (c[6] / max(c[5], 1), c[8] / max(c[5], 1)))
+print("  inside the solve, per trial: panel columns out + diagonal block %.0f  trailing update (registers) %.0f  (rest = load, panel rows, backward substitution)" % (c[9] / max(c[5], 1), c[11] / max(c[5], 1)))
 print("  barriers of workgroup 0, per trial (all phases, setup included): own workgroup %.0f  other workgroups + fences %.0f" % (c[7] / max(c[5], 1), c[10] / max(c[5], 1)))
