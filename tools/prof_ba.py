@@ -8,10 +8,12 @@ import gmmloc_amd
 from gmmloc_amd import api
 import bench
 NF = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SHAPE = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 if len(sys.argv) > 2:
     pass
 mean, cov, cam, frames = bench.make_workload(NF)
 ctx = gmmloc_amd.Context(0); prm = api.Params(); g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+ctx.set_option("ba_shape", SHAPE)
 T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
 pose, Xw, obs, octv = T("pose_init"), T("Xw"), T("obs"), T("octave")
 p2, x2 = pose.clone(), Xw.clone()
