@@ -26,6 +26,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from gmmloc_amd import launch  # noqa: E402
 
 N_PTS, K_GAUSS = 2000, 4096
 FLOP_PER_PAIR = 21           # centred symmetric Mahalanobis form
@@ -47,22 +48,37 @@ def make_workload(B, seed0=20200901):
     return mean, cov, cam, frames
 
 
+def kernel_source_fingerprint():
+    """sha256 over the HIP sources the library is built from: the PMC summaries record it (tools/pmc_traffic.py), so a
+    traffic figure measured on OTHER kernels than the ones being timed is flagged instead of going stale silently."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "gmmloc_amd", "csrc", "*.h*"))):
+        if path.endswith((".hip", ".hpp")):
+            with open(path, "rb") as f:
+                h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel, frames_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script at 512
-    frames per launch; the traffic is per frame, so it is scaled to this run's launch size).
-    None when the summary is missing: bench.py itself cannot run under two profilers."""
+    WRITE_SIZE, collected per MI355X_MICROARCH.md in separate --pmc runs of this script;
+    the traffic is per frame, so it is scaled to this run's launch size).
+    None when the summary is missing: bench.py itself cannot run under two profilers.
+    -> (bytes, source file, stale): stale = the summary was made from other kernel sources than the ones in the tree."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):  # the latest summary that has it
         name = os.path.basename(path)
-        if os.path.exists(path):
-            with open(path) as f:
-                t = json.load(f).get(kernel)
-            if t and "bench" in t:  # per-shape entry (the sweep: k_assoc_brute + its merge kernel)
-                t = t["bench"]
-            if t:
-                return t["hbm_bytes_per_frame"] * frames_per_launch, "profiles/" + name
-    return None, None
+        with open(path) as f:
+            doc = json.load(f)
+        t = doc.get(kernel)
+        if t and "bench" in t:  # per-shape entry (the sweep: k_assoc_brute + its merge kernel)
+            t = t["bench"]
+        if t:
+            stale = doc.get("kernel_source_sha") != kernel_source_fingerprint()
+            return t["hbm_bytes_per_frame"] * frames_per_launch, "profiles/" + name, stale
+    return None, None, None
 
 
 _W = {}
@@ -141,7 +157,7 @@ def cpu_baseline_worker(seed0, budget_s):
     if orc is None:
         orc, flags = oracle_lib.load(), "-O2 -mavx2 -mfma (portable checker build: the native build failed on this host)"
     h = orc.gmm_create(mean, cov)
-    _W.update(orc=orc, h=h, cam=cam, frames=frames, tree=orc.nanoflann_tree3d(mean) if orc.nf is not None else None)
+    _W.update(orc=orc, h=h, cam=cam, frames=frames, tree=orc.nanoflann_tree3d(mean) if (orc.nf is not None and hasattr(orc.nf, "nfref_tree3d_create")) else None)
 
     def timed(fn, budget):
         t0 = time.perf_counter()
@@ -198,33 +214,55 @@ def cpu_baseline(seed0, budget_s=24.0):
     return json.loads(r.stdout.strip().split("\n")[-1])
 
 
+def stub_bench(args, ranks):
+    """CPU test of the launch plumbing (tests/test_bench_contract.py): the same spawn, barrier, timing and MAX-over-ranks
+    code as the real bench over gloo, with a stand-in step.  Not a measurement."""
+    state = {"n": 0}
+
+    def step():
+        state["n"] += int(np.arange(1000).sum() > 0)
+    dt = launch.timed_steps(step, args.steps, args.warmup, ranks)
+    total = ranks.sum(float(state["n"]))
+    if ranks.rank == 0:
+        print(json.dumps({"metric": "stub (launch plumbing test, no GPU work)", "value": total / dt, "unit": "steps/s",
+                          "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "steps_run_all_ranks": total, "backend": ranks.backend}))
+    ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without a launcher: bench.py starts them itself")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("SEED", "BUDGET_S"), help=argparse.SUPPRESS)
+    ap.add_argument("--stub", choices=["gloo"], default=None, help=argparse.SUPPRESS)  # CPU test of the launch plumbing
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(int(args.cpu_baseline_worker[0]), float(args.cpu_baseline_worker[1]))
         return
 
+    # --gpus N is the number of ranks.  Under a launcher (torchrun: RANK / WORLD_SIZE set) this process is one of them;
+    # started plainly with N > 1 it starts the N ranks itself (one process per GPU, RCCL) and relays rank 0's line.
+    if args.gpus > 1 and not launch.is_rank():
+        sys.exit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_gpus=args.stub is None))
+    ranks = launch.Ranks(args.stub or "nccl")
+    if ranks.world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n"
+                         % (args.gpus, ranks.world, ranks.world))
+    ranks.init()
+    if args.stub:
+        stub_bench(args, ranks)
+        return
+
     import torch
-    import torch.distributed as dist
     import gmmloc_amd
     from gmmloc_amd import api
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    world, rank, local, dev = ranks.world, ranks.rank, ranks.local, ranks.device
 
     B = args.batch
     mean, cov, cam, frames = make_workload(B, 20200901 + 100000 * rank)
@@ -238,11 +276,7 @@ def main():
     pose0, Xw0, obs, octv = dev_t("pose_init"), dev_t("Xw"), dev_t("obs"), dev_t("octave")
     pose, Xw = pose0.clone(), Xw0.clone()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = ranks.barrier
 
     trials = torch.zeros(B, dtype=torch.int32, device=dev)
     ctx.set_stats_buffer(trials)  # per-frame Levenberg trial counts of the last step (algorithmic work of k_ba1_fast)
@@ -252,19 +286,14 @@ def main():
         Xw.copy_(Xw0)
         return gmmloc_amd.track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octv, want_d2=False)
 
-    with torch.cuda.stream(ctx.stream):
-        for _ in range(args.warmup):
-            step()
+    def start_timers():
         ctx.timing(True)
         ctx.timing_read(api.TIMER_ASSOC, reset=True)
         ctx.timing_read(api.TIMER_BA, reset=True)
         ctx.timing_read(api.TIMER_BA_PREP, reset=True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            assoc, _ = step()
-        barrier()
-        dt = time.perf_counter() - t0
+
+    with torch.cuda.stream(ctx.stream):
+        dt = launch.timed_steps(step, args.steps, args.warmup, ranks, before_timed=start_timers)
     assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
     prep_ms, prep_n = ctx.timing_read(api.TIMER_BA_PREP)
@@ -273,16 +302,11 @@ def main():
     # the same step with the association forced to the plain N x K sweep (option assoc_grid = 0): same results
     # (tests/test_gpu_track.py), the arithmetic of the same-math CPU baseline pair for pair
     sweep_steps = max(2, args.steps // 4)
+    grid_before = ctx.get_option("assoc_grid")  # (may have been set through GMMLOC_ASSOC_GRID: put back what was there)
     ctx.set_option("assoc_grid", 0)
     with torch.cuda.stream(ctx.stream):
-        step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(sweep_steps):
-            step()
-        barrier()
-        dt_sweep = (time.perf_counter() - t0) / sweep_steps
-    ctx.set_option("assoc_grid", -1)
+        dt_sweep = launch.timed_steps(step, sweep_steps, 1, ranks) / sweep_steps
+    ctx.set_option("assoc_grid", grid_before)
 
     # outside the timed region: the plain N x K sweep on the same points (its roofline record), and
     # the number of chi2 evaluations the cell index needed for them
@@ -334,11 +358,6 @@ def main():
             h2h[mpts] = 1e3 * float(np.median(lat[5:]))
         hp.close()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
     if rank == 0:
         frames_total = B * args.steps * world
         pairs = float(B) * N_PTS * K_GAUSS
@@ -353,8 +372,11 @@ def main():
         ba_flop = FLOP_PER_POINT_TRIAL * N_PTS * n_trials
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
         ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8 + 24 + 4) + 2 * 56)  # Xw, obs, octave, assoc, d2 in; points, final assoc out; pose in/out
-        ba_traffic, ba_traffic_src = measured_traffic("k_ba1_fast", B)
-        sw_traffic, sw_traffic_src = measured_traffic("k_assoc_brute", B)
+        ba_traffic, ba_traffic_src, ba_traffic_stale = measured_traffic("k_ba1_fast", B)
+        sw_traffic, sw_traffic_src, _ = measured_traffic("k_assoc_brute", B)
+        if ba_traffic_stale:
+            sys.stderr.write("bench.py: %s was measured on other kernel sources than the ones in gmmloc_amd/csrc "
+                             "(roofline.traffic_stale = true): re-run tools/profile_bench.sh\n" % ba_traffic_src)
         out = {
             "metric": "frames/sec (associate+pose-refine), 2k pts x 4k GMM",
             "value": frames_total / dt,
@@ -383,6 +405,7 @@ def main():
                 "frac": (ba_tflops / PEAK_FP64_VALU_TFLOPS) if ba_tflops else None,
                 "traffic": ba_traffic,
                 "traffic_source": ba_traffic_src,
+                "traffic_stale": ba_traffic_stale,
                 "traffic_setup_kernel": measured_traffic("k_ba1_prep", B)[0],  # k_ba1_prep: gate, flags, order, normalised observations
                 "avg_launch_ms": 1e3 * ba_s,
                 "flop_per_launch": ba_flop,
@@ -422,7 +445,7 @@ def main():
         out["step_with_exhaustive_sweep"] = {
             "value": B * world / dt_sweep, "unit": "frames/s", "ms_per_step": 1e3 * dt_sweep, "steps": sweep_steps,
             "what": "the same step with GL_ASSOC_EXHAUSTIVE-style association (all 2000 x 4096 pairs per frame swept, option "
-                    "assoc_grid = 0) instead of the exact cell index; rank 0's clock"}
+                    "assoc_grid = 0) instead of the exact cell index; MAX over ranks like the headline"}
         out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20",
                           "host_to_host_ms": h2h[N_PTS], "host_to_host_700pts_ms": h2h[700],
                           "host_to_host_what": "gl_track_frame_host: host buffers -> the context's page-locked staging -> one H2D + "
@@ -442,9 +465,7 @@ def main():
                 "vs_cpu_reference_algorithm_1thread": (out["value"] / cb["reference_algorithm"]["value"]) if cb.get("reference_algorithm") else None,
                 "note": "like with like: the sweep step against the brute-force CPU path, the indexed step against the kd-tree CPU path"}
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -17,4 +17,5 @@ from .api import (  # noqa: F401
     ASSOC_EXHAUSTIVE,
     optimize_current_pose,
     track_frames,
+    track_frames_anchored,
 )

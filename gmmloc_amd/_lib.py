@@ -18,6 +18,11 @@ class gl_params(C.Structure):
                 ("sigma2_inv", C.c_float * 8)]
 
 
+class gl_track_anchor(C.Structure):
+    _fields_ = [("prior_dev", C.c_void_p), ("F", C.c_int32), ("fixed_pose_dev", C.c_void_p), ("fixed_obs_dev", C.c_void_p),
+                ("fixed_oct_dev", C.c_void_p), ("fixed_erase_dev", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -73,7 +78,10 @@ def load():
         "gl_create_map_points": (i32, [vp, vp, P(gl_camera), P(gl_params), C.c_float, i32] + [vp] * 12 + [i32, vp, vp, vp]),
         "gl_optimize_current_pose": (i32, [vp, P(gl_camera), P(gl_params), i32, i32, vp, vp, vp, vp, vp, vp]),
         "gl_joint_optimization": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32, i32, i32, i32] + [vp] * 11),
+        "gl_joint_optimization_stoppable": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32, i32, i32, i32] + [vp] * 12),
         "gl_track_frames": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32, vp, vp, vp, vp, vp, vp]),
+        "gl_track_frames_anchored": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32, vp, vp, vp, vp, vp, vp, P(gl_track_anchor)]),
+        "gl_track_frame_host_anchored": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, vp, vp, vp, vp, vp]),
         "gl_malloc": (i32, [vp, C.c_size_t, P(vp)]),
         "gl_free": (i32, [vp, vp]),
         "gl_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),

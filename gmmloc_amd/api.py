@@ -272,6 +272,27 @@ def track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octave, want_d2=True):
     return assoc, d2
 
 
+def track_frames_anchored(ctx, gmm, cam, prm, pose, Xw, obs, octave, prior=None, fixed_pose=None, fixed_obs=None,
+                          fixed_oct=None, want_d2=True, want_erase=False):
+    """gl_track_frames_anchored: the per-frame path with the reference's gauge anchors (localization_opt.cpp:491-516,
+    556-581).  prior (B,) uint8 or None: EdgeSE3QuatPrior on the input pose (or the pose fixed when
+    prm.ba_first_as_prior == 0); fixed_pose (B,F,7), fixed_obs (B,M,F,3), fixed_oct (B,M,F) int32 (<0: not observed):
+    F fixed observer key-frames.  pose and Xw are updated in place.
+    Returns (assoc int32 (B,M), d2 or None, fixed_erase uint8 (B,M,F) or None)."""
+    import torch
+    B, M = octave.shape
+    F = 0 if fixed_pose is None else fixed_pose.shape[1]
+    assoc = torch.empty((B, M), dtype=torch.int32, device=pose.device)
+    d2 = torch.empty((B, M), dtype=torch.float64, device=pose.device) if want_d2 else None
+    erase = torch.zeros((B, M, F), dtype=torch.uint8, device=pose.device) if (want_erase and F) else None
+    an = _lib.gl_track_anchor(_ptr(prior), F, _ptr(fixed_pose), _ptr(fixed_obs), _ptr(fixed_oct), _ptr(erase))
+    ctx._enter()
+    _check(ctx.lib.gl_track_frames_anchored(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
+                                            _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2), C.byref(an)))
+    ctx._exit()
+    return assoc, d2, erase
+
+
 class HostFramePath:
     """The frame-at-a-time caller with HOST buffers in and out - gl_track_frame_host, what
     include/gmmloc_hip/gmm_adapter.hpp::trackFrame does for the reference host (tracking.cpp calls the path once per
@@ -281,12 +302,27 @@ class HostFramePath:
     def __init__(self, ctx, gmm, cam, prm, max_points=0):
         self.ctx, self.gmm, self.cam, self.prm = ctx, gmm, cam.c(), prm.c()
 
-    def track_frame(self, pose, Xw, obs, octave):
-        """pose (7,), Xw (M,3) float64 are updated in place; returns assoc (M,) int32.  All arrays C-contiguous."""
+    @staticmethod
+    def _arr(a, dtype, shape, name, writable=False):
+        # the C entry point reads raw host memory: a float32 Xw or an int64 octave would be read out of bounds
+        if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous and a.shape == shape
+                and (a.flags.writeable or not writable)):
+            raise TypeError("HostFramePath: %s must be a C-contiguous %s array of shape %s%s"
+                            % (name, np.dtype(dtype).name, shape, " (writable: updated in place)" if writable else ""))
+        return a
+
+    def track_frame(self, pose, Xw, obs, octave, anchored=False):
+        """pose (7,), Xw (M,3) float64 are updated in place; obs (M,3) float64, octave (M,) int32; returns assoc (M,) int32.
+        anchored: with the prior edge on the input pose (gl_track_frame_host_anchored)."""
         M = octave.shape[0]
+        self._arr(pose, np.float64, (7,), "pose", True)
+        self._arr(Xw, np.float64, (M, 3), "Xw", True)
+        self._arr(obs, np.float64, (M, 3), "obs")
+        self._arr(octave, np.int32, (M,), "octave")
         assoc = np.empty(M, np.int32)
-        _check(self.ctx.lib.gl_track_frame_host(self.ctx.h, self.gmm.h, C.byref(self.cam), C.byref(self.prm), M, pose.ctypes.data,
-                                                Xw.ctypes.data, obs.ctypes.data, octave.ctypes.data, assoc.ctypes.data))
+        fn = self.ctx.lib.gl_track_frame_host_anchored if anchored else self.ctx.lib.gl_track_frame_host
+        _check(fn(self.ctx.h, self.gmm.h, C.byref(self.cam), C.byref(self.prm), M, pose.ctypes.data,
+                  Xw.ctypes.data, obs.ctypes.data, octave.ctypes.data, assoc.ctypes.data))
         return assoc
 
     def close(self):
@@ -375,9 +411,10 @@ def optimize_triangulation(ctx, gmm, cam, prm, x3d, pose1, uvr1, oct1, pose2, uv
     return out
 
 
-def joint_optimization(ctx, gmm, cam, prm, P, F, poses, prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_oct):
+def joint_optimization(ctx, gmm, cam, prm, P, F, poses, prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_oct, stop_flag=None):
     """Localization::jointOptimization (localization_opt.cpp:456-925) on B flat problems of one shape.
-    poses (B,P+F,7) and points (B,L,3) are updated in place.
+    poses (B,P+F,7) and points (B,L,3) are updated in place.  stop_flag: int32 tensor of one element (device or
+    pinned host memory) = the reference's pbStopFlag (gl_joint_optimization_stoppable: > 0 stop, < 0 iteration budget).
     Returns (assoc_dropped uint8 (B,L), obs_erase uint8 (B,NOBS), iters int32 (B,))."""
     import torch
     B, L = points.shape[0], points.shape[1]
@@ -387,10 +424,16 @@ def joint_optimization(ctx, gmm, cam, prm, P, F, poses, prior, points, assoc, ob
     erase = torch.zeros((B, NOBS), dtype=torch.uint8, device=dev)
     iters = torch.zeros(B, dtype=torch.int32, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_joint_optimization(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
-                                         _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
-                                         _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
-                                         _ptr(iters)))
+    if stop_flag is None:
+        _check(ctx.lib.gl_joint_optimization(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
+                                             _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
+                                             _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
+                                             _ptr(iters)))
+    else:
+        _check(ctx.lib.gl_joint_optimization_stoppable(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
+                                                       _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
+                                                       _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
+                                                       _ptr(iters), _ptr(stop_flag)))
     ctx._exit()
     return dropped, erase, iters
 

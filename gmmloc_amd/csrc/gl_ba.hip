@@ -448,7 +448,12 @@ namespace gl {
 bool ba1_fast_supported(int L);
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
-                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch);
+                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch, const uint8_t* prior);
+
+// gl_track_frames_anchored with fixed observer key-frames (gl_ba_gen.hip: the general kernel does those)
+int track_frames_fixed(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
+                       double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev, int32_t* assoc_dev,
+                       double* d2_dev, const gl_track_anchor* anchor);
 
 // Single-free-pose jointOptimization for B frames; assoc in/out; scratch from ctx.
 int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
@@ -473,14 +478,14 @@ int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm,
 
 // fast path: plane records (32 B) + normalised observations (24 B) + permutation, flags, gated association (12 B) per
 // point; general kernel: trial points, chi2, levels (33 B); + per frame: 2 x 4 x 32 x 2 exchange words of the latency
-// shape (gl_ba_fast.hip)
-size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 36 + (size_t)B * (8192 + 8) + 512; }
+// shape, 12 doubles of the prior edge's inverse measurement (gl_ba_fast.hip)
+size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 36 + (size_t)B * (8192 + 8 + 96) + 512; }
 
 }  // namespace gl
 
-extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
-                               int M, double* pose_dev, double* Xw_dev, const double* obs_dev,
-                               const int32_t* octave_dev, int32_t* assoc_dev, double* d2_dev) {
+static int track_frames_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
+                             double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
+                             int32_t* assoc_dev, double* d2_dev, const uint8_t* prior_dev) {
   GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
   if (B == 0 || M == 0) return GL_OK;
   GL_REQUIRE(B > 0 && M > 0, "bad B / M");
@@ -511,16 +516,33 @@ extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_came
   // on-chip fast path (gl_ba_fast.hip) for M <= 2000; option ba_slow forces the general kernel
   if (c->opt.ba_slow == 0 && gl::ba1_fast_supported(M))
     return gl::launch_ba1_fast(c, g, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
-                               nullptr, nullptr, nullptr, scratch);
-  return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, nullptr, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
+                               nullptr, nullptr, nullptr, scratch, prior_dev);
+  return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, prior_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
                         nullptr, nullptr, nullptr, scratch);
+}
+
+extern "C" int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
+                               int M, double* pose_dev, double* Xw_dev, const double* obs_dev,
+                               const int32_t* octave_dev, int32_t* assoc_dev, double* d2_dev) {
+  return track_frames_impl(ctx, gmm, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2_dev, nullptr);
+}
+
+extern "C" int gl_track_frames_anchored(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
+                                        int M, double* pose_dev, double* Xw_dev, const double* obs_dev,
+                                        const int32_t* octave_dev, int32_t* assoc_dev, double* d2_dev,
+                                        const gl_track_anchor* anchor) {
+  GL_REQUIRE(anchor, "null anchor");
+  GL_REQUIRE(anchor->F >= 0 && anchor->F <= GL_TRACK_MAX_FIXED, "bad number of fixed observer key-frames");
+  if (anchor->F == 0)
+    return track_frames_impl(ctx, gmm, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2_dev, anchor->prior_dev);
+  return gl::track_frames_fixed(ctx, gmm, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2_dev, anchor);
 }
 
 // One frame, host buffers in and out: | pose | Xw | assoc || obs | octave | staged through the context's page-locked
 // buffer; only the part before || comes back.
-extern "C" int gl_track_frame_host(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
-                                   double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
-                                   int32_t* assoc_host) {
+static int track_frame_host_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
+                                 double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
+                                 int32_t* assoc_host, int with_prior) {
   GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
   GL_REQUIRE(M >= 0, "bad M");
   if (M == 0) return GL_OK;
@@ -543,17 +565,33 @@ extern "C" int gl_track_frame_host(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   char* st = (char*)c->host_stage;
   char* dv = (char*)c->dev_stage;
   memcpy(st, pose_host, 56);
+  st[56] = with_prior ? 1 : 0;  // (the 8 bytes between the pose and the points: the frame's anchor flag)
   memcpy(st + oX, Xw_host, (size_t)M * 24);
   memcpy(st + oO, obs_host, (size_t)M * 24);
   memcpy(st + oC, octave_host, (size_t)M * 4);
   GL_HIP(hipMemcpyAsync(dv, st, total, hipMemcpyHostToDevice, c->stream));
-  const int rc = gl_track_frames(ctx, gmm, cam, prm, 1, M, (double*)dv, (double*)(dv + oX), (const double*)(dv + oO),
-                                 (const int32_t*)(dv + oC), (int32_t*)(dv + oA), nullptr);
-  if (rc != GL_OK) return rc;
+  const int rc = track_frames_impl(ctx, gmm, cam, prm, 1, M, (double*)dv, (double*)(dv + oX), (const double*)(dv + oO),
+                                   (const int32_t*)(dv + oC), (int32_t*)(dv + oA), nullptr,
+                                   with_prior ? (const uint8_t*)(dv + 56) : nullptr);
+  if (rc != GL_OK) {
+    (void)hipStreamSynchronize(c->stream);  // the copy above may still read the staging buffer: the next call rewrites it
+    return rc;
+  }
   GL_HIP(hipMemcpyAsync(st, dv, oO, hipMemcpyDeviceToHost, c->stream));
   GL_HIP(hipStreamSynchronize(c->stream));
   memcpy(pose_host, st, 56);
   memcpy(Xw_host, st + oX, (size_t)M * 24);
   memcpy(assoc_host, st + oA, (size_t)M * 4);
   return GL_OK;
+}
+
+extern "C" int gl_track_frame_host(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
+                                   double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
+                                   int32_t* assoc_host) {
+  return track_frame_host_impl(ctx, gmm, cam, prm, M, pose_host, Xw_host, obs_host, octave_host, assoc_host, 0);
+}
+extern "C" int gl_track_frame_host_anchored(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
+                                            double* pose_host, double* Xw_host, const double* obs_host,
+                                            const int32_t* octave_host, int32_t* assoc_host) {
+  return track_frame_host_impl(ctx, gmm, cam, prm, M, pose_host, Xw_host, obs_host, octave_host, assoc_host, 1);
 }

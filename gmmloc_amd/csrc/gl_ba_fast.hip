@@ -43,13 +43,24 @@ constexpr int PREP_T = 256, PREP_C = 8;  // rounds of 256 consecutive points: fr
 __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, int L, const double* __restrict__ obs_all,
                                                     const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
                                                     const double* __restrict__ d2_all, double* __restrict__ scratch,
-                                                    unsigned long long* __restrict__ xwords, int* __restrict__ xctl, int nxw) {
+                                                    unsigned long long* __restrict__ xwords, int* __restrict__ xctl, int nxw,
+                                                    const double* __restrict__ pose_all, const uint8_t* __restrict__ prior_all,
+                                                    double* __restrict__ prior_mi) {
   __shared__ int cnt[PREP_C][PREP_T / 64];  // non-degenerate-component points per (round, wave)
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (f >= B) return;
   if (xwords) {  // latency shape next: this frame's exchange words and {abort, done} start at zero (no separate memset)
     for (int i = tid; i < nxw; i += PREP_T) xwords[(size_t)f * nxw + i] = 0ull;
     if (tid < 2) xctl[2 * f + tid] = 0;
+  }
+  if (prior_all && prior_all[f] && tid == 0) {  // EdgeSE3QuatPrior::_inverseMeasurement of the frame's INPUT pose, as {R, t}
+    const SE3 Ti = se3_inverse(se3_load(pose_all + (size_t)f * 7));
+    double Ri[9];
+    qtoR(Ti.r, Ri);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prior_mi[(size_t)f * 12 + i] = Ri[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) prior_mi[(size_t)f * 12 + 9 + i] = Ti.t[i];
   }
   const size_t gbase = (size_t)f * L;
   const PrepView pv = prep_view(scratch, B, L);
@@ -115,79 +126,148 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 }
 }  // namespace
 
-// (namespace, LDS capacity in points, waves at most, SPREAD, fp32-cached step)
-#define GL_BAF_NS bafd496   // DENSE, exact step: 4 frames per CU
+// (namespace, LDS capacity in points, waves at most, SPREAD, fp32-cached step, gauge anchor of the pose)
+#define GL_BAF_NS bafd496  // DENSE, exact step: 4 frames per CU
 #define GL_BAF_MCAP 496
 #define GL_BAF_NW 2
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
 
 #define GL_BAF_NS bafd1000  // 2 frames per CU
 #define GL_BAF_MCAP 1000
 #define GL_BAF_NW 4
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
 
 #define GL_BAF_NS bafd2000  // 1 frame per CU
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
 
-#define GL_BAF_NS bafs      // SPREAD (latency shape), exact step
+#define GL_BAF_NS bafs  // SPREAD (latency shape), exact step
 #define GL_BAF_MCAP 256
 #define GL_BAF_NW 8
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
 
 // fp32-cached point step (option ba_step32): the SPREAD kernel and the largest DENSE class
-#define GL_BAF_NS bafs32
+#define GL_BAF_NS bafs32  // 
 #define GL_BAF_MCAP 256
 #define GL_BAF_NW 8
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 1
+#define GL_BAF_PRIOR 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
 
-#define GL_BAF_NS bafd2000s32
+#define GL_BAF_NS bafd2000s32  // 
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 1
+#define GL_BAF_PRIOR 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+
+// anchored instances (gl_track_frames_anchored: prior edge on the frame's pose, or fixed pose), exact step
+#define GL_BAF_NS bafd496p  // 
+#define GL_BAF_MCAP 496
+#define GL_BAF_NW 2
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+
+#define GL_BAF_NS bafd1000p  // 
+#define GL_BAF_MCAP 1000
+#define GL_BAF_NW 4
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+
+#define GL_BAF_NS bafd2000p  // 
+#define GL_BAF_MCAP 2000
+#define GL_BAF_NW 8
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+
+#define GL_BAF_NS bafsp  // 
+#define GL_BAF_MCAP 256
+#define GL_BAF_NW 8
+#define GL_BAF_SPREAD 1
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
 
 namespace {
 // HW_REG_XCC_ID (hwreg 20, 4 bits): the XCD the wave runs on
@@ -234,7 +314,7 @@ static void canon_order(int L, int* G, int* S) {
 }
 
 typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*, int*, long long, int);
+                          unsigned long long*, int*, long long, int, const uint8_t*, const double*);
 
 struct BafArgs {
   BaK k;
@@ -252,19 +332,23 @@ struct BafArgs {
   int NB;
   unsigned long long* parts;
   int* ctl = nullptr;  // per frame {abort, done} of a latency-shape launch (the follow-up DENSE launch skips the done ones)
+  const uint8_t* prior = nullptr;  // per frame: gauge anchor of the pose (prior edge / fixed), or null
+  const double* prior_mi = nullptr;  // per frame: inverse measurement of the prior edge {R, t} (written by k_ba1_prep)
 };
 
 // one workgroup of G waves per frame; LDS class by stride (4 / 2 / 1 frames per CU)
 static int launch_dense(Ctx* c, BafArgs& a) {
-  const bool s32 = c->opt.ba_step32 != 0;
+  const bool s32 = c->opt.ba_step32 != 0 && !a.prior;  // (the anchored instances exist with the exact step only)
   const int cap = s32 ? 2000 : (a.L <= 496 ? 496 : a.L <= 1000 ? 1000 : 2000);
-  const BafKernel kern = s32 ? bafd2000s32::k_ba1_fast : cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast;
+  const BafKernel kern = s32 ? bafd2000s32::k_ba1_fast
+                         : a.prior ? (cap == 496 ? bafd496p::k_ba1_fast : cap == 1000 ? bafd1000p::k_ba1_fast : bafd2000p::k_ba1_fast)
+                                   : (cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast);
   const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap == 1000 ? 4 : 8) * 32 + 64 + 40) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;
   kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts, a.ctl, 0ll, 0);
+                                          a.NB, a.parts, a.ctl, 0ll, 0, a.prior, a.prior_mi);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -278,7 +362,7 @@ static int launch_dense(Ctx* c, BafArgs& a) {
 // anything, and the one-workgroup kernel that follows redoes exactly those frames - same bits, so the caller never sees
 // which kernel answered.  Returns 1 when the shape does not fit the device at all (the caller goes DENSE).
 static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
-  const BafKernel kern = c->opt.ba_step32 != 0 ? bafs32::k_ba1_fast : bafs::k_ba1_fast;
+  const BafKernel kern = a.prior ? bafsp::k_ba1_fast : c->opt.ba_step32 != 0 ? bafs32::k_ba1_fast : bafs::k_ba1_fast;
   const size_t lds = (size_t)(10 * 256 + 1 * 32 + 64 + 40 + 29 * 256) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = a.G;
@@ -299,7 +383,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
   kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0);
+                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.prior, a.prior_mi);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }
@@ -309,8 +393,9 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
 // (option ba_shape forces one: 0 DENSE, 1 SPREAD).
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
-                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch) {
+                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch, const uint8_t* prior) {
   BafArgs a;
+  a.prior = prior;
   a.k = make_bak(cam, prm, gate);
   a.gm = GmmDev{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   a.B = B;
@@ -336,7 +421,10 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
     unsigned long long* xw = nullptr;
     if (spread) xw = (unsigned long long*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64);
     const int nxw = 2 * a.G * 64;
-    k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch, xw, xw ? (int*)(xw + (size_t)B * nxw) : nullptr, nxw);
+    // inverse measurements of the prior edges: behind the records, the exchange words and {abort, done} (ba1_scratch_bytes)
+    a.prior_mi = (double*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64 + (size_t)B * (8192 + 8) + 64);
+    k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch, xw, xw ? (int*)(xw + (size_t)B * nxw) : nullptr, nxw,
+                                            pose, prior, (double*)a.prior_mi);
   }
   GL_HIP(hipGetLastError());
   TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper

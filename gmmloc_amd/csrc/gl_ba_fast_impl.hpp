@@ -1,4 +1,4 @@
-// (included by gl_ba_fast.hip once per instance: GL_BAF_NS / GL_BAF_MCAP / GL_BAF_NW / GL_BAF_SPREAD / GL_BAF_STEP32)
+// (included by gl_ba_fast.hip once per instance: GL_BAF_NS / GL_BAF_MCAP / GL_BAF_NW / GL_BAF_SPREAD / GL_BAF_STEP32 / GL_BAF_PRIOR)
 // On-chip fast path of the single-pose structure-constrained refinement (same algorithm and control flow as
 // k_ba1 in gl_ba.hip, which stays as the general / large-M path and as the A/B reference), M <= 2000 points.
 //
@@ -47,6 +47,11 @@ constexpr bool kSpread = false;
 constexpr bool kStep32 = true;
 #else
 constexpr bool kStep32 = false;
+#endif
+#if GL_BAF_PRIOR
+constexpr bool kPrior = true;   // instance with the gauge anchor of the pose (prior edge / fixed pose); the plain instances
+#else                           // carry none of its code, so their register allocation is that of the unanchored refine
+constexpr bool kPrior = false;
 #endif
 constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of this LDS class has at most
 constexpr int NRED = kSpread ? 1 : NWC;    // group totals kept in LDS (a SPREAD workgroup is ONE group)
@@ -128,6 +133,10 @@ GL_DEV double uni(double v) {
   u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.d;
 }
+
+#ifndef GL_U
+#define GL_U(i, j) ((i) * 6 - (i) * ((i)-1) / 2 + ((j) - (i)))  // packed upper triangle of a 6x6, i <= j
+#endif
 
 struct Pose {  // T_cw as rotation matrix + translation
   double R[9], t[3];
@@ -417,6 +426,109 @@ GL_DEV void point_solve_fast(const Lin& o, double lambda, double* Dinv, double* 
   const double D[6] = {o.D[0] + lambda, o.D[1], o.D[2], o.D[3] + lambda, o.D[4], o.D[5] + lambda};
   sym3_inv_fast(D, Dinv);
   sym3_mul_vec(Dinv, o.b, u);
+}
+
+// ---- gauge anchor of the frame's pose ----------------------------------------------------------------------------
+// The reference never runs its structure BA without one (localization_opt.cpp:491-516, 556-581).  Per frame: the
+// EdgeSE3QuatPrior of key-frame 0 (factors.cpp:19-53; measurement = the INPUT pose, sigma_rot 2 deg, sigma_t 1 cm) when
+// loc::ba_first_as_prior, else the pose vertex is fixed (:578-580).  The inverse measurement {R (9), t (3)} is written by
+// k_ba1_prep into the launch's scratch and fetched by the solving wave with scalar loads when it is needed (the LDS of the
+// 1 000-point class has no 96 bytes to spare at two frames per CU, and 24 more live registers would spill in the passes).
+typedef const double __attribute__((address_space(4))) cdouble_k;
+struct Anchor {
+  bool has_prior, pose_fixed;
+  const cdouble_k* mi;
+};
+// _error = (_inverseMeasurement * Tj).log()   (SE3Quat::log: small-angle branch above |d| = 0.99999)
+GL_DEV void prior_error(const cdouble_k* mi_k, const Pose& P, double* e) {
+  double mi[12], dR[9], dt[3];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) mi[i] = mi_k[i];
+  mm3(mi, P.R, dR);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dt[i] = fma(mi[i * 3], P.t[0], fma(mi[i * 3 + 1], P.t[1], fma(mi[i * 3 + 2], P.t[2], mi[9 + i])));
+  const double d = 0.5 * (dR[0] + dR[4] + dR[8] - 1);
+  const double v[3] = {dR[7] - dR[5], dR[2] - dR[6], dR[3] - dR[1]};
+  double w[3], g;
+  if (fabs(d) > 0.99999) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = 0.5 * v[i];
+    g = 1. / 12.;
+  } else {
+    const double theta = acos(d);
+    const double f = theta / (2 * sqrt(1 - d * d));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = f * v[i];
+    g = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+  }
+  // upsilon = V^-1 dt,  V^-1 = I - 1/2 [w]x + g [w]x^2  =  dt - 1/2 w x dt + g w x (w x dt)
+  double c1[3], c2[3];
+  cross(w, dt, c1);
+  cross(w, c1, c2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    e[i] = w[i];
+    e[3 + i] = fma(g, c2[i], fma(-0.5, c1[i], dt[i]));
+  }
+}
+GL_DEV double prior_chi2(const double* e) {
+  const double sr = 1.0 / ((2.0 * M_PI / 180.0) * (2.0 * M_PI / 180.0)), st = 1.0 / (0.01 * 0.01);
+  return sr * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + st * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+}
+// linearizeOplus (factors.cpp:30-53): J = (I + 1/2 [[phi]x [upsilon]x; 0 [phi]x]) Adj(T^-1); H (packed upper, 21) += J^T Omega J,
+// b -= J^T Omega e; returns chi2
+GL_DEV double prior_lin(const cdouble_k* mi, const Pose& P, double* H, double* b) {
+  double e[6];
+  prior_error(mi, P, e);
+  const double sr = 1.0 / ((2.0 * M_PI / 180.0) * (2.0 * M_PI / 180.0)), st = 1.0 / (0.01 * 0.01);
+  // T^-1 = (R^T, -R^T t);  Adj = [[Ri, 0], [[ti]x Ri, Ri]]
+  double Ri[9], ti[3], S[9], SR[9], A1[9], Lh[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = P.R[j * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ti[i] = -(Ri[i * 3] * P.t[0] + Ri[i * 3 + 1] * P.t[1] + Ri[i * 3 + 2] * P.t[2]);
+  skew(ti, S);
+  mm3(S, Ri, SR);
+  skew(e, A1);
+  skew(e + 3, Lh);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    A1[i] = 0.5 * A1[i] + ((i % 4 == 0) ? 1.0 : 0.0);
+    Lh[i] = 0.5 * Lh[i];
+  }
+  double AR[9], ASR[9], LSR[9], LR[9];
+  mm3(A1, Ri, AR);
+  mm3(A1, SR, ASR);
+  mm3(Lh, SR, LSR);
+  mm3(Lh, Ri, LR);
+  double J[36];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      J[i * 6 + j] = AR[i * 3 + j] + LSR[i * 3 + j];
+      J[i * 6 + 3 + j] = LR[i * 3 + j];
+      J[(3 + i) * 6 + j] = ASR[i * 3 + j];
+      J[(3 + i) * 6 + 3 + j] = AR[i * 3 + j];
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double om_e[6] = {sr * e[0], sr * e[1], sr * e[2], st * e[3], st * e[4], st * e[5]};
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s = fma(J[r * 6 + i], om_e[r], s);
+    if (b) b[i] -= s;
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      double h = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) h = fma(J[r * 6 + i] * (r < 3 ? sr : st), J[r * 6 + j], h);
+      H[GL_U(i, j)] += h;
+    }
+  }
+  return prior_chi2(e);
 }
 
 // The terms of a point enter the sums through a sink: DENSE adds them to the thread's registers (level 1 of the
@@ -1144,7 +1256,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
                          const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
-                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C) {
+                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, const Anchor& An) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -1158,7 +1270,8 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     }
   }
   reduce2<2>(acc, R, C);
-  const bool pose_active = acc[0] > 0.0;
+  const bool pose_active = kPrior ? !An.pose_fixed && (acc[0] > 0.0 || An.has_prior) : acc[0] > 0.0;
+  const bool prior_on = kPrior && An.has_prior && pose_active;
   if (!pose_active && !(acc[1] > 0.0)) return -1;
 
   double lambda = 0.0, ni = 2.0;
@@ -1171,6 +1284,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
       if (pose_active) {
+        if (prior_on) prior_lin(An.mi, P, acc, nullptr);
 #pragma unroll
         for (int i = 0; i < 6; ++i) md = fmax(md, fabs(acc[GL_U(i, i)]));
       }
@@ -1191,11 +1305,12 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       // 6x6 solve by wave 0; the step and the status are broadcast through LDS behind a barrier.  The trial pose
       // exp(dx) P is computed by wave 0 AFTER that barrier, while the other waves are already in pass B (its first use
       // is the evaluation of their first point, ~200 instructions in), and handed over through LDS + a sequence word.
-      double* bc = R.tot + 32;  // 27 doubles: dx[6] R[9] t[3] ok g[6] sum u.b chi2
+      double* bc = R.tot + 32;  // 28 doubles: dx[6] R[9] t[3] ok g[6] sum u.b chi2, chi2 of the prior edge at the trial pose
       volatile int* pnflag = (volatile int*)(R.tot + 60);
       if (threadIdx.x < 64) {
         double dxs[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
+        if (prior_on) acc[27] += prior_lin(An.mi, P, acc, acc + 21);  // the prior edge: H_pp, b_p and chi2 of the pose block
         if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -1224,6 +1339,11 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
           for (int i = 0; i < 9; ++i) bc[6 + i] = Pw.R[i];
 #pragma unroll
           for (int i = 0; i < 3; ++i) bc[15 + i] = Pw.t[i];
+          if (prior_on) {  // chi2 of the prior edge at the trial pose (read behind pass B's barrier)
+            double ep[6];
+            prior_error(An.mi, Pw, ep);
+            bc[27] = prior_chi2(ep);
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           *pnflag = seq;
         }
@@ -1258,7 +1378,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
       // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
       double scale = lambda * acc[0] + uni(bc[25]);
-      const double tempChi = ok2 ? acc[1] : 1.7976931348623157e308;
+      const double tempChi = ok2 ? (prior_on ? acc[1] + uni(bc[27]) : acc[1]) : 1.7976931348623157e308;
       if (pose_active) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) scale += dx[i] * (lambda * dx[i] + uni(bc[19 + i]));
@@ -1303,7 +1423,8 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   double* __restrict__ pts_io, int32_t* __restrict__ assoc_all,
                                                   uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                   int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
-                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted) {
+                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted,
+                                                  const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1381,6 +1502,10 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     D.stab[19] = k.delta_stereo * k.delta_stereo;
   }
   Pose P = pose_from_se3(se3_load(pose_io + (size_t)f * 7));
+  // vSE3->setFixed(idx_ == 0) or e->setMeasurement(kfi->getTcw()) (:556-581)
+  const bool prior_flag = kPrior && prior_all ? prior_all[f] != 0 : false;
+  const Anchor An{prior_flag && k.first_as_prior != 0, prior_flag && k.first_as_prior == 0,
+                  (const cdouble_k*)(prior_mi + (size_t)f * 12)};
 #ifndef GL_BAF_NO_PRIO
   if (!kSpread && NWC == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -1402,7 +1527,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, pc, phase < 2, phase < 2 ? 5 : 40, R, trials, C);
+    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, pc, phase < 2, phase < 2 ? 5 : 40, R, trials, C, An);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
@@ -1462,7 +1587,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     T.t[1] = P.t[1];
     T.t[2] = P.t[2];
     normalize_rotation(T);
-    se3_store(T, pose_io + (size_t)f * 7);
+    if (!(kPrior && An.pose_fixed)) se3_store(T, pose_io + (size_t)f * 7);
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
     if (kSpread && C.ctl) C.ctl[1] = 1;  // done

@@ -84,8 +84,14 @@ struct GenP {
   unsigned* bar;       // 64 arrival words of the problem's barrier
   unsigned epoch;      // barriers passed
   double* part;        // NB x 4 partial sums
-  int* flagg;          // solve status
+  int* flagg;          // [0] solve status, [1] the stop word as workgroup 0 last saw it
+  // setForceStopFlag (localization_opt.cpp:541-542): optional stop word, polled once per Levenberg trial by workgroup 0 and
+  // acted on where g2o tests terminate(): before an outer iteration.  > 0: stop; < 0: a budget of -value outer iterations
+  const int32_t* stop;
+  int stop_seen, done_iters;
 };
+GL_DEV bool stop_now(const GenP& G) { return G.stop_seen > 0 || (G.stop_seen < 0 && G.done_iters >= -G.stop_seen); }
+GL_DEV int stop_word_load(const int32_t* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // barrier over the NB <= 64 workgroups of one problem (all co-resident: cooperative launch).  One flag word per
 // workgroup (zeroed by the host): a workgroup announces its k-th arrival by storing k into its own word and the lanes
@@ -911,6 +917,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
   double lambda = 0.0, ni = 2.0;
   int cj = 0;
   for (int it = 0; it < iters; ++it) {
+    if (stop_now(G)) break;  // SparseOptimizer::optimize: `i < iterations && !terminate()`
     // Prior edges at the current state: that state changes once per outer iteration (an accepted trial ends the
     // inner loop), so their information / rhs / chi2 are formed here and not per trial, by the LAST threads of the
     // problem - which have no point of the first pass when the problem's threads outnumber its points - so that the
@@ -1004,7 +1011,10 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         if (any_pose)
           ok = small ? ldlt_solve_small(G, k, lambda, S, ld, G.NB > 1, (lds_double*)s_lds, ld, G.dxv, n, s_flag, red)
                      : ldlt_solve_large(S, G.dxv, n, ld, s_flag);
-        if (tid == 0) *G.flagg = ok ? 1 : 0;
+        if (tid == 0) {
+          *G.flagg = ok ? 1 : 0;
+          if (G.stop) G.flagg[1] = stop_word_load(G.stop);
+        }
         __syncthreads();
         GP_T(u2);
         GP_ADD(6, t3, u0); GP_ADD(8, u0, u2);
@@ -1028,6 +1038,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       }
       prob_sync(G);
       ok2 = *G.flagg != 0;
+      if (G.stop) G.stop_seen = G.flagg[1];
       for (int j = 0; j < P; ++j) chiA += G.pchi[j];
       if (qmax == 0) currentChi = chiA;
       GP_T(t4);
@@ -1066,8 +1077,9 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       qmax++;
       GP_T(t5);
       GP_ADD(0, t0, t1); GP_ADD(1, t1, t2); GP_ADD(2, t2, t3); GP_ADD(3, t3, t4); GP_ADD(4, t4, t5); GP_ADD(5, 0, 1);
-    } while (rho < 0 && qmax < 10);
+    } while (rho < 0 && qmax < 10 && !(G.stop_seen > 0));  // (g2o's retry loop tests terminate() too)
     ++cj;
+    ++G.done_iters;
     if (qmax == 10 || rho == 0) break;
   }
   return cj;
@@ -1082,7 +1094,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
                                                  const int32_t* __restrict__ ooct_all,
                                                  uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                  int32_t* __restrict__ iters_all, char* __restrict__ scratch,
-                                                 size_t scratch_per_problem, int s_in_lds) {
+                                                 size_t scratch_per_problem, int s_in_lds, const int32_t* __restrict__ stop_dev) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // reduced camera system when it fits
   __shared__ double red[NW_BA * 32 + 128];  // reductions / reciprocal pivots (128) + the right-hand side of the solve (128)
   __shared__ double p2part[NW_BA * 64];  // pass_blocks: sums of the waves that share a block
@@ -1108,6 +1120,10 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   // scratch = | B x 512 B headers {64 barrier words, solve flag} (zeroed by the host) | per-problem areas |
   G.bar = (unsigned*)(scratch + (size_t)f * 512);
   G.flagg = (int*)(G.bar + 64);
+  G.stop = stop_dev;
+  G.stop_seen = 0;
+  G.done_iters = 0;
+  if (stop_dev && G.pb == 0 && tid == 0) G.flagg[1] = stop_word_load(stop_dev);  // (published by the set-up's first barrier)
   // carve the problem's area (doubles first, then ints, then bytes)
   char* s = scratch + (size_t)B * 512 + (size_t)f * scratch_per_problem;
   auto takeD = [&](size_t cnt) {
@@ -1181,6 +1197,13 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   }
   for (size_t i = GSTART; i < (size_t)nobs * P; i += GSTRIDE) G.plm[i] = -1;
   prob_sync(G);
+  if (stop_dev) {
+    G.stop_seen = G.flagg[1];
+    if (G.stop_seen > 0) {  // `if (pbStopFlag) if (*pbStopFlag) return;` (:765-767): nothing is written
+      if (G.pb == 0 && tid == 0 && iters_all) iters_all[f] = 0;
+      return;
+    }
+  }
   // pose-major CSR: wave-per-pose ordered compaction (two sweeps: count, fill)
   {
     const int lane = tid & 63, gw = G.pb * NW_BA + (tid >> 6), gnw = G.NB * NW_BA;
@@ -1242,23 +1265,26 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   prob_sync(G);
   gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds, p2part);
   prob_sync(G);
-  for (int l = GSTART; l < L; l += GSTRIDE)
-    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
-      const double* Rt = G.Rt + (size_t)G.opose[o] * 12;
-      const double* p = G.pts + (size_t)l * 3;
-      const double z = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
-      const bool stereo = !(G.ouvr[(size_t)o * 3 + 2] < 0);
-      if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
+  int it3 = 0;
+  if (!stop_now(G)) {  // bDoMore (:791-796)
+    for (int l = GSTART; l < L; l += GSTRIDE)
+      for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+        const double* Rt = G.Rt + (size_t)G.opose[o] * 12;
+        const double* p = G.pts + (size_t)l * 3;
+        const double z = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
+        const bool stereo = !(G.ouvr[(size_t)o * 3 + 2] < 0);
+        if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
+      }
+    prob_sync(G);
+    // the partner table forgets the edges that are now at level 1
+    for (size_t i = GSTART; i < (size_t)G.pl_ptr[P] * P; i += GSTRIDE) {
+      const int o2 = G.plm[i];
+      if (o2 >= 0 && (G.lev_o[o2] || G.lev_o[G.pl_obs[i / P]])) G.plm[i] = -1;
     }
-  prob_sync(G);
-  // the partner table forgets the edges that are now at level 1
-  for (size_t i = GSTART; i < (size_t)G.pl_ptr[P] * P; i += GSTRIDE) {
-    const int o2 = G.plm[i];
-    if (o2 >= 0 && (G.lev_o[o2] || G.lev_o[G.pl_obs[i / P]])) G.plm[i] = -1;
+    prob_sync(G);
+    it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds, p2part);
+    prob_sync(G);
   }
-  prob_sync(G);
-  const int it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds, p2part);
-  prob_sync(G);
   // ---- outputs (:837-879) ---------------------------------------------------------------------------
   for (int l = GSTART; l < L; l += GSTRIDE) {
     GmmRef g;
@@ -1290,25 +1316,19 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
 
 }  // namespace
 
-extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
-                                     int B, int P, int F, int L, int NOBS, double* poses_dev,
-                                     const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
-                                     const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev,
-                                     const double* obs_uvr_dev, const int32_t* obs_oct_dev,
-                                     uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev) {
-  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
-  if (B == 0) return GL_OK;
-  GL_REQUIRE(B > 0 && P >= 1 && F >= 0 && L >= 1 && NOBS >= 1, "bad problem shape");
-  GL_REQUIRE(poses_dev && prior_dev && points_dev && assoc_dev && obs_ptr_dev && obs_pose_dev && obs_uvr_dev &&
-                 obs_oct_dev && assoc_dropped_dev && obs_erase_dev,
-             "null buffer");
-  gl::Ctx* c = gl::C(ctx);
-  gl::Gmm* g = gl::G(gmm);
-  GL_HIP(hipSetDevice(c->device));
+namespace gl {
+size_t ba_gen_scratch_bytes(int B, int P, int F, int L, int NOBS) {
   const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
-  void* scratch = nullptr;
-  int rc = gl::ctx_scratch(c, (size_t)B * 512 + per * B, &scratch);
-  if (rc != GL_OK) return rc;
+  return (size_t)B * 512 + per * B;
+}
+
+// the launch proper; scratch: ba_gen_scratch_bytes() bytes of the context's scratch block
+int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+                  double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                  const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
+                  const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                  const int32_t* stop_dev, void* scratch) {
+  const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   const size_t n = 6 * (size_t)P;
   const size_t s_bytes = n * (n + GL_LD_PAD) * sizeof(double);
@@ -1349,7 +1369,7 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     if (NB > 1) {
       void* args[] = {&kk, &gm, &B, &NB, &P, &F, &L, &NOBS, &poses_dev, &prior_dev, &points_dev, &assoc_dev, &obs_ptr_dev,
                       &obs_pose_dev, &obs_uvr_dev, &obs_oct_dev, &assoc_dropped_dev, &obs_erase_dev, &iters_dev, &scr, &per_v,
-                      &s_in_lds};
+                      &s_in_lds, &stop_dev};
       hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(B * NB), dim3(T_BA), args, lds, c->stream);
       if (e != hipSuccess) {  // not co-resident after all: one workgroup per problem
         (void)hipGetLastError();
@@ -1359,8 +1379,215 @@ extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const g
     if (NB == 1)
       k_ba_gen<<<B, T_BA, lds, c->stream>>>(kk, gm, B, 1, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev,
                                             obs_pose_dev, obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev,
-                                            scr, per_v, s_in_lds);
+                                            scr, per_v, s_in_lds, stop_dev);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
+}  // namespace gl
+
+static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
+                                   int B, int P, int F, int L, int NOBS, double* poses_dev,
+                                   const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev,
+                                   const double* obs_uvr_dev, const int32_t* obs_oct_dev,
+                                   uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                                   const int32_t* stop_dev) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && P >= 1 && F >= 0 && L >= 1 && NOBS >= 1, "bad problem shape");
+  GL_REQUIRE(poses_dev && prior_dev && points_dev && assoc_dev && obs_ptr_dev && obs_pose_dev && obs_uvr_dev &&
+                 obs_oct_dev && assoc_dropped_dev && obs_erase_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  gl::Gmm* g = gl::G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  void* scratch = nullptr;
+  int rc = gl::ctx_scratch(c, gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
+  if (rc != GL_OK) return rc;
+  return gl::launch_ba_gen(c, g, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
+                           obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, stop_dev, scratch);
+}
+
+extern "C" int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
+                                     int B, int P, int F, int L, int NOBS, double* poses_dev,
+                                     const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                                     const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev,
+                                     const double* obs_uvr_dev, const int32_t* obs_oct_dev,
+                                     uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev) {
+  return joint_optimization_impl(ctx, gmm, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev,
+                                 obs_pose_dev, obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, nullptr);
+}
+
+extern "C" int gl_joint_optimization_stoppable(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
+                                               int B, int P, int F, int L, int NOBS, double* poses_dev,
+                                               const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                                               const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev,
+                                               const double* obs_uvr_dev, const int32_t* obs_oct_dev,
+                                               uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                                               const int32_t* stop_flag) {
+  return joint_optimization_impl(ctx, gmm, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev,
+                                 obs_pose_dev, obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, stop_flag);
+}
+
+// ---- gl_track_frames_anchored with F > 0 fixed observer key-frames --------------------------------------------------
+// The per-frame layout (one observation per point in the frame itself + up to F in fixed key-frames, dense B x M x F
+// arrays) is packed into the flat problems of gl_joint_optimization - P = 1 free pose, F fixed ones, observations in CSR
+// order by point: the frame's own first, then the fixed key-frames' in index order - and solved by the general kernel;
+// localization_opt.cpp:491-516 (fixed observers), :556-581 (prior / fixed first key-frame), :706-760 (edges).
+namespace {
+constexpr int PK_T = 256;
+__global__ __launch_bounds__(PK_T) void k_track_pack(int B, int M, int F, double gate, const double* __restrict__ pose, const uint8_t* __restrict__ prior,
+                                                     const double* __restrict__ fpose, const double* __restrict__ obs, const int32_t* __restrict__ oct,
+                                                     const double* __restrict__ fobs, const int32_t* __restrict__ foct, int32_t* __restrict__ assoc,
+                                                     const double* __restrict__ d2, double* __restrict__ poses, uint8_t* __restrict__ prior_o,
+                                                     int32_t* __restrict__ optr, int32_t* __restrict__ opose, double* __restrict__ ouvr,
+                                                     int32_t* __restrict__ ooct) {
+  __shared__ int wsum[PK_T / 64];
+  __shared__ int s_base;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (f >= B) return;
+  const int NOBS = M * (1 + F);
+  if (tid < 7 * (1 + F)) {
+    const int j = tid / 7, r = tid % 7;
+    poses[((size_t)f * (1 + F) + j) * 7 + r] = j == 0 ? pose[(size_t)f * 7 + r] : fpose[((size_t)f * F + (j - 1)) * 7 + r];
+  }
+  if (tid == 0) {
+    prior_o[f] = prior ? prior[f] : 0;
+    s_base = 0;
+  }
+  __syncthreads();
+  for (int l0 = 0; l0 < M; l0 += PK_T) {
+    const int l = l0 + tid;
+    int cnt = 0, oc = -1;
+    if (l < M) {
+      const size_t g = (size_t)f * M + l;
+      oc = oct[g];
+      int a = assoc[g];
+      if (d2 && gate >= 0 && !(d2[g] <= gate)) a = -1;  // checkMapAssociation's gate (gmmloc_opt.cpp:230-232)
+      if (oc < 0) a = -1;
+      assoc[g] = a;
+      if (oc >= 0) {
+        cnt = 1;
+        for (int j = 0; j < F; ++j) cnt += foct[g * F + j] >= 0 ? 1 : 0;
+      }
+    }
+    // exclusive scan over the 256 points of the round
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    const int at = before + inc - cnt;
+    if (l < M) {
+      const size_t g = (size_t)f * M + l;
+      optr[(size_t)f * (M + 1) + l] = at;
+      if (oc >= 0) {
+        size_t o = (size_t)f * NOBS + at;
+        opose[o] = 0;
+        ooct[o] = oc;
+        for (int r = 0; r < 3; ++r) ouvr[o * 3 + r] = obs[g * 3 + r];
+        for (int j = 0; j < F; ++j) {
+          const int fo = foct[g * F + j];
+          if (fo < 0) continue;
+          ++o;
+          opose[o] = 1 + j;
+          ooct[o] = fo;
+          for (int r = 0; r < 3; ++r) ouvr[o * 3 + r] = fobs[(g * F + j) * 3 + r];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int t = s_base;
+      for (int w = 0; w < PK_T / 64; ++w) t += wsum[w];
+      s_base = t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) optr[(size_t)f * (M + 1) + M] = s_base;
+}
+
+__global__ __launch_bounds__(PK_T) void k_track_unpack(int B, int M, int F, const double* __restrict__ poses, const int32_t* __restrict__ optr,
+                                                       const int32_t* __restrict__ opose, const uint8_t* __restrict__ dropped,
+                                                       const uint8_t* __restrict__ erase, double* __restrict__ pose, int32_t* __restrict__ assoc,
+                                                       uint8_t* __restrict__ ferase) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= B) return;
+  const int NOBS = M * (1 + F);
+  if (tid < 7) pose[(size_t)f * 7 + tid] = poses[(size_t)f * (1 + F) * 7 + tid];
+  for (int l = tid; l < M; l += PK_T) {
+    const size_t g = (size_t)f * M + l;
+    if (dropped[g]) assoc[g] = -1;  // the final association, as gl_track_frames reports it
+    if (ferase) {
+      for (int j = 0; j < F; ++j) ferase[g * F + j] = 0;
+      for (int o = optr[(size_t)f * (M + 1) + l]; o < optr[(size_t)f * (M + 1) + l + 1]; ++o) {
+        const int j = opose[(size_t)f * NOBS + o];
+        if (j >= 1) ferase[g * F + (j - 1)] = erase[(size_t)f * NOBS + o];
+      }
+    }
+  }
+}
+}  // namespace
+
+namespace gl {
+int track_frames_fixed(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
+                       double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev, int32_t* assoc_dev,
+                       double* d2_dev, const gl_track_anchor* an) {
+  GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
+  if (B == 0 || M == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && M > 0, "bad B / M");
+  GL_REQUIRE(pose_dev && Xw_dev && obs_dev && octave_dev && assoc_dev, "null buffer");
+  const int F = an->F;
+  GL_REQUIRE(an->fixed_pose_dev && an->fixed_obs_dev && an->fixed_oct_dev, "null buffer of the fixed observer key-frames");
+  Ctx* c = C(ctx);
+  Gmm* g = G(gmm);
+  GL_HIP(hipSetDevice(c->device));
+  const size_t n = (size_t)B * M, NOBS = (size_t)M * (1 + F);
+  const bool use_grid = g->grid.enabled && c->opt.assoc_grid != 0;
+  const size_t assoc_bytes = use_grid ? assoc_index_scratch_bytes(g->K, (int)n, d2_dev != nullptr) : assoc_scratch_bytes(g->K, (int)n);
+  auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+  // | association scratch | d2 | poses | prior | optr | opose | ouvr | ooct | dropped | erase | general kernel |
+  size_t off = up(assoc_bytes);
+  const size_t o_d2 = off;      off += up(n * 8);
+  const size_t o_poses = off;   off += up((size_t)B * (1 + F) * 56);
+  const size_t o_prior = off;   off += up((size_t)B);
+  const size_t o_optr = off;    off += up((size_t)B * (M + 1) * 4);
+  const size_t o_opose = off;   off += up((size_t)B * NOBS * 4);
+  const size_t o_ouvr = off;    off += up((size_t)B * NOBS * 24);
+  const size_t o_ooct = off;    off += up((size_t)B * NOBS * 4);
+  const size_t o_drop = off;    off += up(n);
+  const size_t o_erase = off;   off += up((size_t)B * NOBS);
+  const size_t o_gen = off;     off += ba_gen_scratch_bytes(B, 1, F, M, (int)NOBS);
+  void* scratch = nullptr;
+  int rc = ctx_scratch(c, off + 256, &scratch);
+  if (rc != GL_OK) return rc;
+  char* s = (char*)scratch;
+  double* d2 = d2_dev ? d2_dev : (double*)(s + o_d2);
+  if (use_grid)
+    rc = launch_assoc_index(c, g, Xw_dev, (int)n, assoc_dev, d2, d2_dev != nullptr, scratch);
+  else
+    rc = launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
+  if (rc != GL_OK) return rc;
+  {
+    TimerScope ts(c, GL_TIMER_BA_PREP);
+    k_track_pack<<<B, PK_T, 0, c->stream>>>(B, M, F, 9.0, pose_dev, an->prior_dev, an->fixed_pose_dev, obs_dev, octave_dev, an->fixed_obs_dev,
+                                            an->fixed_oct_dev, assoc_dev, d2, (double*)(s + o_poses), (uint8_t*)(s + o_prior),
+                                            (int32_t*)(s + o_optr), (int32_t*)(s + o_opose), (double*)(s + o_ouvr), (int32_t*)(s + o_ooct));
+  }
+  GL_HIP(hipGetLastError());
+  rc = launch_ba_gen(c, g, cam, prm, B, 1, F, M, (int)NOBS, (double*)(s + o_poses), (const uint8_t*)(s + o_prior), Xw_dev, assoc_dev,
+                     (const int32_t*)(s + o_optr), (const int32_t*)(s + o_opose), (const double*)(s + o_ouvr), (const int32_t*)(s + o_ooct),
+                     (uint8_t*)(s + o_drop), (uint8_t*)(s + o_erase), nullptr, nullptr, s + o_gen);
+  if (rc != GL_OK) return rc;
+  k_track_unpack<<<B, PK_T, 0, c->stream>>>(B, M, F, (const double*)(s + o_poses), (const int32_t*)(s + o_optr), (const int32_t*)(s + o_opose),
+                                            (const uint8_t*)(s + o_drop), (const uint8_t*)(s + o_erase), pose_dev, assoc_dev, an->fixed_erase_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+}  // namespace gl

@@ -402,6 +402,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   }
   const int n_init = (int)block_total1(cnt, part);
   if (n_init < 3) {  // :139-140
+    if (REGS) {  // the on-chip shapes keep the flags in registers: the reset of :63-69 happened before this return
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = ((lane >> 6) * S + i) * 64 + (lane & 63);
+        if (E.oc[i] >= 0) level[e] = 0;
+      }
+    }
     if (lane == 0) ninlier[f] = 0;
     return;
   }

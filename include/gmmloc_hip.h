@@ -302,6 +302,21 @@ int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* c
                           const int32_t* obs_pose_dev, const double* obs_uvr_dev, const int32_t* obs_oct_dev,
                           uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev);
 
+/* The same with the reference's stop word (`pbStopFlag`, Localization::jointOptimization's abort: localization_opt.cpp:541-542
+ * setForceStopFlag, :765-767, :792-796).  stop_flag: one int32 in device or host-mapped memory (gl_malloc / gl_malloc_host),
+ * read with system scope once per Levenberg trial and acted on where g2o tests terminate() - before an outer iteration:
+ *   > 0 on entry      the call returns at once, nothing is written (the reference's `return` at :765-767; iters = 0);
+ *   > 0 later         the running outer iteration finishes, no further one starts; the reprojection gating and optimize(40)
+ *                     are skipped (bDoMore = false), outputs are those of the last accepted step;
+ *   < 0               a BUDGET of -value outer iterations in total (deterministic; what the parity tests use);
+ *   0 / NULL          gl_joint_optimization. */
+int gl_joint_optimization_stoppable(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B,
+                                    int P, int F, int L, int NOBS, double* poses_dev, const uint8_t* prior_dev,
+                                    double* points_dev, const int32_t* assoc_dev, const int32_t* obs_ptr_dev,
+                                    const int32_t* obs_pose_dev, const double* obs_uvr_dev, const int32_t* obs_oct_dev,
+                                    uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                                    const int32_t* stop_flag);
+
 /* North-star per-frame path: associate + structure-constrained pose refinement for B
  * frames of M map points each:
  *   1. idx = argmin_k chi2_k(Xw)  (GL_ASSOC_BRUTE), association kept iff chi2 <= 9
@@ -315,6 +330,31 @@ int gl_joint_optimization(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* c
 int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
                     double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
                     int32_t* assoc_dev, double* d2_dev);
+/* The same with a gauge anchor.  The reference never runs its structure BA without one: the other observers of the
+ * local map points enter as FIXED key-frames (localization_opt.cpp:491-516) and key-frame 0 carries an EdgeSE3QuatPrior
+ * (factors.cpp:19-53; measurement = its pose on entry, sigma_rot 2 deg, sigma_t 1 cm) or is fixed itself when
+ * !ba_first_as_prior (:556-581).  Per frame:
+ *   prior_dev       B uint8 or NULL; 1 = the frame's pose is "key-frame 0": prior edge on pose_dev's input value
+ *                   (gl_params.ba_first_as_prior != 0) or fixed pose (== 0: only the points move);
+ *   F               fixed observer key-frames per frame, 0 .. GL_TRACK_MAX_FIXED;
+ *   fixed_pose_dev  B x F x 7; fixed_obs_dev B x M x F x 3 (u, v, u_right; u_right < 0 => mono);
+ *   fixed_oct_dev   B x M x F int32 (< 0: point not observed by that key-frame);
+ *   fixed_erase_dev B x M x F uint8 out or NULL (observations the reference would erase, :855-879).
+ * F == 0 runs on the on-chip refine of gl_track_frames (the prior costs one 6x6 block per Levenberg trial); F > 0 is
+ * packed into flat problems (P = 1) and solved by the general kernel of gl_joint_optimization.  Same arithmetic as
+ * jointOptimization with P = 1: parity tests against the oracle's joint_optimization(P = 1, prior / F fixed). */
+#define GL_TRACK_MAX_FIXED 8
+typedef struct gl_track_anchor {
+  const uint8_t* prior_dev;
+  int32_t F;
+  const double* fixed_pose_dev;
+  const double* fixed_obs_dev;
+  const int32_t* fixed_oct_dev;
+  uint8_t* fixed_erase_dev;
+} gl_track_anchor;
+int gl_track_frames_anchored(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
+                             double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
+                             int32_t* assoc_dev, double* d2_dev, const gl_track_anchor* anchor);
 /* The same for ONE frame with HOST buffers in and out - what the reference's tracking thread would call once per frame
  * (tracking.cpp:274,312,356).  The context keeps a page-locked staging buffer and its device mirror (grown on demand),
  * enqueues one copy each way around gl_track_frames(B = 1) on its stream and synchronises once; pose_host (7) and
@@ -322,6 +362,10 @@ int gl_track_frames(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, co
 int gl_track_frame_host(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
                         double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
                         int32_t* assoc_host);
+/* ... anchored by the prior edge on the input pose (gl_track_frames_anchored with prior = 1, F = 0) */
+int gl_track_frame_host_anchored(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int M,
+                                 double* pose_host, double* Xw_host, const double* obs_host, const int32_t* octave_host,
+                                 int32_t* assoc_host);
 
 /* ---- device memory helpers for hosts without their own HIP allocator ------ */
 int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out);

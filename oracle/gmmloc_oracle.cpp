@@ -563,11 +563,12 @@ struct BAProblem {
   uint8_t* obs_erase;        // nobs out: observation to erase (:855-879)
 };
 
-int joint_optimization(OGmm& g, BAProblem& pb, const Camera& cam, const Params& prm, const bool* stop_flag) {
+int joint_optimization(OGmm& g, BAProblem& pb, const Camera& cam, const Params& prm, const bool* stop_flag, int stop_budget = -1) {
   Optimizer opt;
   opt.algorithm = ALG_LM;
   opt.linearSolver = LS_EIGEN;
   opt.forceStop = stop_flag;
+  opt.stopBudget = stop_budget;
   auto poseOf = [&](int i) {
     const double* p = pb.poses + (size_t)i * 7;
     return se3_make(Quat{p[0], p[1], p[2], p[3]}, p + 4);
@@ -642,7 +643,7 @@ int joint_optimization(OGmm& g, BAProblem& pb, const Camera& cam, const Params& 
       eobs[o] = e;
     }
   }
-  if (stop_flag && *stop_flag) return 0;
+  if (stop_flag && *stop_flag) return 0;  // :765-767 (the pointer is tested there, not the optimizer's terminate())
   opt.initializeOptimization();
   opt.optimize(5);  // :770-771
   const double str_thresh = prm.tri_str_thresh * prm.ba_lambda2;
@@ -656,7 +657,7 @@ int joint_optimization(OGmm& g, BAProblem& pb, const Camera& cam, const Params& 
   opt.initializeOptimization(0);
   opt.optimize(5);  // :788-789
   bool doMore = true;
-  if (stop_flag && *stop_flag) doMore = false;
+  if (opt.terminate()) doMore = false;  // :791-796 (*pbStopFlag; + the test hook's iteration budget)
   int actual_iter = 0;
   if (doMore) {  // :799-828
     for (int o = 0; o < pb.nobs; ++o) {
@@ -1128,6 +1129,18 @@ int orc_joint_optimization(void* h, const orc_camera* cam, const orc_params* prm
   OGmm* g = (OGmm*)h;
   BAProblem pb{P, F, L, nobs, poses, has_prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_octave, assoc_dropped, obs_erase};
   return joint_optimization(*g, pb, to_cam(cam), to_prm(prm), nullptr);
+}
+
+// the same with the stop word of gl_joint_optimization_stoppable: > 0 the flag is set on entry, < 0 it reads true after
+// -value outer iterations (og::Optimizer::stopBudget), 0 no stop
+int orc_joint_optimization_stop(void* h, const orc_camera* cam, const orc_params* prm, int P, int F, int L, int nobs,
+                                double* poses, const uint8_t* has_prior, double* points, const int32_t* assoc,
+                                const int32_t* obs_ptr, const int32_t* obs_pose, const double* obs_uvr,
+                                const int32_t* obs_octave, uint8_t* assoc_dropped, uint8_t* obs_erase, int stop_value) {
+  OGmm* g = (OGmm*)h;
+  BAProblem pb{P, F, L, nobs, poses, has_prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_octave, assoc_dropped, obs_erase};
+  const bool set = stop_value > 0;
+  return joint_optimization(*g, pb, to_cam(cam), to_prm(prm), set ? &set : nullptr, stop_value < 0 ? -stop_value : -1);
 }
 
 // SE3 helpers exposed for tests

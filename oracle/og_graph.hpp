@@ -383,6 +383,9 @@ struct Optimizer {
   int algorithm = ALG_LM;
   int linearSolver = LS_DENSE;
   const bool* forceStop = nullptr;
+  // test hook with the semantics of gl_joint_optimization_stoppable's negative stop word: the flag reads true once
+  // `stopBudget` outer iterations have completed in total (deterministic stand-in for another thread raising *forceStop)
+  int stopBudget = -1, itersDone = 0;
 
   // solver state
   bool doSchur = false;
@@ -432,7 +435,7 @@ struct Optimizer {
     return true;
   }
 
-  bool terminate() const { return forceStop ? *forceStop : false; }
+  bool terminate() const { return (forceStop && *forceStop) || (stopBudget >= 0 && itersDone >= stopBudget); }
 
   // SparseOptimizer::initializeOptimization(level) over all vertices
   bool initializeOptimization(int level = 0) {
@@ -778,6 +781,7 @@ struct Optimizer {
       result = (algorithm == ALG_GN) ? solveGN(i) : solveLM(i);
       ok = (result == R_OK);
       ++cj;
+      ++itersDone;
     }
     if (result == R_FAIL) return 0;
     return cj;

@@ -171,16 +171,16 @@ class Oracle:
         return pose, outl, n
 
     def joint_optimization(self, h, cam, P, F, poses, has_prior, points, assoc, obs_ptr, obs_pose, obs_uvr,
-                           obs_oct, prm=None):
+                           obs_oct, prm=None, stop=0):
         poses, points, obs_uvr = _f64(poses).copy(), _f64(points).copy(), _f64(obs_uvr)
         has_prior = np.ascontiguousarray(has_prior, np.uint8)
         assoc, obs_ptr, obs_pose, obs_oct = _i32(assoc), _i32(obs_ptr), _i32(obs_pose), _i32(obs_oct)
         L, nobs = points.shape[0], obs_pose.shape[0]
         dropped, erase = np.zeros(L, np.uint8), np.zeros(max(nobs, 1), np.uint8)
         c = self.camera(cam)
-        it = self.lib.orc_joint_optimization(h, C.byref(c), C.byref(prm or self.prm), P, F, L, nobs, _p(poses),
-                                             _p(has_prior), _p(points), _p(assoc), _p(obs_ptr), _p(obs_pose),
-                                             _p(obs_uvr), _p(obs_oct), _p(dropped), _p(erase))
+        it = self.lib.orc_joint_optimization_stop(h, C.byref(c), C.byref(prm or self.prm), P, F, L, nobs, _p(poses),
+                                                  _p(has_prior), _p(points), _p(assoc), _p(obs_ptr), _p(obs_pose),
+                                                  _p(obs_uvr), _p(obs_oct), _p(dropped), _p(erase), int(stop))
         return poses, points, dropped, erase[:nobs], it
 
     def search_by_projection(self, width, height, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level,

@@ -107,6 +107,34 @@ def test_optimize_current_pose_keeps_flags_without_map_point(gpu, oracle, map_v1
     assert np.array_equal(got[none], preset[none]) and np.array_equal(got[~none], o_ref[~none]) and int(nin[0]) == n_ref
 
 
+@pytest.mark.parametrize("regs", [0, 1])
+@pytest.mark.parametrize("waves", [0, 1, 4, 8])
+@pytest.mark.parametrize("npts", [1, 2])
+def test_optimize_current_pose_resets_flags_before_the_too_few_edges_return(gpu, oracle, map_v1, gt_sync, opt, regs, waves, npts):
+    """Frames with 1-2 correspondences return 0 at tracking_opt.cpp:139 - AFTER is_outlier_ was reset for the features
+    with a map point (:63-69).  The flags the host passes in must come back 0 for those and untouched for the others,
+    whichever launch shape answers (the on-chip shapes hold the flags in registers until the end of the kernel)."""
+    torch, ctx = gpu
+    opt("pose_regs", regs)
+    opt("pose_waves", waves)
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    f = make_frames(mean, cov, gt_sync["V1_01_easy"], cam, 1, 200, 901)[0]
+    keep = np.array([17, 150])[:npts]
+    f["octave"][np.setdiff1d(np.arange(200), keep)] = -1
+    preset = np.ones(200, np.uint8)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a[None])).cuda()
+    pose, outl = T(f["pose_init"]), T(preset)
+    _, nin = gmmloc_amd.optimize_current_pose(ctx, cam, prm, pose, T(f["Xw"]), T(f["obs"]), T(f["octave"]), outlier=outl)
+    torch.cuda.synchronize()
+    p_ref, o_ref, n_ref = oracle.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
+    got = outl.cpu().numpy()[0]
+    want = preset.copy()
+    want[keep] = 0
+    assert n_ref == 0 and int(nin[0]) == 0 and np.array_equal(o_ref[keep], np.zeros(npts, np.uint8))
+    assert np.array_equal(got, want), (got[keep], int((got != want).sum()))
+
+
 def test_optimize_current_pose_bit_identical_across_shapes_and_batches(gpu, map_v1, gt_sync, opt):
     """One canonical summation order (gl_refine_pose.hip): the refined pose, the outlier mask and the inlier count of a
     frame are the same BITS on one wave (batch shape), on a wave per group (few frames), and whatever rides in the call."""

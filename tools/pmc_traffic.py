@@ -47,6 +47,9 @@ def main(root):
         if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
             d["valu_active_over_wave_cycles"] = d.get("SQ_ACTIVE_INST_VALU", 0.0) / d["SQ_WAVE_CYCLES"]
             d["wait_any_over_wave_cycles"] = d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["kernel_source_sha"] = bench.kernel_source_fingerprint()  # bench.py flags a summary made from other sources as stale
     out["how"] = ("rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline, one run per "
                   "counter group (tools/profile_bench.sh); averages over the 4096-frame launches")
     print(json.dumps(out, indent=1))
