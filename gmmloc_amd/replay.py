@@ -114,9 +114,32 @@ EUROC_SEQUENCES = (("V1_01_easy", "map_v1"), ("V1_02_medium", "map_v1"), ("V1_03
 ROW_D = 18
 
 
-def materialise_euroc(golden_dir, cam, M=300, limit=None, seed0=20200901, sequences=EUROC_SEQUENCES):
+def _observe(cam, T, X, rng):
+    """Noisy stereo observations (u, v, u_right; octave) of world points X from pose T, as synth.synth_frame makes them;
+    octave -1 where the point is not in the image."""
+    from . import synth
+    R, t = synth.quat_to_R(T[:4]), T[4:]
+    pc = X @ R.T + t
+    z = np.maximum(pc[:, 2], 0.2)
+    octave = rng.integers(0, 8, len(X)).astype(np.int32)
+    sig = 1.2 ** octave
+    u = cam.fx * pc[:, 0] / z + cam.cx + rng.standard_normal(len(X)) * sig
+    v = cam.fy * pc[:, 1] / z + cam.cy + rng.standard_normal(len(X)) * sig
+    ur = u - cam.bf / z + rng.standard_normal(len(X)) * sig * 0.5
+    ur = np.where(rng.uniform(size=len(X)) < 0.15, -1.0, np.maximum(ur, 0.0)).astype(np.float32).astype(np.float64)
+    vis = (pc[:, 2] > 0.3) & (u >= 0) & (u < cam.width) & (v >= 0) & (v < cam.height)
+    return np.stack([u, v, ur], 1), np.where(vis, octave, -1).astype(np.int32)
+
+
+def materialise_euroc(golden_dir, cam, M=300, limit=None, seed0=20200901, sequences=EUROC_SEQUENCES, map_sigma=0.0, fixed=0,
+                      fixed_stride=10):
     """-> (maps {name: (mean, cov)}, frames [dict + seq / map / stamp / row], in sequence order); limit = frames per
-    sequence (evenly spaced over it)."""
+    sequence (evenly spaced over it).  map_sigma > 0: the map points the tracker is GIVEN carry isotropic noise of that
+    many metres (a real local map is triangulated, not exact) while the observations are those of the true points
+    (kept as "Xw_true"); 0 = the exact points of the earlier rounds.  fixed = F > 0: every frame also carries F FIXED
+    observer key-frames (localization_opt.cpp:491-516) - the ground-truth poses fixed_stride, 2 fixed_stride, ... rows
+    earlier in its sequence - with their own noisy observations of the frame's (true) points: "fixed_pose" (F,7),
+    "fixed_obs" (M,F,3), "fixed_oct" (M,F)."""
     import os
     from . import synth
     gt = np.load(os.path.join(golden_dir, "gt_sync.npz"))
@@ -131,6 +154,15 @@ def materialise_euroc(golden_dir, cam, M=300, limit=None, seed0=20200901, sequen
             row = gt[seq][i]
             f = synth.synth_frame(mean, cov, synth.gt_row_to_Tcw(row), cam, M, seed0 + len(frames))
             f.update(seq=seq, map=mapname, stamp=float(row[0]), row=int(i))
+            if fixed:
+                rng = np.random.default_rng(seed0 + 104729 * (len(frames) + 1))
+                fp = np.stack([synth.gt_row_to_Tcw(gt[seq][max(0, i - (j + 1) * fixed_stride)]) for j in range(fixed)])
+                fo = [_observe(cam, fp[j], f["Xw"], rng) for j in range(fixed)]
+                f.update(fixed_pose=fp, fixed_obs=np.ascontiguousarray(np.stack([o for o, _ in fo], 1)),
+                         fixed_oct=np.ascontiguousarray(np.stack([c for _, c in fo], 1)))
+            if map_sigma > 0:
+                f["Xw_true"] = f["Xw"]
+                f["Xw"] = f["Xw"] + np.random.default_rng(seed0 + 7919 * (len(frames) + 1)).standard_normal(f["Xw"].shape) * map_sigma
             frames.append(f)
     return maps, frames
 
@@ -139,11 +171,14 @@ class TrackCompute:
     """compute callback of replay(): a batch of frame problems -> ROW_D result rows, the per-frame sequence of the
     reference's tracker on the HIP path: Tracking::optimizeCurrentPose on the frame's correspondences
     (gl_optimize_current_pose: the pose of the trajectory), then the north-star association + structure-constrained
-    refinement from that pose (gl_track_frames: one free pose and free points, held by the map's Gaussians only -
-    no prior or fixed key-frame anchors its gauge, so its pose is reported next to the tracker's, not instead)."""
+    refinement from that pose - anchor "prior" (default): gl_track_frames_anchored with the reference's EdgeSE3QuatPrior
+    on the tracker's pose (sigma 2 deg / 1 cm, localization_opt.cpp:556-581), the gauge anchor the reference's
+    structure BA always has; anchor "none": gl_track_frames, one free pose and free points held by the map's Gaussians
+    only (the earlier rounds' replay)."""
 
-    def __init__(self, ctx, gmms, cam, prm):
-        self.ctx, self.gmms, self.cam, self.prm = ctx, gmms, cam, prm
+    def __init__(self, ctx, gmms, cam, prm, anchor="prior"):
+        assert anchor in ("prior", "none", "fixed")  # "fixed": prior + the frames' fixed observer key-frames
+        self.ctx, self.gmms, self.cam, self.prm, self.anchor = ctx, gmms, cam, prm, anchor
 
     def __call__(self, frames):
         import time
@@ -159,7 +194,15 @@ class TrackCompute:
             t0 = time.perf_counter()
             outl, nin = api.optimize_current_pose(self.ctx, self.cam, self.prm, pose, Xw, obs, octv)
             pose_track = pose.clone()
-            assoc, _ = api.track_frames(self.ctx, self.gmms[mapname], self.cam, self.prm, pose, Xw, obs, octv, want_d2=False)
+            # "Discard outliers" (tracking.cpp:313-324, 360-371): a feature optimizeCurrentPose flagged loses its map point
+            octv = torch.where(outl != 0, torch.full_like(octv, -1), octv)
+            if self.anchor in ("prior", "fixed"):
+                prior = torch.ones(len(sel), dtype=torch.uint8, device=dev)
+                fx = {} if self.anchor == "prior" else dict(fixed_pose=T("fixed_pose"), fixed_obs=T("fixed_obs"), fixed_oct=T("fixed_oct"))
+                assoc, _, _ = api.track_frames_anchored(self.ctx, self.gmms[mapname], self.cam, self.prm, pose, Xw, obs, octv,
+                                                        prior=prior, want_d2=False, **fx)
+            else:
+                assoc, _ = api.track_frames(self.ctx, self.gmms[mapname], self.cam, self.prm, pose, Xw, obs, octv, want_d2=False)
             torch.cuda.synchronize(dev)
             ms = 1e3 * (time.perf_counter() - t0) / len(sel)
             out[sel, :7] = pose_track.cpu().numpy()

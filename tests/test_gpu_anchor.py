@@ -194,7 +194,9 @@ def test_track_frames_fixed_observers_match_oracle(gpu, oracle, map_v1, gt_sync,
         assert np.array_equal(assoc[i][keep], a_ref), (i, int((assoc[i][keep] != a_ref).sum()))
         assert np.array_equal(ferase[i][keep], fe_ref), (i, int((ferase[i][keep] != fe_ref).sum()))
         assert fe_ref.sum() > 0  # (the planted outliers are found)
-        assert np.abs(Xw[i][keep] - pts_ref).max() < 1e-6  # observed from fixed poses: every point is well constrained
+        err = np.abs(Xw[i][keep] - pts_ref).max(1)
+        well = (f["obs"][keep][:, 2] >= 0) | ((f["fixed_oct"][keep] >= 0) & ~fe_ref.astype(bool)).any(1)  # stereo, or a second view
+        assert err[well].max() < 1e-6 and err.max() < 1e-4, (i, err[well].max(), err.max())
         assert (assoc[i][f["octave"] < 0] == -1).all() and not ferase[i][f["octave"] < 0].any()
         untouched = f["octave"] < 0
         assert np.array_equal(Xw[i][untouched], f["Xw"][untouched])

@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="frames per gl_track_frames call")
     ap.add_argument("--out", default=None, help="directory for the TUM trajectories")
     ap.add_argument("--map-sigma", type=float, default=0.0, help="noise (m) on the map points the tracker is given (0: exact points)")
-    ap.add_argument("--anchor", default="prior", choices=["none", "prior"], help="gauge anchor of the structure refine")
+    ap.add_argument("--anchor", default="prior", choices=["none", "prior", "fixed"], help="gauge anchor of the structure refine")
+    ap.add_argument("--fixed", type=int, default=2, help="fixed observer key-frames per frame (--anchor fixed)")
     ap.add_argument("--collective-at-world-1", action="store_true", help="run the RCCL gather / all_reduce even with one rank")
     args = ap.parse_args()
     from gmmloc_amd import launch
@@ -38,7 +39,8 @@ def main():
     world, rank, local, dist = ranks.world, ranks.rank, ranks.local, ranks.dist
     cam, prm = api.Camera(), api.Params()
     t0 = time.time()
-    maps, frames = replay.materialise_euroc(os.path.join(ROOT, "tests", "golden"), cam, args.M, args.limit, map_sigma=args.map_sigma)
+    maps, frames = replay.materialise_euroc(os.path.join(ROOT, "tests", "golden"), cam, args.M, args.limit, map_sigma=args.map_sigma,
+                                            fixed=args.fixed if args.anchor == "fixed" else 0)
     t_mat = time.time() - t0
     ctx = gmmloc_amd.Context(local)
     gmms = {name: gmmloc_amd.GMM(ctx, mean, cov, prm) for name, (mean, cov) in maps.items()}
