@@ -122,6 +122,12 @@ class Context:
         _check(self.lib.gl_ctx_timing_read(self.h, timer, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
+    def counter_read(self, counter=0, reset=True):
+        """gl_ctx_counter_read: 0 = GL_COUNTER_BA_REDONE (frames of latency-shape launches redone by the follow-up kernel)."""
+        v = C.c_int64(0)
+        _check(self.lib.gl_ctx_counter_read(self.h, counter, C.byref(v), 1 if reset else 0))
+        return v.value
+
     def set_stats_buffer(self, trials):
         """Register (or clear with None) an int32 CUDA tensor that receives per-frame LM trial counts."""
         self._stats = trials

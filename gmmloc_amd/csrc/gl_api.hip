@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 // option table: name as in gl_ctx_set_option; the environment variable is GMMLOC_<NAME IN CAPITALS>
 #define GL_OPTION_LIST(X) \
-  X(ba_shape) X(ba_step32) X(ba_slow) X(ba_rendezvous_us) X(ba_same_xcd) X(pose_waves) X(pose_regs) X(bagen_nb) X(view_slot_lds) X(view_threads) \
+  X(ba_shape) X(ba_step32) X(ba_slow) X(ba_rendezvous_us) X(ba_test_abort_seq) X(ba_same_xcd) X(pose_waves) X(pose_regs) X(bagen_nb) X(view_slot_lds) X(view_threads) \
   X(assoc_index_min) X(assoc_grid) X(match_desc_lds)
 double* option_slot(Options& o, const char* name) {
 #define X(n) \
@@ -140,6 +140,12 @@ int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out) {
   c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
   gl::options_from_env(c->opt);         // the only place the knobs are read from the environment
   c->xcc_ids_trusted = gl::probe_xcc_ids(c);
+  if (hipMalloc((void**)&c->counters, GL_COUNTER_COUNT * sizeof(int32_t)) != hipSuccess ||
+      hipMemsetAsync(c->counters, 0, GL_COUNTER_COUNT * sizeof(int32_t), c->stream) != hipSuccess) {
+    gl::set_error("gl_ctx_create: counter allocation failed");
+    delete c;
+    return GL_ERR_NOMEM;
+  }
   *out = (gl_ctx_t*)c;
   return GL_OK;
 }
@@ -155,6 +161,7 @@ int gl_ctx_destroy(gl_ctx_t* ctx) {
     (void)hipEventDestroy(p.second);
   }
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->counters) (void)hipFree(c->counters);
   if (c->dev_stage) (void)hipFree(c->dev_stage);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -210,6 +217,18 @@ int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* laun
     c->timer_ms[timer] = 0.0;
     c->timer_n[timer] = 0;
   }
+  return GL_OK;
+}
+
+int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset) {
+  GL_REQUIRE(ctx && value && counter >= 0 && counter < GL_COUNTER_COUNT, "bad argument");
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  int32_t v = 0;
+  GL_HIP(hipMemcpyAsync(&v, c->counters + counter, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  if (reset) GL_HIP(hipMemsetAsync(c->counters + counter, 0, sizeof(v), c->stream));
+  GL_HIP(hipStreamSynchronize(c->stream));
+  *value = v;
   return GL_OK;
 }
 

@@ -478,8 +478,13 @@ int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm,
 
 // fast path: plane records (32 B) + normalised observations (24 B) + permutation, flags, gated association (12 B) per
 // point; general kernel: trial points, chi2, levels (33 B); + per frame: 2 x 4 x 32 x 2 exchange words of the latency
-// shape, 12 doubles of the prior edge's inverse measurement (gl_ba_fast.hip)
-size_t ba1_scratch_bytes(int B, int L) { return (size_t)B * L * 36 + (size_t)B * (8192 + 8 + 96) + 512; }
+// shape, 12 doubles of the prior edge's inverse measurement, and for small batches the staging area of the latency shape's
+// results (points 24 B + association 4 B per point, pose 64 B per frame) (gl_ba_fast.hip)
+size_t ba1_scratch_bytes(int B, int L) {
+  size_t n = (size_t)B * L * 36 + (size_t)B * (8192 + 8 + 96) + 512;
+  if ((size_t)B * ((L + 255) / 256) <= 1024) n += (size_t)B * L * 28 + (size_t)B * 64 + 64;  // a batch the latency shape may take: its staging area
+  return n;
+}
 
 }  // namespace gl
 

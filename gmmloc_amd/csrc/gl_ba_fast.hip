@@ -314,7 +314,7 @@ static void canon_order(int L, int* G, int* S) {
 }
 
 typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*, int*, long long, int, const uint8_t*, const double*);
+                          unsigned long long*, int*, long long, int, const int32_t*, const uint8_t*, const double*, double*, int, int32_t*);
 
 struct BafArgs {
   BaK k;
@@ -334,6 +334,9 @@ struct BafArgs {
   int* ctl = nullptr;  // per frame {abort, done} of a latency-shape launch (the follow-up DENSE launch skips the done ones)
   const uint8_t* prior = nullptr;  // per frame: gauge anchor of the pose (prior edge / fixed), or null
   const double* prior_mi = nullptr;  // per frame: inverse measurement of the prior edge {R, t} (written by k_ba1_prep)
+  double* stage = nullptr;           // latency shape: staging area of the results {points | pose | association}
+  int nb_prev = 0;                   // follow-up launch: workgroups per frame of the latency-shape launch before it
+  int32_t* counters = nullptr;       // the context's device counters (gl_ctx_counter_read)
 };
 
 // one workgroup of G waves per frame; LDS class by stride (4 / 2 / 1 frames per CU)
@@ -348,7 +351,7 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   a.NB = 1;
   a.parts = nullptr;
   kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts, a.ctl, 0ll, 0, a.prior, a.prior_mi);
+                                          a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior, a.prior_mi, a.stage, a.nb_prev, a.counters);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -374,16 +377,20 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds) != hipSuccess) occ = 0;
       hit = c->occupancy.emplace(key, occ).first;
     }
-    if ((long)a.B * a.NB > (long)hit->second * c->ncu) return 1;
+    // ... per XCD: the kernel keeps the workgroups of a frame on ONE XCD (frame f -> XCD f % 8), so what has to fit is the
+    // ceil(B / 8) frames of an XCD into that XCD's share of the slots (a frame whose siblings queue behind the resident
+    // ones would sit in the rendezvous until its time limit and be redone by the follow-up kernel: correct, but slow)
+    if ((long)((a.B + 7) / 8) * a.NB > (long)hit->second * (c->ncu / 8)) return 1;
   }
   // the exchange words of the frames sit behind the per-point records, {abort, done} per frame behind them
   a.parts = (unsigned long long*)((char*)scratch + (((size_t)a.B * a.L * 36 + 63) / 64) * 64);
   a.ctl = (int*)(a.parts + (size_t)a.B * 2 * a.NB * 64);  // (both zeroed by k_ba1_prep)
-  const long long limit = (long long)(c->opt.ba_rendezvous_us * 100.0);  // wall_clock64() ticks at 100 MHz
+  long long limit = (long long)(c->opt.ba_rendezvous_us * 100.0);  // wall_clock64() ticks at 100 MHz
+  if (c->opt.ba_test_abort_seq > 0) limit = -(long long)c->opt.ba_test_abort_seq;  // tests: a give-up in the middle of the schedule
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
   kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.prior, a.prior_mi);
+                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }
@@ -412,6 +419,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   a.iters = iters;
   a.pn = (double*)scratch;
   a.stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
+  a.counters = c->counters;
   bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD; checked in launch_spread)
   if (c->opt.ba_shape == 0) spread = false;
   if (c->opt.ba_shape == 1) spread = true;  // forced (tests); a shape that does not fit the device still goes DENSE
@@ -423,6 +431,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
     const int nxw = 2 * a.G * 64;
     // inverse measurements of the prior edges: behind the records, the exchange words and {abort, done} (ba1_scratch_bytes)
     a.prior_mi = (double*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64 + (size_t)B * (8192 + 8) + 64);
+    if (spread) a.stage = (double*)(a.prior_mi + (size_t)B * 12);  // {points B x L x 3 | pose B x 8 | association B x L}
     k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch, xw, xw ? (int*)(xw + (size_t)B * nxw) : nullptr, nxw,
                                             pose, prior, (double*)a.prior_mi);
   }
@@ -432,6 +441,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
     const int rc = launch_spread(c, a, scratch);
     if (rc <= 0) return rc;
     if (rc == 1) a.ctl = nullptr;  // shape does not fit: every frame goes DENSE
+    else a.nb_prev = a.NB;         // follow-up: staged results of the complete frames -> the caller's buffers, the others redone
   }
   return launch_dense(c, a);
 }

@@ -742,6 +742,8 @@ GL_DEV double spread_collect(const Coop& C, unsigned seq, int t) {
   constexpr int NBMAX = 8;
   unsigned long long w0[NBMAX], w1[NBMAX];
   bool all, off = false;
+  int spins = 0;
+  long long t0 = 0;
   do {
     all = true;
 #pragma unroll
@@ -753,16 +755,17 @@ GL_DEV double spread_collect(const Coop& C, unsigned seq, int t) {
       }
     }
     // the abort word travels with the same batch of requests (asked for afterwards it would add a round trip to every
-    // poll that has to be repeated: one frame 0.440 -> 0.430 ms); never the first exchange of a launch here, so no time
-    // limit.  (Two polls in flight half a round trip apart were measured too: 0.48 ms - a repeated poll is cheap, the wait
-    // is for the slowest sibling's pass, not for the fabric.)
+    // poll that has to be repeated: one frame 0.440 -> 0.430 ms).  (Two polls in flight half a round trip apart were
+    // measured too: 0.48 ms - a repeated poll is cheap, the wait is for the slowest sibling's pass, not for the fabric.)
+    // Every exchange has the time limit of the rendezvous (gld::coop_give_up: the clock is read only after POLL_FREE
+    // unsuccessful polls): a sibling that stops answering sends the frame to the follow-up kernel instead of hanging it.
     const int ab = __hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int p = 0; p < NBMAX; ++p)
       if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
-    off = !all && ab != 0;
+    if (!all) off = coop_give_up(C, ab, spins, t0);
   } while (!all && !off);
-  if (off) *C.lds_fail = 1;
+  if (off || coop_test_abort(C, seq)) *C.lds_fail = 1;
   double g[NBMAX];
 #pragma unroll
   for (int p = 0; p < NBMAX; ++p) g[p] = p < C.NB ? __longlong_as_double((long long)((w1[p] & 0xffffffff00000000ull) | (w0[p] >> 32))) : 0.0;
@@ -1424,7 +1427,9 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                   int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
                                                   int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted,
-                                                  const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi) {
+                                                  const int32_t* __restrict__ oct_all,
+                                                  const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi, double* __restrict__ stage, int nb_prev,
+                                                  int32_t* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1444,7 +1449,26 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   const int f = kSpread ? (NB > 1 ? (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 6) : (int)blockIdx.x) : (int)blockIdx.x;
   const int pb_ = kSpread && NB > 1 ? (int)((blockIdx.x >> 3) & 7) : 0;
   if (f >= B || pb_ >= NB) return;
-  if (!kSpread && ctl && ctl[2 * f + 1]) return;  // follow-up of a latency-shape launch: this frame completed there
+  // latency-shape launches write to a staging area {points B x L x 3 | pose B x 7 (stride 8) | association B x L}
+  double* const st_pts = stage;
+  double* const st_pose = stage ? stage + (size_t)B * L * 3 : nullptr;
+  int32_t* const st_assoc = stage ? (int32_t*)(st_pose + (size_t)B * 8) : nullptr;
+  if (!kSpread && ctl) {  // follow-up of a latency-shape launch
+    if (ctl[2 * f + 1] == nb_prev) {  // every workgroup of the frame finished there: its staged result becomes the answer
+      const int32_t* oc = oct_all + (size_t)f * L;
+      for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const size_t g = (size_t)f * L + l;
+        if (oc[l] >= 0) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) pts_io[g * 3 + j] = st_pts[g * 3 + j];
+        }
+        assoc_all[g] = st_assoc[g];
+      }
+      if (threadIdx.x < 7) pose_io[(size_t)f * 7 + threadIdx.x] = st_pose[(size_t)f * 8 + threadIdx.x];
+      return;
+    }
+    if (counters && threadIdx.x == 0) atomicAdd(&counters[0], 1);  // GL_COUNTER_BA_REDONE: recomputed here, from the untouched inputs
+  }
   Coop C{kSpread && NB > 1 ? parts + (size_t)f * 2 * NB * 64 : nullptr, kSpread ? NB : 1, pb_, 0u,
          ctl ? ctl + 2 * f : nullptr, (int*)(R.tot + 61), limit, 0, 0};
   Map mp;
@@ -1551,11 +1575,14 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     __syncthreads();
   }
 
-  if (kSpread && C.NB > 1) {  // a frame whose workgroups did not all meet writes nothing: the follow-up launch redoes it
+  if (kSpread && C.NB > 1) {  // a frame whose workgroups lost each other writes nothing: the follow-up launch redoes it
     __syncthreads();
     C.failed |= *C.lds_fail;
     if (C.failed) return;
   }
+  const bool staged = kSpread && C.NB > 1;  // (results of a latency-shape launch go through the staging area)
+  double* const pts_out = staged ? st_pts : pts_io;
+  int32_t* const assoc_out = staged ? st_assoc : assoc_all;
 #pragma unroll 1
   for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
     const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
@@ -1573,12 +1600,12 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
       const double z = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];
       if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) pts_io[g * 3 + j] = p[j];
+      for (int j = 0; j < 3; ++j) pts_out[g * 3 + j] = p[j];
     }
     if (dropped_all) dropped_all[g] = dr;
     if (erase_all) erase_all[g] = er;
     if (!dropped_all && dr) a = -1;
-    assoc_all[g] = a;
+    assoc_out[g] = a;
   }
   if (tid == 0 && C.pb == 0) {
     SE3 T;
@@ -1587,10 +1614,16 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     T.t[1] = P.t[1];
     T.t[2] = P.t[2];
     normalize_rotation(T);
-    if (!(kPrior && An.pose_fixed)) se3_store(T, pose_io + (size_t)f * 7);
+    if (kPrior && An.pose_fixed) {  // a fixed vertex keeps the caller's bits
+      if (staged) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) st_pose[(size_t)f * 8 + r] = pose_io[(size_t)f * 7 + r];
+      }
+    } else {
+      se3_store(T, staged ? st_pose + (size_t)f * 8 : pose_io + (size_t)f * 7);
+    }
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
-    if (kSpread && C.ctl) C.ctl[1] = 1;  // done
 #ifdef GL_BA_TRACE
     if (f == 0)
       for (int i = 0; i < 10 * 128 && i < L * 3; ++i) pts_io[i] = g_trace[i];
@@ -1601,6 +1634,13 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
       for (int i = 0; i < 64 * 8 * 4 && i < L * 3; ++i) pts_io[i] = (double)g_prof_w[i];
     }
 #endif
+  }
+  if (kSpread && C.ctl) {  // this workgroup's share of the frame is in place: count it done (the follow-up kernel wants all NB)
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(C.ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -559,26 +559,45 @@ GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
 // are used alternately: a workgroup can only be one reduction ahead of the slowest one (it needs that one's
 // partial), so what it overwrites has been read by everybody.
 // The workgroups of a problem must be co-resident for this to terminate.  A cooperative launch guarantees it but costs
-// ~30 us per launch on this stack; the kernels are launched plainly and protect themselves instead: the FIRST exchange of
-// a launch is a rendezvous with a time limit - a workgroup whose siblings do not show up (they are queued behind another
-// launch that is itself waiting for ITS siblings) raises the problem's abort word and leaves; every later poll watches that
-// word, so a problem either completes in all its workgroups or in none, and nothing is written unless it completed (the
-// launcher follows up with the one-workgroup kernel for the problems whose `done` word stayed 0: same bits by construction).
-// Once all workgroups of a problem have met they stay resident until they exit, so later polls need no limit.
+// ~30 us per launch on this stack; the kernels are launched plainly and protect themselves instead: EVERY exchange has a
+// time limit (option ba_rendezvous_us, default 200 us against the ~1 us a sibling's pass takes).  A workgroup whose
+// siblings do not show up (the first exchange: they are queued behind another launch that is itself waiting for ITS
+// siblings) or stop answering (a later one: preempted, or a word that never becomes visible) raises the problem's abort
+// word and leaves; every poll watches that word.  The workgroups write their results to a STAGING area of the launch's
+// scratch and count themselves done; the launcher always follows up with the one-workgroup kernel, which copies the staged
+// result of a problem to the caller's buffers iff all its workgroups are done and recomputes the problem from the untouched
+// inputs otherwise - same bits by construction, whenever the give-up happened.
 struct Coop {
   unsigned long long* part;  // 2 buffers x NB (<= 8) workgroups x 32 values x 2 words, zero before the launch
   int NB, pb;
   unsigned seq;              // reductions so far (the same in every workgroup)
   int* ctl;                  // global {abort, done} of the problem, zero before the launch
   int* lds_fail;             // LDS word: a poll of this workgroup failed (read by everybody behind the next barrier)
-  long long limit;           // rendezvous time limit in wall_clock64() ticks (100 MHz)
+  long long limit;           // time limit of an exchange in wall_clock64() ticks (100 MHz)
   int failed;                // this thread knows the problem is off
   int same_xcd;              // 1 once the workgroups have reported one and the same XCC id (and the host trusts the ids)
 };
-// poll helper of the exchange loops: true = give up (abort raised by a sibling, or the rendezvous timed out)
-GL_DEV bool coop_give_up(const Coop& C, int abort_word, unsigned seq, long long t0) {
+// poll helper of the exchange loops: true = give up (abort raised by a sibling, or this exchange timed out).  The clock is
+// only read from the POLL_FREE-th unsuccessful poll on (a poll is a fabric round trip, ~1 us: an exchange that completes
+// normally never pays for the clock); t0 is set by the first read.
+// limit == 0 (tests): a workgroup gives up at its first unsuccessful look.  limit < 0 (tests, option ba_test_abort_seq):
+// the LAST workgroup of every problem raises the abort word at its exchange number -limit, whatever it sees
+// (coop_test_abort) - a give-up in the middle of the schedule - and the polls use the default limit.
+constexpr int POLL_FREE = 12;
+constexpr long long POLL_LIMIT_DEFAULT = 20000;  // 200 us
+GL_DEV bool coop_give_up(const Coop& C, int abort_word, int& spins, long long& t0) {
   if (abort_word != 0) return true;
-  if (seq == 1u && (long long)wall_clock64() - t0 > C.limit) {
+  if (C.limit != 0) {
+    if (++spins < POLL_FREE) return false;
+    const long long now = (long long)wall_clock64();
+    if (spins == POLL_FREE) t0 = now;
+    if (now - t0 <= (C.limit < 0 ? POLL_LIMIT_DEFAULT : C.limit)) return false;
+  }
+  __hip_atomic_store(C.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+GL_DEV bool coop_test_abort(const Coop& C, unsigned seq) {
+  if (C.limit < 0 && C.pb == C.NB - 1 && (long long)seq == -C.limit) {
     __hip_atomic_store(C.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
   }
@@ -606,7 +625,8 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
     constexpr int NBMAX = 8;
     unsigned long long w0[NBMAX], w1[NBMAX];
     bool all, off = false;
-    const long long t0 = seq == 1u ? (long long)wall_clock64() : 0;
+    int spins = 0;
+    long long t0 = 0;
     do {
       all = true;
       const int ab = __hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // with the same batch of requests
@@ -621,9 +641,9 @@ GL_DEV void coop_totals(Coop& C, double* tot) {
 #pragma unroll
       for (int p = 0; p < NBMAX; ++p)
         if (p < C.NB) all = all && (unsigned)w0[p] == seq && (unsigned)w1[p] == seq;
-      if (!all) off = coop_give_up(C, ab, seq, t0);
+      if (!all) off = coop_give_up(C, ab, spins, t0);
     } while (!all && !off);
-    if (off) *C.lds_fail = 1;
+    if (off || coop_test_abort(C, seq)) *C.lds_fail = 1;
     double v[NBMAX];
 #pragma unroll
     for (int p = 0; p < NBMAX; ++p)

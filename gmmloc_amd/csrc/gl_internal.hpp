@@ -84,7 +84,9 @@ struct Options {
   double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
   double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame
   double ba_same_xcd = 1;          //   0: the latency shape never uses the same-XCD form of its exchange (A/B, tests)
-  double ba_rendezvous_us = 50000;  // time limit of the latency shape's rendezvous (0: every frame gives up -> follow-up kernel; tests)
+  double ba_rendezvous_us = 200;   // time limit of EVERY exchange of the latency shape (the fallback it protects costs ~0.5 ms; 0: a workgroup
+                                   // gives up at its first unsuccessful look -> follow-up kernel; tests)
+  double ba_test_abort_seq = 0;    // tests: n > 0 makes the last workgroup of every frame give up at its n-th exchange
   double pose_regs = 1;         //   0: the frame-at-a-time shapes read their edges from global memory every trial (A/B)
   double bagen_nb = 0;          // gl_joint_optimization: 0 auto, n workgroups per problem
   double view_slot_lds = 0;     // gl_search2d: accepted-list records kept in LDS (0 = all that fit)
@@ -116,6 +118,8 @@ struct Ctx {
   void* host_stage = nullptr;
   void* dev_stage = nullptr;
   size_t stage_bytes = 0;
+  // device counters (gl_ctx_counter_read): [0] frames of latency-shape launches redone by the follow-up kernel
+  int32_t* counters = nullptr;
   // optional statistics buffer (gl_ctx_set_stats_buffer)
   int32_t* stats = nullptr;
   int stats_n = 0;

@@ -83,7 +83,20 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   ba_shape (-1 auto | 0 one workgroup per frame | 1 one point per thread; same bits either way),
  *   ba_step32 (1: fp32-cached point step in gl_track_frames, faster, NOT bit-compatible with the default),
  *   assoc_grid (0: every association is the plain N x K sweep, never the cell index),
- *   ba_slow, ba_rendezvous_us, ba_same_xcd, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
+ *   ba_rendezvous_us (200): time limit of every exchange between the workgroups of a frame on the latency shape of
+ *     gl_track_frames (one point per thread, up to 8 workgroups per frame, launched plainly).  A frame whose workgroups do
+ *     not find each other in time - another launch holds the CUs - or lose each other later gives up; its results only
+ *     ever reach the caller's buffers through the one-workgroup kernel that always follows, which copies the staged result
+ *     of a complete frame and recomputes the others from the untouched inputs: same bits, <= ~0.5 ms more.
+ *     GL_COUNTER_BA_REDONE counts those frames,
+ *   ba_same_xcd (1): the exchange of that shape may use its same-XCD form - workgroup-scope atomic stores that stay in the
+ *     XCD's L2, polled by the siblings with agent-scope (L1-bypassing) loads.  HARDWARE ASSUMPTION, outside the HIP memory
+ *     model: a workgroup-scope store becomes visible to an agent-scope load of ANOTHER workgroup on the same XCD because
+ *     the vector L1 of gfx942 / gfx950 is write-through and the XCD's workgroups share one L2.  It is used only when (a) a
+ *     probe at gl_ctx_create found block b on XCC id b % 8 and (b) the frame's workgroups reported one and the same id in
+ *     the launch's first (device-scope) exchange; a word that did not become visible would time the exchange out
+ *     (ba_rendezvous_us) and send the frame to the follow-up kernel.  0: device-scope stores only (0.37 instead of 0.34 ms),
+ *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
 /* Kernel timing with HIP events on the context's stream: while enabled, every
@@ -98,6 +111,12 @@ enum gl_timer {
 };
 int gl_ctx_timing_enable(gl_ctx_t* ctx, int on);
 int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* launches, int reset);
+/* Event counters of a context (device-side, read with one small synchronous copy on the context's stream). */
+enum gl_counter {
+  GL_COUNTER_BA_REDONE = 0, /* frames of latency-shape launches of gl_track_frames that gave up and were recomputed by the follow-up kernel */
+  GL_COUNTER_COUNT = 4
+};
+int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset);
 /* Optional statistics: while a device buffer of n int32 is registered, gl_track_frames writes the
  * number of Levenberg trials (linearise + solve + evaluate) each frame b < n spent, so that the
  * algorithmic work of a launch can be reported.  NULL / 0 unregisters. */

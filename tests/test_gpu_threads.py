@@ -115,3 +115,66 @@ def test_two_contexts_oversubscribe_the_latency_shape(gpu, map_v1, gt_sync):
         for r in results[name]:
             for x, y in zip(ref, r):
                 assert np.array_equal(x, y, equal_nan=True), name
+
+
+def test_frame_latency_bounded_next_to_local_ba(gpu, map_v1, gt_sync):
+    """The reference runs tracking and the local BA on two threads over one GPU-resident map.  Here a second context keeps
+    launching gl_joint_optimization windows back-to-back (8 + 4 key-frames, 1 500 points: a cooperative launch that holds up
+    to 64 CUs for milliseconds) while this thread calls the frame-at-a-time path (gl_track_frame_host, latency shape) 300
+    times.  A frame whose workgroups cannot meet within ba_rendezvous_us (200 us) falls back to the one-workgroup kernel
+    (~0.5 ms): the worst frame stays far below the reference's 50 ms frame budget - p99 < 2 ms - and every answer is the
+    same bits as on an idle GPU."""
+    import time
+    torch, ctx0 = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx0, mean, cov)
+    frames = make_frames(mean, cov, gt_sync["V1_03_difficult"], cam, 4, 1200, 606, outlier_frac=0.05)
+    prob = make_ba_problem(mean, cov, gt_sync["V1_01_easy"], cam, 8, 4, 1500, 78, True)
+    idx, d2 = g.associate3d(torch.from_numpy(prob["points"]).cuda())
+    a = np.where(d2.cpu().numpy() <= 9.0, idx.cpu().numpy(), -1).astype(np.int32)
+    hp = api.HostFramePath(ctx0, g, cam, prm)
+
+    def one(f):
+        pose, X = f["pose_init"].copy(), f["Xw"].copy()
+        t0 = time.perf_counter()
+        assoc = hp.track_frame(pose, X, f["obs"], f["octave"])
+        return time.perf_counter() - t0, (pose, X, assoc)
+
+    ref = [one(f)[1] for f in frames]
+    for f in frames:  # warm
+        one(f)
+    idle = np.array([one(frames[i % 4])[0] for i in range(100)])
+    stop, errors, windows = threading.Event(), [], [0]
+
+    def ba_main():
+        try:
+            ctx = gmmloc_amd.Context(0)
+            while not stop.is_set():
+                run_gpu((torch, ctx), g, cam, prm, [prob], [a])
+                windows[0] += 1
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    t = threading.Thread(target=ba_main)
+    t.start()
+    while windows[0] < 2 and t.is_alive():
+        time.sleep(0.01)
+    ctx0.counter_read(0)
+    lat = []
+    for i in range(300):
+        dt, res = one(frames[i % 4])
+        lat.append(dt)
+        for x, y in zip(ref[i % 4], res):
+            assert np.array_equal(x, y), i
+    redone = ctx0.counter_read(0)
+    w = windows[0]
+    stop.set()
+    t.join(timeout=120)
+    assert not errors and not t.is_alive(), errors
+    lat = np.sort(np.array(lat)) * 1e3
+    print("frame latency ms: idle median %.3f | next to %d BA windows: median %.3f p99 %.3f max %.3f, %d of 300 frames redone by the follow-up kernel"
+          % (1e3 * np.median(idle), w, np.median(lat), lat[int(0.99 * len(lat))], lat[-1], redone))
+    assert w >= 3  # the BA thread really ran alongside
+    assert lat[int(0.99 * len(lat))] < 2.0, lat[-10:]

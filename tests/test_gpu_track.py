@@ -208,11 +208,13 @@ def test_track_frames_bit_identical_across_shapes(gpu, map_v1, gt_sync, opt):
 
 
 def test_track_frames_rendezvous_gives_up_cleanly(gpu, map_v1, gt_sync, opt):
-    """The latency shape is launched plainly (a cooperative launch costs 31 us per call): the workgroups of a frame meet
-    in a rendezvous with a time limit, a frame whose workgroups do not all show up writes NOTHING and is redone by the
-    one-workgroup kernel that follows.  With the limit at 0 (every workgroup that does not find all its siblings' words
-    at its first look gives up) most frames take that path: the results must be the same bits, and the inputs of a frame
-    that gave up must have been left alone for the follow-up."""
+    """The latency shape is launched plainly (a cooperative launch costs 31 us per call): every exchange between the
+    workgroups of a frame has a time limit, the workgroups write to a staging area, and the one-workgroup kernel that
+    always follows copies the staged result of a complete frame and recomputes the others from the untouched inputs.
+    With the limit at 0 (a workgroup that does not find all its siblings' words at its first look gives up) most frames
+    take the recompute path at the rendezvous; with ba_test_abort_seq = n the last workgroup of EVERY frame gives up at its
+    n-th exchange - in the middle of the schedule, after thousands of LDS updates, or at the very last reduction while its
+    siblings have already staged their share.  The caller must get the same bits every time."""
     torch, ctx = gpu
     mean, cov = map_v1
     cam, prm = api.Camera(), api.Params()
@@ -222,12 +224,40 @@ def test_track_frames_rendezvous_gives_up_cleanly(gpu, map_v1, gt_sync, opt):
         opt("ba_shape", 0)
         ref = _run_track(torch, ctx, g, cam, prm, frames)
         opt("ba_shape", 1)
-        for limit_us in (0, 50000):
+        ctx.counter_read(0)
+        res = _run_track(torch, ctx, g, cam, prm, frames)
+        assert ctx.counter_read(0) == 0  # an undisturbed launch completes on the latency shape
+        for a, b, what in zip(ref, res, ("pose", "points", "assoc", "chi2")):
+            assert np.array_equal(a, b, equal_nan=True), (M, B, what)
+        for limit_us, abort_seq in ((0, 0), (200, 1), (200, 2), (200, 9), (200, 40), (50000, 0)):
             opt("ba_rendezvous_us", limit_us)
+            opt("ba_test_abort_seq", abort_seq)
             for _ in range(3):  # the outcome of the rendezvous at limit 0 varies from launch to launch
                 res = _run_track(torch, ctx, g, cam, prm, frames)
                 for a, b, what in zip(ref, res, ("pose", "points", "assoc", "chi2")):
-                    assert np.array_equal(a, b, equal_nan=True), (M, B, limit_us, what)
+                    assert np.array_equal(a, b, equal_nan=True), (M, B, limit_us, abort_seq, what)
+            redone = ctx.counter_read(0)
+            if abort_seq:
+                assert redone == 3 * B  # every frame gave up and was recomputed by the follow-up kernel
+            elif limit_us == 50000:
+                assert redone == 0
+        opt("ba_rendezvous_us", 200)
+        opt("ba_test_abort_seq", 0)
+    # the last exchange of a frame: find it (the trial count is data dependent) and abort exactly there
+    frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, 1, 1000, 4000, outlier_frac=0.05)
+    opt("ba_shape", 0)
+    ref = _run_track(torch, ctx, g, cam, prm, frames)
+    opt("ba_shape", 1)
+    last = None
+    for seq in range(60, 220):
+        opt("ba_test_abort_seq", seq)
+        res = _run_track(torch, ctx, g, cam, prm, frames)
+        for a, b, what in zip(ref, res, ("pose", "points", "assoc", "chi2")):
+            assert np.array_equal(a, b, equal_nan=True), (seq, what)
+        if ctx.counter_read(0) == 0:  # the schedule has fewer exchanges than `seq`: the abort never fired
+            last = seq - 1
+            break
+    assert last is not None and last >= 60
 
 
 def test_track_frames_result_independent_of_batch(gpu, map_v1, gt_sync, opt):
