@@ -531,6 +531,12 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
     double R1[9], t1[3], R2[9], t2[3];
     load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
     load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
+    // Software-pipelined variant (-DGL_BAGEN_PIPE, round 3: the indices and the three records of entry e + step are
+    // requested while entry e is worked on) measured against this loop on one box (tools/ab_gen.sh, profiles/r3_bagen_ab.txt):
+    // 20 + 8 key-frames 6.51 -> 6.41 ms, 256-problem batches 0.113 -> 0.107 ms per problem, but 8 + 4 key-frames
+    // 2.89 -> 3.53 ms and 12 + 4 4.70 -> 5.57 ms - there 2 waves share a block, a lane has 8 entries, and the 33 live
+    // prefetch registers take the kernel from 337 to 536 spilled VGPRs.  Not the default.
+#ifndef GL_BAGEN_PIPE
     for (int e = G.pl_ptr[j1] + sub * 64 + lane; act && e < G.pl_ptr[j1 + 1]; e += 64 * W) {
       // (partner, observation and point come from position-indexed tables in one round of loads; the level flags
       // are folded into the partner table when they change)
@@ -541,8 +547,52 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
       const double* l1 = G.lin + (size_t)o1 * 12;
       const double* l2 = G.lin + (size_t)o2 * 12;
       const double* pw = G.ptw + (size_t)l * 12;
-      // (reading the three records into local arrays first - the way to software-pipeline this loop - changes the
-      // compiler's contraction of the block products, i.e. the last bits of the validated build: measured, not done)
+  #else
+    // Software pipeline (round 3): the indices of entry e + step {partner, observation, point} and then its three records
+    // are requested while entry e is being worked on - an entry cost two DEPENDENT L2 round trips (index -> record) in front
+    // of ~500 instructions, 33 times in sequence per lane at 20 poses, on a workgroup with one wave per SIMD.
+    const int e_end = act ? G.pl_ptr[j1 + 1] : 0, e_step = 64 * W;
+    int e = G.pl_ptr[j1] + sub * 64 + lane;
+    int n_o2 = -1, n_o1 = 0, n_l = 0;
+    if (e < e_end) {
+      n_o2 = G.plm[(size_t)e * P + j2];
+      n_o1 = G.pl_obs[e];
+      n_l = G.pl_pt[e];
+    }
+    double nl1[12], nl2[12], npw[9];
+    {
+      const int o2c = max(n_o2, 0);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) nl1[i] = G.lin[(size_t)n_o1 * 12 + i];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) nl2[i] = G.lin[(size_t)o2c * 12 + i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) npw[i] = G.ptw[(size_t)n_l * 12 + i];
+    }
+    for (; e < e_end; e += e_step) {
+      const int o2 = n_o2;
+      double l1[12], l2[12], pw[9];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) l1[i] = nl1[i];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) l2[i] = nl2[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pw[i] = npw[i];
+      {  // next entry: indices now, records as soon as they are there (both rounds overlap this entry's arithmetic)
+        const int en = min(e + e_step, e_end - 1);  // (one past the end: re-reads a valid entry)
+        n_o2 = (e + e_step < e_end) ? G.plm[(size_t)en * P + j2] : -1;
+        n_o1 = G.pl_obs[en];
+        n_l = G.pl_pt[en];
+        const int o2c = max(n_o2, 0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) nl1[i] = G.lin[(size_t)n_o1 * 12 + i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) nl2[i] = G.lin[(size_t)o2c * 12 + i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) npw[i] = G.ptw[(size_t)n_l * 12 + i];
+      }
+      if (o2 < 0) continue;
+#endif
       double A1[9], A2[9], Dv[9];
       sym_to_full(l1 + 3, A1);
       sym_to_full(l2 + 3, A2);
@@ -695,6 +745,54 @@ GL_DEV void ldlt_diag_block(SP S, int ld, int base, double* idg, double* yv, int
     for (int c = 0; c <= r; ++c) S[(size_t)(base + r) * ld + base + c] = a[r][c];
   }
 }
+// The same on a WAVE (round 3): lane r < 6 holds row r of the block; per pivot the pivot, the pivot row's y and the
+// column's elements of the rows below travel as v_readlane broadcasts and every row updates its own elements - 6 x
+// (a division + a handful of dependent operations) on the critical path instead of the ~350 sequential double-precision
+// instructions of the one-thread version (2.8 k cycles per pose block, a third of the factorisation at 20 poses).
+GL_DEV double readlane_f64(double v, int lane) {
+  union {
+    double d;
+    int i[2];
+  } u, w;
+  u.d = v;
+  w.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  w.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return w.d;
+}
+template <class SP>
+GL_DEV void ldlt_diag_block_wave(SP S, int ld, int base, double* idg, double* yv, int* s_flag) {
+  const int lane = threadIdx.x & 63, rr = min(lane, 5);
+  double a[6], id[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) a[c] = c <= rr ? S[(size_t)(base + rr) * ld + base + c] : 0.0;
+  double y = yv[base + rr];
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double d = readlane_f64(a[c], c);
+    bad = bad || d == 0.0 || !isfinite(d);
+    id[c] = 1.0 / d;
+    const double yc = readlane_f64(y, c);
+    const double ci = a[c] * id[c];
+#pragma unroll
+    for (int j = c + 1; j < 6; ++j) {
+      const double ajc = readlane_f64(a[c], j);  // a[j][c]
+      if (rr >= j) a[j] -= ci * ajc;
+    }
+    if (rr > c) y = __builtin_fma(-ci, yc, y);
+  }
+  if (lane < 6) {
+    yv[base + lane] = y;
+    if (lane == 0) {  // (the reciprocal pivots are wave-uniform)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) idg[base + c] = id[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      if (c <= lane) S[(size_t)(base + lane) * ld + base + c] = a[c];
+  }
+  if (lane == 0 && bad) *s_flag = 0;
+}
 // panel: the block's six columns of row i (one thread per row), and the row's part of the forward substitution
 template <class SP>
 GL_DEV void ldlt_panel_row(SP S, int ld, int base, int i, const double* idg, double* yv) {
@@ -800,7 +898,11 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       }
     }
     __syncthreads();
+#ifdef GL_BAGEN_NO_WAVEDIAG
     if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
+#else
+    if (tid < 64) ldlt_diag_block_wave(S, ld, base, idg, yv, s_flag);
+#endif
     __syncthreads();
     GP_T(q1);
     if (m0 + tid < n) ldlt_panel_row(S, ld, base, m0 + tid, idg, yv);
