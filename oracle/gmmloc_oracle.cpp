@@ -18,6 +18,7 @@
 // HIP kernels (bit-exact index parity).
 // ============================================================================
 #include <cmath>
+#include <functional>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -426,6 +427,12 @@ int optimize_triangulation(OGmm& g, double* x3d, const SE3& T1, const double* uv
     if (comps1[i] >= 0) push(comps1[i]);
   for (int i = 0; i < n2; ++i)
     if (comps2[i] >= 0) push(comps2[i]);
+  switch (og::switches().tri_order) {  // the reference walks an unordered_set<GaussianComponent*>: any order is "the" order
+    case 1: std::reverse(cand.begin(), cand.end()); break;
+    case 2: std::sort(cand.begin(), cand.end()); break;
+    case 3: std::sort(cand.begin(), cand.end(), std::greater<int>()); break;
+    default: break;
+  }
 
   Edge* edge_str = nullptr;
   int min_comp = -1;
@@ -1141,6 +1148,15 @@ int orc_joint_optimization_stop(void* h, const orc_camera* cam, const orc_params
   BAProblem pb{P, F, L, nobs, poses, has_prior, points, assoc, obs_ptr, obs_pose, obs_uvr, obs_octave, assoc_dropped, obs_erase};
   const bool set = stop_value > 0;
   return joint_optimization(*g, pb, to_cam(cam), to_prm(prm), set ? &set : nullptr, stop_value < 0 ? -stop_value : -1);
+}
+
+// switches of the oracle's declared deviations (og_math.hpp): which = 0 ldlt, 1 eig, 2 lambda_break, 3 tri_order
+void orc_set_switch(int which, int value) {
+  og::Switches& w = og::switches();
+  if (which == 0) w.ldlt = value;
+  else if (which == 1) w.eig = value;
+  else if (which == 2) w.lambda_break = value;
+  else if (which == 3) w.tri_order = value;
 }
 
 // SE3 helpers exposed for tests

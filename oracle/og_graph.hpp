@@ -757,6 +757,7 @@ struct Optimizer {
         currentLambda *= ni;
         ni *= 2;
         pop();
+        if (switches().lambda_break && !std::isfinite(currentLambda)) break;  // newer g2o: `if (!g2o_isfinite(_currentLambda)) break;`
       }
       qmax++;
     } while (rho < 0 && qmax < maxTrials && !terminate());

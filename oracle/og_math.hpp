@@ -21,6 +21,27 @@ namespace og {
 
 // ---- 3x3 (row-major double[9]) ---------------------------------------------
 // Eigen::Matrix3d::determinant(): bruteforce_det3_helper (Eigen/src/LU/Determinant.h)
+// ---- switches for the oracle's DECLARED deviations from Eigen / g2o internals (tests/test_oracle_switches.py) ----------
+// The reference's arithmetic lives in un-vendored Eigen / g2o, so four choices of this restatement cannot be
+// pinned against the real code.  Each has an alternative here that is at least as close to the library it stands in for;
+// the CPU test runs every golden problem and 200 soak problems under each alternative and requires the same decisions
+// and poses within 1e-9 - it does not pin g2o, it shows the results do not hang on what could not be pinned.
+//   ldlt   0: un-pivoted LDL^T (default)   1: diagonal pivoting, largest |d_ii| first (Eigen::LDLT, what
+//          g2o::LinearSolverDense runs)     2: a static symmetric permutation (reversed elimination order: a stand-in for
+//          the fill-reducing ordering of Eigen::SimplicialLDLT, what g2o::LinearSolverEigen runs)
+//   eig    0: cyclic Jacobi (default)      1: Householder tridiagonalisation + implicit QL (the algorithm family of
+//          Eigen::SelfAdjointEigenSolver::compute)
+//   lambda_break  1: `if (!g2o_isfinite(_currentLambda)) break;` after a rejected Levenberg trial (newer g2o)
+//   tri_order     order in which optimizeTriangulationVec walks its candidate set (the reference iterates an
+//          unordered_set of pointers, localization_opt.cpp:144-158): 0 insertion, 1 reversed, 2 ascending / 3 descending index
+struct Switches {
+  int ldlt = 0, eig = 0, lambda_break = 0, tri_order = 0;
+};
+inline Switches& switches() {
+  static Switches s;
+  return s;
+}
+
 inline double det3(const double* m) {
   auto h = [&](int a, int b, int c) {
     return m[0 * 3 + a] * (m[1 * 3 + b] * m[2 * 3 + c] - m[1 * 3 + c] * m[2 * 3 + b]);
@@ -79,7 +100,7 @@ inline void transpose(const double* A, double* At, int r, int c) {
 // to rounding and the vectors up to sign -- only thresholds on the values and
 // n n^T / |n.v| of the vectors are consumed downstream.
 // Output: w ascending, V column c = eigenvector c (V row-major n x n).
-inline void eig_sym(const double* Ain, int n, double* w, double* V) {
+inline void eig_sym_jacobi(const double* Ain, int n, double* w, double* V) {
   double A[9];
   for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
   // symmetrise exactly like a SelfAdjointView reads the lower triangle
@@ -132,6 +153,132 @@ inline void eig_sym(const double* Ain, int n, double* w, double* V) {
   }
 }
 
+
+// The same by Householder tridiagonalisation + implicit-shift QL iteration (EISPACK tred2 / tql2; the algorithm family
+// of Eigen's SelfAdjointEigenSolver::compute: tridiagonalise, then shifted QR/QL sweeps).  Output as eig_sym_jacobi.
+inline void eig_sym_ql(const double* Ain, int n, double* w, double* V) {
+  double a[3][3], d[3], e[3];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) a[i][j] = (j <= i) ? Ain[i * n + j] : Ain[j * n + i];  // lower triangle, like a SelfAdjointView
+  // tred2
+  for (int i = n - 1; i > 0; --i) {
+    const int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(a[i][k]);
+      if (scale == 0.0) {
+        e[i] = a[i][l];
+      } else {
+        for (int k = 0; k <= l; ++k) {
+          a[i][k] /= scale;
+          h += a[i][k] * a[i][k];
+        }
+        double f = a[i][l];
+        const double g = (f >= 0.0 ? -std::sqrt(h) : std::sqrt(h));
+        e[i] = scale * g;
+        h -= f * g;
+        a[i][l] = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          a[j][i] = a[i][j] / h;
+          double gg = 0.0;
+          for (int k = 0; k <= j; ++k) gg += a[j][k] * a[i][k];
+          for (int k = j + 1; k <= l; ++k) gg += a[k][j] * a[i][k];
+          e[j] = gg / h;
+          f += e[j] * a[i][j];
+        }
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = a[i][j];
+          const double gg = e[j] - hh * f;
+          e[j] = gg;
+          for (int k = 0; k <= j; ++k) a[j][k] -= (f * e[k] + gg * a[i][k]);
+        }
+      }
+    } else {
+      e[i] = a[i][l];
+    }
+    d[i] = h;
+  }
+  d[0] = 0.0;
+  e[0] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += a[i][k] * a[k][j];
+        for (int k = 0; k <= l; ++k) a[k][j] -= g * a[k][i];
+      }
+    }
+    d[i] = a[i][i];
+    a[i][i] = 1.0;
+    for (int j = 0; j <= l; ++j) a[j][i] = a[i][j] = 0.0;
+  }
+  // tql2
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (m != l) {
+        if (++iter > 60) break;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double sn = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = sn * e[i];
+          const double b = c * e[i];
+          e[i + 1] = (r = std::hypot(f, g));
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          sn = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * sn + 2.0 * c * b;
+          d[i + 1] = g + (p = sn * r);
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = a[k][i + 1];
+            a[k][i + 1] = sn * a[k][i] + c * f;
+            a[k][i] = c * a[k][i] - sn * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  for (int i = 0; i < n; ++i) {
+    w[i] = d[i];
+    for (int k = 0; k < n; ++k) V[k * n + i] = a[k][i];
+  }
+  for (int i = 0; i < n - 1; ++i) {  // ascending
+    int m = i;
+    for (int j = i + 1; j < n; ++j)
+      if (w[j] < w[m]) m = j;
+    if (m != i) {
+      std::swap(w[i], w[m]);
+      for (int k = 0; k < n; ++k) std::swap(V[k * n + i], V[k * n + m]);
+    }
+  }
+}
+inline void eig_sym(const double* Ain, int n, double* w, double* V) {
+  if (switches().eig == 1) eig_sym_ql(Ain, n, w, V);
+  else eig_sym_jacobi(Ain, n, w, V);
+}
+
 // Lower Cholesky factor of the SPD 3x3 A (reads the lower triangle), as
 // Eigen::LLT<Matrix3d>::matrixL() (unblocked, column by column).
 inline bool chol3_lower(const double* A, double* L) {
@@ -154,7 +301,7 @@ inline bool chol3_lower(const double* A, double* L) {
 // Dense symmetric solve H x = b (n <= 192) by LDL^T without pivoting.
 // g2o: LinearSolverDense = Eigen::LDLT + isPositive(); LinearSolverEigen =
 // SimplicialLDLT.  `require_positive` mirrors the isPositive() check.
-inline bool ldlt_solve(const double* H, const double* b, double* x, int n, bool require_positive) {
+inline bool ldlt_solve_plain(const double* H, const double* b, double* x, int n, bool require_positive) {
   std::vector<double> Ls((size_t)n * n, 0.0), D(n, 0.0), y(n, 0.0);
   double* L = Ls.data();
   for (int j = 0; j < n; ++j) {
@@ -182,6 +329,68 @@ inline bool ldlt_solve(const double* H, const double* b, double* x, int n, bool 
     x[i] = s;
   }
   return true;
+}
+
+
+// H x = b through P H P^T = L D L^T with a symmetric permutation: `dynamic` picks the largest remaining |diagonal| at
+// every step (Eigen::LDLT), otherwise `perm0` is applied up front (any elimination order: SimplicialLDLT's ordering is one).
+inline bool ldlt_solve_perm(const double* H, const double* b, double* x, int n, bool require_positive, bool dynamic, const int* perm0) {
+  std::vector<double> A((size_t)n * n), bb(n), D(n), y(n), z(n);
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; ++i) perm[i] = perm0 ? perm0[i] : i;
+  for (int i = 0; i < n; ++i) {
+    bb[i] = b[perm[i]];
+    for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = H[(size_t)perm[i] * n + perm[j]];
+  }
+  std::vector<double> L((size_t)n * n, 0.0);
+  for (int k = 0; k < n; ++k) {
+    if (dynamic) {  // the trailing matrix A[k:, k:] is kept explicitly (right-looking), pivot = its largest |diagonal|
+      int m = k;
+      for (int i = k + 1; i < n; ++i)
+        if (std::fabs(A[(size_t)i * n + i]) > std::fabs(A[(size_t)m * n + m])) m = i;
+      if (m != k) {
+        for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)m * n + j]);
+        for (int i = 0; i < n; ++i) std::swap(A[(size_t)i * n + k], A[(size_t)i * n + m]);
+        for (int j = 0; j < k; ++j) std::swap(L[(size_t)k * n + j], L[(size_t)m * n + j]);
+        std::swap(bb[k], bb[m]);
+        std::swap(perm[k], perm[m]);
+      }
+    }
+    const double d = A[(size_t)k * n + k];
+    if (d == 0.0 || !std::isfinite(d)) return false;
+    if (require_positive && !(d > 0.0)) return false;
+    D[k] = d;
+    L[(size_t)k * n + k] = 1.0;
+    for (int i = k + 1; i < n; ++i) L[(size_t)i * n + k] = A[(size_t)i * n + k] / d;
+    for (int i = k + 1; i < n; ++i)
+      for (int j = k + 1; j <= i; ++j) {
+        A[(size_t)i * n + j] -= L[(size_t)i * n + k] * d * L[(size_t)j * n + k];
+        A[(size_t)j * n + i] = A[(size_t)i * n + j];
+      }
+  }
+  for (int i = 0; i < n; ++i) {
+    double s = bb[i];
+    for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * y[k];
+    y[i] = s;
+  }
+  for (int i = 0; i < n; ++i) y[i] /= D[i];
+  for (int i = n - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * z[k];
+    z[i] = s;
+  }
+  for (int i = 0; i < n; ++i) x[perm[i]] = z[i];
+  return true;
+}
+inline bool ldlt_solve(const double* H, const double* b, double* x, int n, bool require_positive) {
+  const int mode = switches().ldlt;
+  if (mode == 1) return ldlt_solve_perm(H, b, x, n, require_positive, true, nullptr);
+  if (mode == 2) {
+    std::vector<int> rev(n);
+    for (int i = 0; i < n; ++i) rev[i] = n - 1 - i;
+    return ldlt_solve_perm(H, b, x, n, require_positive, false, rev.data());
+  }
+  return ldlt_solve_plain(H, b, x, n, require_positive);
 }
 
 // ---- quaternion (Eigen coeff order x,y,z,w) --------------------------------
