@@ -294,6 +294,7 @@ def main():
 
     with torch.cuda.stream(ctx.stream):
         dt = launch.timed_steps(step, args.steps, args.warmup, ranks, before_timed=start_timers)
+    n_trials = float(trials.sum().item())  # (of the last timed step; the legs below reuse the buffer)
     assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
     prep_ms, prep_n = ctx.timing_read(api.TIMER_BA_PREP)
@@ -308,7 +309,34 @@ def main():
         dt_sweep = launch.timed_steps(step, sweep_steps, 1, ranks) / sweep_steps
     ctx.set_option("assoc_grid", grid_before)
 
-    # outside the timed region: the plain N x K sweep on the same points (its roofline record), and
+    # outside the timed region: (a) the refine on the 1 000-point LDS class - the first 1 000 points of every frame; real
+    # tracking frames have <= 1 200 features (cfg/v1.yaml:24) and two such frames share a CU, so the serial 6 x 6 solve of one
+    # overlaps the passes of the other - and (b) the anchored step (gl_track_frames_anchored: prior edge on every pose)
+    def refine_leg(M, prior):
+        x0, ob, oc = Xw0[:, :M].contiguous(), obs[:, :M].contiguous(), octv[:, :M].contiguous()
+        p, x = pose0.clone(), x0.clone()
+        pr = torch.ones(B, dtype=torch.uint8, device=dev) if prior else None
+
+        def st():
+            p.copy_(pose0)
+            x.copy_(x0)
+            if prior:
+                return gmmloc_amd.track_frames_anchored(ctx, gmm, cam, prm, p, x, ob, oc, prior=pr, want_d2=False)
+            return gmmloc_amd.track_frames(ctx, gmm, cam, prm, p, x, ob, oc, want_d2=False)
+        nst = max(2, args.steps // 4)
+        with torch.cuda.stream(ctx.stream):
+            t = launch.timed_steps(st, nst, 1, ranks, before_timed=start_timers)
+        ms, nn = ctx.timing_read(api.TIMER_BA)
+        ctx.timing(False)
+        ntr = float(trials.sum().item())
+        ks = ms / 1e3 / max(nn, 1)
+        tf = FLOP_PER_POINT_TRIAL * M * ntr / ks / 1e12 if nn else None
+        return {"value": B * world * nst / t, "unit": "frames/s", "points_per_frame": M, "steps": nst, "refine_avg_launch_ms": 1e3 * ks,
+                "trials_per_frame": ntr / B, "refine_TFLOPs": tf, "refine_frac_of_fp64_valu_peak": tf / PEAK_FP64_VALU_TFLOPS if tf else None}
+    leg_1000 = refine_leg(1000, False)
+    leg_prior = refine_leg(N_PTS, True)
+
+    # the plain N x K sweep on the same points (its roofline record), and
     # the number of chi2 evaluations the cell index needed for them
     sweep_ms = None
     idx_pairs = None
@@ -367,7 +395,6 @@ def main():
         # algorithmic HBM bytes of one association launch: points in, records in, idx+d2 out
         alg_bytes = B * N_PTS * 24 + K_GAUSS * 96 + B * N_PTS * 12
         info = gmm.index_info()
-        n_trials = float(trials.sum().item())
         ba_s = ba_ms / 1e3 / max(ba_n, 1)
         ba_flop = FLOP_PER_POINT_TRIAL * N_PTS * n_trials
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
@@ -442,6 +469,12 @@ def main():
             "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine_setup": prep_ms / max(args.steps, 1),
                                    "refine": ba_ms / max(args.steps, 1)},
         }
+        leg_1000["what"] = ("the same step on the first 1000 points of every frame: the 1000-point LDS class of the refine (2 frames per CU; "
+                            "tracking frames have <= 1200 features, cfg/v1.yaml:24); MAX over ranks")
+        out["roofline"]["class_1000"] = leg_1000
+        leg_prior["what"] = ("the same step through gl_track_frames_anchored with the prior edge (EdgeSE3QuatPrior, sigma 2 deg / 1 cm) on every "
+                             "frame's pose: the gauge anchor the reference's structure BA always has (localization_opt.cpp:556-581)")
+        out["step_anchored_prior"] = leg_prior
         out["step_with_exhaustive_sweep"] = {
             "value": B * world / dt_sweep, "unit": "frames/s", "ms_per_step": 1e3 * dt_sweep, "steps": sweep_steps,
             "what": "the same step with GL_ASSOC_EXHAUSTIVE-style association (all 2000 x 4096 pairs per frame swept, option "

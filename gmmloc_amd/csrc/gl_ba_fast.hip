@@ -227,8 +227,8 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 
-#define GL_BAF_NS bafd1000p  // 
-#define GL_BAF_MCAP 1000
+#define GL_BAF_NS bafd1000p  // (992 points: two frames per CU with the 512 bytes of the prior edge's records)
+#define GL_BAF_MCAP 992
 #define GL_BAF_NW 4
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
@@ -342,11 +342,12 @@ struct BafArgs {
 // one workgroup of G waves per frame; LDS class by stride (4 / 2 / 1 frames per CU)
 static int launch_dense(Ctx* c, BafArgs& a) {
   const bool s32 = c->opt.ba_step32 != 0 && !a.prior;  // (the anchored instances exist with the exact step only)
-  const int cap = s32 ? 2000 : (a.L <= 496 ? 496 : a.L <= 1000 ? 1000 : 2000);
+  const int mid = a.prior ? 992 : 1000;                // (the anchored middle class gives 8 points for the prior edge's LDS records)
+  const int cap = s32 ? 2000 : (a.L <= 496 ? 496 : a.L <= mid ? mid : 2000);
   const BafKernel kern = s32 ? bafd2000s32::k_ba1_fast
-                         : a.prior ? (cap == 496 ? bafd496p::k_ba1_fast : cap == 1000 ? bafd1000p::k_ba1_fast : bafd2000p::k_ba1_fast)
+                         : a.prior ? (cap == 496 ? bafd496p::k_ba1_fast : cap == 992 ? bafd1000p::k_ba1_fast : bafd2000p::k_ba1_fast)
                                    : (cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast);
-  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap == 1000 ? 4 : 8) * 32 + 64 + 40) * sizeof(double);
+  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap <= 1000 ? 4 : 8) * 32 + 64 + 40 + (a.prior ? 64 + (cap == 496 ? 108 : 0) : 0)) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;
@@ -366,7 +367,7 @@ static int launch_dense(Ctx* c, BafArgs& a) {
 // which kernel answered.  Returns 1 when the shape does not fit the device at all (the caller goes DENSE).
 static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   const BafKernel kern = a.prior ? bafsp::k_ba1_fast : c->opt.ba_step32 != 0 ? bafs32::k_ba1_fast : bafs::k_ba1_fast;
-  const size_t lds = (size_t)(10 * 256 + 1 * 32 + 64 + 40 + 29 * 256) * sizeof(double);
+  const size_t lds = (size_t)(10 * 256 + 1 * 32 + 64 + 40 + (a.prior ? 64 : 0) + 29 * 256) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = a.G;
   {  // all the workgroups of the launch must fit the device at once (the occupancy answer is cached per context)

@@ -434,10 +434,23 @@ GL_DEV void point_solve_fast(const Lin& o, double lambda, double* Dinv, double* 
 // loc::ba_first_as_prior, else the pose vertex is fixed (:578-580).  The inverse measurement {R (9), t (3)} is written by
 // k_ba1_prep into the launch's scratch and fetched by the solving wave with scalar loads when it is needed (the LDS of the
 // 1 000-point class has no 96 bytes to spare at two frames per CU, and 24 more live registers would spill in the passes).
+// The edge's linearisation costs ~500 dependent double-precision instructions (log, the 6 x 6 Jacobian J = Jr Adj, J^T Omega J):
+// on the solving wave, between the two passes of every trial, it made the anchored refine 60 % slower than the plain one.
+// It is therefore evaluated at the TRIAL pose during pass B, by one designated wave (the last one; an idle slot wave on the
+// latency shape) next to its points, into the second of two LDS records {H (21, packed upper), b (6), chi2}: the chi2 feeds
+// this trial's accept / reject test, and an accepted trial makes the record the current one, which the next solve only has
+// to add - a rejected trial keeps the old record.  The record of the input pose is made once, at the start of the kernel.
 typedef const double __attribute__((address_space(4))) cdouble_k;
 struct Anchor {
   bool has_prior, pose_fixed;
   const cdouble_k* mi;
+  double* rec;  // LDS: 2 x 32 doubles
+  int cur;      // which record belongs to the current pose
+  double* work; // LDS work area of prior_record_wave (108 doubles, free during pass B and at the start of the kernel)
+  bool rezero;  //   ... borrowed from the group totals: zero it again after use
+  int wave;     // the wave that makes the records: wave 1 of a batch workgroup (on 8-wave frames the waves 0 - 3 finish pass B
+                // ~3 k cycles before 4 - 7, which the issue priority favours less: the edge's ~400 instructions fit that slack);
+                // the last slot wave - idle unless the group has all four chunks - on the latency shape
 };
 // _error = (_inverseMeasurement * Tj).log()   (SE3Quat::log: small-angle branch above |d| = 0.99999)
 GL_DEV void prior_error(const cdouble_k* mi_k, const Pose& P, double* e) {
@@ -455,11 +468,11 @@ GL_DEV void prior_error(const cdouble_k* mi_k, const Pose& P, double* e) {
     for (int i = 0; i < 3; ++i) w[i] = 0.5 * v[i];
     g = 1. / 12.;
   } else {
-    const double theta = acos(d);
-    const double f = theta / (2 * sqrt(1 - d * d));
+    const double theta = acos(d), sn = sqrt(1 - d * d);
+    const double f = theta / (2 * sn);
 #pragma unroll
     for (int i = 0; i < 3; ++i) w[i] = f * v[i];
-    g = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+    g = (1 - theta * (1 + d) / (2 * sn)) / (theta * theta);  // tan(theta / 2) = sin / (1 + cos), theta in (0, pi)
   }
   // upsilon = V^-1 dt,  V^-1 = I - 1/2 [w]x + g [w]x^2  =  dt - 1/2 w x dt + g w x (w x dt)
   double c1[3], c2[3];
@@ -529,6 +542,77 @@ GL_DEV double prior_lin(const cdouble_k* mi, const Pose& P, double* H, double* b
     }
   }
   return prior_chi2(e);
+}
+
+// The edge's record at pose P -> LDS {H (21, packed upper), b (6), chi2}, made by ONE wave and read behind a barrier.
+// The 6 x 6 products run lane-parallel out of an LDS work area (108 doubles: Jr, Adj, J = Jr Adj; lane (i, j) owns one
+// element): evaluated in registers (prior_lin: J[36] and ~120 live values) the edge took the register allocation of the
+// PASS LOOPS from 36 to 181 spilled VGPRs - inlined - or forced everything that lives across a call into the callee-saved
+// registers - as a function - and the whole anchored kernel ran at 0.4 - 0.6 of the plain one (profiles/r3_prior_cost.txt).
+GL_DEV void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+GL_DEV void prior_record_wave(const cdouble_k* mi, const Pose& P, double* rec, double* work, bool rezero) {
+  const int lane = threadIdx.x & 63;
+  double e[6];
+  prior_error(mi, P, e);
+  // staging (static indices, one lane): Ri = R^T -> work[72..80], ti = -R^T t -> work[81..83], e -> work[84..89]
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) work[72 + a * 3 + c] = P.R[c * 3 + a];
+      work[81 + a] = -(P.R[a] * P.t[0] + P.R[3 + a] * P.t[1] + P.R[6 + a] * P.t[2]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) work[84 + a] = e[a];
+  }
+  wave_lds_order();
+  {  // lane (i, j) builds its element of  Jr = I + 1/2 [[phi]x [upsilon]x; 0 [phi]x]  (-> work[0..35])  and of
+     // Adj(T^-1) = [[Ri, 0], [[ti]x Ri, Ri]]  (-> work[36..71]);  [v]x(a, b) = +-v[3 - a - b] off the diagonal
+    const int l0 = min(lane, 35), bi = l0 / 6, bj = l0 - 6 * bi, a3 = bi % 3, b3 = bj % 3;
+    const bool top = bi < 3, left = bj < 3, offd = a3 != b3;
+    const int kx = offd ? 3 - a3 - b3 : 0;
+    const double sgn = ((b3 - a3 + 3) % 3 == 1) ? -0.5 : 0.5;
+    const double sk_phi = offd ? sgn * work[84 + kx] : 0.0, sk_ups = offd ? sgn * work[87 + kx] : 0.0;
+    const double jr = (top == left) ? sk_phi + (offd ? 0.0 : 1.0) : (top ? sk_ups : 0.0);
+    // ([ti]x Ri)(a, c) = ti[a+1] Ri[a+2][c] - ti[a+2] Ri[a+1][c]  (indices mod 3)
+    const int a1 = (a3 + 1) % 3, a2 = (a3 + 2) % 3;
+    const double sr_ac = work[81 + a1] * work[72 + a2 * 3 + b3] - work[81 + a2] * work[72 + a1 * 3 + b3];
+    const double ri_ab = work[72 + a3 * 3 + b3];
+    const double adj = (top == left) ? ri_ab : (top ? 0.0 : sr_ac);
+    wave_lds_order();
+    if (lane < 36) {
+      work[l0] = jr;
+      work[36 + l0] = adj;
+    }
+  }
+  wave_lds_order();
+  const int lc = min(lane, 35), i = lc / 6, j = lc - 6 * i;
+  {  // J = Jr Adj
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < 6; ++l) s = fma(work[i * 6 + l], work[36 + l * 6 + j], s);
+    wave_lds_order();
+    if (lane < 36) work[72 + lc] = s;
+  }
+  wave_lds_order();
+  const double sr = 1.0 / ((2.0 * M_PI / 180.0) * (2.0 * M_PI / 180.0)), st = 1.0 / (0.01 * 0.01);
+  {  // H = J^T Omega J (upper triangle, packed), b = -J^T Omega e
+    double h = 0.0, g = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double w = r < 3 ? sr : st, jri = work[72 + r * 6 + i], jrj = work[72 + r * 6 + j];
+      h = fma(jri * w, jrj, h);
+      g = fma(jrj, w * e[r], g);  // (lanes i == 0: column j)
+    }
+    if (lane < 36 && i <= j) rec[i * 6 - i * (i - 1) / 2 + (j - i)] = h;
+    if (lane < 6) rec[21 + lane] = -g;
+  }
+  if (lane == 0) rec[27] = prior_chi2(e);
+  if (rezero) {  // the work area is borrowed from the group totals, whose rows of absent groups must read 0.0
+    wave_lds_order();
+    work[lane] = 0.0;
+    if (lane < 44) work[64 + lane] = 0.0;
+  }
 }
 
 // The terms of a point enter the sums through a sink: DENSE adds them to the thread's registers (level 1 of the
@@ -1259,7 +1343,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
                          const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
-                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, const Anchor& An) {
+                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, Anchor& An) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -1287,7 +1371,10 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
       if (pose_active) {
-        if (prior_on) prior_lin(An.mi, P, acc, nullptr);
+        if (prior_on) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc[GL_U(i, i)] += An.rec[An.cur * 32 + GL_U(i, i)];
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) md = fmax(md, fabs(acc[GL_U(i, i)]));
       }
@@ -1313,7 +1400,11 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       if (threadIdx.x < 64) {
         double dxs[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
-        if (prior_on) acc[27] += prior_lin(An.mi, P, acc, acc + 21);  // the prior edge: H_pp, b_p and chi2 of the pose block
+        if (prior_on) {  // the prior edge at the current pose: H_pp, b_p and chi2 from its record
+          const double* rc = An.rec + An.cur * 32;
+#pragma unroll
+          for (int i = 0; i < 28; ++i) acc[i] += rc[i];
+        }
         if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -1342,11 +1433,6 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
           for (int i = 0; i < 9; ++i) bc[6 + i] = Pw.R[i];
 #pragma unroll
           for (int i = 0; i < 3; ++i) bc[15 + i] = Pw.t[i];
-          if (prior_on) {  // chi2 of the prior edge at the trial pose (read behind pass B's barrier)
-            double ep[6];
-            prior_error(An.mi, Pw, ep);
-            bc[27] = prior_chi2(ep);
-          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           *pnflag = seq;
         }
@@ -1373,6 +1459,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       });
       GL_BAF_GET_PN();  // (a wave without an active point still takes the pose: P = Pn on acceptance)
 #undef GL_BAF_GET_PN
+      if (prior_on && (int)(threadIdx.x >> 6) == An.wave) prior_record_wave(An.mi, Pn, An.rec + (An.cur ^ 1) * 32, An.work, An.rezero);
       PROF_T(tB1);
       PROF_W(trials, 3);
       if (kSpread) spread_reduce2_all(acc, R, C);
@@ -1381,7 +1468,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
       // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
       double scale = lambda * acc[0] + uni(bc[25]);
-      const double tempChi = ok2 ? (prior_on ? acc[1] + uni(bc[27]) : acc[1]) : 1.7976931348623157e308;
+      const double tempChi = ok2 ? (prior_on ? acc[1] + uni(An.rec[(An.cur ^ 1) * 32 + 27]) : acc[1]) : 1.7976931348623157e308;
       if (pose_active) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) scale += dx[i] * (lambda * dx[i] + uni(bc[19 + i]));
@@ -1397,6 +1484,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         ni = 2;
         currentChi = tempChi;
         P = Pn;
+        if (kPrior) An.cur ^= 1;  // the record made at the trial pose is the current one now
       } else {
         lambda *= ni;
         ni *= 2;
@@ -1440,7 +1528,13 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   R.tot = R.red + NRED * 32;        // 32 (+ 32 broadcast slots)
   D.stab = R.tot + 64;              // 24
   R.red2 = D.stab + 24;             // 16
-  R.tb = R.red2 + 16;               // SPREAD: 29 x TSP
+  double* const prec = R.red2 + 16; // anchored instances: 2 x 32, the prior edge's records
+  // ... and the work area of prior_record_wave: the group totals `red` where they are large enough (4 / 8 groups) - idle
+  // during pass B and before the first reduction -, the transpose rows pass B does not use on the latency shape, 108 doubles
+  // of its own in the small class (which has LDS to spare)
+  constexpr int kPriorWorkOwn = (kPrior && !kSpread && NWC < 4) ? 108 : 0;
+  R.tb = prec + (kPrior ? 64 : 0) + kPriorWorkOwn;  // SPREAD: 29 x TSP
+  double* const pwork = kSpread ? R.tb + 2 * TSP : (NWC >= 4 ? R.red : prec + 64);
   R.S = S;
   FlagW fw = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1528,12 +1622,17 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   Pose P = pose_from_se3(se3_load(pose_io + (size_t)f * 7));
   // vSE3->setFixed(idx_ == 0) or e->setMeasurement(kfi->getTcw()) (:556-581)
   const bool prior_flag = kPrior && prior_all ? prior_all[f] != 0 : false;
-  const Anchor An{prior_flag && k.first_as_prior != 0, prior_flag && k.first_as_prior == 0,
-                  (const cdouble_k*)(prior_mi + (size_t)f * 12)};
+  Anchor An{prior_flag && k.first_as_prior != 0, prior_flag && k.first_as_prior == 0,
+            (const cdouble_k*)(prior_mi + (size_t)f * 12), prec, 0, pwork, !kSpread && NWC >= 4,
+            kSpread ? (int)(blockDim.x >> 6) - 1 : min(1, (int)(blockDim.x >> 6) - 1)};
 #ifndef GL_BAF_NO_PRIO
   if (!kSpread && NWC == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   __syncthreads();
+  if (kPrior && An.has_prior) {  // the record of the input pose (its work area may be the freshly zeroed group totals)
+    if (wave == An.wave) prior_record_wave(An.mi, P, prec, pwork, An.rezero);
+    __syncthreads();
+  }
   if (kSpread && C.NB > 1 && xcc_trusted) {
     // do the frame's workgroups share an XCD?  Every contributing thread adds its XCC id and the id's square (through the
     // device-scope exchange: this is also the launch's rendezvous); they are all equal iff N sum(id^2) == sum(id)^2

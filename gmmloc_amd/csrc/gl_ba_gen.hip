@@ -89,6 +89,7 @@ struct GenP {
   // acted on where g2o tests terminate(): before an outer iteration.  > 0: stop; < 0: a budget of -value outer iterations
   const int32_t* stop;
   int stop_seen, done_iters;
+  int trials;  // Levenberg trials so far (linearise + reduce + solve + evaluate): the unit of the kernel's algorithmic work
 };
 GL_DEV bool stop_now(const GenP& G) { return G.stop_seen > 0 || (G.stop_seen < 0 && G.done_iters >= -G.stop_seen); }
 GL_DEV int stop_word_load(const int32_t* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -1177,6 +1178,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       }
       prob_sync(G);
       qmax++;
+      ++G.trials;
       GP_T(t5);
       GP_ADD(0, t0, t1); GP_ADD(1, t1, t2); GP_ADD(2, t2, t3); GP_ADD(3, t3, t4); GP_ADD(4, t4, t5); GP_ADD(5, 0, 1);
     } while (rho < 0 && qmax < 10 && !(G.stop_seen > 0));  // (g2o's retry loop tests terminate() too)
@@ -1196,7 +1198,8 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
                                                  const int32_t* __restrict__ ooct_all,
                                                  uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
                                                  int32_t* __restrict__ iters_all, char* __restrict__ scratch,
-                                                 size_t scratch_per_problem, int s_in_lds, const int32_t* __restrict__ stop_dev) {
+                                                 size_t scratch_per_problem, int s_in_lds, const int32_t* __restrict__ stop_dev,
+                                                 int32_t* __restrict__ trials_out) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // reduced camera system when it fits
   __shared__ double red[NW_BA * 32 + 128];  // reductions / reciprocal pivots (128) + the right-hand side of the solve (128)
   __shared__ double p2part[NW_BA * 64];  // pass_blocks: sums of the waves that share a block
@@ -1225,6 +1228,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.stop = stop_dev;
   G.stop_seen = 0;
   G.done_iters = 0;
+  G.trials = 0;
   if (stop_dev && G.pb == 0 && tid == 0) G.flagg[1] = stop_word_load(stop_dev);  // (published by the set-up's first barrier)
   // carve the problem's area (doubles first, then ints, then bytes)
   char* s = scratch + (size_t)B * 512 + (size_t)f * scratch_per_problem;
@@ -1401,6 +1405,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
     }
   }
   if (G.pb == 0 && tid == 0 && iters_all) iters_all[f] = it3;
+  if (G.pb == 0 && tid == 0 && trials_out) trials_out[f] = G.trials;
 #ifdef GL_BAGEN_PROF
   if (blockIdx.x == 0 && tid == 0)
     for (int i = 0; i < 12; ++i) G.poses[i] = (double)g_gprof[i];  // debug build: phase cycles instead of poses 0-1
@@ -1466,12 +1471,13 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
     gl::TimerScope ts(c, GL_TIMER_BA);
     GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 512, c->stream));
     BaK kk = make_bak(cam, prm, -1.0);
+    int32_t* stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;  // gl_ctx_set_stats_buffer: trials per problem
     char* scr = (char*)scratch;
     size_t per_v = per;
     if (NB > 1) {
       void* args[] = {&kk, &gm, &B, &NB, &P, &F, &L, &NOBS, &poses_dev, &prior_dev, &points_dev, &assoc_dev, &obs_ptr_dev,
                       &obs_pose_dev, &obs_uvr_dev, &obs_oct_dev, &assoc_dropped_dev, &obs_erase_dev, &iters_dev, &scr, &per_v,
-                      &s_in_lds, &stop_dev};
+                      &s_in_lds, &stop_dev, &stats};
       hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(B * NB), dim3(T_BA), args, lds, c->stream);
       if (e != hipSuccess) {  // not co-resident after all: one workgroup per problem
         (void)hipGetLastError();
@@ -1481,7 +1487,7 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
     if (NB == 1)
       k_ba_gen<<<B, T_BA, lds, c->stream>>>(kk, gm, B, 1, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev,
                                             obs_pose_dev, obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev,
-                                            scr, per_v, s_in_lds, stop_dev);
+                                            scr, per_v, s_in_lds, stop_dev, stats);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

@@ -117,9 +117,9 @@ enum gl_counter {
   GL_COUNTER_COUNT = 4
 };
 int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset);
-/* Optional statistics: while a device buffer of n int32 is registered, gl_track_frames writes the
- * number of Levenberg trials (linearise + solve + evaluate) each frame b < n spent, so that the
- * algorithmic work of a launch can be reported.  NULL / 0 unregisters. */
+/* Optional statistics: while a device buffer of n int32 is registered, gl_track_frames (and gl_track_frames_anchored,
+ * gl_joint_optimization) write the number of Levenberg trials (linearise + solve + evaluate) each frame / problem
+ * b < n spent, so that the algorithmic work of a launch can be reported.  NULL / 0 unregisters. */
 int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n);
 
 /* ---- GMM map: replaces GMMUtility::loadGMMModel (gmm_utils.cpp:9-67),

@@ -9,6 +9,7 @@ from gmmloc_amd import api
 import bench
 NF = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPE = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+PRIOR = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 if len(sys.argv) > 2:
     pass
 mean, cov, cam, frames = bench.make_workload(NF)
@@ -17,7 +18,10 @@ ctx.set_option("ba_shape", SHAPE)
 T = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).cuda()
 pose, Xw, obs, octv = T("pose_init"), T("Xw"), T("obs"), T("octave")
 p2, x2 = pose.clone(), Xw.clone()
-gmmloc_amd.track_frames(ctx, g, cam, prm, p2, x2, obs, octv)
+if PRIOR:
+    gmmloc_amd.track_frames_anchored(ctx, g, cam, prm, p2, x2, obs, octv, prior=torch.ones(NF, dtype=torch.uint8).cuda())
+else:
+    gmmloc_amd.track_frames(ctx, g, cam, prm, p2, x2, obs, octv)
 torch.cuda.synchronize()
 c = p2[0].cpu().numpy()
 names = ["passA", "reduceA", "solve+bcast", "passB", "reduceB", "accept", "trials"]

@@ -196,8 +196,13 @@ def config_ba(torch, ctx, out):
     gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_01_easy"]
     cam, prm = api.Camera(), api.Params()
     g = gmmloc_amd.GMM(ctx, mean, cov, prm)
-    res = {"config": "local BA (jointOptimization), synthetic multi-view problems on v1.gmm"}
-    for (P, F, L, B) in ((8, 4, 1500, 1), (8, 4, 1500, 64), (20, 8, 3000, 1)):
+    res = {"config": "local BA (jointOptimization), synthetic multi-view problems on v1.gmm",
+           "flop_model": "per Levenberg trial: observations x 337 (P1 linearise 225: transform, residual, Huber, w J^T J, R^T A R; P3 112: "
+                         "back-substitution term + error at the trial state) + points x 150 (3x3 inverse, GMM edge, step) + (pose pairs per point, "
+                         "diagonal included) x 324 (G1^T [A1 R1 D^-1 R2^T A2] G2 = 162 FMA) + diagonal pairs x 150 + 2 n^3 / 3 (LDL^T, n = 6 P); "
+                         "level-0 counts (an upper bound after the gating); trials counted by the kernel (gl_ctx_set_stats_buffer)",
+           "peak_TFLOPs": 78.6}
+    for (P, F, L, B) in ((8, 4, 1500, 1), (8, 4, 1500, 64), (8, 4, 1500, 256), (20, 8, 3000, 1)):
         probs = [make_ba_problem(mean, cov, gt, cam, P, F, L, 100 + b) for b in range(min(B, 4))]
         probs = [probs[b % len(probs)] for b in range(B)]
         NOBS = max(len(p["obs_pose"]) for p in probs)
@@ -210,8 +215,23 @@ def config_ba(torch, ctx, out):
         opose = T(np.stack([pad(p["obs_pose"], NOBS) for p in probs]))
         ouvr = T(np.stack([pad(p["obs_uvr"], NOBS) for p in probs]))
         ooct = T(np.stack([pad(p["obs_oct"], NOBS) for p in probs]))
+        trials = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ctx.set_stats_buffer(trials)
         t = ev_time(torch, lambda: api.joint_optimization(ctx, g, cam, prm, P, F, poses0.clone(), prior, pts0.clone(), assoc, optr, opose, ouvr, ooct), 3, ctx.stream)
-        res["P%d_F%d_L%d_B%d" % (P, F, L, B)] = {"ms_per_call": 1e3 * t, "ms_per_problem": 1e3 * t / B, "observations": int(NOBS)}
+        torch.cuda.synchronize()
+        ctx.set_stats_buffer(None)
+        flop = 0.0
+        tr = trials.cpu().numpy()
+        for b in range(B):
+            p = probs[b]
+            nfree = np.array([(p["obs_pose"][p["obs_ptr"][l]:p["obs_ptr"][l + 1]] < P).sum() for l in range(L)])
+            pairs, diag = float((nfree * (nfree + 1) // 2).sum()), float(nfree.sum())
+            per_trial = len(p["obs_pose"]) * 337.0 + L * 150.0 + pairs * 324.0 + diag * 150.0 + 2.0 * (6 * P) ** 3 / 3.0
+            flop += per_trial * float(tr[b])
+        res["P%d_F%d_L%d_B%d" % (P, F, L, B)] = {"ms_per_call": 1e3 * t, "ms_per_problem": 1e3 * t / B, "observations": int(NOBS),
+                                                 "trials_per_problem": float(tr.mean()),
+                                                 "roofline_ba": {"kernel": "k_ba_gen", "bound": "latency (valu_fp64 peak for reference)", "flop_per_launch": flop,
+                                                                 "achieved": flop / t / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flop / t / 1e12 / 78.6}}
     out(res)
 
 
