@@ -1423,6 +1423,816 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
 
 }  // namespace
 
+
+// =====================================================================================================================
+// The PIPELINED shape of the local BA (round 3): the same phases as k_ba_gen - P1 linearise, P2 Schur blocks, solve, P3 trial
+// state, accept / reject - as SEPARATE kernels over the same scratch layout and the same per-element arithmetic (pass_points,
+// pass_trial, gmg, the LDL^T of ldlt_solve_small), driven by a per-problem state word in global memory.
+// Why: the persistent kernel is one register allocation for every phase (512 registers, hundreds spilled, one wave per SIMD:
+// every dependent load of P2 / P3 is exposed), its phases are separated by problem-wide barriers among 16 - 64 co-resident
+// workgroups (10 - 14 % of a trial), and 15 - 63 of them idle while workgroup 0 factorises (a quarter to a third of a trial).
+// Here every phase has its own allocation and its own grid - P2 runs one wave per 256 entries of a block's list, thousands of
+// waves at 20 poses - kernel boundaries replace the barriers, and the factorisation is the only single-workgroup step.
+// The Levenberg control flow is data dependent, so the host enqueues CYCLES of the five kernels ahead of the device
+// (a cycle = one trial; a kernel whose problem has finished, or whose phase does not apply, exits at once) and looks at the
+// device-side count of unfinished problems between chunks of cycles: the call returns with the work complete.
+// Sums are deterministic: per-workgroup / per-chunk partials added in index order, independent of the batch.
+struct PipeSt {  // per problem, in global memory
+  int stage;     // 0, 1, 2: which optimize() of the 5 / 5 / 40 schedule; 3: finished
+  int iters_max; // of this stage
+  int it;        // outer iteration of the stage
+  int qmax;      // trials of the outer iteration so far
+  int cj;        // outer iterations completed in the stage
+  int init;      // 1: the next cycle is the computeLambdaInit pass of the stage (no solve, no trial)
+  int skip;      // 1: this cycle's trial / decide kernels have nothing to do (an init cycle)
+  int any_point, any_pose, ok;
+  int trials, done_iters, stop_seen, it3;
+#ifdef GL_PIPE_PROF
+  long long dbg[8];
+#endif
+  int chunk_len;  // entries of a pose's list per wave of the Schur pass: ceil(longest list / nchunk), a multiple of 64
+  double lambda, ni, currentChi, chiA, rho;
+};
+struct PipeA {  // kernel arguments (by value)
+  BaK k;
+  GmmDev gm;
+  int B, P, F, L, NOBS;
+  double* poses;
+  const uint8_t* prior;
+  double* pts;
+  const int32_t* assoc;
+  const int32_t* optr;
+  const int32_t* opose;
+  const double* ouvr;
+  const int32_t* ooct;
+  uint8_t* dropped;
+  uint8_t* erase;
+  int32_t* iters;
+  int32_t* trials_out;
+  const int32_t* stop;
+  char* scratch;      // | B x 512 B headers | per-problem areas |  (the layout of k_ba_gen)
+  size_t per;
+  PipeSt* st;         // B
+  double* partA;      // B x nba x 2   {robust chi2, max point diagonal} per workgroup of the point pass
+  double* partD;      // B x nba x 2   {scale part, chi2 at the trial state}
+  double* partS;      // B x nblk x nchunk x 48
+  int* unfinished;    // problems not at stage 3
+  int* arrive;        // B x nblk: waves of the Schur pass that have delivered their chunk of a block (back to 0 by the last)
+  int nba, lpp, nblk, nchunk;
+};
+GL_DEV void genp_init(GenP& G, const PipeA& a, int f, int NB, int pb) {
+  const int P = a.P, F = a.F, L = a.L, NOBS = a.NOBS, n = 6 * P;
+  G.NB = NB;
+  G.pb = pb;
+  G.P = P;
+  G.F = F;
+  G.L = L;
+  G.poses = a.poses + (size_t)f * (P + F) * 7;
+  G.prior = a.prior + (size_t)f * P;
+  G.pts = a.pts + (size_t)f * L * 3;
+  G.assoc = a.assoc + (size_t)f * L;
+  G.optr = a.optr + (size_t)f * (L + 1);
+  G.opose = a.opose + (size_t)f * NOBS;
+  G.ouvr = a.ouvr + (size_t)f * NOBS * 3;
+  G.ooct = a.ooct + (size_t)f * NOBS;
+  G.nobs = G.optr[L];
+  G.bar = (unsigned*)(a.scratch + (size_t)f * 512);
+  G.flagg = (int*)(G.bar + 64);
+  G.stop = a.stop;
+  G.stop_seen = 0;
+  G.done_iters = 0;
+  G.trials = 0;
+  char* s = a.scratch + (size_t)a.B * 512 + (size_t)f * a.per;
+  auto takeD = [&](size_t cnt) {
+    double* p = (double*)s;
+    s += cnt * 8;
+    return p;
+  };
+  G.Rt = takeD((size_t)(P + F) * 12);
+  G.RtN = takeD((size_t)P * 12);
+  G.qN = takeD((size_t)P * 7);
+  G.pinv = takeD((size_t)P * 7);
+  G.pn = takeD((size_t)L * 3);
+  G.lin = takeD((size_t)NOBS * 12);
+  G.ptw = takeD((size_t)L * 12);
+  G.chi_o = takeD((size_t)NOBS);
+  G.ld = n + GL_LD_PAD;
+  G.S = takeD((size_t)n * G.ld);
+  G.part = takeD((size_t)2 * 64 * 4);
+  G.toggle = 0;
+  G.epoch = 0u;
+  G.gv = takeD(n);
+  G.bp = takeD(n);
+  G.dxv = takeD(n);
+  G.pchi = takeD(P);
+  G.pchi2 = takeD(P);
+  G.prH = takeD((size_t)P * 36);
+  G.prb = takeD((size_t)P * 6);
+  auto takeI = [&](size_t cnt) {
+    int32_t* p = (int32_t*)s;
+    s += ((cnt * 4 + 7) / 8) * 8;
+    return p;
+  };
+  G.opoint = takeI(NOBS);
+  G.pl_ptr = takeI(P + 1);
+  G.pl_obs = takeI(NOBS);
+  G.pl_pos = takeI(NOBS);
+  G.pl_pt = takeI(NOBS);
+  G.plm = takeI((size_t)NOBS * P);
+  auto takeB = [&](size_t cnt) {
+    uint8_t* p = (uint8_t*)s;
+    s += ((cnt + 7) / 8) * 8;
+    return p;
+  };
+  G.lev_o = takeB(NOBS);
+  G.lev_g = takeB(L);
+  G.pfree = takeB(P + F);
+  G.pact = takeB(P);
+  G.lact = takeB(L);
+}
+
+// initializeOptimization(0) of a stage + the prior edges at the current state, by ONE workgroup (the problem's state
+// kernels): active poses / points; returns through st->any_point / any_pose
+GL_DEV void pipe_census(const BaK& k, GenP& G, PipeSt* st, int* s_cnt) {
+  // (walked by observation, coalesced, with same-value stores - a thread per point with a loop over its observations costs a
+  // dependent load per observation on one workgroup: 100+ us at 58 000 observations)
+  const int P = G.P, tid = threadIdx.x, nobs = G.nobs, NT = blockDim.x;
+  for (int j = tid; j < P; j += NT) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
+  for (int l = tid; l < G.L; l += NT) G.lact[l] = (G.assoc[l] >= 0 && !G.lev_g[l]) ? 1 : 0;
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  for (int o0 = tid * 4; o0 < nobs; o0 += NT * 4) {  // four observations per step: their loads go out together
+    int lv[4], l[4], j[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oc = min(o0 + q, nobs - 1);
+      lv[q] = G.lev_o[oc];
+      l[q] = G.opoint[oc];
+      j[q] = G.opose[oc];
+    }
+    int fr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fr[q] = G.pfree[j[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (o0 + q < nobs && !lv[q]) {
+        G.lact[l[q]] = 1;
+        if (fr[q]) G.pact[j[q]] = 1;
+      }
+  }
+  __syncthreads();
+  int np = 0, na = 0;
+  for (int l = tid; l < G.L; l += NT) np += G.lact[l] ? 1 : 0;
+  for (int j = tid; j < P; j += NT) na += G.pact[j] ? 1 : 0;
+  if (np) atomicAdd(&s_cnt[0], np);
+  if (na) atomicAdd(&s_cnt[1], na);
+  __syncthreads();
+  if (tid == 0) {
+    st->any_point = s_cnt[0] > 0;
+    st->any_pose = s_cnt[1] > 0;
+  }
+  __syncthreads();
+}
+// prior edges at the current state (once per outer iteration: gen_optimize does the same)
+GL_DEV void pipe_priors(const BaK& k, GenP& G) {
+  const int NT = blockDim.x;
+  for (int j = threadIdx.x; j < G.P; j += NT) {
+    double H[36], b[6] = {0, 0, 0, 0, 0, 0}, chi = 0.0;
+    for (int r = 0; r < 36; ++r) H[r] = 0.0;
+    if (G.pact[j] && G.prior[j] && k.first_as_prior)
+      chi = prior_terms(se3_load(G.pinv + (size_t)j * 7), se3_load(G.poses + (size_t)j * 7), true, H, b);
+    for (int r = 0; r < 36; ++r) G.prH[(size_t)j * 36 + r] = H[r];
+    for (int r = 0; r < 6; ++r) G.prb[(size_t)j * 6 + r] = b[r];
+    G.pchi[j] = chi;
+  }
+}
+GL_DEV bool pipe_stop_now(const PipeSt* st) { return st->stop_seen > 0 || (st->stop_seen < 0 && st->done_iters >= -st->stop_seen); }
+
+// opens stage `stage` (st->stage already set): census, priors, loop variables; a stage with nothing active (optimize()
+// returns -1) or a raised stop word is over at once - returns false then
+GL_DEV bool pipe_open_stage(const BaK& k, GenP& G, PipeSt* st, int* s_cnt) {
+  pipe_census(k, G, st, s_cnt);
+  const bool run = (st->any_point || st->any_pose) && !pipe_stop_now(st);
+  if (threadIdx.x == 0) {
+    st->iters_max = st->stage < 2 ? 5 : 40;
+    st->it = 0;
+    st->qmax = 0;
+    st->cj = 0;
+    st->init = 1;
+    st->skip = 0;
+    st->rho = 0.0;
+  }
+  if (run) pipe_priors(k, G);
+  __syncthreads();
+  return run;
+}
+
+// the gating between the stages and the outputs (k_ba_gen's schedule code), one workgroup; advances st->stage until a
+// stage really runs or the problem is finished
+// The reprojection gate of every observation at the current state - stale chi2 above the threshold of its edge type, or the
+// point behind the camera (:799-825, :855-879) - four observations per thread and step with their loads hoisted (on ONE
+// workgroup a dependent chain per observation costs ~1 us each).  body(o, l, j, bad)
+template <class F>
+GL_DEV void for_obs_gate(const GenP& G, F&& body) {
+  const int NT = blockDim.x, nobs = G.nobs;
+  for (int o0 = threadIdx.x * 4; o0 < nobs; o0 += NT * 4) {
+    int l[4], j[4];
+    double chi[4], ur[4], z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oc = min(o0 + q, nobs - 1);
+      l[q] = G.opoint[oc];
+      j[q] = G.opose[oc];
+      chi[q] = G.chi_o[oc];
+      ur[q] = G.ouvr[(size_t)oc * 3 + 2];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* Rt = G.Rt + (size_t)j[q] * 12;
+      const double* p = G.pts + (size_t)l[q] * 3;
+      z[q] = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (o0 + q < nobs) body(o0 + q, l[q], j[q], chi[q] > (!(ur[q] < 0) ? 7.815 : 5.991) || !(z[q] > 0.0));
+  }
+}
+GL_DEV void pipe_advance(const PipeA& a, GenP& G, PipeSt* st, int f, int* s_cnt) {
+  const BaK& k = a.k;
+  const int L = G.L, tid = threadIdx.x, NT = blockDim.x;
+  for (;;) {
+    const int done_stage = st->stage;  // (uniform: written by thread 0 behind barriers)
+    if (done_stage == 2 && tid == 0 && st->it3 != -1) st->it3 = st->cj;
+    __syncthreads();
+    if (done_stage == 0) {  // fresh error of the degenerate GMM edges (:773-786)
+      for (int l = tid; l < L; l += NT) {
+        GmmRef g;
+        load_gmm(G.assoc[l], a.gm.axis, a.gm.rec12, a.gm.sqrt_info, a.gm.flags, g);
+        if (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) G.lev_g[l] = 1;
+      }
+    } else if (done_stage == 1 && !pipe_stop_now(st)) {  // bDoMore (:791-796): reprojection gating, kernels off
+      // by observation (coalesced)
+      for_obs_gate(G, [&](int o, int, int, bool bad) {
+        if (bad) G.lev_o[o] = 1;  // (the Schur pass of this shape tests the level flags itself: no sweep of the partner table)
+      });
+    }
+    __syncthreads();
+    const int next = (done_stage == 1 && pipe_stop_now(st)) ? 3 : done_stage + 1;
+    if (tid == 0) st->stage = next;
+    __syncthreads();
+    if (next >= 3) break;
+    if (pipe_open_stage(k, G, st, s_cnt)) return;  // the stage runs: the next cycle is its lambda-init pass
+    // nothing active (optimize() returned -1) or stopped (0 iterations): on to the next gate
+    if (next == 2 && tid == 0 && !(st->any_point || st->any_pose)) st->it3 = -1;
+    __syncthreads();
+  }
+  // ---- outputs (:837-879) -----------------------------------------------------------------------------------
+  for (int l = tid; l < L; l += NT) {
+    GmmRef g;
+    load_gmm(G.assoc[l], a.gm.axis, a.gm.rec12, a.gm.sqrt_info, a.gm.flags, g);
+    a.dropped[(size_t)f * L + l] = (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) ? 1 : 0;
+  }
+  uint8_t* er = a.erase + (size_t)f * a.NOBS;
+  for_obs_gate(G, [&](int o, int, int, bool bad) { er[o] = bad ? 1 : 0; });
+  if (tid == 0) {
+    if (a.iters) a.iters[f] = st->it3;
+    if (a.trials_out) a.trials_out[f] = st->trials;
+    atomicSub(a.unfinished, 1);
+  }
+}
+
+// ---- set-up: k_ba_gen's, as parallel kernels (one workgroup builds the pose-major lists of 58 000 observations in 4 ms) ----
+// (1) per-pose / per-point / per-observation initial state, the partner table cleared
+__global__ __launch_bounds__(T_BA) void kp_setup_init(PipeA a) {
+  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, tid = threadIdx.x, P = a.P, F = a.F, L = a.L;
+  GenP G;
+  genp_init(G, a, f, a.nba, pb);
+  PipeSt* st = a.st + f;
+  if (pb == 0) {
+    if (tid == 0) {
+#ifdef GL_PIPE_PROF
+      for (int i = 0; i < 8; ++i) st->dbg[i] = 0;
+#endif
+      const int sw = a.stop ? stop_word_load(a.stop) : 0;
+      st->stage = sw > 0 ? 3 : 0;  // `if (pbStopFlag) if (*pbStopFlag) return;` (:765-767): nothing is written
+      st->trials = 0;
+      st->done_iters = 0;
+      st->it3 = 0;
+      st->stop_seen = sw;
+      st->lambda = 0.0;
+      st->ni = 2.0;
+      st->currentChi = 0.0;
+      if (sw > 0) {
+        if (a.iters) a.iters[f] = 0;
+        atomicSub(a.unfinished, 1);
+      }
+    }
+    for (int j = tid; j < P + F; j += T_BA) {
+      const SE3 T = se3_load(G.poses + (size_t)j * 7);
+      store_pose_Rt(T, G.Rt + (size_t)j * 12);
+      bool fr = j < P;
+      if (fr && G.prior[j] && !a.k.first_as_prior) fr = false;  // vSE3->setFixed(idx_ == 0) (:578-580)
+      G.pfree[j] = fr ? 1 : 0;
+      if (j < P) se3_store(se3_inverse(T), G.pinv + (size_t)j * 7);  // e->setMeasurement(kf->getTcw())
+    }
+  }
+  for (int l = GSTART; l < L; l += GSTRIDE) {
+    G.lev_g[l] = 0;
+    for (int o = G.optr[l]; o < G.optr[l + 1]; ++o) {
+      G.opoint[o] = l;
+      G.lev_o[o] = 0;
+      G.chi_o[o] = 0.0;
+    }
+  }
+  for (size_t i = GSTART; i < (size_t)G.nobs * P; i += GSTRIDE) G.plm[i] = -1;
+}
+// (2) / (4) pose-major CSR of the free poses' observations, ascending within a pose: a stable counting sort - a wave per 512
+// observations counts per pose (2), one workgroup scans the counts (3), the same waves scatter (4).  FILL = 0 / 1
+constexpr int SORT_SPAN = 512;
+template <int FILL>
+__global__ __launch_bounds__(T_BA) void kp_setup_lists(PipeA a, int nws) {
+  const int lane = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * NW_BA + (threadIdx.x >> 6);
+  const int f = (int)(gw / nws), w = (int)(gw % nws);
+  if (f >= a.B || a.st[f].stage >= 3) return;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  const int P = a.P, nobs = G.nobs;
+  int* cnt = (int*)a.partS + ((size_t)f * nws + w) * P;  // (the Schur partials are idle during the set-up)
+  const int o0 = w * SORT_SPAN, o1 = min(nobs, o0 + SORT_SPAN);
+  for (int jj = lane; jj < P && !FILL; jj += 64) cnt[jj] = 0;
+  for (int jj = 0; jj < P; ++jj) {  // (P <= ~20: a ballot per pose and step)
+    int run = FILL ? cnt[jj] : 0;   // FILL: the list position of this wave's first observation of pose jj (from the scan)
+    for (int o = o0 + lane; o - lane < o1; o += 64) {
+      const bool hit = o < o1 && G.opose[o] == jj;
+      const unsigned long long m = __ballot(hit);
+      if (FILL && hit) {
+        const int e = run + __popcll(m & ((1ull << lane) - 1ull));
+        G.pl_obs[e] = o;
+        G.pl_pos[o] = e;
+        G.pl_pt[e] = G.opoint[o];
+      }
+      run += __popcll(m);
+    }
+    if (!FILL && lane == 0) cnt[jj] = run;
+  }
+}
+// (3) counts -> list positions (exclusive scan in (pose, wave) order), pl_ptr, the chunk length of the Schur pass
+__global__ __launch_bounds__(T_BA) void kp_setup_scan(PipeA a, int nws) {
+  const int f = blockIdx.x, tid = threadIdx.x, P = a.P;
+  PipeSt* st = a.st + f;
+  if (st->stage >= 3) return;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  int* cnt = (int*)a.partS + (size_t)f * nws * P;
+  __shared__ int tot[256];
+  for (int j = tid; j < P; j += T_BA) {  // a thread per pose walks its column (nws <= ~120)
+    int s = 0;
+    for (int w = 0; w < nws; ++w) {
+      const int c = cnt[(size_t)w * P + j];
+      cnt[(size_t)w * P + j] = s;
+      s += c;
+    }
+    tot[j] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int base = 0, longest = 1;
+    G.pl_ptr[0] = 0;
+    for (int j = 0; j < P; ++j) {
+      longest = max(longest, tot[j]);
+      const int t = tot[j];
+      tot[j] = base;
+      base += t;
+      G.pl_ptr[j + 1] = base;
+    }
+    st->chunk_len = (((longest + a.nchunk - 1) / a.nchunk + 63) / 64) * 64;
+  }
+  __syncthreads();
+  for (int i = tid; i < nws * P; i += T_BA) cnt[i] += tot[i % P];
+}
+// (5) partner table, by list position: entry (e, j2) = the observation of the same point in free pose j2
+__global__ __launch_bounds__(T_BA) void kp_setup_partner(PipeA a) {
+  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, P = a.P;
+  if (a.st[f].stage >= 3) return;
+  GenP G;
+  genp_init(G, a, f, a.nba, pb);
+  for (int l = GSTART; l < a.L; l += GSTRIDE)
+    for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1) {
+      if (G.opose[o1] >= P) continue;
+      const size_t row = (size_t)G.pl_pos[o1] * P;
+      for (int o2 = G.optr[l]; o2 < G.optr[l + 1]; ++o2) {
+        const int j2 = G.opose[o2];
+        if (j2 < P) G.plm[row + j2] = o2;
+      }
+    }
+}
+// (6) the first stage opens
+__global__ __launch_bounds__(512) void kp_setup_open(PipeA a) {
+  __shared__ int s_cnt[2];
+  const int f = blockIdx.x;
+  PipeSt* st = a.st + f;
+  if (st->stage >= 3) return;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  if (!pipe_open_stage(a.k, G, st, s_cnt)) pipe_advance(a, G, st, f, s_cnt);
+}
+
+// ---- P1: point pass (linearise the observations, point blocks), nba workgroups per problem ------------------------
+__global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
+  __shared__ double red[NW_BA * 32 + 8];
+  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba;
+  const PipeSt* st = a.st + f;
+  if (st->stage >= 3) return;
+  GenP G;
+  genp_init(G, a, f, a.nba, pb);
+  double acc[32], md = 0.0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  acc[0] = pass_points_lpp(a.lpp, a.k, a.gm, G, st->stage < 2, st->init ? 0.0 : st->lambda, md);
+  block_reduce<1, NW_BA>(acc, red);
+  md = block_max(md, red);
+  if (threadIdx.x == 0) {
+    double* pa = a.partA + ((size_t)f * a.nba + pb) * 2;
+    pa[0] = acc[0];
+    pa[1] = md;
+  }
+}
+
+// ---- P2: one wave per (block (j1 <= j2) of the reduced camera system, chunk of pose j1's list: 1 / nchunk of the longest) ----------
+__global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
+  const int lane = threadIdx.x & 63;
+  const long gwave = (long)blockIdx.x * NW_BA + (threadIdx.x >> 6);
+  const int per_prob = a.nblk * a.nchunk;
+  const int f = (int)(gwave / per_prob), w = (int)(gwave % per_prob);
+  if (f >= a.B) return;
+  const PipeSt* st = a.st + f;
+  if (st->stage >= 3) return;
+  const bool schur = !st->init;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  const int P = a.P, b = w / a.nchunk, chunk = w % a.nchunk;
+  int j1 = 0, rem = b;
+  while (rem >= P - j1) {
+    rem -= P - j1;
+    ++j1;
+  }
+  const int j2 = j1 + rem;
+  const bool act = G.pact[j1] && G.pact[j2] && (schur || j1 == j2);
+  double v1[32], v2[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    v1[i] = 0.0;
+    v2[i] = 0.0;
+  }
+  if (act) {
+    double R1[9], t1[3], R2[9], t2[3];
+    load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
+    load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
+    const int e0 = G.pl_ptr[j1] + chunk * st->chunk_len, e1 = min(G.pl_ptr[j1 + 1], e0 + st->chunk_len);
+    for (int e = e0 + lane; e < e1; e += 64) {
+      const int o2 = G.plm[(size_t)e * P + j2];
+      const int o1 = G.pl_obs[e];
+      const int l = G.pl_pt[e];
+      if (o2 < 0) continue;
+      if (G.lev_o[o1] | G.lev_o[o2]) continue;  // an edge at level 1 (k_ba_gen folds these flags into the partner table)
+      const double* l1 = G.lin + (size_t)o1 * 12;
+      const double* l2 = G.lin + (size_t)o2 * 12;
+      const double* pw = G.ptw + (size_t)l * 12;
+      double A1[9], A2[9], Dv[9];
+      sym_to_full(l1 + 3, A1);
+      sym_to_full(l2 + 3, A2);
+      sym_to_full(pw, Dv);
+      double blk[36];
+      if (schur) {  // M = A1 R1 D^-1 R2^T A2
+        double X[9], Y[9], Z[9], M[9];
+        mm3(A1, R1, X);
+        mm3(X, Dv, Y);
+        mm3t(Y, R2, Z);
+        mm3(Z, A2, M);
+        gmg(l1, M, l2, blk);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
+      }
+      double gq[6] = {0, 0, 0, 0, 0, 0}, bq[6] = {0, 0, 0, 0, 0, 0};
+      if (j1 == j2) {
+        double hpp[36];
+        gmg(l1, A1, l1, hpp);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = hpp[i] - blk[i];
+        const double* aa = l1 + 9;  // bp = G^T a ; g = G^T (a - A1 R1 u)
+        double c[3] = {aa[0], aa[1], aa[2]};
+        if (schur) {
+          const double* u = pw + 6;
+          double Ru[3], ARu[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Ru[i] = R1[i * 3] * u[0] + R1[i * 3 + 1] * u[1] + R1[i * 3 + 2] * u[2];
+          sym3_mul_vec(l1 + 3, Ru, ARu);
+          c[0] -= ARu[0];
+          c[1] -= ARu[1];
+          c[2] -= ARu[2];
+        }
+        double qc[3], qa[3];
+        cross(l1, c, qc);
+        cross(l1, aa, qa);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          gq[i] = qc[i];
+          gq[3 + i] = c[i];
+          bq[i] = qa[i];
+          bq[3 + i] = aa[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) blk[i] = -blk[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v1[i] += blk[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v2[i] += blk[32 + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        v2[4 + i] += gq[i];
+        v2[10 + i] += bq[i];
+      }
+    }
+  }
+  const double r1 = wave_reduce_scatter32(v1), r2 = wave_reduce_scatter32(v2);
+  double* const pblk = a.partS + ((size_t)f * a.nblk + b) * a.nchunk * 48;
+  if (wave_slot_owner(lane)) {  // 48 sums of this chunk: [0..35] the block, [36..41] g, [42..47] b_p (diagonal blocks)
+    double* ps = pblk + (size_t)chunk * 48;
+    const int s = wave_slot(lane);
+    ps[s] = r1;
+    if (s < 16) ps[32 + s] = r2;
+  }
+}
+
+// ---- P2b: the chunks of a block added in chunk order -> the assembled system (a thread per (block, sum); the solve kernel
+// read nblk x nchunk x 48 partials itself at first - 63 us of its 155 at 20 poses; letting the last wave of a block do it
+// behind device-scope fences made the Schur pass 3.5 x slower) ------------------------------------------------------------
+__global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
+  const long g = (long)blockIdx.x * T_BA + threadIdx.x;
+  const int per_prob = a.nblk * 48;
+  const int f = (int)(g / per_prob), r0 = (int)(g % per_prob), b = r0 / 48, sidx = r0 % 48;
+  if (f >= a.B || a.st[f].stage >= 3) return;
+  const int P = a.P, ld = 6 * P + GL_LD_PAD;
+  int j1 = 0, rem = b;
+  while (rem >= P - j1) {
+    rem -= P - j1;
+    ++j1;
+  }
+  const int j2 = j1 + rem;
+  const double* ps = a.partS + ((size_t)f * a.nblk + b) * a.nchunk * 48 + sidx;
+  double x[16];  // all chunks requested before the first add (the adds stay in chunk order); nchunk is 4 or 16
+#pragma unroll
+  for (int c = 0; c < 16; ++c) x[c] = c < a.nchunk ? ps[(size_t)c * 48] : 0.0;
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v += x[c];
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  if (sidx < 36) {  // only the lower triangle of S is read: block (j2, j1) = block (j1, j2)^T
+    const int r = sidx / 6, c = sidx % 6;
+    G.S[j1 == j2 ? (size_t)(6 * j1 + r) * ld + 6 * j1 + c : (size_t)(6 * j2 + c) * ld + 6 * j1 + r] = v;
+  } else if (j1 == j2) {
+    if (sidx < 42) G.gv[6 * j1 + (sidx - 36)] = v;
+    else G.bp[6 * j1 + (sidx - 42)] = v;
+  }
+}
+
+// ---- solve: assemble S / g from the chunk sums, (lambda init |) LDL^T, trial poses; one workgroup per problem ---------
+__global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+  __shared__ double red[NW_BA * 32 + 128 + 128];
+  __shared__ int s_flag;
+  const int f = blockIdx.x, tid = threadIdx.x, P = a.P, n = 6 * P;
+  PipeSt* st = a.st + f;
+  if (st->stage >= 3) return;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  const int ld = G.ld;
+  const bool small = n <= 128;
+  double* S = small ? dyn_lds : G.S;  // (n > 128: the scalar-pivot path factorises in global memory)
+  // the assembled system (lower triangle; blocks of inactive poses hold zeros) was written by the Schur pass
+  if (small)
+    for (int i = tid; i < n * n; i += T_BA) {
+      const int r = i / n, c = i - r * n;
+      if (c <= r) S[(size_t)r * ld + c] = G.S[(size_t)r * ld + c];
+    }
+  __syncthreads();
+  // partial sums of the point pass and the prior chi2: fetched in parallel into LDS, added in index order
+  double* stage = red + NW_BA * 32 + 128;  // 128 doubles behind the solve's own areas
+  double chiA = 0.0, md = 0.0;
+  for (int w0 = 0; w0 < a.nba; w0 += 64) {
+    if (tid < 128 && w0 + (tid >> 1) < a.nba) stage[tid] = a.partA[((size_t)f * a.nba + w0) * 2 + tid];
+    __syncthreads();
+    for (int w = 0; w < min(64, a.nba - w0); ++w) {
+      chiA += stage[2 * w];
+      md = fmax(md, stage[2 * w + 1]);
+    }
+    __syncthreads();
+  }
+  if (tid < P) stage[tid] = G.pchi[tid];
+  __syncthreads();
+  if (st->init) {  // computeLambdaInit: 1e-5 x the largest diagonal of H_pp (+ prior) and H_ll
+    double mine = 0.0;
+    for (int i = tid; i < n; i += T_BA) {
+      const int j = i / 6, r = i - 6 * j;
+      if (G.pact[j]) mine = fabs(S[(size_t)i * ld + i] + G.prH[(size_t)j * 36 + r * 6 + r]);
+    }
+    md = fmax(md, block_max(mine, red));
+    if (tid == 0) {
+      st->lambda = 1e-5 * md;
+      st->ni = 2.0;
+      st->init = 0;
+      st->skip = 1;
+    }
+    return;
+  }
+  const double lambda = st->lambda;
+  for (int j = 0; j < P; ++j) chiA += stage[j];
+  for (int j = tid; j < P; j += T_BA) {
+    if (!G.pact[j]) {
+      for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * ld + 6 * j + r] = 1.0;
+      continue;
+    }
+    if (G.prior[j] && a.k.first_as_prior) {
+      const double* H = G.prH + (size_t)j * 36;
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * ld + 6 * j + c] += H[r * 6 + c];
+    }
+    for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * ld + 6 * j + r] += lambda;
+  }
+  for (int i = tid; i < n; i += T_BA) {
+    const int j = i / 6;
+    double v = G.gv[i];
+    if (G.pact[j] && G.prior[j] && a.k.first_as_prior) {
+      const double b = G.prb[i];
+      v += b;
+      G.bp[i] += b;
+    }
+    G.dxv[i] = v;
+    if (small) red[128 + i] = v;
+  }
+  __syncthreads();
+  bool ok = true;
+  if (st->any_pose)
+    ok = small ? ldlt_solve_small(G, a.k, lambda, S, ld, false, (lds_double*)dyn_lds, ld, G.dxv, n, &s_flag, red)
+               : ldlt_solve_large(S, G.dxv, n, ld, &s_flag);
+  __syncthreads();
+  for (int j = tid; j < P; j += T_BA) {  // trial poses
+    const SE3 T = se3_load(G.poses + (size_t)j * 7);
+    SE3 Tn = T;
+    if (G.pact[j] && ok) {
+      double dx[6];
+      for (int r = 0; r < 6; ++r) dx[r] = G.dxv[6 * j + r];
+      Tn = se3_mul(se3_exp(dx), T);
+    } else {
+      for (int r = 0; r < 6; ++r) G.dxv[6 * j + r] = 0.0;
+    }
+    se3_store(Tn, G.qN + (size_t)j * 7);
+    store_pose_Rt(Tn, G.RtN + (size_t)j * 12);
+    G.pchi2[j] = (G.pact[j] && G.prior[j] && a.k.first_as_prior)
+                     ? prior_terms(se3_load(G.pinv + (size_t)j * 7), Tn, false, nullptr, nullptr)
+                     : 0.0;
+  }
+  if (tid == 0) {
+    st->ok = ok ? 1 : 0;
+    st->chiA = chiA;
+    st->skip = 0;
+    if (a.stop) st->stop_seen = stop_word_load(a.stop);
+  }
+}
+
+// ---- P3: back-substitution of the points, trial points, their chi2 -------------------------------------------------
+__global__ __launch_bounds__(T_BA) void kp_trial(PipeA a) {
+  __shared__ double red[NW_BA * 32 + 8];
+  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba;
+  const PipeSt* st = a.st + f;
+  if (st->stage >= 3 || st->skip) return;
+  GenP G;
+  genp_init(G, a, f, a.nba, pb);
+  double acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  pass_trial_lpp(a.lpp, a.k, a.gm, G, st->stage < 2, st->lambda, a.P, acc);
+  block_reduce<2, NW_BA>(acc, red);
+  if (threadIdx.x == 0) {
+    double* pd = a.partD + ((size_t)f * a.nba + pb) * 2;
+    pd[0] = acc[0];
+    pd[1] = acc[1];
+  }
+}
+
+// ---- accept / reject, loop control, stage changes; one workgroup per problem ---------------------------------------------
+constexpr int T_DEC = 512;  // the state kernels: a workgroup per problem, loops over its points / observations
+__global__ __launch_bounds__(T_DEC) void kp_decide(PipeA a) {
+  __shared__ int s_cnt[2];
+  __shared__ int s_accept, s_next;  // s_next: 0 retry, 1 next outer iteration, 2 stage over
+  const int f = blockIdx.x, tid = threadIdx.x, P = a.P, n = 6 * P, NT = blockDim.x;
+  PipeSt* st = a.st + f;
+  if (st->stage >= 3 || st->skip) return;
+#ifdef GL_PIPE_PROF
+  const long long c0 = clock64();
+#endif
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  // the terms of the two sums are fetched in parallel into LDS and added by one thread in index order
+  __shared__ double s_d[2 * 64 + 3 * 128];
+  double scale0 = 0.0, temp0 = 0.0;
+  for (int w0 = 0; w0 < a.nba; w0 += 64) {
+    if (tid < 128 && w0 + (tid >> 1) < a.nba) s_d[tid] = a.partD[((size_t)f * a.nba + w0) * 2 + tid];
+    __syncthreads();
+    if (tid == 0)
+      for (int w = 0; w < min(64, a.nba - w0); ++w) {
+        scale0 += s_d[2 * w];
+        temp0 += s_d[2 * w + 1];
+      }
+    __syncthreads();
+  }
+  for (int i = tid; i < n && i < 128; i += NT) {
+    s_d[128 + i] = G.dxv[i];
+    s_d[256 + i] = G.bp[i];
+  }
+  if (tid < P) s_d[384 + tid] = G.pchi2[tid];
+  __syncthreads();
+#ifdef GL_PIPE_PROF
+  const long long c1 = clock64();
+#endif
+  if (tid == 0) {
+    PipeSt q = *st;  // (one burst of loads: every st-> access below was a dependent global round trip)
+    double scale = scale0, tempChi = temp0;
+    const double lambda = q.lambda;
+    if (q.qmax == 0) q.currentChi = q.chiA;
+    for (int j = 0; j < P; ++j) tempChi += s_d[384 + j];
+    if (n <= 128) {
+      for (int i = 0; i < n; ++i) scale += s_d[128 + i] * (lambda * s_d[128 + i] + s_d[256 + i]);
+    } else {
+      for (int i = 0; i < n; ++i) scale += G.dxv[i] * (lambda * G.dxv[i] + G.bp[i]);
+    }
+    if (!q.ok) tempChi = 1.7976931348623157e308;
+    scale += 1e-3;
+    const double rho = (q.currentChi - tempChi) / scale;
+    const bool acc = rho > 0 && isfinite(tempChi);
+    if (acc) {
+      const double uu = 2 * rho - 1;
+      double alpha = 1. - uu * uu * uu;
+      alpha = fmin(alpha, 2. / 3.);
+      q.lambda = lambda * fmax(1. / 3., alpha);
+      q.ni = 2;
+      q.currentChi = tempChi;
+    } else {
+      q.lambda = lambda * q.ni;
+      q.ni *= 2;
+    }
+    q.rho = rho;
+    q.qmax += 1;
+    q.trials += 1;
+    s_accept = acc ? 1 : 0;
+    int next = 0;
+    if (!(rho < 0 && q.qmax < 10 && !(q.stop_seen > 0))) {  // the outer iteration is over
+      q.cj += 1;
+      q.done_iters += 1;
+      q.it += 1;
+      next = (q.qmax == 10 || rho == 0 || q.it >= q.iters_max || pipe_stop_now(&q)) ? 2 : 1;
+      q.qmax = 0;
+    }
+    *st = q;
+    s_next = next;
+  }
+  __syncthreads();
+#ifdef GL_PIPE_PROF
+  const long long c2 = clock64();
+#endif
+  if (s_accept) {
+    for (int j = tid; j < P; j += NT) {
+      if (!G.pact[j]) continue;
+      for (int r = 0; r < 7; ++r) G.poses[(size_t)j * 7 + r] = G.qN[(size_t)j * 7 + r];
+      for (int r = 0; r < 12; ++r) G.Rt[(size_t)j * 12 + r] = G.RtN[(size_t)j * 12 + r];
+    }
+    for (int l = tid; l < G.L; l += NT) {
+      if (!G.lact[l]) continue;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) G.pts[(size_t)l * 3 + i] = G.pn[(size_t)l * 3 + i];
+    }
+  }
+  __syncthreads();
+#ifdef GL_PIPE_PROF
+  const long long c3 = clock64();
+#endif
+  if (s_next == 1) pipe_priors(a.k, G);  // the state the next outer iteration linearises the prior edges at
+  else if (s_next == 2) pipe_advance(a, G, st, f, s_cnt);
+#ifdef GL_PIPE_PROF
+  __syncthreads();
+  if (tid == 0 && f == 0) {
+    const long long c4 = clock64();
+    st->dbg[0] += c1 - c0; st->dbg[1] += c2 - c1; st->dbg[2] += c3 - c2; st->dbg[s_next == 2 ? 4 : 3] += c4 - c3; st->dbg[5] += 1;
+    if (st->stage >= 3) printf("decide cycles: fetch %lld serial %lld accept-copy %lld priors %lld advance %lld calls %lld\n", st->dbg[0], st->dbg[1], st->dbg[2], st->dbg[3], st->dbg[4], st->dbg[5]);
+  }
+#endif
+}
+
 namespace gl {
 size_t ba_gen_scratch_bytes(int B, int P, int F, int L, int NOBS) {
   const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
@@ -1492,6 +2302,108 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
+
+// scratch of the pipelined shape: k_ba_gen's layout + the state words and the partial sums
+static void pipe_shape(int P, int L, int NOBS, int* nba, int* lpp, int* nblk, int* nchunk) {
+  *lpp = 4;
+  *nba = std::max(1, (L * 4 + T_BA - 1) / T_BA);
+  *nblk = P * (P + 1) / 2;
+  *nchunk = NOBS <= 1024 ? 4 : 16;            // waves per block of the Schur pass (each takes 1 / nchunk of the longest pose list)
+}
+size_t ba_pipe_scratch_bytes(int B, int P, int F, int L, int NOBS) {
+  int nba, lpp, nblk, nchunk;
+  pipe_shape(P, L, NOBS, &nba, &lpp, &nblk, &nchunk);
+  auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+  return ba_gen_scratch_bytes(B, P, F, L, NOBS) + up((size_t)B * sizeof(PipeSt)) + 2 * up((size_t)B * nba * 16) +
+         up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * nblk * 4) + 1024;
+}
+
+int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+                   double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
+                   const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                   const int32_t* stop_dev, void* scratch) {
+  PipeA a;
+  a.k = make_bak(cam, prm, -1.0);
+  a.gm = GmmDev{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
+  a.B = B;
+  a.P = P;
+  a.F = F;
+  a.L = L;
+  a.NOBS = NOBS;
+  a.poses = poses_dev;
+  a.prior = prior_dev;
+  a.pts = points_dev;
+  a.assoc = assoc_dev;
+  a.optr = obs_ptr_dev;
+  a.opose = obs_pose_dev;
+  a.ouvr = obs_uvr_dev;
+  a.ooct = obs_oct_dev;
+  a.dropped = assoc_dropped_dev;
+  a.erase = obs_erase_dev;
+  a.iters = iters_dev;
+  a.trials_out = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
+  a.stop = stop_dev;
+  a.scratch = (char*)scratch;
+  a.per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
+  pipe_shape(P, L, NOBS, &a.nba, &a.lpp, &a.nblk, &a.nchunk);
+  auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+  char* s = (char*)scratch + ba_gen_scratch_bytes(B, P, F, L, NOBS);
+  a.st = (PipeSt*)s;
+  s += up((size_t)B * sizeof(PipeSt));
+  a.partA = (double*)s;
+  s += up((size_t)B * a.nba * 16);
+  a.partD = (double*)s;
+  s += up((size_t)B * a.nba * 16);
+  a.partS = (double*)s;
+  s += up((size_t)B * a.nblk * a.nchunk * 48 * 8);
+  a.unfinished = (int*)s;
+  s += 256;
+  a.arrive = (int*)s;
+  GL_HIP(hipMemsetAsync(a.arrive, 0, (size_t)B * a.nblk * sizeof(int), c->stream));
+  const size_t n = 6 * (size_t)P;
+  const size_t s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;
+  if (s_bytes) GL_HIP(ensure_dynamic_lds(c, (const void*)kp_solve, s_bytes));
+  // page-locked word the device's count of unfinished problems is copied to between chunks of cycles
+  if (!c->host_word) GL_HIP(hipHostMalloc((void**)&c->host_word, 64, hipHostMallocDefault));
+  TimerScope ts(c, GL_TIMER_BA);
+  *c->host_word = B;
+  GL_HIP(hipMemcpyAsync(a.unfinished, c->host_word, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  {
+    const int nws = std::max(1, (NOBS + SORT_SPAN - 1) / SORT_SPAN);
+    const int lblocks = (int)(((long)B * nws + NW_BA - 1) / NW_BA);
+    kp_setup_init<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+    kp_setup_lists<0><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
+    kp_setup_scan<<<B, T_BA, 0, c->stream>>>(a, nws);
+    kp_setup_lists<1><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
+    kp_setup_partner<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+    kp_setup_open<<<B, 512, 0, c->stream>>>(a);
+  }
+  const long schur_waves = (long)B * a.nblk * a.nchunk;
+  const int schur_blocks = (int)((schur_waves + NW_BA - 1) / NW_BA);
+  // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
+  // one): enough cycles for the common case are enqueued before the first look at the counter, fewer per look afterwards
+  int chunk = 36;
+  for (int total = 0;; total += chunk, chunk = 8) {
+    for (int cyc = 0; cyc < chunk; ++cyc) {
+      kp_lin<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+      kp_schur<<<schur_blocks, T_BA, 0, c->stream>>>(a);
+      kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, c->stream>>>(a);
+      kp_solve<<<B, T_BA, s_bytes, c->stream>>>(a);
+      kp_trial<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+      kp_decide<<<B, T_DEC, 0, c->stream>>>(a);
+    }
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipMemcpyAsync(c->host_word, a.unfinished, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    GL_HIP(hipStreamSynchronize(c->stream));
+    if (*c->host_word <= 0) break;
+    if (total > 600) {  // 3 x (40 iterations x 10 trials) is the schedule's bound; this is a defect, not a slow problem
+      set_error("launch_ba_pipe: %d problem(s) did not finish in %d cycles", *c->host_word, total + chunk);
+      return GL_ERR_DEVICE;
+    }
+  }
+  return GL_OK;
+}
 }  // namespace gl
 
 static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
@@ -1511,8 +2423,18 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   gl::Gmm* g = gl::G(gmm);
   GL_HIP(hipSetDevice(c->device));
   void* scratch = nullptr;
-  int rc = gl::ctx_scratch(c, gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
+  // Shape (option bagen_mode: 0 by size, 1 the persistent kernel, 2 the pipelined shape).  Measured on single windows
+  // (profiles/r3_bagen_shapes.txt): 8 + 4 key-frames / 12 600 observations 2.96 ms pipelined vs 2.87 persistent, 12 + 4 /
+  // 22 400 3.15 vs 4.70, 20 + 8 / 58 600 7.24 vs 6.51 (there the 120 x 120 factorisation, one workgroup in either shape, is
+  // 40 % of a cycle and the persistent kernel needs no lambda-init cycles); batches 0.23 vs 0.107 ms per problem.
+  const bool pipe = c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 2 && P <= 16 && NOBS >= 15000);
+  int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_bytes(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
+  if (pipe) {
+    GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 512, c->stream));
+    return gl::launch_ba_pipe(c, g, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
+                              obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, stop_dev, scratch);
+  }
   return gl::launch_ba_gen(c, g, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
                            obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, stop_dev, scratch);
 }

@@ -88,7 +88,8 @@ struct Options {
                                    // gives up at its first unsuccessful look -> follow-up kernel; tests)
   double ba_test_abort_seq = 0;    // tests: n > 0 makes the last workgroup of every frame give up at its n-th exchange
   double pose_regs = 1;         //   0: the frame-at-a-time shapes read their edges from global memory every trial (A/B)
-  double bagen_nb = 0;          // gl_joint_optimization: 0 auto, n workgroups per problem
+  double bagen_nb = 0;          // gl_joint_optimization, persistent kernel: 0 auto, n workgroups per problem
+  double bagen_mode = 0;        //   0 / 2: the pipelined shape (a kernel per phase, host-enqueued cycles), 1: the persistent kernel k_ba_gen
   double view_slot_lds = 0;     // gl_search2d: accepted-list records kept in LDS (0 = all that fit)
   double view_threads = 0;      //   0 auto, 256 / 1024
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
@@ -120,6 +121,7 @@ struct Ctx {
   size_t stage_bytes = 0;
   // device counters (gl_ctx_counter_read): [0] frames of latency-shape launches redone by the follow-up kernel
   int32_t* counters = nullptr;
+  int* host_word = nullptr;  // page-locked word (the pipelined local BA's count of unfinished problems)
   // optional statistics buffer (gl_ctx_set_stats_buffer)
   int32_t* stats = nullptr;
   int stats_n = 0;

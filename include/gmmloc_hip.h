@@ -96,6 +96,10 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *     probe at gl_ctx_create found block b on XCC id b % 8 and (b) the frame's workgroups reported one and the same id in
  *     the launch's first (device-scope) exchange; a word that did not become visible would time the exchange out
  *     (ba_rendezvous_us) and send the frame to the follow-up kernel.  0: device-scope stores only (0.37 instead of 0.34 ms),
+ *   bagen_mode (0): launch shape of gl_joint_optimization - 1 the persistent cooperative kernel (asynchronous), 2 the
+ *     pipelined shape (a kernel per phase, cycles enqueued ahead, the call returns with the work complete), 0 by window
+ *     size (the pipelined shape for single mid-size windows, where it is up to 1.5 x faster); same arithmetic, both held
+ *     to the oracle,
  *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
