@@ -153,16 +153,24 @@ class GMM {
   // frame's M map points (kept iff chi2 <= 9, gmmloc_opt.cpp:230-232) + jointOptimization restricted to the
   // frame (1 free pose, M marginalised points, 5 / 5 / 40 Levenberg schedule).  Tcw and Xw are updated;
   // assoc[i] = component after the final gates or -1; octave[i] < 0 = no map point.
+  // anchored = true (default): with the reference's gauge anchor of key-frame 0 - an EdgeSE3QuatPrior on the pose the call
+  // starts from (sigma 2 deg / 1 cm; the pose is FIXED when gl_params.ba_first_as_prior == 0), localization_opt.cpp:556-581;
+  // the reference never runs its structure BA without one.  false: the pose is held by the map's Gaussians alone.
   void trackFrame(Pose& Tcw, std::vector<double>& Xw, const std::vector<double>& obs, const std::vector<int32_t>& octave,
-                  std::vector<int32_t>& assoc) {
+                  std::vector<int32_t>& assoc, bool anchored = true) {
     const int M = (int)octave.size();
     assoc.assign(M, -1);
     if (!M) return;
     // the per-frame caller: the library keeps a page-locked staging buffer and its device mirror in the context, one
-    // transfer each way on the context's stream and ONE synchronize per frame (gl_track_frame_host)
-    check(gl_track_frame_host(ctx_, gmm_, &cam_, &prm_, M, reinterpret_cast<double*>(&Tcw), Xw.data(), obs.data(), octave.data(),
-                              assoc.data()),
-          "gl_track_frame_host");
+    // transfer each way on the context's stream and ONE synchronize per frame (gl_track_frame_host[_anchored])
+    if (anchored)
+      check(gl_track_frame_host_anchored(ctx_, gmm_, &cam_, &prm_, M, reinterpret_cast<double*>(&Tcw), Xw.data(), obs.data(),
+                                         octave.data(), assoc.data()),
+            "gl_track_frame_host_anchored");
+    else
+      check(gl_track_frame_host(ctx_, gmm_, &cam_, &prm_, M, reinterpret_cast<double*>(&Tcw), Xw.data(), obs.data(), octave.data(),
+                                assoc.data()),
+            "gl_track_frame_host");
   }
 
   // Localization::jointOptimization on one flattened local window (layout: gmmloc_hip.h, gl_joint_optimization):
@@ -181,7 +189,9 @@ class GMM {
     std::vector<uint8_t> obs_erase;     // out, NOBS (:855-879)
     int iters = 0;                      // out: actual_iter of the last optimize(40)
   };
-  void jointOptimization(LocalWindow& w) {
+  // stop_flag: the reference's pbStopFlag (setForceStopFlag, localization_opt.cpp:541-542) as one int32 in memory from
+  // gl_malloc_host (another thread raises it to 1) or NULL: the window returns with the state of the last accepted step
+  void jointOptimization(LocalWindow& w, const int32_t* stop_flag = nullptr) {
     const int L = (int)w.assoc.size(), NOBS = (int)w.obs_pose.size(), NP = w.P + w.F;
     w.assoc_dropped.assign(L, 0);
     w.obs_erase.assign(NOBS, 0);
@@ -200,10 +210,10 @@ class GMM {
     dop.upload(w.obs_pose.data());
     duvr.upload(w.obs_uvr.data());
     doct.upload(w.obs_oct.data());
-    check(gl_joint_optimization(ctx_, gmm_, &cam_, &prm_, 1, w.P, w.F, L, NOBS, dposes.as<double>(), dprior.as<uint8_t>(),
-                                dpts.as<double>(), dassoc.as<int32_t>(), dptr.as<int32_t>(), dop.as<int32_t>(),
-                                duvr.as<double>(), doct.as<int32_t>(), ddrop.as<uint8_t>(), derase.as<uint8_t>(),
-                                dit.as<int32_t>()),
+    check(gl_joint_optimization_stoppable(ctx_, gmm_, &cam_, &prm_, 1, w.P, w.F, L, NOBS, dposes.as<double>(), dprior.as<uint8_t>(),
+                                          dpts.as<double>(), dassoc.as<int32_t>(), dptr.as<int32_t>(), dop.as<int32_t>(),
+                                          duvr.as<double>(), doct.as<int32_t>(), ddrop.as<uint8_t>(), derase.as<uint8_t>(),
+                                          dit.as<int32_t>(), stop_flag),
           "gl_joint_optimization");
     check(gl_ctx_synchronize(ctx_), "sync");
     dposes.download(w.poses.data());

@@ -74,11 +74,11 @@ int main(int argc, char** argv) {
     fclose(f);
     FILE* o = fopen(argv[3], "wb");
     if (!o) return 1;
-    {  // north-star path
+    for (int anchored = 0; anchored < 2; ++anchored) {  // north-star path: unanchored, then with the prior edge on the pose
       gmmloc_hip::Pose p = pose0;
       std::vector<double> X = Xw;
       std::vector<int32_t> assoc;
-      gmm.trackFrame(p, X, obs, oct, assoc);
+      gmm.trackFrame(p, X, obs, oct, assoc, anchored != 0);
       wr(o, reinterpret_cast<double*>(&p), 7);
       wr(o, X.data(), X.size());
       wr(o, assoc.data(), assoc.size());

@@ -63,6 +63,14 @@ def test_cpp_adapter_matches_python_host(gpu, map_v1, gt_sync, tmp_path):
     assert np.array_equal(rd(np.float64, 7), pose.cpu().numpy()[0])
     assert np.array_equal(rd(np.float64, M * 3).reshape(M, 3), Xw.cpu().numpy()[0])
     assert np.array_equal(rd(np.int32, M), assoc.cpu().numpy()[0])
+    # ... anchored by the prior edge (the adapter's default)
+    pose_a, Xw_a = T(f["pose_init"][None]), T(f["Xw"][None])
+    assoc_a, _, _ = gmmloc_amd.track_frames_anchored(ctx, g, cam, prm, pose_a, Xw_a, T(f["obs"][None]), T(f["octave"][None]),
+                                                     prior=torch.ones(1, dtype=torch.uint8).cuda(), want_d2=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(rd(np.float64, 7), pose_a.cpu().numpy()[0]) and not torch.equal(pose_a, pose)
+    assert np.array_equal(rd(np.float64, M * 3).reshape(M, 3), Xw_a.cpu().numpy()[0])
+    assert np.array_equal(rd(np.int32, M), assoc_a.cpu().numpy()[0])
     # the same host-buffer path from Python (api.HostFramePath: pinned staging, enqueued copies, one synchronize)
     hp = api.HostFramePath(ctx, g, cam, prm, M)
     for _ in range(2):  # the staging buffers are reused between frames

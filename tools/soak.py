@@ -34,8 +34,8 @@ ctx = gmmloc_amd.Context(0)
 cam, prm = api.Camera(), api.Params()
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 gts = sc.load_gt()
-count = dict(chain=0, chain_fallback=0, tri=0, tri_rejected=0, tri_far=0, track=0, pose=0, ba=0, shape=0)
-checked = dict(chain=0, tri=0, track=0, pose=0, ba=0, shape=0)
+count = dict(chain=0, chain_fallback=0, tri=0, tri_rejected=0, tri_far=0, track=0, track_prior=0, pose=0, ba=0, shape=0)
+checked = dict(chain=0, tri=0, track=0, track_prior=0, pose=0, ba=0, shape=0)
 t0 = time.time()
 
 
@@ -126,6 +126,26 @@ for mapname in args.maps.split(","):
                 report("track", mapname, r, "M %d pose |dt| %.3g m |dr| %.3g rad, associations equal %s, chi2 equal %s"
                        % (len(ft["octave"]), dt, dr, a_ok, d_ok), pose_gpu=pose.cpu().numpy()[0], Xw_gpu=Xw.cpu().numpy()[0],
                        assoc_gpu=assoc.cpu().numpy()[0])
+            # ---- the same frame anchored by the prior edge (gl_track_frames_anchored), both launch shapes
+            one = torch.ones(1, dtype=torch.uint8).cuda()
+            res_p = []
+            for shape in (-1, 0):
+                ctx.set_option("ba_shape", shape)
+                pose_p, Xw_p = T(ft["pose_init"][None]), T(ft["Xw"][None])
+                assoc_p, _, _ = gmmloc_amd.track_frames_anchored(ctx, g, cam, prm, pose_p, Xw_p, T(ft["obs"][None]), T(ft["octave"][None]), prior=one)
+                torch.cuda.synchronize()
+                res_p.append((pose_p, Xw_p, assoc_p))
+            ctx.set_option("ba_shape", -1)
+            checked["shape"] += 1
+            if not all(torch.equal(x, y) for x, y in zip(res_p[0], res_p[1])):
+                report("shape", mapname, r, "gl_track_frames_anchored: batch shape and latency shape differ in bits")
+            keepf, p_ref, pts_ref, a_ref, _, _ = sc.track_oracle(orc, h, cam, ft, prior=True)
+            dt, dr = pose_err(res_p[0][0].cpu().numpy()[0], p_ref)
+            checked["track_prior"] += 1
+            a_ok = np.array_equal(res_p[0][2].cpu().numpy()[0][keepf], a_ref)
+            if not (dt < 1e-6 and dr < 1e-6 and a_ok):
+                report("track_prior", mapname, r, "M %d pose |dt| %.3g m |dr| %.3g rad, associations equal %s" % (len(ft["octave"]), dt, dr, a_ok),
+                       pose_gpu=res_p[0][0].cpu().numpy()[0], Xw_gpu=res_p[0][1].cpu().numpy()[0], assoc_gpu=res_p[0][2].cpu().numpy()[0])
         # ---- optimizeCurrentPose
         fp = c["pose"]
         pose = T(fp["pose_init"][None])
@@ -156,6 +176,7 @@ g = gmmloc_amd.GMM(ctx, mean, cov, prm)
 h = orc.gmm_create(mean, cov)
 for b in sc.gen_ba(max(10, rounds // 4), mean, cov, gts, cam):
     ctx.set_option("bagen_nb", b["nb"])
+    ctx.set_option("bagen_mode", 2 if b["r"] % 2 else 1)  # odd rounds: the pipelined shape (a kernel per phase)
     p = b["problem"]
     idx, d2 = orc.associate3d(h, p["points"])
     a = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
@@ -168,14 +189,15 @@ for b in sc.gen_ba(max(10, rounds // 4), mean, cov, gts, cam):
     stereo = np.array([(p["obs_uvr"][p["obs_ptr"][l]:p["obs_ptr"][l + 1], 2] >= 0).any() for l in range(len(p["points"]))])
     dpts = np.abs(res[1][0] - ref[1])[stereo].max() if stereo.any() else 0.0
     if not (dpose < 1e-6 and dec_ok and dpts < 1e-5):
-        report("ba", "map_v1", b["r"], "P %d F %d L %d NB %d prior %s: pose %.3g, decisions equal %s, stereo points %.3g"
-               % (b["P"], b["F"], b["L"], b["nb"], b["prior"], dpose, dec_ok, dpts),
+        report("ba", "map_v1", b["r"], "P %d F %d L %d %s prior %s: pose %.3g, decisions equal %s, stereo points %.3g"
+               % (b["P"], b["F"], b["L"], "pipelined" if b["r"] % 2 else "NB %d" % b["nb"], b["prior"], dpose, dec_ok, dpts),
                poses_gpu=res[0][0], points_gpu=res[1][0], dropped_gpu=res[2][0], erase_gpu=res[3][0], iters_gpu=res[4][0])
     elif abs(int(res[4][0]) - ref[4]) > 8:
         # not an output of jointOptimization: the last optimize(40) ends after 10 failed trials at convergence, where the
         # sign of rho is rounding noise - the count is not a stable quantity across summation orders (results above equal)
         notes.append("ba r%d: %d vs %d outer iterations of the last optimize(40), results equal to %.1e" % (b["r"], int(res[4][0]), ref[4], dpose))
 ctx.set_option("bagen_nb", 0)
+ctx.set_option("bagen_mode", 0)
 orc.gmm_destroy(h)
 for n in notes:
     print("NOTE", n)

@@ -72,9 +72,10 @@ def gen_ba(nrounds, mean, cov, gts, cam):
     return out
 
 
-def track_oracle(orc, h, cam, f, perm=None):
+def track_oracle(orc, h, cam, f, perm=None, prior=False):
     """oracle associate3d + single-pose joint_optimization of frame f; `perm` re-orders the points first
-    (the mathematics is order-free, the floating-point sums are not)."""
+    (the mathematics is order-free, the floating-point sums are not); prior: with the prior edge on the pose
+    (gl_track_frames_anchored)."""
     keep = np.nonzero(f["octave"] >= 0)[0]
     if perm is not None:
         keep = keep[perm]
@@ -83,7 +84,7 @@ def track_oracle(orc, h, cam, f, perm=None):
     assoc = np.where(d2 <= 9.0, idx, -1).astype(np.int32)
     L = len(keep)
     poses, pts, dropped, erase, it = orc.joint_optimization(
-        h, cam, 1, 0, f["pose_init"][None], np.zeros(1, np.uint8), Xw, assoc, np.arange(L + 1, dtype=np.int32),
+        h, cam, 1, 0, f["pose_init"][None], np.full(1, 1 if prior else 0, np.uint8), Xw, assoc, np.arange(L + 1, dtype=np.int32),
         np.zeros(L, np.int32), f["obs"][keep], f["octave"][keep])
     final = np.where(dropped == 1, -1, assoc)
     return keep, poses[0], pts, final, idx, d2
