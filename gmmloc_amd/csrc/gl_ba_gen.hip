@@ -945,9 +945,75 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
   __syncthreads();
   return *s_flag != 0;
 }
+// n <= NMAX <= 48 (up to 8 free poses), round 3: the whole factorisation on ONE WAVE, lane r = row r held in registers
+// (NMAX doubles), no barrier and no LDS inside: per pivot k the pivot and the column's elements of the rows below travel as
+// v_readlane broadcasts (A[j][k] is register k of lane j - static indices in the unrolled code) and every lane updates its own
+// row, S[r][j] -= l_rk S[j][k] in ascending k like the scalar loop; the forward substitution rides along, z = D^-1 y by
+// division, L^T x = z as 48 wave sums.  ~4 300 instructions on one wave against the blocked algorithm's 8 x (3 barriers +
+// a one-wave diagonal block + panel + register-tile update).  MEASURED (profiles/r3_bagen_shapes.txt), NOT ENABLED (-DGL_BAGEN_WAVE_LDLT): in
+// the pipelined shape's solve kernel a window of 8 + 4 key-frames goes 2.96 -> 2.90 ms; inlined into the persistent kernel the
+// 48-register rows take it from 272 to 809 spilled VGPRs and the same window from 2.87 to 3.65 ms.
+// Rows n .. NMAX-1 are identity padding (they cost their share of the unrolled code: two instances, 24 and 48).
+template <int NMAX>
+GL_DEV bool ldlt_solve_wave(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, double* g, int n,
+                            int* s_flag, const double* yv) {
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x & 63, rr = min(r, n - 1);
+    double a[NMAX], y = r < n ? yv[rr] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+      double v = (c == r) ? 1.0 : 0.0;  // identity padding beyond the system
+      if (r < n && c <= r) {
+        v = src[(size_t)r * lsrc + c];
+        if (fuse && c >= 6 * (r / 6)) v = diag_terms(G, k, lambda, r, c, v);
+      }
+      a[c] = v;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int kk = 0; kk < NMAX; ++kk) {
+      const double d = readlane_f64(a[kk], kk);
+      bad = bad || d == 0.0 || !isfinite(d);
+      const double yk = readlane_f64(y, kk);
+      const double l = a[kk] * (1.0 / d);  // l_rk of this lane's row (meaningful for r > k)
+#pragma unroll
+      for (int j = kk + 1; j < NMAX; ++j) a[j] = __builtin_fma(-l, readlane_f64(a[kk], j), a[j]);  // (entries right of the diagonal: never read)
+      if (r > kk) {
+        y = __builtin_fma(-l, yk, y);
+        a[kk] = l;
+      }
+    }
+    // z = D^-1 y (division, like the reference LDL^T); a[r] of lane r is d_r
+    double dr = 1.0;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c)
+      if (c == r) dr = a[c];
+    double x = y / dr;
+    // L^T x = z: x_k = z_k - sum_{r > k} l_rk x_r, k descending; lane r holds l_rk (register k) and x_r
+#pragma unroll
+    for (int kk = NMAX - 2; kk >= 0; --kk) {
+      double t = r > kk ? a[kk] * x : 0.0;
+      t += dpp_f64<0xB1>(t);   // lane ^ 1
+      t += dpp_f64<0x4E>(t);   // lane ^ 2
+      t += dpp_f64<0x141>(t);  // lane ^ 7  (row_half_mirror)
+      t += dpp_f64<0x140>(t);  // lane ^ 15 (row_mirror): every lane of a row of 16 holds the row's sum
+      const double tot = (readlane_f64(t, 0) + readlane_f64(t, 16)) + (readlane_f64(t, 32) + readlane_f64(t, 48));
+      if (r == kk) x -= tot;
+    }
+    if (r < n) g[r] = x;
+    if (r == 0) *s_flag = bad ? 0 : 1;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
 template <class SP>
 GL_DEV bool ldlt_solve_small(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
                              double* g, int n, int* s_flag, double* idg) {
+#ifdef GL_BAGEN_WAVE_LDLT  // (measured, not the default: see ldlt_solve_wave)
+  if (n <= 24) return ldlt_solve_wave<24>(G, k, lambda, src, lsrc, fuse, g, n, s_flag, idg + 128);
+  if (n <= 48) return ldlt_solve_wave<48>(G, k, lambda, src, lsrc, fuse, g, n, s_flag, idg + 128);
+#endif
   if (n <= 32) return ldlt_solve_tiles<2>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
   if (n <= 48) return ldlt_solve_tiles<3>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
   if (n <= 80) return ldlt_solve_tiles<5>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
