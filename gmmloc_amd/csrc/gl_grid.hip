@@ -47,6 +47,7 @@ struct GridDev {
   const int32_t* ptr;
   const int32_t* idx;
   const int32_t* glob;
+  const int4* cell4;
 };
 
 // lexicographic (chi2, index) minimum: the all-pairs sweep keeps the FIRST index of the minimum
@@ -80,10 +81,24 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
                       fz < (double)G.dim[2];  // false for NaN
   if (inside) {
     const int c = ((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx;
-    const int e0 = G.ptr[c], e1 = G.ptr[c + 1];
-    for (int e = e0; e < e1; ++e) {
-      const int k = G.idx[e];
-      upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
+    if (G.cell4) {  // packed cell: the list of up to three candidates arrives with the count (ascending, like the CSR list)
+      const int4 q = G.cell4[c];
+      if (q.x <= 3) {
+        if (q.x > 0) upd_min(chi2_rec(rec12 + (size_t)q.y * 12, x, y, z), q.y, best, bi);
+        if (q.x > 1) upd_min(chi2_rec(rec12 + (size_t)q.z * 12, x, y, z), q.z, best, bi);
+        if (q.x > 2) upd_min(chi2_rec(rec12 + (size_t)q.w * 12, x, y, z), q.w, best, bi);
+      } else {
+        for (int e = q.y; e < q.y + q.x; ++e) {
+          const int k = G.idx[e];
+          upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
+        }
+      }
+    } else {
+      const int e0 = G.ptr[c], e1 = G.ptr[c + 1];
+      for (int e = e0; e < e1; ++e) {
+        const int k = G.idx[e];
+        upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
+      }
     }
   }
   if (best <= G.t_resolve) {
@@ -184,6 +199,21 @@ __global__ void k_index_csr(const unsigned long long* __restrict__ keys, size_t 
     ptr[i] = (int32_t)lo;
   }
 }
+// packed cells from the CSR: {count, i0, i1, i2} for lists of up to three, {count, offset, 0, 0} above
+__global__ void k_index_pack(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, size_t ncell, int4* __restrict__ cell4) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int e0 = ptr[c], n = ptr[c + 1] - e0;
+  int4 q = make_int4(n, 0, 0, 0);
+  if (n > 3) {
+    q.y = e0;
+  } else {
+    if (n > 0) q.y = idx[e0];
+    if (n > 1) q.z = idx[e0 + 1];
+    if (n > 2) q.w = idx[e0 + 2];
+  }
+  cell4[c] = q;
+}
 // sum over the registered components of the list length at their own mean (does the index prune?)
 __global__ void k_index_mean_lists(const CompReg* __restrict__ regs, int nreg, GridGeom gg, const int32_t* __restrict__ ptr,
                                    unsigned long long* __restrict__ sum) {
@@ -254,6 +284,7 @@ void free_cell_index(Gmm* g) {
   if (g->grid.ptr) (void)hipFree(g->grid.ptr);
   if (g->grid.idx) (void)hipFree(g->grid.idx);
   if (g->grid.glob) (void)hipFree(g->grid.glob);
+  if (g->grid.cell4) (void)hipFree(g->grid.cell4);
   g->grid = CellIndex();
 }
 
@@ -456,6 +487,19 @@ int build_cell_index(Ctx* c, Gmm* g) {
   G.nglob = (int)glob.size();
   G.nnz = (size_t)nnz;
   G.ncell = ncell;
+  G.cell4 = nullptr;
+  if (ncell * 16 <= ((size_t)1 << 29) && !getenv("GMMLOC_ASSOC_NOPACK")) {  // (512 MB budget; the bench map: 11 M cells = 176 MB)
+    if (hipMalloc(&G.cell4, ncell * 16) == hipSuccess) {
+      k_index_pack<<<(unsigned)((ncell + 255) / 256), 256, 0, c->stream>>>(d_ptr, d_idx, ncell, (int4*)G.cell4);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(G.cell4);
+        G.cell4 = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      G.cell4 = nullptr;
+    }
+  }
   G.enabled = true;
   return GL_OK;
 }
@@ -478,6 +522,7 @@ static GridDev grid_dev(const CellIndex& I) {
   G.ptr = I.ptr;
   G.idx = I.idx;
   G.glob = I.glob;
+  G.cell4 = (const int4*)I.cell4;
   return G;
 }
 

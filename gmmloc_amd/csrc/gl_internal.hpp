@@ -52,6 +52,9 @@ struct CellIndex {
   int32_t* ptr = nullptr;   // ncell + 1
   int32_t* idx = nullptr;   // nnz, ascending within a cell
   int32_t* glob = nullptr;  // nglob, ascending
+  // packed cells (round 3): {count, then the list itself when count <= 3, else the offset into idx}: ONE random 16-byte
+  // read per point where ptr[c], ptr[c + 1] and idx[...] are two (the kernel is bound by the fabric's random sectors)
+  void* cell4 = nullptr;    // ncell x int4, or null (table above the memory budget)
 };
 
 struct Gmm {

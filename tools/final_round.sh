@@ -1,0 +1,18 @@
+#!/bin/bash
+# Everything the round's numbers come from, on one box: tools/final_round.sh <tag>   -> gpurun_out/<tag>_*
+set -u
+TAG=${1:-r3}
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt
+python tools/kernel_meta.py > gpurun_out/${TAG}_kernel_meta.txt 2>&1
+bash tools/profile_bench.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
+python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
+python tools/run_configs.py --configs 2,3,4,5,ba,kf,match > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err
+python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>/dev/null
+python tools/replay_euroc.py --anchor prior > gpurun_out/${TAG}_replay_euroc.json 2>/dev/null
+ANCHORS="none prior" SIGMAS="0" bash tools/replay_matrix.sh > gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
+ANCHORS="fixed" SIGMAS="0 0.02" EXTRA="--limit 400" bash tools/replay_matrix.sh >> gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
+python tools/ba_time.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_time.txt
+python tools/soak.py 2000 > gpurun_out/${TAG}_soak_strict.txt 2>&1
+tail -2 gpurun_out/${TAG}_soak_strict.txt | cut -c1-500
+cat gpurun_out/${TAG}_gpu_tests.txt
