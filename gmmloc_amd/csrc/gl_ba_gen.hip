@@ -30,7 +30,7 @@ using namespace glba;
 
 namespace {
 
-#ifdef GL_BAGEN_PROF  // phase cycles of workgroup 0 (tools/prof_bagen.py)
+#if defined(GL_BAGEN_PROF) || defined(GL_PIPE_PROF)  // phase cycles of workgroup 0 (tools/prof_bagen.py)
 __device__ unsigned long long g_gprof[12];
 #define GP_T(v) const long long v = clock64()
 #define GP_ADD(slot, a, b) if (blockIdx.x == 0 && threadIdx.x == 0) g_gprof[slot] += (unsigned long long)((b) - (a))
@@ -856,9 +856,93 @@ GL_DEV void ldlt_backward(SP S, int ld, int n, const double* idg, double* yv, do
   if (tid < n) g[tid] = yv[tid];
 }
 
+// Diagonal block AND panel of a pose in one phase (the solve kernel of the pipelined shape): the panel rows do, per pivot, exactly
+// what the rows of the block below the pivot do - l_rc = a_rc / d_c from the broadcast pivot, a_rj -= l_rc a_jc with the
+// broadcast column entries of the block's rows, y_r -= l_rc y_c - so they ride in the spare lanes: every wave keeps the six rows
+// of the block in its lanes 0 .. 5 (redundantly) and 58 panel rows in the others.  One phase and one barrier less per pose, and
+// the panel's own pass (0.6 - 0.7 k cycles) is gone; the operands and their order per element are those of ldlt_diag_block_wave
+// + ldlt_panel_row.  The block's own rows and y leave wave 0 AFTER the barrier that follows (ad / yd): the other waves read them
+// at their start.
+template <class SP>
+GL_DEV void ldlt_diag_panel_wave(SP S, int ld, int base, int n, double* idg, double* yv, int* s_flag, double* ad, double& yd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool isd = lane < 6;
+  const int prow = base + 6 + wave * 58 + (lane - 6);
+  const int row = isd ? base + lane : prow, rr = min(row, n - 1);
+  double a[6], id[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) a[c] = (!isd || c <= lane) ? S[(size_t)rr * ld + base + c] : 0.0;
+  double y = yv[rr];
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double d = readlane_f64(a[c], c);
+    bad = bad || d == 0.0 || !isfinite(d);
+    id[c] = 1.0 / d;
+    const double yc = readlane_f64(y, c);
+    const double ci = a[c] * id[c];
+#pragma unroll
+    for (int j = c + 1; j < 6; ++j) {
+      const double ajc = readlane_f64(a[c], j);  // a[j][c] of the block
+      if (!isd || lane >= j) a[j] -= ci * ajc;
+    }
+    if (!isd || lane > c) y = __builtin_fma(-ci, yc, y);
+  }
+  if (!isd && prow < n) {
+#pragma unroll
+    for (int c = 1; c < 6; ++c) S[(size_t)prow * ld + base + c] = a[c];
+    yv[prow] = y;
+  }
+  if (wave == 0 && lane == 0) {  // (the reciprocal pivots are wave-uniform)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) idg[base + c] = id[c];
+    if (bad) *s_flag = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) ad[c] = a[c];
+  yd = y;
+}
+// L^T x = z on ONE WAVE, no barrier: lane r holds rows r and r + 64; x_k travels as a v_readlane broadcast in descending k and
+// every row above takes  y_r -= (S[k][r] / d_r) x_k  - the plain substitution, operand for operand what ldlt_backward does by
+// pose blocks with two workgroup barriers per block (0.9 k cycles per block: a sixth to a third of the whole solve).
+template <class SP>
+GL_DEV void ldlt_backward_wave(SP S, int ld, int n, const double* idg, double* yv, double* g) {
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x, r0 = min(r, n - 1), r1 = min(r + 64, n - 1);
+    double y0 = yv[r0] / S[(size_t)r0 * ld + r0];  // z = D^-1 y by division, like the reference LDL^T
+    double y1 = yv[r1] / S[(size_t)r1 * ld + r1];
+    const double ir0 = idg[r0], ir1 = idg[r1];
+    int k = n - 1;
+    for (; k >= 64; --k) {
+      const double s0 = S[(size_t)k * ld + r0], s1 = S[(size_t)k * ld + r1];
+      const double xk = readlane_f64(y1, k - 64);
+      if (r + 64 < k) y1 = __builtin_fma(-(s1 * ir1), xk, y1);
+      y0 = __builtin_fma(-(s0 * ir0), xk, y0);
+    }
+    for (; k >= 4; k -= 4) {  // (the four column entries requested before the dependent chain)
+      double sk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sk[q] = S[(size_t)(k - q) * ld + r0] * ir0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double xk = readlane_f64(y0, k - q);
+        if (r < k - q) y0 = __builtin_fma(-sk[q], xk, y0);
+      }
+    }
+    for (; k >= 1; --k) {
+      const double s0 = S[(size_t)k * ld + r0] * ir0;
+      const double xk = readlane_f64(y0, k);
+      if (r < k) y0 = __builtin_fma(-s0, xk, y0);
+    }
+    if (r < n) g[r] = y0;
+    if (r + 64 < n) g[r + 64] = y1;
+  }
+}
+
 // n <= 16 A <= 128, n a multiple of 6.  src (row stride lsrc): the assembled system, global memory or the work matrix
-// itself; fuse: add the diagonal terms while loading.  The right-hand side is in yv = idg + 128 (put there by the caller).
-template <int A, class SP>
+// itself; fuse: add the diagonal terms while loading.  V = 1 (the solve kernel of the pipelined shape): diagonal block and panel
+// in one phase, one-wave backward substitution - same operands and order per element, so the same bits.  The right-hand side is in yv = idg + 128 (put there by the caller).
+template <int A, int V, class SP>
 GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
                              double* g, int n, int* s_flag, double* idg) {
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
@@ -899,16 +983,29 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       }
     }
     __syncthreads();
+    GP_T(qa);
+    GP_ADD(8, q0, qa);
+    double ad[6], yd = 0.0;
+    if (V == 1) {
+      ldlt_diag_panel_wave(S, ld, base, n, idg, yv, s_flag, ad, yd);
+    } else {
 #ifdef GL_BAGEN_NO_WAVEDIAG
-    if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
+      if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
 #else
-    if (tid < 64) ldlt_diag_block_wave(S, ld, base, idg, yv, s_flag);
+      if (tid < 64) ldlt_diag_block_wave(S, ld, base, idg, yv, s_flag);
 #endif
-    __syncthreads();
+      __syncthreads();
+    }
     GP_T(q1);
-    if (m0 + tid < n) ldlt_panel_row(S, ld, base, m0 + tid, idg, yv);
+    if (V != 1 && m0 + tid < n) ldlt_panel_row(S, ld, base, m0 + tid, idg, yv);
     __syncthreads();
     GP_T(q2);
+    if (V == 1 && tid < 6) {  // the block's own rows (nobody reads them before the backward substitution)
+      yv[base + tid] = yd;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        if (c <= tid) S[(size_t)(base + tid) * ld + base + c] = ad[c];
+    }
     double idc[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) idc[c] = idg[base + c];
@@ -939,10 +1036,18 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       }
     }
     GP_T(q3);
-    GP_ADD(9, q0, q1); GP_ADD(11, q2, q3);
+    GP_ADD(9, qa, q1); GP_ADD(10, q1, q2); GP_ADD(11, q2, q3);
   }
-  ldlt_backward(S, ld, n, idg, yv, g);
+  GP_T(qb0);
+  if (V == 1) {
+    __syncthreads();  // (the last block's rows)
+    ldlt_backward_wave(S, ld, n, idg, yv, g);
+  } else {
+    ldlt_backward(S, ld, n, idg, yv, g);
+  }
   __syncthreads();
+  GP_T(qb1);
+  GP_ADD(7, qb0, qb1);
   return *s_flag != 0;
 }
 // n <= NMAX <= 48 (up to 8 free poses), round 3: the whole factorisation on ONE WAVE, lane r = row r held in registers
@@ -1007,17 +1112,17 @@ GL_DEV bool ldlt_solve_wave(const GenP& G, const BaK& k, double lambda, const do
   return *s_flag != 0;
 }
 
-template <class SP>
+template <int V = 0, class SP>
 GL_DEV bool ldlt_solve_small(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
                              double* g, int n, int* s_flag, double* idg) {
 #ifdef GL_BAGEN_WAVE_LDLT  // (measured, not the default: see ldlt_solve_wave)
   if (n <= 24) return ldlt_solve_wave<24>(G, k, lambda, src, lsrc, fuse, g, n, s_flag, idg + 128);
   if (n <= 48) return ldlt_solve_wave<48>(G, k, lambda, src, lsrc, fuse, g, n, s_flag, idg + 128);
 #endif
-  if (n <= 32) return ldlt_solve_tiles<2>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
-  if (n <= 48) return ldlt_solve_tiles<3>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
-  if (n <= 80) return ldlt_solve_tiles<5>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
-  return ldlt_solve_tiles<8>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 32) return ldlt_solve_tiles<2, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 48) return ldlt_solve_tiles<3, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 80) return ldlt_solve_tiles<5, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  return ldlt_solve_tiles<8, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
 }
 
 // n > 128 (more than 21 free poses): scalar pivots, ONE barrier per pivot, on the matrix in memory; g in, x out
@@ -1510,11 +1615,12 @@ struct PipeSt {  // per problem, in global memory
   int qmax;      // trials of the outer iteration so far
   int cj;        // outer iterations completed in the stage
   int init;      // 1: the next cycle is the computeLambdaInit pass of the stage (no solve, no trial)
-  int skip;      // 1: this cycle's trial / decide kernels have nothing to do (an init cycle)
+  int pend;      // 1: a trial state has been evaluated (solve + trial of this cycle); the next cycle's first kernel judges it
+  int adv;       // 1: the stage is over (decided at the head of this cycle): the solve kernel runs the gate / opens the next stage
   int any_point, any_pose, ok;
   int trials, done_iters, stop_seen, it3;
 #ifdef GL_PIPE_PROF
-  long long dbg[8];
+  long long dbg[16];
 #endif
   int chunk_len;  // entries of a pose's list per wave of the Schur pass: ceil(longest list / nchunk), a multiple of 64
   double lambda, ni, currentChi, chiA, rho;
@@ -1538,7 +1644,9 @@ struct PipeA {  // kernel arguments (by value)
   const int32_t* stop;
   char* scratch;      // | B x 512 B headers | per-problem areas |  (the layout of k_ba_gen)
   size_t per;
-  PipeSt* st;         // B
+  PipeSt* st;         // 2 x B: a cycle of parity `par` reads [par] (the state its predecessor left) in its first kernel, which
+                      // writes the judged state to [par ^ 1]; the rest of the cycle works on [par ^ 1]
+  int par;
   double* partA;      // B x nba x 2   {robust chi2, max point diagonal} per workgroup of the point pass
   double* partD;      // B x nba x 2   {scale part, chi2 at the trial state}
   double* partS;      // B x nblk x nchunk x 48
@@ -1546,6 +1654,8 @@ struct PipeA {  // kernel arguments (by value)
   int* arrive;        // B x nblk: waves of the Schur pass that have delivered their chunk of a block (back to 0 by the last)
   int nba, lpp, nblk, nchunk;
 };
+GL_DEV PipeSt* st_cur(const PipeA& a, int f) { return a.st + (size_t)(a.par ^ 1) * a.B + f; }
+GL_DEV const PipeSt* st_prev(const PipeA& a, int f) { return a.st + (size_t)a.par * a.B + f; }
 GL_DEV void genp_init(GenP& G, const PipeA& a, int f, int NB, int pb) {
   const int P = a.P, F = a.F, L = a.L, NOBS = a.NOBS, n = 6 * P;
   G.NB = NB;
@@ -1660,13 +1770,13 @@ GL_DEV void pipe_census(const BaK& k, GenP& G, PipeSt* st, int* s_cnt) {
   __syncthreads();
 }
 // prior edges at the current state (once per outer iteration: gen_optimize does the same)
-GL_DEV void pipe_priors(const BaK& k, GenP& G) {
+GL_DEV void pipe_priors(const BaK& k, GenP& G, const double* poses) {
   const int NT = blockDim.x;
   for (int j = threadIdx.x; j < G.P; j += NT) {
     double H[36], b[6] = {0, 0, 0, 0, 0, 0}, chi = 0.0;
     for (int r = 0; r < 36; ++r) H[r] = 0.0;
     if (G.pact[j] && G.prior[j] && k.first_as_prior)
-      chi = prior_terms(se3_load(G.pinv + (size_t)j * 7), se3_load(G.poses + (size_t)j * 7), true, H, b);
+      chi = prior_terms(se3_load(G.pinv + (size_t)j * 7), se3_load(poses + (size_t)j * 7), true, H, b);
     for (int r = 0; r < 36; ++r) G.prH[(size_t)j * 36 + r] = H[r];
     for (int r = 0; r < 6; ++r) G.prb[(size_t)j * 6 + r] = b[r];
     G.pchi[j] = chi;
@@ -1685,10 +1795,11 @@ GL_DEV bool pipe_open_stage(const BaK& k, GenP& G, PipeSt* st, int* s_cnt) {
     st->qmax = 0;
     st->cj = 0;
     st->init = 1;
-    st->skip = 0;
+    st->pend = 0;
+    st->adv = 0;
     st->rho = 0.0;
   }
-  if (run) pipe_priors(k, G);
+  if (run) pipe_priors(k, G, G.poses);
   __syncthreads();
   return run;
 }
@@ -1773,11 +1884,11 @@ __global__ __launch_bounds__(T_BA) void kp_setup_init(PipeA a) {
   const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, tid = threadIdx.x, P = a.P, F = a.F, L = a.L;
   GenP G;
   genp_init(G, a, f, a.nba, pb);
-  PipeSt* st = a.st + f;
+  PipeSt* st = st_cur(a, f);  // (the set-up kernels are launched with par = 1: buffer 0, which cycle 0 reads)
   if (pb == 0) {
     if (tid == 0) {
 #ifdef GL_PIPE_PROF
-      for (int i = 0; i < 8; ++i) st->dbg[i] = 0;
+      for (int i = 0; i < 16; ++i) st->dbg[i] = 0;
 #endif
       const int sw = a.stop ? stop_word_load(a.stop) : 0;
       st->stage = sw > 0 ? 3 : 0;  // `if (pbStopFlag) if (*pbStopFlag) return;` (:765-767): nothing is written
@@ -1820,7 +1931,7 @@ __global__ __launch_bounds__(T_BA) void kp_setup_lists(PipeA a, int nws) {
   const int lane = threadIdx.x & 63;
   const long gw = (long)blockIdx.x * NW_BA + (threadIdx.x >> 6);
   const int f = (int)(gw / nws), w = (int)(gw % nws);
-  if (f >= a.B || a.st[f].stage >= 3) return;
+  if (f >= a.B || st_cur(a, f)->stage >= 3) return;
   GenP G;
   genp_init(G, a, f, 1, 0);
   const int P = a.P, nobs = G.nobs;
@@ -1846,7 +1957,7 @@ __global__ __launch_bounds__(T_BA) void kp_setup_lists(PipeA a, int nws) {
 // (3) counts -> list positions (exclusive scan in (pose, wave) order), pl_ptr, the chunk length of the Schur pass
 __global__ __launch_bounds__(T_BA) void kp_setup_scan(PipeA a, int nws) {
   const int f = blockIdx.x, tid = threadIdx.x, P = a.P;
-  PipeSt* st = a.st + f;
+  PipeSt* st = st_cur(a, f);
   if (st->stage >= 3) return;
   GenP G;
   genp_init(G, a, f, 1, 0);
@@ -1880,7 +1991,7 @@ __global__ __launch_bounds__(T_BA) void kp_setup_scan(PipeA a, int nws) {
 // (5) partner table, by list position: entry (e, j2) = the observation of the same point in free pose j2
 __global__ __launch_bounds__(T_BA) void kp_setup_partner(PipeA a) {
   const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, P = a.P;
-  if (a.st[f].stage >= 3) return;
+  if (st_cur(a, f)->stage >= 3) return;
   GenP G;
   genp_init(G, a, f, a.nba, pb);
   for (int l = GSTART; l < a.L; l += GSTRIDE)
@@ -1897,25 +2008,143 @@ __global__ __launch_bounds__(T_BA) void kp_setup_partner(PipeA a) {
 __global__ __launch_bounds__(512) void kp_setup_open(PipeA a) {
   __shared__ int s_cnt[2];
   const int f = blockIdx.x;
-  PipeSt* st = a.st + f;
+  PipeSt* st = st_cur(a, f);
   if (st->stage >= 3) return;
   GenP G;
   genp_init(G, a, f, 1, 0);
   if (!pipe_open_stage(a.k, G, st, s_cnt)) pipe_advance(a, G, st, f, s_cnt);
 }
 
-// ---- P1: point pass (linearise the observations, point blocks), nba workgroups per problem ------------------------
+// ---- head of a cycle: the trial of the previous cycle is JUDGED (accept / reject, lambda, loop control: the arithmetic of
+// SparseOptimizer / OptimizationAlgorithmLevenberg in k_ba_gen's order), then P1: point pass (linearise the observations, point
+// blocks); nba workgroups per problem.  Every workgroup judges for itself - the sums it needs are a few hundred doubles, added in
+// index order by one thread - and applies the verdict to what it is about to read: its own 64 points (trial -> current on
+// acceptance) and an LDS copy of the poses (trial poses of the free key-frames on acceptance).  Workgroup 0 also writes the
+// state word of this cycle, the accepted poses and, at the start of an outer iteration, the prior edges.  (A separate
+// one-workgroup kernel did this at first: 13 - 23 us per cycle, most of it its own launch floor and the copy of every point.)
+GL_DEV void pipe_judge(const PipeA& a, const GenP& G, const PipeSt& in, PipeSt& q, const double* s_d, int* accept, int* next) {
+  const int P = a.P, n = 6 * P;
+  double scale = 0.0, tempChi = 0.0;
+  for (int w = 0; w < a.nba; ++w) {
+    scale += s_d[2 * w];
+    tempChi += s_d[2 * w + 1];
+  }
+  const double* dxs = s_d + 2 * a.nba;
+  const double* bps = dxs + n;
+  const double* pc2 = bps + n;
+  q = in;
+  const double lambda = q.lambda;
+  if (q.qmax == 0) q.currentChi = q.chiA;
+  for (int j = 0; j < P; ++j) tempChi += pc2[j];
+  for (int i = 0; i < n; ++i) scale += dxs[i] * (lambda * dxs[i] + bps[i]);
+  if (!q.ok) tempChi = 1.7976931348623157e308;
+  scale += 1e-3;
+  const double rho = (q.currentChi - tempChi) / scale;
+  const bool acc = rho > 0 && isfinite(tempChi);
+  if (acc) {
+    const double uu = 2 * rho - 1;
+    double alpha = 1. - uu * uu * uu;
+    alpha = fmin(alpha, 2. / 3.);
+    q.lambda = lambda * fmax(1. / 3., alpha);
+    q.ni = 2;
+    q.currentChi = tempChi;
+  } else {
+    q.lambda = lambda * q.ni;
+    q.ni *= 2;
+  }
+  q.rho = rho;
+  q.qmax += 1;
+  q.trials += 1;
+  int nx = 0;  // 0 retry, 1 next outer iteration, 2 stage over
+  if (!(rho < 0 && q.qmax < 10 && !(q.stop_seen > 0))) {  // the outer iteration is over
+    q.cj += 1;
+    q.done_iters += 1;
+    q.it += 1;
+    nx = (q.qmax == 10 || rho == 0 || q.it >= q.iters_max || pipe_stop_now(&q)) ? 2 : 1;
+    q.qmax = 0;
+  }
+  q.pend = 0;
+  q.adv = nx == 2 ? 1 : 0;
+  *accept = acc ? 1 : 0;
+  *next = nx;
+}
+constexpr int PIPE_JUDGE_MAX = 2 * 256 + 2 * 132 + 24;  // partials of <= 256 workgroups, dx and b_p of <= 22 poses, their prior chi2
 __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   __shared__ double red[NW_BA * 32 + 8];
-  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba;
-  const PipeSt* st = a.st + f;
-  if (st->stage >= 3) return;
+  __shared__ double s_d[PIPE_JUDGE_MAX];
+  __shared__ double s_Rt[32 * 12];
+  __shared__ PipeSt s_q;
+  __shared__ int s_accept, s_next;
+  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, tid = threadIdx.x, P = a.P, F = a.F, n = 6 * P;
+  const PipeSt* sp = st_prev(a, f);
+  PipeSt* sc = st_cur(a, f);
+  if (sp->stage >= 3) {  // finished: the state word travels on (both buffers must say so)
+    if (pb == 0 && tid == 0) *sc = *sp;
+    return;
+  }
   GenP G;
   genp_init(G, a, f, a.nba, pb);
+  const bool judge = sp->pend != 0;
+  const bool lds_ok = 2 * a.nba + 2 * n + P <= PIPE_JUDGE_MAX && P + F <= 32;  // (launch_ba_pipe only takes such windows)
+  if (judge && lds_ok) {  // every term of the two sums requested at once
+    for (int i = tid; i < 2 * a.nba; i += T_BA) s_d[i] = a.partD[(size_t)f * a.nba * 2 + i];
+    for (int i = tid; i < n; i += T_BA) {
+      s_d[2 * a.nba + i] = G.dxv[i];
+      s_d[2 * a.nba + n + i] = G.bp[i];
+    }
+    if (tid < P) s_d[2 * a.nba + 2 * n + tid] = G.pchi2[tid];
+  }
+  if (tid == 0 && !judge) {
+    s_q = *sp;
+    s_accept = 0;
+    s_next = -1;
+  }
+  __syncthreads();
+  if (tid == 0 && judge) {
+    PipeSt q;
+    int acc, nx;
+    pipe_judge(a, G, *sp, q, s_d, &acc, &nx);
+    s_q = q;
+    s_accept = acc;
+    s_next = nx;
+  }
+  __syncthreads();
+  const bool accept = s_accept != 0;
+  const int next = s_next;
+  // the poses this workgroup linearises at: LDS copy, trial poses of the active free key-frames on acceptance
+  for (int i = tid; i < (P + F) * 12; i += T_BA) {
+    const int j = i / 12;
+    s_Rt[i] = (accept && j < P && G.pact[j]) ? G.RtN[i] : G.Rt[i];
+  }
+  // its points: trial -> current
+  if (accept) {
+    const int per = T_BA / a.lpp;  // points of a workgroup per round of the point pass (pass_points: l = GSTART / LPP)
+    for (int l = pb * per + tid; l < G.L; l += a.nba * per) {
+      if (tid >= per) break;
+      if (!G.lact[l]) continue;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) G.pts[(size_t)l * 3 + i] = G.pn[(size_t)l * 3 + i];
+    }
+  }
+  if (pb == 0) {
+    if (accept) {
+      for (int j = tid; j < P; j += T_BA) {
+        if (!G.pact[j]) continue;
+        for (int r = 0; r < 7; ++r) G.poses[(size_t)j * 7 + r] = G.qN[(size_t)j * 7 + r];
+        for (int r = 0; r < 12; ++r) G.Rt[(size_t)j * 12 + r] = G.RtN[(size_t)j * 12 + r];
+      }
+    }
+    // the state the next outer iteration linearises the prior edges at (k_ba_gen: once per outer iteration)
+    if (next == 1) pipe_priors(a.k, G, accept ? G.qN : G.poses);
+    if (tid == 0) *sc = s_q;
+  }
+  __syncthreads();
+  if (s_q.adv) return;  // the stage is over: the solve kernel of this cycle runs the gate
+  G.Rt = s_Rt;
   double acc[32], md = 0.0;
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  acc[0] = pass_points_lpp(a.lpp, a.k, a.gm, G, st->stage < 2, st->init ? 0.0 : st->lambda, md);
+  acc[0] = pass_points_lpp(a.lpp, a.k, a.gm, G, s_q.stage < 2, s_q.init ? 0.0 : s_q.lambda, md);
   block_reduce<1, NW_BA>(acc, red);
   md = block_max(md, red);
   if (threadIdx.x == 0) {
@@ -1932,8 +2161,8 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
   const int per_prob = a.nblk * a.nchunk;
   const int f = (int)(gwave / per_prob), w = (int)(gwave % per_prob);
   if (f >= a.B) return;
-  const PipeSt* st = a.st + f;
-  if (st->stage >= 3) return;
+  const PipeSt* st = st_cur(a, f);
+  if (st->stage >= 3 || st->adv) return;
   const bool schur = !st->init;
   GenP G;
   genp_init(G, a, f, 1, 0);
@@ -2041,7 +2270,7 @@ __global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
   const long g = (long)blockIdx.x * T_BA + threadIdx.x;
   const int per_prob = a.nblk * 48;
   const int f = (int)(g / per_prob), r0 = (int)(g % per_prob), b = r0 / 48, sidx = r0 % 48;
-  if (f >= a.B || a.st[f].stage >= 3) return;
+  if (f >= a.B || st_cur(a, f)->stage >= 3 || st_cur(a, f)->adv) return;
   const int P = a.P, ld = 6 * P + GL_LD_PAD;
   int j1 = 0, rem = b;
   while (rem >= P - j1) {
@@ -2067,86 +2296,122 @@ __global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
   }
 }
 
-// ---- solve: assemble S / g from the chunk sums, (lambda init |) LDL^T, trial poses; one workgroup per problem ---------
+// ---- solve: (lambda init |) LDL^T of the assembled system, trial poses; at the end of a stage the gate / the next stage's
+// opening instead; one workgroup per problem.  The factorisation loads its register tiles straight from the assembled system
+// in global memory and adds the prior information / lambda / the unit diagonal of inactive poses on the way (diag_terms, as in
+// the persistent kernel): a copy into LDS with those terms added there cost 10 - 60 k cycles of the kernel's 65 - 210 k.
 __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ double red[NW_BA * 32 + 128 + 128];
+  __shared__ double s_part[2 * 256 + 24];
+  __shared__ double s_prH[22 * 36];  // prior information and the pose flags the factorisation adds / tests while it loads its tiles
+  __shared__ uint8_t s_pact[32], s_prior[32];
   __shared__ int s_flag;
+  __shared__ int s_cnt[2];
   const int f = blockIdx.x, tid = threadIdx.x, P = a.P, n = 6 * P;
-  PipeSt* st = a.st + f;
+  PipeSt* st = st_cur(a, f);
   if (st->stage >= 3) return;
   GenP G;
   genp_init(G, a, f, 1, 0);
+  if (st->adv) {  // the stage ended at the head of this cycle: gate, next stage (or the outputs)
+    pipe_advance(a, G, st, f, s_cnt);
+    if (tid == 0) {
+      st->adv = 0;
+      st->pend = 0;
+    }
+    return;
+  }
+#ifdef GL_PIPE_PROF
+  const long long s0 = clock64();
+#endif
   const int ld = G.ld;
   const bool small = n <= 128;
-  double* S = small ? dyn_lds : G.S;  // (n > 128: the scalar-pivot path factorises in global memory)
-  // the assembled system (lower triangle; blocks of inactive poses hold zeros) was written by the Schur pass
-  if (small)
-    for (int i = tid; i < n * n; i += T_BA) {
-      const int r = i / n, c = i - r * n;
-      if (c <= r) S[(size_t)r * ld + c] = G.S[(size_t)r * ld + c];
+  const bool init = st->init != 0;
+  const double lambda = st->lambda;
+  // partial sums of the point pass, the prior chi2 and the reduced right-hand side: requested together, added in index order
+  for (int i = tid; i < 2 * a.nba; i += T_BA) s_part[i] = a.partA[(size_t)f * a.nba * 2 + i];
+  if (tid < P) s_part[2 * a.nba + tid] = G.pchi[tid];
+  const bool stage_lds = P <= 22;
+  if (stage_lds) {
+    for (int i = tid; i < P * 36; i += T_BA) s_prH[i] = G.prH[i];
+    if (tid < P) {
+      s_pact[tid] = G.pact[tid];
+      s_prior[tid] = G.prior[tid];
     }
-  __syncthreads();
-  // partial sums of the point pass and the prior chi2: fetched in parallel into LDS, added in index order
-  double* stage = red + NW_BA * 32 + 128;  // 128 doubles behind the solve's own areas
-  double chiA = 0.0, md = 0.0;
-  for (int w0 = 0; w0 < a.nba; w0 += 64) {
-    if (tid < 128 && w0 + (tid >> 1) < a.nba) stage[tid] = a.partA[((size_t)f * a.nba + w0) * 2 + tid];
-    __syncthreads();
-    for (int w = 0; w < min(64, a.nba - w0); ++w) {
-      chiA += stage[2 * w];
-      md = fmax(md, stage[2 * w + 1]);
-    }
-    __syncthreads();
   }
-  if (tid < P) stage[tid] = G.pchi[tid];
-  __syncthreads();
-  if (st->init) {  // computeLambdaInit: 1e-5 x the largest diagonal of H_pp (+ prior) and H_ll
-    double mine = 0.0;
+  double mine = 0.0;
+  if (init) {
     for (int i = tid; i < n; i += T_BA) {
       const int j = i / 6, r = i - 6 * j;
-      if (G.pact[j]) mine = fabs(S[(size_t)i * ld + i] + G.prH[(size_t)j * 36 + r * 6 + r]);
+      if (G.pact[j]) mine = fabs(G.S[(size_t)i * ld + i] + G.prH[(size_t)j * 36 + r * 6 + r]);
     }
+  } else {
+    for (int i = tid; i < n; i += T_BA) {
+      const int j = i / 6;
+      double v = G.gv[i];
+      if (G.pact[j] && G.prior[j] && a.k.first_as_prior) {
+        const double b = G.prb[i];
+        v += b;
+        G.bp[i] += b;
+      }
+      G.dxv[i] = v;
+      if (small) red[128 + i] = v;
+    }
+  }
+  __syncthreads();
+  double chiA = 0.0, md = 0.0;
+  for (int w = 0; w < a.nba; ++w) {
+    chiA += s_part[2 * w];
+    md = fmax(md, s_part[2 * w + 1]);
+  }
+#ifdef GL_PIPE_PROF
+  const long long s1 = clock64();
+#endif
+  if (init) {  // computeLambdaInit: 1e-5 x the largest diagonal of H_pp (+ prior) and H_ll
     md = fmax(md, block_max(mine, red));
     if (tid == 0) {
       st->lambda = 1e-5 * md;
       st->ni = 2.0;
       st->init = 0;
-      st->skip = 1;
+      st->pend = 0;
     }
     return;
   }
-  const double lambda = st->lambda;
-  for (int j = 0; j < P; ++j) chiA += stage[j];
-  for (int j = tid; j < P; j += T_BA) {
-    if (!G.pact[j]) {
-      for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * ld + 6 * j + r] = 1.0;
-      continue;
-    }
-    if (G.prior[j] && a.k.first_as_prior) {
-      const double* H = G.prH + (size_t)j * 36;
-      for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) S[(size_t)(6 * j + r) * ld + 6 * j + c] += H[r * 6 + c];
-    }
-    for (int r = 0; r < 6; ++r) S[(size_t)(6 * j + r) * ld + 6 * j + r] += lambda;
-  }
-  for (int i = tid; i < n; i += T_BA) {
-    const int j = i / 6;
-    double v = G.gv[i];
-    if (G.pact[j] && G.prior[j] && a.k.first_as_prior) {
-      const double b = G.prb[i];
-      v += b;
-      G.bp[i] += b;
-    }
-    G.dxv[i] = v;
-    if (small) red[128 + i] = v;
-  }
-  __syncthreads();
+  for (int j = 0; j < P; ++j) chiA += s_part[2 * a.nba + j];
+#ifdef GL_PIPE_PROF
+  const long long s2 = clock64();
+#endif
   bool ok = true;
-  if (st->any_pose)
-    ok = small ? ldlt_solve_small(G, a.k, lambda, S, ld, false, (lds_double*)dyn_lds, ld, G.dxv, n, &s_flag, red)
-               : ldlt_solve_large(S, G.dxv, n, ld, &s_flag);
+  if (st->any_pose) {
+    if (small) {
+      GenP GL = G;
+      if (stage_lds) {
+        GL.prH = s_prH;
+        GL.pact = s_pact;
+        GL.prior = s_prior;
+      }
+      ok = ldlt_solve_small<1>(GL, a.k, lambda, G.S, ld, true, (lds_double*)dyn_lds, ld, G.dxv, n, &s_flag, red);
+    } else {  // the scalar-pivot path factorises in global memory: the diagonal terms go in first
+      for (int j = tid; j < P; j += T_BA) {
+        if (!G.pact[j]) {
+          for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * ld + 6 * j + r] = 1.0;
+          continue;
+        }
+        if (G.prior[j] && a.k.first_as_prior) {
+          const double* H = G.prH + (size_t)j * 36;
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) G.S[(size_t)(6 * j + r) * ld + 6 * j + c] += H[r * 6 + c];
+        }
+        for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * ld + 6 * j + r] += lambda;
+      }
+      __syncthreads();
+      ok = ldlt_solve_large(G.S, G.dxv, n, ld, &s_flag);
+    }
+  }
   __syncthreads();
+#ifdef GL_PIPE_PROF
+  const long long s3 = clock64();
+#endif
   for (int j = tid; j < P; j += T_BA) {  // trial poses
     const SE3 T = se3_load(G.poses + (size_t)j * 7);
     SE3 Tn = T;
@@ -2166,17 +2431,26 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   if (tid == 0) {
     st->ok = ok ? 1 : 0;
     st->chiA = chiA;
-    st->skip = 0;
+    st->pend = 1;
     if (a.stop) st->stop_seen = stop_word_load(a.stop);
   }
+#ifdef GL_PIPE_PROF
+  __syncthreads();
+  if (tid == 0 && f == 0) {
+    const long long s4 = clock64();
+    st->dbg[8] += s1 - s0; st->dbg[9] += s2 - s1; st->dbg[10] += s3 - s2; st->dbg[11] += s4 - s3; st->dbg[12] += 1;
+    printf("solve cycles: load %lld add %lld ldlt %lld poses %lld calls %lld | ldlt: colstore %llu diag %llu panel %llu trailing %llu backward %llu\n", st->dbg[8], st->dbg[9], st->dbg[10], st->dbg[11], st->dbg[12],
+           g_gprof[8], g_gprof[9], g_gprof[10], g_gprof[11], g_gprof[7]);
+  }
+#endif
 }
 
 // ---- P3: back-substitution of the points, trial points, their chi2 -------------------------------------------------
 __global__ __launch_bounds__(T_BA) void kp_trial(PipeA a) {
   __shared__ double red[NW_BA * 32 + 8];
   const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba;
-  const PipeSt* st = a.st + f;
-  if (st->stage >= 3 || st->skip) return;
+  const PipeSt* st = st_cur(a, f);
+  if (st->stage >= 3 || !st->pend) return;
   GenP G;
   genp_init(G, a, f, a.nba, pb);
   double acc[32];
@@ -2189,114 +2463,6 @@ __global__ __launch_bounds__(T_BA) void kp_trial(PipeA a) {
     pd[0] = acc[0];
     pd[1] = acc[1];
   }
-}
-
-// ---- accept / reject, loop control, stage changes; one workgroup per problem ---------------------------------------------
-constexpr int T_DEC = 512;  // the state kernels: a workgroup per problem, loops over its points / observations
-__global__ __launch_bounds__(T_DEC) void kp_decide(PipeA a) {
-  __shared__ int s_cnt[2];
-  __shared__ int s_accept, s_next;  // s_next: 0 retry, 1 next outer iteration, 2 stage over
-  const int f = blockIdx.x, tid = threadIdx.x, P = a.P, n = 6 * P, NT = blockDim.x;
-  PipeSt* st = a.st + f;
-  if (st->stage >= 3 || st->skip) return;
-#ifdef GL_PIPE_PROF
-  const long long c0 = clock64();
-#endif
-  GenP G;
-  genp_init(G, a, f, 1, 0);
-  // the terms of the two sums are fetched in parallel into LDS and added by one thread in index order
-  __shared__ double s_d[2 * 64 + 3 * 128];
-  double scale0 = 0.0, temp0 = 0.0;
-  for (int w0 = 0; w0 < a.nba; w0 += 64) {
-    if (tid < 128 && w0 + (tid >> 1) < a.nba) s_d[tid] = a.partD[((size_t)f * a.nba + w0) * 2 + tid];
-    __syncthreads();
-    if (tid == 0)
-      for (int w = 0; w < min(64, a.nba - w0); ++w) {
-        scale0 += s_d[2 * w];
-        temp0 += s_d[2 * w + 1];
-      }
-    __syncthreads();
-  }
-  for (int i = tid; i < n && i < 128; i += NT) {
-    s_d[128 + i] = G.dxv[i];
-    s_d[256 + i] = G.bp[i];
-  }
-  if (tid < P) s_d[384 + tid] = G.pchi2[tid];
-  __syncthreads();
-#ifdef GL_PIPE_PROF
-  const long long c1 = clock64();
-#endif
-  if (tid == 0) {
-    PipeSt q = *st;  // (one burst of loads: every st-> access below was a dependent global round trip)
-    double scale = scale0, tempChi = temp0;
-    const double lambda = q.lambda;
-    if (q.qmax == 0) q.currentChi = q.chiA;
-    for (int j = 0; j < P; ++j) tempChi += s_d[384 + j];
-    if (n <= 128) {
-      for (int i = 0; i < n; ++i) scale += s_d[128 + i] * (lambda * s_d[128 + i] + s_d[256 + i]);
-    } else {
-      for (int i = 0; i < n; ++i) scale += G.dxv[i] * (lambda * G.dxv[i] + G.bp[i]);
-    }
-    if (!q.ok) tempChi = 1.7976931348623157e308;
-    scale += 1e-3;
-    const double rho = (q.currentChi - tempChi) / scale;
-    const bool acc = rho > 0 && isfinite(tempChi);
-    if (acc) {
-      const double uu = 2 * rho - 1;
-      double alpha = 1. - uu * uu * uu;
-      alpha = fmin(alpha, 2. / 3.);
-      q.lambda = lambda * fmax(1. / 3., alpha);
-      q.ni = 2;
-      q.currentChi = tempChi;
-    } else {
-      q.lambda = lambda * q.ni;
-      q.ni *= 2;
-    }
-    q.rho = rho;
-    q.qmax += 1;
-    q.trials += 1;
-    s_accept = acc ? 1 : 0;
-    int next = 0;
-    if (!(rho < 0 && q.qmax < 10 && !(q.stop_seen > 0))) {  // the outer iteration is over
-      q.cj += 1;
-      q.done_iters += 1;
-      q.it += 1;
-      next = (q.qmax == 10 || rho == 0 || q.it >= q.iters_max || pipe_stop_now(&q)) ? 2 : 1;
-      q.qmax = 0;
-    }
-    *st = q;
-    s_next = next;
-  }
-  __syncthreads();
-#ifdef GL_PIPE_PROF
-  const long long c2 = clock64();
-#endif
-  if (s_accept) {
-    for (int j = tid; j < P; j += NT) {
-      if (!G.pact[j]) continue;
-      for (int r = 0; r < 7; ++r) G.poses[(size_t)j * 7 + r] = G.qN[(size_t)j * 7 + r];
-      for (int r = 0; r < 12; ++r) G.Rt[(size_t)j * 12 + r] = G.RtN[(size_t)j * 12 + r];
-    }
-    for (int l = tid; l < G.L; l += NT) {
-      if (!G.lact[l]) continue;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) G.pts[(size_t)l * 3 + i] = G.pn[(size_t)l * 3 + i];
-    }
-  }
-  __syncthreads();
-#ifdef GL_PIPE_PROF
-  const long long c3 = clock64();
-#endif
-  if (s_next == 1) pipe_priors(a.k, G);  // the state the next outer iteration linearises the prior edges at
-  else if (s_next == 2) pipe_advance(a, G, st, f, s_cnt);
-#ifdef GL_PIPE_PROF
-  __syncthreads();
-  if (tid == 0 && f == 0) {
-    const long long c4 = clock64();
-    st->dbg[0] += c1 - c0; st->dbg[1] += c2 - c1; st->dbg[2] += c3 - c2; st->dbg[s_next == 2 ? 4 : 3] += c4 - c3; st->dbg[5] += 1;
-    if (st->stage >= 3) printf("decide cycles: fetch %lld serial %lld accept-copy %lld priors %lld advance %lld calls %lld\n", st->dbg[0], st->dbg[1], st->dbg[2], st->dbg[3], st->dbg[4], st->dbg[5]);
-  }
-#endif
 }
 
 namespace gl {
@@ -2380,7 +2546,7 @@ size_t ba_pipe_scratch_bytes(int B, int P, int F, int L, int NOBS) {
   int nba, lpp, nblk, nchunk;
   pipe_shape(P, L, NOBS, &nba, &lpp, &nblk, &nchunk);
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
-  return ba_gen_scratch_bytes(B, P, F, L, NOBS) + up((size_t)B * sizeof(PipeSt)) + 2 * up((size_t)B * nba * 16) +
+  return ba_gen_scratch_bytes(B, P, F, L, NOBS) + up((size_t)2 * B * sizeof(PipeSt)) + 2 * up((size_t)B * nba * 16) +
          up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * nblk * 4) + 1024;
 }
 
@@ -2416,7 +2582,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
   char* s = (char*)scratch + ba_gen_scratch_bytes(B, P, F, L, NOBS);
   a.st = (PipeSt*)s;
-  s += up((size_t)B * sizeof(PipeSt));
+  s += up((size_t)2 * B * sizeof(PipeSt));
   a.partA = (double*)s;
   s += up((size_t)B * a.nba * 16);
   a.partD = (double*)s;
@@ -2438,6 +2604,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   {
     const int nws = std::max(1, (NOBS + SORT_SPAN - 1) / SORT_SPAN);
     const int lblocks = (int)(((long)B * nws + NW_BA - 1) / NW_BA);
+    a.par = 1;  // the set-up writes state buffer 0
     kp_setup_init<<<B * a.nba, T_BA, 0, c->stream>>>(a);
     kp_setup_lists<0><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
     kp_setup_scan<<<B, T_BA, 0, c->stream>>>(a, nws);
@@ -2448,16 +2615,18 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   const long schur_waves = (long)B * a.nblk * a.nchunk;
   const int schur_blocks = (int)((schur_waves + NW_BA - 1) / NW_BA);
   // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
-  // one): enough cycles for the common case are enqueued before the first look at the counter, fewer per look afterwards
-  int chunk = 36;
+  // one) + 3 stage-end cycles + the one that judges the last trial: enough cycles for the common case are enqueued before the
+  // first look at the counter, fewer per look afterwards
+  int chunk = 40, par = 0;
   for (int total = 0;; total += chunk, chunk = 8) {
     for (int cyc = 0; cyc < chunk; ++cyc) {
+      a.par = par;
+      par ^= 1;
       kp_lin<<<B * a.nba, T_BA, 0, c->stream>>>(a);
       kp_schur<<<schur_blocks, T_BA, 0, c->stream>>>(a);
       kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, c->stream>>>(a);
       kp_solve<<<B, T_BA, s_bytes, c->stream>>>(a);
       kp_trial<<<B * a.nba, T_BA, 0, c->stream>>>(a);
-      kp_decide<<<B, T_DEC, 0, c->stream>>>(a);
     }
     GL_HIP(hipGetLastError());
     GL_HIP(hipMemcpyAsync(c->host_word, a.unfinished, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2493,7 +2662,8 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   // (profiles/r3_bagen_shapes.txt): 8 + 4 key-frames / 12 600 observations 2.96 ms pipelined vs 2.87 persistent, 12 + 4 /
   // 22 400 3.15 vs 4.70, 20 + 8 / 58 600 7.24 vs 6.51 (there the 120 x 120 factorisation, one workgroup in either shape, is
   // 40 % of a cycle and the persistent kernel needs no lambda-init cycles); batches 0.23 vs 0.107 ms per problem.
-  const bool pipe = c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 2 && P <= 16 && NOBS >= 15000);
+  const bool pipe_fits = P <= 22 && P + F <= 32 && L <= 16384;  // (the judging workgroups hold the partial sums and the poses in LDS)
+  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 2 && P <= 16 && NOBS >= 15000));
   int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_bytes(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
   if (pipe) {

@@ -10,6 +10,8 @@ d = np.load(G + "/map_v1.npz"); mean, cov = d["mean"], d["cov"]
 gt = np.load(G + "/gt_sync.npz")["V1_01_easy"]
 cam, prm = api.Camera(), api.Params()
 ctx = gmmloc_amd.Context(0); g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+if os.environ.get("BAGEN_MODE"):
+    ctx.set_option("bagen_mode", int(os.environ["BAGEN_MODE"]))  # 1 persistent kernel, 2 pipelined shape
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 for (P, F, L, prior) in [(1, 0, 120, False), (1, 1, 200, True), (2, 2, 400, True), (4, 2, 800, False), (8, 4, 1500, True),
                          (12, 4, 2000, True), (20, 8, 3000, True), (21, 2, 1000, True), (22, 2, 1000, True)]:

@@ -10,6 +10,8 @@ d = np.load(os.path.join(ROOT, "tests", "golden", "map_v1.npz")); mean, cov = d[
 gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_01_easy"]
 cam, prm = api.Camera(), api.Params()
 ctx = gmmloc_amd.Context(0); g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+if os.environ.get("BAGEN_MODE"):
+    ctx.set_option("bagen_mode", int(os.environ["BAGEN_MODE"]))  # 1 persistent kernel, 2 pipelined shape
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
