@@ -1608,15 +1608,16 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
 // (a cycle = one trial; a kernel whose problem has finished, or whose phase does not apply, exits at once) and looks at the
 // device-side count of unfinished problems between chunks of cycles: the call returns with the work complete.
 // Sums are deterministic: per-workgroup / per-chunk partials added in index order, independent of the batch.
-struct PipeSt {  // per problem, in global memory
+struct alignas(16) PipeSt {  // per problem, in global memory
+  // (the four words every kernel of a cycle tests first: one 16-byte load - pipe_ctl)
   int stage;     // 0, 1, 2: which optimize() of the 5 / 5 / 40 schedule; 3: finished
+  int init;      // 1: the next cycle is the computeLambdaInit pass of the stage (no solve, no trial)
+  int pend;      // 1: a trial state has been evaluated (solve + trial of this cycle); the next cycle's first kernel judges it
+  int adv;       // 1: the stage is over (decided at the head of this cycle): the solve kernel runs the gate / opens the next stage
   int iters_max; // of this stage
   int it;        // outer iteration of the stage
   int qmax;      // trials of the outer iteration so far
   int cj;        // outer iterations completed in the stage
-  int init;      // 1: the next cycle is the computeLambdaInit pass of the stage (no solve, no trial)
-  int pend;      // 1: a trial state has been evaluated (solve + trial of this cycle); the next cycle's first kernel judges it
-  int adv;       // 1: the stage is over (decided at the head of this cycle): the solve kernel runs the gate / opens the next stage
   int any_point, any_pose, ok;
   int trials, done_iters, stop_seen, it3;
 #ifdef GL_PIPE_PROF
@@ -1654,6 +1655,14 @@ struct PipeA {  // kernel arguments (by value)
   int* arrive;        // B x nblk: waves of the Schur pass that have delivered their chunk of a block (back to 0 by the last)
   int nba, lpp, nblk, nchunk;
 };
+struct PipeCtl {
+  int stage, init, pend, adv;
+};
+// (fetched together: `st->stage >= 3 || st->adv` is two dependent round trips at the top of a 5 - 15 us kernel)
+GL_DEV PipeCtl pipe_ctl(const PipeSt* st) {
+  const int4 w = *(const int4*)st;
+  return PipeCtl{w.x, w.y, w.z, w.w};
+}
 GL_DEV PipeSt* st_cur(const PipeA& a, int f) { return a.st + (size_t)(a.par ^ 1) * a.B + f; }
 GL_DEV const PipeSt* st_prev(const PipeA& a, int f) { return a.st + (size_t)a.par * a.B + f; }
 GL_DEV void genp_init(GenP& G, const PipeA& a, int f, int NB, int pb) {
@@ -1727,48 +1736,6 @@ GL_DEV void genp_init(GenP& G, const PipeA& a, int f, int NB, int pb) {
   G.lact = takeB(L);
 }
 
-// initializeOptimization(0) of a stage + the prior edges at the current state, by ONE workgroup (the problem's state
-// kernels): active poses / points; returns through st->any_point / any_pose
-GL_DEV void pipe_census(const BaK& k, GenP& G, PipeSt* st, int* s_cnt) {
-  // (walked by observation, coalesced, with same-value stores - a thread per point with a loop over its observations costs a
-  // dependent load per observation on one workgroup: 100+ us at 58 000 observations)
-  const int P = G.P, tid = threadIdx.x, nobs = G.nobs, NT = blockDim.x;
-  for (int j = tid; j < P; j += NT) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
-  for (int l = tid; l < G.L; l += NT) G.lact[l] = (G.assoc[l] >= 0 && !G.lev_g[l]) ? 1 : 0;
-  if (tid < 2) s_cnt[tid] = 0;
-  __syncthreads();
-  for (int o0 = tid * 4; o0 < nobs; o0 += NT * 4) {  // four observations per step: their loads go out together
-    int lv[4], l[4], j[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oc = min(o0 + q, nobs - 1);
-      lv[q] = G.lev_o[oc];
-      l[q] = G.opoint[oc];
-      j[q] = G.opose[oc];
-    }
-    int fr[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) fr[q] = G.pfree[j[q]];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (o0 + q < nobs && !lv[q]) {
-        G.lact[l[q]] = 1;
-        if (fr[q]) G.pact[j[q]] = 1;
-      }
-  }
-  __syncthreads();
-  int np = 0, na = 0;
-  for (int l = tid; l < G.L; l += NT) np += G.lact[l] ? 1 : 0;
-  for (int j = tid; j < P; j += NT) na += G.pact[j] ? 1 : 0;
-  if (np) atomicAdd(&s_cnt[0], np);
-  if (na) atomicAdd(&s_cnt[1], na);
-  __syncthreads();
-  if (tid == 0) {
-    st->any_point = s_cnt[0] > 0;
-    st->any_pose = s_cnt[1] > 0;
-  }
-  __syncthreads();
-}
 // prior edges at the current state (once per outer iteration: gen_optimize does the same)
 GL_DEV void pipe_priors(const BaK& k, GenP& G, const double* poses) {
   const int NT = blockDim.x;
@@ -1784,98 +1751,111 @@ GL_DEV void pipe_priors(const BaK& k, GenP& G, const double* poses) {
 }
 GL_DEV bool pipe_stop_now(const PipeSt* st) { return st->stop_seen > 0 || (st->stop_seen < 0 && st->done_iters >= -st->stop_seen); }
 
-// opens stage `stage` (st->stage already set): census, priors, loop variables; a stage with nothing active (optimize()
-// returns -1) or a raised stop word is over at once - returns false then
-GL_DEV bool pipe_open_stage(const BaK& k, GenP& G, PipeSt* st, int* s_cnt) {
-  pipe_census(k, G, st, s_cnt);
-  const bool run = (st->any_point || st->any_pose) && !pipe_stop_now(st);
-  if (threadIdx.x == 0) {
-    st->iters_max = st->stage < 2 ? 5 : 40;
+
+// ---- the end of a stage (k_ba_gen's schedule code between its three optimize() calls, :773-879), spread over the kernels of ONE
+// cycle so that nothing that walks the points or the observations sits on a single workgroup (one workgroup took 75 k cycles per
+// stage change at 12 600 observations, 280 k at 58 600 - 4 - 6 % of the whole call):
+//   (A) the head kernel, by point (each workgroup its own points, right after it has accepted them): the fresh error of the
+//       degenerate GMM edges after stage 0 (:773-786), the point half of initializeOptimization(0) of the next stage - or, after
+//       the last stage, the `dropped` output;
+//   (B) the Schur pass's grid, by observation: the reprojection gate after stage 1 (bDoMore, :791-796), the observation half of
+//       initializeOptimization(0) (same-value stores) - or the `erase` output;
+//   (C) the solve kernel's workgroup: the counts, the loop variables of the next stage, its prior edges - or the scalar outputs.
+// A stage that does not run (nothing active: optimize() returns -1; or the stop word) leaves `adv` set and the next cycle does
+// the next gate.  ds = the stage that has ended (-1: none yet, the call opens), the same in the three kernels of the cycle.
+GL_DEV int pipe_next_stage(const PipeSt& q) { return (q.stage == 1 && pipe_stop_now(&q)) ? 3 : q.stage + 1; }
+
+GL_DEV void pipe_adv_points(const PipeA& a, const GenP& G, const PipeSt& q, int f, int pb) {
+  const int ds = q.stage, next = pipe_next_stage(q), per = T_BA / a.lpp, tid = threadIdx.x;
+  if (tid < per) {
+    for (int l = pb * per + tid; l < G.L; l += a.nba * per) {
+      GmmRef g;
+      load_gmm(G.assoc[l], a.gm.axis, a.gm.rec12, a.gm.sqrt_info, a.gm.flags, g);
+      const bool over = g.has && g.deg && gmm_chi2(a.k, g, G.pts + (size_t)l * 3) > a.k.str_thresh;
+      int lg = G.lev_g[l];
+      if (ds == 0 && over) {
+        lg = 1;
+        G.lev_g[l] = 1;
+      }
+      if (next >= 3) a.dropped[(size_t)f * G.L + l] = over ? 1 : 0;
+      else G.lact[l] = (G.assoc[l] >= 0 && !lg) ? 1 : 0;
+    }
+  }
+  if (pb == 0 && next < 3)
+    for (int j = tid; j < G.P; j += T_BA) G.pact[j] = (G.pfree[j] && G.prior[j] && a.k.first_as_prior) ? 1 : 0;
+}
+// (B) `w` of `nw` waves of the problem; the reprojection gate of an observation at the current state: stale chi2 above the threshold
+// of its edge type, or the point behind the camera (:799-825, :855-879)
+GL_DEV void pipe_adv_obs(const PipeA& a, const GenP& G, const PipeSt& q, int f, int w, int nw) {
+  const int ds = q.stage, next = pipe_next_stage(q), lane = threadIdx.x & 63, nobs = G.nobs;
+  const bool gate = ds == 1 && !pipe_stop_now(&q);
+  uint8_t* er = a.erase + (size_t)f * a.NOBS;
+  for (int o = w * 64 + lane; o < nobs; o += nw * 64) {
+    const int l = G.opoint[o], j = G.opose[o];
+    const double chi = G.chi_o[o], ur = G.ouvr[(size_t)o * 3 + 2];
+    int lv = G.lev_o[o];
+    const int fr = G.pfree[j];
+    const double* Rt = G.Rt + (size_t)j * 12;
+    const double* p = G.pts + (size_t)l * 3;
+    const double z = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
+    const bool bad = chi > (!(ur < 0) ? 7.815 : 5.991) || !(z > 0.0);
+    if (gate && bad) {
+      lv = 1;
+      G.lev_o[o] = 1;  // (the Schur pass of this shape tests the level flags itself: no sweep of the partner table)
+    }
+    if (next >= 3) {
+      er[o] = bad ? 1 : 0;
+    } else if (!lv) {
+      G.lact[l] = 1;
+      if (fr) G.pact[j] = 1;
+    }
+  }
+}
+// (C)
+GL_DEV void pipe_adv_open(const PipeA& a, GenP& G, PipeSt* st, int f, int* s_cnt) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const PipeSt q = *st;
+  const int ds = q.stage, next = pipe_next_stage(q);
+  if (next >= 3) {
+    if (tid == 0) {
+      const int it3 = (ds == 2 && q.it3 != -1) ? q.cj : q.it3;
+      st->it3 = it3;
+      st->stage = 3;
+      st->adv = 0;
+      st->pend = 0;
+      if (a.iters) a.iters[f] = it3;
+      if (a.trials_out) a.trials_out[f] = q.trials;
+      atomicSub(a.unfinished, 1);
+    }
+    return;
+  }
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  int np = 0, na = 0;
+  for (int l = tid; l < G.L; l += NT) np += G.lact[l] ? 1 : 0;
+  for (int j = tid; j < G.P; j += NT) na += G.pact[j] ? 1 : 0;
+  if (np) atomicAdd(&s_cnt[0], np);
+  if (na) atomicAdd(&s_cnt[1], na);
+  __syncthreads();
+  const bool any = s_cnt[0] > 0 || s_cnt[1] > 0;
+  const bool run = any && !pipe_stop_now(&q);
+  if (tid == 0) {
+    int it3 = (ds == 2 && q.it3 != -1) ? q.cj : q.it3;
+    if (!run && next == 2 && !any) it3 = -1;
+    st->it3 = it3;
+    st->stage = next;
+    st->any_point = s_cnt[0] > 0;
+    st->any_pose = s_cnt[1] > 0;
+    st->iters_max = next < 2 ? 5 : 40;
     st->it = 0;
     st->qmax = 0;
     st->cj = 0;
     st->init = 1;
     st->pend = 0;
-    st->adv = 0;
+    st->adv = run ? 0 : 1;
     st->rho = 0.0;
   }
-  if (run) pipe_priors(k, G, G.poses);
-  __syncthreads();
-  return run;
-}
-
-// the gating between the stages and the outputs (k_ba_gen's schedule code), one workgroup; advances st->stage until a
-// stage really runs or the problem is finished
-// The reprojection gate of every observation at the current state - stale chi2 above the threshold of its edge type, or the
-// point behind the camera (:799-825, :855-879) - four observations per thread and step with their loads hoisted (on ONE
-// workgroup a dependent chain per observation costs ~1 us each).  body(o, l, j, bad)
-template <class F>
-GL_DEV void for_obs_gate(const GenP& G, F&& body) {
-  const int NT = blockDim.x, nobs = G.nobs;
-  for (int o0 = threadIdx.x * 4; o0 < nobs; o0 += NT * 4) {
-    int l[4], j[4];
-    double chi[4], ur[4], z[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oc = min(o0 + q, nobs - 1);
-      l[q] = G.opoint[oc];
-      j[q] = G.opose[oc];
-      chi[q] = G.chi_o[oc];
-      ur[q] = G.ouvr[(size_t)oc * 3 + 2];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double* Rt = G.Rt + (size_t)j[q] * 12;
-      const double* p = G.pts + (size_t)l[q] * 3;
-      z[q] = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (o0 + q < nobs) body(o0 + q, l[q], j[q], chi[q] > (!(ur[q] < 0) ? 7.815 : 5.991) || !(z[q] > 0.0));
-  }
-}
-GL_DEV void pipe_advance(const PipeA& a, GenP& G, PipeSt* st, int f, int* s_cnt) {
-  const BaK& k = a.k;
-  const int L = G.L, tid = threadIdx.x, NT = blockDim.x;
-  for (;;) {
-    const int done_stage = st->stage;  // (uniform: written by thread 0 behind barriers)
-    if (done_stage == 2 && tid == 0 && st->it3 != -1) st->it3 = st->cj;
-    __syncthreads();
-    if (done_stage == 0) {  // fresh error of the degenerate GMM edges (:773-786)
-      for (int l = tid; l < L; l += NT) {
-        GmmRef g;
-        load_gmm(G.assoc[l], a.gm.axis, a.gm.rec12, a.gm.sqrt_info, a.gm.flags, g);
-        if (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) G.lev_g[l] = 1;
-      }
-    } else if (done_stage == 1 && !pipe_stop_now(st)) {  // bDoMore (:791-796): reprojection gating, kernels off
-      // by observation (coalesced)
-      for_obs_gate(G, [&](int o, int, int, bool bad) {
-        if (bad) G.lev_o[o] = 1;  // (the Schur pass of this shape tests the level flags itself: no sweep of the partner table)
-      });
-    }
-    __syncthreads();
-    const int next = (done_stage == 1 && pipe_stop_now(st)) ? 3 : done_stage + 1;
-    if (tid == 0) st->stage = next;
-    __syncthreads();
-    if (next >= 3) break;
-    if (pipe_open_stage(k, G, st, s_cnt)) return;  // the stage runs: the next cycle is its lambda-init pass
-    // nothing active (optimize() returned -1) or stopped (0 iterations): on to the next gate
-    if (next == 2 && tid == 0 && !(st->any_point || st->any_pose)) st->it3 = -1;
-    __syncthreads();
-  }
-  // ---- outputs (:837-879) -----------------------------------------------------------------------------------
-  for (int l = tid; l < L; l += NT) {
-    GmmRef g;
-    load_gmm(G.assoc[l], a.gm.axis, a.gm.rec12, a.gm.sqrt_info, a.gm.flags, g);
-    a.dropped[(size_t)f * L + l] = (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) ? 1 : 0;
-  }
-  uint8_t* er = a.erase + (size_t)f * a.NOBS;
-  for_obs_gate(G, [&](int o, int, int, bool bad) { er[o] = bad ? 1 : 0; });
-  if (tid == 0) {
-    if (a.iters) a.iters[f] = st->it3;
-    if (a.trials_out) a.trials_out[f] = st->trials;
-    atomicSub(a.unfinished, 1);
-  }
+  if (run) pipe_priors(a.k, G, G.poses);
 }
 
 // ---- set-up: k_ba_gen's, as parallel kernels (one workgroup builds the pose-major lists of 58 000 observations in 4 ms) ----
@@ -1891,7 +1871,19 @@ __global__ __launch_bounds__(T_BA) void kp_setup_init(PipeA a) {
       for (int i = 0; i < 16; ++i) st->dbg[i] = 0;
 #endif
       const int sw = a.stop ? stop_word_load(a.stop) : 0;
-      st->stage = sw > 0 ? 3 : 0;  // `if (pbStopFlag) if (*pbStopFlag) return;` (:765-767): nothing is written
+      st->stage = sw > 0 ? 3 : -1;  // `if (pbStopFlag) if (*pbStopFlag) return;` (:765-767): nothing is written
+      st->adv = 1;                  // cycle 0 opens stage 0 (initializeOptimization(0): pipe_adv_*)
+      st->init = 0;
+      st->pend = 0;
+      st->cj = 0;
+      st->qmax = 0;
+      st->it = 0;
+      st->iters_max = 0;
+      st->any_point = 0;
+      st->any_pose = 0;
+      st->ok = 1;
+      st->rho = 0.0;
+      st->chiA = 0.0;
       st->trials = 0;
       st->done_iters = 0;
       st->it3 = 0;
@@ -2004,17 +1996,6 @@ __global__ __launch_bounds__(T_BA) void kp_setup_partner(PipeA a) {
       }
     }
 }
-// (6) the first stage opens
-__global__ __launch_bounds__(512) void kp_setup_open(PipeA a) {
-  __shared__ int s_cnt[2];
-  const int f = blockIdx.x;
-  PipeSt* st = st_cur(a, f);
-  if (st->stage >= 3) return;
-  GenP G;
-  genp_init(G, a, f, 1, 0);
-  if (!pipe_open_stage(a.k, G, st, s_cnt)) pipe_advance(a, G, st, f, s_cnt);
-}
-
 // ---- head of a cycle: the trial of the previous cycle is JUDGED (accept / reject, lambda, loop control: the arithmetic of
 // SparseOptimizer / OptimizationAlgorithmLevenberg in k_ba_gen's order), then P1: point pass (linearise the observations, point
 // blocks); nba workgroups per problem.  Every workgroup judges for itself - the sums it needs are a few hundred doubles, added in
@@ -2078,13 +2059,14 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, tid = threadIdx.x, P = a.P, F = a.F, n = 6 * P;
   const PipeSt* sp = st_prev(a, f);
   PipeSt* sc = st_cur(a, f);
-  if (sp->stage >= 3) {  // finished: the state word travels on (both buffers must say so)
+  const PipeCtl ctl = pipe_ctl(sp);
+  if (ctl.stage >= 3) {  // finished: the state word travels on (both buffers must say so)
     if (pb == 0 && tid == 0) *sc = *sp;
     return;
   }
   GenP G;
   genp_init(G, a, f, a.nba, pb);
-  const bool judge = sp->pend != 0;
+  const bool judge = ctl.pend != 0;
   const bool lds_ok = 2 * a.nba + 2 * n + P <= PIPE_JUDGE_MAX && P + F <= 32;  // (launch_ba_pipe only takes such windows)
   if (judge && lds_ok) {  // every term of the two sums requested at once
     for (int i = tid; i < 2 * a.nba; i += T_BA) s_d[i] = a.partD[(size_t)f * a.nba * 2 + i];
@@ -2139,7 +2121,10 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
     if (tid == 0) *sc = s_q;
   }
   __syncthreads();
-  if (s_q.adv) return;  // the stage is over: the solve kernel of this cycle runs the gate
+  if (s_q.adv) {  // the stage is over (or none is open yet): this cycle's kernels do the gate and open the next one
+    pipe_adv_points(a, G, s_q, f, pb);
+    return;
+  }
   G.Rt = s_Rt;
   double acc[32], md = 0.0;
 #pragma unroll
@@ -2162,10 +2147,15 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
   const int f = (int)(gwave / per_prob), w = (int)(gwave % per_prob);
   if (f >= a.B) return;
   const PipeSt* st = st_cur(a, f);
-  if (st->stage >= 3 || st->adv) return;
-  const bool schur = !st->init;
+  const PipeCtl ctl = pipe_ctl(st);
+  if (ctl.stage >= 3) return;
+  const bool schur = !ctl.init;
   GenP G;
   genp_init(G, a, f, 1, 0);
+  if (ctl.adv) {
+    pipe_adv_obs(a, G, *st, f, w, per_prob);
+    return;
+  }
   const int P = a.P, b = w / a.nchunk, chunk = w % a.nchunk;
   int j1 = 0, rem = b;
   while (rem >= P - j1) {
@@ -2270,7 +2260,9 @@ __global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
   const long g = (long)blockIdx.x * T_BA + threadIdx.x;
   const int per_prob = a.nblk * 48;
   const int f = (int)(g / per_prob), r0 = (int)(g % per_prob), b = r0 / 48, sidx = r0 % 48;
-  if (f >= a.B || st_cur(a, f)->stage >= 3 || st_cur(a, f)->adv) return;
+  if (f >= a.B) return;
+  const PipeCtl ctl = pipe_ctl(st_cur(a, f));
+  if ((ctl.stage >= 3) | ctl.adv) return;
   const int P = a.P, ld = 6 * P + GL_LD_PAD;
   int j1 = 0, rem = b;
   while (rem >= P - j1) {
@@ -2310,15 +2302,14 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   __shared__ int s_cnt[2];
   const int f = blockIdx.x, tid = threadIdx.x, P = a.P, n = 6 * P;
   PipeSt* st = st_cur(a, f);
-  if (st->stage >= 3) return;
+  const PipeCtl ctl = pipe_ctl(st);
+  const double lambda = st->lambda;
+  const int any_pose = st->any_pose;
+  if (ctl.stage >= 3) return;
   GenP G;
   genp_init(G, a, f, 1, 0);
-  if (st->adv) {  // the stage ended at the head of this cycle: gate, next stage (or the outputs)
-    pipe_advance(a, G, st, f, s_cnt);
-    if (tid == 0) {
-      st->adv = 0;
-      st->pend = 0;
-    }
+  if (ctl.adv) {  // the stage ended at the head of this cycle: gate, next stage (or the outputs)
+    pipe_adv_open(a, G, st, f, s_cnt);
     return;
   }
 #ifdef GL_PIPE_PROF
@@ -2326,8 +2317,7 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
 #endif
   const int ld = G.ld;
   const bool small = n <= 128;
-  const bool init = st->init != 0;
-  const double lambda = st->lambda;
+  const bool init = ctl.init != 0;
   // partial sums of the point pass, the prior chi2 and the reduced right-hand side: requested together, added in index order
   for (int i = tid; i < 2 * a.nba; i += T_BA) s_part[i] = a.partA[(size_t)f * a.nba * 2 + i];
   if (tid < P) s_part[2 * a.nba + tid] = G.pchi[tid];
@@ -2382,7 +2372,7 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   const long long s2 = clock64();
 #endif
   bool ok = true;
-  if (st->any_pose) {
+  if (any_pose) {
     if (small) {
       GenP GL = G;
       if (stage_lds) {
@@ -2450,13 +2440,15 @@ __global__ __launch_bounds__(T_BA) void kp_trial(PipeA a) {
   __shared__ double red[NW_BA * 32 + 8];
   const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba;
   const PipeSt* st = st_cur(a, f);
-  if (st->stage >= 3 || !st->pend) return;
+  const PipeCtl ctl = pipe_ctl(st);
+  const double lambda = st->lambda;
+  if ((ctl.stage >= 3) | !ctl.pend) return;
   GenP G;
   genp_init(G, a, f, a.nba, pb);
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  pass_trial_lpp(a.lpp, a.k, a.gm, G, st->stage < 2, st->lambda, a.P, acc);
+  pass_trial_lpp(a.lpp, a.k, a.gm, G, ctl.stage < 2, lambda, a.P, acc);
   block_reduce<2, NW_BA>(acc, red);
   if (threadIdx.x == 0) {
     double* pd = a.partD + ((size_t)f * a.nba + pb) * 2;
@@ -2610,14 +2602,13 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
     kp_setup_scan<<<B, T_BA, 0, c->stream>>>(a, nws);
     kp_setup_lists<1><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
     kp_setup_partner<<<B * a.nba, T_BA, 0, c->stream>>>(a);
-    kp_setup_open<<<B, 512, 0, c->stream>>>(a);
   }
   const long schur_waves = (long)B * a.nblk * a.nchunk;
   const int schur_blocks = (int)((schur_waves + NW_BA - 1) / NW_BA);
   // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
-  // one) + 3 stage-end cycles + the one that judges the last trial: enough cycles for the common case are enqueued before the
+  // one) + 4 cycles that open / change the stage + the one that judges the last trial: enough cycles for the common case are enqueued before the
   // first look at the counter, fewer per look afterwards
-  int chunk = 40, par = 0;
+  int chunk = 44, par = 0;
   for (int total = 0;; total += chunk, chunk = 8) {
     for (int cyc = 0; cyc < chunk; ++cyc) {
       a.par = par;

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for cfg in "8 4 1500" "20 8 3000"; do
-  echo "== $cfg"; GMMLOC_HIP_LIB=$PWD/gmmloc_amd/variants/lib_pipeprof.so python tools/ba_one.py $cfg 2 2>&1 | grep "cycles:" | tail -1
-done
+mkdir -p gpurun_out
+BAGEN_MODE=2 python tools/ba_bits.py > gpurun_out/bits_new.txt 2>&1
+echo "== new"; BAGEN_MODE=2 python tools/ba_time.py 2>&1 | grep "^P"
+timeout 900 python -m pytest tests/test_gpu_ba.py -x -q 2>&1 | tail -3
