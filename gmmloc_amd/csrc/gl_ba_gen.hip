@@ -864,8 +864,8 @@ GL_DEV void ldlt_backward(SP S, int ld, int n, const double* idg, double* yv, do
 // + ldlt_panel_row.  The block's own rows and y leave wave 0 AFTER the barrier that follows (ad / yd): the other waves read them
 // at their start.
 template <class SP>
-GL_DEV void ldlt_diag_panel_wave(SP S, int ld, int base, int n, double* idg, double* yv, int* s_flag, double* ad, double& yd) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+GL_DEV void ldlt_diag_panel_wave(SP S, int ld, int base, int n, double* idg, double* yv, int* s_flag, double* ad, double& yd, int wave) {
+  const int lane = threadIdx.x & 63;
   const bool isd = lane < 6;
   const int prow = base + 6 + wave * 58 + (lane - 6);
   const int row = isd ? base + lane : prow, rr = min(row, n - 1);
@@ -957,7 +957,26 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       const int i = ti + 16 * a, j = tj + 16 * b;
       v[a][b] = (i < n && j <= i) ? src[(size_t)i * lsrc + j] : 0.0;
     }
-  if (fuse) {
+  if (fuse && V == 1) {
+    // diag_terms() without its branches and dependent loads (a third of the kernel at 20 poses when called per tile): an element of
+    // the diagonal block of its row's pose sits in column tile a or a - 1; flags and prior information per row tile come first
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const int i = ti + 16 * a, jp = min(i, n - 1) / 6, r6 = min(i, n - 1) - 6 * jp;
+      const bool act = G.pact[jp] != 0, pri = act && G.prior[jp] && k.first_as_prior;
+      const double* H = G.prH + (size_t)jp * 36 + r6 * 6;
+#pragma unroll
+      for (int b = (a > 0 ? a - 1 : 0); b <= a; ++b) {
+        const int j = tj + 16 * b, c6 = j - 6 * jp;
+        const bool in = i < n && j <= i && c6 >= 0;
+        const double h = H[min(max(c6, 0), 5)];
+        double x = v[a][b];
+        x = pri ? x + h : x;
+        if (i == j) x = act ? x + lambda : 1.0;
+        v[a][b] = in ? x : v[a][b];
+      }
+    }
+  } else if (fuse) {
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -974,6 +993,7 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
 #pragma unroll
     for (int b = 0; b < A; ++b) {
       const int j = tj + 16 * b;
+      if (V == 1 && b != base / 16 && b != (base + 5) / 16) continue;  // (uniform: the six columns touch at most two column tiles)
       if (j >= base && j < m0) {
 #pragma unroll
         for (int a = b; a < A; ++a) {
@@ -987,7 +1007,7 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
     GP_ADD(8, q0, qa);
     double ad[6], yd = 0.0;
     if (V == 1) {
-      ldlt_diag_panel_wave(S, ld, base, n, idg, yv, s_flag, ad, yd);
+      ldlt_diag_panel_wave(S, ld, base, n, idg, yv, s_flag, ad, yd, tid >> 6);
     } else {
 #ifdef GL_BAGEN_NO_WAVEDIAG
       if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
@@ -1048,6 +1068,149 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
   __syncthreads();
   GP_T(qb1);
   GP_ADD(7, qb0, qb1);
+  return *s_flag != 0;
+}
+// The factorisation on TWO TEAMS of four waves (the solve kernel of the pipelined shape, 512 threads): team T = the 256 threads
+// of ldlt_solve_tiles with the trailing matrix in their registers, team D = four waves that factorise diagonal block + panel
+// (ldlt_diag_panel_wave).  One block AHEAD: as soon as T has updated the column tiles that hold the NEXT pose's six columns and
+// put those columns into LDS, D factorises that pose while T applies the current panel to the rest of its tiles - the two
+// phases that were a third each of a pose step run side by side (a T wave and a D wave per SIMD).  Per pose step:
+//     T: TU1 (column tiles of the next pose) + column store | D: -          -> barrier
+//     T: TU2 (the other tiles)                              | D: diag + panel of the next pose   -> barrier
+// Operands and order per element are those of ldlt_solve_tiles: the same bits.
+template <int A, class SP>
+GL_DEV bool ldlt_solve_teams(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, SP S, int ld, double* g, int n,
+                             int* s_flag, double* idg) {
+  const int tid = threadIdx.x, tt = tid & 255, ti = tt >> 4, tj = tt & 15;
+  const bool teamT = tid < 256;
+  double* yv = idg + 128;
+  if (tid == 0) *s_flag = 1;
+  GP_T(u0);
+  double v[A][A];
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = ti + 16 * a, j = tj + 16 * b;
+      v[a][b] = (teamT && i < n && j <= i) ? src[(size_t)i * lsrc + j] : 0.0;
+    }
+  GP_T(u1);
+  GP_ADD(4, u0, u1);
+  if (teamT) {
+    // diag_terms() without its branches and dependent loads: an element of the diagonal block of its row's pose sits in column
+    // tile a or a - 1; flags and prior information per row tile come first
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const int i = ti + 16 * a, jp = min(i, n - 1) / 6, r6 = min(i, n - 1) - 6 * jp;
+      const bool act = G.pact[jp] != 0, pri = act && G.prior[jp] && k.first_as_prior;
+      const double* H = G.prH + (size_t)jp * 36 + r6 * 6;
+#pragma unroll
+      for (int b = (a > 0 ? a - 1 : 0); b <= a; ++b) {
+        const int j = tj + 16 * b, c6 = j - 6 * jp;
+        const bool in = i < n && j <= i && c6 >= 0;
+        const double h = H[min(max(c6, 0), 5)];
+        double x = v[a][b];
+        x = pri ? x + h : x;
+        if (i == j) x = act ? x + lambda : 1.0;
+        v[a][b] = in ? x : v[a][b];
+      }
+    }
+  }
+  // the six columns [cb, cb + 6) leave the registers of their owners
+  auto colstore = [&](int cb) {
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      if (b != cb / 16 && b != (cb + 5) / 16) continue;  // (uniform: six columns touch at most two column tiles)
+      const int j = tj + 16 * b;
+      if (j >= cb && j < cb + 6) {
+#pragma unroll
+        for (int a = b; a < A; ++a) {
+          const int i = ti + 16 * a;
+          if (i < n && j <= i) S[(size_t)i * ld + j] = v[a][b];
+        }
+      }
+    }
+  };
+  double ad[6], yd = 0.0;  // D, wave 0, lanes 0 .. 5: the block's own rows, stored behind the barrier that follows (see ldlt_diag_panel_wave)
+  auto diag_store = [&](int base) {
+    if (tid >= 256 && tid < 256 + 6) {
+      const int r = tid - 256;
+      yv[base + r] = yd;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        if (c <= r) S[(size_t)(base + r) * ld + base + c] = ad[c];
+    }
+  };
+  GP_T(u2);
+  GP_ADD(5, u1, u2);
+  if (teamT) colstore(0);
+  __syncthreads();
+  if (!teamT) ldlt_diag_panel_wave(S, ld, 0, n, idg, yv, s_flag, ad, yd, (tid >> 6) - 4);
+  __syncthreads();
+  GP_T(u3);
+  GP_ADD(6, u2, u3);
+  for (int base = 0; base < n; base += 6) {
+    const int m0 = base + 6;
+    const int nb0 = m0 / 16, nb1 = (m0 + 5) / 16;  // column tiles of the next pose
+    double ci[A][6];
+    if (teamT) {
+      double idc[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) idc[c] = idg[base + c];
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        if (16 * a + 15 < m0) continue;  // (uniform) the whole row tile is factorised
+        const int i = min(ti + 16 * a, n - 1);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ci[a][c] = S[(size_t)i * ld + base + c] * idc[c];
+      }
+    } else {
+      diag_store(base);
+    }
+    auto update = [&](bool first) {
+#pragma unroll
+      for (int b = 0; b < A; ++b) {
+        if (16 * b + 15 < m0) continue;
+        if (((b == nb0) | (b == nb1)) != first) continue;  // (uniform)
+        const int j = tj + 16 * b, jc = min(j, n - 1);
+        double sj[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sj[c] = S[(size_t)jc * ld + base + c];
+#pragma unroll
+        for (int a = b; a < A; ++a) {
+          const int i = ti + 16 * a;
+          if (j >= m0 && j <= i && i < n) {
+            double x = v[a][b];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x -= ci[a][c] * sj[c];
+            v[a][b] = x;
+          }
+        }
+      }
+    };
+    if (m0 < n) {
+      GP_T(t0);
+      if (teamT) {
+        update(true);
+        colstore(m0);
+      }
+      GP_T(t1);
+      __syncthreads();
+      GP_T(t2);
+      if (teamT) update(false);
+      else ldlt_diag_panel_wave(S, ld, m0, n, idg, yv, s_flag, ad, yd, (tid >> 6) - 4);
+      GP_T(t3);
+      __syncthreads();
+      GP_T(t4);
+      GP_ADD(8, t0, t1); GP_ADD(9, t1, t2); GP_ADD(10, t2, t3); GP_ADD(11, t3, t4);
+    }
+  }
+  __syncthreads();  // (the last pose's own rows come from team D)
+  GP_T(tb0);
+  ldlt_backward_wave(S, ld, n, idg, yv, g);
+  __syncthreads();
+  GP_T(tb1);
+  GP_ADD(7, tb0, tb1);
   return *s_flag != 0;
 }
 // n <= NMAX <= 48 (up to 8 free poses), round 3: the whole factorisation on ONE WAVE, lane r = row r held in registers
@@ -1135,7 +1298,7 @@ GL_DEV bool ldlt_solve_large(double* S, double* g, int n, int ld, int* s_flag) {
     if (tid == 0 && (d == 0.0 || !isfinite(d))) *s_flag = 0;
     // trailing update with the un-scaled column: S[i][j] -= c_i c_j / d  (kk < j <= i)
     const double id = 1.0 / d;
-    for (int i = kk + 1 + (tid >> 4); i < n; i += T_BA / 16) {
+    for (int i = kk + 1 + (tid >> 4); i < n && tid < T_BA; i += T_BA / 16) {  // (the solve kernel of the pipelined shape has 512 threads)
       const double ci = S[(size_t)i * ld + kk] * id;
       for (int j = kk + 1 + (tid & 15); j <= i; j += 16) S[(size_t)i * ld + j] -= ci * S[(size_t)j * ld + kk];
     }
@@ -1144,15 +1307,15 @@ GL_DEV bool ldlt_solve_large(double* S, double* g, int n, int ld, int* s_flag) {
   for (int kk = 0; kk < n; ++kk) {
     const double yk = g[kk] / S[(size_t)kk * ld + kk];
     __syncthreads();
-    for (int i = kk + 1 + tid; i < n; i += T_BA) g[i] -= S[(size_t)i * ld + kk] * yk;
+    for (int i = kk + 1 + tid; i < n && tid < T_BA; i += T_BA) g[i] -= S[(size_t)i * ld + kk] * yk;
     __syncthreads();
   }
-  for (int i = tid; i < n; i += T_BA) g[i] /= S[(size_t)i * ld + i];
+  for (int i = tid; i < n && tid < T_BA; i += T_BA) g[i] /= S[(size_t)i * ld + i];
   __syncthreads();
   for (int kk = n - 1; kk >= 0; --kk) {
     const double xk = g[kk];
     __syncthreads();
-    for (int i = tid; i < kk; i += T_BA) g[i] -= S[(size_t)kk * ld + i] / S[(size_t)i * ld + i] * xk;
+    for (int i = tid; i < kk && tid < T_BA; i += T_BA) g[i] -= S[(size_t)kk * ld + i] / S[(size_t)i * ld + i] * xk;
     __syncthreads();
   }
   return *s_flag != 0;
@@ -1929,17 +2092,29 @@ __global__ __launch_bounds__(T_BA) void kp_setup_lists(PipeA a, int nws) {
   const int P = a.P, nobs = G.nobs;
   int* cnt = (int*)a.partS + ((size_t)f * nws + w) * P;  // (the Schur partials are idle during the set-up)
   const int o0 = w * SORT_SPAN, o1 = min(nobs, o0 + SORT_SPAN);
-  for (int jj = lane; jj < P && !FILL; jj += 64) cnt[jj] = 0;
-  for (int jj = 0; jj < P; ++jj) {  // (P <= ~20: a ballot per pose and step)
-    int run = FILL ? cnt[jj] : 0;   // FILL: the list position of this wave's first observation of pose jj (from the scan)
-    for (int o = o0 + lane; o - lane < o1; o += 64) {
-      const bool hit = o < o1 && G.opose[o] == jj;
+  // the wave's 512 observations (pose, point) fetched ONCE, eight per lane (re-reading the pose of every observation for
+  // every pose made this pass 70 us at 58 000 observations); then a ballot per pose and round
+  constexpr int NR = SORT_SPAN / 64;
+  int ps[NR], pt[NR], start = 0;
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const int o = o0 + q * 64 + lane;
+    ps[q] = o < o1 ? G.opose[o] : -1;
+    pt[q] = (FILL && o < o1) ? G.opoint[o] : 0;
+  }
+  if (FILL && lane < P) start = cnt[lane];  // the list position of this wave's first observation of pose `lane` (from the scan)
+  for (int jj = 0; jj < P; ++jj) {
+    int run = FILL ? __shfl(start, jj & 63) : 0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const bool hit = ps[q] == jj;
       const unsigned long long m = __ballot(hit);
       if (FILL && hit) {
+        const int o = o0 + q * 64 + lane;
         const int e = run + __popcll(m & ((1ull << lane) - 1ull));
         G.pl_obs[e] = o;
         G.pl_pos[o] = e;
-        G.pl_pt[e] = G.opoint[o];
+        G.pl_pt[e] = pt[q];
       }
       run += __popcll(m);
     }
@@ -1955,14 +2130,24 @@ __global__ __launch_bounds__(T_BA) void kp_setup_scan(PipeA a, int nws) {
   genp_init(G, a, f, 1, 0);
   int* cnt = (int*)a.partS + (size_t)f * nws * P;
   __shared__ int tot[256];
-  for (int j = tid; j < P; j += T_BA) {  // a thread per pose walks its column (nws <= ~120)
+  // a wave per pose: exclusive scan of its column of counts, 64 waves' counts per round (a thread per pose walking its column
+  // was a chain of ~120 dependent read-modify-writes)
+  for (int j = tid >> 6; j < P; j += NW_BA) {
+    const int lane = tid & 63;
     int s = 0;
-    for (int w = 0; w < nws; ++w) {
-      const int c = cnt[(size_t)w * P + j];
-      cnt[(size_t)w * P + j] = s;
-      s += c;
+    for (int w0 = 0; w0 < nws; w0 += 64) {
+      const int w = w0 + lane;
+      const int c = w < nws ? cnt[(size_t)w * P + j] : 0;
+      int x = c;  // inclusive scan over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+      }
+      if (w < nws) cnt[(size_t)w * P + j] = s + x - c;
+      s += __shfl(x, 63);
     }
-    tot[j] = s;
+    if (lane == 0) tot[j] = s;
   }
   __syncthreads();
   if (tid == 0) {
@@ -1986,15 +2171,18 @@ __global__ __launch_bounds__(T_BA) void kp_setup_partner(PipeA a) {
   if (st_cur(a, f)->stage >= 3) return;
   GenP G;
   genp_init(G, a, f, a.nba, pb);
-  for (int l = GSTART; l < a.L; l += GSTRIDE)
-    for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1) {
-      if (G.opose[o1] >= P) continue;
-      const size_t row = (size_t)G.pl_pos[o1] * P;
-      for (int o2 = G.optr[l]; o2 < G.optr[l + 1]; ++o2) {
-        const int j2 = G.opose[o2];
-        if (j2 < P) G.plm[row + j2] = o2;
-      }
+  // a thread per observation of a free pose (a thread per point walked (observations of the point)^2 dependent loads: 130 us
+  // at 20 poses)
+  for (int o1 = GSTART; o1 < G.nobs; o1 += GSTRIDE) {
+    const int l = G.opoint[o1], j1 = G.opose[o1], e = G.pl_pos[o1];
+    const int ob = G.optr[l], oe = G.optr[l + 1];
+    if (j1 >= P) continue;
+    const size_t row = (size_t)e * P;
+    for (int o2 = ob; o2 < oe; ++o2) {
+      const int j2 = G.opose[o2];
+      if (j2 < P) G.plm[row + j2] = o2;
     }
+  }
 }
 // ---- head of a cycle: the trial of the previous cycle is JUDGED (accept / reject, lambda, loop control: the arithmetic of
 // SparseOptimizer / OptimizationAlgorithmLevenberg in k_ba_gen's order), then P1: point pass (linearise the observations, point
@@ -2292,7 +2480,8 @@ __global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
 // opening instead; one workgroup per problem.  The factorisation loads its register tiles straight from the assembled system
 // in global memory and adds the prior information / lambda / the unit diagonal of inactive poses on the way (diag_terms, as in
 // the persistent kernel): a copy into LDS with those terms added there cost 10 - 60 k cycles of the kernel's 65 - 210 k.
-__global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
+constexpr int T_SOLVE = 512;  // two teams of four waves in the factorisation (ldlt_solve_teams)
+__global__ __launch_bounds__(T_SOLVE) void kp_solve(PipeA a) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ double red[NW_BA * 32 + 128 + 128];
   __shared__ double s_part[2 * 256 + 24];
@@ -2319,11 +2508,11 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   const bool small = n <= 128;
   const bool init = ctl.init != 0;
   // partial sums of the point pass, the prior chi2 and the reduced right-hand side: requested together, added in index order
-  for (int i = tid; i < 2 * a.nba; i += T_BA) s_part[i] = a.partA[(size_t)f * a.nba * 2 + i];
+  for (int i = tid; i < 2 * a.nba; i += T_SOLVE) s_part[i] = a.partA[(size_t)f * a.nba * 2 + i];
   if (tid < P) s_part[2 * a.nba + tid] = G.pchi[tid];
   const bool stage_lds = P <= 22;
   if (stage_lds) {
-    for (int i = tid; i < P * 36; i += T_BA) s_prH[i] = G.prH[i];
+    for (int i = tid; i < P * 36; i += T_SOLVE) s_prH[i] = G.prH[i];
     if (tid < P) {
       s_pact[tid] = G.pact[tid];
       s_prior[tid] = G.prior[tid];
@@ -2331,12 +2520,12 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   }
   double mine = 0.0;
   if (init) {
-    for (int i = tid; i < n; i += T_BA) {
+    for (int i = tid; i < n; i += T_SOLVE) {
       const int j = i / 6, r = i - 6 * j;
       if (G.pact[j]) mine = fabs(G.S[(size_t)i * ld + i] + G.prH[(size_t)j * 36 + r * 6 + r]);
     }
   } else {
-    for (int i = tid; i < n; i += T_BA) {
+    for (int i = tid; i < n; i += T_SOLVE) {
       const int j = i / 6;
       double v = G.gv[i];
       if (G.pact[j] && G.prior[j] && a.k.first_as_prior) {
@@ -2380,9 +2569,13 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
         GL.pact = s_pact;
         GL.prior = s_prior;
       }
-      ok = ldlt_solve_small<1>(GL, a.k, lambda, G.S, ld, true, (lds_double*)dyn_lds, ld, G.dxv, n, &s_flag, red);
+      lds_double* W = (lds_double*)dyn_lds;
+      ok = n <= 32   ? ldlt_solve_teams<2>(GL, a.k, lambda, G.S, ld, W, ld, G.dxv, n, &s_flag, red)
+           : n <= 48 ? ldlt_solve_teams<3>(GL, a.k, lambda, G.S, ld, W, ld, G.dxv, n, &s_flag, red)
+           : n <= 80 ? ldlt_solve_teams<5>(GL, a.k, lambda, G.S, ld, W, ld, G.dxv, n, &s_flag, red)
+                     : ldlt_solve_teams<8>(GL, a.k, lambda, G.S, ld, W, ld, G.dxv, n, &s_flag, red);
     } else {  // the scalar-pivot path factorises in global memory: the diagonal terms go in first
-      for (int j = tid; j < P; j += T_BA) {
+      for (int j = tid; j < P; j += T_SOLVE) {
         if (!G.pact[j]) {
           for (int r = 0; r < 6; ++r) G.S[(size_t)(6 * j + r) * ld + 6 * j + r] = 1.0;
           continue;
@@ -2402,7 +2595,7 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
 #ifdef GL_PIPE_PROF
   const long long s3 = clock64();
 #endif
-  for (int j = tid; j < P; j += T_BA) {  // trial poses
+  for (int j = tid; j < P; j += T_SOLVE) {  // trial poses
     const SE3 T = se3_load(G.poses + (size_t)j * 7);
     SE3 Tn = T;
     if (G.pact[j] && ok) {
@@ -2429,8 +2622,8 @@ __global__ __launch_bounds__(T_BA) void kp_solve(PipeA a) {
   if (tid == 0 && f == 0) {
     const long long s4 = clock64();
     st->dbg[8] += s1 - s0; st->dbg[9] += s2 - s1; st->dbg[10] += s3 - s2; st->dbg[11] += s4 - s3; st->dbg[12] += 1;
-    printf("solve cycles: load %lld add %lld ldlt %lld poses %lld calls %lld | ldlt: colstore %llu diag %llu panel %llu trailing %llu backward %llu\n", st->dbg[8], st->dbg[9], st->dbg[10], st->dbg[11], st->dbg[12],
-           g_gprof[8], g_gprof[9], g_gprof[10], g_gprof[11], g_gprof[7]);
+    printf("solve cycles: load %lld add %lld ldlt %lld poses %lld calls %lld | ldlt(T thread 0): TU1+colstore %llu wait %llu TU2 %llu wait(D) %llu backward %llu tileload %llu diagterms %llu first %llu\n", st->dbg[8], st->dbg[9], st->dbg[10], st->dbg[11], st->dbg[12],
+           g_gprof[8], g_gprof[9], g_gprof[10], g_gprof[11], g_gprof[7], g_gprof[4], g_gprof[5], g_gprof[6]);
   }
 #endif
 }
@@ -2616,7 +2809,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
       kp_lin<<<B * a.nba, T_BA, 0, c->stream>>>(a);
       kp_schur<<<schur_blocks, T_BA, 0, c->stream>>>(a);
       kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, c->stream>>>(a);
-      kp_solve<<<B, T_BA, s_bytes, c->stream>>>(a);
+      kp_solve<<<B, T_SOLVE, s_bytes, c->stream>>>(a);
       kp_trial<<<B * a.nba, T_BA, 0, c->stream>>>(a);
     }
     GL_HIP(hipGetLastError());
