@@ -878,13 +878,23 @@ GL_DEV void ldlt_diag_panel_wave(SP S, int ld, int base, int n, double* idg, dou
   for (int c = 0; c < 6; ++c) {
     const double d = readlane_f64(a[c], c);
     bad = bad || d == 0.0 || !isfinite(d);
+#ifdef GL_PIPE_IEEE_DIV
     id[c] = 1.0 / d;
+#else
+    {  // reciprocal pivot by v_rcp_f64 + two Newton steps (<= 1 ulp from 1 / d): the correctly rounded division is 12 dependent
+       // instructions on the one chain a pose step cannot shorten - pivot -> multiplier -> next pivot, six times per pose
+      double x = __builtin_amdgcn_rcp(d);
+      x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+      x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+      id[c] = x;
+    }
+#endif
     const double yc = readlane_f64(y, c);
     const double ci = a[c] * id[c];
 #pragma unroll
     for (int j = c + 1; j < 6; ++j) {
       const double ajc = readlane_f64(a[c], j);  // a[j][c] of the block
-      if (!isd || lane >= j) a[j] -= ci * ajc;
+      a[j] -= ci * ajc;  // (a lane of the block's own rows also touches its entries right of the diagonal: never read)
     }
     if (!isd || lane > c) y = __builtin_fma(-ci, yc, y);
   }
@@ -1811,6 +1821,7 @@ struct PipeA {  // kernel arguments (by value)
   PipeSt* st;         // 2 x B: a cycle of parity `par` reads [par] (the state its predecessor left) in its first kernel, which
                       // writes the judged state to [par ^ 1]; the rest of the cycle works on [par ^ 1]
   int par;
+  int cyc;            // index of the cycle (the call's last one is reported through unfinished[1]: the next call's look-ahead)
   double* partA;      // B x nba x 2   {robust chi2, max point diagonal} per workgroup of the point pass
   double* partD;      // B x nba x 2   {scale part, chi2 at the trial state}
   double* partS;      // B x nblk x nchunk x 48
@@ -1988,6 +1999,7 @@ GL_DEV void pipe_adv_open(const PipeA& a, GenP& G, PipeSt* st, int f, int* s_cnt
       st->pend = 0;
       if (a.iters) a.iters[f] = it3;
       if (a.trials_out) a.trials_out[f] = q.trials;
+      atomicMax(a.unfinished + 1, a.cyc + 1);
       atomicSub(a.unfinished, 1);
     }
     return;
@@ -2264,8 +2276,35 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
     }
     if (tid < P) s_d[2 * a.nba + 2 * n + tid] = G.pchi2[tid];
   }
+  // what the verdict will be applied to is requested in the same round trip as the terms it is made from: both versions of
+  // the poses (two elements per thread) and the trial state of the thread's point
+  PipeSt qin;
+  if (tid == 0) qin = *sp;
+  double rt_cur[2] = {0.0, 0.0}, rt_new[2] = {0.0, 0.0};
+  int rt_act[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = tid + q * T_BA, j = i / 12;
+    if (i < (P + F) * 12) {
+      rt_cur[q] = G.Rt[i];
+      if (j < P) {
+        rt_new[q] = G.RtN[i];
+        rt_act[q] = G.pact[j];
+      }
+    }
+  }
+  const int per = T_BA / a.lpp;  // points of a workgroup per round of the point pass (pass_points: l = GSTART / LPP)
+  const int l0 = pb * per + tid;
+  const bool has = tid < per && l0 < G.L;
+  int la0 = 0;
+  double pn0[3] = {0.0, 0.0, 0.0};
+  if (has && judge) {
+    la0 = G.lact[l0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pn0[i] = G.pn[(size_t)l0 * 3 + i];
+  }
   if (tid == 0 && !judge) {
-    s_q = *sp;
+    s_q = qin;
     s_accept = 0;
     s_next = -1;
   }
@@ -2273,7 +2312,7 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   if (tid == 0 && judge) {
     PipeSt q;
     int acc, nx;
-    pipe_judge(a, G, *sp, q, s_d, &acc, &nx);
+    pipe_judge(a, G, qin, q, s_d, &acc, &nx);
     s_q = q;
     s_accept = acc;
     s_next = nx;
@@ -2282,14 +2321,18 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   const bool accept = s_accept != 0;
   const int next = s_next;
   // the poses this workgroup linearises at: LDS copy, trial poses of the active free key-frames on acceptance
-  for (int i = tid; i < (P + F) * 12; i += T_BA) {
-    const int j = i / 12;
-    s_Rt[i] = (accept && j < P && G.pact[j]) ? G.RtN[i] : G.Rt[i];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = tid + q * T_BA;
+    if (i < (P + F) * 12) s_Rt[i] = (accept && rt_act[q]) ? rt_new[q] : rt_cur[q];
   }
   // its points: trial -> current
   if (accept) {
-    const int per = T_BA / a.lpp;  // points of a workgroup per round of the point pass (pass_points: l = GSTART / LPP)
-    for (int l = pb * per + tid; l < G.L; l += a.nba * per) {
+    if (has && la0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) G.pts[(size_t)l0 * 3 + i] = pn0[i];
+    }
+    for (int l = l0 + a.nba * per; l < G.L; l += a.nba * per) {  // (further rounds: none with nba = ceil(L lpp / T_BA))
       if (tid >= per) break;
       if (!G.lact[l]) continue;
 #pragma unroll
@@ -2725,7 +2768,9 @@ static void pipe_shape(int P, int L, int NOBS, int* nba, int* lpp, int* nblk, in
   *lpp = 4;
   *nba = std::max(1, (L * 4 + T_BA - 1) / T_BA);
   *nblk = P * (P + 1) / 2;
-  *nchunk = NOBS <= 1024 ? 4 : 16;            // waves per block of the Schur pass (each takes 1 / nchunk of the longest pose list)
+  // waves per block of the Schur pass (each takes 1 / nchunk of the longest pose list); at 20 poses 12 (2 520 waves of 4 rounds)
+  // is 8 % faster than 16 (3 360 of 3: a second wave of workgroups behind the first)
+  *nchunk = NOBS <= 1024 ? 4 : NOBS <= 40000 ? 16 : 12;
 }
 size_t ba_pipe_scratch_bytes(int B, int P, int F, int L, int NOBS) {
   int nba, lpp, nblk, nchunk;
@@ -2784,8 +2829,9 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   // page-locked word the device's count of unfinished problems is copied to between chunks of cycles
   if (!c->host_word) GL_HIP(hipHostMalloc((void**)&c->host_word, 64, hipHostMallocDefault));
   TimerScope ts(c, GL_TIMER_BA);
-  *c->host_word = B;
-  GL_HIP(hipMemcpyAsync(a.unfinished, c->host_word, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->host_word[0] = B;
+  c->host_word[1] = 0;
+  GL_HIP(hipMemcpyAsync(a.unfinished, c->host_word, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   {
     const int nws = std::max(1, (NOBS + SORT_SPAN - 1) / SORT_SPAN);
     const int lblocks = (int)(((long)B * nws + NW_BA - 1) / NW_BA);
@@ -2801,10 +2847,13 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
   // one) + 4 cycles that open / change the stage + the one that judges the last trial: enough cycles for the common case are enqueued before the
   // first look at the counter, fewer per look afterwards
-  int chunk = 44, par = 0;
+  // (the look-ahead of a call is what the context's previous window needed, + 2: windows follow each other with similar trial
+  // counts; a cycle beyond the end costs five empty launches, a cycle short a host round trip)
+  int chunk = c->pipe_hint > 0 ? std::min(std::max(c->pipe_hint + 2, 12), 80) : 44, par = 0;
   for (int total = 0;; total += chunk, chunk = 8) {
     for (int cyc = 0; cyc < chunk; ++cyc) {
       a.par = par;
+      a.cyc = total + cyc;
       par ^= 1;
       kp_lin<<<B * a.nba, T_BA, 0, c->stream>>>(a);
       kp_schur<<<schur_blocks, T_BA, 0, c->stream>>>(a);
@@ -2813,9 +2862,12 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
       kp_trial<<<B * a.nba, T_BA, 0, c->stream>>>(a);
     }
     GL_HIP(hipGetLastError());
-    GL_HIP(hipMemcpyAsync(c->host_word, a.unfinished, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    GL_HIP(hipMemcpyAsync(c->host_word, a.unfinished, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     GL_HIP(hipStreamSynchronize(c->stream));
-    if (*c->host_word <= 0) break;
+    if (c->host_word[0] <= 0) {
+      if (c->host_word[1] > 0) c->pipe_hint = c->host_word[1];
+      break;
+    }
     if (total > 600) {  // 3 x (40 iterations x 10 trials) is the schedule's bound; this is a defect, not a slow problem
       set_error("launch_ba_pipe: %d problem(s) did not finish in %d cycles", *c->host_word, total + chunk);
       return GL_ERR_DEVICE;

@@ -125,6 +125,7 @@ struct Ctx {
   // device counters (gl_ctx_counter_read): [0] frames of latency-shape launches redone by the follow-up kernel
   int32_t* counters = nullptr;
   int* host_word = nullptr;  // page-locked word (the pipelined local BA's count of unfinished problems)
+  int pipe_hint = 0;         // cycles the last pipelined local BA needed (the next call enqueues that many + 2 ahead)
   // optional statistics buffer (gl_ctx_set_stats_buffer)
   int32_t* stats = nullptr;
   int stats_n = 0;
