@@ -2894,12 +2894,14 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   gl::Gmm* g = gl::G(gmm);
   GL_HIP(hipSetDevice(c->device));
   void* scratch = nullptr;
-  // Shape (option bagen_mode: 0 by size, 1 the persistent kernel, 2 the pipelined shape).  Measured on single windows
-  // (profiles/r3_bagen_shapes.txt): 8 + 4 key-frames / 12 600 observations 2.96 ms pipelined vs 2.87 persistent, 12 + 4 /
-  // 22 400 3.15 vs 4.70, 20 + 8 / 58 600 7.24 vs 6.51 (there the 120 x 120 factorisation, one workgroup in either shape, is
-  // 40 % of a cycle and the persistent kernel needs no lambda-init cycles); batches 0.23 vs 0.107 ms per problem.
+  // Shape (option bagen_mode: 0 by size, 1 the persistent kernel, 2 the pipelined shape).  Measured per Levenberg trial
+  // (profiles/r3c_ba_modes.txt; the two shapes add their partial sums in different orders, so a window can take a different
+  // NUMBER of trials in each - 22 against 33 on the 20 + 8 window - which says nothing about either): 8 + 4 key-frames / 12 600
+  // observations 73 us pipelined against 103 persistent, 12 + 4 / 22 400 103 against 149, 20 + 8 / 58 600 155 against 299; equal
+  // at 3 - 4 free poses (57 us), the persistent kernel ahead below (1 pose: 32 against 49) and in batches (64 windows of 8 + 4:
+  // 0.18 against 0.23 ms per window).
   const bool pipe_fits = P <= 22 && P + F <= 32 && L <= 16384;  // (the judging workgroups hold the partial sums and the poses in LDS)
-  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 2 && P <= 16 && NOBS >= 15000));
+  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 8 && NOBS >= 5000));
   int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_bytes(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
   if (pipe) {
