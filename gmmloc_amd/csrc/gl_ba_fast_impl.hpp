@@ -1307,7 +1307,21 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 // arbiter favours the older one, which then finishes its 4 slots a third of the pass early and leaves the younger
 // one alone on the SIMD at single-wave speed (measured: 11.6 k vs 18.3 k cycles).  Waves 4..7 sit at priority 1; waves
 // 0..3 start a pass at 2 and drop to 0 for their last slot, so that the pair ends the pass together.
-#ifdef GL_BAF_NO_PRIO
+#if defined(GL_BAF_BAL)
+// (experiment) self-balancing pair: each wave publishes how many point slots it has started (a byte per wave in LDS); at the start
+// of a slot a wave that is AHEAD of the other wave of its SIMD (w ^ 4) steps down to priority 0, one that is level or behind
+// goes to 2 - the lag stays within about one slot instead of growing to a third of the pass.
+#define GL_BAF_PRIO_PASS_BEGIN()
+#define GL_BAF_PRIO_SLOT(i)                                                                         \
+  if (NWC == 8) {                                                                                    \
+    volatile unsigned char* bal_ = (volatile unsigned char*)(R.tot + 62);                             \
+    ++bal_n;                                                                                         \
+    if ((threadIdx.x & 63) == 0) bal_[threadIdx.x >> 6] = (unsigned char)bal_n;                       \
+    const int other_ = __builtin_amdgcn_readfirstlane((int)bal_[(threadIdx.x >> 6) ^ 4]);             \
+    if ((signed char)((unsigned char)bal_n - (unsigned char)other_) > 0) __builtin_amdgcn_s_setprio(0); \
+    else __builtin_amdgcn_s_setprio(2);                                                              \
+  }
+#elif defined(GL_BAF_NO_PRIO)
 #define GL_BAF_PRIO_PASS_BEGIN()
 #define GL_BAF_PRIO_SLOT(i)
 #else
@@ -1365,6 +1379,8 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
                          const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
                          const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, Anchor& An) {
   double acc[32];
+  int bal_n = 0;  // (GL_BAF_BAL: point slots this wave has started)
+  (void)bal_n;
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
   {
@@ -1629,6 +1645,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   if (tid == 0) {
     *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
     *(int*)(R.tot + 61) = 0;  // a poll of the exchange gave up (SPREAD)
+    *(long long*)(R.tot + 62) = 0;  // (GL_BAF_BAL: slots started, a byte per wave)
   }
   {
     const int ns = kSpread ? 1 : mp.S;

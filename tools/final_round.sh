@@ -13,6 +13,7 @@ python tools/replay_euroc.py --anchor prior > gpurun_out/${TAG}_replay_euroc.jso
 ANCHORS="none prior" SIGMAS="0" bash tools/replay_matrix.sh > gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
 ANCHORS="fixed" SIGMAS="0 0.02" EXTRA="--limit 400" bash tools/replay_matrix.sh >> gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
 python tools/ba_time.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_time.txt
+python tools/ba_modes.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_modes.txt
 python tools/soak.py 2000 > gpurun_out/${TAG}_soak_strict.txt 2>&1
 tail -2 gpurun_out/${TAG}_soak_strict.txt | cut -c1-500
 cat gpurun_out/${TAG}_gpu_tests.txt
