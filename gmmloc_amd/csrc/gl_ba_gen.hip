@@ -298,6 +298,7 @@ template <int LPP>
 GL_DEV double group_sum(double v) {
   if (LPP >= 2) v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
   if (LPP >= 4) v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+  if (LPP >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the eight (every lane of a quad holds its sum)
   return v;
 }
 // LPP adjacent lanes per point (1, 2 or 4: as many as the problem's workgroups have threads for): the
@@ -407,6 +408,13 @@ GL_DEV double pass_points_lpp(int lpp, const BaK& k, const GmmDev& gm, const Gen
   return pass_points<1>(k, gm, G, robust, lambda, mdiag);
 }
 
+// (the kernels of the pipelined shape: 4 lanes per point, 8 where a point has six or more observations on average - half
+// the dependent loads per lane; instances of their own, so that the persistent kernel's code is what it was)
+GL_DEV double pass_points_pipe(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
+  if (lpp == 8) return pass_points<8>(k, gm, G, robust, lambda, mdiag);
+  return pass_points<4>(k, gm, G, robust, lambda, mdiag);
+}
+
 // ---- P3: back-substitution of the points, trial points, their chi2 (LPP lanes per point like P1) ------------
 template <int LPP>
 GL_DEV void pass_trial(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, int P, double* acc) {
@@ -498,6 +506,11 @@ GL_DEV void pass_trial_lpp(int lpp, const BaK& k, const GmmDev& gm, const GenP& 
   if (lpp == 4) return pass_trial<4>(k, gm, G, robust, lambda, P, acc);
   if (lpp == 2) return pass_trial<2>(k, gm, G, robust, lambda, P, acc);
   return pass_trial<1>(k, gm, G, robust, lambda, P, acc);
+}
+
+GL_DEV void pass_trial_pipe(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, int P, double* acc) {
+  if (lpp == 8) return pass_trial<8>(k, gm, G, robust, lambda, P, acc);
+  return pass_trial<4>(k, gm, G, robust, lambda, P, acc);
 }
 
 // ---- P2 -------------------------------------------------------------------------------------
@@ -2360,7 +2373,7 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   double acc[32], md = 0.0;
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  acc[0] = pass_points_lpp(a.lpp, a.k, a.gm, G, s_q.stage < 2, s_q.init ? 0.0 : s_q.lambda, md);
+  acc[0] = pass_points_pipe(a.lpp, a.k, a.gm, G, s_q.stage < 2, s_q.init ? 0.0 : s_q.lambda, md);
   block_reduce<1, NW_BA>(acc, red);
   md = block_max(md, red);
   if (threadIdx.x == 0) {
@@ -2684,7 +2697,7 @@ __global__ __launch_bounds__(T_BA) void kp_trial(PipeA a) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  pass_trial_lpp(a.lpp, a.k, a.gm, G, ctl.stage < 2, lambda, a.P, acc);
+  pass_trial_pipe(a.lpp, a.k, a.gm, G, ctl.stage < 2, lambda, a.P, acc);
   block_reduce<2, NW_BA>(acc, red);
   if (threadIdx.x == 0) {
     double* pd = a.partD + ((size_t)f * a.nba + pb) * 2;
@@ -2765,8 +2778,8 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
 
 // scratch of the pipelined shape: k_ba_gen's layout + the state words and the partial sums
 static void pipe_shape(int P, int L, int NOBS, int* nba, int* lpp, int* nblk, int* nchunk) {
-  *lpp = 4;
-  *nba = std::max(1, (L * 4 + T_BA - 1) / T_BA);
+  *lpp = NOBS >= 6 * L ? 8 : 4;  // lanes per point in the point passes
+  *nba = std::max(1, (L * *lpp + T_BA - 1) / T_BA);
   *nblk = P * (P + 1) / 2;
   // waves per block of the Schur pass (each takes 1 / nchunk of the longest pose list); at 20 poses 12 (2 520 waves of 4 rounds)
   // is 8 % faster than 16 (3 360 of 3: a second wave of workgroups behind the first)
@@ -2900,7 +2913,7 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   // observations 73 us pipelined against 103 persistent, 12 + 4 / 22 400 103 against 149, 20 + 8 / 58 600 155 against 299; equal
   // at 3 - 4 free poses (57 us), the persistent kernel ahead below (1 pose: 32 against 49) and in batches (64 windows of 8 + 4:
   // 0.18 against 0.23 ms per window).
-  const bool pipe_fits = P <= 22 && P + F <= 32 && L <= 16384;  // (the judging workgroups hold the partial sums and the poses in LDS)
+  const bool pipe_fits = P <= 22 && P + F <= 32 && (size_t)L * (NOBS >= 6 * L ? 8 : 4) <= 65536;  // (the judging workgroups hold <= 256 partial sums and the poses in LDS)
   const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 8 && NOBS >= 5000));
   int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_bytes(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;

@@ -22,6 +22,9 @@ def timed(P, F, L, B, reps=5):
     rep = lambda a: T(np.repeat(a[None], B, 0))
     args = [rep(p["prior"]), assoc, rep(p["obs_ptr"]), rep(p["obs_pose"]), rep(p["obs_uvr"]), rep(p["obs_oct"])]
 
+    stats = torch.zeros(B, dtype=torch.int32).cuda()
+    ctx.set_stats_buffer(stats)
+
     def run():
         poses, pts = rep(p["poses"]), rep(p["points"])
         r = api.joint_optimization(ctx, g, cam, prm, P, F, poses, args[0], pts, *args[1:])
@@ -33,8 +36,9 @@ def timed(P, F, L, B, reps=5):
         poses, r = run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    print("P%d F%d L%d obs %d x %d problem(s): %.3f ms per launch, %.3f ms per problem, iters %s" %
-          (P, F, L, len(p["obs_pose"]), B, ms, ms / B, r[2][:3].cpu().numpy()), flush=True)
+    tr = int(stats[0].item())
+    print("P%d F%d L%d obs %d x %d problem(s): %.3f ms per launch, %.3f ms per problem, iters %s, %d Levenberg trials (%.1f us per trial)" %
+          (P, F, L, len(p["obs_pose"]), B, ms, ms / B, r[2][:3].cpu().numpy(), tr, ms * 1e3 / max(tr, 1)), flush=True)
 
 
 for P, F, L in ((8, 4, 1500), (12, 4, 2000), (20, 8, 3000)):
