@@ -230,7 +230,9 @@ def config_ba(torch, ctx, out):
             flop += per_trial * float(tr[b])
         res["P%d_F%d_L%d_B%d" % (P, F, L, B)] = {"ms_per_call": 1e3 * t, "ms_per_problem": 1e3 * t / B, "observations": int(NOBS),
                                                  "trials_per_problem": float(tr.mean()),
-                                                 "roofline_ba": {"kernel": "k_ba_gen", "bound": "latency (valu_fp64 peak for reference)", "flop_per_launch": flop,
+                                                 "us_per_trial": 1e6 * t / max(float(tr.mean()), 1.0),
+                                                 "roofline_ba": {"kernel": "kp_lin + kp_schur + kp_assemble + kp_solve + kp_trial (pipelined shape)" if (B <= 8 and NOBS >= 5000) else "k_ba_gen",
+                                                                 "bound": "latency (valu_fp64 peak for reference)", "flop_per_launch": flop,
                                                                  "achieved": flop / t / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flop / t / 1e12 / 78.6}}
     out(res)
 
