@@ -98,8 +98,9 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *     (ba_rendezvous_us) and send the frame to the follow-up kernel.  0: device-scope stores only (0.37 instead of 0.34 ms),
  *   bagen_mode (0): launch shape of gl_joint_optimization - 1 the persistent cooperative kernel (asynchronous), 2 the
  *     pipelined shape (a kernel per phase, cycles enqueued ahead, the call returns with the work complete), 0 by window
- *     size (the pipelined shape for single mid-size windows, where it is up to 1.5 x faster); same arithmetic, both held
- *     to the oracle,
+ *     size (the pipelined shape from 5 000 observations for up to 8 windows per call: 1.4 - 2 x less per Levenberg trial);
+ *     same arithmetic, both held to the oracle; the two add their partial sums in different orders, so a window may take a
+ *     different number of trials in each,
  *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
