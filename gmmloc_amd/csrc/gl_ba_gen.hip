@@ -963,9 +963,9 @@ GL_DEV void ldlt_backward_wave(SP S, int ld, int n, const double* idg, double* y
 }
 
 // n <= 16 A <= 128, n a multiple of 6.  src (row stride lsrc): the assembled system, global memory or the work matrix
-// itself; fuse: add the diagonal terms while loading.  V = 1 (the solve kernel of the pipelined shape): diagonal block and panel
-// in one phase, one-wave backward substitution - same operands and order per element, so the same bits.  The right-hand side is in yv = idg + 128 (put there by the caller).
-template <int A, int V, class SP>
+// itself; fuse: add the diagonal terms while loading.  (The solve kernel of the pipelined shape runs
+// ldlt_solve_teams below: the same operands and order per element, so the same bits.)  The right-hand side is in yv = idg + 128 (put there by the caller).
+template <int A, class SP>
 GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
                              double* g, int n, int* s_flag, double* idg) {
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
@@ -980,26 +980,7 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       const int i = ti + 16 * a, j = tj + 16 * b;
       v[a][b] = (i < n && j <= i) ? src[(size_t)i * lsrc + j] : 0.0;
     }
-  if (fuse && V == 1) {
-    // diag_terms() without its branches and dependent loads (a third of the kernel at 20 poses when called per tile): an element of
-    // the diagonal block of its row's pose sits in column tile a or a - 1; flags and prior information per row tile come first
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      const int i = ti + 16 * a, jp = min(i, n - 1) / 6, r6 = min(i, n - 1) - 6 * jp;
-      const bool act = G.pact[jp] != 0, pri = act && G.prior[jp] && k.first_as_prior;
-      const double* H = G.prH + (size_t)jp * 36 + r6 * 6;
-#pragma unroll
-      for (int b = (a > 0 ? a - 1 : 0); b <= a; ++b) {
-        const int j = tj + 16 * b, c6 = j - 6 * jp;
-        const bool in = i < n && j <= i && c6 >= 0;
-        const double h = H[min(max(c6, 0), 5)];
-        double x = v[a][b];
-        x = pri ? x + h : x;
-        if (i == j) x = act ? x + lambda : 1.0;
-        v[a][b] = in ? x : v[a][b];
-      }
-    }
-  } else if (fuse) {
+  if (fuse) {
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -1016,7 +997,6 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
 #pragma unroll
     for (int b = 0; b < A; ++b) {
       const int j = tj + 16 * b;
-      if (V == 1 && b != base / 16 && b != (base + 5) / 16) continue;  // (uniform: the six columns touch at most two column tiles)
       if (j >= base && j < m0) {
 #pragma unroll
         for (int a = b; a < A; ++a) {
@@ -1026,29 +1006,16 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       }
     }
     __syncthreads();
-    GP_T(qa);
-    GP_ADD(8, q0, qa);
-    double ad[6], yd = 0.0;
-    if (V == 1) {
-      ldlt_diag_panel_wave(S, ld, base, n, idg, yv, s_flag, ad, yd, tid >> 6);
-    } else {
 #ifdef GL_BAGEN_NO_WAVEDIAG
-      if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
+    if (tid == 0) ldlt_diag_block(S, ld, base, idg, yv, s_flag);
 #else
-      if (tid < 64) ldlt_diag_block_wave(S, ld, base, idg, yv, s_flag);
+    if (tid < 64) ldlt_diag_block_wave(S, ld, base, idg, yv, s_flag);
 #endif
-      __syncthreads();
-    }
+    __syncthreads();
     GP_T(q1);
-    if (V != 1 && m0 + tid < n) ldlt_panel_row(S, ld, base, m0 + tid, idg, yv);
+    if (m0 + tid < n) ldlt_panel_row(S, ld, base, m0 + tid, idg, yv);
     __syncthreads();
     GP_T(q2);
-    if (V == 1 && tid < 6) {  // the block's own rows (nobody reads them before the backward substitution)
-      yv[base + tid] = yd;
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-        if (c <= tid) S[(size_t)(base + tid) * ld + base + c] = ad[c];
-    }
     double idc[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) idc[c] = idg[base + c];
@@ -1079,18 +1046,10 @@ GL_DEV bool ldlt_solve_tiles(const GenP& G, const BaK& k, double lambda, const d
       }
     }
     GP_T(q3);
-    GP_ADD(9, qa, q1); GP_ADD(10, q1, q2); GP_ADD(11, q2, q3);
+    GP_ADD(9, q0, q1); GP_ADD(11, q2, q3);
   }
-  GP_T(qb0);
-  if (V == 1) {
-    __syncthreads();  // (the last block's rows)
-    ldlt_backward_wave(S, ld, n, idg, yv, g);
-  } else {
-    ldlt_backward(S, ld, n, idg, yv, g);
-  }
+  ldlt_backward(S, ld, n, idg, yv, g);
   __syncthreads();
-  GP_T(qb1);
-  GP_ADD(7, qb0, qb1);
   return *s_flag != 0;
 }
 // The factorisation on TWO TEAMS of four waves (the solve kernel of the pipelined shape, 512 threads): team T = the 256 threads
@@ -1108,7 +1067,6 @@ GL_DEV bool ldlt_solve_teams(const GenP& G, const BaK& k, double lambda, const d
   const bool teamT = tid < 256;
   double* yv = idg + 128;
   if (tid == 0) *s_flag = 1;
-  GP_T(u0);
   double v[A][A];
 #pragma unroll
   for (int a = 0; a < A; ++a)
@@ -1117,8 +1075,6 @@ GL_DEV bool ldlt_solve_teams(const GenP& G, const BaK& k, double lambda, const d
       const int i = ti + 16 * a, j = tj + 16 * b;
       v[a][b] = (teamT && i < n && j <= i) ? src[(size_t)i * lsrc + j] : 0.0;
     }
-  GP_T(u1);
-  GP_ADD(4, u0, u1);
   if (teamT) {
     // diag_terms() without its branches and dependent loads: an element of the diagonal block of its row's pose sits in column
     // tile a or a - 1; flags and prior information per row tile come first
@@ -1164,14 +1120,10 @@ GL_DEV bool ldlt_solve_teams(const GenP& G, const BaK& k, double lambda, const d
         if (c <= r) S[(size_t)(base + r) * ld + base + c] = ad[c];
     }
   };
-  GP_T(u2);
-  GP_ADD(5, u1, u2);
   if (teamT) colstore(0);
   __syncthreads();
   if (!teamT) ldlt_diag_panel_wave(S, ld, 0, n, idg, yv, s_flag, ad, yd, (tid >> 6) - 4);
   __syncthreads();
-  GP_T(u3);
-  GP_ADD(6, u2, u3);
   for (int base = 0; base < n; base += 6) {
     const int m0 = base + 6;
     const int nb0 = m0 / 16, nb1 = (m0 + 5) / 16;  // column tiles of the next pose
@@ -1212,28 +1164,19 @@ GL_DEV bool ldlt_solve_teams(const GenP& G, const BaK& k, double lambda, const d
       }
     };
     if (m0 < n) {
-      GP_T(t0);
       if (teamT) {
         update(true);
         colstore(m0);
       }
-      GP_T(t1);
       __syncthreads();
-      GP_T(t2);
       if (teamT) update(false);
       else ldlt_diag_panel_wave(S, ld, m0, n, idg, yv, s_flag, ad, yd, (tid >> 6) - 4);
-      GP_T(t3);
       __syncthreads();
-      GP_T(t4);
-      GP_ADD(8, t0, t1); GP_ADD(9, t1, t2); GP_ADD(10, t2, t3); GP_ADD(11, t3, t4);
     }
   }
   __syncthreads();  // (the last pose's own rows come from team D)
-  GP_T(tb0);
   ldlt_backward_wave(S, ld, n, idg, yv, g);
   __syncthreads();
-  GP_T(tb1);
-  GP_ADD(7, tb0, tb1);
   return *s_flag != 0;
 }
 // n <= NMAX <= 48 (up to 8 free poses), round 3: the whole factorisation on ONE WAVE, lane r = row r held in registers
@@ -1298,17 +1241,17 @@ GL_DEV bool ldlt_solve_wave(const GenP& G, const BaK& k, double lambda, const do
   return *s_flag != 0;
 }
 
-template <int V = 0, class SP>
+template <class SP>
 GL_DEV bool ldlt_solve_small(const GenP& G, const BaK& k, double lambda, const double* src, int lsrc, bool fuse, SP S, int ld,
                              double* g, int n, int* s_flag, double* idg) {
 #ifdef GL_BAGEN_WAVE_LDLT  // (measured, not the default: see ldlt_solve_wave)
   if (n <= 24) return ldlt_solve_wave<24>(G, k, lambda, src, lsrc, fuse, g, n, s_flag, idg + 128);
   if (n <= 48) return ldlt_solve_wave<48>(G, k, lambda, src, lsrc, fuse, g, n, s_flag, idg + 128);
 #endif
-  if (n <= 32) return ldlt_solve_tiles<2, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
-  if (n <= 48) return ldlt_solve_tiles<3, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
-  if (n <= 80) return ldlt_solve_tiles<5, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
-  return ldlt_solve_tiles<8, V>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 32) return ldlt_solve_tiles<2>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 48) return ldlt_solve_tiles<3>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  if (n <= 80) return ldlt_solve_tiles<5>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
+  return ldlt_solve_tiles<8>(G, k, lambda, src, lsrc, fuse, S, ld, g, n, s_flag, idg);
 }
 
 // n > 128 (more than 21 free poses): scalar pivots, ONE barrier per pivot, on the matrix in memory; g in, x out
@@ -2678,8 +2621,8 @@ __global__ __launch_bounds__(T_SOLVE) void kp_solve(PipeA a) {
   if (tid == 0 && f == 0) {
     const long long s4 = clock64();
     st->dbg[8] += s1 - s0; st->dbg[9] += s2 - s1; st->dbg[10] += s3 - s2; st->dbg[11] += s4 - s3; st->dbg[12] += 1;
-    printf("solve cycles: load %lld add %lld ldlt %lld poses %lld calls %lld | ldlt(T thread 0): TU1+colstore %llu wait %llu TU2 %llu wait(D) %llu backward %llu tileload %llu diagterms %llu first %llu\n", st->dbg[8], st->dbg[9], st->dbg[10], st->dbg[11], st->dbg[12],
-           g_gprof[8], g_gprof[9], g_gprof[10], g_gprof[11], g_gprof[7], g_gprof[4], g_gprof[5], g_gprof[6]);
+    printf("solve cycles (cumulative over the run): fetch %lld  right-hand side %lld  factorisation + substitutions %lld  trial poses %lld  calls %lld\n", st->dbg[8], st->dbg[9], st->dbg[10],
+           st->dbg[11], st->dbg[12]);
   }
 #endif
 }
