@@ -442,7 +442,7 @@ def main():
             },
             # the association inside the step: exact argmin through the cell index (gather bound)
             "assoc_index": {
-                "kernel": "k_assoc_cells (exact cell index, chi2 <= 9 resolved, the rest gated out)",
+                "kernel": "k_assoc_cells_coop (exact cell index, wave-cooperative record gather; chi2 <= 9 resolved, the rest gated out)",
                 "avg_launch_ms": 1e3 * assoc_s,
                 "pairs_evaluated": idx_pairs,
                 "pairs_per_point": idx_pairs / float(B * N_PTS),

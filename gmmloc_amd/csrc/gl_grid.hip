@@ -111,6 +111,109 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
   }
 }
 
+// The same association with a WAVE-COOPERATIVE record gather.  In k_assoc_cells every lane fetches its own candidates' 96-byte
+// records: 6 loads of 16 bytes per candidate with 64 different lines per instruction.  Here the wave lists its candidates
+// (<= 3 per lane from the packed cell, compacted with a prefix sum over the lanes), six lanes fetch one record as six
+// neighbouring 16-byte pieces and the records reach their points through LDS, 60 records per round; lanes whose cell holds
+// more than three candidates (rare) walk their list as before.  Same arithmetic per pair, same (chi2, index) minimum.
+// Measured on the bench points: 0.421 -> 0.392 ms per 8.19 M points - the address cycles of the gather drop to a third, the
+// ~50 M line requests per launch to the XCDs' L2 (two lines per record, the 393 KB of records do not live in a 32 KB L1) do not.
+constexpr int CG_REC = 60;  // records per round: 10 per load instruction (6 lanes each, 4 lanes idle), 6 instructions
+__global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restrict__ rec12, GridDev G,
+                                                          const double* __restrict__ pts, int N,
+                                                          int32_t* __restrict__ out_idx, double* __restrict__ out_d2,
+                                                          int32_t* __restrict__ rest_list, int32_t* __restrict__ rest_count) {
+  __shared__ __attribute__((aligned(16))) double s_rec[4][CG_REC * 12];
+  __shared__ int s_id[4][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  const double x = pts[(size_t)nc * 3], y = pts[(size_t)nc * 3 + 1], z = pts[(size_t)nc * 3 + 2];
+  double best = __builtin_inf();
+  int bi = 0x7fffffff;
+  cdouble* rc = (cdouble*)rec12;
+  for (int j = 0; j < G.nglob; ++j) {  // wave-uniform: records through scalar loads
+    const int k = G.glob[j];
+    cdouble* r = rc + (size_t)k * 12;
+    const double d0 = x - r[0], d1 = y - r[1], d2 = z - r[2];
+    const double r0 = fma(d2, r[9], fma(d1, r[6], d0 * r[3]));
+    const double r1 = fma(d2, r[10], fma(d1, r[7], d0 * r[4]));
+    const double r2 = fma(d2, r[11], fma(d1, r[8], d0 * r[5]));
+    upd_min(fma(r2, d2, fma(r1, d1, r0 * d0)), k, best, bi);
+  }
+  const double fx = (x - G.lo[0]) * G.inv_h, fy = (y - G.lo[1]) * G.inv_h, fz = (z - G.lo[2]) * G.inv_h;
+  const bool inside = live && fx >= 0.0 && fx < (double)G.dim[0] && fy >= 0.0 && fy < (double)G.dim[1] && fz >= 0.0 &&
+                      fz < (double)G.dim[2];  // false for NaN
+  int4 q = make_int4(0, 0, 0, 0);
+  if (inside) q = G.cell4[((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx];
+  const int cnt = q.x <= 3 ? q.x : 0;
+  // exclusive prefix sum of the counts over the wave
+  int pos = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(pos, o);
+    if (lane >= o) pos += t;
+  }
+  const int total = __shfl(pos, 63);
+  pos -= cnt;
+  if (cnt > 0) s_id[wave][pos] = q.y;
+  if (cnt > 1) s_id[wave][pos + 1] = q.z;
+  if (cnt > 2) s_id[wave][pos + 2] = q.w;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int sub = lane / 6, part = lane - 6 * sub;  // lanes 60 .. 63 idle in the gather
+  for (int r0 = 0; r0 < total; r0 += CG_REC) {
+    const int nr = min(CG_REC, total - r0);
+    double2 piece[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int rr = t * 10 + sub;
+      const bool ld = lane < 60 && rr < nr;
+      const int id = s_id[wave][ld ? r0 + rr : 0];
+      piece[t] = ld ? *(const double2*)(rec12 + (size_t)id * 12 + part * 2) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int rr = t * 10 + sub;
+      if (lane < 60 && rr < nr) *(double2*)(&s_rec[wave][rr * 12 + part * 2]) = piece[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = pos + j - r0;
+      if (j < cnt && r >= 0 && r < nr) {
+        const int k = j == 0 ? q.y : j == 1 ? q.z : q.w;
+        double rec[12];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const double2 v = *(const double2*)(&s_rec[wave][r * 12 + e * 2]);
+          rec[2 * e] = v.x;
+          rec[2 * e + 1] = v.y;
+        }
+        upd_min(chi2_rec(rec, x, y, z), k, best, bi);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (inside && q.x > 3) {  // long list: by the lane itself
+    for (int e = q.y; e < q.y + q.x; ++e) {
+      const int k = G.idx[e];
+      upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
+    }
+  }
+  if (!live) return;
+  if (best <= G.t_resolve) {
+    out_idx[n] = bi;
+    if (out_d2) out_d2[n] = best;
+  } else {
+    out_idx[n] = -1;
+    if (out_d2) out_d2[n] = __builtin_inf();
+    if (rest_list) rest_list[atomicAdd(rest_count, 1)] = n;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_index_work(GridDev G, const double* __restrict__ pts, int N,
                                                     unsigned long long* __restrict__ total) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -536,8 +639,10 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   int32_t* list = count + 16;
   TimerScope ts(c, GL_TIMER_ASSOC);
   if (resolve_all) GL_HIP(hipMemsetAsync(count, 0, 4, c->stream));
-  k_assoc_cells<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr,
-                                                        count);
+  if (G.cell4 && c->opt.assoc_coop != 0 && N >= 4096)
+    k_assoc_cells_coop<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr, count);
+  else
+    k_assoc_cells<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr, count);
   GL_HIP(hipGetLastError());
   if (resolve_all)  // the unresolved points go through the all-pairs sweep (grid sized for N, empty tiles exit)
     return launch_assoc_sweep(c, g, pts, N, idx, d2, list, count, (char*)scratch + index_list_bytes(N));

@@ -97,6 +97,7 @@ struct Options {
   double view_threads = 0;      //   0 auto, 256 / 1024
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
   double assoc_grid = -1;       // 0: never use the cell index (every association is the N x K sweep); A/B and bench
+  double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
   double match_desc_lds = -1;   // gl_search_by_projection: descriptors in LDS (-1 auto, 0 / 1)
 };
 // name -> member; nullptr if unknown

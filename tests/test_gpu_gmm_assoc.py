@@ -161,10 +161,12 @@ def _both(torch, g, pts):
 
 @pytest.mark.parametrize("which,N,seed", [("v1", 20000, 21), ("v2", 20000, 22), ("synth4096", 50000, 23),
                                            ("synth300", 5000, 24), ("synth65536", 4000, 25)])
-def test_cell_index_equals_exhaustive(gpu, oracle, map_v1, map_v2, which, N, seed):
+@pytest.mark.parametrize("coop", [1, 0])  # wave-cooperative record gather (default) / a lane per record
+def test_cell_index_equals_exhaustive(gpu, oracle, map_v1, map_v2, opt, which, N, seed, coop):
     """idx and chi2 bit-identical to the all-pairs sweep, for inliers, outliers (swept again) and
     points far outside the map."""
     torch, ctx = gpu
+    opt("assoc_coop", coop)
     mean, cov = {"v1": map_v1, "v2": map_v2, "synth4096": synth.synth_gmm(4096, seed),
                  "synth300": synth.synth_gmm(300, seed), "synth65536": synth.synth_gmm(65536, seed)}[which]
     g = api.GMM(ctx, mean, cov)
