@@ -54,13 +54,13 @@ def test_track_frames_matches_oracle(gpu, oracle, map_v1, gt_sync, opt, mapname,
         dt, dr = pose_err(pose[i], p_ref)
         assert dt < 1e-6 and dr < 1e-6, (i, dt, dr)
         assert np.array_equal(assoc[i][keep], a_ref), (i, int((assoc[i][keep] != a_ref).sum()))
-        # points: well-constrained ones (stereo observation, still an inlier) to 1e-6 m; a monocular
-        # or gated-out point is only held by the LM damping along its ray -> looser bound
+        # points: stereo observations to 1e-6 m; a monocular point has its depth from the GMM edge alone (a plane that may
+        # graze the ray) or from the LM damping: measured <= 1.0e-6 m on these frames (stereo <= 1.1e-7), held to 5e-6
         err = np.abs(Xw[i][keep] - pts_ref).max(1)
         stereo = f["obs"][keep][:, 2] >= 0
         worst = int(np.argmax(err))
         assert err[stereo].max() < 1e-6, (i, worst, err[worst], f["obs"][keep][worst], a_ref[worst])
-        assert err.max() < 1e-4
+        assert err.max() < 5e-6, (i, worst, err[worst])
         assert (assoc[i][f["octave"] < 0] == -1).all()
         # structure actually constrains the pose: close to the generating pose
         gdt, gdr = pose_err(pose[i], f["pose_gt"])
