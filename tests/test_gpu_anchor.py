@@ -93,7 +93,7 @@ def test_track_frames_prior_matches_oracle(gpu, oracle, map_v1, gt_sync, opt, ma
         assert dt < 1e-6 and dr < 1e-6, (i, dt, dr)
         assert np.array_equal(assoc[i][keep], a_ref), (i, int((assoc[i][keep] != a_ref).sum()))
         err = np.abs(Xw[i][keep] - pts_ref).max(1)
-        assert err[f["obs"][keep][:, 2] >= 0].max() < 1e-6 and err.max() < 1e-4
+        assert err[f["obs"][keep][:, 2] >= 0].max() < 1e-6 and err.max() < 1e-5
         # the anchor does something: the oracle's unanchored answer is another pose
         _, p_free, _, _, _ = oracle_anchored(oracle, h, cam, f, False, 0)
         moved.append(pose_err(p_ref, p_free)[0])
@@ -123,7 +123,7 @@ def test_track_frames_fixed_first_keyframe(gpu, oracle, map_v1, gt_sync):
         assert torch.equal(pose[i], pose0[i])
         assert np.array_equal(assoc[i][keep], a_ref)
         err = np.abs(Xw[i][keep] - pts_ref).max(1)
-        assert err[f["obs"][keep][:, 2] >= 0].max() < 1e-6 and err.max() < 1e-4
+        assert err[f["obs"][keep][:, 2] >= 0].max() < 1e-6 and err.max() < 1e-5
     oracle.gmm_destroy(h)
 
 
@@ -196,7 +196,7 @@ def test_track_frames_fixed_observers_match_oracle(gpu, oracle, map_v1, gt_sync,
         assert fe_ref.sum() > 0  # (the planted outliers are found)
         err = np.abs(Xw[i][keep] - pts_ref).max(1)
         well = (f["obs"][keep][:, 2] >= 0) | ((f["fixed_oct"][keep] >= 0) & ~fe_ref.astype(bool)).any(1)  # stereo, or a second view
-        assert err[well].max() < 1e-6 and err.max() < 1e-4, (i, err[well].max(), err.max())
+        assert err[well].max() < 1e-6 and err.max() < 1e-5, (i, err[well].max(), err.max())
         assert (assoc[i][f["octave"] < 0] == -1).all() and not ferase[i][f["octave"] < 0].any()
         untouched = f["octave"] < 0
         assert np.array_equal(Xw[i][untouched], f["Xw"][untouched])
