@@ -309,6 +309,28 @@ def main():
         dt_sweep = launch.timed_steps(step, sweep_steps, 1, ranks) / sweep_steps
     ctx.set_option("assoc_grid", grid_before)
 
+    # the same step taken in turn by TWO contexts (two streams, two scratch blocks; same device, same inputs): what a host that
+    # keeps two batches in flight gets - the association / set-up kernels of step k + 1 run in the tail of step k's refine,
+    # where CUs are already free (a refine workgroup owns its CU's LDS and registers, so nothing else overlaps).  Reported
+    # beside `value`, which stays the one-stream figure; the results of the two contexts are bit-identical.
+    ctx_b = gmmloc_amd.Context(local)
+    gmm_b = gmmloc_amd.GMM(ctx_b, mean, cov, prm)
+    pose_b, Xw_b = pose0.clone(), Xw0.clone()
+    lanes = [(ctx, gmm, pose, Xw), (ctx_b, gmm_b, pose_b, Xw_b)]
+    turn = [0]
+
+    def step2():
+        c_, g_, p_, x_ = lanes[turn[0] & 1]
+        turn[0] += 1
+        with torch.cuda.stream(c_.stream):
+            p_.copy_(pose0)
+            x_.copy_(Xw0)
+            gmmloc_amd.track_frames(c_, g_, cam, prm, p_, x_, obs, octv, want_d2=False)
+    two_steps = max(4, 2 * (args.steps // 4))
+    dt_two = launch.timed_steps(step2, two_steps, 2, ranks) / two_steps
+    two_same = bool(torch.equal(pose, pose_b) and torch.equal(Xw, Xw_b))
+    del gmm_b, ctx_b
+
     # outside the timed region: (a) the refine on the 1 000-point LDS class - the first 1 000 points of every frame; real
     # tracking frames have <= 1 200 features (cfg/v1.yaml:24) and two such frames share a CU, so the serial 6 x 6 solve of one
     # overlaps the passes of the other - and (b) the anchored step (gl_track_frames_anchored: prior edge on every pose)
@@ -479,6 +501,10 @@ def main():
             "value": B * world / dt_sweep, "unit": "frames/s", "ms_per_step": 1e3 * dt_sweep, "steps": sweep_steps,
             "what": "the same step with GL_ASSOC_EXHAUSTIVE-style association (all 2000 x 4096 pairs per frame swept, option "
                     "assoc_grid = 0) instead of the exact cell index; MAX over ranks like the headline"}
+        out["step_two_streams"] = {
+            "value": B * world / dt_two, "unit": "frames/s", "ms_per_step": 1e3 * dt_two, "steps": two_steps, "bit_identical_results": two_same,
+            "what": "the same step taken in turn by two contexts per GPU (two streams, two scratch blocks): the association and set-up "
+                    "kernels of step k + 1 run in the tail of step k's refine; `value` above is the one-stream figure; MAX over ranks"}
         out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20",
                           "host_to_host_ms": h2h[N_PTS], "host_to_host_700pts_ms": h2h[700],
                           "host_to_host_what": "gl_track_frame_host: host buffers -> the context's page-locked staging -> one H2D + "
