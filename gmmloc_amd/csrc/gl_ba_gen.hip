@@ -1727,7 +1727,8 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
 // =====================================================================================================================
 // The PIPELINED shape of the local BA (round 3): the same phases as k_ba_gen - P1 linearise, P2 Schur blocks, solve, P3 trial
 // state, accept / reject - as SEPARATE kernels over the same scratch layout and the same per-element arithmetic (pass_points,
-// pass_trial, gmg, the LDL^T of ldlt_solve_small), driven by a per-problem state word in global memory.
+// pass_trial, gmg, the LDL^T of ldlt_solve_tiles element for element), driven by a per-problem state word in global memory:
+// kp_lin (judges the previous trial, then P1) -> kp_schur (P2) -> kp_assemble -> kp_solve -> kp_trial (P3) per Levenberg trial.
 // Why: the persistent kernel is one register allocation for every phase (512 registers, hundreds spilled, one wave per SIMD:
 // every dependent load of P2 / P3 is exposed), its phases are separated by problem-wide barriers among 16 - 64 co-resident
 // workgroups (10 - 14 % of a trial), and 15 - 63 of them idle while workgroup 0 factorises (a quarter to a third of a trial).
@@ -1739,10 +1740,10 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
 // Sums are deterministic: per-workgroup / per-chunk partials added in index order, independent of the batch.
 struct alignas(16) PipeSt {  // per problem, in global memory
   // (the four words every kernel of a cycle tests first: one 16-byte load - pipe_ctl)
-  int stage;     // 0, 1, 2: which optimize() of the 5 / 5 / 40 schedule; 3: finished
+  int stage;     // 0, 1, 2: which optimize() of the 5 / 5 / 40 schedule; 3: finished; -1: none opened yet (the call's first cycle opens stage 0)
   int init;      // 1: the next cycle is the computeLambdaInit pass of the stage (no solve, no trial)
   int pend;      // 1: a trial state has been evaluated (solve + trial of this cycle); the next cycle's first kernel judges it
-  int adv;       // 1: the stage is over (decided at the head of this cycle): the solve kernel runs the gate / opens the next stage
+  int adv;       // 1: the stage is over (decided at the head of this cycle): this cycle's kernels run the gate and open the next stage (pipe_adv_*)
   int iters_max; // of this stage
   int it;        // outer iteration of the stage
   int qmax;      // trials of the outer iteration so far
@@ -1782,7 +1783,6 @@ struct PipeA {  // kernel arguments (by value)
   double* partD;      // B x nba x 2   {scale part, chi2 at the trial state}
   double* partS;      // B x nblk x nchunk x 48
   int* unfinished;    // problems not at stage 3
-  int* arrive;        // B x nblk: waves of the Schur pass that have delivered their chunk of a block (back to 0 by the last)
   int nba, lpp, nblk, nchunk;
 };
 struct PipeCtl {
@@ -2775,10 +2775,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   s += up((size_t)B * a.nba * 16);
   a.partS = (double*)s;
   s += up((size_t)B * a.nblk * a.nchunk * 48 * 8);
-  a.unfinished = (int*)s;
-  s += 256;
-  a.arrive = (int*)s;
-  GL_HIP(hipMemsetAsync(a.arrive, 0, (size_t)B * a.nblk * sizeof(int), c->stream));
+  a.unfinished = (int*)s;  // [0] problems not finished, [1] cycles the slowest of them needed
   const size_t n = 6 * (size_t)P;
   const size_t s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;
   if (s_bytes) GL_HIP(ensure_dynamic_lds(c, (const void*)kp_solve, s_bytes));
