@@ -338,3 +338,45 @@ def test_soak_ba_pipelined_gauge_free_window(env, oracle, opt, r):
     assert spread > TOL and hip < 10 * spread, (hip, spread)
     if flips == 0:
         assert np.array_equal(out[2][0], ref[2]) and np.array_equal(out[3][0][:nobs], ref[3])
+
+
+# ---- round 3, 50 000-round soak (profiles/r3c_soak_strict_50000.txt): ONE decision of createMapPoints in 48 M matches ------------
+def test_soak_create_map_points_parallax_knife_edge(env, oracle):
+    """createMapPoints decides between the two-view triangulation and the stereo un-projection with
+    `cosParallaxRays < cos(2 atan2(mb / 2, depth))`, both sides FLOAT (localization_opt.cpp:306-321).  On match 270 of
+    map_v2 round 33994 the exact value of the right-hand side lies 0.5015 float ulps above the float cosParallaxRays: whether
+    the comparison holds is the last bit of a float cosine of a float arc tangent, i.e. of the math library (glibc in the oracle,
+    the device library on the GPU) - HIP takes the stereo branch, the oracle the two-view one.  The created point is the SAME
+    (both initial points converge in optimizeTriangulationVec: 8.9e-16), so is its component; only the MapPoint type records
+    the branch (2 against 4).  Every other match of the batch is exact."""
+    e = env
+    mapname, r, j = "map_v2", 33994, 270
+    mean, cov, g, h = e["maps"][mapname]
+    m = sc.gen(mapname, r, mean, cov, e["gts"], e["cam"])["tri"]
+    x_ref, t_ref, c_ref = oracle.create_map_points(h, e["cam"], **m)
+    x, t, c = api.create_map_points(e["ctx"], g, e["cam"], e["prm"], *[e["T"](m[k]) for k in sc.TRI_KEYS])
+    e["torch"].cuda.synchronize()
+    xg, tg, cg = x.cpu().numpy(), t.cpu().numpy(), c.cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        sane = (np.arange(len(t_ref)) != j) & (np.linalg.norm(x_ref, axis=1) < 100.0)
+    assert np.array_equal(tg[sane], t_ref[sane]) and np.array_equal(cg[sane], c_ref[sane])
+    acc = sane & (t_ref > 0)
+    assert np.abs(xg[acc] - x_ref[acc]).max() <= 1e-8
+    # the match in question: same point, same component, the type differs at most by the branch (1 <-> 3, 2 <-> 4)
+    assert cg[j] == c_ref[j] and np.abs(xg[j] - x_ref[j]).max() <= 1e-8
+    assert tg[j] == t_ref[j] or {int(tg[j]), int(t_ref[j])} in ({1, 3}, {2, 4})
+    # ... and the threshold really is a knife edge: the exact right-hand side within one float ulp of the float left-hand side
+    cam = e["cam"]
+    k1, k2, p1, p2 = m["uvr1"][j], m["uvr2"][j], m["pose1"][j], m["pose2"][j]
+
+    def ray(p, k):  # world direction of the key-point's viewing ray (pose = qx qy qz qw t: T_cw)
+        qx, qy, qz, qw = -p[0], -p[1], -p[2], p[3]
+        R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                      [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                      [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+        return R @ np.array([(k[0] - cam.cx) / cam.fx, (k[1] - cam.cy) / cam.fy, 1.0])
+    r1, r2 = ray(p1, k1), ray(p2, k2)
+    cos_rays = np.float32(r1 @ r2 / np.linalg.norm(r1) / np.linalg.norm(r2))
+    depth = np.float64(m["depth1"][j] if k1[2] >= 0 else m["depth2"][j])
+    cps_exact = np.cos(2.0 * np.arctan2(np.float64(np.float32(cam.bf / cam.fx / 2)), depth))
+    assert abs(float(cos_rays) - cps_exact) < float(np.spacing(np.float32(cps_exact)))

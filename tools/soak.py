@@ -24,7 +24,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("rounds", nargs="?", type=int, default=40)
 ap.add_argument("--dump", default=None, help="directory for the inputs / GPU outputs of every deviation")
 ap.add_argument("--maps", default="map_v1,map_v2")
+ap.add_argument("--only", default=None, help="map_v1:1572,3986;map_v2:292 - run just these rounds (to dump the deviations of a long run)")
 args = ap.parse_args()
+only = None
+if args.only:
+    only = {m.split(":")[0]: sorted(int(x) for x in m.split(":")[1].split(",") if x) for m in args.only.split(";") if m}
 rounds = args.rounds
 if args.dump:
     os.makedirs(args.dump, exist_ok=True)
@@ -50,7 +54,7 @@ for mapname in args.maps.split(","):
     mean, cov = sc.load_map(mapname)
     g = gmmloc_amd.GMM(ctx, mean, cov, prm)
     h = orc.gmm_create(mean, cov)
-    for r in range(rounds):
+    for r in (only.get(mapname, []) if only is not None else range(rounds)):
         c = sc.gen(mapname, r, mean, cov, gts, cam)
         # ---- key-frame association chain: renderView + searchCorrespondence, then checkMapAssociation
         ch = c["chain"]

@@ -104,10 +104,31 @@ def classify_tri(mapname, r, dump):
     return rows
 
 
-def classify_track(mapname, r, dump, with_numpy):
+def classify_tri_rejected(mapname, r, dump):
+    """a match all sides REJECT (type 0): what optimizeTriangulationVec leaves behind (the candidate it settled on last) is no
+    output of the reference; the oracle's own by-product under 1-ulp changes of one input"""
+    mean, cov, h, comps = get_map(mapname)
+    m = sc.gen(mapname, r, mean, cov, gts, cam)["tri"]
+    x_ref, t_ref, c_ref = orc.create_map_points(h, cam, **m)
+    tg, cg = dump["type_gpu"], dump["comp_gpu"]
+    rows = []
+    for j in np.nonzero((tg == 0) & (t_ref == 0) & (cg != c_ref))[0]:
+        one = {k: m[k][j:j + 1] for k in m}
+        seen, probes = {int(c_ref[j])}, 0
+        for key in ("uvr1", "uvr2", "pose1", "pose2"):
+            for v in ulp_variants(m[key][j], 12):
+                _, tv, cv = orc.create_map_points(h, cam, **dict(one, **{key: v[None]}))
+                seen.add(int(cv[0]) if tv[0] == 0 else -2)
+                probes += 1
+        rows.append(dict(match=int(j), comp_hip=int(cg[j]), comp_oracle=int(c_ref[j]), oracle_by_products_under_1ulp=sorted(seen), probes=probes,
+                         hip_among_them=int(cg[j]) in seen))
+    return rows
+
+
+def classify_track(mapname, r, dump, with_numpy, prior=False):
     mean, cov, h, comps = get_map(mapname)
     f = sc.gen(mapname, r, mean, cov, gts, cam)["track"]
-    keep, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(orc, h, cam, f)
+    keep, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(orc, h, cam, f, prior=prior)
     dt, dr = pose_err(dump["pose_gpu"], p_ref)
     row = dict(M=len(keep), hip_vs_oracle=(dt, dr), oracle_vs_gt=pose_err(p_ref, f["pose_gt"]), init_vs_gt=pose_err(f["pose_init"], f["pose_gt"]))
     # the oracle's own sensitivity: (1) its points re-ordered (summation order), (2) every observation moved by a
@@ -118,20 +139,20 @@ def classify_track(mapname, r, dump, with_numpy):
     d_perm, d_ulp = [], []
     for _ in range(12):
         perm = rng.permutation(len(keep))
-        _, p1, _, a1, _, _ = sc.track_oracle(orc, h, cam, f, perm)
+        _, p1, _, a1, _, _ = sc.track_oracle(orc, h, cam, f, perm, prior=prior)
         d_perm.append(max(pose_err(p1, p_ref)))
     for _ in range(36):
         g = dict(f)
         g["obs"] = f["obs"] * (1 + 3e-16 * rng.standard_normal(f["obs"].shape))
         g["obs"][f["obs"] < 0] = f["obs"][f["obs"] < 0]
-        _, p1, _, a1, _, _ = sc.track_oracle(orc, h, cam, g)
+        _, p1, _, a1, _, _ = sc.track_oracle(orc, h, cam, g, prior=prior)
         d_ulp.append(max(pose_err(p1, p_ref)))
     d_all = np.array(d_perm + d_ulp)
     row["oracle_probes"] = len(d_all)
     row["oracle_probe_median"] = float(np.median(d_all))
     row["oracle_probe_max"] = float(d_all.max())
     row["oracle_probes_above_1e-6"] = int((d_all > 1e-6).sum())
-    if with_numpy:
+    if with_numpy and not prior:
         L = len(keep)
         assoc = np.where(d20 <= 9.0, idx0, -1).astype(np.int32)
         res = nr.joint_optimization(1, 0, f["pose_init"][None], np.zeros(1, np.uint8), f["Xw"][keep], assoc, np.arange(L + 1),
@@ -151,14 +172,20 @@ def classify_ba(r, dump, with_numpy):
     ref = orc.joint_optimization(h, cam, p["P"], p["F"], p["poses"], p["prior"], p["points"], a, *args)
     row = dict(P=p["P"], F=p["F"], L=len(p["points"]), nb=b["nb"], prior=b["prior"],
                hip_vs_oracle=max(pose_err(dump["poses_gpu"][j], ref[0][j]) for j in range(p["P"])))
+    stereo = np.array([(p["obs_uvr"][p["obs_ptr"][l]:p["obs_ptr"][l + 1], 2] >= 0).any() for l in range(len(p["points"]))])
+    if "points_gpu" in dump and stereo.any():
+        dp = np.abs(dump["points_gpu"] - ref[1]).max(1)
+        row["hip_vs_oracle_stereo_points"] = float(dp[stereo].max())
+        row["worst_point"] = int(np.nonzero(stereo)[0][np.argmax(dp[stereo])])
     for k in ("dropped_gpu", "erase_gpu"):
         if k in dump:
             row[k + "_differs"] = int((dump[k][:len(ref[2 if k[0] == "d" else 3])] != ref[2 if k[0] == "d" else 3]).sum())
     # the oracle on the same problem with its points (and their observations) re-ordered
     rng = np.random.default_rng(0)
     sp = (0.0, 0.0)
+    psp = 0.0
     L = len(p["points"])
-    for _ in range(4):
+    for _ in range(8):
         perm = rng.permutation(L)
         cnt = np.diff(p["obs_ptr"])[perm]
         optr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
@@ -167,7 +194,12 @@ def classify_ba(r, dump, with_numpy):
                                     p["obs_pose"][sel], p["obs_uvr"][sel], p["obs_oct"][sel])
         e = max(pose_err(r2[0][j], ref[0][j]) for j in range(p["P"]))
         sp = (max(sp[0], e[0]), max(sp[1], e[1]))
+        back = np.empty_like(r2[1])
+        back[perm] = r2[1]  # the re-ordered run's points in the original order
+        if stereo.any():
+            psp = max(psp, float(np.abs(back - ref[1]).max(1)[stereo].max()))
     row["oracle_reorder_spread"] = sp
+    row["oracle_reorder_spread_stereo_points"] = psp
     if with_numpy:
         res = nr.joint_optimization(p["P"], p["F"], p["poses"], p["prior"], p["points"], a, *args, comps, mean, ncam, nprm)
         row["numpy_vs_oracle"] = max(pose_err(res[0][j], ref[0][j]) for j in range(p["P"]))
@@ -194,7 +226,7 @@ def main():
         return orc.search_correspondence(h, uv, k)
     orc.search_correspondence_for_pose = scfp
     for path in sorted(glob.glob(os.path.join(a.dump, "*.npz"))):
-        m = re.match(r"(chain_fallback|chain|tri_far|tri|track|pose|ba)_(map_v[12])_r(\d+)\.npz", os.path.basename(path))
+        m = re.match(r"(chain_fallback|chain|tri_far|tri_rejected|tri|track_prior|track|pose|ba)_(map_v[12])_r(\d+)\.npz", os.path.basename(path))
         if not m:
             continue
         kind, mapname, r = m.group(1), m.group(2), int(m.group(3))
@@ -203,8 +235,10 @@ def main():
             rows = classify_chain_fallback(mapname, r, dump)
         elif kind in ("tri", "tri_far"):
             rows = classify_tri(mapname, r, dump)
-        elif kind == "track":
-            rows = classify_track(mapname, r, dump, a.numpy)
+        elif kind == "tri_rejected":
+            rows = classify_tri_rejected(mapname, r, dump)
+        elif kind in ("track", "track_prior"):
+            rows = classify_track(mapname, r, dump, a.numpy, prior=kind == "track_prior")
         elif kind == "ba":
             rows = classify_ba(r, dump, a.numpy)
         else:
