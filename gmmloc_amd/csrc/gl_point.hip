@@ -502,10 +502,17 @@ __global__ void k_tri_pre(TriK k, int N, const double* __restrict__ pose1, const
   const float cosRays = (float)(dot / (nr1 * nr2));
   float cps = cosRays + 1;
   float cps1 = cps, cps2 = cps;
+  // cos(2 atan2(mb / 2, depth)) in FLOAT (localization_opt.cpp:311-315).  Whether `cosRays < cps` holds can be the last bit of
+  // this value (one match in 48 million of the 50 000-round soak), and the last bit of a float cosine of a float arc tangent
+  // is the math library's: glibc's cosf(2 atan2f()) and the device library's differ on 0.34 % of the depths.  Each of the two
+  // functions is therefore evaluated in double and rounded once - the correctly rounded float function, which glibc's is on all
+  // but 0.036 % of the depths.
+  const float mbh = k.mb / 2;
+  auto cps_of = [&](float dp) { return (float)cos(2.0 * (double)(float)atan2((double)mbh, (double)dp)); };
   if (bStereo1)
-    cps1 = cosf(2 * atan2f(k.mb / 2, dp1));
+    cps1 = cps_of(dp1);
   else if (bStereo2)
-    cps2 = cosf(2 * atan2f(k.mb / 2, dp2));
+    cps2 = cps_of(dp2);
   cps = fminf(cps1, cps2);
   double pt[3] = {0, 0, 0};
   int st = 0;
