@@ -24,6 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("rounds", nargs="?", type=int, default=40)
 ap.add_argument("--dump", default=None, help="directory for the inputs / GPU outputs of every deviation")
 ap.add_argument("--maps", default="map_v1,map_v2")
+ap.add_argument("--start", type=int, default=0, help="first round (rounds are seeds: --start 50000 continues a 50 000-round run)")
 ap.add_argument("--only", default=None, help="map_v1:1572,3986;map_v2:292 - run just these rounds (to dump the deviations of a long run)")
 args = ap.parse_args()
 only = None
@@ -54,7 +55,7 @@ for mapname in args.maps.split(","):
     mean, cov = sc.load_map(mapname)
     g = gmmloc_amd.GMM(ctx, mean, cov, prm)
     h = orc.gmm_create(mean, cov)
-    for r in (only.get(mapname, []) if only is not None else range(rounds)):
+    for r in (only.get(mapname, []) if only is not None else range(args.start, args.start + rounds)):
         c = sc.gen(mapname, r, mean, cov, gts, cam)
         # ---- key-frame association chain: renderView + searchCorrespondence, then checkMapAssociation
         ch = c["chain"]
@@ -178,7 +179,9 @@ notes = []
 mean, cov = sc.load_map("map_v1")
 g = gmmloc_amd.GMM(ctx, mean, cov, prm)
 h = orc.gmm_create(mean, cov)
-for b in sc.gen_ba(max(10, rounds // 4), mean, cov, gts, cam):
+for b in sc.gen_ba(max(10, (args.start + rounds) // 4), mean, cov, gts, cam):
+    if b["r"] < args.start // 4:
+        continue  # (windows of an earlier run: one shared random stream, so they are generated and skipped)
     ctx.set_option("bagen_nb", b["nb"])
     ctx.set_option("bagen_mode", 2 if b["r"] % 2 else 1)  # odd rounds: the pipelined shape (a kernel per phase)
     p = b["problem"]
