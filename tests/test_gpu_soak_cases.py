@@ -383,3 +383,48 @@ def test_soak_create_map_points_parallax_knife_edge(env, oracle):
     depth = np.float64(m["depth1"][j] if k1[2] >= 0 else m["depth2"][j])
     cps_exact = np.cos(2.0 * np.arctan2(np.float64(np.float32(cam.bf / cam.fx / 2)), depth))
     assert abs(float(cos_rays) - cps_exact) < float(np.spacing(np.float32(cps_exact)))
+
+
+# ---- round 3, rounds 50 000 .. 86 000 of the soak: ONE anchored frame in 43 000 that is NOT ill-conditioned ----------------------------
+def test_soak_track_prior_single_pose_kernels_real_deviation(env, oracle, opt):
+    """map_v1 round 63072 (138 points, prior edge): gl_track_frames_anchored ends 3.6e-5 rad / 5.2e-6 m from the oracle (the general
+    single-pose kernel k_ba1, option ba_slow, 6.2e-5 rad), and this time the ORACLE IS STABLE - it moves by < 4e-8 under re-orderings
+    and under relative changes of its inputs from 3e-16 to 1e-12, the numpy restatement agrees with it to 1.6e-8, and HIP's own
+    general local-BA kernels (both launch shapes) solve the same problem (one free pose with the prior edge) to 2e-8 of it.  The
+    Levenberg traces of the fast kernel and the oracle agree to 1e-14 for 28 trials and part in the trials with lambda < 1e-6
+    (5e-10 of chi2 at trial 30, 1e-8 from then on): the single-pose kernels carry more rounding noise into the late, nearly
+    undamped iterations than the other three implementations.  A REAL deviation (1 of 43 000 anchored frames in 86 000 soak
+    rounds), not classified away; the cause was not found in round 3.  The test holds the picture: oracle stable, general kernels
+    exact, single-pose kernels within 2e-4 with exact associations - tighten it when the cause is found."""
+    e = env
+    mapname, r = "map_v1", 63072
+    mean, cov, g, h = e["maps"][mapname]
+    f = sc.gen(mapname, r, mean, cov, e["gts"], e["cam"])["track"]
+    keep, p_ref, pts_ref, a_ref, idx0, d20 = sc.track_oracle(oracle, h, e["cam"], f, prior=True)
+    rng = np.random.default_rng(0)
+    for _ in range(6):  # the oracle itself: stable under re-ordering and input noise
+        _, p1, _, _, _, _ = sc.track_oracle(oracle, h, e["cam"], f, rng.permutation(len(keep)), prior=True)
+        assert max(pose_err(p1, p_ref)) < 2e-7
+        q = dict(f)
+        q["obs"] = np.where(f["obs"] < 0, f["obs"], f["obs"] * (1 + 1e-13 * rng.standard_normal(f["obs"].shape)))
+        _, p1, _, _, _, _ = sc.track_oracle(oracle, h, e["cam"], q, prior=True)
+        assert max(pose_err(p1, p_ref)) < 2e-7
+    T, torch, ctx = e["T"], e["torch"], e["ctx"]
+    one = torch.ones(1, dtype=torch.uint8).cuda()
+    pose, Xw = T(f["pose_init"][None]), T(f["Xw"][None])
+    assoc = gmmloc_amd.track_frames_anchored(ctx, g, e["cam"], e["prm"], pose, Xw, T(f["obs"][None]), T(f["octave"][None]), prior=one)[0]
+    torch.cuda.synchronize()
+    dt, dr = pose_err(pose.cpu().numpy()[0], p_ref)
+    assert np.array_equal(assoc.cpu().numpy()[0][keep], a_ref)
+    assert dt < 2e-4 and dr < 2e-4, (dt, dr)  # (3.6e-5 rad today: see above)
+    # the same problem through gl_joint_optimization: one free pose with the prior edge, both launch shapes
+    L = len(keep)
+    a0 = np.where(d20 <= 9.0, idx0, -1).astype(np.int32)
+    for mode in (1, 2):
+        opt("bagen_mode", mode)
+        poses, pts = T(f["pose_init"][None, None].copy()), T(f["Xw"][keep][None].copy())
+        api.joint_optimization(ctx, g, e["cam"], e["prm"], 1, 0, poses, T(np.ones((1, 1), np.uint8)), pts, T(a0[None]),
+                               T(np.arange(L + 1, dtype=np.int32)[None]), T(np.zeros((1, L), np.int32)), T(f["obs"][keep][None].copy()),
+                               T(f["octave"][keep][None].astype(np.int32)))
+        torch.cuda.synchronize()
+        assert max(pose_err(poses.cpu().numpy()[0, 0], p_ref)) < 1e-6
