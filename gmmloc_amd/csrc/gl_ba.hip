@@ -228,6 +228,19 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
             for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Mf[i * 3] * AD[j * 3] + Mf[i * 3 + 1] * AD[j * 3 + 1] + Mf[i * 3 + 2] * AD[j * 3 + 2];
 #pragma unroll
           for (int i = 0; i < 3; ++i) c[i] = (Mf[i * 3] * u[0] + Mf[i * 3 + 1] * u[1] + Mf[i * 3 + 2] * u[2]) - o.bc[i];
+#ifdef GL_BA1_PLAIN_SCHUR  // (experiment: the subtraction form A - (A D^-1) A, a - A u of the oracle / k_ba_gen)
+          {
+            const double Af[9] = {o.A[0], o.A[1], o.A[2], o.A[1], o.A[3], o.A[4], o.A[2], o.A[4], o.A[5]};
+            double Au[3];
+            sym3_mul_vec(o.A, u, Au);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              c[i] = o.a[i] - Au[i];
+#pragma unroll
+              for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Af[i * 3 + j] - (AD[i * 3] * Af[j] + AD[i * 3 + 1] * Af[3 + j] + AD[i * 3 + 2] * Af[6 + j]);
+            }
+          }
+#endif
           accum_pose(o.q, Cf, c, acc);
         }
       }
