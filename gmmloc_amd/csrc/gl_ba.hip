@@ -241,6 +241,14 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
             }
           }
 #endif
+#ifndef GL_BA1_NO_SYM_C  // the product form is symmetric in exact arithmetic only (gl_ba_fast_impl.hpp: pt_pass_a): the mean of its two triangles
+          {
+            const double s01 = 0.5 * (Cf[1] + Cf[3]), s02 = 0.5 * (Cf[2] + Cf[6]), s12 = 0.5 * (Cf[5] + Cf[7]);
+            Cf[1] = Cf[3] = s01;
+            Cf[2] = Cf[6] = s02;
+            Cf[5] = Cf[7] = s12;
+          }
+#endif
           accum_pose(o.q, Cf, c, acc);
         }
       }

@@ -101,12 +101,18 @@ GL_DEV double add_nc(double a, double b) {
 }
 
 GL_DEV double rcp_nr(double a) {
+#ifdef GL_BAF_IEEE_DIV  // (experiment: correctly rounded division / square root instead of the Newton forms)
+  return 1.0 / a;
+#endif
   double x = __builtin_amdgcn_rcp(a);
   x = fma(fma(-a, x, 1.0), x, x);
   x = fma(fma(-a, x, 1.0), x, x);
   return x;
 }
 GL_DEV double rsq_nr(double a) {
+#ifdef GL_BAF_IEEE_DIV
+  return 1.0 / sqrt(a);
+#endif
   double y = __builtin_amdgcn_rsq(a);
   const double h = 0.5 * a;
   y = y * fma(-h * y, y, 1.5);
@@ -1202,12 +1208,19 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
       const double M[9] = {(o.D[0] - o.A[0]) + lambda, o.D[1] - o.A[1], o.D[2] - o.A[2],
                            o.D[1] - o.A[1], (o.D[3] - o.A[3]) + lambda, o.D[4] - o.A[4],
                            o.D[2] - o.A[2], o.D[4] - o.A[4], (o.D[5] - o.A[5]) + lambda};
-      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k)
+      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k).  The product is symmetric in exact arithmetic only: the two factors
+      // round differently, and reading one triangle as THE matrix put an unsymmetric error of the size of the product's last
+      // digits x cond(D) into the pose blocks (soak frame v1 r63072, anchored: 3.6e-5 rad off a stable oracle; the mean of the
+      // two triangles is what the blocks get now).
       const int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
         const int r = ri[e], j = ci[e];
         C[e] = fma(M[r * 3], AD[j * 3], fma(M[r * 3 + 1], AD[j * 3 + 1], M[r * 3 + 2] * AD[j * 3 + 2]));
+        if (r != j) {
+          const double lo = fma(M[j * 3], AD[r * 3], fma(M[j * 3 + 1], AD[r * 3 + 1], M[j * 3 + 2] * AD[r * 3 + 2]));
+          C[e] = 0.5 * (C[e] + lo);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(M[r * 3], u[0], fma(M[r * 3 + 1], u[1], fma(M[r * 3 + 2], u[2], o.a[r] - o.b[r])));
