@@ -1208,19 +1208,21 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
       const double M[9] = {(o.D[0] - o.A[0]) + lambda, o.D[1] - o.A[1], o.D[2] - o.A[2],
                            o.D[1] - o.A[1], (o.D[3] - o.A[3]) + lambda, o.D[4] - o.A[4],
                            o.D[2] - o.A[2], o.D[4] - o.A[4], (o.D[5] - o.A[5]) + lambda};
-      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k).  The product is symmetric in exact arithmetic only: the two factors
-      // round differently, and reading one triangle as THE matrix put an unsymmetric error of the size of the product's last
-      // digits x cond(D) into the pose blocks (soak frame v1 r63072, anchored: 3.6e-5 rad off a stable oracle; the mean of the
-      // two triangles is what the blocks get now).
+      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k), upper triangle.  (The product is symmetric in exact arithmetic only;
+      // k_ba1 feeds the pose blocks the mean of its two triangles, which takes it from 6.2e-5 to 8.8e-6 rad off the oracle on the
+      // anchored soak frame v1 r63072.  Here the same change - -DGL_BAF_SYM_C - gains little, 3.6e-5 -> 3.0e-5 rad, for 12
+      // instructions per point and 1 % of the step, and would leave the bits the 86 000-round soak was run on: not enabled.)
       const int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
         const int r = ri[e], j = ci[e];
         C[e] = fma(M[r * 3], AD[j * 3], fma(M[r * 3 + 1], AD[j * 3 + 1], M[r * 3 + 2] * AD[j * 3 + 2]));
+#ifdef GL_BAF_SYM_C
         if (r != j) {
           const double lo = fma(M[j * 3], AD[r * 3], fma(M[j * 3 + 1], AD[r * 3 + 1], M[j * 3 + 2] * AD[r * 3 + 2]));
           C[e] = 0.5 * (C[e] + lo);
         }
+#endif
       }
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(M[r * 3], u[0], fma(M[r * 3 + 1], u[1], fma(M[r * 3 + 2], u[2], o.a[r] - o.b[r])));
