@@ -9,7 +9,7 @@
 //   pass A (state, lambda): per point, in the CAMERA frame q = R p + t
 //       A  = w Jpi^T Jpi,  a = w Jpi^T e            (reprojection, w = rho' / sigma^2)
 //       Hc = R Hg R^T,     bc = R bg                (GMM edge)
-//       D  = A + Hc + lambda I  -> D^-1 (cofactors, as g2o's Dinv = D->inverse())
+//       D  = A + Hc + lambda I  -> L Delta L^T (ldl3_factor; g2o inverts the block by cofactors, which is noise for a badly scaled one)
 //       Schur:  S += G^T (A - A D^-1 A) G,  g += G^T (a - A D^-1 (a + bc)),  G = [-[q]x | I]
 //               (evaluated as M D^-1 A and M u - bc, M = Hc + lambda I: no cancellation)
 //     (the orthogonal change of variables eps = R dp leaves lambda I and
@@ -31,18 +31,18 @@ using namespace glba;
 
 namespace {
 
-// D^-1 (with LM damping), u = D^-1 b
-GL_DEV void point_solve(const PtLin& o, double lambda, double* Dinv, double* b, double* u) {
+// factors of the damped point block D (ldl3_factor: f), u = D^-1 b
+GL_DEV void point_solve(const PtLin& o, double lambda, double* f, double* b, double* u) {
   double D[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) D[i] = o.A[i] + o.Hc[i];
   D[0] += lambda;
   D[3] += lambda;
   D[5] += lambda;
-  sym3_inv(D, Dinv);
+  ldl3_factor(D, f);
 #pragma unroll
   for (int i = 0; i < 3; ++i) b[i] = o.a[i] + o.bc[i];
-  sym3_mul_vec(Dinv, b, u);
+  ldl3_solve(f, b, u);
 }
 
 // acc[0..20] += upper(G^T C G), acc[21..26] += G^T c ; G = [-[q]x | I], C symmetric (full 3x3 given)
@@ -215,12 +215,16 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
         if (o.act_r) fv.chi_r[l] = o.chi_r;  // computeActiveErrors
         acc[27] += o.rho0_r + o.chi_g;
         if (pose_active && o.act_r) {
-          double Dinv[6], b[3], u[3];
-          point_solve(o, lambda, Dinv, b, u);
+          double Df[6], b[3], u[3];
+          point_solve(o, lambda, Df, b, u);
           // A - A D^-1 A = M D^-1 A and a - A u = M u - bc with M = D - A = Hc + lambda I: products instead of the
           // subtraction, which loses most of its digits for a point held by its reprojection alone (gl_ba_fast_impl.hpp)
           double AD[9], Cf[9], c[3];
-          sym3_mul(o.A, Dinv, AD);  // A D^-1
+          {  // A D^-1: row r = D^-1 (row r of A)
+            const double Af[9] = {o.A[0], o.A[1], o.A[2], o.A[1], o.A[3], o.A[4], o.A[2], o.A[4], o.A[5]};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ldl3_solve(Df, Af + r * 3, AD + r * 3);
+          }
           const double Mf[9] = {o.Hc[0] + lambda, o.Hc[1], o.Hc[2], o.Hc[1], o.Hc[3] + lambda, o.Hc[4], o.Hc[2], o.Hc[4], o.Hc[5] + lambda};
 #pragma unroll
           for (int i = 0; i < 3; ++i)
@@ -228,27 +232,12 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
             for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Mf[i * 3] * AD[j * 3] + Mf[i * 3 + 1] * AD[j * 3 + 1] + Mf[i * 3 + 2] * AD[j * 3 + 2];
 #pragma unroll
           for (int i = 0; i < 3; ++i) c[i] = (Mf[i * 3] * u[0] + Mf[i * 3 + 1] * u[1] + Mf[i * 3 + 2] * u[2]) - o.bc[i];
-#ifdef GL_BA1_PLAIN_SCHUR  // (experiment: the subtraction form A - (A D^-1) A, a - A u of the oracle / k_ba_gen)
-          {
-            const double Af[9] = {o.A[0], o.A[1], o.A[2], o.A[1], o.A[3], o.A[4], o.A[2], o.A[4], o.A[5]};
-            double Au[3];
-            sym3_mul_vec(o.A, u, Au);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              c[i] = o.a[i] - Au[i];
-#pragma unroll
-              for (int j = 0; j < 3; ++j) Cf[i * 3 + j] = Af[i * 3 + j] - (AD[i * 3] * Af[j] + AD[i * 3 + 1] * Af[3 + j] + AD[i * 3 + 2] * Af[6 + j]);
-            }
-          }
-#endif
-#ifndef GL_BA1_NO_SYM_C  // the product form is symmetric in exact arithmetic only (gl_ba_fast_impl.hpp: pt_pass_a): the mean of its two triangles
-          {
+          {  // the product is symmetric in exact arithmetic only: the pose blocks get the mean of its two triangles
             const double s01 = 0.5 * (Cf[1] + Cf[3]), s02 = 0.5 * (Cf[2] + Cf[6]), s12 = 0.5 * (Cf[5] + Cf[7]);
             Cf[1] = Cf[3] = s01;
             Cf[2] = Cf[6] = s02;
             Cf[5] = Cf[7] = s12;
           }
-#endif
           accum_pose(o.q, Cf, c, acc);
         }
       }
@@ -290,8 +279,8 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
           if (!(ar || (ag && g.has))) continue;
           PtLin o;
           lin_point(k, R, T.t, p, fv.obs + (size_t)l * 3, oc, g, ar, ag, robust, o);
-          double Dinv[6], b[3], u[3];
-          point_solve(o, lambda, Dinv, b, u);
+          double Df[6], b[3], u[3];
+          point_solve(o, lambda, Df, b, u);
           // eps = D^-1 (b - A (w x q + v))
           double gd[3], Agd[3], rhs[3], eps[3];
           cross(dx, o.q, gd);
@@ -306,7 +295,7 @@ GL_DEV int ba_optimize(const BaK& k, const GmmDev& gm, FrameView& fv, SE3& T, bo
           }
 #pragma unroll
           for (int i = 0; i < 3; ++i) rhs[i] = b[i] - Agd[i];
-          sym3_mul_vec(Dinv, rhs, eps);
+          ldl3_solve(Df, rhs, eps);
           // computeScale(): x (lambda x + b), landmark part (rotation invariant)
           acc[0] += eps[0] * (lambda * eps[0] + b[0]) + eps[1] * (lambda * eps[1] + b[1]) + eps[2] * (lambda * eps[2] + b[2]);
           double pn[3];

@@ -50,6 +50,32 @@ GL_DEV void sym3_inv(const double* S, double* I) {
   I[4] = (S[1] * S[2] - S[0] * S[4]) * id;
   I[5] = (S[0] * S[3] - S[1] * S[1]) * id;
 }
+// D = L Delta L^T of a symmetric positive definite 3x3 (unpivoted), f = {l10, l20, l21, 1/d0, 1/d1, 1/d2}, and the solve with
+// the factors.  The single-pose refine kernels use these for the damped point blocks instead of the cofactor inverse: a point
+// block may be arbitrarily badly scaled (a point that ran away along its plane: eigenvalues 400 / 7e-3 / lambda), the
+// cofactor determinant is rounding noise there, the factorisation is backward stable (gl_ba_fast_impl.hpp: ldl3_factor_fast).
+GL_DEV void ldl3_factor(const double* D, double* f) {
+  const double i0 = 1.0 / D[0];
+  const double l1 = D[1] * i0, l2 = D[2] * i0;
+  const double d1 = fma(-l1, D[1], D[3]);
+  const double e = fma(-l1, D[2], D[4]);
+  const double i1 = 1.0 / d1;
+  const double l3 = e * i1;
+  const double d2 = fma(-l3, e, fma(-l2, D[2], D[5]));
+  f[0] = l1;
+  f[1] = l2;
+  f[2] = l3;
+  f[3] = i0;
+  f[4] = i1;
+  f[5] = 1.0 / d2;
+}
+GL_DEV void ldl3_solve(const double* f, const double* b, double* x) {
+  const double y1 = fma(-f[0], b[0], b[1]);
+  const double y2 = fma(-f[2], y1, fma(-f[1], b[0], b[2]));
+  x[2] = y2 * f[5];
+  x[1] = fma(-f[2], x[2], y1 * f[4]);
+  x[0] = fma(-f[1], x[2], fma(-f[0], x[1], b[0] * f[3]));
+}
 // P = X * Y for symmetric X, Y (full 3x3 row-major result)
 GL_DEV void sym3_mul(const double* X, const double* Y, double* P) {
   const double x[9] = {X[0], X[1], X[2], X[1], X[3], X[4], X[2], X[4], X[5]};

@@ -26,7 +26,7 @@
 //
 // Per-frame state in LDS, SoA over the points, for the whole 5/5/40 schedule: current point (3 fp64), stale
 // chi2 (1 fp64) and a 48-byte slot with two lifetimes: between the two passes of a Levenberg trial it holds
-// the damped point block inverse D^-1 (6 fp64) of pass A, so that pass B computes the point step
+// the L Delta L^T factors of the damped point block D (6 fp64) of pass A, so that pass B computes the point step
 //     eps = D^-1 (b - A (omega x q + upsilon)) = D^-1 (Jpi^T W (e - Jpi gd) + b_gmm)
 // exactly in fp64 from the re-evaluated residual (no fp32 anywhere; GL_BAF_STEP32 instead caches the fp32
 // pair {u = D^-1 b, A D^-1} of round 1: ~8 % faster, but its 1e-7 step error is amplified by badly conditioned
@@ -101,18 +101,12 @@ GL_DEV double add_nc(double a, double b) {
 }
 
 GL_DEV double rcp_nr(double a) {
-#ifdef GL_BAF_IEEE_DIV  // (experiment: correctly rounded division / square root instead of the Newton forms)
-  return 1.0 / a;
-#endif
   double x = __builtin_amdgcn_rcp(a);
   x = fma(fma(-a, x, 1.0), x, x);
   x = fma(fma(-a, x, 1.0), x, x);
   return x;
 }
 GL_DEV double rsq_nr(double a) {
-#ifdef GL_BAF_IEEE_DIV
-  return 1.0 / sqrt(a);
-#endif
   double y = __builtin_amdgcn_rsq(a);
   const double h = 0.5 * a;
   y = y * fma(-h * y, y, 1.5);
@@ -221,7 +215,7 @@ struct Lds {      // per-frame state, SoA over MCAP points (index = local point 
   double* sp;     // 3 x MCAP  current point (world)
   double* chir;   // MCAP      stale chi2 of the reprojection edge (e->chi2())
   // 6 x MCAP doubles, two lifetimes sharing one slot per point:
-  //   pass A -> pass B : D^-1 (sym6, fp64)   [GL_BAF_STEP32: 12 fp32 words {u = D^-1 b (3), A D^-1 (3x3)}]
+  //   pass A -> pass B : the factors of D (ldl3_factor_fast, 6 fp64)   [GL_BAF_STEP32: 12 fp32 words {u = D^-1 b (3), A D^-1 (3x3)}]
   //   pass B -> accept : backup of the point (3 fp64) while the trial point sits in `sp`; restored only
   //                      when the trial is rejected.
   double* un;
@@ -415,24 +409,50 @@ GL_DEV double gmm_chi2_fast(double lm, const GmmDev& gm, const double* nd, int f
   return gmm_nondeg(gm, asc, nullptr, p, nullptr, nullptr);
 }
 
-GL_DEV void sym3_inv_fast(const double* S, double* I) {
-  const double c00 = S[3] * S[5] - S[4] * S[4];
-  const double c01 = S[2] * S[4] - S[1] * S[5];
-  const double c02 = S[1] * S[4] - S[2] * S[3];
-  const double det = S[0] * c00 + S[1] * c01 + S[2] * c02;
-  const double id = rcp_nr(det);
-  I[0] = c00 * id;
-  I[1] = c01 * id;
-  I[2] = c02 * id;
-  I[3] = (S[0] * S[5] - S[2] * S[2]) * id;
-  I[4] = (S[1] * S[2] - S[0] * S[4]) * id;
-  I[5] = (S[0] * S[3] - S[1] * S[1]) * id;
+// The damped point block D = A + (GMM block) + lambda I is factorised, D = L Delta L^T (unpivoted: D is symmetric positive
+// definite), and every product with D^-1 - u = D^-1 b, the rows of A D^-1, the point step of pass B - is a pair of triangular
+// solves with the factors f = {l10, l20, l21, 1/d0, 1/d1, 1/d2}.  Until round 4 the block was inverted by cofactors, like Eigen's
+// fixed-size inverse() that g2o calls on its landmark blocks: fine for a well-conditioned block, but a point that has run away
+// along its plane (soak frame map_v1 r63072: an outlier 5 km from the camera, eigenvalues of D = 400 / 7e-3 / lambda) has a
+// determinant that is the rounding residue of three products of size 1e3 as soon as lambda < 1e-6, its "inverse" is garbage, and
+// through G = [-[q]x | I] with |q| = 5e3 that garbage entered the reduced pose system amplified by |q|^2: pose steps of 1e-4 ..
+// 1e-3 where the oracle's are 1e-6 - 3.6e-5 rad off an oracle that no perturbation moves by more than 4e-8.  (The oracle inverts
+// by cofactors too; its subtraction form A - A D^-1 A turns the same garbage into a relative error of the point's small
+// contribution.)  The factorisation is backward stable whatever the scaling of the block: the frame ends 3e-8 from the oracle,
+// for the same instruction count (tools/emul_ba1.py replays the arithmetic on the host).
+// The first two pivots' reciprocals do not depend on each other (1/d1 = d0 / (d0 d1), the leading 2 x 2 minor by one fma, which
+// is as accurate as the recurrence d1 = D11 - l10 D10): two reciprocals in sequence instead of three.
+GL_DEV void ldl3_factor_fast(const double* D, double* f) {
+  const double i0 = rcp_nr(D[0]);
+  const double m2 = fma(D[0], D[3], -(D[1] * D[1]));  // d0 d1
+  const double e2 = fma(D[0], D[4], -(D[1] * D[2]));  // d0 (D12 - l10 D02)
+  const double im = rcp_nr(m2);
+  const double l1 = D[1] * i0, l2 = D[2] * i0;
+  const double i1 = D[0] * im, l3 = e2 * im;
+  const double e = e2 * i0;
+  const double d2 = fma(-l3, e, fma(-l2, D[2], D[5]));
+  f[0] = l1;
+  f[1] = l2;
+  f[2] = l3;
+  f[3] = i0;
+  f[4] = i1;
+  f[5] = rcp_nr(d2);
+}
+// back half of a solve: (L Delta L^T)^-1 b from y = L^-1 b
+GL_DEV void ldl3_back(const double* f, double y0, double y1, double y2, double* x) {
+  x[2] = y2 * f[5];
+  x[1] = fma(-f[2], x[2], y1 * f[4]);
+  x[0] = fma(-f[1], x[2], fma(-f[0], x[1], y0 * f[3]));
+}
+GL_DEV void ldl3_solve_fast(const double* f, const double* b, double* x) {
+  const double y1 = fma(-f[0], b[0], b[1]);
+  ldl3_back(f, b[0], y1, fma(-f[2], y1, fma(-f[1], b[0], b[2])), x);
 }
 
-GL_DEV void point_solve_fast(const Lin& o, double lambda, double* Dinv, double* u) {
+GL_DEV void point_solve_fast(const Lin& o, double lambda, double* f, double* u) {
   const double D[6] = {o.D[0] + lambda, o.D[1], o.D[2], o.D[3] + lambda, o.D[4], o.D[5] + lambda};
-  sym3_inv_fast(D, Dinv);
-  sym3_mul_vec(Dinv, o.b, u);
+  ldl3_factor_fast(D, f);
+  ldl3_solve_fast(f, o.b, u);
 }
 
 // ---- gauge anchor of the frame's pose ----------------------------------------------------------------------------
@@ -676,16 +696,23 @@ GL_DEV void pose_terms(const double* q, const double* C, const double* c, bool w
   }
 }
 
-// The reprojection block A = sum_r w_r j_r^T j_r has A(0,1) = 0 by construction (no row of Jpi touches x and y):
-// written out, the products below skip the multiplications by that zero (IEEE arithmetic may not drop them itself).
-// AD = A Dinv (3x3), A = {A0, 0, A2, A3, A4, A5} sym6, Dinv sym6
-GL_DEV void ad_product(const double* A, const double* Di, double* AD) {
-  const double y[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    AD[j] = fma(A[0], y[j], A[2] * y[6 + j]);
-    AD[3 + j] = fma(A[3], y[3 + j], A[4] * y[6 + j]);
-    AD[6 + j] = fma(A[2], y[j], fma(A[4], y[3 + j], A[5] * y[6 + j]));
+// AD = A D^-1 (3x3): row r = D^-1 (row r of A), three solves with the factors.  The reprojection block
+// A = sum_r w_r j_r^T j_r = {A0, 0, A2, A3, A4, A5} (sym6) has A(0,1) = 0 by construction (no row of Jpi touches x and y): written
+// out, the forward substitutions skip the multiplications by that zero (IEEE arithmetic may not drop them itself).
+GL_DEV void ad_solve(const double* A, const double* f, double* AD) {
+  {
+    const double y1 = -f[0] * A[0];
+    ldl3_back(f, A[0], y1, fma(-f[2], y1, fma(-f[1], A[0], A[2])), AD);
+  }
+  {  // y0 = 0
+    const double y2 = fma(-f[2], A[3], A[4]);
+    AD[5] = y2 * f[5];
+    AD[4] = fma(-f[2], AD[5], A[3] * f[4]);
+    AD[3] = fma(-f[1], AD[5], -f[0] * AD[4]);
+  }
+  {
+    const double y1 = fma(-f[0], A[2], A[4]);
+    ldl3_back(f, A[2], y1, fma(-f[2], y1, fma(-f[1], A[2], A[5])), AD + 6);
   }
 }
 
@@ -1082,14 +1109,14 @@ GL_DEV void restore_point(const Lds& D, int ll) {
 // (Software-prefetching slot i+1 was measured: it costs 14 VGPRs -> 6 spilled registers and
 // ~1 GB of scratch writes per launch for no gain; the second wave of the SIMD hides the latency.)
 GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gobn, const double* __restrict__ gnd,
-                    const int32_t* __restrict__ gassoc, int i, PtCtx& c, int a_pre = -2) {
+                    const int32_t* __restrict__ gassoc, int i, PtCtx& c) {
   c.fl = fw_get(fw, i);
   if (!(c.fl & (F_AR | F_AG))) return false;
   c.l = mp.base + mp.step * i;
   c.ll = mp.lbase + mp.step * i;
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.ob[j] = gobn[(size_t)c.l * 3 + j];
-  const int a = a_pre != -2 ? a_pre : gassoc[c.l];
+  const int a = gassoc[c.l];
   const int ap = a > 0 ? a : 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];  // plane normal n and n . mean: the map's table, by component
@@ -1169,7 +1196,7 @@ GL_DEV void pt_lambda_init(const Uni& U, const GmmDev& gm, const Lds& D, const P
     pose_terms(o.q, o.A, zero, false, sk);
   }
 }
-// pass A: linearise, point solve, Schur terms 0..26, robust chi2 (27), sum u.b (28); leaves D^-1 in the slot and the
+// pass A: linearise, point solve, Schur terms 0..26, robust chi2 (27), sum u.b (28); leaves the factors of D in the slot and the
 // Huber weight rho' of the reprojection edge in the stale-chi2 cell (dead until pass B rewrites it)
 template <class Sink>
 GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double lambda,
@@ -1177,8 +1204,8 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
   Lin o;
   lin_fast(U, gm, D, P, c, robust, o);
   sk.put(27, o.rho0_r + o.chi_g);
-  double Dinv[6], u[3];
-  point_solve_fast(o, lambda, Dinv, u);
+  double Df[6], u[3];
+  point_solve_fast(o, lambda, Df, u);
   sk.put(28, fma(u[0], o.b[0], fma(u[1], o.b[1], u[2] * o.b[2])));
   if (kStep32) {
     int* un = (int*)D.un;
@@ -1186,12 +1213,12 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
     for (int j = 0; j < 3; ++j) un[j * MCAP + c.ll] = __float_as_int((float)u[j]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) D.un[j * MCAP + c.ll] = Dinv[j];
+    for (int j = 0; j < 6; ++j) D.un[j * MCAP + c.ll] = Df[j];
   }
   if (c.ar) {
     if (!kStep32) D.chir[c.ll] = o.rho1;
     double C[6], cc[3], AD[9];
-    ad_product(o.A, Dinv, AD);
+    ad_solve(o.A, Df, AD);
     if (kStep32) {
       int* un = (int*)D.un;
 #pragma unroll
@@ -1208,21 +1235,12 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
       const double M[9] = {(o.D[0] - o.A[0]) + lambda, o.D[1] - o.A[1], o.D[2] - o.A[2],
                            o.D[1] - o.A[1], (o.D[3] - o.A[3]) + lambda, o.D[4] - o.A[4],
                            o.D[2] - o.A[2], o.D[4] - o.A[4], (o.D[5] - o.A[5]) + lambda};
-      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k), upper triangle.  (The product is symmetric in exact arithmetic only;
-      // k_ba1 feeds the pose blocks the mean of its two triangles, which takes it from 6.2e-5 to 8.8e-6 rad off the oracle on the
-      // anchored soak frame v1 r63072.  Here the same change - -DGL_BAF_SYM_C - gains little, 3.6e-5 -> 3.0e-5 rad, for 12
-      // instructions per point and 1 % of the step, and would leave the bits the 86 000-round soak was run on: not enabled.)
+      // C = M (A D^-1)^T:  C(r, j) = sum_k M(r, k) AD(j, k), upper triangle
       const int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
         const int r = ri[e], j = ci[e];
         C[e] = fma(M[r * 3], AD[j * 3], fma(M[r * 3 + 1], AD[j * 3 + 1], M[r * 3 + 2] * AD[j * 3 + 2]));
-#ifdef GL_BAF_SYM_C
-        if (r != j) {
-          const double lo = fma(M[j * 3], AD[r * 3], fma(M[j * 3 + 1], AD[r * 3 + 1], M[j * 3 + 2] * AD[r * 3 + 2]));
-          C[e] = 0.5 * (C[e] + lo);
-        }
-#endif
       }
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(M[r * 3], u[0], fma(M[r * 3 + 1], u[1], fma(M[r * 3 + 2], u[2], o.a[r] - o.b[r])));
@@ -1257,7 +1275,7 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
       for (int a = 0; a < 3; ++a) e -= (double)__int_as_float(un[(3 + a * 3 + j) * MCAP + c.ll]) * gd[a];
       eps[j] = e;
     }
-  } else {  // exact: b - A gd = Jpi^T W (e - Jpi gd) + b_gmm from the re-evaluated residual, times the cached D^-1
+  } else {  // exact: b - A gd = Jpi^T W (e - Jpi gd) + b_gmm from the re-evaluated residual, solved with the cached factors of D
     double rhs[3] = {0.0, 0.0, 0.0};
     if (c.ar) {
       const double rho1 = D.chir[c.ll];  // the edge's Huber weight, left there by pass A
@@ -1286,10 +1304,10 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
         for (int j = 0; j < 3; ++j) rhs[j] += bc[j];
       }
     }
-    double Dinv[6];
+    double Df[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) Dinv[j] = D.un[j * MCAP + c.ll];
-    sym3_mul_vec(Dinv, rhs, eps);
+    for (int j = 0; j < 6; ++j) Df[j] = D.un[j * MCAP + c.ll];
+    ldl3_solve_fast(Df, rhs, eps);
   }
   sk.put(0, eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2]);
 #pragma unroll
@@ -1322,21 +1340,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 // arbiter favours the older one, which then finishes its 4 slots a third of the pass early and leaves the younger
 // one alone on the SIMD at single-wave speed (measured: 11.6 k vs 18.3 k cycles).  Waves 4..7 sit at priority 1; waves
 // 0..3 start a pass at 2 and drop to 0 for their last slot, so that the pair ends the pass together.
-#if defined(GL_BAF_BAL)
-// (experiment) self-balancing pair: each wave publishes how many point slots it has started (a byte per wave in LDS); at the start
-// of a slot a wave that is AHEAD of the other wave of its SIMD (w ^ 4) steps down to priority 0, one that is level or behind
-// goes to 2 - the lag stays within about one slot instead of growing to a third of the pass.
-#define GL_BAF_PRIO_PASS_BEGIN()
-#define GL_BAF_PRIO_SLOT(i)                                                                         \
-  if (NWC == 8) {                                                                                    \
-    volatile unsigned char* bal_ = (volatile unsigned char*)(R.tot + 62);                             \
-    ++bal_n;                                                                                         \
-    if ((threadIdx.x & 63) == 0) bal_[threadIdx.x >> 6] = (unsigned char)bal_n;                       \
-    const int other_ = __builtin_amdgcn_readfirstlane((int)bal_[(threadIdx.x >> 6) ^ 4]);             \
-    if ((signed char)((unsigned char)bal_n - (unsigned char)other_) > 0) __builtin_amdgcn_s_setprio(0); \
-    else __builtin_amdgcn_s_setprio(2);                                                              \
-  }
-#elif defined(GL_BAF_NO_PRIO)
+#if defined(GL_BAF_NO_PRIO)
 #define GL_BAF_PRIO_PASS_BEGIN()
 #define GL_BAF_PRIO_SLOT(i)
 #else
@@ -1349,23 +1353,6 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 #define GL_BAF_PRIO_DROP 3
 #endif
 
-// (-DGL_BAF_APF, round 3: the association of slot i + 1 is requested while slot i is worked on, so that the plane record of a slot
-// can be gathered in the same round as its observation - one dependent L2 round trip per slot instead of two, for one VGPR.
-// Measured on 1 024 bench frames: 3.42 -> 3.53 ms per call, the spill counts unchanged.  Not enabled.)
-#ifdef GL_BAF_APF
-#define GL_BAF_APF_INIT() int a_nxt_ = mp.base < mp.L ? gassoc[mp.base] : -1, a_cur_ = -1
-#define GL_BAF_APF_STEP()                                                                      \
-  a_cur_ = a_nxt_;                                                                             \
-  {                                                                                            \
-    const int ln_ = mp.base + mp.step * (i + 1);                                               \
-    a_nxt_ = (i + 1 < mp.S && ln_ < mp.L) ? gassoc[ln_] : -1;                                    \
-  }
-#define GL_BAF_APF_ARG , a_cur_
-#else
-#define GL_BAF_APF_INIT()
-#define GL_BAF_APF_STEP()
-#define GL_BAF_APF_ARG
-#endif
 // one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
 // point's terms there (zeros when the thread has no active point)
 #define GL_BAF_PASS(BODY)                                                     \
@@ -1378,12 +1365,10 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
     } else {                                                                  \
       const SinkAcc sk{acc};                                                  \
       GL_BAF_PRIO_PASS_BEGIN();                                               \
-      GL_BAF_APF_INIT();                                                      \
       _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
         GL_BAF_PRIO_SLOT(i);                                                  \
         PtCtx c;                                                              \
-        GL_BAF_APF_STEP();                                                    \
-        if (!load_pt(D, mp, fw, gobn, gnd, gassoc, i, c GL_BAF_APF_ARG)) continue; \
+        if (!load_pt(D, mp, fw, gobn, gnd, gassoc, i, c)) continue;               \
         BODY;                                                                 \
       }                                                                       \
     }                                                                         \
@@ -1394,8 +1379,6 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
                          const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
                          const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, Anchor& An) {
   double acc[32];
-  int bal_n = 0;  // (GL_BAF_BAL: point slots this wave has started)
-  (void)bal_n;
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
   {
@@ -1660,7 +1643,6 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   if (tid == 0) {
     *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
     *(int*)(R.tot + 61) = 0;  // a poll of the exchange gave up (SPREAD)
-    *(long long*)(R.tot + 62) = 0;  // (GL_BAF_BAL: slots started, a byte per wave)
   }
   {
     const int ns = kSpread ? 1 : mp.S;

@@ -387,15 +387,16 @@ def test_soak_create_map_points_parallax_knife_edge(env, oracle):
 
 # ---- round 3, rounds 50 000 .. 86 000 of the soak: ONE anchored frame in 43 000 that is NOT ill-conditioned ----------------------------
 def test_soak_track_prior_single_pose_kernels_real_deviation(env, oracle, opt):
-    """map_v1 round 63072 (138 points, prior edge): gl_track_frames_anchored ends 3.6e-5 rad / 5.2e-6 m from the oracle (the general
-    single-pose kernel k_ba1, option ba_slow, 6.2e-5 rad), and this time the ORACLE IS STABLE - it moves by < 4e-8 under re-orderings
-    and under relative changes of its inputs from 3e-16 to 1e-12, the numpy restatement agrees with it to 1.6e-8, and HIP's own
-    general local-BA kernels (both launch shapes) solve the same problem (one free pose with the prior edge) to 2e-8 of it.  The
-    Levenberg traces of the fast kernel and the oracle agree to 1e-14 for 28 trials and part in the trials with lambda < 1e-6
-    (5e-10 of chi2 at trial 30, 1e-8 from then on): the single-pose kernels carry more rounding noise into the late, nearly
-    undamped iterations than the other three implementations.  A REAL deviation (1 of 43 000 anchored frames in 86 000 soak
-    rounds), not classified away; the cause was not found in round 3.  The test holds the picture: oracle stable, general kernels
-    exact, single-pose kernels within 2e-4 with exact associations - tighten it when the cause is found."""
+    """map_v1 round 63072 (138 points, prior edge): in round 3 gl_track_frames_anchored ended 3.6e-5 rad / 5.2e-6 m from the oracle
+    (the general single-pose kernel k_ba1, option ba_slow, 6.2e-5 rad) although the ORACLE IS STABLE here - it moves by < 4e-8 under
+    re-orderings and under relative changes of its inputs from 3e-16 to 1e-12, the numpy restatement agrees with it to 1.6e-8,
+    and HIP's own general local-BA kernels solve the same problem to 2e-8 of it.  A REAL deviation (1 of 43 000 anchored frames in
+    86 000 soak rounds).  Cause, found in round 4 by replaying the kernel's arithmetic on the host (tools/emul_ba1.py): point 83
+    of the frame, an outlier with a plane edge, runs away along its plane to 5 km from the camera; its damped 3 x 3 block then
+    has the eigenvalues 400 / 7e-3 / lambda, the determinant of the cofactor inverse is rounding noise once lambda < 1e-6, and the
+    product form of the Schur term carried that noise - times |q|^2 = 2.6e7 through G = [-[q]x | I] - into the reduced pose system:
+    pose steps of 1e-4 .. 1e-3 where the oracle's are 1e-6.  The single-pose kernels factorise the block (L Delta L^T, backward
+    stable whatever its scaling) since; every launch shape and the general kernel hold the contract's 1e-6 here."""
     e = env
     mapname, r = "map_v1", 63072
     mean, cov, g, h = e["maps"][mapname]
@@ -411,12 +412,20 @@ def test_soak_track_prior_single_pose_kernels_real_deviation(env, oracle, opt):
         assert max(pose_err(p1, p_ref)) < 2e-7
     T, torch, ctx = e["T"], e["torch"], e["ctx"]
     one = torch.ones(1, dtype=torch.uint8).cuda()
-    pose, Xw = T(f["pose_init"][None]), T(f["Xw"][None])
-    assoc = gmmloc_amd.track_frames_anchored(ctx, g, e["cam"], e["prm"], pose, Xw, T(f["obs"][None]), T(f["octave"][None]), prior=one)[0]
-    torch.cuda.synchronize()
-    dt, dr = pose_err(pose.cpu().numpy()[0], p_ref)
-    assert np.array_equal(assoc.cpu().numpy()[0][keep], a_ref)
-    assert dt < 2e-4 and dr < 2e-4, (dt, dr)  # (3.6e-5 rad today; 3.0e-5 with -DGL_BAF_SYM_C: see DESIGN 7)
+    bits = {}
+    for name, options in (("batch", {"ba_shape": 0}), ("latency", {"ba_shape": 1}), ("general", {"ba_slow": 1})):
+        for k, v in options.items():
+            opt(k, v)
+        pose, Xw = T(f["pose_init"][None]), T(f["Xw"][None])
+        assoc = gmmloc_amd.track_frames_anchored(ctx, g, e["cam"], e["prm"], pose, Xw, T(f["obs"][None]), T(f["octave"][None]), prior=one)[0]
+        torch.cuda.synchronize()
+        for k in options:
+            opt(k, {"ba_shape": -1, "ba_slow": 0}[k])
+        dt, dr = pose_err(pose.cpu().numpy()[0], p_ref)
+        assert np.array_equal(assoc.cpu().numpy()[0][keep], a_ref), name
+        assert dt < 1e-6 and dr < 1e-6, (name, dt, dr)  # the north-star tolerance (round 3: 5.2e-6 m / 3.6e-5 rad, asserted 2e-4)
+        bits[name] = pose.cpu().numpy().tobytes()
+    assert bits["batch"] == bits["latency"]
     # the same problem through gl_joint_optimization: one free pose with the prior edge, both launch shapes
     L = len(keep)
     a0 = np.where(d20 <= 9.0, idx0, -1).astype(np.int32)
