@@ -31,6 +31,9 @@ from gmmloc_amd import launch  # noqa: E402
 N_PTS, K_GAUSS = 2000, 4096
 FLOP_PER_PAIR = 21           # centred symmetric Mahalanobis form
 FLOP_PER_POINT_TRIAL = 800   # structure refine, per point per LM iteration (linearise, 3x3 inverse, Schur)
+# ... and for a trial BEYOND the first of an outer iteration: g2o keeps the linearisation and only re-damps, re-solves and
+# re-evaluates (3x3 inverse 40 + Schur and g 270 + transform / project / robust chi2 40, same table)
+FLOP_PER_POINT_RETRIAL = 350
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X fp64 vector peak (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
 
@@ -231,6 +234,84 @@ def stub_bench(args, ranks):
     ranks.close()
 
 
+def refine_flop(points, trials, outer):
+    """algorithmic flop of the structure refine: an outer Levenberg iteration linearises (800 flop per point); a trial
+    beyond the first of an iteration only re-damps, re-solves and re-evaluates (350)"""
+    return points * (FLOP_PER_POINT_TRIAL * outer + FLOP_PER_POINT_RETRIAL * max(trials - outer, 0.0))
+
+
+def extra_legs(args, ranks, ctx, gmm, cam, prm, mean, cov, pose0, Xw0, obs, octv, pose, Xw, step, start_timers, trials, outer, B, world, local, dev):
+    """the legs reported beside the headline (sweep step, two streams, 1000-point class, anchored step): outside the timed region"""
+    import torch
+    import gmmloc_amd
+    from gmmloc_amd import api
+    # the same step with the association forced to the plain N x K sweep (option assoc_grid = 0): same results
+    # (tests/test_gpu_track.py), the arithmetic of the same-math CPU baseline pair for pair
+    sweep_steps = max(2, args.steps // 4)
+    grid_before = ctx.get_option("assoc_grid")  # (may have been set through GMMLOC_ASSOC_GRID: put back what was there)
+    ctx.set_option("assoc_grid", 0)
+    with torch.cuda.stream(ctx.stream):
+        dt_sweep = launch.timed_steps(step, sweep_steps, 1, ranks) / sweep_steps
+    ctx.set_option("assoc_grid", grid_before)
+
+    # the same step taken in turn by TWO contexts (two streams, two scratch blocks; same device, same inputs): what a host that
+    # keeps two batches in flight gets - the association / set-up kernels of step k + 1 run in the tail of step k's refine,
+    # where CUs are already free (a refine workgroup owns its CU's LDS and registers, so nothing else overlaps).  Reported
+    # beside `value`, which stays the one-stream figure; the results of the two contexts are bit-identical.
+    ctx_b = gmmloc_amd.Context(local)
+    gmm_b = gmmloc_amd.GMM(ctx_b, mean, cov, prm)
+    pose_b, Xw_b = pose0.clone(), Xw0.clone()
+    lanes = [(ctx, gmm, pose, Xw), (ctx_b, gmm_b, pose_b, Xw_b)]
+    turn = [0]
+
+    def step2():
+        c_, g_, p_, x_ = lanes[turn[0] & 1]
+        turn[0] += 1
+        with torch.cuda.stream(c_.stream):
+            p_.copy_(pose0)
+            x_.copy_(Xw0)
+            gmmloc_amd.track_frames(c_, g_, cam, prm, p_, x_, obs, octv, want_d2=False)
+    two_steps = max(4, 2 * (args.steps // 4))
+    dt_two = launch.timed_steps(step2, two_steps, 2, ranks) / two_steps
+    two_same = bool(torch.equal(pose, pose_b) and torch.equal(Xw, Xw_b))
+    # the second context and its map (incl. the packed cell table) go before the legs below (nothing else holds them)
+    lanes.clear()
+    pose_b = Xw_b = None
+    gmm_b.close()
+    ctx_b.close()
+    del gmm_b, ctx_b
+
+    # outside the timed region: (a) the refine on the 1 000-point LDS class - the first 1 000 points of every frame; real
+    # tracking frames have <= 1 200 features (cfg/v1.yaml:24) and two such frames share a CU, so the serial 6 x 6 solve of one
+    # overlaps the passes of the other - and (b) the anchored step (gl_track_frames_anchored: prior edge on every pose)
+    def refine_leg(M, prior):
+        x0, ob, oc = Xw0[:, :M].contiguous(), obs[:, :M].contiguous(), octv[:, :M].contiguous()
+        p, x = pose0.clone(), x0.clone()
+        pr = torch.ones(B, dtype=torch.uint8, device=dev) if prior else None
+
+        def st():
+            p.copy_(pose0)
+            x.copy_(x0)
+            if prior:
+                return gmmloc_amd.track_frames_anchored(ctx, gmm, cam, prm, p, x, ob, oc, prior=pr, want_d2=False)
+            return gmmloc_amd.track_frames(ctx, gmm, cam, prm, p, x, ob, oc, want_d2=False)
+        nst = max(2, args.steps // 4)
+        with torch.cuda.stream(ctx.stream):
+            t = launch.timed_steps(st, nst, 1, ranks, before_timed=start_timers)
+        ms, nn = ctx.timing_read(api.TIMER_BA)
+        ctx.timing(False)
+        ntr, nou = float(trials.sum().item()), float(outer.sum().item())  # (read straight after the leg: the buffers are shared)
+        ks = ms / 1e3 / max(nn, 1)
+        tf = refine_flop(M, ntr, nou) / ks / 1e12 if nn else None
+        return {"value": B * world * nst / t, "unit": "frames/s", "points_per_frame": M, "steps": nst, "refine_avg_launch_ms": 1e3 * ks,
+                "trials_per_frame": ntr / B, "outer_iterations_per_frame": nou / B, "refine_TFLOPs": tf,
+                "refine_frac_of_fp64_valu_peak": tf / PEAK_FP64_VALU_TFLOPS if tf else None}
+    leg_1000 = refine_leg(1000, False)
+    leg_prior = refine_leg(N_PTS, True)
+
+    return dt_sweep, sweep_steps, dt_two, two_steps, two_same, leg_1000, leg_prior
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without a launcher: bench.py starts them itself")
@@ -238,6 +319,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="the timed step only (what tools/profile_bench.sh profiles: the two-stream / sweep / class legs launch the same kernels)")
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("SEED", "BUDGET_S"), help=argparse.SUPPRESS)
     ap.add_argument("--stub", choices=["gloo"], default=None, help=argparse.SUPPRESS)  # CPU test of the launch plumbing
     args = ap.parse_args()
@@ -279,7 +362,8 @@ def main():
     barrier = ranks.barrier
 
     trials = torch.zeros(B, dtype=torch.int32, device=dev)
-    ctx.set_stats_buffer(trials)  # per-frame Levenberg trial counts of the last step (algorithmic work of k_ba1_fast)
+    outer = torch.zeros(B, dtype=torch.int32, device=dev)
+    ctx.set_stats_buffer(trials, outer)  # per-frame Levenberg trials and outer iterations of the last step (algorithmic work of k_ba1_fast)
 
     def step():
         pose.copy_(pose0)
@@ -294,69 +378,21 @@ def main():
 
     with torch.cuda.stream(ctx.stream):
         dt = launch.timed_steps(step, args.steps, args.warmup, ranks, before_timed=start_timers)
-    n_trials = float(trials.sum().item())  # (of the last timed step; the legs below reuse the buffer)
+    n_trials = float(trials.sum().item())  # (of the last timed step; the legs below reuse the buffers)
+    n_outer = float(outer.sum().item())
     assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
     prep_ms, prep_n = ctx.timing_read(api.TIMER_BA_PREP)
     ctx.timing(False)
 
-    # the same step with the association forced to the plain N x K sweep (option assoc_grid = 0): same results
-    # (tests/test_gpu_track.py), the arithmetic of the same-math CPU baseline pair for pair
-    sweep_steps = max(2, args.steps // 4)
-    grid_before = ctx.get_option("assoc_grid")  # (may have been set through GMMLOC_ASSOC_GRID: put back what was there)
-    ctx.set_option("assoc_grid", 0)
-    with torch.cuda.stream(ctx.stream):
-        dt_sweep = launch.timed_steps(step, sweep_steps, 1, ranks) / sweep_steps
-    ctx.set_option("assoc_grid", grid_before)
-
-    # the same step taken in turn by TWO contexts (two streams, two scratch blocks; same device, same inputs): what a host that
-    # keeps two batches in flight gets - the association / set-up kernels of step k + 1 run in the tail of step k's refine,
-    # where CUs are already free (a refine workgroup owns its CU's LDS and registers, so nothing else overlaps).  Reported
-    # beside `value`, which stays the one-stream figure; the results of the two contexts are bit-identical.
-    ctx_b = gmmloc_amd.Context(local)
-    gmm_b = gmmloc_amd.GMM(ctx_b, mean, cov, prm)
-    pose_b, Xw_b = pose0.clone(), Xw0.clone()
-    lanes = [(ctx, gmm, pose, Xw), (ctx_b, gmm_b, pose_b, Xw_b)]
-    turn = [0]
-
-    def step2():
-        c_, g_, p_, x_ = lanes[turn[0] & 1]
-        turn[0] += 1
-        with torch.cuda.stream(c_.stream):
-            p_.copy_(pose0)
-            x_.copy_(Xw0)
-            gmmloc_amd.track_frames(c_, g_, cam, prm, p_, x_, obs, octv, want_d2=False)
-    two_steps = max(4, 2 * (args.steps // 4))
-    dt_two = launch.timed_steps(step2, two_steps, 2, ranks) / two_steps
-    two_same = bool(torch.equal(pose, pose_b) and torch.equal(Xw, Xw_b))
-    del gmm_b, ctx_b
-
-    # outside the timed region: (a) the refine on the 1 000-point LDS class - the first 1 000 points of every frame; real
-    # tracking frames have <= 1 200 features (cfg/v1.yaml:24) and two such frames share a CU, so the serial 6 x 6 solve of one
-    # overlaps the passes of the other - and (b) the anchored step (gl_track_frames_anchored: prior edge on every pose)
-    def refine_leg(M, prior):
-        x0, ob, oc = Xw0[:, :M].contiguous(), obs[:, :M].contiguous(), octv[:, :M].contiguous()
-        p, x = pose0.clone(), x0.clone()
-        pr = torch.ones(B, dtype=torch.uint8, device=dev) if prior else None
-
-        def st():
-            p.copy_(pose0)
-            x.copy_(x0)
-            if prior:
-                return gmmloc_amd.track_frames_anchored(ctx, gmm, cam, prm, p, x, ob, oc, prior=pr, want_d2=False)
-            return gmmloc_amd.track_frames(ctx, gmm, cam, prm, p, x, ob, oc, want_d2=False)
-        nst = max(2, args.steps // 4)
-        with torch.cuda.stream(ctx.stream):
-            t = launch.timed_steps(st, nst, 1, ranks, before_timed=start_timers)
-        ms, nn = ctx.timing_read(api.TIMER_BA)
-        ctx.timing(False)
-        ntr = float(trials.sum().item())
-        ks = ms / 1e3 / max(nn, 1)
-        tf = FLOP_PER_POINT_TRIAL * M * ntr / ks / 1e12 if nn else None
-        return {"value": B * world * nst / t, "unit": "frames/s", "points_per_frame": M, "steps": nst, "refine_avg_launch_ms": 1e3 * ks,
-                "trials_per_frame": ntr / B, "refine_TFLOPs": tf, "refine_frac_of_fp64_valu_peak": tf / PEAK_FP64_VALU_TFLOPS if tf else None}
-    leg_1000 = refine_leg(1000, False)
-    leg_prior = refine_leg(N_PTS, True)
+    extra = not args.no_extra_legs
+    dt_sweep = dt_two = None
+    two_same = None
+    sweep_steps = two_steps = 0
+    leg_1000 = leg_prior = None
+    if extra:
+        dt_sweep, sweep_steps, dt_two, two_steps, two_same, leg_1000, leg_prior = extra_legs(
+            args, ranks, ctx, gmm, cam, prm, mean, cov, pose0, Xw0, obs, octv, pose, Xw, step, start_timers, trials, outer, B, world, local, dev)
 
     # the plain N x K sweep on the same points (its roofline record), and
     # the number of chi2 evaluations the cell index needed for them
@@ -380,17 +416,25 @@ def main():
         # host call -> result synchronised, on the first frame of the batch
         p1, x1, o1, c1 = pose0[:1].contiguous(), Xw0[:1].contiguous(), obs[:1].contiguous(), octv[:1].contiguous()
         pl, xl = p1.clone(), x1.clone()
-        lat = []
-        with torch.cuda.stream(ctx.stream):
-            for it in range(25):
-                pl.copy_(p1)
-                xl.copy_(x1)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                gmmloc_amd.track_frames(ctx, gmm, cam, prm, pl, xl, o1, c1, want_d2=False)
-                torch.cuda.synchronize()
-                lat.append(time.perf_counter() - t1)
-        latency_ms = 1e3 * float(np.median(lat[5:]))
+
+        def one_frame_latency():
+            lat = []
+            with torch.cuda.stream(ctx.stream):
+                for it in range(25):
+                    pl.copy_(p1)
+                    xl.copy_(x1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    gmmloc_amd.track_frames(ctx, gmm, cam, prm, pl, xl, o1, c1, want_d2=False)
+                    torch.cuda.synchronize()
+                    lat.append(time.perf_counter() - t1)
+            return 1e3 * float(np.median(lat[5:]))
+        latency_ms = one_frame_latency()
+        # (option ba_same_xcd = 1: the opt-in same-XCD form of the latency shape's exchange, outside the HIP memory model - gmmloc_hip.h)
+        xcd_before = ctx.get_option("ba_same_xcd")
+        ctx.set_option("ba_same_xcd", 1)
+        latency_same_xcd_ms = one_frame_latency()
+        ctx.set_option("ba_same_xcd", xcd_before)
         # host buffers in, host buffers out (what the reference host would call once per frame through the adapter):
         # page-locked staging, one enqueued copy each way, one synchronize; at the bench frame and at 700 points
         h2h = {}
@@ -418,7 +462,8 @@ def main():
         alg_bytes = B * N_PTS * 24 + K_GAUSS * 96 + B * N_PTS * 12
         info = gmm.index_info()
         ba_s = ba_ms / 1e3 / max(ba_n, 1)
-        ba_flop = FLOP_PER_POINT_TRIAL * N_PTS * n_trials
+        ba_flop = refine_flop(N_PTS, n_trials, n_outer)
+        ba_flop_every_trial = FLOP_PER_POINT_TRIAL * N_PTS * n_trials  # (what rounds 1-3 reported: every trial priced as a linearisation)
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
         ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8 + 24 + 4) + 2 * 56)  # Xw, obs, octave, assoc, d2 in; points, final assoc out; pose in/out
         ba_traffic, ba_traffic_src, ba_traffic_stale = measured_traffic("k_ba1_fast", B)
@@ -458,7 +503,14 @@ def main():
                 "traffic_setup_kernel": measured_traffic("k_ba1_prep", B)[0],  # k_ba1_prep: gate, flags, order, normalised observations
                 "avg_launch_ms": 1e3 * ba_s,
                 "flop_per_launch": ba_flop,
-                "units": "%d frames x %d points x %.1f LM trials/frame x %d flop" % (B, N_PTS, n_trials / B, FLOP_PER_POINT_TRIAL),
+                "units": "%d frames x %d points x (%.1f outer iterations/frame x %d flop + %.1f further trials/frame x %d flop)"
+                         % (B, N_PTS, n_outer / B, FLOP_PER_POINT_TRIAL, (n_trials - n_outer) / B, FLOP_PER_POINT_RETRIAL),
+                "trials_per_frame": n_trials / B,
+                "outer_iterations_per_frame": n_outer / B,
+                "frac_pricing_every_trial_as_a_linearisation": (ba_flop_every_trial / ba_s / 1e12 / PEAK_FP64_VALU_TFLOPS) if ba_n else None,
+                "flop_model": "SURVEY 8d: 800 flop per point and outer iteration (linearise + 3x3 inverse + Schur + error); a Levenberg trial "
+                              "beyond the first of an iteration needs no new linearisation: 350 (inverse, Schur, error).  The kernel "
+                              "re-linearises in every trial (it keeps no Jacobians): that is its choice, not algorithmic work",
                 "hbm": {"achieved_GBs": ba_bytes / ba_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
                         "algorithmic_bytes_per_launch": ba_bytes},
             },
@@ -491,6 +543,10 @@ def main():
             "kernel_ms_per_step": {"associate": assoc_ms / max(args.steps, 1), "refine_setup": prep_ms / max(args.steps, 1),
                                    "refine": ba_ms / max(args.steps, 1)},
         }
+        if not extra:
+            print(json.dumps(out))
+            ranks.close()
+            return
         leg_1000["what"] = ("the same step on the first 1000 points of every frame: the 1000-point LDS class of the refine (2 frames per CU; "
                             "tracking frames have <= 1200 features, cfg/v1.yaml:24); MAX over ranks")
         out["roofline"]["class_1000"] = leg_1000
@@ -505,7 +561,10 @@ def main():
             "value": B * world / dt_two, "unit": "frames/s", "ms_per_step": 1e3 * dt_two, "steps": two_steps, "bit_identical_results": two_same,
             "what": "the same step taken in turn by two contexts per GPU (two streams, two scratch blocks): the association and set-up "
                     "kernels of step k + 1 run in the tail of step k's refine; `value` above is the one-stream figure; MAX over ranks"}
-        out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20",
+        out["latency"] = {"single_frame_ms": latency_ms, "what": "gl_track_frames(B=1) call + stream sync, median of 20; default options "
+                                                                  "(device-scope exchange between the frame's workgroups: the model-conforming path)",
+                          "single_frame_same_xcd_ms": latency_same_xcd_ms,
+                          "same_xcd_what": "the same with the opt-in option ba_same_xcd = 1 (workgroup-scope stores into the XCD's shared L2)",
                           "host_to_host_ms": h2h[N_PTS], "host_to_host_700pts_ms": h2h[700],
                           "host_to_host_what": "gl_track_frame_host: host buffers -> the context's page-locked staging -> one H2D + "
                                                "gl_track_frames + one D2H on its stream -> one synchronize -> host buffers (what the "

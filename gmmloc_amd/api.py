@@ -128,10 +128,13 @@ class Context:
         _check(self.lib.gl_ctx_counter_read(self.h, counter, C.byref(v), 1 if reset else 0))
         return v.value
 
-    def set_stats_buffer(self, trials):
-        """Register (or clear with None) an int32 CUDA tensor that receives per-frame LM trial counts."""
-        self._stats = trials
-        _check(self.lib.gl_ctx_set_stats_buffer(self.h, _ptr(trials), trials.numel() if trials is not None else 0))
+    def set_stats_buffer(self, trials, iters=None):
+        """Register (or clear with None) an int32 CUDA tensor that receives per-frame LM trial counts; `iters` (same size,
+        optional) receives the outer Levenberg iterations of the per-frame refine."""
+        self._stats = (trials, iters)
+        n = trials.numel() if trials is not None else 0
+        assert iters is None or iters.numel() >= n
+        _check(self.lib.gl_ctx_set_stats_buffers(self.h, _ptr(trials), _ptr(iters), n))
 
     def close(self):
         if getattr(self, "h", None):

@@ -233,12 +233,14 @@ int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset) {
   return GL_OK;
 }
 
-int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n) {
-  GL_REQUIRE(ctx && n >= 0, "bad argument");
+int gl_ctx_set_stats_buffers(gl_ctx_t* ctx, int32_t* trials_dev, int32_t* iters_dev, int n) {
+  GL_REQUIRE(ctx, "null context");
   gl::C(ctx)->stats = n > 0 ? trials_dev : nullptr;
+  gl::C(ctx)->stats_iters = (n > 0 && trials_dev) ? iters_dev : nullptr;
   gl::C(ctx)->stats_n = trials_dev ? n : 0;
   return GL_OK;
 }
+int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n) { return gl_ctx_set_stats_buffers(ctx, trials_dev, nullptr, n); }
 
 int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out) {
   GL_REQUIRE(ctx && dev_out, "null argument");

@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted,
                                                   const int32_t* __restrict__ oct_all,
                                                   const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi, double* __restrict__ stage, int nb_prev,
-                                                  int32_t* __restrict__ counters) {
+                                                  int32_t* __restrict__ counters, int32_t* __restrict__ outer_out) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1698,11 +1698,12 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
 
   // schedule (:770-828): optimize(5) -> gate degenerate GMM edges -> optimize(5) -> gate reprojection
   // edges, robust kernels off -> optimize(40).  One rolled phase loop = one copy of the optimiser code.
-  int it3 = 0, trials = 0;
+  int it3 = 0, trials = 0, outer = 0;
   const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
     it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, pc, phase < 2, phase < 2 ? 5 : 40, R, trials, C, An);
+    outer += it3 > 0 ? it3 : 0;
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
@@ -1775,6 +1776,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     }
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
+    if (outer_out) outer_out[f] = outer;
 #ifdef GL_BA_TRACE
     if (f == 0)
       for (int i = 0; i < 10 * 128 && i < L * 3; ++i) pts_io[i] = g_trace[i];

@@ -86,7 +86,7 @@ struct Options {
   double ba_step32 = 0;         // 1: point step from an fp32 cache of the pass-A solve (faster, not the default)
   double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
   double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame
-  double ba_same_xcd = 1;          //   0: the latency shape never uses the same-XCD form of its exchange (A/B, tests)
+  double ba_same_xcd = 0;          //   1: the latency shape may use the same-XCD form of its exchange (outside the HIP memory model: opt-in, gmmloc_hip.h)
   double ba_rendezvous_us = 200;   // time limit of EVERY exchange of the latency shape (the fallback it protects costs ~0.5 ms; 0: a workgroup
                                    // gives up at its first unsuccessful look -> follow-up kernel; tests)
   double ba_test_abort_seq = 0;    // tests: n > 0 makes the last workgroup of every frame give up at its n-th exchange
@@ -129,6 +129,7 @@ struct Ctx {
   int pipe_hint = 0;         // cycles the last pipelined local BA needed (the next call enqueues that many + 2 ahead)
   // optional statistics buffer (gl_ctx_set_stats_buffer)
   int32_t* stats = nullptr;
+  int32_t* stats_iters = nullptr;  // (gl_ctx_set_stats_buffers) outer Levenberg iterations per frame
   int stats_n = 0;
   // timing
   bool timing = false;

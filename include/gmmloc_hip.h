@@ -90,13 +90,14 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *     ever reach the caller's buffers through the one-workgroup kernel that always follows, which copies the staged result
  *     of a complete frame and recomputes the others from the untouched inputs: same bits, <= ~0.5 ms more.
  *     GL_COUNTER_BA_REDONE counts those frames,
- *   ba_same_xcd (1): the exchange of that shape may use its same-XCD form - workgroup-scope atomic stores that stay in the
- *     XCD's L2, polled by the siblings with agent-scope (L1-bypassing) loads.  HARDWARE ASSUMPTION, outside the HIP memory
- *     model: a workgroup-scope store becomes visible to an agent-scope load of ANOTHER workgroup on the same XCD because
- *     the vector L1 of gfx942 / gfx950 is write-through and the XCD's workgroups share one L2.  It is used only when (a) a
- *     probe at gl_ctx_create found block b on XCC id b % 8 and (b) the frame's workgroups reported one and the same id in
- *     the launch's first (device-scope) exchange; a word that did not become visible would time the exchange out
- *     (ba_rendezvous_us) and send the frame to the follow-up kernel.  0: device-scope stores only (0.37 instead of 0.34 ms),
+ *   ba_same_xcd (0): 1 lets the exchange of that shape use its same-XCD form - workgroup-scope atomic stores that stay in
+ *     the XCD's L2, polled by the siblings with agent-scope (L1-bypassing) loads: 0.34 instead of 0.37 ms per frame of 2 000
+ *     points.  OPT-IN, because it rests on a HARDWARE ASSUMPTION outside the HIP memory model: a workgroup-scope store becomes
+ *     visible to an agent-scope load of ANOTHER workgroup on the same XCD because the vector L1 of gfx942 / gfx950 is
+ *     write-through and the XCD's workgroups share one L2.  Even when enabled it is used only if (a) a probe at gl_ctx_create
+ *     found block b on XCC id b % 8 and (b) the frame's workgroups reported one and the same id in the launch's first
+ *     (device-scope) exchange; a word that did not become visible would time the exchange out (ba_rendezvous_us) and send the
+ *     frame to the follow-up kernel.  The default (0) uses device-scope stores only: the model-conforming path; same bits,
  *   bagen_mode (0): launch shape of gl_joint_optimization - 1 the persistent cooperative kernel (asynchronous), 2 the
  *     pipelined shape (a kernel per phase, cycles enqueued ahead, the call returns with the work complete), 0 by window
  *     size (the pipelined shape from 5 000 observations for up to 8 windows per call: 1.4 - 2 x less per Levenberg trial);
@@ -127,6 +128,10 @@ int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset);
  * gl_joint_optimization) write the number of Levenberg trials (linearise + solve + evaluate) each frame / problem
  * b < n spent, so that the algorithmic work of a launch can be reported.  NULL / 0 unregisters. */
 int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n);
+/* ... and, for the per-frame refine (gl_track_frames / gl_track_frames_anchored), the number of OUTER Levenberg iterations
+ * (g2o's optimize() iterations: one linearisation each; a trial beyond the first of an iteration re-solves the same
+ * linearisation with a larger lambda) into iters_dev (n int32, may be NULL): the two counts bracket the algorithmic work. */
+int gl_ctx_set_stats_buffers(gl_ctx_t* ctx, int32_t* trials_dev, int32_t* iters_dev, int n);
 
 /* ---- GMM map: replaces GMMUtility::loadGMMModel (gmm_utils.cpp:9-67),
  *      GaussianComponent ctor + decompose (gaussian.h:30-39, gaussian.cpp:36-63)

@@ -160,7 +160,7 @@ def test_track_frames_prior_bit_identical_across_shapes_and_batches(gpu, map_v1,
             opt("ba_same_xcd", same)
             for a, b in zip(ref, run()):
                 assert np.array_equal(a, b, equal_nan=True), (M, same)
-        opt("ba_same_xcd", 1)
+        opt("ba_same_xcd", 0)
         opt("ba_shape", -1)
         one = run(slice(2, 3))
         for a, b in zip(ref, one):

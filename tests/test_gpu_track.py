@@ -201,10 +201,10 @@ def test_track_frames_bit_identical_across_shapes(gpu, map_v1, gt_sync, opt):
             res[shape] = _run_track(torch, ctx, g, cam, prm, frames)
         for a, b, what in zip(res[0], res[1], ("pose", "points", "assoc", "chi2")):
             assert np.array_equal(a, b, equal_nan=True), (M, B, what, np.abs(a - b).max())
-        opt("ba_same_xcd", 0)  # the latency shape with the device-scope form of its exchange only
+        opt("ba_same_xcd", 1)  # the latency shape with the opt-in same-XCD form of its exchange (the default is device scope)
         for a, b, what in zip(res[1], _run_track(torch, ctx, g, cam, prm, frames), ("pose", "points", "assoc", "chi2")):
             assert np.array_equal(a, b, equal_nan=True), (M, B, what)
-        opt("ba_same_xcd", 1)
+        opt("ba_same_xcd", 0)
 
 
 def test_track_frames_rendezvous_gives_up_cleanly(gpu, map_v1, gt_sync, opt):

@@ -8,7 +8,7 @@ TAG=${1:-r2}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- $BENCH > $OUT/bench_line_under_rocprof.json 2> $OUT/stats.err
 DB=$(ls $OUT/stats/*/*_results.db $OUT/stats/*_results.db 2>/dev/null | head -1)
 python tools/rocpd_summary.py "$DB" > gpurun_out/${TAG}_bench_kernel_stats.txt
