@@ -2671,7 +2671,7 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
     GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_ba_gen, s_bytes));
   // workgroups per problem: as many as stay co-resident (the per-problem barrier needs that; the
   // cooperative launch enforces it), at most 64; large batches run one workgroup per problem
-  int NB = 1;
+  int NB = 1, bsub = B;
   {
     // the occupancy query is a driver call: the context (one device, one host thread) remembers it per LDS size
     auto key = std::make_pair((const void*)k_ba_gen, lds);
@@ -2688,32 +2688,54 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
     // cross-workgroup barrier at all), 8 up to 2 000, 16 up to 6 000, 32 up to 16 000, 64 above; NOBS (the
     // stride) stands in for the observation count
     const int want = NOBS <= 600 ? 1 : NOBS <= 2000 ? 8 : NOBS <= 6000 ? 16 : NOBS <= 16000 ? 32 : 64;
-    NB = (int)std::min<long>(want, cap / B);
-    if (c->opt.bagen_nb > 0) NB = (int)std::min<long>(std::max(1, (int)c->opt.bagen_nb), cap / B);  // knob: that many workgroups per problem (tests: 1)
-    NB = std::min(NB, 64);  // (the barrier has 64 arrival words)
+    // The workgroup count of a problem decides the order of its partial sums, i.e. its bits: it is a function of the WINDOW
+    // (its observation stride) alone, never of how many windows ride in the call - a batch too large to keep B x NB workgroups
+    // co-resident is launched in sub-batches of cap / NB windows, one after the other on the stream (round 3 shrank NB instead:
+    // a window's bits then depended on the batch size).
+    NB = std::min(want, (int)std::min<long>(cap, 64));
+    if (c->opt.bagen_nb > 0) NB = (int)std::min<long>(std::max(1, (int)c->opt.bagen_nb), std::min<long>(cap, 64));  // knob: that many workgroups per problem (tests)
+    // bagen_mode 3 (opt-in, throughput of large batches): the whole batch in ONE launch, with as many workgroups per window as
+    // stay co-resident - the round-3 rule; a window's bits then depend on the batch size
+    if (c->opt.bagen_mode == 3) NB = (int)std::min<long>(NB, cap / B);
     if (NB < 2) NB = 1;
+    bsub = NB > 1 ? (int)std::max<long>(1, cap / NB) : B;
   }
   {
     gl::TimerScope ts(c, GL_TIMER_BA);
-    GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 512, c->stream));
     BaK kk = make_bak(cam, prm, -1.0);
-    int32_t* stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;  // gl_ctx_set_stats_buffer: trials per problem
-    char* scr = (char*)scratch;
+    int32_t* stats_all = (c->stats && c->stats_n >= B) ? c->stats : nullptr;  // gl_ctx_set_stats_buffer: trials per problem
     size_t per_v = per;
-    if (NB > 1) {
-      void* args[] = {&kk, &gm, &B, &NB, &P, &F, &L, &NOBS, &poses_dev, &prior_dev, &points_dev, &assoc_dev, &obs_ptr_dev,
-                      &obs_pose_dev, &obs_uvr_dev, &obs_oct_dev, &assoc_dropped_dev, &obs_erase_dev, &iters_dev, &scr, &per_v,
-                      &s_in_lds, &stop_dev, &stats};
-      hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(B * NB), dim3(T_BA), args, lds, c->stream);
-      if (e != hipSuccess) {  // not co-resident after all: one workgroup per problem
-        (void)hipGetLastError();
-        NB = 1;
+    for (int b0 = 0; b0 < B; b0 += bsub) {
+      int Bs = std::min(bsub, B - b0);
+      // the sub-batch's slices of the caller's arrays (strides: gmmloc_hip.h); the scratch is re-used, launches are in stream order
+      double* poses_s = poses_dev + (size_t)b0 * (P + F) * 7;
+      const uint8_t* prior_s = prior_dev + (size_t)b0 * P;
+      double* points_s = points_dev + (size_t)b0 * L * 3;
+      const int32_t* assoc_s = assoc_dev + (size_t)b0 * L;
+      const int32_t* optr_s = obs_ptr_dev + (size_t)b0 * (L + 1);
+      const int32_t* opose_s = obs_pose_dev + (size_t)b0 * NOBS;
+      const double* ouvr_s = obs_uvr_dev + (size_t)b0 * NOBS * 3;
+      const int32_t* ooct_s = obs_oct_dev + (size_t)b0 * NOBS;
+      uint8_t* dropped_s = assoc_dropped_dev + (size_t)b0 * L;
+      uint8_t* erase_s = obs_erase_dev + (size_t)b0 * NOBS;
+      int32_t* iters_s = iters_dev ? iters_dev + b0 : nullptr;
+      int32_t* stats = stats_all ? stats_all + b0 : nullptr;
+      char* scr = (char*)scratch;
+      GL_HIP(hipMemsetAsync(scratch, 0, (size_t)Bs * 512, c->stream));
+      bool launched = false;
+      if (NB > 1) {
+        void* args[] = {&kk, &gm, &Bs, &NB, &P, &F, &L, &NOBS, &poses_s, &prior_s, &points_s, &assoc_s, &optr_s,
+                        &opose_s, &ouvr_s, &ooct_s, &dropped_s, &erase_s, &iters_s, &scr, &per_v,
+                        &s_in_lds, &stop_dev, &stats};
+        hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(Bs * NB), dim3(T_BA), args, lds, c->stream);
+        launched = e == hipSuccess;
+        if (!launched) (void)hipGetLastError();  // not co-resident after all (another context holds CUs): one workgroup per problem
       }
+      if (!launched)
+        k_ba_gen<<<Bs, T_BA, lds, c->stream>>>(kk, gm, Bs, 1, P, F, L, NOBS, poses_s, prior_s, points_s, assoc_s, optr_s,
+                                               opose_s, ouvr_s, ooct_s, dropped_s, erase_s, iters_s,
+                                               scr, per_v, s_in_lds, stop_dev, stats);
     }
-    if (NB == 1)
-      k_ba_gen<<<B, T_BA, lds, c->stream>>>(kk, gm, B, 1, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev,
-                                            obs_pose_dev, obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev,
-                                            scr, per_v, s_in_lds, stop_dev, stats);
   }
   GL_HIP(hipGetLastError());
   return GL_OK;
@@ -2854,7 +2876,9 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   // at 3 - 4 free poses (57 us), the persistent kernel ahead below (1 pose: 32 against 49) and in batches (64 windows of 8 + 4:
   // 0.18 against 0.23 ms per window).
   const bool pipe_fits = P <= 22 && P + F <= 32 && (size_t)L * (NOBS >= 6 * L ? 8 : 4) <= 65536;  // (the judging workgroups hold <= 256 partial sums and the poses in LDS)
-  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && B <= 8 && NOBS >= 5000));
+  // (mode 0 chooses from the WINDOW alone - never from B: the two shapes add their partial sums in different orders, and a
+  // window must not change its bits, or the call its blocking behaviour, with the number of windows that ride along)
+  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && NOBS >= 5000));
   int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_bytes(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
   if (pipe) {

@@ -92,7 +92,7 @@ struct Options {
   double ba_test_abort_seq = 0;    // tests: n > 0 makes the last workgroup of every frame give up at its n-th exchange
   double pose_regs = 1;         //   0: the frame-at-a-time shapes read their edges from global memory every trial (A/B)
   double bagen_nb = 0;          // gl_joint_optimization, persistent kernel: 0 auto, n workgroups per problem
-  double bagen_mode = 0;        //   0 / 2: the pipelined shape (a kernel per phase, host-enqueued cycles), 1: the persistent kernel k_ba_gen
+  double bagen_mode = 0;        //   0: by WINDOW size (never by B), 1: the persistent kernel k_ba_gen, 2: the pipelined shape, 3: persistent, whole batch in one launch (gmmloc_hip.h)
   double view_slot_lds = 0;     // gl_search2d: accepted-list records kept in LDS (0 = all that fit)
   double view_threads = 0;      //   0 auto, 256 / 1024
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)

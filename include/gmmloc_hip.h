@@ -98,11 +98,20 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *     found block b on XCC id b % 8 and (b) the frame's workgroups reported one and the same id in the launch's first
  *     (device-scope) exchange; a word that did not become visible would time the exchange out (ba_rendezvous_us) and send the
  *     frame to the follow-up kernel.  The default (0) uses device-scope stores only: the model-conforming path; same bits,
- *   bagen_mode (0): launch shape of gl_joint_optimization - 1 the persistent cooperative kernel (asynchronous), 2 the
- *     pipelined shape (a kernel per phase, cycles enqueued ahead, the call returns with the work complete), 0 by window
- *     size (the pipelined shape from 5 000 observations for up to 8 windows per call: 1.4 - 2 x less per Levenberg trial);
- *     same arithmetic, both held to the oracle; the two add their partial sums in different orders, so a window may take a
- *     different number of trials in each,
+ *   bagen_mode (0): launch shape of gl_joint_optimization.  A window's RESULT BITS and the call's BLOCKING BEHAVIOUR are a
+ *     function of the window shape (P, F, L, NOBS) and this option alone - never of B:
+ *       0  by window: the pipelined shape (a kernel per phase, cycles enqueued ahead; 1.4 - 2 x less per Levenberg trial) for
+ *          windows of >= 5 000 observations (NOBS), the persistent cooperative kernel below that;
+ *       1  the persistent kernel for every window: ASYNCHRONOUS on the context's stream (stream-capturable; the caller
+ *          synchronises).  Its workgroup count per window follows NOBS; a batch too large to keep B x that many workgroups
+ *          co-resident is launched in sub-batches, in stream order;
+ *       2  the pipelined shape for every window that fits it (P <= 22, P + F <= 32): BLOCKING - the call returns with the work
+ *          complete (it reads the count of unfinished windows back between chunks of cycles; not stream-capturable);
+ *       3  the persistent kernel with the whole batch in ONE launch and as many workgroups per window as stay co-resident:
+ *          the fastest form of large batches (round 3's default); asynchronous; the ONE mode in which a window's bits depend
+ *          on the batch size (the workgroup count decides the order of its partial sums).
+ *     Same arithmetic everywhere, every mode held to the oracle; the shapes add their partial sums in different orders, so a
+ *     window may take a different number of trials in each,
  *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
