@@ -226,11 +226,13 @@ def stub_bench(args, ranks):
         state["n"] += int(np.arange(1000).sum() > 0)
     dt = launch.timed_steps(step, args.steps, args.warmup, ranks)
     total = ranks.sum(float(state["n"]))
+    per_rank = ranks.gather(args.steps / max(ranks.last_own_dt, 1e-9))
     if ranks.rank == 0:
         print(json.dumps({"metric": "stub (launch plumbing test, no GPU work)", "value": total / dt, "unit": "steps/s",
                           "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
-                          "steps_run_all_ranks": total, "backend": ranks.backend}))
+                          "steps_run_all_ranks": total, "backend": ranks.backend, "ranks_in_group": ranks.group_size(),
+                          "per_rank_rate": per_rank}))
     ranks.close()
 
 
@@ -322,7 +324,10 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="the timed step only (what tools/profile_bench.sh profiles: the two-stream / sweep / class legs launch the same kernels)")
     ap.add_argument("--cpu-baseline-worker", nargs=2, metavar=("SEED", "BUDGET_S"), help=argparse.SUPPRESS)
-    ap.add_argument("--stub", choices=["gloo"], default=None, help=argparse.SUPPRESS)  # CPU test of the launch plumbing
+    # tests of the launch plumbing: "gloo" = the whole path on CPU with a stand-in step; "nccl-dry" = the REAL backend selection
+    # (Ranks("nccl"): set_device, init_process_group over RCCL, barrier / MAX / gather on device tensors) with the stand-in step -
+    # on a GPU node a rehearsal of the N-rank job without the workload, on a CPU node it must stop at the first device call
+    ap.add_argument("--stub", choices=["gloo", "nccl-dry"], default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(int(args.cpu_baseline_worker[0]), float(args.cpu_baseline_worker[1]))
@@ -331,12 +336,12 @@ def main():
     # --gpus N is the number of ranks.  Under a launcher (torchrun: RANK / WORLD_SIZE set) this process is one of them;
     # started plainly with N > 1 it starts the N ranks itself (one process per GPU, RCCL) and relays rank 0's line.
     if args.gpus > 1 and not launch.is_rank():
-        sys.exit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_gpus=args.stub is None))
-    ranks = launch.Ranks(args.stub or "nccl")
+        sys.exit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_gpus=args.stub != "gloo"))
+    ranks = launch.Ranks("gloo" if args.stub == "gloo" else "nccl")
     if ranks.world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n"
                          % (args.gpus, ranks.world, ranks.world))
-    ranks.init()
+    ranks.init(always=args.stub == "nccl-dry")
     if args.stub:
         stub_bench(args, ranks)
         return
@@ -378,6 +383,7 @@ def main():
 
     with torch.cuda.stream(ctx.stream):
         dt = launch.timed_steps(step, args.steps, args.warmup, ranks, before_timed=start_timers)
+    per_rank_rate = ranks.gather(B * args.steps / ranks.last_own_dt)  # each rank's own clock around its own steps (the headline uses the MAX)
     n_trials = float(trials.sum().item())  # (of the last timed step; the legs below reuse the buffers)
     n_outer = float(outer.sum().item())
     assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
@@ -476,6 +482,8 @@ def main():
             "value": frames_total / dt,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_in_group": ranks.group_size(),  # what the process group (RCCL) reports: == n_gpus, or the launch is not what it says
+            "per_rank_frames_per_s": per_rank_rate,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,

@@ -51,6 +51,7 @@ class Ranks:
         self.backend = backend
         self.dist = None
         self.device = None
+        self.last_own_dt = None  # timed_steps: this rank's own elapsed seconds (the barrier-to-barrier time is the MAX over ranks)
 
     def init(self, always=False):
         """Join the process group (world > 1, or always=True to run the collectives with one rank too)."""
@@ -94,6 +95,20 @@ class Ranks:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather(self, value):
+        """every rank's float, in rank order (all_gather)"""
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        if self.dist is None:
+            return [float(t.item())]
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def group_size(self):
+        """ranks the process group really has (what RCCL / gloo report, not what the command line said)"""
+        return int(self.dist.get_world_size()) if self.dist is not None else 1
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -113,5 +128,7 @@ def timed_steps(step, steps, warmup, ranks, before_timed=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    own = time.perf_counter() - t0  # this rank's own steps, before it waits for the others
     ranks.barrier()
+    ranks.last_own_dt = own
     return ranks.max(time.perf_counter() - t0)

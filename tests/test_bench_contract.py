@@ -107,3 +107,44 @@ def test_bench_line_contract_live():
     assert lat["speedup_vs_cpu_same_math_brute"] >= 50.0  # north-star latency target, against the same arithmetic
     if d["cpu_baseline"]["reference_algorithm"] is not None:
         assert lat["speedup_vs_cpu_reference_algorithm"] >= 50.0  # ... and against the reference's kd-tree algorithm
+
+
+def test_bench_gpus_n_walks_the_nccl_path_up_to_the_first_device_call(monkeypatch):
+    """Dress rehearsal of the first N > 1 run on a node without GPUs: with torch.cuda.device_count() faked to 2, the REAL argument
+    path (`bench.py --gpus 2`, no launcher) must spawn two ranks under torch.distributed.run that each take the nccl branch
+    (launch.Ranks("nccl").init) and stop at its first device call with the loud assertion - not fall back to anything."""
+    import torch
+    from gmmloc_amd import launch
+    if torch.cuda.is_available():
+        pytest.skip("node has a GPU: covered live by test_bench_nccl_dry_run_on_the_gpu_box")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    seen = {}
+    real_call = launch.subprocess.call
+
+    def call(cmd, env=None):
+        seen["cmd"] = cmd
+        r = launch.subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        seen["out"], seen["err"] = r.stdout, r.stderr
+        return r.returncode
+    monkeypatch.setattr(launch.subprocess, "call", call)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    rc = launch.spawn_ranks(2, os.path.join(ROOT, "bench.py"), ["--gpus", "2", "--steps", "2", "--warmup", "1", "--stub", "nccl-dry"], need_gpus=True)
+    monkeypatch.setattr(launch.subprocess, "call", real_call)
+    cmd = seen["cmd"]
+    # the driver's own command line, rank for rank
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert rc != 0 and not [l for l in seen["out"].split("\n") if l.startswith("{")]  # no line without GPUs
+    assert seen["err"].count("the HIP path needs a GPU") >= 2  # BOTH ranks reached Ranks("nccl").init()'s device check
+
+
+@pytest.mark.gpu
+def test_bench_nccl_dry_run_on_the_gpu_box():
+    """the same path live with the GPUs the box has (1 here): RCCL process group, barrier / MAX / gather on device tensors"""
+    import torch
+    n = max(1, min(torch.cuda.device_count(), 2))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _stub_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--stub", "nccl-dry"], env)
+    assert d["backend"] == "nccl" and d["n_gpus"] == n and d["ranks_in_group"] == n and len(d["per_rank_rate"]) == n
+    assert d["steps_run_all_ranks"] == n * (3 + 1)
