@@ -458,7 +458,7 @@ namespace gl {
 bool ba1_fast_supported(int L);
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
-                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch, const uint8_t* prior);
+                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch, const uint8_t* prior, const TrackFixed* fixed);
 
 // gl_track_frames_anchored with fixed observer key-frames (gl_ba_gen.hip: the general kernel does those)
 int track_frames_fixed(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
@@ -490,9 +490,12 @@ int launch_ba1(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm,
 // point; general kernel: trial points, chi2, levels (33 B); + per frame: 2 x 4 x 32 x 2 exchange words of the latency
 // shape, 12 doubles of the prior edge's inverse measurement, and for small batches the staging area of the latency shape's
 // results (points 24 B + association 4 B per point, pose 64 B per frame) (gl_ba_fast.hip)
-size_t ba1_scratch_bytes(int B, int L) {
+// F > 0 (fixed observer key-frames on the on-chip path): behind all that, per key-frame its pose {R, t} and per point and
+// key-frame the normalised observation, the octave word and the stale chi2 (96 + L x 36 bytes)
+size_t ba1_scratch_bytes(int B, int L, int F) {
   size_t n = (size_t)B * L * 36 + (size_t)B * (8192 + 8 + 96) + 512;
   if ((size_t)B * ((L + 255) / 256) <= 1024) n += (size_t)B * L * 28 + (size_t)B * 64 + 64;  // a batch the latency shape may take: its staging area
+  if (F > 0) n = ((n + 63) / 64) * 64 + (size_t)B * F * (96 + (size_t)L * 36) + 64;
   return n;
 }
 
@@ -500,7 +503,7 @@ size_t ba1_scratch_bytes(int B, int L) {
 
 static int track_frames_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm, int B, int M,
                              double* pose_dev, double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
-                             int32_t* assoc_dev, double* d2_dev, const uint8_t* prior_dev) {
+                             int32_t* assoc_dev, double* d2_dev, const uint8_t* prior_dev, const gl::TrackFixed* fixed = nullptr) {
   GL_REQUIRE(ctx && gmm && cam && prm, "null argument");
   if (B == 0 || M == 0) return GL_OK;
   GL_REQUIRE(B > 0 && M > 0, "bad B / M");
@@ -513,7 +516,7 @@ static int track_frames_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera
   // partial buffers come from the same context scratch, so carve everything from one block.
   // Layout: | assoc partials (used first, dead afterwards) ... reused by ba1 | d2 |
   void* scratch = nullptr;
-  const size_t ba_bytes = gl::ba1_scratch_bytes(B, M);
+  const size_t ba_bytes = gl::ba1_scratch_bytes(B, M, fixed ? fixed->F : 0);
   const bool use_grid = g->grid.enabled && c->opt.assoc_grid != 0;
   const size_t assoc_bytes =
       use_grid ? gl::assoc_index_scratch_bytes(g->K, (int)n, d2_dev != nullptr) : gl::assoc_scratch_bytes(g->K, (int)n);
@@ -529,9 +532,9 @@ static int track_frames_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera
     rc = gl::launch_assoc_brute(c, g, Xw_dev, (int)n, assoc_dev, d2);
   if (rc != GL_OK) return rc;
   // on-chip fast path (gl_ba_fast.hip) for M <= 2000; option ba_slow forces the general kernel
-  if (c->opt.ba_slow == 0 && gl::ba1_fast_supported(M))
+  if ((c->opt.ba_slow == 0 || fixed) && gl::ba1_fast_supported(M))
     return gl::launch_ba1_fast(c, g, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
-                               nullptr, nullptr, nullptr, scratch, prior_dev);
+                               nullptr, nullptr, nullptr, scratch, prior_dev, fixed);
   return gl::launch_ba1(c, g, cam, prm, B, M, pose_dev, prior_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2, 9.0,
                         nullptr, nullptr, nullptr, scratch);
 }
@@ -550,6 +553,13 @@ extern "C" int gl_track_frames_anchored(gl_ctx_t* ctx, const gl_gmm_t* gmm, cons
   GL_REQUIRE(anchor->F >= 0 && anchor->F <= GL_TRACK_MAX_FIXED, "bad number of fixed observer key-frames");
   if (anchor->F == 0)
     return track_frames_impl(ctx, gmm, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2_dev, anchor->prior_dev);
+  GL_REQUIRE(anchor->fixed_pose_dev && anchor->fixed_obs_dev && anchor->fixed_oct_dev, "null buffer of the fixed observer key-frames");
+  // up to 4 fixed observers on frames of up to 2 000 points: on chip, inside the per-frame refine (gl_ba_fast.hip: the kFixed
+  // instances); beyond that - or with option ba_fixed_pack = 1 (A/B, tests) - packed into flat problems for the general kernel
+  if (ctx && anchor->F <= 4 && gl::ba1_fast_supported(M) && gl::C(ctx)->opt.ba_fixed_pack == 0 && gl::C(ctx)->opt.ba_slow == 0) {
+    const gl::TrackFixed fx{anchor->F, anchor->fixed_pose_dev, anchor->fixed_obs_dev, anchor->fixed_oct_dev, anchor->fixed_erase_dev};
+    return track_frames_impl(ctx, gmm, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2_dev, anchor->prior_dev, &fx);
+  }
   return gl::track_frames_fixed(ctx, gmm, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, assoc_dev, d2_dev, anchor);
 }
 

@@ -21,6 +21,17 @@ struct PrepView {
   int32_t* pfl;
   int32_t* assoc_p;
 };
+// Fixed observer key-frames of an anchored launch (kFixed instances of the refine), written by k_ba1_prep into the launch's
+// scratch: the key-frames' poses as {R, t}; per point and key-frame - SoA by key-frame, the frame's permuted point order -
+// the normalised observation, octave | stereo << 4 (-1: not observed) and the edge's stale chi2; ferase: the caller's output.
+struct FixedV {
+  int F;
+  const double* fRt;   // B x F x 12
+  const double* fobn;  // B x F x L x 3
+  const int32_t* foct; // B x F x L
+  double* chif;        // B x F x L
+  uint8_t* ferase;     // B x L x F (caller's order) or null
+};
 __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
   PrepView v;
   const size_t n = (size_t)B * L;
@@ -45,7 +56,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
                                                     const double* __restrict__ d2_all, double* __restrict__ scratch,
                                                     unsigned long long* __restrict__ xwords, int* __restrict__ xctl, int nxw,
                                                     const double* __restrict__ pose_all, const uint8_t* __restrict__ prior_all,
-                                                    double* __restrict__ prior_mi) {
+                                                    double* __restrict__ prior_mi, int F, const double* __restrict__ fpose_all,
+                                                    const double* __restrict__ fobs_all, const int32_t* __restrict__ foct_all, double* __restrict__ fRt,
+                                                    double* __restrict__ fobn, int32_t* __restrict__ foct, double* __restrict__ chif) {
   __shared__ int cnt[PREP_C][PREP_T / 64];  // non-degenerate-component points per (round, wave)
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (f >= B) return;
@@ -61,6 +74,16 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
     for (int i = 0; i < 9; ++i) prior_mi[(size_t)f * 12 + i] = Ri[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) prior_mi[(size_t)f * 12 + 9 + i] = Ti.t[i];
+  }
+  if (F > 0 && tid < F) {  // the fixed key-frames' poses T_cw as {R, t}
+    const SE3 T = se3_load(fpose_all + ((size_t)f * F + tid) * 7);
+    double Rm[9];
+    qtoR(T.r, Rm);
+    double* o = fRt + ((size_t)f * F + tid) * 12;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = Rm[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[9 + i] = T.t[i];
   }
   const size_t gbase = (size_t)f * L;
   const PrepView pv = prep_view(scratch, B, L);
@@ -118,6 +141,16 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
       pv.gobn[gp * 3] = (obs_all[g * 3] - k.cx) * ifx;
       pv.gobn[gp * 3 + 1] = (obs_all[g * 3 + 1] - k.cy) * ify;
       pv.gobn[gp * 3 + 2] = (obs_all[g * 3 + 2] - k.cx) * ifx;
+      for (int kf = 0; kf < F; ++kf) {  // the point's observations by the fixed key-frames, by key-frame, in the permuted order
+        const size_t src = g * F + kf, dst = ((size_t)f * F + kf) * L + lp;
+        const int fo = fl_[j] ? foct_all[src] : -1;
+        const double u = fobs_all[src * 3], v = fobs_all[src * 3 + 1], ur = fobs_all[src * 3 + 2];
+        fobn[dst * 3] = (u - k.cx) * ifx;
+        fobn[dst * 3 + 1] = (v - k.cy) * ify;
+        fobn[dst * 3 + 2] = (ur - k.cx) * ifx;
+        foct[dst] = fo < 0 ? -1 : ((fo & 7) | (!(ur < 0) ? 16 : 0));
+        chif[dst] = 0.0;
+      }
     }
 #pragma unroll
     for (int w = 0; w < PREP_T / 64; ++w)
@@ -133,6 +166,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -140,6 +174,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafd1000  // 2 frames per CU
 #define GL_BAF_MCAP 1000
@@ -147,6 +182,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -154,6 +190,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafd2000  // 1 frame per CU
 #define GL_BAF_MCAP 2000
@@ -161,6 +198,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -168,6 +206,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafs  // SPREAD (latency shape), exact step
 #define GL_BAF_MCAP 256
@@ -175,6 +214,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -182,6 +222,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 // fp32-cached point step (option ba_step32): the SPREAD kernel and the largest DENSE class
 #define GL_BAF_NS bafs32  // 
@@ -190,6 +231,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 1
 #define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -197,6 +239,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafd2000s32  // 
 #define GL_BAF_MCAP 2000
@@ -204,6 +247,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 1
 #define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -211,6 +255,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 // anchored instances (gl_track_frames_anchored: prior edge on the frame's pose, or fixed pose), exact step
 #define GL_BAF_NS bafd496p  // 
@@ -219,6 +264,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -226,6 +272,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafd1000p  // (992 points: two frames per CU with the 512 bytes of the prior edge's records)
 #define GL_BAF_MCAP 992
@@ -233,6 +280,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -240,6 +288,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafd2000p  // 
 #define GL_BAF_MCAP 2000
@@ -247,6 +296,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -254,6 +304,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafsp  // 
 #define GL_BAF_MCAP 256
@@ -261,6 +312,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #define GL_BAF_SPREAD 1
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
@@ -268,6 +320,56 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_SPREAD
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
+
+// anchored instances WITH fixed observer key-frames (F = 1 .. 4; the prior edge / fixed pose stays a per-frame flag), batch shape
+#define GL_BAF_NS bafd496f
+#define GL_BAF_MCAP 496
+#define GL_BAF_NW 2
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
+
+#define GL_BAF_NS bafd1000f  // (984 points: two frames per CU with the prior edge's records and the key-frames' poses)
+#define GL_BAF_MCAP 984
+#define GL_BAF_NW 4
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
+
+#define GL_BAF_NS bafd2000f
+#define GL_BAF_MCAP 2000
+#define GL_BAF_NW 8
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 1
+#define GL_BAF_FIXED 1
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
 
 namespace {
 // HW_REG_XCC_ID (hwreg 20, 4 bits): the XCD the wave runs on
@@ -314,7 +416,7 @@ static void canon_order(int L, int* G, int* S) {
 }
 
 typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*, int*, long long, int, const int32_t*, const uint8_t*, const double*, double*, int, int32_t*, int32_t*);
+                          unsigned long long*, int*, long long, int, const int32_t*, const uint8_t*, const double*, double*, int, int32_t*, int32_t*, FixedV);
 
 struct BafArgs {
   BaK k;
@@ -338,22 +440,27 @@ struct BafArgs {
   double* stage = nullptr;           // latency shape: staging area of the results {points | pose | association}
   int nb_prev = 0;                   // follow-up launch: workgroups per frame of the latency-shape launch before it
   int32_t* counters = nullptr;       // the context's device counters (gl_ctx_counter_read)
+  FixedV fx = {0, nullptr, nullptr, nullptr, nullptr, nullptr};  // fixed observer key-frames (F > 0: the kFixed instances)
 };
 
 // one workgroup of G waves per frame; LDS class by stride (4 / 2 / 1 frames per CU)
 static int launch_dense(Ctx* c, BafArgs& a) {
-  const bool s32 = c->opt.ba_step32 != 0 && !a.prior;  // (the anchored instances exist with the exact step only)
-  const int mid = a.prior ? 992 : 1000;                // (the anchored middle class gives 8 points for the prior edge's LDS records)
+  const bool fixed = a.fx.F > 0;
+  const bool anch = a.prior || fixed;                  // (the fixed-observer instances carry the anchored code: the prior is a per-frame flag)
+  const bool s32 = c->opt.ba_step32 != 0 && !anch;     // (the anchored instances exist with the exact step only)
+  // (the anchored middle classes give 8 / 16 points for the prior edge's LDS records and the key-frames' poses)
+  const int mid = fixed ? 984 : a.prior ? 992 : 1000;
   const int cap = s32 ? 2000 : (a.L <= 496 ? 496 : a.L <= mid ? mid : 2000);
   const BafKernel kern = s32 ? bafd2000s32::k_ba1_fast
+                         : fixed ? (cap == 496 ? bafd496f::k_ba1_fast : cap == 984 ? bafd1000f::k_ba1_fast : bafd2000f::k_ba1_fast)
                          : a.prior ? (cap == 496 ? bafd496p::k_ba1_fast : cap == 992 ? bafd1000p::k_ba1_fast : bafd2000p::k_ba1_fast)
                                    : (cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast);
-  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap <= 1000 ? 4 : 8) * 32 + 64 + 40 + (a.prior ? 64 + (cap == 496 ? 108 : 0) : 0)) * sizeof(double);
+  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap <= 1000 ? 4 : 8) * 32 + 64 + 40 + (anch ? 64 + (cap == 496 ? 108 : 0) : 0) + (fixed ? 48 : 0)) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;
   kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior, a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters);
+                                          a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior, a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -392,7 +499,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
   kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters);
+                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }
@@ -402,9 +509,20 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
 // (option ba_shape forces one: 0 DENSE, 1 SPREAD).
 int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int L, double* pose,
                     double* pts, const double* obs, const int32_t* oct, int32_t* assoc, const double* d2, double gate,
-                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch, const uint8_t* prior) {
+                    uint8_t* dropped, uint8_t* erase, int32_t* iters, void* scratch, const uint8_t* prior, const TrackFixed* fixed) {
   BafArgs a;
   a.prior = prior;
+  const int F = fixed ? fixed->F : 0;
+  double *fRt = nullptr, *fobn = nullptr, *chif = nullptr;
+  int32_t* foct = nullptr;
+  if (F > 0) {  // the fixed-observer records sit behind everything else of the launch's scratch (ba1_scratch_bytes)
+    char* fs = (char*)scratch + ((ba1_scratch_bytes(B, L, 0) + 63) / 64) * 64;
+    fRt = (double*)fs;
+    fobn = fRt + (size_t)B * F * 12;
+    chif = fobn + (size_t)B * F * L * 3;
+    foct = (int32_t*)(chif + (size_t)B * F * L);
+    a.fx = FixedV{F, fRt, fobn, foct, chif, fixed->erase};
+  }
   a.k = make_bak(cam, prm, gate);
   a.gm = GmmDev{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   a.B = B;
@@ -426,6 +544,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD; checked in launch_spread)
   if (c->opt.ba_shape == 0) spread = false;
   if (c->opt.ba_shape == 1) spread = true;  // forced (tests); a shape that does not fit the device still goes DENSE
+  if (F > 0) spread = false;                // (fixed observers: batch-shaped instances only)
   {  // set-up: gate, flags, normalised observations, the order the refine walks each frame in - and, before a latency-shape
      // launch, the zeros its exchange words start from
     TimerScope ts(c, GL_TIMER_BA_PREP);
@@ -436,7 +555,8 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
     a.prior_mi = (double*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64 + (size_t)B * (8192 + 8) + 64);
     if (spread) a.stage = (double*)(a.prior_mi + (size_t)B * 12);  // {points B x L x 3 | pose B x 8 | association B x L}
     k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch, xw, xw ? (int*)(xw + (size_t)B * nxw) : nullptr, nxw,
-                                            pose, prior, (double*)a.prior_mi);
+                                            pose, prior, (double*)a.prior_mi, F, F ? fixed->pose : nullptr, F ? fixed->obs : nullptr,
+                                            F ? fixed->oct : nullptr, fRt, fobn, foct, chif);
   }
   GL_HIP(hipGetLastError());
   TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper

@@ -1,4 +1,4 @@
-// (included by gl_ba_fast.hip once per instance: GL_BAF_NS / GL_BAF_MCAP / GL_BAF_NW / GL_BAF_SPREAD / GL_BAF_STEP32 / GL_BAF_PRIOR)
+// (included by gl_ba_fast.hip once per instance: GL_BAF_NS / GL_BAF_MCAP / GL_BAF_NW / GL_BAF_SPREAD / GL_BAF_STEP32 / GL_BAF_PRIOR / GL_BAF_FIXED)
 // On-chip fast path of the single-pose structure-constrained refinement (same algorithm and control flow as
 // k_ba1 in gl_ba.hip, which stays as the general / large-M path and as the A/B reference), M <= 2000 points.
 //
@@ -53,6 +53,11 @@ constexpr bool kPrior = true;   // instance with the gauge anchor of the pose (p
 #else                           // carry none of its code, so their register allocation is that of the unanchored refine
 constexpr bool kPrior = false;
 #endif
+#if GL_BAF_FIXED
+constexpr bool kFixed = true;   // instance with fixed observer key-frames (gl_track_frames_anchored, F = 1 .. 4): further reprojection
+#else                           // edges of the frame's points with FIXED pose vertices (localization_opt.cpp:491-516, 706-760)
+constexpr bool kFixed = false;
+#endif
 constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of this LDS class has at most
 constexpr int NRED = kSpread ? 1 : NWC;    // group totals kept in LDS (a SPREAD workgroup is ONE group)
 constexpr int TSP = 256;                   // SPREAD: threads of a workgroup = the <= 4 slot waves of its group
@@ -91,7 +96,10 @@ __device__ unsigned long long g_prof_w[64 * 8 * 4];  // [trial < 64][wave][marke
 // F_AR / F_AG: the point's reprojection / GMM edge is ACTIVE (exists, level 0) - derived bits, refreshed whenever the
 // levels change (fw_activity), so that a pass tests one mask instead of re-deriving them per point and trial
 // (the values of the first four and the octave at bits 8..10 are what k_ba1_prep writes: gl_ba_fast.hip)
-enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32, F_AR = 64, F_AG = 128 };
+// (fixed-observer instances: bit 11 + k = the point's edge to fixed key-frame k is INACTIVE - not observed, or at level 1 -, F_AF =
+// some fixed edge of the point is active; bits 8..10 hold the octave)
+enum { F_EXISTS = 1, F_STEREO = 2, F_ASSOC = 4, F_DEG = 8, F_LEVR = 16, F_LEVG = 32, F_AR = 64, F_AG = 128, F_OFFF = 1 << 11, F_AF = 1 << 15 };
+constexpr int kMaxFixed = 4;  // fixed observer key-frames the on-chip path takes (more: the general kernel, gl_ba_gen.hip)
 
 // a + b that is never contracted with a multiplication feeding it: every term of a canonical sum is rounded on
 // its own, whichever kernel adds it (this file is compiled with contraction allowed)
@@ -222,6 +230,14 @@ struct Lds {      // per-frame state, SoA over MCAP points (index = local point 
   // 24 uniform constants: [0..7] sx = fx^2 / sigma^2 and [8..15] sy = fy^2 / sigma^2 per pyramid octave (the residuals
   // are kept in NORMALISED image coordinates, see reproj_n), [16..19] Huber {delta, delta^2} mono / stereo
   double* stab;
+  // fixed observer key-frames (kFixed): their poses {R (9), t (3)} x F in LDS; per point and key-frame, in the launch's scratch
+  // (SoA by key-frame, the frame's permuted point order): normalised observation, octave | stereo << 4 (-1: none), and the
+  // stale chi2 of the edge (its Huber weight rho' between the two passes of a trial, like `chir`)
+  double* frt;
+  const double* gfobn;
+  const int32_t* gfoct;
+  double* gchif;
+  int F, Lf;
 };
 // per-point flag bits + octave (bits 8..10) live in REGISTERS: 16 bits per point slot of the thread
 typedef unsigned long long FlagW;
@@ -232,7 +248,8 @@ GL_DEV void fw_activity(FlagW& fw, int i) {
   int act = 0;
   if ((fl & F_EXISTS) && !(fl & F_LEVR)) act |= F_AR;
   if ((fl & F_EXISTS) && (fl & F_ASSOC) && !(fl & F_LEVG)) act |= F_AG;
-  fw = (fw & ~((FlagW)(F_AR | F_AG) << (16 * i))) | ((FlagW)act << (16 * i));
+  if (kFixed && (fl & F_EXISTS) && ((fl / F_OFFF) & 15) != 15) act |= F_AF;
+  fw = (fw & ~((FlagW)(F_AR | F_AG | F_AF) << (16 * i))) | ((FlagW)act << (16 * i));
 }
 
 // the canonical order of a frame of stride L and this thread's place in it
@@ -283,6 +300,23 @@ GL_DEV Jpi jpi_n(const double* q, double iz, double bn) {
   return J;
 }
 
+// Hc = R Hg R^T (sym6): a point block from the world into the camera frame
+GL_DEV void rot_sym(const double* R, const double* Hg, double* Hc) {
+  double RH[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    RH[i * 3 + 0] = R[i * 3] * Hg[0] + R[i * 3 + 1] * Hg[1] + R[i * 3 + 2] * Hg[2];
+    RH[i * 3 + 1] = R[i * 3] * Hg[1] + R[i * 3 + 1] * Hg[3] + R[i * 3 + 2] * Hg[4];
+    RH[i * 3 + 2] = R[i * 3] * Hg[2] + R[i * 3 + 1] * Hg[4] + R[i * 3 + 2] * Hg[5];
+  }
+  Hc[0] = RH[0] * R[0] + RH[1] * R[1] + RH[2] * R[2];
+  Hc[1] = RH[0] * R[3] + RH[1] * R[4] + RH[2] * R[5];
+  Hc[2] = RH[0] * R[6] + RH[1] * R[7] + RH[2] * R[8];
+  Hc[3] = RH[3] * R[3] + RH[4] * R[4] + RH[5] * R[5];
+  Hc[4] = RH[3] * R[6] + RH[4] * R[7] + RH[5] * R[8];
+  Hc[5] = RH[6] * R[6] + RH[7] * R[7] + RH[8] * R[8];
+}
+
 // GMM edge of a NON-degenerate component (rare): EdgePt2Gaussian, e = L^T d, J = L^T, so
 // J^T J = L L^T (precomputed per component, world frame), b = -L L^T d, chi2 = d^T L L^T d.
 GL_DEV double gmm_nondeg(const GmmDev& gm, int a, const double* R, const double* p, double* Hc, double* bc) {
@@ -298,22 +332,7 @@ GL_DEV double gmm_nondeg(const GmmDev& gm, int a, const double* R, const double*
 #pragma unroll
     for (int i = 0; i < 3; ++i) bc[i] = -(R[i * 3] * Hd[0] + R[i * 3 + 1] * Hd[1] + R[i * 3 + 2] * Hd[2]);
   }
-  if (Hc) {
-    // Hc = R Hg R^T
-    double RH[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      RH[i * 3 + 0] = R[i * 3] * Hg[0] + R[i * 3 + 1] * Hg[1] + R[i * 3 + 2] * Hg[2];
-      RH[i * 3 + 1] = R[i * 3] * Hg[1] + R[i * 3 + 1] * Hg[3] + R[i * 3 + 2] * Hg[4];
-      RH[i * 3 + 2] = R[i * 3] * Hg[2] + R[i * 3 + 1] * Hg[4] + R[i * 3 + 2] * Hg[5];
-    }
-    Hc[0] = RH[0] * R[0] + RH[1] * R[1] + RH[2] * R[2];
-    Hc[1] = RH[0] * R[3] + RH[1] * R[4] + RH[2] * R[5];
-    Hc[2] = RH[0] * R[6] + RH[1] * R[7] + RH[2] * R[8];
-    Hc[3] = RH[3] * R[3] + RH[4] * R[4] + RH[5] * R[5];
-    Hc[4] = RH[3] * R[6] + RH[4] * R[7] + RH[5] * R[8];
-    Hc[5] = RH[6] * R[6] + RH[7] * R[7] + RH[8] * R[8];
-  }
+  if (Hc) rot_sym(R, Hg, Hc);
   return chi;
 }
 
@@ -322,7 +341,7 @@ struct PtCtx {
   int l, ll, fl, asc;  // frame-local point index, LDS index, flags, non-degenerate component (or -1)
   double sx, sy;       // fx^2 / sigma^2, fy^2 / sigma^2 of the point's octave
   double ob[3], nd[4], p[3];
-  bool ar, ag;
+  bool ar, ag, af;
 };
 
 // Huber weight of the point's reprojection edge from its un-robustified chi2 (delta by edge type, LDS table)
@@ -407,6 +426,114 @@ GL_DEV double gmm_chi2_fast(double lm, const GmmDev& gm, const double* nd, int f
     return eg * (lm * eg);
   }
   return gmm_nondeg(gm, asc, nullptr, p, nullptr, nullptr);
+}
+
+// ---- fixed observer key-frames (kFixed instances) --------------------------------------------------------------------
+// The reference's structure BA holds the local map points with the OTHER key-frames that observe them, as fixed pose vertices
+// (localization_opt.cpp:491-516; EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ with Huber, :706-760).  Such an edge touches the
+// point's block and right-hand side only - never the reduced pose system directly.  It is evaluated in its key-frame's camera
+// (q_f = R_f p + t_f, the normalised-coordinate residual of reproj_n), its Jacobian rows are taken to the WORLD frame
+// (g = j R_f: R_f is constant for the whole kernel, in LDS), summed there over the point's key-frames and rotated into the
+// current camera frame once per point: D += R (sum w g g^T) R^T, b += R (sum w e g).  tools/emul_fixed.py replays this on the
+// host against the oracle's joint_optimization(P = 1, F fixed).
+struct FxE {
+  double e[3], chi, sx, sy;
+  double g[9];  // Jacobian rows in the world frame
+  bool stereo;
+};
+// edge (point l, key-frame k) at world point p; rows: also the Jacobian
+GL_DEV bool fixed_eval(const Uni& U, const Lds& D, int k, int l, const double* p, bool rows, FxE& E) {
+  const int oc = D.gfoct[(size_t)k * D.Lf + l];
+  const double* Rf = D.frt + k * 12;
+  double q[3], ob[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) ob[j] = D.gfobn[((size_t)k * D.Lf + l) * 3 + j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) q[j] = fma(Rf[j * 3], p[0], fma(Rf[j * 3 + 1], p[1], fma(Rf[j * 3 + 2], p[2], Rf[9 + j])));
+  E.stereo = (oc & 16) != 0;
+  E.sx = D.stab[oc & 7];
+  E.sy = D.stab[8 + (oc & 7)];
+  double iz;
+  E.chi = reproj_n(q, ob, E.stereo, U.bn, E.sx, E.sy, E.e, iz);
+  if (rows) {
+    const Jpi J = jpi_n(q, iz, U.bn);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      E.g[j] = fma(iz, Rf[j], J.c0 * Rf[6 + j]);
+      E.g[3 + j] = fma(iz, Rf[3 + j], J.c1 * Rf[6 + j]);
+      E.g[6 + j] = fma(iz, Rf[j], J.c2 * Rf[6 + j]);
+    }
+  }
+  return true;
+}
+// sum over the point's active fixed edges of w e g (-> bw) and, with Hw, of w g g^T (world frame); rho' of every edge comes
+// from (keep_rho < 0) / goes to (> 0) its stale-chi2 cell; returns the robustified chi2
+GL_DEV double fixed_sum(const Uni& U, const Lds& D, const PtCtx& c, bool robust, double* Hw, double* bw, int keep_rho) {
+  double sum = 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bw[j] = 0.0;
+  if (Hw) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Hw[j] = 0.0;
+  }
+#pragma unroll 1
+  for (int k = 0; k < D.F; ++k) {
+    if (c.fl & (F_OFFF << k)) continue;
+    FxE E;
+    fixed_eval(U, D, k, c.l, c.p, true, E);
+    double rho0 = E.chi, rho1 = 1.0;
+    double* cell = D.gchif + (size_t)k * D.Lf + c.l;
+    if (keep_rho < 0) {
+      rho1 = *cell;
+    } else {
+      if (robust) huber_pt(D, E.stereo, E.chi, rho0, rho1);
+      if (keep_rho > 0) *cell = rho1;
+    }
+    sum += rho0;
+    const double w[3] = {rho1 * E.sx, rho1 * E.sy, E.stereo ? rho1 * E.sx : 0.0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double* g = E.g + r * 3;
+      const double wg[3] = {w[r] * g[0], w[r] * g[1], w[r] * g[2]};
+      if (Hw) {
+        Hw[0] = fma(wg[0], g[0], Hw[0]);
+        Hw[1] = fma(wg[0], g[1], Hw[1]);
+        Hw[2] = fma(wg[0], g[2], Hw[2]);
+        Hw[3] = fma(wg[1], g[1], Hw[3]);
+        Hw[4] = fma(wg[1], g[2], Hw[4]);
+        Hw[5] = fma(wg[2], g[2], Hw[5]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bw[j] = fma(E.e[r], wg[j], bw[j]);
+    }
+  }
+  return sum;
+}
+// pass A / lambda init: the fixed edges into the point's block and right-hand side (camera frame)
+GL_DEV double fixed_lin(const Uni& U, const Lds& D, const Pose& P, const PtCtx& c, bool robust, Lin& o, bool keep_rho) {
+  double Hw[6], bw[3], Hc[6];
+  const double sum = fixed_sum(U, D, c, robust, Hw, bw, keep_rho ? 1 : 0);
+  rot_sym(P.R, Hw, Hc);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) o.D[j] += Hc[j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) o.b[j] += fma(P.R[j * 3], bw[0], fma(P.R[j * 3 + 1], bw[1], P.R[j * 3 + 2] * bw[2]));
+  return sum;
+}
+// pass B, evaluation half: robustified chi2 of the fixed edges at the trial point; the stale chi2 cells are rewritten
+GL_DEV double fixed_chi(const Uni& U, const Lds& D, const PtCtx& c, const double* pn, bool robust) {
+  double sum = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < D.F; ++k) {
+    if (c.fl & (F_OFFF << k)) continue;
+    FxE E;
+    fixed_eval(U, D, k, c.l, pn, false, E);
+    D.gchif[(size_t)k * D.Lf + c.l] = E.chi;
+    double r0 = E.chi, r1;
+    if (robust) huber_pt(D, E.stereo, E.chi, r0, r1);
+    sum += r0;
+  }
+  return sum;
 }
 
 // The damped point block D = A + (GMM block) + lambda I is factorised, D = L Delta L^T (unpivoted: D is symmetric positive
@@ -1111,7 +1238,7 @@ GL_DEV void restore_point(const Lds& D, int ll) {
 GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gobn, const double* __restrict__ gnd,
                     const int32_t* __restrict__ gassoc, int i, PtCtx& c) {
   c.fl = fw_get(fw, i);
-  if (!(c.fl & (F_AR | F_AG))) return false;
+  if (!(c.fl & (F_AR | F_AG | F_AF))) return false;
   c.l = mp.base + mp.step * i;
   c.ll = mp.lbase + mp.step * i;
 #pragma unroll
@@ -1122,6 +1249,7 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
   for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];  // plane normal n and n . mean: the map's table, by component
   c.ar = c.fl & F_AR;
   c.ag = c.fl & F_AG;
+  c.af = kFixed && (c.fl & F_AF);
   const int oc = (c.fl >> 8) & 7;
   c.sx = D.stab[oc];
   c.sy = D.stab[8 + oc];
@@ -1165,6 +1293,7 @@ GL_DEV bool load_pt_const(const Lds& D, const Map& mp, FlagW fw, const PtConst& 
   for (int j = 0; j < 4; ++j) c.nd[j] = pc.nd[j];
   c.ar = c.fl & F_AR;
   c.ag = c.fl & F_AG;
+  c.af = false;  // (the fixed-observer instances are batch-shaped only)
   const int oc = (c.fl >> 8) & 7;
   c.sx = D.stab[oc];
   c.sy = D.stab[8 + oc];
@@ -1181,6 +1310,7 @@ template <class Sink>
 GL_DEV void pt_lambda_init(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double& md, const Sink& sk) {
   Lin o;
   lin_fast(U, gm, D, P, c, robust, o);
+  if (kFixed && c.af) fixed_lin(U, D, P, c, robust, o, false);
   const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -1203,6 +1333,10 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
                       const Sink& sk) {
   Lin o;
   lin_fast(U, gm, D, P, c, robust, o);
+  if (kFixed) {
+    const double chi_f = c.af ? fixed_lin(U, D, P, c, robust, o, true) : 0.0;
+    sk.put(27, (o.rho0_r + o.chi_g) + chi_f);
+  } else
   sk.put(27, o.rho0_r + o.chi_g);
   double Df[6], u[3];
   point_solve_fast(o, lambda, Df, u);
@@ -1304,6 +1438,12 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
         for (int j = 0; j < 3; ++j) rhs[j] += bc[j];
       }
     }
+    if (kFixed && c.af) {  // the fixed edges do not couple to the pose step: their part of b, at the linearisation point
+      double bw[3];
+      fixed_sum(U, D, c, false, nullptr, bw, -1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rhs[j] += fma(P.R[j * 3], bw[0], fma(P.R[j * 3 + 1], bw[1], P.R[j * 3 + 2] * bw[2]));
+    }
     double Df[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) Df[j] = D.un[j * MCAP + c.ll];
@@ -1333,6 +1473,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
     chi = r0;
   }
   if (c.ag) chi += gmm_chi2_fast(U.lm, gm, c.nd, c.fl, c.asc, pn);
+  if (kFixed && c.af) chi += fixed_chi(U, D, c, pn, robust);
   sk.put(1, chi);
 }
 
@@ -1387,7 +1528,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     for (int i = 0; i < ns; ++i) {
       const int fl = fw_get(fw, i);
       if (fl & F_AR) acc[0] += 1.0;
-      if (fl & (F_AR | F_AG)) acc[1] += 1.0;
+      if (fl & (F_AR | F_AG | F_AF)) acc[1] += 1.0;
     }
   }
   reduce2<2>(acc, R, C);
@@ -1526,7 +1667,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
         for (int i = 0; i < ns; ++i) {  // discardTop: restore the backed-up points
-          if (fw_get(fw, i) & (F_AR | F_AG)) restore_point(D, mp.lbase + mp.step * i);
+          if (fw_get(fw, i) & (F_AR | F_AG | F_AF)) restore_point(D, mp.lbase + mp.step * i);
         }
       }
       qmax++;
@@ -1551,7 +1692,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted,
                                                   const int32_t* __restrict__ oct_all,
                                                   const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi, double* __restrict__ stage, int nb_prev,
-                                                  int32_t* __restrict__ counters, int32_t* __restrict__ outer_out) {
+                                                  int32_t* __restrict__ counters, int32_t* __restrict__ outer_out, FixedV fxv) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1567,8 +1708,14 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   // during pass B and before the first reduction -, the transpose rows pass B does not use on the latency shape, 108 doubles
   // of its own in the small class (which has LDS to spare)
   constexpr int kPriorWorkOwn = (kPrior && !kSpread && NWC < 4) ? 108 : 0;
-  R.tb = prec + (kPrior ? 64 : 0) + kPriorWorkOwn;  // SPREAD: 29 x TSP
+  D.frt = prec + (kPrior ? 64 : 0) + kPriorWorkOwn;  // fixed-observer instances: F x 12, the key-frames' poses {R, t}
+  R.tb = D.frt + (kFixed ? kMaxFixed * 12 : 0);      // SPREAD: 29 x TSP
   double* const pwork = kSpread ? R.tb + 2 * TSP : (NWC >= 4 ? R.red : prec + 64);
+  D.F = 0;
+  D.Lf = L;
+  D.gfobn = nullptr;
+  D.gfoct = nullptr;
+  D.gchif = nullptr;
   R.S = S;
   FlagW fw = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1638,6 +1785,13 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   const int32_t* gperm = pv.perm + gbase;
   const int32_t* gassoc = pv.assoc_p + gbase;
   const Uni U{uni(k.bf / k.fx), uni(k.ba_lambda2)};
+  if (kFixed) {  // this frame's slices of the fixed-observer records (k_ba1_prep), its key-frames' poses into LDS
+    D.F = fxv.F;
+    D.gfobn = fxv.fobn + (size_t)f * fxv.F * L * 3;
+    D.gfoct = fxv.foct + (size_t)f * fxv.F * L;
+    D.gchif = fxv.chif + (size_t)f * fxv.F * L;
+    if (tid < fxv.F * 12) D.frt[tid] = fxv.fRt[(size_t)f * fxv.F * 12 + tid];
+  }
   for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
   if (tid < 16) R.red2[tid] = 0.0;
   if (tid == 0) {
@@ -1655,6 +1809,11 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
       for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = pts_io[g * 3 + j];
       D.chir[ll] = 0.0;
       fw_or(fw, i, pv.pfl[gbase + l]);
+      if (kFixed) {  // edges the point does not have (not observed by that key-frame / no such key-frame) count as inactive
+#pragma unroll
+        for (int kf = 0; kf < kMaxFixed; ++kf)
+          if (kf >= D.F || D.gfoct[(size_t)kf * L + l] < 0) fw_or(fw, i, F_OFFF << kf);
+      }
       fw_activity(fw, i);
     }
   }
@@ -1721,6 +1880,16 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
         if (!(fl & F_EXISTS)) continue;
         const double z = P.R[6] * D.sp[ll] + P.R[7] * D.sp[MCAP + ll] + P.R[8] * D.sp[2 * MCAP + ll] + P.t[2];
         if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) fw_or(fw, i, F_LEVR);
+        if (kFixed) {  // the fixed observers' edges: the same gate on their stale chi2, the depth in THEIR camera
+#pragma unroll 1
+          for (int kf = 0; kf < D.F; ++kf) {
+            const int oc = D.gfoct[(size_t)kf * L + l];
+            if (oc < 0) continue;
+            const double* Rf = D.frt + kf * 12;
+            const double zf = Rf[6] * D.sp[ll] + Rf[7] * D.sp[MCAP + ll] + Rf[8] * D.sp[2 * MCAP + ll] + Rf[11];
+            if (D.gchif[(size_t)kf * L + l] > ((oc & 16) ? 7.815 : 5.991) || !(zf > 0.0)) fw_or(fw, i, F_OFFF << kf);
+          }
+        }
       }
       fw_activity(fw, i);
     }
@@ -1753,6 +1922,19 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
       if (D.chir[ll] > ((fl & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) er = 1;
 #pragma unroll
       for (int j = 0; j < 3; ++j) pts_out[g * 3 + j] = p[j];
+    }
+    if (kFixed && fxv.ferase) {  // observations of the fixed key-frames the reference would erase (:855-879): stale chi2, fresh depth
+#pragma unroll 1
+      for (int kf = 0; kf < D.F; ++kf) {
+        uint8_t fe = 0;
+        const int oc = D.gfoct[(size_t)kf * L + l];
+        if ((fl & F_EXISTS) && oc >= 0) {
+          const double* Rf = D.frt + kf * 12;
+          const double zf = Rf[6] * D.sp[ll] + Rf[7] * D.sp[MCAP + ll] + Rf[8] * D.sp[2 * MCAP + ll] + Rf[11];
+          if (D.gchif[(size_t)kf * L + l] > ((oc & 16) ? 7.815 : 5.991) || !(zf > 0.0)) fe = 1;
+        }
+        fxv.ferase[g * D.F + kf] = fe;
+      }
     }
     if (dropped_all) dropped_all[g] = dr;
     if (erase_all) erase_all[g] = er;

@@ -85,6 +85,7 @@ struct Options {
   double ba_shape = -1;         // gl_track_frames refine: -1 auto, 0 one workgroup per frame, 1 one point per thread
   double ba_step32 = 0;         // 1: point step from an fp32 cache of the pass-A solve (faster, not the default)
   double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
+  double ba_fixed_pack = 0;     // 1: gl_track_frames_anchored with fixed observers always through the general kernel (k_track_pack -> k_ba_gen; A/B, tests)
   double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame
   double ba_same_xcd = 0;          //   1: the latency shape may use the same-XCD form of its exchange (outside the HIP memory model: opt-in, gmmloc_hip.h)
   double ba_rendezvous_us = 200;   // time limit of EVERY exchange of the latency shape (the fallback it protects costs ~0.5 ms; 0: a workgroup
@@ -166,6 +167,16 @@ inline gl::Ctx* C(gl_ctx_t* c) { return (gl::Ctx*)c; }
 // .gmm stream (gl_io.cpp)
 int read_gmm_file(const char* path, std::vector<double>& mean, std::vector<double>& cov);
 int write_gmm_file(const char* path, const double* mean, const double* cov, const uint8_t* flags, int K);
+
+// fixed observer key-frames of gl_track_frames_anchored (the caller's device arrays: gmmloc_hip.h, gl_track_anchor)
+struct TrackFixed {
+  int F;
+  const double* pose;   // B x F x 7
+  const double* obs;    // B x M x F x 3
+  const int32_t* oct;   // B x M x F
+  uint8_t* erase;       // B x M x F out, or null
+};
+size_t ba1_scratch_bytes(int B, int L, int F);
 
 // launchers implemented across the .hip files
 int launch_build_components(Ctx* c, Gmm* g);

@@ -228,3 +228,47 @@ def test_track_frame_host_anchored(gpu, map_v1, gt_sync):
         hp.track_frame(f["pose_init"].copy(), f["Xw"].astype(np.float32), f["obs"], f["octave"])
     with pytest.raises(TypeError):
         hp.track_frame(f["pose_init"].copy(), f["Xw"].copy(), f["obs"], f["octave"].astype(np.int64))
+
+
+@pytest.mark.parametrize("M,F,seed", [(300, 2, 5), (900, 4, 9), (1500, 3, 10)])
+def test_track_frames_fixed_observers_on_chip_route(gpu, oracle, map_v1, gt_sync, opt, M, F, seed):
+    """Round 4: up to 4 fixed observers run inside the on-chip per-frame refine (the kFixed instances of k_ba1_fast) instead of
+    k_track_pack -> k_ba_gen -> k_track_unpack.  Held to the oracle (above, every F <= 3 case) and here: (a) the packed route
+    (option ba_fixed_pack = 1, still the route of F > 4) gives the same decisions and the same pose to 1e-6; (b) a frame's bits
+    do not depend on the batch it rides in (alone, among 3, among 40 with other sizes of LDS class excluded by the common
+    stride); (c) F = 4 against the oracle."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    frames = [add_fixed(f, cam, F, 300 + seed + i) for i, f in
+              enumerate(make_frames(mean, cov, gt_sync["V1_02_medium"], cam, 3, M, 70 + seed, outlier_frac=0.05))]
+    frames[1]["octave"][::6] = -1
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+
+    def run(fr, prior):
+        pose, Xw = dev(torch, fr, "pose_init"), dev(torch, fr, "Xw")
+        pr = torch.full((len(fr),), prior, dtype=torch.uint8).cuda()
+        a, d2, fe = gmmloc_amd.track_frames_anchored(ctx, g, cam, prm, pose, Xw, dev(torch, fr, "obs"), dev(torch, fr, "octave"), prior=pr,
+                                                     fixed_pose=dev(torch, fr, "fixed_pose"), fixed_obs=dev(torch, fr, "fixed_obs"),
+                                                     fixed_oct=dev(torch, fr, "fixed_oct"), want_erase=True)
+        torch.cuda.synchronize()
+        return pose.cpu().numpy(), Xw.cpu().numpy(), a.cpu().numpy(), fe.cpu().numpy()
+    for prior in (0, 1):
+        chip = run(frames, prior)
+        opt("ba_fixed_pack", 1)
+        pack = run(frames, prior)
+        opt("ba_fixed_pack", 0)
+        for i, f in enumerate(frames):
+            keep, p_ref, pts_ref, a_ref, fe_ref = oracle_anchored(oracle, h, cam, f, bool(prior), F)
+            for name, out in (("on chip", chip), ("packed", pack)):
+                dt, dr = pose_err(out[0][i], p_ref)
+                assert dt < 1e-6 and dr < 1e-6, (name, prior, i, dt, dr)
+                assert np.array_equal(out[2][i][keep], a_ref) and np.array_equal(out[3][i][keep], fe_ref), (name, prior, i)
+            assert not chip[3][i][f["octave"] < 0].any() and (chip[2][i][f["octave"] < 0] == -1).all()
+        one = run(frames[1:2], prior)
+        many = run(frames + frames * 12 + frames[:1], prior)
+        for k in range(4):
+            assert np.array_equal(one[k][0], chip[k][1], equal_nan=True), (prior, k)
+            assert np.array_equal(many[k][1], chip[k][1], equal_nan=True) and np.array_equal(many[k][39], chip[k][0], equal_nan=True), (prior, k)
+    oracle.gmm_destroy(h)

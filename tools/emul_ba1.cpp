@@ -241,6 +241,12 @@ struct Frame {
   double sx[8], sy[8];
   double bn, lm, str_thresh;
   double dmono, dstereo;
+  // fixed observer key-frames (gl_track_frames_anchored, F > 0): poses {R, t} x NF, per point and key-frame the normalised
+  // observation and the octave (< 0: not observed)
+  int NF = 0;
+  const double* fRt = nullptr;   // NF x 12
+  const double* fobn = nullptr;  // L x NF x 3
+  const int32_t* foct = nullptr; // L x NF
 };
 
 struct Lin {
@@ -288,7 +294,40 @@ struct Pt {
   const double* ob;
   const double* nd;
   int asc;
+  int l;
+  bool af;  // some fixed-observer edge of the point is active
 };
+
+// rows of a fixed key-frame's projection Jacobian, rotated into the CURRENT camera frame: j' = j (R_f R^T)
+struct FixedEdge {
+  bool stereo;
+  double e[3], iz, chi, sx, sy;
+  double j0[3], j1[3], j2[3];
+};
+void fixed_eval(const Frame& F, const double* Rf, const double* p, const double* ob, int oc, FixedEdge& E) {
+  double q[3];
+  for (int k = 0; k < 3; ++k) q[k] = std::fma(Rf[k * 3], p[0], std::fma(Rf[k * 3 + 1], p[1], std::fma(Rf[k * 3 + 2], p[2], Rf[9 + k])));
+  E.stereo = !(ob[2] < -1e29);
+  E.sx = F.sx[oc];
+  E.sy = F.sy[oc];
+  E.chi = reproj_n(q, ob, E.stereo, F.bn, E.sx, E.sy, E.e, E.iz);
+  const double iz2 = E.iz * E.iz;
+  const double c0 = -q[0] * iz2, c1 = -q[1] * iz2, c2 = std::fma(F.bn, iz2, c0);
+  E.j0[0] = E.iz; E.j0[1] = 0.0; E.j0[2] = c0;
+  E.j1[0] = 0.0; E.j1[1] = E.iz; E.j1[2] = c1;
+  E.j2[0] = E.iz; E.j2[1] = 0.0; E.j2[2] = c2;
+}
+void rows_to_camera(const double* Rf, const Pose& P, FixedEdge& E) {
+  // Rel = R_f R^T; j' = j Rel
+  double Rel[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rel[i * 3 + j] = Rf[i * 3] * P.R[j * 3] + Rf[i * 3 + 1] * P.R[j * 3 + 1] + Rf[i * 3 + 2] * P.R[j * 3 + 2];
+  double* rows[3] = {E.j0, E.j1, E.j2};
+  for (int r = 0; r < 3; ++r) {
+    const double a = rows[r][0], b = rows[r][1], c = rows[r][2];
+    for (int j = 0; j < 3; ++j) rows[r][j] = a * Rel[j] + b * Rel[3 + j] + c * Rel[6 + j];
+  }
+}
 
 double lin_fast(const Frame& F, const Pose& P, const Pt& c, const double* p, bool robust, Lin& o) {
   for (int k = 0; k < 3; ++k) o.q[k] = std::fma(P.R[k * 3], p[0], std::fma(P.R[k * 3 + 1], p[1], std::fma(P.R[k * 3 + 2], p[2], P.t[k])));
@@ -457,8 +496,18 @@ void ad_product(const double* A, const double* Di, double* AD) {
 struct State {
   std::vector<double> sp, chir, un, bk, ucache, adcache;  // L x 3, L, L x 6, L x 3
   std::vector<int> fl;
+  std::vector<double> chif;  // L x NF: stale chi2 of the fixed-observer edges (rho' between the two passes of a trial)
+  std::vector<int> levf;     // L x NF: the edge is at level 1
 };
 
+bool fixed_active(const Frame& F, const State& S, int l, int f) {
+  return (S.fl[l] & F_EXISTS) && F.foct[(size_t)l * F.NF + f] >= 0 && !S.levf[(size_t)l * F.NF + f];
+}
+bool any_fixed(const Frame& F, const State& S, int l) {
+  for (int f = 0; f < F.NF; ++f)
+    if (fixed_active(F, S, l, f)) return true;
+  return false;
+}
 Pt make_pt(const Frame& F, const State& S, int l) {
   Pt c;
   c.fl = S.fl[l];
@@ -471,7 +520,69 @@ Pt make_pt(const Frame& F, const State& S, int l) {
   const int a = F.assoc[l];
   c.nd = F.plane4 + (size_t)(a > 0 ? a : 0) * 4;
   c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? a : -1;
+  c.l = l;
+  c.af = any_fixed(F, S, l);
   return c;
+}
+
+// pass A / lambda init: the fixed-observer edges of point l add to its block and right-hand side (camera frame); returns
+// their robustified chi2; leaves rho' of every edge in its stale-chi2 cell for pass B
+double fixed_lin(const Frame& F, State& S, const Pose& P, int l, const double* p, bool robust, Lin& o, bool keep_rho) {
+  double sum = 0.0;
+  for (int f = 0; f < F.NF; ++f) {
+    if (!fixed_active(F, S, l, f)) continue;
+    const double* Rf = F.fRt + (size_t)f * 12;
+    FixedEdge E;
+    fixed_eval(F, Rf, p, F.fobn + ((size_t)l * F.NF + f) * 3, F.foct[(size_t)l * F.NF + f], E);
+    double rho0 = E.chi, rho1 = 1.0;
+    if (robust) huber_bf(E.chi, E.stereo ? F.dstereo : F.dmono, E.stereo ? F.dstereo * F.dstereo : F.dmono * F.dmono, rho0, rho1);
+    sum += rho0;
+    if (keep_rho) S.chif[(size_t)l * F.NF + f] = rho1;
+    rows_to_camera(Rf, P, E);
+    const double w[3] = {rho1 * E.sx, rho1 * E.sy, E.stereo ? rho1 * E.sx : 0.0};
+    const double* rows[3] = {E.j0, E.j1, E.j2};
+    for (int r = 0; r < 3; ++r) {
+      const double* j = rows[r];
+      const double wj[3] = {w[r] * j[0], w[r] * j[1], w[r] * j[2]};
+      o.D[0] = std::fma(wj[0], j[0], o.D[0]);
+      o.D[1] = std::fma(wj[0], j[1], o.D[1]);
+      o.D[2] = std::fma(wj[0], j[2], o.D[2]);
+      o.D[3] = std::fma(wj[1], j[1], o.D[3]);
+      o.D[4] = std::fma(wj[1], j[2], o.D[4]);
+      o.D[5] = std::fma(wj[2], j[2], o.D[5]);
+      for (int k = 0; k < 3; ++k) o.b[k] = std::fma(E.e[r], wj[k], o.b[k]);
+    }
+  }
+  return sum;
+}
+// pass B, step half: right-hand sides of the fixed edges at the linearisation point (they do not couple to the pose step)
+void fixed_rhs(const Frame& F, const State& S, const Pose& P, int l, const double* p, double* rhs) {
+  for (int f = 0; f < F.NF; ++f) {
+    if (!fixed_active(F, S, l, f)) continue;
+    const double* Rf = F.fRt + (size_t)f * 12;
+    FixedEdge E;
+    fixed_eval(F, Rf, p, F.fobn + ((size_t)l * F.NF + f) * 3, F.foct[(size_t)l * F.NF + f], E);
+    const double rho1 = S.chif[(size_t)l * F.NF + f];
+    rows_to_camera(Rf, P, E);
+    const double w[3] = {rho1 * E.sx, rho1 * E.sy, E.stereo ? rho1 * E.sx : 0.0};
+    const double* rows[3] = {E.j0, E.j1, E.j2};
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 3; ++k) rhs[k] = std::fma(E.e[r] * w[r], rows[r][k], rhs[k]);
+  }
+}
+// pass B, evaluation half: chi2 of the fixed edges at the trial point; the stale chi2 is rewritten
+double fixed_chi(const Frame& F, State& S, int l, const double* pn, bool robust) {
+  double sum = 0.0;
+  for (int f = 0; f < F.NF; ++f) {
+    if (!fixed_active(F, S, l, f)) continue;
+    FixedEdge E;
+    fixed_eval(F, F.fRt + (size_t)f * 12, pn, F.fobn + ((size_t)l * F.NF + f) * 3, F.foct[(size_t)l * F.NF + f], E);
+    S.chif[(size_t)l * F.NF + f] = E.chi;
+    double rho0 = E.chi, rho1;
+    if (robust) huber_bf(E.chi, E.stereo ? F.dstereo : F.dmono, E.stereo ? F.dstereo * F.dstereo : F.dmono * F.dmono, rho0, rho1);
+    sum += rho0;
+  }
+  return sum;
 }
 
 int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int& trials, bool has_prior, const double* mi, int variant,
@@ -481,7 +592,7 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
   for (int l = 0; l < L; ++l) {
     const Pt c = make_pt(F, S, l);
     n_ar += c.ar;
-    n_any += c.ar || c.ag;
+    n_any += c.ar || c.ag || c.af;
   }
   const bool pose_active = n_ar > 0 || has_prior;
   const bool prior_on = has_prior && pose_active;
@@ -498,9 +609,10 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
       double md = 0.0, acc[32] = {0};
       for (int l = 0; l < L; ++l) {
         const Pt c = make_pt(F, S, l);
-        if (!(c.ar || c.ag)) continue;
+        if (!(c.ar || c.ag || c.af)) continue;
         Lin o;
         lin_fast(F, P, c, &S.sp[(size_t)l * 3], robust, o);
+        if (c.af) fixed_lin(F, S, P, l, &S.sp[(size_t)l * 3], robust, o, false);
         const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
         for (int j = 0; j < 3; ++j) {
           double s = 0.0;
@@ -526,11 +638,13 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
       // pass A
       for (int l = 0; l < L; ++l) {
         const Pt c = make_pt(F, S, l);
-        if (!(c.ar || c.ag)) continue;
+        if (!(c.ar || c.ag || c.af)) continue;
         Lin o;
         const double* p = &S.sp[(size_t)l * 3];
         lin_fast(F, P, c, p, robust, o);
-        acc[27] += o.rho0_r + o.chi_g;
+        double chi_f = 0.0;
+        if (c.af) chi_f = fixed_lin(F, S, P, l, p, robust, o, true);
+        acc[27] += (o.rho0_r + o.chi_g) + chi_f;
         double Dinv[6], u[3];
         const double D[6] = {o.D[0] + lambda, o.D[1], o.D[2], o.D[3] + lambda, o.D[4], o.D[5] + lambda};
         if (variant & V_DINV_LDL) {
@@ -648,7 +762,7 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
       double sum_eps2 = 0.0, chi_t = 0.0;
       for (int l = 0; l < L; ++l) {
         const Pt c = make_pt(F, S, l);
-        if (!(c.ar || c.ag)) continue;
+        if (!(c.ar || c.ag || c.af)) continue;
         double* p = &S.sp[(size_t)l * 3];
         double q[3], gd[3], eps[3];
         for (int j = 0; j < 3; ++j) q[j] = std::fma(P.R[j * 3], p[0], std::fma(P.R[j * 3 + 1], p[1], std::fma(P.R[j * 3 + 2], p[2], P.t[j])));
@@ -690,6 +804,7 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
               for (int j = 0; j < 3; ++j) rhs[j] += bc[j];
             }
           }
+          if (c.af) fixed_rhs(F, S, P, l, p, rhs);
           if (variant & V_DINV_LDL) ldl3_solve(&S.un[(size_t)l * 6], rhs, eps);
           else sym3_mul_vec(&S.un[(size_t)l * 6], rhs, eps);
         }
@@ -711,6 +826,7 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
           chi = r0;
         }
         if (c.ag) chi += gmm_chi2_fast(F, c.nd, c.fl, c.asc, pn);
+        if (c.af) chi += fixed_chi(F, S, l, pn, robust);
         chi_t += chi;
       }
       if (prior_on) prior_record(mi, Pn, rec[cur ^ 1]);
@@ -742,7 +858,7 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
         ni *= 2;
         for (int l = 0; l < L; ++l) {
           const Pt c = make_pt(F, S, l);
-          if (c.ar || c.ag)
+          if (c.ar || c.ag || c.af)
             for (int j = 0; j < 3; ++j) S.sp[(size_t)l * 3 + j] = S.bk[(size_t)l * 3 + j];
         }
       }
@@ -760,6 +876,21 @@ int optimize_fast(const Frame& F, State& S, Pose& P, bool robust, int iters, int
 // pose_io: 7 (qx qy qz qw tx ty tz); pts_io: L x 3; obn: L x 3 normalised; fl: L flag words; assoc: gated associations;
 // trace: cap x 10 (currentChi, tempChi, lambda, rho, dx[6]); returns the number of Levenberg trials
 extern "C" void emul_set_diag(int t) { g_diag_trial = t; }
+namespace {
+int g_NF = 0;
+const double *g_fRt = nullptr, *g_fobn = nullptr;
+const int32_t* g_foct = nullptr;
+uint8_t* g_ferase = nullptr;
+}  // namespace
+// fixed observer key-frames of the NEXT emul_track call: poses {R (9), t (3)} x NF, normalised observations L x NF x 3 (third
+// component < -1e29: mono), octaves L x NF (< 0: not observed), erase flags out L x NF
+extern "C" void emul_set_fixed(int NF, const double* fRt, const double* fobn, const int32_t* foct, uint8_t* ferase) {
+  g_NF = NF;
+  g_fRt = fRt;
+  g_fobn = fobn;
+  g_foct = foct;
+  g_ferase = ferase;
+}
 extern "C" int emul_track(int L, double* pose_io, double* pts_io, const double* obn, const int32_t* fl, const int32_t* assoc,
                           const double* plane4, const double* hgw, const double* mean, const double* sx, const double* sy, double bn,
                           double lm, double str_thresh, double dmono, double dstereo, int has_prior, int variant, double* trace,
@@ -781,7 +912,13 @@ extern "C" int emul_track(int L, double* pose_io, double* pts_io, const double* 
   F.str_thresh = str_thresh;
   F.dmono = dmono;
   F.dstereo = dstereo;
+  F.NF = g_NF;
+  F.fRt = g_fRt;
+  F.fobn = g_fobn;
+  F.foct = g_foct;
   State S;
+  S.chif.assign((size_t)L * (g_NF > 0 ? g_NF : 1), 0.0);
+  S.levf.assign((size_t)L * (g_NF > 0 ? g_NF : 1), 0);
   S.sp.assign(pts_io, pts_io + (size_t)L * 3);
   S.chir.assign(L, 0.0);
   S.un.assign((size_t)L * 6, 0.0);
@@ -815,9 +952,29 @@ extern "C" int emul_track(int L, double* pose_io, double* pts_io, const double* 
         if (!(f & F_EXISTS)) continue;
         const double z = P.R[6] * p[0] + P.R[7] * p[1] + P.R[8] * p[2] + P.t[2];
         if (S.chir[l] > ((f & F_STEREO) ? 7.815 : 5.991) || !(z > 0.0)) S.fl[l] |= F_LEVR;
+        for (int k = 0; k < F.NF; ++k) {  // the fixed observers' edges: same gate, depth in THEIR camera
+          if (F.foct[(size_t)l * F.NF + k] < 0) continue;
+          const double* Rf = F.fRt + (size_t)k * 12;
+          const double zf = Rf[6] * p[0] + Rf[7] * p[1] + Rf[8] * p[2] + Rf[11];
+          const bool st = !(F.fobn[((size_t)l * F.NF + k) * 3 + 2] < -1e29);
+          if (S.chif[(size_t)l * F.NF + k] > (st ? 7.815 : 5.991) || !(zf > 0.0)) S.levf[(size_t)l * F.NF + k] = 1;
+        }
       }
     }
   }
+  if (g_ferase)
+    for (int l = 0; l < L; ++l)
+      for (int k = 0; k < F.NF; ++k) {
+        uint8_t er = 0;
+        if ((S.fl[l] & F_EXISTS) && F.foct[(size_t)l * F.NF + k] >= 0) {
+          const double* p = &S.sp[(size_t)l * 3];
+          const double* Rf = F.fRt + (size_t)k * 12;
+          const double zf = Rf[6] * p[0] + Rf[7] * p[1] + Rf[8] * p[2] + Rf[11];
+          const bool st = !(F.fobn[((size_t)l * F.NF + k) * 3 + 2] < -1e29);
+          if (S.chif[(size_t)l * F.NF + k] > (st ? 7.815 : 5.991) || !(zf > 0.0)) er = 1;
+        }
+        g_ferase[(size_t)l * F.NF + k] = er;
+      }
   double q[4];
   qfromR(P.R, q);
   const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
