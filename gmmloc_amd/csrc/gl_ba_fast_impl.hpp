@@ -509,16 +509,21 @@ GL_DEV double fixed_sum(const Uni& U, const Lds& D, const PtCtx& c, bool robust,
   }
   return sum;
 }
-// pass A / lambda init: the fixed edges into the point's block and right-hand side (camera frame)
-GL_DEV double fixed_lin(const Uni& U, const Lds& D, const Pose& P, const PtCtx& c, bool robust, Lin& o, bool keep_rho) {
-  double Hw[6], bw[3], Hc[6];
+// pass A / lambda init: the fixed edges' part of the point's block and right-hand side, in the camera frame (Hc sym6, bc);
+// evaluated BEFORE the frame's own edge is linearised, so that only these nine values are live across lin_fast
+GL_DEV double fixed_lin(const Uni& U, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double* Hc, double* bc, bool keep_rho) {
+  double Hw[6], bw[3];
   const double sum = fixed_sum(U, D, c, robust, Hw, bw, keep_rho ? 1 : 0);
   rot_sym(P.R, Hw, Hc);
 #pragma unroll
+  for (int j = 0; j < 3; ++j) bc[j] = fma(P.R[j * 3], bw[0], fma(P.R[j * 3 + 1], bw[1], P.R[j * 3 + 2] * bw[2]));
+  return sum;
+}
+GL_DEV void fixed_add(const double* Hc, const double* bc, Lin& o) {
+#pragma unroll
   for (int j = 0; j < 6; ++j) o.D[j] += Hc[j];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) o.b[j] += fma(P.R[j * 3], bw[0], fma(P.R[j * 3 + 1], bw[1], P.R[j * 3 + 2] * bw[2]));
-  return sum;
+  for (int j = 0; j < 3; ++j) o.b[j] += bc[j];
 }
 // pass B, evaluation half: robustified chi2 of the fixed edges at the trial point; the stale chi2 cells are rewritten
 GL_DEV double fixed_chi(const Uni& U, const Lds& D, const PtCtx& c, const double* pn, bool robust) {
@@ -1309,8 +1314,14 @@ GL_DEV bool load_pt_const(const Lds& D, const Map& mp, FlagW fw, const PtConst& 
 template <class Sink>
 GL_DEV void pt_lambda_init(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double& md, const Sink& sk) {
   Lin o;
-  lin_fast(U, gm, D, P, c, robust, o);
-  if (kFixed && c.af) fixed_lin(U, D, P, c, robust, o, false);
+  if (kFixed && c.af) {
+    double Hx[6], bx[3];
+    fixed_lin(U, D, P, c, robust, Hx, bx, false);
+    lin_fast(U, gm, D, P, c, robust, o);
+    fixed_add(Hx, bx, o);
+  } else {
+    lin_fast(U, gm, D, P, c, robust, o);
+  }
   const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -1332,12 +1343,16 @@ template <class Sink>
 GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double lambda,
                       const Sink& sk) {
   Lin o;
-  lin_fast(U, gm, D, P, c, robust, o);
-  if (kFixed) {
-    const double chi_f = c.af ? fixed_lin(U, D, P, c, robust, o, true) : 0.0;
+  if (kFixed && c.af) {
+    double Hx[6], bx[3];
+    const double chi_f = fixed_lin(U, D, P, c, robust, Hx, bx, true);
+    lin_fast(U, gm, D, P, c, robust, o);
+    fixed_add(Hx, bx, o);
     sk.put(27, (o.rho0_r + o.chi_g) + chi_f);
-  } else
-  sk.put(27, o.rho0_r + o.chi_g);
+  } else {
+    lin_fast(U, gm, D, P, c, robust, o);
+    sk.put(27, kFixed ? (o.rho0_r + o.chi_g) + 0.0 : o.rho0_r + o.chi_g);
+  }
   double Df[6], u[3];
   point_solve_fast(o, lambda, Df, u);
   sk.put(28, fma(u[0], o.b[0], fma(u[1], o.b[1], u[2] * o.b[2])));
@@ -1411,6 +1426,12 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
     }
   } else {  // exact: b - A gd = Jpi^T W (e - Jpi gd) + b_gmm from the re-evaluated residual, solved with the cached factors of D
     double rhs[3] = {0.0, 0.0, 0.0};
+    if (kFixed && c.af) {  // the fixed edges do not couple to the pose step: their part of b, at the linearisation point
+      double bw[3];
+      fixed_sum(U, D, c, false, nullptr, bw, -1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rhs[j] = fma(P.R[j * 3], bw[0], fma(P.R[j * 3 + 1], bw[1], P.R[j * 3 + 2] * bw[2]));
+    }
     if (c.ar) {
       const double rho1 = D.chir[c.ll];  // the edge's Huber weight, left there by pass A
       const double iz = rcp_nr(q[2]);
@@ -1420,9 +1441,10 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
       const double f0 = wx * fma(-J.c0, gd[2], fma(-(q[0] + gd[0]), iz, c.ob[0]));
       const double f1 = wy * fma(-J.c1, gd[2], fma(-(q[1] + gd[1]), iz, c.ob[1]));
       const double f2 = stereo ? wx * fma(-J.c2, gd[2], fma(U.bn - (q[0] + gd[0]), iz, c.ob[2])) : 0.0;
-      rhs[0] = iz * (f0 + f2);
-      rhs[1] = iz * f1;
-      rhs[2] = fma(J.c2, f2, fma(J.c1, f1, J.c0 * f0));
+      const double r0 = iz * (f0 + f2), r1 = iz * f1, r2 = fma(J.c2, f2, fma(J.c1, f1, J.c0 * f0));
+      rhs[0] = kFixed ? rhs[0] + r0 : r0;
+      rhs[1] = kFixed ? rhs[1] + r1 : r1;
+      rhs[2] = kFixed ? rhs[2] + r2 : r2;
     }
     if (c.ag) {
       if (c.fl & F_DEG) {
@@ -1437,12 +1459,6 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
 #pragma unroll
         for (int j = 0; j < 3; ++j) rhs[j] += bc[j];
       }
-    }
-    if (kFixed && c.af) {  // the fixed edges do not couple to the pose step: their part of b, at the linearisation point
-      double bw[3];
-      fixed_sum(U, D, c, false, nullptr, bw, -1);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) rhs[j] += fma(P.R[j * 3], bw[0], fma(P.R[j * 3 + 1], bw[1], P.R[j * 3 + 2] * bw[2]));
     }
     double Df[6];
 #pragma unroll

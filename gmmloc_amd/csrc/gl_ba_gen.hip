@@ -2660,7 +2660,7 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
                   double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
                   const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
-                  const int32_t* stop_dev, void* scratch) {
+                  const int32_t* stop_dev, void* scratch, int force_nb = 0) {
   const size_t per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
   GmmDev gm{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   const size_t n = 6 * (size_t)P;
@@ -2697,6 +2697,7 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
     // bagen_mode 3 (opt-in, throughput of large batches): the whole batch in ONE launch, with as many workgroups per window as
     // stay co-resident - the round-3 rule; a window's bits then depend on the batch size
     if (c->opt.bagen_mode == 3) NB = (int)std::min<long>(NB, cap / B);
+    if (force_nb > 0) NB = force_nb;  // (the packed route of gl_track_frames_anchored: one workgroup per frame, whatever the batch)
     if (NB < 2) NB = 1;
     bsub = NB > 1 ? (int)std::max<long>(1, cap / NB) : B;
   }
@@ -3064,7 +3065,8 @@ int track_frames_fixed(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam,
   GL_HIP(hipGetLastError());
   rc = launch_ba_gen(c, g, cam, prm, B, 1, F, M, (int)NOBS, (double*)(s + o_poses), (const uint8_t*)(s + o_prior), Xw_dev, assoc_dev,
                      (const int32_t*)(s + o_optr), (const int32_t*)(s + o_opose), (const double*)(s + o_ouvr), (const int32_t*)(s + o_ooct),
-                     (uint8_t*)(s + o_drop), (uint8_t*)(s + o_erase), nullptr, nullptr, s + o_gen);
+                     (uint8_t*)(s + o_drop), (uint8_t*)(s + o_erase), nullptr, nullptr, s + o_gen,
+                     1);  // one workgroup per frame: per-frame batches are large, and a frame's bits must not depend on the batch
   if (rc != GL_OK) return rc;
   k_track_unpack<<<B, PK_T, 0, c->stream>>>(B, M, F, (const double*)(s + o_poses), (const int32_t*)(s + o_optr), (const int32_t*)(s + o_opose),
                                             (const uint8_t*)(s + o_drop), (const uint8_t*)(s + o_erase), pose_dev, assoc_dev, an->fixed_erase_dev);
