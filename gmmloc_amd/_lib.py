@@ -69,6 +69,7 @@ def load():
         "gl_gmm_nbs_count": (i32, [vp]),
         "gl_associate3d": (i32, [vp, vp, vp, i32, i32, vp, vp]),
         "gl_gmm_index_info": (i32, [vp, P(C.c_double)]),
+        "gl_gmm_index_bytes": (i32, [vp, P(C.c_double)]),
         "gl_assoc_index_work": (i32, [vp, vp, vp, i32, vp]),
         "gl_knn3d": (i32, [vp, vp, vp, i32, i32, vp, vp]),
         "gl_search2d": (i32, [vp, vp, P(gl_camera), i32, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp]),

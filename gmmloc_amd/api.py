@@ -210,8 +210,11 @@ class GMM:
         import ctypes as C
         info = (C.c_double * 8)()
         _check(self.lib.gl_gmm_index_info(self.h, info))
+        b = (C.c_double * 3)()
+        _check(self.lib.gl_gmm_index_bytes(self.h, b))
         return {"enabled": bool(info[0]), "cell": info[1], "dims": (int(info[2]), int(info[3]), int(info[4])),
-                "entries": int(info[5]), "always": int(info[6]), "t_resolve": info[7]}
+                "entries": int(info[5]), "always": int(info[6]), "t_resolve": info[7],
+                "bytes": {"cell_pointers": int(b[0]), "lists": int(b[1]), "packed_cells": int(b[2])}}
 
     def index_work(self, pts):
         """Number of (point, component) evaluations the cell index performs for these points."""

@@ -393,8 +393,9 @@ void free_cell_index(Gmm* g) {
 
 int build_cell_index(Ctx* c, Gmm* g) {
   g->grid = CellIndex();
-  if (const char* e = getenv("GMMLOC_ASSOC_GRID"))
-    if (atoi(e) == 0) return GL_OK;  // knob: serve GL_ASSOC_BRUTE with the all-pairs sweep
+  // (options of the creating context, read from GMMLOC_<NAME> once at gl_ctx_create like every other knob: assoc_grid,
+  // assoc_cell, assoc_globcells, assoc_pack_mb - no environment scan here)
+  if (c->opt.assoc_grid == 0) return GL_OK;  // knob: serve GL_ASSOC_BRUTE with the all-pairs sweep
   const int K = g->K;
   const double T = kT0;
   const double t_reg = T * (1.0 + 4e-6);
@@ -457,14 +458,14 @@ int build_cell_index(Ctx* c, Gmm* g) {
     if (ins > max_ins) break;
     h = hc;
   }
-  if (const char* e = getenv("GMMLOC_ASSOC_CELL")) h = atof(e);  // tuning knob (metres)
+  if (c->opt.assoc_cell > 0) h = c->opt.assoc_cell;  // tuning knob (metres)
   int dim[3];
   for (int a = 0; a < 3; ++a) dim[a] = std::max(1, (int)std::ceil(span[a] / h));
   const size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
   const double eps_idx = 1e-9;
   const double rho = h * std::sqrt(3.0) * 0.5 * (1.0 + 1e-9) + 1e-9 * smax;
   double glob_cells = 4194304.0;  // boxes above 2^22 cells: evaluated for every point instead
-  if (const char* e = getenv("GMMLOC_ASSOC_GLOBCELLS")) glob_cells = atof(e);  // tuning knob
+  if (c->opt.assoc_globcells > 0) glob_cells = c->opt.assoc_globcells;  // tuning knob
   std::vector<CompReg> regs;
   regs.reserve(K);
   const double betas[3] = {0.5, 1.0, 2.0};
@@ -591,7 +592,9 @@ int build_cell_index(Ctx* c, Gmm* g) {
   G.nnz = (size_t)nnz;
   G.ncell = ncell;
   G.cell4 = nullptr;
-  if (ncell * 16 <= ((size_t)1 << 29) && !getenv("GMMLOC_ASSOC_NOPACK")) {  // (512 MB budget; the bench map: 11 M cells = 176 MB)
+  // the packed cell table (16 bytes per cell; the bench map: 11 M cells = 176 MB) within the option's memory budget (assoc_pack_mb,
+  // default 512, 0 = never); gl_gmm_index_info reports its size
+  if ((double)ncell * 16.0 <= c->opt.assoc_pack_mb * 1048576.0) {
     if (hipMalloc(&G.cell4, ncell * 16) == hipSuccess) {
       k_index_pack<<<(unsigned)((ncell + 255) / 256), 256, 0, c->stream>>>(d_ptr, d_idx, ncell, (int4*)G.cell4);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -652,6 +655,15 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
 }  // namespace gl
 
 extern "C" {
+
+int gl_gmm_index_bytes(const gl_gmm_t* gmm, double bytes[3]) {
+  GL_REQUIRE(gmm && bytes, "null argument");
+  const gl::CellIndex& I = gl::G(gmm)->grid;
+  bytes[0] = I.enabled ? (double)(I.ncell + 1) * 4.0 : 0.0;  // cell pointers
+  bytes[1] = I.enabled ? (double)I.nnz * 4.0 + (double)I.nglob * 4.0 : 0.0;  // candidate lists
+  bytes[2] = I.cell4 ? (double)I.ncell * 16.0 : 0.0;  // packed cell table (option assoc_pack_mb)
+  return GL_OK;
+}
 
 int gl_gmm_index_info(const gl_gmm_t* gmm, double info[8]) {
   GL_REQUIRE(gmm && info, "null argument");

@@ -99,6 +99,9 @@ struct Options {
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
   double assoc_grid = -1;       // 0: never use the cell index (every association is the N x K sweep); A/B and bench
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
+  double assoc_pack_mb = 512;   // memory budget (MB) of the packed cell table a GMM built with this context may add to its cell index (0: none)
+  double assoc_cell = 0;        // > 0: cell size (m) of the index instead of the automatic one (tuning)
+  double assoc_globcells = 0;   // > 0: components whose box covers more cells than this are evaluated for every point (tuning)
   double match_desc_lds = -1;   // gl_search_by_projection: descriptors in LDS (-1 auto, 0 / 1)
 };
 // name -> member; nullptr if unknown

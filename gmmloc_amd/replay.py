@@ -182,7 +182,8 @@ class TrackCompute:
     structure BA always has; anchor "none": gl_track_frames, one free pose and free points held by the map's Gaussians
     only (the earlier rounds' replay)."""
 
-    def __init__(self, ctx, gmms, cam, prm, anchor="prior"):
+    def __init__(self, ctx, gmms, cam, prm, anchor):
+        # (no default: "none" was the behaviour of rounds 1 - 2, "prior" that of round 3 - a caller says which refine it replays)
         assert anchor in ("prior", "none", "fixed")  # "fixed": prior + the frames' fixed observer key-frames
         self.ctx, self.gmms, self.cam, self.prm, self.anchor = ctx, gmms, cam, prm, anchor
 

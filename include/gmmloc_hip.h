@@ -112,6 +112,9 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *          on the batch size (the workgroup count decides the order of its partial sums).
  *     Same arithmetic everywhere, every mode held to the oracle; the shapes add their partial sums in different orders, so a
  *     window may take a different number of trials in each,
+ *   assoc_pack_mb (512; memory budget in MB of the packed cell table of a GMM created with this context, 0 = none),
+ *   assoc_cell, assoc_globcells (> 0: cell size in metres / cell-count threshold of the index instead of the automatic ones),
+ *   ba_fixed_pack (1: fixed observers of gl_track_frames_anchored always through the general kernel),
  *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
@@ -202,6 +205,10 @@ int gl_associate3d(gl_ctx_t* ctx, const gl_gmm_t* gmm, const double* pts_dev, in
  * info[8] = {enabled, cell size [m], dim x, dim y, dim z, entries (sum of list lengths),
  *            always-evaluated components, resolve threshold (chi2)}. */
 int gl_gmm_index_info(const gl_gmm_t* gmm, double info[8]);
+/* Device memory of that index: bytes[3] = {cell pointers, candidate lists, packed cell table}.  The packed table (16 bytes per
+ * cell: one random read per point instead of two; 176 MB on the 4 096-Gaussian bench map) is built only within the memory
+ * budget of the creating context's option assoc_pack_mb (default 512, 0 = never). */
+int gl_gmm_index_bytes(const gl_gmm_t* gmm, double bytes[3]);
 /* Number of (point, component) chi2 evaluations the index performs for these N points (its
  * algorithmic work, excluding the exhaustive sweep of unresolved points): *pairs_dev (device
  * int64) is overwritten. */

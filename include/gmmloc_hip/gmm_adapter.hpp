@@ -23,6 +23,9 @@
 
 namespace gmmloc_hip {
 
+// 3: trackFrame is the unanchored refine again, trackFrameAnchored the anchored one (2: trackFrame(..., anchored = true))
+constexpr int kAdapterVersion = 3;
+
 inline void check(int rc, const char* what) {
   if (rc != GL_OK) throw std::runtime_error(std::string(what) + ": " + gl_last_error_string());
 }
@@ -153,11 +156,13 @@ class GMM {
   // frame's M map points (kept iff chi2 <= 9, gmmloc_opt.cpp:230-232) + jointOptimization restricted to the
   // frame (1 free pose, M marginalised points, 5 / 5 / 40 Levenberg schedule).  Tcw and Xw are updated;
   // assoc[i] = component after the final gates or -1; octave[i] < 0 = no map point.
-  // anchored = true (default): with the reference's gauge anchor of key-frame 0 - an EdgeSE3QuatPrior on the pose the call
-  // starts from (sigma 2 deg / 1 cm; the pose is FIXED when gl_params.ba_first_as_prior == 0), localization_opt.cpp:556-581;
-  // the reference never runs its structure BA without one.  false: the pose is held by the map's Gaussians alone.
+  // trackFrame: the pose is held by the map's Gaussians alone (rounds 1 - 2; the default again since adapter version 3 - version 2
+  // silently switched this entry point to the anchored refine).  trackFrameAnchored: with the reference's gauge
+  // anchor of key-frame 0 - an EdgeSE3QuatPrior on the pose the call starts from (sigma 2 deg / 1 cm; the pose is FIXED when
+  // gl_params.ba_first_as_prior == 0), localization_opt.cpp:556-581: the reference never runs its structure BA without one, so
+  // this is the entry point a port of Localization's per-frame refine wants; the two give DIFFERENT poses and points.
   void trackFrame(Pose& Tcw, std::vector<double>& Xw, const std::vector<double>& obs, const std::vector<int32_t>& octave,
-                  std::vector<int32_t>& assoc, bool anchored = true) {
+                  std::vector<int32_t>& assoc, bool anchored = false) {
     const int M = (int)octave.size();
     assoc.assign(M, -1);
     if (!M) return;
@@ -171,6 +176,10 @@ class GMM {
       check(gl_track_frame_host(ctx_, gmm_, &cam_, &prm_, M, reinterpret_cast<double*>(&Tcw), Xw.data(), obs.data(), octave.data(),
                                 assoc.data()),
             "gl_track_frame_host");
+  }
+  void trackFrameAnchored(Pose& Tcw, std::vector<double>& Xw, const std::vector<double>& obs, const std::vector<int32_t>& octave,
+                          std::vector<int32_t>& assoc) {
+    trackFrame(Tcw, Xw, obs, octave, assoc, true);
   }
 
   // Localization::jointOptimization on one flattened local window (layout: gmmloc_hip.h, gl_joint_optimization):

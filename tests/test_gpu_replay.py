@@ -28,7 +28,7 @@ def test_replay_euroc_full_size_matches_unsharded_oracle_and_scores(gpu, oracle,
     maps, frames = replay.materialise_euroc(GOLDEN, cam, M=300)
     assert len(frames) == 13735 and {f["map"] for f in frames} == {"map_v1", "map_v2"}
     gmms = {name: gmmloc_amd.GMM(ctx, mean, cov, prm) for name, (mean, cov) in maps.items()}
-    compute = replay.TrackCompute(ctx, gmms, cam, prm)  # anchor = the prior edge on the tracker's pose
+    compute = replay.TrackCompute(ctx, gmms, cam, prm, anchor="prior")  # the prior edge on the tracker's pose
     whole = compute(frames)  # every frame of a map in ONE call
     # the replay proper: batches of 1024, and the same with the frames dealt to 3 "ranks" (run one after the other)
     res1, _ = replay.replay(frames, compute, 0, 1, None, "cpu", batch=1024)

@@ -1,4 +1,4 @@
-"""k_assoc_cells on the bench points (8.19 M points x 4 096 Gaussians), ms per launch; GMMLOC_ASSOC_NOPACK=1: CSR path"""
+"""k_assoc_cells on the bench points (8.19 M points x 4 096 Gaussians), ms per launch; GMMLOC_ASSOC_PACK_MB=0: CSR path (no packed cell table)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,4 +14,4 @@ for want in (False, True):
     for _ in range(5): idx, d2 = g.associate3d(pts, api.ASSOC_BRUTE, want_d2=want)
     torch.cuda.synchronize()
     ms, n = ctx.timing_read(api.TIMER_ASSOC); ctx.timing(False)
-    print("pack" if not os.environ.get("GMMLOC_ASSOC_NOPACK") else "csr ", "want_d2", want, "%.3f ms per call (%d timed launches)" % (ms / 5, n), "checksum", int(idx.sum().item()))
+    print("pack" if not os.environ.get("GMMLOC_ASSOC_PACK_MB") == "0" else "csr ", "want_d2", want, "%.3f ms per call (%d timed launches)" % (ms / 5, n), "checksum", int(idx.sum().item()))
