@@ -489,6 +489,30 @@ def search_by_projection_frame(ctx, cam, pose_cw, pose_lw, feat_uv, feat_ur, fea
     return match, nm
 
 
+KF_KEYS = ("uv", "ur", "oct", "angle", "desc", "has_mp", "nnode", "node_id", "node_ptr", "node_idx")
+
+
+def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, check_orientation=True, scale_factor=1.2):
+    """ORBmatcher::searchForTriangulation (orb_matcher.cpp:141-293) for B key-frame pairs.  kf1 / kf2: dicts of CUDA tensors
+    with the keys KF_KEYS - uv (B,N,2) f64, ur (B,N) f32, oct (B,N) i32, angle (B,N) f32, desc (B,N,32) u8, has_mp (B,N) u8 and
+    the DBoW2 feature vector as CSR: nnode (B,) i32, node_id (B,NN) i32 ascending, node_ptr (B,NN+1) i32, node_idx (B,N) i32;
+    fmat (B,9) f64, epipole (B,2) f32 -> (match12 int32 (B,N1): feature of key-frame 2 or -1, nmatches int32 (B,))."""
+    import torch
+    B, N1 = kf1["oct"].shape
+    N2 = kf2["oct"].shape[1]
+    NN1, NN2 = kf1["node_id"].shape[1], kf2["node_id"].shape[1]
+    assert kf1["node_ptr"].shape[1] == NN1 + 1 and kf2["node_ptr"].shape[1] == NN2 + 1
+    dev = kf1["oct"].device
+    match = torch.empty((B, N1), dtype=torch.int32, device=dev)
+    nm = torch.empty(B, dtype=torch.int32, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_search_for_triangulation(ctx.h, float(scale_factor), B, N1, N2, NN1, NN2, *[_ptr(kf1[k]) for k in KF_KEYS],
+                                               *[_ptr(kf2[k]) for k in KF_KEYS], _ptr(fmat), _ptr(epipole), int(bool(only_stereo)),
+                                               int(bool(check_orientation)), _ptr(match), _ptr(nm)))
+    ctx._exit()
+    return match, nm
+
+
 def create_map_points(ctx, gmm, cam, prm, pose1, uvr1, depth1, oct1, pose2, uvr2, depth2, oct2, cand1, n1, cand2, n2,
                       scale_factor=1.2):
     """Localization::createMapPoints per-match block (localization_opt.cpp:286-420), N matches ->

@@ -1,0 +1,303 @@
+// ORBmatcher::searchForTriangulation (orb_matcher.cpp:141-293) with checkEpipolarDist (:119-139) and computeThreeMaxima
+// (:544-578) for B key-frame pairs: the producer of the matches Localization::createMapPoints triangulates
+// (localization_opt.cpp:266; gl_create_map_points takes them from here).  Integer / byte work: per vocabulary node the two
+// key-frames share, 256-bit Hamming distances between its features of key-frame 1 and of key-frame 2, the epipole test of
+// mono pairs, the epipolar chi2, then the rotation histogram.
+//
+// The reference loop is ORDER DEPENDENT like searchByProjection's (gl_match.hip): a feature of key-frame 2 taken by an
+// earlier feature of key-frame 1 - earlier node, or earlier in the node's list - is skipped by every later one, which falls
+// back to its next-best partner.  Same fixed point: queries are numbered by their position in key-frame 1's feature-vector
+// list (= the order the reference visits them in: std::map iterates node ids ascending, the lists are in push order); in every
+// round each query picks its best partner among those not owned by a LOWER query in the previous round, owner[partner] = min
+// query that picked it; the choices of the queries 0 .. r-1 are final after round r, and the iteration stops when the owner
+// table repeats.  "Best" is the reference's scan: minimum descriptor distance among the partners that pass the geometric
+// tests, the LAST one of equal distance (`dist > bestDist` only skips worse candidates) - the geometric tests do not depend on
+// the state of the scan, so this is what the sequential scan returns.
+// The DBoW2 feature vectors arrive as CSR (node ids ascending, node_ptr, node_idx in list order); the fundamental matrix and
+// the epipole are the host's (Eigen: K^-T E K^-1 and quaternion products, MathUtils::computeFundamentalMatrix).
+// Every float / double conversion of the reference is kept (the file is compiled without contraction).
+#include <climits>
+
+#include "gl_internal.hpp"
+
+namespace {
+
+constexpr int T_T = 512;
+
+struct TriP {
+  int N1, N2, NN1, NN2, only_stereo, check_orientation;
+  float sf[8], sigma2[8];
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b) {
+  int d = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) d += __popc(a[w] ^ b[w]);
+  return d;
+}
+
+// largest i with ptr[i] <= a  (the node of list entry a)
+__device__ __forceinline__ int node_of(const int32_t* __restrict__ ptr, int nn, int a) {
+  int lo = 0, hi = nn;  // ptr[lo] <= a < ptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= a) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(T_T) void k_search_for_triangulation(
+    TriP P, int B, const double* __restrict__ uv1_all, const float* __restrict__ ur1_all, const int32_t* __restrict__ oct1_all,
+    const float* __restrict__ angle1_all, const uint8_t* __restrict__ desc1_all, const uint8_t* __restrict__ mp1_all,
+    const int32_t* __restrict__ nn1_all, const int32_t* __restrict__ nid1_all, const int32_t* __restrict__ nptr1_all,
+    const int32_t* __restrict__ nidx1_all, const double* __restrict__ uv2_all, const float* __restrict__ ur2_all,
+    const int32_t* __restrict__ oct2_all, const float* __restrict__ angle2_all, const uint8_t* __restrict__ desc2_all,
+    const uint8_t* __restrict__ mp2_all, const int32_t* __restrict__ nn2_all, const int32_t* __restrict__ nid2_all,
+    const int32_t* __restrict__ nptr2_all, const int32_t* __restrict__ nidx2_all, const double* __restrict__ fmat_all,
+    const float* __restrict__ epi_all, int32_t* __restrict__ match_all, int32_t* __restrict__ nmatches_all) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int N1 = P.N1, N2 = P.N2;
+  int32_t* owner = lds;             // N2: lowest query that picked the feature in the previous round (-1: not available at all)
+  int32_t* owner_n = owner + N2;    // N2: being rebuilt
+  int32_t* choice = owner_n + N2;   // N1 (by query)
+  int32_t* q_idx1 = choice + N1;    // N1: the query's feature of key-frame 1, or -1 (not a query: map point, mono under only-stereo, node not shared)
+  int32_t* q_lo = q_idx1 + N1;      // N1: its partners = node_idx2[q_lo .. q_hi)
+  int32_t* q_hi = q_lo + N1;
+  __shared__ int s_changed, s_hist[32], s_keep[4], s_cnt[T_T / 64];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= B) return;
+  const double* uv1 = uv1_all + (size_t)f * N1 * 2;
+  const float* ur1 = ur1_all + (size_t)f * N1;
+  const int32_t* oct1 = oct1_all + (size_t)f * N1;
+  const uint32_t* desc1 = (const uint32_t*)(desc1_all + (size_t)f * N1 * 32);
+  const uint8_t* mp1 = mp1_all + (size_t)f * N1;
+  const double* uv2 = uv2_all + (size_t)f * N2 * 2;
+  const float* ur2 = ur2_all + (size_t)f * N2;
+  const int32_t* oct2 = oct2_all + (size_t)f * N2;
+  const uint32_t* desc2 = (const uint32_t*)(desc2_all + (size_t)f * N2 * 32);
+  const uint8_t* mp2 = mp2_all + (size_t)f * N2;
+  const int nn1 = min(nn1_all[f], P.NN1), nn2 = min(nn2_all[f], P.NN2);
+  const int32_t* nid1 = nid1_all + (size_t)f * P.NN1;
+  const int32_t* nptr1 = nptr1_all + (size_t)f * (P.NN1 + 1);
+  const int32_t* nidx1 = nidx1_all + (size_t)f * N1;
+  const int32_t* nid2 = nid2_all + (size_t)f * P.NN2;
+  const int32_t* nptr2 = nptr2_all + (size_t)f * (P.NN2 + 1);
+  const int32_t* nidx2 = nidx2_all + (size_t)f * N2;
+  const double* F = fmat_all + (size_t)f * 9;
+  const float ex = epi_all[2 * f], ey = epi_all[2 * f + 1];
+  const int nq = nn1 > 0 ? min(nptr1[nn1], N1) : 0;  // list entries of key-frame 1 = queries, in the reference's visiting order
+
+  // ---- queries: list entry a of key-frame 1 -> its feature and the partner list of the same node in key-frame 2 ----
+  for (int a = tid; a < N1; a += T_T) {
+    int idx1 = -1, lo = 0, hi = 0;
+    if (a < nq) {
+      const int n1 = node_of(nptr1, nn1, a);
+      const int id = nid1[n1];
+      int l = 0, h = nn2;  // lower_bound of id in nid2
+      while (l < h) {
+        const int mid = (l + h) >> 1;
+        if (nid2[mid] < id) l = mid + 1;
+        else h = mid;
+      }
+      if (l < nn2 && nid2[l] == id) {
+        const int i1 = nidx1[a];
+        if (i1 >= 0 && i1 < N1 && oct1[i1] >= 0 && !mp1[i1] && !(P.only_stereo && !(ur1[i1] >= 0))) {
+          idx1 = i1;
+          lo = nptr2[l];
+          hi = min(nptr2[l + 1], N2);
+        }
+      }
+    }
+    q_idx1[a] = idx1;
+    q_lo[a] = lo;
+    q_hi[a] = hi;
+    choice[a] = -1;
+  }
+  for (int i = tid; i < N2; i += T_T) owner[i] = (oct2[i] >= 0 && !mp2[i] && !(P.only_stereo && !(ur2[i] >= 0))) ? INT_MAX : -1;
+  __syncthreads();
+
+  // ---- rounds of the fixed point ------------------------------------------------------------------------------------
+  int rounds = 0;
+  for (;;) {
+    for (int i = tid; i < N2; i += T_T) owner_n[i] = owner[i] < 0 ? -1 : INT_MAX;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int m = tid; m < nq; m += T_T) {
+      const int idx1 = q_idx1[m];
+      int bestIdx2 = -1;
+      if (idx1 >= 0) {
+        const bool bStereo1 = ur1[idx1] >= 0;
+        const double u1 = uv1[2 * idx1], v1 = uv1[2 * idx1 + 1];
+        // checkEpipolarDist: the line of kp1 in key-frame 2
+        const double ea = u1 * F[0] + v1 * F[3] + F[6];
+        const double eb = u1 * F[1] + v1 * F[4] + F[7];
+        const double ec = u1 * F[2] + v1 * F[5] + F[8];
+        const float den = (float)(ea * ea + eb * eb);
+        uint32_t d1[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
+        int bestDist = 50;  // TH_LOW
+        for (int b = q_lo[m]; b < q_hi[m]; ++b) {
+          const int idx2 = nidx2[b];
+          if (idx2 < 0 || idx2 >= N2) continue;
+          if (owner[idx2] < m) continue;  // not available at all (-1), or taken by an earlier feature of key-frame 1
+          const int dist = hamming256(d1, desc2 + (size_t)idx2 * 8);
+          if (dist > 50 || dist > bestDist) continue;
+          const double u2 = uv2[2 * idx2], v2 = uv2[2 * idx2 + 1];
+          const int oc2 = oct2[idx2] & 7;
+          if (!bStereo1 && !(ur2[idx2] >= 0)) {
+            const float distex = (float)((double)ex - u2);
+            const float distey = (float)((double)ey - v2);
+            if (distex * distex + distey * distey < 100.0f * P.sf[oc2]) continue;
+          }
+          const float num = (float)(ea * u2 + eb * v2 + ec);
+          if (den == 0) continue;
+          const float dsqr = num * num / den;
+          if (!((double)dsqr < 3.84 * (double)P.sigma2[oc2])) continue;
+          bestIdx2 = idx2;
+          bestDist = dist;
+        }
+      }
+      choice[m] = bestIdx2;
+      if (bestIdx2 >= 0) atomicMin(&owner_n[bestIdx2], m);
+    }
+    __syncthreads();
+    int ch = 0;
+    for (int i = tid; i < N2; i += T_T) {
+      const int o = owner_n[i];
+      if (o != owner[i]) ch = 1;
+      owner[i] = o;
+    }
+    if (ch) s_changed = 1;
+    __syncthreads();
+    ++rounds;
+    if (!s_changed || rounds > nq + 1) break;
+    __syncthreads();
+  }
+
+  // ---- rotation consistency (:235-246, :264-281, computeThreeMaxima :544-578) ----------------------------------------
+  // (a query keeps its choice iff it owns it: in the fixed point every choice is owned by its query)
+  if (P.check_orientation) {
+    const float* angle1 = angle1_all + (size_t)f * N1;
+    const float* angle2 = angle2_all + (size_t)f * N2;
+    const float factor = 30 / 360.0f;
+    auto bin_of = [&](int m) -> int {
+      float rot = angle1[q_idx1[m]] - angle2[choice[m]];
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == 30) bin = 0;
+      return bin;
+    };
+    if (tid < 32) s_hist[tid] = 0;
+    __syncthreads();
+    for (int m = tid; m < nq; m += T_T)
+      if (choice[m] >= 0) {
+        const int b = bin_of(m);
+        if (b >= 0 && b < 30) atomicAdd(&s_hist[b], 1);
+      }
+    __syncthreads();
+    if (tid == 0) {
+      int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+      for (int i = 0; i < 30; i++) {
+        const int sz = s_hist[i];
+        if (sz > max1) {
+          max3 = max2;
+          max2 = max1;
+          max1 = sz;
+          ind3 = ind2;
+          ind2 = ind1;
+          ind1 = i;
+        } else if (sz > max2) {
+          max3 = max2;
+          max2 = sz;
+          ind3 = ind2;
+          ind2 = i;
+        } else if (sz > max3) {
+          max3 = sz;
+          ind3 = i;
+        }
+      }
+      if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+      } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+      }
+      s_keep[0] = ind1;
+      s_keep[1] = ind2;
+      s_keep[2] = ind3;
+    }
+    __syncthreads();
+    for (int m = tid; m < nq; m += T_T)
+      if (choice[m] >= 0) {
+        const int b = bin_of(m);
+        if (b >= 0 && b < 30 && b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) choice[m] = -1;
+      }
+    __syncthreads();
+  }
+
+  // ---- outputs: matches12 by feature of key-frame 1 ----------------------------------------------------------------
+  int32_t* match = match_all + (size_t)f * N1;
+  for (int i = tid; i < N1; i += T_T) match[i] = -1;
+  __syncthreads();
+  int cnt = 0;
+  for (int m = tid; m < nq; m += T_T)
+    if (q_idx1[m] >= 0 && choice[m] >= 0) {
+      match[q_idx1[m]] = choice[m];
+      ++cnt;
+    }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < T_T / 64; ++w) tot += s_cnt[w];
+    nmatches_all[f] = tot;
+  }
+}
+
+}  // namespace
+
+extern "C" int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1, int N2, int NN1, int NN2,
+                                           const double* uv1_dev, const float* ur1_dev, const int32_t* oct1_dev, const float* angle1_dev,
+                                           const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev,
+                                           const int32_t* node_id1_dev, const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev,
+                                           const double* uv2_dev, const float* ur2_dev, const int32_t* oct2_dev, const float* angle2_dev,
+                                           const uint8_t* desc2_dev, const uint8_t* has_mp2_dev, const int32_t* nnode2_dev,
+                                           const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
+                                           const double* fmat_dev, const float* epipole_dev, int only_stereo, int check_orientation,
+                                           int32_t* match12_dev, int32_t* nmatches_dev) {
+  GL_REQUIRE(ctx, "null context");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && N1 >= 1 && N2 >= 1 && NN1 >= 1 && NN2 >= 1, "bad B / N1 / N2 / NN1 / NN2");
+  GL_REQUIRE(N1 <= 4096 && N2 <= 4096, "N1 / N2 above the on-chip capacity (4096 features per key-frame)");
+  GL_REQUIRE(uv1_dev && ur1_dev && oct1_dev && angle1_dev && desc1_dev && has_mp1_dev && nnode1_dev && node_id1_dev && node_ptr1_dev &&
+                 node_idx1_dev && uv2_dev && ur2_dev && oct2_dev && angle2_dev && desc2_dev && has_mp2_dev && nnode2_dev && node_id2_dev &&
+                 node_ptr2_dev && node_idx2_dev && fmat_dev && epipole_dev && match12_dev && nmatches_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  TriP P;
+  P.N1 = N1;
+  P.N2 = N2;
+  P.NN1 = NN1;
+  P.NN2 = NN2;
+  P.only_stereo = only_stereo;
+  P.check_orientation = check_orientation;
+  P.sf[0] = 1.0f;  // init_config.hpp:63-79
+  P.sigma2[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) {
+    P.sf[i] = P.sf[i - 1] * scale_factor;
+    P.sigma2[i] = P.sf[i] * P.sf[i];
+  }
+  const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1) * sizeof(int32_t);
+  GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_for_triangulation, lds));
+  k_search_for_triangulation<<<B, T_T, lds, c->stream>>>(P, B, uv1_dev, ur1_dev, oct1_dev, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
+                                                        node_id1_dev, node_ptr1_dev, node_idx1_dev, uv2_dev, ur2_dev, oct2_dev, angle2_dev,
+                                                        desc2_dev, has_mp2_dev, nnode2_dev, node_id2_dev, node_ptr2_dev, node_idx2_dev, fmat_dev,
+                                                        epipole_dev, match12_dev, nmatches_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}

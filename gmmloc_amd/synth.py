@@ -279,3 +279,91 @@ def synth_tri_matches(mean, cov, pose1, pose2, cam, N, seed, K_cand=5, allowed=N
     return dict(pose1=np.tile(pose1, (N, 1)), uvr1=k1, depth1=d1, oct1=o1, pose2=np.tile(pose2, (N, 1)), uvr2=k2,
                 depth2=d2, oct2=o2, cand1=c1, n1=(c1 >= 0).sum(1).astype(np.int32), cand2=c2,
                 n2=(c2 >= 0).sum(1).astype(np.int32))
+
+
+def fundamental_and_epipole(pose1, pose2, cam):
+    """MathUtils::computeFundamentalMatrix(Tcw1, K1, Tcw2, K2) (math_utils.cpp:16-43) and the epipole of
+    searchForTriangulation (orb_matcher.cpp:155-160; the reference maps Tcw1.translation(), not kf1's camera centre, into
+    kf2 - kept) - the host's part of gl_search_for_triangulation's inputs (plain fp64 here; Eigen in the reference host)."""
+    R1, t1 = quat_to_R(pose1[:4]), pose1[4:]
+    R2, t2 = quat_to_R(pose2[:4]), pose2[4:]
+    R12 = R1 @ R2.T
+    t12 = -(R12 @ t2) + t1
+    sk = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    E = sk @ R12
+    fx, fy, cx, cy = (float(np.float32(v)) for v in (cam.fx, cam.fy, cam.cx, cam.cy))  # (config.h: float scalars)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    F = np.linalg.inv(K.T) @ E @ np.linalg.inv(K)
+    C2 = R2 @ t1 + t2
+    invz = np.float32(1.0) / np.float32(C2[2])
+    ex = np.float32(fx * C2[0] * invz + cx)
+    ey = np.float32(fy * C2[1] * invz + cy)
+    return F, np.array([ex, ey], np.float32)
+
+
+def synth_tri_search_pair(N1, N2, seed, cam, n_nodes=160, only_stereo_frac=0.6, pad=0):
+    """Inputs of ORBmatcher::searchForTriangulation for one key-frame pair: two key-frames a short baseline apart that see the
+    same 3-D points (pixel noise, descriptor bit flips, mostly the same vocabulary node: DBoW2 words of the same patch agree
+    at the feature-vector level most of the time), distractor features, features that already have map points, a dominant
+    rotation bin with outliers; the two feature vectors as CSR (node ids ascending, feature indices ascending inside a node:
+    DBoW2 appends them in index order).  Nodes are few and crowded, so that features compete for the same partner (the
+    order-dependent part of the reference loop) and equal descriptor distances occur."""
+    rng = np.random.default_rng(seed)
+    W, H = cam.width, cam.height
+    pose1 = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    ang = np.deg2rad(rng.uniform(-3, 3))
+    pose2 = np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2), rng.uniform(0.1, 0.3), rng.uniform(-0.05, 0.05), rng.uniform(-0.1, 0.1)])
+    NP = max(N1, N2)
+    depth = rng.uniform(1.5, 9.0, NP)
+    u1, v1 = rng.uniform(10, W - 10, NP), rng.uniform(10, H - 10, NP)
+    X = np.stack([(u1 - cam.cx) / cam.fx * depth, (v1 - cam.cy) / cam.fy * depth, depth], 1)
+    R2, t2 = quat_to_R(pose2[:4]), pose2[4:]
+    pc2 = X @ R2.T + t2
+    u2 = cam.fx * pc2[:, 0] / pc2[:, 2] + cam.cx
+    v2 = cam.fy * pc2[:, 1] / pc2[:, 2] + cam.cy
+    base_desc = rng.integers(0, 256, (NP, 32), dtype=np.uint8)
+    base_node = rng.integers(0, n_nodes, NP) * 7 + 3  # sparse node ids
+    base_oct = rng.integers(0, 8, NP)
+    base_angle = rng.uniform(0, 360, NP)
+    sf = 1.2 ** np.arange(8)
+
+    def view(N, u, v, z, rot, sd):
+        r = np.random.default_rng(sd)
+        src = r.permutation(NP)[:N] if N <= NP else r.integers(0, NP, N)
+        ndup = int(0.15 * N)  # several features of the SAME point (neighbouring pyramid levels do that): rivals for one partner
+        src[r.integers(0, N, ndup)] = src[r.integers(0, N, ndup)]
+        real = r.uniform(size=N) < 0.75
+        octv = np.clip(base_oct[src] + r.integers(-1, 2, N), 0, 7).astype(np.int32)
+        noise = r.normal(0, 0.6, (N, 2)) * sf[octv][:, None]
+        gross = r.uniform(size=N) < 0.08  # off the epipolar line
+        noise[gross] += r.uniform(-25, 25, (int(gross.sum()), 2))
+        uv = np.where(real[:, None], np.stack([u[src], v[src]], 1) + noise, np.stack([r.uniform(0, W, N), r.uniform(0, H, N)], 1))
+        stereo = r.uniform(size=N) < only_stereo_frac
+        ur = np.where(stereo, uv[:, 0] - cam.bf / np.maximum(z[src], 0.1), -1.0).astype(np.float32)
+        desc = base_desc[src].copy()
+        nflip = r.choice([0, 4, 8, 8, 12, 16, 16, 24, 40, 60], N)  # few distinct values: equal distances happen
+        for i in range(N):
+            if real[i]:
+                bits = r.choice(256, nflip[i], replace=False)
+                np.bitwise_xor.at(desc[i], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+            else:
+                desc[i] = r.integers(0, 256, 32, dtype=np.uint8)
+        node = np.where(real & (r.uniform(size=N) < 0.85), base_node[src], r.integers(0, n_nodes, N) * 7 + 3)
+        out_rot = r.uniform(size=N) < 0.12
+        angle = np.where(out_rot, r.uniform(0, 360, N), (base_angle[src] + rot + r.normal(0, 3, N)) % 360.0).astype(np.float32)
+        has_mp = (r.uniform(size=N) < 0.3).astype(np.uint8)
+        if pad:
+            octv[r.uniform(size=N) < 0.02] = -1
+        ids = np.unique(node[octv >= 0])
+        ptr, idx = [0], []
+        for n in ids:
+            members = np.nonzero((node == n) & (octv >= 0))[0]
+            idx.extend(members.tolist())
+            ptr.append(len(idx))
+        return dict(uv=uv, ur=ur, oct=octv, angle=angle, desc=desc, has_mp=has_mp, node_id=ids.astype(np.int32),
+                    node_ptr=np.array(ptr, np.int32), node_idx=np.array(idx, np.int32))
+
+    kf1 = view(N1, u1, v1, depth, 0.0, seed * 2 + 1)
+    kf2 = view(N2, u2, v2, pc2[:, 2], -14.0, seed * 2 + 2)
+    fmat, epi = fundamental_and_epipole(pose1, pose2, cam)
+    return dict(kf1=kf1, kf2=kf2, fmat=fmat, epipole=epi, pose1=pose1, pose2=pose2)

@@ -272,6 +272,29 @@ int gl_search_by_projection_frame(gl_ctx_t* ctx, const gl_camera* cam, float sca
                                   const uint8_t* last_valid_dev, const int32_t* last_oct_dev,
                                   const float* last_angle_dev, const uint8_t* last_desc_dev, float th, int mono,
                                   int check_orientation, int32_t* feat_match_dev, int32_t* nmatches_dev);
+/* ORBmatcher::searchForTriangulation (orb_matcher.cpp:141-293) with checkEpipolarDist (:119-139) and the rotation histogram
+ * (computeThreeMaxima, :544-578) for B key-frame pairs: the matches Localization::createMapPoints triangulates
+ * (localization_opt.cpp:266).  Per pair and key-frame k = 1, 2 (strides N1 / N2 features, NN1 / NN2 vocabulary nodes):
+ *   uv{k}_dev B x N x 2 double, ur{k}_dev B x N float (u_right, < 0: mono), oct{k}_dev B x N int32 (< 0: padding slot),
+ *   angle{k}_dev B x N float (key-point angle, degrees), desc{k}_dev B x N x 32 uint8, has_mp{k}_dev B x N uint8 (the feature
+ *   already has a map point: getMapPoint(idx) != nullptr);
+ *   the DBoW2::FeatureVector of the key-frame as CSR: nnode{k}_dev B int32 (nodes in use), node_id{k}_dev B x NN int32
+ *   ASCENDING (std::map order), node_ptr{k}_dev B x (NN + 1) int32, node_idx{k}_dev B x N int32 (feature indices, list order);
+ *   fmat_dev B x 9 double: MathUtils::computeFundamentalMatrix(Tcw1, K1, Tcw2, K2), row-major; epipole_dev B x 2 float:
+ *   (ex, ey) of :155-160 - both built by the host (Eigen there), see INTEGRATION.md;
+ *   scale_factor: frame::scale_factor (the level tables of init_config.hpp:63-79 are rebuilt from it);
+ *   only_stereo: bOnlyStereo; check_orientation: ORBmatcher::check_orientation_.
+ * out: match12_dev B x N1 int32 = matches12 (feature of key-frame 2 or -1; `matched_pairs` = its non-negative entries in
+ * index order), nmatches_dev B int32 (the return value).  Order-exact: the same pairs as the sequential loop. */
+int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1, int N2, int NN1, int NN2,
+                                const double* uv1_dev, const float* ur1_dev, const int32_t* oct1_dev, const float* angle1_dev,
+                                const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev,
+                                const int32_t* node_id1_dev, const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev,
+                                const double* uv2_dev, const float* ur2_dev, const int32_t* oct2_dev, const float* angle2_dev,
+                                const uint8_t* desc2_dev, const uint8_t* has_mp2_dev, const int32_t* nnode2_dev,
+                                const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
+                                const double* fmat_dev, const float* epipole_dev, int only_stereo, int check_orientation,
+                                int32_t* match12_dev, int32_t* nmatches_dev);
 
 /* ---- point refinement ----------------------------------------------------- */
 /* GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N independent problems.

@@ -1425,6 +1425,135 @@ int orc_search_by_projection_frame(const orc_camera* cam, float scale_factor, co
   return nmatches;
 }
 
+// ORBmatcher::searchForTriangulation (orb_matcher.cpp:141-293) with checkEpipolarDist (:119-139) and computeThreeMaxima
+// (:544-578), one key-frame pair: the producer of createMapPoints' matches (localization_opt.cpp:266).
+// The two DBoW2::FeatureVector maps (node id -> feature indices, std::map: ascending node id) arrive as CSR: node_id ascending,
+// node_ptr (nn + 1), node_idx in list order.  fmat = MathUtils::computeFundamentalMatrix(Tcw1, K1, Tcw2, K2) (row-major) and the
+// epipole (ex, ey) of :155-160 are inputs: they are built with the host's Eigen (K^-T E K^-1, quaternion products) and are not
+// part of this path.  has_mp: the feature already has a map point (getMapPoint(idx) != nullptr).  match12: N1, idx2 or -1.
+int orc_search_for_triangulation(float scale_factor, int N1, const double* uv1, const float* ur1, const int32_t* oct1, const float* angle1,
+                                 const uint8_t* desc1, const uint8_t* has_mp1, int nn1, const int32_t* node_id1, const int32_t* node_ptr1,
+                                 const int32_t* node_idx1, int N2, const double* uv2, const float* ur2, const int32_t* oct2,
+                                 const float* angle2, const uint8_t* desc2, const uint8_t* has_mp2, int nn2, const int32_t* node_id2,
+                                 const int32_t* node_ptr2, const int32_t* node_idx2, const double* fmat, const float* epipole,
+                                 int only_stereo, int check_orientation, int32_t* match12) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;  // orb_matcher.cpp:21-22
+  float scale_factors[8], sigma2[8];          // init_config.hpp:63-79
+  scale_factors[0] = 1.0f;
+  sigma2[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) {
+    scale_factors[i] = scale_factors[i - 1] * scale_factor;
+    sigma2[i] = scale_factors[i] * scale_factors[i];
+  }
+  const float ex = epipole[0], ey = epipole[1];
+  auto F = [&](int r, int c) { return fmat[r * 3 + c]; };
+  int nmatches = 0;
+  std::vector<bool> matched2(N2, false);
+  for (int i = 0; i < N1; ++i) match12[i] = -1;
+  std::vector<int> rotHist[30];
+  const float factor = HISTO_LENGTH / 360.0f;
+  int i1n = 0, i2n = 0;
+  while (i1n < nn1 && i2n < nn2) {
+    if (node_id1[i1n] == node_id2[i2n]) {
+      for (int a = node_ptr1[i1n]; a < node_ptr1[i1n + 1]; ++a) {
+        const int idx1 = node_idx1[a];
+        if (has_mp1[idx1]) continue;
+        const bool bStereo1 = ur1[idx1] >= 0;
+        if (only_stereo && !bStereo1) continue;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int b = node_ptr2[i2n]; b < node_ptr2[i2n + 1]; ++b) {
+          const int idx2 = node_idx2[b];
+          if (matched2[idx2] || has_mp2[idx2]) continue;
+          const bool bStereo2 = ur2[idx2] >= 0;
+          if (only_stereo && !bStereo2) continue;
+          const int32_t* pa = (const int32_t*)(desc1 + (size_t)idx1 * 32);
+          const int32_t* pb = (const int32_t*)(desc2 + (size_t)idx2 * 32);
+          int dist = 0;
+          for (int w = 0; w < 8; ++w) {  // DescriptorDistance (:580-596)
+            unsigned int vv = pa[w] ^ pb[w];
+            vv = vv - ((vv >> 1) & 0x55555555);
+            vv = (vv & 0x33333333) + ((vv >> 2) & 0x33333333);
+            dist += (((vv + (vv >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+          }
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const double u2 = uv2[2 * idx2], v2 = uv2[2 * idx2 + 1];
+          if (!bStereo1 && !bStereo2) {
+            const float distex = ex - u2;
+            const float distey = ey - v2;
+            if (distex * distex + distey * distey < 100 * scale_factors[oct2[idx2]]) continue;
+          }
+          {  // checkEpipolarDist(kp1, kp2, fmat)
+            const double u1 = uv1[2 * idx1], v1 = uv1[2 * idx1 + 1];
+            const double ea = u1 * F(0, 0) + v1 * F(1, 0) + F(2, 0);
+            const double eb = u1 * F(0, 1) + v1 * F(1, 1) + F(2, 1);
+            const double ec = u1 * F(0, 2) + v1 * F(1, 2) + F(2, 2);
+            const float num = ea * u2 + eb * v2 + ec;
+            const float den = ea * ea + eb * eb;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if (!(dsqr < 3.84 * sigma2[oct2[idx2]])) continue;
+          }
+          bestIdx2 = idx2;
+          bestDist = dist;
+        }
+        if (bestIdx2 >= 0) {
+          match12[idx1] = bestIdx2;
+          matched2[bestIdx2] = true;
+          nmatches++;
+          if (check_orientation) {
+            float rot = angle1[idx1] - angle2[bestIdx2];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(idx1);  // (assert in the reference)
+          }
+        }
+      }
+      ++i1n;
+      ++i2n;
+    } else if (node_id1[i1n] < node_id2[i2n]) {
+      i1n = (int)(std::lower_bound(node_id1, node_id1 + nn1, node_id2[i2n]) - node_id1);
+    } else {
+      i2n = (int)(std::lower_bound(node_id2, node_id2 + nn2, node_id1[i1n]) - node_id2);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int sz = rotHist[i].size();
+      if (sz > max1) {
+        max3 = max2;
+        max2 = max1;
+        max1 = sz;
+        ind3 = ind2;
+        ind2 = ind1;
+        ind1 = i;
+      } else if (sz > max2) {
+        max3 = max2;
+        max2 = sz;
+        ind3 = ind2;
+        ind2 = i;
+      } else if (sz > max3) {
+        max3 = sz;
+        ind3 = i;
+      }
+    }
+    if (max2 < 0.1f * (float)max1) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+      ind3 = -1;
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) {
+          match12[idx] = -1;
+          nmatches--;
+        }
+  }
+  return nmatches;
+}
+
 void orc_se3_exp(const double* u, double* pose) { from_se3(se3_exp(u), pose); }
 void orc_se3_log(const double* pose, double* u) { se3_log(to_se3(pose), u); }
 void orc_se3_mul(const double* a, const double* b, double* out) { from_se3(se3_mul(to_se3(a), to_se3(b)), out); }

@@ -892,3 +892,88 @@ def search_by_projection_frame(cam, pose_cw, pose_lw, feat_uv, feat_ur, feat_oct
             if b not in (i1, i2, i3):
                 match[idx] = -1
     return match, int((match >= 0).sum())
+
+
+def search_for_triangulation(kf1, kf2, fmat, epipole, only_stereo=False, check_orientation=True, scale_factor=1.2):
+    """ORBmatcher::searchForTriangulation (orb_matcher.cpp:141-293) + checkEpipolarDist (:119-139), independent restatement:
+    the two feature vectors as python dicts (node -> list), table popcount, every candidate's geometric tests evaluated as
+    vectors up front (they do not depend on the state of the loop), the selection itself as the literal double loop."""
+    f32 = np.float32
+    sf = [f32(1.0)]
+    for _ in range(7):
+        sf.append(f32(sf[-1] * f32(scale_factor)))
+    sf = np.array(sf, f32)
+    sigma2 = (sf * sf).astype(f32)
+    fv1 = {int(n): kf1["node_idx"][kf1["node_ptr"][i]:kf1["node_ptr"][i + 1]] for i, n in enumerate(kf1["node_id"])}
+    fv2 = {int(n): kf2["node_idx"][kf2["node_ptr"][i]:kf2["node_ptr"][i + 1]] for i, n in enumerate(kf2["node_id"])}
+    N1, N2 = len(kf1["oct"]), len(kf2["oct"])
+    st1, st2 = kf1["ur"] >= 0, kf2["ur"] >= 0
+    F = np.asarray(fmat, np.float64).reshape(3, 3)
+    ex, ey = f32(epipole[0]), f32(epipole[1])
+    # per kf2 feature: squared distance to the epipole (float), its threshold, and the chi2 bound of the epipolar test
+    dex = (np.float64(ex) - kf2["uv"][:, 0]).astype(f32)
+    dey = (np.float64(ey) - kf2["uv"][:, 1]).astype(f32)
+    oc2 = np.maximum(kf2["oct"], 0)
+    near_epipole = (dex * dex + dey * dey) < (f32(100) * sf[oc2])
+    bound = np.float64(3.84) * sigma2[oc2].astype(np.float64)
+    matched2 = np.zeros(N2, bool)
+    match = -np.ones(N1, np.int32)
+    rot_bin = {}
+    rnd = lambda v: float(np.floor(v + 0.5)) if v >= 0 else float(np.ceil(v - 0.5))
+    for node in sorted(set(fv1) & set(fv2)):
+        for idx1 in fv1[node]:
+            idx1 = int(idx1)
+            if kf1["has_mp"][idx1] or (only_stereo and not st1[idx1]):
+                continue
+            u1, v1 = kf1["uv"][idx1]
+            a = u1 * F[0, 0] + v1 * F[1, 0] + F[2, 0]
+            b = u1 * F[0, 1] + v1 * F[1, 1] + F[2, 1]
+            c = u1 * F[0, 2] + v1 * F[1, 2] + F[2, 2]
+            den = f32(a * a + b * b)
+            best, bidx = 50, -1
+            for idx2 in fv2[node]:
+                idx2 = int(idx2)
+                if matched2[idx2] or kf2["has_mp"][idx2] or (only_stereo and not st2[idx2]):
+                    continue
+                d = int(_POP8[np.bitwise_xor(kf1["desc"][idx1], kf2["desc"][idx2])].sum())
+                if d > 50 or d > best:
+                    continue
+                if not st1[idx1] and not st2[idx2] and near_epipole[idx2]:
+                    continue
+                num = f32(a * kf2["uv"][idx2, 0] + b * kf2["uv"][idx2, 1] + c)
+                if den == 0:
+                    continue
+                with np.errstate(over="ignore"):
+                    dsqr = f32(f32(num * num) / den)
+                if not (np.float64(dsqr) < bound[idx2]):
+                    continue
+                best, bidx = d, idx2
+            if bidx >= 0:
+                match[idx1] = bidx
+                matched2[bidx] = True
+                if check_orientation:
+                    rot = f32(f32(kf1["angle"][idx1]) - f32(kf2["angle"][bidx]))
+                    if rot < 0.0:
+                        rot = f32(rot + f32(360.0))
+                    bb = int(rnd(float(f32(rot * f32(f32(30) / f32(360.0))))))
+                    rot_bin[idx1] = 0 if bb == 30 else bb
+    if check_orientation and rot_bin:
+        cnt = np.bincount(np.array(list(rot_bin.values())), minlength=30)
+        m1 = m2 = m3 = 0
+        i1 = i2 = i3 = -1
+        for bb in range(30):
+            cc = int(cnt[bb])
+            if cc > m1:
+                m3, m2, m1, i3, i2, i1 = m2, m1, cc, i2, i1, bb
+            elif cc > m2:
+                m3, m2, i3, i2 = m2, cc, i2, bb
+            elif cc > m3:
+                m3, i3 = cc, bb
+        if m2 < f32(0.1) * f32(m1):
+            i2 = i3 = -1
+        elif m3 < f32(0.1) * f32(m1):
+            i3 = -1
+        for idx, bb in rot_bin.items():
+            if bb not in (i1, i2, i3):
+                match[idx] = -1
+    return match, int((match >= 0).sum())

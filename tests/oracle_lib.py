@@ -224,6 +224,25 @@ class Oracle:
                                                     int(bool(check_orientation)), _p(out))
         return out, int(n)
 
+    def search_for_triangulation(self, kf1, kf2, fmat, epipole, only_stereo=False, check_orientation=True, scale_factor=1.2):
+        """ORBmatcher::searchForTriangulation on one key-frame pair (dicts: uv, ur, oct, angle, desc, has_mp, node_id,
+        node_ptr, node_idx) -> (match12 [N1], nmatches)."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        args = []
+        keep = []
+        for kf in (kf1, kf2):
+            arrs = [_f64(kf["uv"]), f32(kf["ur"]), _i32(kf["oct"]), f32(kf["angle"]), u8(kf["desc"]), u8(kf["has_mp"]),
+                    _i32(kf["node_id"]), _i32(kf["node_ptr"]), _i32(kf["node_idx"])]
+            keep.append(arrs)
+            args += [arrs[0].shape[0]] + [_p(a) for a in arrs[:6]] + [len(arrs[6])] + [_p(a) for a in arrs[6:]]
+        fm, ep = _f64(fmat), f32(epipole)
+        out = np.zeros(keep[0][0].shape[0], np.int32)
+        self.lib.orc_search_for_triangulation.restype = C.c_int
+        n = self.lib.orc_search_for_triangulation(C.c_float(scale_factor), *args, _p(fm), _p(ep), int(bool(only_stereo)),
+                                                  int(bool(check_orientation)), _p(out))
+        return out, int(n)
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

@@ -121,3 +121,73 @@ def test_search_by_projection_frame_matches_oracle(gpu, oracle, NF, NL, th, moti
         assert np.array_equal(m[b], m_ref), (b, int((m[b] != m_ref).sum()))
         tot += n_ref
     assert tot > 50
+
+
+def _pack_pairs(torch, pairs):
+    """list of synth_tri_search_pair dicts -> the batched CUDA tensors of api.search_for_triangulation (strides = the maxima)"""
+    N1 = max(len(p["kf1"]["oct"]) for p in pairs)
+    N2 = max(len(p["kf2"]["oct"]) for p in pairs)
+    out = []
+    for key, N in (("kf1", N1), ("kf2", N2)):
+        NN = max(len(p[key]["node_id"]) for p in pairs)
+        B = len(pairs)
+        t = dict(uv=np.zeros((B, N, 2)), ur=np.full((B, N), -1.0, np.float32), oct=np.full((B, N), -1, np.int32), angle=np.zeros((B, N), np.float32),
+                 desc=np.zeros((B, N, 32), np.uint8), has_mp=np.zeros((B, N), np.uint8), nnode=np.zeros(B, np.int32),
+                 node_id=np.zeros((B, NN), np.int32), node_ptr=np.zeros((B, NN + 1), np.int32), node_idx=np.zeros((B, N), np.int32))
+        for b, p in enumerate(pairs):
+            k = p[key]
+            n, nn = len(k["oct"]), len(k["node_id"])
+            for name in ("uv", "ur", "oct", "angle", "desc", "has_mp"):
+                t[name][b, :n] = k[name]
+            t["nnode"][b] = nn
+            t["node_id"][b, :nn] = k["node_id"]
+            t["node_ptr"][b, :nn + 1] = k["node_ptr"]
+            t["node_ptr"][b, nn + 1:] = k["node_ptr"][-1]
+            t["node_idx"][b, :len(k["node_idx"])] = k["node_idx"]
+        out.append({name: torch.from_numpy(v).cuda() for name, v in t.items()})
+    fm = torch.from_numpy(np.stack([p["fmat"].reshape(9) for p in pairs])).cuda()
+    ep = torch.from_numpy(np.stack([p["epipole"] for p in pairs]).astype(np.float32)).cuda()
+    return out[0], out[1], fm, ep
+
+
+@pytest.mark.parametrize("only_stereo,check_orientation", [(False, True), (True, True), (False, False)])
+def test_search_for_triangulation_matches_oracle(gpu, oracle, only_stereo, check_orientation):
+    """gl_search_for_triangulation (ORBmatcher::searchForTriangulation, orb_matcher.cpp:141-293) against the sequential oracle:
+    matches12 bit for bit - crowded nodes with rival features (the order-dependent hand-over), equal descriptor distances
+    (last one wins), mono / stereo mixes, padding slots, pairs of different sizes in one batch, the rotation histogram."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    pairs = [synth.synth_tri_search_pair(N1, N2, 400 + i, cam, n_nodes=nodes, pad=1)
+             for i, (N1, N2, nodes) in enumerate(((300, 350, 60), (1200, 1100, 200), (700, 900, 25), (64, 70, 5), (2000, 1900, 300), (500, 40, 80)))]
+    k1, k2, fm, ep = _pack_pairs(torch, pairs)
+    match, nm = api.search_for_triangulation(ctx, k1, k2, fm, ep, only_stereo, check_orientation)
+    torch.cuda.synchronize()
+    match, nm = match.cpu().numpy(), nm.cpu().numpy()
+    total = 0
+    for b, p in enumerate(pairs):
+        m_ref, n_ref = oracle.search_for_triangulation(p["kf1"], p["kf2"], p["fmat"], p["epipole"], only_stereo, check_orientation)
+        n1 = len(m_ref)
+        assert np.array_equal(match[b, :n1], m_ref), (b, int((match[b, :n1] != m_ref).sum()))
+        assert (match[b, n1:] == -1).all() and nm[b] == n_ref
+        total += n_ref
+    assert total > 100
+
+
+def test_search_for_triangulation_soak(gpu, oracle):
+    """200 random key-frame pairs (sizes, node counts, stereo fractions): every match equal to the oracle's."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    rng = np.random.default_rng(77)
+    pairs = [synth.synth_tri_search_pair(int(rng.integers(20, 1400)), int(rng.integers(20, 1400)), 5000 + i, cam, n_nodes=int(rng.integers(3, 250)),
+                                         only_stereo_frac=float(rng.uniform(0.0, 1.0)), pad=int(rng.integers(0, 2))) for i in range(200)]
+    k1, k2, fm, ep = _pack_pairs(torch, pairs)
+    checked = 0
+    for only_stereo, chk in ((False, True), (True, False)):
+        match, nm = api.search_for_triangulation(ctx, k1, k2, fm, ep, only_stereo, chk)
+        torch.cuda.synchronize()
+        match, nm = match.cpu().numpy(), nm.cpu().numpy()
+        for b, p in enumerate(pairs):
+            m_ref, n_ref = oracle.search_for_triangulation(p["kf1"], p["kf2"], p["fmat"], p["epipole"], only_stereo, chk)
+            assert np.array_equal(match[b, :len(m_ref)], m_ref) and nm[b] == n_ref, (b, only_stereo, chk)
+            checked += n_ref
+    assert checked > 5000

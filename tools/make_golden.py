@@ -234,6 +234,17 @@ def main():
         out["f%d_match" % i] = m
         out["f%d_n" % i] = np.array(n)
     np.savez_compressed(os.path.join(G, "golden_match.npz"), **out)
+
+    # ---- searchForTriangulation: key-frame pairs through the independent numpy restatement (inputs regenerated from the seeds)
+    out = {}
+    for i, (N1, N2, seed, only_stereo, chk, nodes) in enumerate(((300, 350, 201, 0, 1, 60), (700, 650, 202, 0, 1, 120), (500, 500, 203, 1, 1, 90),
+                                                                 (400, 450, 204, 0, 0, 40))):
+        pr = synth.synth_tri_search_pair(N1, N2, seed, CamF, n_nodes=nodes, pad=1)
+        m, n = nr.search_for_triangulation(pr["kf1"], pr["kf2"], pr["fmat"], pr["epipole"], bool(only_stereo), bool(chk))
+        out["t%d_args" % i] = np.array([N1, N2, seed, only_stereo, chk, nodes])
+        out["t%d_match" % i] = m
+        out["t%d_n" % i] = np.array(n)
+    np.savez_compressed(os.path.join(G, "golden_tri_match.npz"), **out)
     print("golden vectors written to", G)
 
 
