@@ -513,6 +513,34 @@ def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, ch
     return match, nm
 
 
+def gather_triangulation_matches(ctx, match12, nmatches, side1, side2, cap=None):
+    """gl_gather_triangulation_matches: the matches of search_for_triangulation as the per-match arrays of create_map_points.
+    side1 / side2: dicts of CUDA tensors pose (B,7), uv (B,N,2), ur (B,N) f32, depth (B,N) f32, oct (B,N) i32, cand (B,N,k) i32,
+    ncand (B,N) i32.  Returns (pair_off (B+1,), dict of the per-match tensors with `cap` rows)."""
+    import torch
+    B, N1 = match12.shape
+    N2 = side2["oct"].shape[1]
+    k = side1["cand"].shape[2]
+    cap = cap or B * min(N1, N2)
+    dev = match12.device
+    off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    m = dict(pose1=torch.zeros((cap, 7), dtype=torch.float64, device=dev), uvr1=torch.zeros((cap, 3), dtype=torch.float64, device=dev),
+             depth1=torch.zeros(cap, dtype=torch.float32, device=dev), oct1=torch.zeros(cap, dtype=torch.int32, device=dev),
+             cand1=torch.zeros((cap, k), dtype=torch.int32, device=dev), n1=torch.zeros(cap, dtype=torch.int32, device=dev),
+             pose2=torch.zeros((cap, 7), dtype=torch.float64, device=dev), uvr2=torch.zeros((cap, 3), dtype=torch.float64, device=dev),
+             depth2=torch.zeros(cap, dtype=torch.float32, device=dev), oct2=torch.zeros(cap, dtype=torch.int32, device=dev),
+             cand2=torch.zeros((cap, k), dtype=torch.int32, device=dev), n2=torch.zeros(cap, dtype=torch.int32, device=dev),
+             pair=torch.full((cap,), -1, dtype=torch.int32, device=dev), idx1=torch.full((cap,), -1, dtype=torch.int32, device=dev),
+             idx2=torch.full((cap,), -1, dtype=torch.int32, device=dev))
+    keys = ("pose", "uv", "ur", "depth", "oct", "cand", "ncand")
+    ctx._enter()
+    _check(ctx.lib.gl_gather_triangulation_matches(
+        ctx.h, B, N1, N2, k, cap, _ptr(match12), _ptr(nmatches), *[_ptr(side1[q]) for q in keys], *[_ptr(side2[q]) for q in keys], _ptr(off),
+        *[_ptr(m[q]) for q in ("pose1", "uvr1", "depth1", "oct1", "cand1", "n1", "pose2", "uvr2", "depth2", "oct2", "cand2", "n2", "pair", "idx1", "idx2")]))
+    ctx._exit()
+    return off, m
+
+
 def create_map_points(ctx, gmm, cam, prm, pose1, uvr1, depth1, oct1, pose2, uvr2, depth2, oct2, cand1, n1, cand2, n2,
                       scale_factor=1.2):
     """Localization::createMapPoints per-match block (localization_opt.cpp:286-420), N matches ->

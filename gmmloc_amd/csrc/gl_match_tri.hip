@@ -258,7 +258,137 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
   }
 }
 
+// ---- matches -> the per-match arrays of gl_create_map_points, on the device ----------------------------------------------
+// Localization::createMapPoints walks matched_pairs (ascending feature index of key-frame 1) and reads, per match, the two
+// key-frames' poses, key-points (u, v, u_right), depths, octaves and candidate components (kf->comps_[idx], localization_opt.cpp:
+// 286-420).  k_tri_offsets: exclusive scan of the pairs' match counts; k_tri_gather: one workgroup per pair compacts its matches
+// in index order behind the pair's offset.
+__global__ __launch_bounds__(256) void k_tri_offsets(int B, const int32_t* __restrict__ nmatches, int32_t* __restrict__ pair_off) {
+  __shared__ int s_part[256];
+  const int tid = threadIdx.x, per = (B + 255) / 256, b0 = tid * per, b1 = min(B, b0 + per);
+  int s = 0;
+  for (int b = b0; b < b1; ++b) s += max(nmatches[b], 0);
+  s_part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = s_part[t];
+      s_part[t] = run;
+      run += v;
+    }
+    pair_off[B] = run;
+  }
+  __syncthreads();
+  int run = s_part[tid];
+  for (int b = b0; b < b1; ++b) {
+    pair_off[b] = run;
+    run += max(nmatches[b], 0);
+  }
+}
+
+struct TriKf {  // one key-frame side of the gather (strides N, k candidates)
+  const double* pose;    // B x 7
+  const double* uv;      // B x N x 2
+  const float* ur;       // B x N
+  const float* depth;    // B x N
+  const int32_t* oct;    // B x N
+  const int32_t* cand;   // B x N x k
+  const int32_t* ncand;  // B x N
+};
+struct TriOut {
+  double* pose;
+  double* uvr;
+  float* depth;
+  int32_t* oct;
+  int32_t* cand;
+  int32_t* ncand;
+};
+
+__global__ __launch_bounds__(256) void k_tri_gather(int B, int N1, int N2, int k, int cap, const int32_t* __restrict__ match_all,
+                                                    const int32_t* __restrict__ pair_off, TriKf a, TriKf b, TriOut oa, TriOut ob,
+                                                    int32_t* __restrict__ pair_of, int32_t* __restrict__ idx1_of, int32_t* __restrict__ idx2_of) {
+  __shared__ int s_w[4], s_base;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (f >= B) return;
+  const int32_t* match = match_all + (size_t)f * N1;
+  if (tid == 0) s_base = pair_off[f];
+  __syncthreads();
+  for (int i0 = 0; i0 < N1; i0 += 256) {
+    const int i = i0 + tid;
+    const int j = i < N1 ? match[i] : -1;
+    const bool on = j >= 0 && j < N2;
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_w[w];
+    const int at = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (on && at < cap) {
+      const size_t g1 = (size_t)f * N1 + i, g2 = (size_t)f * N2 + j;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        oa.pose[(size_t)at * 7 + r] = a.pose[(size_t)f * 7 + r];
+        ob.pose[(size_t)at * 7 + r] = b.pose[(size_t)f * 7 + r];
+      }
+      oa.uvr[(size_t)at * 3] = a.uv[g1 * 2];
+      oa.uvr[(size_t)at * 3 + 1] = a.uv[g1 * 2 + 1];
+      oa.uvr[(size_t)at * 3 + 2] = (double)a.ur[g1];
+      ob.uvr[(size_t)at * 3] = b.uv[g2 * 2];
+      ob.uvr[(size_t)at * 3 + 1] = b.uv[g2 * 2 + 1];
+      ob.uvr[(size_t)at * 3 + 2] = (double)b.ur[g2];
+      oa.depth[at] = a.depth[g1];
+      ob.depth[at] = b.depth[g2];
+      oa.oct[at] = a.oct[g1];
+      ob.oct[at] = b.oct[g2];
+      oa.ncand[at] = a.ncand[g1];
+      ob.ncand[at] = b.ncand[g2];
+      for (int c = 0; c < k; ++c) {
+        oa.cand[(size_t)at * k + c] = a.cand[g1 * k + c];
+        ob.cand[(size_t)at * k + c] = b.cand[g2 * k + c];
+      }
+      pair_of[at] = f;
+      idx1_of[at] = i;
+      idx2_of[at] = j;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int gl_gather_triangulation_matches(gl_ctx_t* ctx, int B, int N1, int N2, int k, int cap, const int32_t* match12_dev,
+                                               const int32_t* nmatches_dev, const double* pose1_dev, const double* uv1_dev,
+                                               const float* ur1_dev, const float* depth1_dev, const int32_t* oct1_dev, const int32_t* cand1_dev,
+                                               const int32_t* ncand1_dev, const double* pose2_dev, const double* uv2_dev, const float* ur2_dev,
+                                               const float* depth2_dev, const int32_t* oct2_dev, const int32_t* cand2_dev,
+                                               const int32_t* ncand2_dev, int32_t* pair_off_dev, double* m_pose1_dev, double* m_uvr1_dev,
+                                               float* m_depth1_dev, int32_t* m_oct1_dev, int32_t* m_cand1_dev, int32_t* m_n1_dev,
+                                               double* m_pose2_dev, double* m_uvr2_dev, float* m_depth2_dev, int32_t* m_oct2_dev,
+                                               int32_t* m_cand2_dev, int32_t* m_n2_dev, int32_t* m_pair_dev, int32_t* m_idx1_dev,
+                                               int32_t* m_idx2_dev) {
+  GL_REQUIRE(ctx, "null context");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && N1 >= 1 && N2 >= 1 && k >= 1 && cap >= 1, "bad B / N1 / N2 / k / cap");
+  GL_REQUIRE(match12_dev && nmatches_dev && pose1_dev && uv1_dev && ur1_dev && depth1_dev && oct1_dev && cand1_dev && ncand1_dev && pose2_dev &&
+                 uv2_dev && ur2_dev && depth2_dev && oct2_dev && cand2_dev && ncand2_dev && pair_off_dev && m_pose1_dev && m_uvr1_dev &&
+                 m_depth1_dev && m_oct1_dev && m_cand1_dev && m_n1_dev && m_pose2_dev && m_uvr2_dev && m_depth2_dev && m_oct2_dev &&
+                 m_cand2_dev && m_n2_dev && m_pair_dev && m_idx1_dev && m_idx2_dev,
+             "null buffer");
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  k_tri_offsets<<<1, 256, 0, c->stream>>>(B, nmatches_dev, pair_off_dev);
+  k_tri_gather<<<B, 256, 0, c->stream>>>(B, N1, N2, k, cap, match12_dev, pair_off_dev,
+                                         TriKf{pose1_dev, uv1_dev, ur1_dev, depth1_dev, oct1_dev, cand1_dev, ncand1_dev},
+                                         TriKf{pose2_dev, uv2_dev, ur2_dev, depth2_dev, oct2_dev, cand2_dev, ncand2_dev},
+                                         TriOut{m_pose1_dev, m_uvr1_dev, m_depth1_dev, m_oct1_dev, m_cand1_dev, m_n1_dev},
+                                         TriOut{m_pose2_dev, m_uvr2_dev, m_depth2_dev, m_oct2_dev, m_cand2_dev, m_n2_dev}, m_pair_dev, m_idx1_dev,
+                                         m_idx2_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
 
 extern "C" int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1, int N2, int NN1, int NN2,
                                            const double* uv1_dev, const float* ur1_dev, const int32_t* oct1_dev, const float* angle1_dev,

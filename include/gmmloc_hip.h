@@ -295,6 +295,21 @@ int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1
                                 const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
                                 const double* fmat_dev, const float* epipole_dev, int only_stereo, int check_orientation,
                                 int32_t* match12_dev, int32_t* nmatches_dev);
+/* The matches of gl_search_for_triangulation as the per-match arrays of gl_create_map_points, without leaving the device:
+ * what Localization::createMapPoints reads per matched pair (localization_opt.cpp:286-420) - the two key-frames' poses,
+ * key-points, depths, octaves and candidate components (kf->comps_[idx]).  Inputs per pair and key-frame: pose B x 7, uv B x N x 2,
+ * ur / depth B x N float, oct B x N, cand B x N x k int32 (+ ncand B x N).  Output: the matches of all pairs, pair after pair, inside
+ * a pair in ascending feature index of key-frame 1 (= matched_pairs), compacted: pair_off_dev B + 1 int32 (exclusive scan of the
+ * counts; [B] = total), m_* arrays of `cap` entries (entries beyond cap are dropped: size cap >= sum of nmatches, e.g. B x
+ * min(N1, N2)), m_pair / m_idx1 / m_idx2: the pair and the two feature indices of every match. */
+int gl_gather_triangulation_matches(gl_ctx_t* ctx, int B, int N1, int N2, int k, int cap, const int32_t* match12_dev,
+                                    const int32_t* nmatches_dev, const double* pose1_dev, const double* uv1_dev, const float* ur1_dev,
+                                    const float* depth1_dev, const int32_t* oct1_dev, const int32_t* cand1_dev, const int32_t* ncand1_dev,
+                                    const double* pose2_dev, const double* uv2_dev, const float* ur2_dev, const float* depth2_dev,
+                                    const int32_t* oct2_dev, const int32_t* cand2_dev, const int32_t* ncand2_dev, int32_t* pair_off_dev,
+                                    double* m_pose1_dev, double* m_uvr1_dev, float* m_depth1_dev, int32_t* m_oct1_dev, int32_t* m_cand1_dev,
+                                    int32_t* m_n1_dev, double* m_pose2_dev, double* m_uvr2_dev, float* m_depth2_dev, int32_t* m_oct2_dev,
+                                    int32_t* m_cand2_dev, int32_t* m_n2_dev, int32_t* m_pair_dev, int32_t* m_idx1_dev, int32_t* m_idx2_dev);
 
 /* ---- point refinement ----------------------------------------------------- */
 /* GMMLoc::optimizePoint (gmmloc_opt.cpp:260-342), N independent problems.

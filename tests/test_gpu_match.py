@@ -191,3 +191,67 @@ def test_search_for_triangulation_soak(gpu, oracle):
             assert np.array_equal(match[b, :len(m_ref)], m_ref) and nm[b] == n_ref, (b, only_stereo, chk)
             checked += n_ref
     assert checked > 5000
+
+
+def test_search_gather_create_map_points_chain_on_device(gpu, oracle, map_v1):
+    """searchForTriangulation -> matched_pairs -> createMapPoints without leaving the device: gl_search_for_triangulation,
+    gl_gather_triangulation_matches, gl_create_map_points on 3 key-frame pairs, against the oracle's matcher + the same gather in
+    numpy + the oracle's create_map_points (types and components exact, points 1e-8 where the triangulation is sane)."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    h = oracle.gmm_create(mean, cov)
+    rng = np.random.default_rng(3)
+    pairs = [synth.synth_tri_search_pair(600, 650, 700 + i, cam, n_nodes=80) for i in range(3)]
+    K = 5
+    sides = []
+    for p in pairs:  # depth, candidate components per feature (kf->comps_), the two poses
+        for key, pose in (("kf1", p["pose1"]), ("kf2", p["pose2"])):
+            k = p[key]
+            n = len(k["oct"])
+            k["depth"] = np.where(k["ur"] >= 0, cam.bf / np.maximum(k["uv"][:, 0] - k["ur"], 1e-3), -1.0).astype(np.float32)
+            k["cand"] = rng.integers(0, mean.shape[0], (n, K)).astype(np.int32)
+            k["ncand"] = rng.integers(0, K + 1, n).astype(np.int32)
+            k["pose"] = pose
+    k1, k2, fm, ep = _pack_pairs(torch, pairs)
+    match, nm = api.search_for_triangulation(ctx, k1, k2, fm, ep, False, True)
+
+    def side(key, N):
+        B = len(pairs)
+        t = dict(pose=np.zeros((B, 7)), uv=np.zeros((B, N, 2)), ur=np.full((B, N), -1.0, np.float32), depth=np.full((B, N), -1.0, np.float32),
+                 oct=np.zeros((B, N), np.int32), cand=np.full((B, N, K), -1, np.int32), ncand=np.zeros((B, N), np.int32))
+        for b, p in enumerate(pairs):
+            k = p[key]
+            n = len(k["oct"])
+            t["pose"][b] = k["pose"]
+            for name in ("uv", "ur", "depth", "oct", "cand", "ncand"):
+                t[name][b, :n] = k[name]
+        return {q: torch.from_numpy(v).cuda() for q, v in t.items()}
+    s1, s2 = side("kf1", match.shape[1]), side("kf2", k2["oct"].shape[1])
+    off, m = api.gather_triangulation_matches(ctx, match, nm, s1, s2)
+    torch.cuda.synchronize()
+    off = off.cpu().numpy()
+    total = int(off[-1])
+    assert total == int(nm.sum().item()) and total > 100
+    keys = ("pose1", "uvr1", "depth1", "oct1", "pose2", "uvr2", "depth2", "oct2", "cand1", "n1", "cand2", "n2")
+    x, t, c = api.create_map_points(ctx, g, cam, prm, *[m[q][:total].contiguous() for q in keys])
+    torch.cuda.synchronize()
+    x, t, c = x.cpu().numpy(), t.cpu().numpy(), c.cpu().numpy()
+    pos = 0
+    for b, p in enumerate(pairs):  # the reference's chain on the host
+        m_ref, n_ref = oracle.search_for_triangulation(p["kf1"], p["kf2"], p["fmat"], p["epipole"], False, True)
+        i1 = np.nonzero(m_ref >= 0)[0]
+        i2 = m_ref[i1]
+        assert off[b] == pos and np.array_equal(m["idx1"][pos:pos + n_ref].cpu().numpy(), i1) and np.array_equal(m["idx2"][pos:pos + n_ref].cpu().numpy(), i2)
+        a, bb = p["kf1"], p["kf2"]
+        args = dict(pose1=np.tile(a["pose"], (n_ref, 1)), uvr1=np.concatenate([a["uv"][i1], a["ur"][i1, None].astype(np.float64)], 1), depth1=a["depth"][i1],
+                    oct1=a["oct"][i1], pose2=np.tile(bb["pose"], (n_ref, 1)), uvr2=np.concatenate([bb["uv"][i2], bb["ur"][i2, None].astype(np.float64)], 1),
+                    depth2=bb["depth"][i2], oct2=bb["oct"][i2], cand1=a["cand"][i1], n1=a["ncand"][i1], cand2=bb["cand"][i2], n2=bb["ncand"][i2])
+        x_ref, t_ref, c_ref = oracle.create_map_points(h, cam, **args)
+        assert np.array_equal(t[pos:pos + n_ref], t_ref) and np.array_equal(c[pos:pos + n_ref], c_ref), b
+        sane = (t_ref > 0) & (np.linalg.norm(x_ref, axis=1) < 100.0)
+        if sane.any():
+            np.testing.assert_allclose(x[pos:pos + n_ref][sane], x_ref[sane], rtol=0, atol=1e-8)
+        pos += n_ref
+    oracle.gmm_destroy(h)
