@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's numbers come from, on one box: tools/final_round.sh <tag>   -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt
 # (tools/kernel_meta.py reads the object files of the build container: run it there -> profiles/<tag>_kernel_meta.txt)
@@ -12,9 +12,15 @@ python tools/run_configs.py --configs 2,3,4,5,ba,kf,match > gpurun_out/${TAG}_co
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>/dev/null
 python tools/replay_euroc.py --anchor prior > gpurun_out/${TAG}_replay_euroc.json 2>/dev/null
 ANCHORS="none prior" SIGMAS="0" bash tools/replay_matrix.sh > gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
-ANCHORS="fixed" SIGMAS="0 0.02" EXTRA="--limit 400" bash tools/replay_matrix.sh >> gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
+ANCHORS="fixed" SIGMAS="0 0.02" bash tools/replay_matrix.sh >> gpurun_out/${TAG}_replay_matrix.txt 2>/dev/null
 python tools/ba_time.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_time.txt
 python tools/ba_modes.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_modes.txt
+python tools/fixed_time.py 4096 300 2 > gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
+python tools/fixed_time.py 2048 1000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
+python tools/fixed_time.py 1024 2000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
+./build_tmp/bench_mfma_reduce > gpurun_out/${TAG}_mfma_reduce.txt 2>/dev/null
 python tools/soak.py 2000 > gpurun_out/${TAG}_soak_strict.txt 2>&1
 tail -2 gpurun_out/${TAG}_soak_strict.txt | cut -c1-500
+python tools/soak_track.py ${SOAK_TRACK:-86000} > gpurun_out/${TAG}_soak_track.txt 2>&1
+tail -1 gpurun_out/${TAG}_soak_track.txt | cut -c1-500
 cat gpurun_out/${TAG}_gpu_tests.txt

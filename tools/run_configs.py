@@ -330,6 +330,22 @@ def config_match(torch, ctx, out):
     for f in uq:
         orc.search_by_projection_frame(CamF, th=7.0, **f)
     tc2 = (time.perf_counter() - t0) / len(uq)
+    # searchForTriangulation: key-frame pairs of 1 200 features, DBoW2 feature vectors of ~240 nodes (level 4 of a 10^6-word tree
+    # gives a few hundred nodes per key-frame)
+    from tests.test_gpu_match import _pack_pairs
+    up = [synth.synth_tri_search_pair(1200, 1200, 1300 + b, api.Camera(), n_nodes=240) for b in range(64)]
+    k1, k2, fm, ep = _pack_pairs(torch, [up[b % 64] for b in range(B)])
+    t3 = ev_time(torch, lambda: api.search_for_triangulation(ctx, k1, k2, fm, ep, False, True), 5, ctx.stream)
+    one = _pack_pairs(torch, up[:1])
+    t3l = ev_time(torch, lambda: api.search_for_triangulation(ctx, *one, False, True), 50, ctx.stream)
+    t0 = time.perf_counter()
+    for p in up:
+        orc.search_for_triangulation(p["kf1"], p["kf2"], p["fmat"], p["epipole"], False, True)
+    tc3 = (time.perf_counter() - t0) / len(up)
+    bytes_pair = 2 * 1200 * (16 + 4 + 4 + 4 + 32 + 1 + 4) + 2 * 240 * 8 + 1200 * 4
+    out({"config": "searchForTriangulation: %d key-frame pairs x 1200 + 1200 features, ~240 vocabulary nodes each" % B,
+         "pairs_per_s": B / t3, "single_pair_latency_us": 1e6 * t3l, "algorithmic_bytes_per_pair": bytes_pair,
+         "algorithmic_GBs": B * bytes_pair / t3 / 1e9, "cpu_oracle_1thread_pairs_per_s": 1.0 / tc3})
     out({"config": "searchByProjection(CurrentFrame, LastFrame): %d frame pairs x %d features x %d last-frame map points, th=7" % (B, NF, NL),
          "frames_per_s": B / t2, "cpu_oracle_1thread_frames_per_s": 1.0 / tc2})
     out({"config": "searchByProjection: %d frames x %d features x %d map points, th=3" % (B, NF, NP),
