@@ -1264,6 +1264,46 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
   return true;
 }
 
+#ifndef GL_BAF_PF
+#define GL_BAF_PF 0
+#endif
+// DENSE, option GL_BAF_PF (A/B build): the observation and the association of slot i + 1 are requested at the top of slot i
+// (7 registers across the loop back-edge), so that a slot opens with its plane gather - whose latency the ~100 instructions of
+// the reprojection part cover - instead of with the dependent chain association -> plane record.
+struct PtPre {
+  double ob[3];
+  int a;
+};
+GL_DEV void prefetch_pt(const Map& mp, const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, int i, PtPre& r) {
+  const int l = min(mp.base + mp.step * min(i, mp.S - 1), mp.L - 1);  // (clamped: never beyond the frame's rows)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) r.ob[j] = gobn[(size_t)l * 3 + j];
+  r.a = gassoc[l];
+}
+GL_DEV bool load_pt_pre(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gnd, int i, const PtPre& pre, PtCtx& c) {
+  c.fl = fw_get(fw, i);
+  if (!(c.fl & (F_AR | F_AG | F_AF))) return false;
+  c.l = mp.base + mp.step * i;
+  c.ll = mp.lbase + mp.step * i;
+  const int a = pre.a;
+  const int ap = a > 0 ? a : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.ob[j] = pre.ob[j];
+  c.ar = c.fl & F_AR;
+  c.ag = c.fl & F_AG;
+  c.af = kFixed && (c.fl & F_AF);
+  const int oc = (c.fl >> 8) & 7;
+  c.sx = D.stab[oc];
+  c.sy = D.stab[8 + oc];
+  c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? a : -1;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
+  return true;
+}
+GL_DEV void pin_pre(const PtPre& r) { asm volatile("" ::"v"(r.ob[0]), "v"(r.ob[1]), "v"(r.ob[2]), "v"(r.a)); }
+
 // SPREAD: a thread owns ONE point for the whole kernel, so what load_pt fetches from global memory - normalised
 // observation, association, plane record: two dependent L2 round trips at the head of every pass, on a SIMD that has
 // nothing else to run - is fetched once and kept in registers.
@@ -1519,6 +1559,20 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
       const SinkSet sk{acc};                                                  \
       PtCtx c;                                                                \
       if (load_pt_const(D, mp, fw, pc, c)) { BODY; }                          \
+    } else if (GL_BAF_PF) {                                                   \
+      const SinkAcc sk{acc};                                                  \
+      GL_BAF_PRIO_PASS_BEGIN();                                               \
+      PtPre cur_;                                                             \
+      prefetch_pt(mp, gobn, gassoc, 0, cur_);                                 \
+      _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
+        GL_BAF_PRIO_SLOT(i);                                                  \
+        PtPre nxt_;                                                           \
+        prefetch_pt(mp, gobn, gassoc, i + 1, nxt_);                           \
+        PtCtx c;                                                              \
+        if (load_pt_pre(D, mp, fw, gnd, i, cur_, c)) { BODY; }                \
+        pin_pre(nxt_);                                                        \
+        cur_ = nxt_;                                                          \
+      }                                                                       \
     } else {                                                                  \
       const SinkAcc sk{acc};                                                  \
       GL_BAF_PRIO_PASS_BEGIN();                                               \

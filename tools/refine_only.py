@@ -39,5 +39,7 @@ ms, n = ctx.timing_read(api.TIMER_BA)
 ntr = float(trials.sum().item())
 ks = ms / 1e3 / max(n, 1)
 tf = bench.FLOP_PER_POINT_TRIAL * M * ntr / ks / 1e12
-print("refine: %d frames x %d points, %.3f ms per launch, %.1f trials/frame, %.2f TFLOP/s = %.4f of the fp64 VALU peak"
-      % (NF, M, 1e3 * ks, ntr / NF, tf, tf / bench.PEAK_FP64_VALU_TFLOPS))
+import hashlib
+fp = hashlib.sha256(p.cpu().numpy().tobytes() + x.cpu().numpy().tobytes()).hexdigest()[:16]  # bits of the last launch's poses + points
+print("refine: %d frames x %d points, %.3f ms per launch, %.1f trials/frame, %.2f TFLOP/s = %.4f of the fp64 VALU peak, result bits %s"
+      % (NF, M, 1e3 * ks, ntr / NF, tf, tf / bench.PEAK_FP64_VALU_TFLOPS, fp))
