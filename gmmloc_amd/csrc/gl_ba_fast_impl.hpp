@@ -1552,24 +1552,26 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 
 // one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
 // point's terms there (zeros when the thread has no active point)
-#define GL_BAF_PASS(BODY)                                                     \
+#define GL_BAF_PASS_(BODY, PF_)                                               \
   {                                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) acc[i_] = 0.0;          \
     if (kSpread) {                                                            \
       const SinkSet sk{acc};                                                  \
       PtCtx c;                                                                \
       if (load_pt_const(D, mp, fw, pc, c)) { BODY; }                          \
-    } else if (GL_BAF_PF) {                                                   \
+    } else if (PF_) {                                                         \
       const SinkAcc sk{acc};                                                  \
       GL_BAF_PRIO_PASS_BEGIN();                                               \
       PtPre cur_;                                                             \
       prefetch_pt(mp, gobn, gassoc, 0, cur_);                                 \
+      pin_pre(cur_); /* (arrived before the loop: the wait-count pass merges the pre-header's pending loads into every iteration) */ \
       _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
         GL_BAF_PRIO_SLOT(i);                                                  \
         PtPre nxt_;                                                           \
-        prefetch_pt(mp, gobn, gassoc, i + 1, nxt_);                           \
         PtCtx c;                                                              \
-        if (load_pt_pre(D, mp, fw, gnd, i, cur_, c)) { BODY; }                \
+        const bool act_ = load_pt_pre(D, mp, fw, gnd, i, cur_, c);            \
+        prefetch_pt(mp, gobn, gassoc, i + 1, nxt_);                           \
+        if (act_) { BODY; }                                                   \
         pin_pre(nxt_);                                                        \
         cur_ = nxt_;                                                          \
       }                                                                       \
@@ -1584,6 +1586,8 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
       }                                                                       \
     }                                                                         \
   }
+#define GL_BAF_PASS(BODY) GL_BAF_PASS_(BODY, GL_BAF_PF)   /* the two passes of a trial */
+#define GL_BAF_PASS_ONCE(BODY) GL_BAF_PASS_(BODY, 0)     /* lambda initialisation: once per optimize() */
 
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
@@ -1613,7 +1617,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     int qmax = 0;
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
-      GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
+      GL_BAF_PASS_ONCE(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
       if (pose_active) {
         if (prior_on) {
