@@ -1264,46 +1264,6 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
   return true;
 }
 
-#ifndef GL_BAF_PF
-#define GL_BAF_PF 0
-#endif
-// DENSE, option GL_BAF_PF (A/B build): the observation and the association of slot i + 1 are requested at the top of slot i
-// (7 registers across the loop back-edge), so that a slot opens with its plane gather - whose latency the ~100 instructions of
-// the reprojection part cover - instead of with the dependent chain association -> plane record.
-struct PtPre {
-  double ob[3];
-  int a;
-};
-GL_DEV void prefetch_pt(const Map& mp, const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, int i, PtPre& r) {
-  const int l = min(mp.base + mp.step * min(i, mp.S - 1), mp.L - 1);  // (clamped: never beyond the frame's rows)
-#pragma unroll
-  for (int j = 0; j < 3; ++j) r.ob[j] = gobn[(size_t)l * 3 + j];
-  r.a = gassoc[l];
-}
-GL_DEV bool load_pt_pre(const Lds& D, const Map& mp, FlagW fw, const double* __restrict__ gnd, int i, const PtPre& pre, PtCtx& c) {
-  c.fl = fw_get(fw, i);
-  if (!(c.fl & (F_AR | F_AG | F_AF))) return false;
-  c.l = mp.base + mp.step * i;
-  c.ll = mp.lbase + mp.step * i;
-  const int a = pre.a;
-  const int ap = a > 0 ? a : 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) c.ob[j] = pre.ob[j];
-  c.ar = c.fl & F_AR;
-  c.ag = c.fl & F_AG;
-  c.af = kFixed && (c.fl & F_AF);
-  const int oc = (c.fl >> 8) & 7;
-  c.sx = D.stab[oc];
-  c.sy = D.stab[8 + oc];
-  c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? a : -1;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
-  return true;
-}
-GL_DEV void pin_pre(const PtPre& r) { asm volatile("" ::"v"(r.ob[0]), "v"(r.ob[1]), "v"(r.ob[2]), "v"(r.a)); }
-
 // SPREAD: a thread owns ONE point for the whole kernel, so what load_pt fetches from global memory - normalised
 // observation, association, plane record: two dependent L2 round trips at the head of every pass, on a SIMD that has
 // nothing else to run - is fetched once and kept in registers.
@@ -1552,29 +1512,13 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 
 // one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
 // point's terms there (zeros when the thread has no active point)
-#define GL_BAF_PASS_(BODY, PF_)                                               \
+#define GL_BAF_PASS(BODY)                                                     \
   {                                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) acc[i_] = 0.0;          \
     if (kSpread) {                                                            \
       const SinkSet sk{acc};                                                  \
       PtCtx c;                                                                \
       if (load_pt_const(D, mp, fw, pc, c)) { BODY; }                          \
-    } else if (PF_) {                                                         \
-      const SinkAcc sk{acc};                                                  \
-      GL_BAF_PRIO_PASS_BEGIN();                                               \
-      PtPre cur_;                                                             \
-      prefetch_pt(mp, gobn, gassoc, 0, cur_);                                 \
-      pin_pre(cur_); /* (arrived before the loop: the wait-count pass merges the pre-header's pending loads into every iteration) */ \
-      _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
-        GL_BAF_PRIO_SLOT(i);                                                  \
-        PtPre nxt_;                                                           \
-        PtCtx c;                                                              \
-        const bool act_ = load_pt_pre(D, mp, fw, gnd, i, cur_, c);            \
-        prefetch_pt(mp, gobn, gassoc, i + 1, nxt_);                           \
-        if (act_) { BODY; }                                                   \
-        pin_pre(nxt_);                                                        \
-        cur_ = nxt_;                                                          \
-      }                                                                       \
     } else {                                                                  \
       const SinkAcc sk{acc};                                                  \
       GL_BAF_PRIO_PASS_BEGIN();                                               \
@@ -1586,8 +1530,6 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
       }                                                                       \
     }                                                                         \
   }
-#define GL_BAF_PASS(BODY) GL_BAF_PASS_(BODY, GL_BAF_PF)   /* the two passes of a trial */
-#define GL_BAF_PASS_ONCE(BODY) GL_BAF_PASS_(BODY, 0)     /* lambda initialisation: once per optimize() */
 
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
@@ -1617,7 +1559,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     int qmax = 0;
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
-      GL_BAF_PASS_ONCE(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
+      GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
       if (pose_active) {
         if (prior_on) {
