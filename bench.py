@@ -57,8 +57,8 @@ def kernel_source_fingerprint():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "gmmloc_amd", "csrc", "*.h*"))):
-        if path.endswith((".hip", ".hpp")):
+    for path in sorted(glob.glob(os.path.join(ROOT, "gmmloc_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "gmmloc_amd", "csrc", "Makefile")]):
+        if path.endswith((".hip", ".hpp", "Makefile")):  # (the compile flags decide spills, i.e. traffic: round 4)
             with open(path, "rb") as f:
                 h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

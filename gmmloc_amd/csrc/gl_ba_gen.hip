@@ -160,6 +160,15 @@ GL_DEV void load_Rt(const double* Rt, double* R, double* t) {
   t[1] = Rt[10];
   t[2] = Rt[11];
 }
+// the same through scalar loads (wave-uniform address, data no kernel in flight writes): {R, t} land in SGPRs
+typedef const double __attribute__((address_space(4))) cdouble_k;
+GL_DEV void load_Rt_k(const cdouble_k* Rt, double* R, double* t) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = Rt[i];
+  t[0] = Rt[9];
+  t[1] = Rt[10];
+  t[2] = Rt[11];
+}
 GL_DEV void store_pose_Rt(const SE3& T, double* Rt) {
   double R[9];
   qtoR(T.r, R);
@@ -2329,7 +2338,9 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
 // ---- P2: one wave per (block (j1 <= j2) of the reduced camera system, chunk of pose j1's list: 1 / nchunk of the longest) ----------
 __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
   const int lane = threadIdx.x & 63;
-  const long gwave = (long)blockIdx.x * NW_BA + (threadIdx.x >> 6);
+  // (the wave index as a SCALAR: block, chunk and the two poses' {R, t} are then scalar loads into SGPRs - as per-lane values the
+  // 24 doubles were loaded into VGPRs one dependent round trip after the other and spilled at once: most of a wave's 12 us)
+  const long gwave = (long)blockIdx.x * NW_BA + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int per_prob = a.nblk * a.nchunk;
   const int f = (int)(gwave / per_prob), w = (int)(gwave % per_prob);
   if (f >= a.B) return;
@@ -2351,16 +2362,15 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
   }
   const int j2 = j1 + rem;
   const bool act = G.pact[j1] && G.pact[j2] && (schur || j1 == j2);
-  double v1[32], v2[32];
+  double v1[32], v2[16];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    v1[i] = 0.0;
-    v2[i] = 0.0;
-  }
+  for (int i = 0; i < 32; ++i) v1[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v2[i] = 0.0;
   if (act) {
     double R1[9], t1[3], R2[9], t2[3];
-    load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
-    load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
+    load_Rt_k((const cdouble_k*)(G.Rt + (size_t)j1 * 12), R1, t1);  // (written by an earlier kernel of the cycle, read-only here)
+    load_Rt_k((const cdouble_k*)(G.Rt + (size_t)j2 * 12), R2, t2);
     const int e0 = G.pl_ptr[j1] + chunk * st->chunk_len, e1 = min(G.pl_ptr[j1 + 1], e0 + st->chunk_len);
     for (int e = e0 + lane; e < e1; e += 64) {
       const int o2 = G.plm[(size_t)e * P + j2];
@@ -2430,14 +2440,11 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
       }
     }
   }
-  const double r1 = wave_reduce_scatter32(v1), r2 = wave_reduce_scatter32(v2);
+  const double r1 = wave_reduce_scatter32(v1), r2 = wave_reduce_scatter16(v2);  // (the 16 further sums: same tree, same bits)
   double* const pblk = a.partS + ((size_t)f * a.nblk + b) * a.nchunk * 48;
-  if (wave_slot_owner(lane)) {  // 48 sums of this chunk: [0..35] the block, [36..41] g, [42..47] b_p (diagonal blocks)
-    double* ps = pblk + (size_t)chunk * 48;
-    const int s = wave_slot(lane);
-    ps[s] = r1;
-    if (s < 16) ps[32 + s] = r2;
-  }
+  double* const ps = pblk + (size_t)chunk * 48;  // 48 sums of this chunk: [0..35] the block, [36..41] g, [42..47] b_p (diagonal blocks)
+  if (wave_slot_owner(lane)) ps[wave_slot(lane)] = r1;
+  if (wave_slot16_owner(lane)) ps[32 + wave_slot16(lane)] = r2;
 }
 
 // ---- P2b: the chunks of a block added in chunk order -> the assembled system (a thread per (block, sum); the solve kernel

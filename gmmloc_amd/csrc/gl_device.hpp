@@ -531,6 +531,28 @@ GL_DEV double wave_reduce_scatter32(double* v) {
   return v[0] + dpp_f64<0x140>(v[0]);
 }
 
+// 16-value variant with the same lane pairings in the same order (32, 16, xor 1, xor 2, then lane ^ 7 and lane ^ 15 as full
+// adds): every value meets the 64 lanes in the tree wave_reduce_scatter32 would use for it, so the totals are the same bits - for
+// half the registers and instructions.  out: every lane holds the wave total of value wave_slot16(lane); store from the lanes
+// with wave_slot16_owner(lane).
+GL_DEV int wave_slot16(int lane) {
+  const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1;
+  return (((lane >> 5) & 1) << 3) | (((lane >> 4) & 1) << 2) | ((l0 ^ l2) << 1) | (l1 ^ l2);
+}
+GL_DEV bool wave_slot16_owner(int lane) { return !(lane & 0xC); }
+GL_DEV double wave_reduce_scatter16(double* v) {
+  const int lane = threadIdx.x & 63;
+  const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1;
+  rs_swap_stage<8, 32>(v);
+  rs_swap_stage<4, 16>(v);
+  rs_stage<2, 0>(v, l0 ^ l2);
+  rs_stage<1, 1>(v, l1 ^ l2);
+  double r = v[0];
+  r = r + dpp_f64<0x141>(r);  // row_half_mirror: lane ^ 7
+  r = r + dpp_f64<0x140>(r);  // row_mirror:      lane ^ 15
+  return r;
+}
+
 template <int NV, int NWAVES>
 GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
