@@ -513,6 +513,28 @@ def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, ch
     return match, nm
 
 
+def search_by_bow(ctx, kf, fr, nn_ratio=0.7, check_orientation=True):
+    """ORBmatcher::searchByBoW (orb_matcher.cpp:295-408) for B key-frame / frame pairs.  kf: dict of CUDA tensors angle (B,N1) f32,
+    desc (B,N1,32) u8, has_mp (B,N1) u8 (valid map point) and the feature vector as CSR (nnode, node_id, node_ptr, node_idx, as in
+    search_for_triangulation); fr: angle, desc and the feature vector of the frame -> (match21 int32 (B,N2): the key-frame feature
+    whose map point the frame feature gets, or -1; nmatches int32 (B,))."""
+    import torch
+    B, N1 = kf["angle"].shape
+    N2 = fr["angle"].shape[1]
+    NN1, NN2 = kf["node_id"].shape[1], fr["node_id"].shape[1]
+    assert kf["node_ptr"].shape[1] == NN1 + 1 and fr["node_ptr"].shape[1] == NN2 + 1
+    dev = kf["angle"].device
+    match = torch.empty((B, N2), dtype=torch.int32, device=dev)
+    nm = torch.empty(B, dtype=torch.int32, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_search_by_bow(ctx.h, float(nn_ratio), int(bool(check_orientation)), B, N1, N2, NN1, NN2,
+                                    *[_ptr(kf[k]) for k in ("angle", "desc", "has_mp", "nnode", "node_id", "node_ptr", "node_idx")],
+                                    *[_ptr(fr[k]) for k in ("angle", "desc", "nnode", "node_id", "node_ptr", "node_idx")],
+                                    _ptr(match), _ptr(nm)))
+    ctx._exit()
+    return match, nm
+
+
 def gather_triangulation_matches(ctx, match12, nmatches, side1, side2, cap=None):
     """gl_gather_triangulation_matches: the matches of search_for_triangulation as the per-match arrays of create_map_points.
     side1 / side2: dicts of CUDA tensors pose (B,7), uv (B,N,2), ur (B,N) f32, depth (B,N) f32, oct (B,N) i32, cand (B,N,k) i32,

@@ -367,3 +367,14 @@ def synth_tri_search_pair(N1, N2, seed, cam, n_nodes=160, only_stereo_frac=0.6, 
     kf2 = view(N2, u2, v2, pc2[:, 2], -14.0, seed * 2 + 2)
     fmat, epi = fundamental_and_epipole(pose1, pose2, cam)
     return dict(kf1=kf1, kf2=kf2, fmat=fmat, epipole=epi, pose1=pose1, pose2=pose2)
+
+
+def synth_bow_pair(N1, N2, seed, cam, n_nodes=160, mp_frac=0.7):
+    """Inputs of ORBmatcher::searchByBoW for one reference key-frame / current frame pair: the two views of synth_tri_search_pair
+    (same points seen twice, descriptor bit flips, crowded vocabulary nodes, rivals for one partner, equal distances), the
+    key-frame's features holding a valid map point with probability mp_frac.  -> (kf, fr) dicts."""
+    pr = synth_tri_search_pair(N1, N2, seed, cam, n_nodes=n_nodes)
+    kf, fr = dict(pr["kf1"]), dict(pr["kf2"])
+    rng = np.random.default_rng(seed + 77777)
+    kf["has_mp"] = (rng.uniform(size=len(kf["oct"])) < mp_frac).astype(np.uint8)
+    return kf, fr

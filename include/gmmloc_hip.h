@@ -295,6 +295,19 @@ int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1
                                 const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
                                 const double* fmat_dev, const float* epipole_dev, int only_stereo, int check_orientation,
                                 int32_t* match12_dev, int32_t* nmatches_dev);
+/* ORBmatcher::searchByBoW (orb_matcher.cpp:295-408; computeThreeMaxima :544-578) for B key-frame / frame pairs: the matcher of
+ * Tracking::trackReferenceKeyFrame (tracking.cpp:303), the last function of the reference's ORBmatcher.  Side 1 = the reference
+ * key-frame: angle B x N1 float, desc B x N1 x 32, has_mp B x N1 uint8 (the feature holds a map point that is valid: `pMP &&
+ * !pMP->not_valid_`), its DBoW2::FeatureVector as CSR like gl_search_for_triangulation's (nnode B; node_id B x NN1 ascending;
+ * node_ptr B x (NN1 + 1); node_idx B x N1 in list order); side 2 = the current frame: angle, desc, feature vector.  nn_ratio /
+ * check_orientation: the matcher's constructor arguments (tracking.cpp:300: 0.7, true).  Out: match21 B x N2 int32 - the
+ * KEY-FRAME FEATURE whose map point the reference stores in matches[realIdxF], or -1 - and nmatches B.  Equal to the sequential
+ * loop bit for bit (the first of equal best distances wins, a later equal one becomes second best). */
+int gl_search_by_bow(gl_ctx_t* ctx, float nn_ratio, int check_orientation, int B, int N1, int N2, int NN1, int NN2,
+                     const float* angle1_dev, const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev,
+                     const int32_t* node_id1_dev, const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev,
+                     const float* angle2_dev, const uint8_t* desc2_dev, const int32_t* nnode2_dev, const int32_t* node_id2_dev,
+                     const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev, int32_t* match21_dev, int32_t* nmatches_dev);
 /* The matches of gl_search_for_triangulation as the per-match arrays of gl_create_map_points, without leaving the device:
  * what Localization::createMapPoints reads per matched pair (localization_opt.cpp:286-420) - the two key-frames' poses,
  * key-points, depths, octaves and candidate components (kf->comps_[idx]).  Inputs per pair and key-frame: pose B x 7, uv B x N x 2,

@@ -1554,6 +1554,106 @@ int orc_search_for_triangulation(float scale_factor, int N1, const double* uv1, 
   return nmatches;
 }
 
+// ORBmatcher::searchByBoW (orb_matcher.cpp:295-408) with computeThreeMaxima (:544-578), one key-frame / frame pair: the matcher of
+// Tracking::trackReferenceKeyFrame (tracking.cpp:303).  Key-frame side ("1"): angle, descriptors, has_mp = the feature has a
+// map point that is valid (`pMP && !pMP->not_valid_`), its DBoW2 feature vector as CSR; frame side ("2"): angle, descriptors,
+// feature vector.  match21: N2 entries, the KEY-FRAME FEATURE whose map point the reference stores in matches[realIdxF], or -1.
+int orc_search_by_bow(float nn_ratio, int check_orientation, int N1, const float* angle1, const uint8_t* desc1, const uint8_t* has_mp1,
+                      int nn1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* node_idx1, int N2, const float* angle2,
+                      const uint8_t* desc2, int nn2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* node_idx2,
+                      int32_t* match21) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;  // orb_matcher.cpp:21-22
+  (void)N1;
+  for (int i = 0; i < N2; ++i) match21[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[30];
+  const float factor = HISTO_LENGTH / 360.0f;
+  int KFit = 0, Fit = 0;
+  while (KFit < nn1 && Fit < nn2) {
+    if (node_id1[KFit] == node_id2[Fit]) {
+      for (int iKF = node_ptr1[KFit]; iKF < node_ptr1[KFit + 1]; ++iKF) {
+        const int realIdxKF = node_idx1[iKF];
+        if (!has_mp1[realIdxKF]) continue;  // !pMP || pMP->not_valid_
+        const int32_t* pa = (const int32_t*)(desc1 + (size_t)realIdxKF * 32);
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int iF = node_ptr2[Fit]; iF < node_ptr2[Fit + 1]; ++iF) {
+          const int realIdxF = node_idx2[iF];
+          if (match21[realIdxF] >= 0) continue;
+          const int32_t* pb = (const int32_t*)(desc2 + (size_t)realIdxF * 32);
+          int dist = 0;
+          for (int w = 0; w < 8; ++w) {  // DescriptorDistance (:580-596)
+            unsigned int vv = pa[w] ^ pb[w];
+            vv = vv - ((vv >> 1) & 0x55555555);
+            vv = (vv & 0x33333333) + ((vv >> 2) & 0x33333333);
+            dist += (((vv + (vv >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+          }
+          if (dist < bestDist1) {
+            bestDist2 = bestDist1;
+            bestDist1 = dist;
+            bestIdxF = realIdxF;
+          } else if (dist < bestDist2) {
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < nn_ratio * static_cast<float>(bestDist2)) {
+            match21[bestIdxF] = realIdxKF;
+            if (check_orientation) {
+              float rot = angle1[realIdxKF] - angle2[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdxF);  // (assert in the reference)
+            }
+            nmatches++;
+          }
+        }
+      }
+      KFit++;
+      Fit++;
+    } else if (node_id1[KFit] < node_id2[Fit]) {
+      KFit = (int)(std::lower_bound(node_id1, node_id1 + nn1, node_id2[Fit]) - node_id1);
+    } else {
+      Fit = (int)(std::lower_bound(node_id2, node_id2 + nn2, node_id1[KFit]) - node_id2);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;  // computeThreeMaxima
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int sz = rotHist[i].size();
+      if (sz > max1) {
+        max3 = max2;
+        max2 = max1;
+        max1 = sz;
+        ind3 = ind2;
+        ind2 = ind1;
+        ind1 = i;
+      } else if (sz > max2) {
+        max3 = max2;
+        max2 = sz;
+        ind3 = ind2;
+        ind2 = i;
+      } else if (sz > max3) {
+        max3 = sz;
+        ind3 = i;
+      }
+    }
+    if (max2 < 0.1f * (float)max1) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+      ind3 = -1;
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) {
+          match21[idx] = -1;
+          nmatches--;
+        }
+  }
+  return nmatches;
+}
+
 void orc_se3_exp(const double* u, double* pose) { from_se3(se3_exp(u), pose); }
 void orc_se3_log(const double* pose, double* u) { se3_log(to_se3(pose), u); }
 void orc_se3_mul(const double* a, const double* b, double* out) { from_se3(se3_mul(to_se3(a), to_se3(b)), out); }

@@ -977,3 +977,67 @@ def search_for_triangulation(kf1, kf2, fmat, epipole, only_stereo=False, check_o
             if bb not in (i1, i2, i3):
                 match[idx] = -1
     return match, int((match >= 0).sum())
+
+
+def search_by_bow(kf, fr, nn_ratio=0.7, check_orientation=True):
+    """ORBmatcher::searchByBoW (orb_matcher.cpp:295-408), independent restatement: the two feature vectors as python dicts,
+    the Hamming distances of a node as ONE table-popcount matrix, the claimed features masked out of it, best / second best by a
+    stable argsort (the reference keeps the FIRST of equal distances as best and lets a later equal one become second best),
+    acceptance and the rotation histogram as in the source.  -> (match21 [N2]: key-frame feature or -1, nmatches)."""
+    f32 = np.float32
+    fv1 = {int(n): kf["node_idx"][kf["node_ptr"][i]:kf["node_ptr"][i + 1]] for i, n in enumerate(kf["node_id"])}
+    fv2 = {int(n): fr["node_idx"][fr["node_ptr"][i]:fr["node_ptr"][i + 1]] for i, n in enumerate(fr["node_id"])}
+    N2 = len(fr["angle"])
+    match = -np.ones(N2, np.int32)
+    rot_bin = {}
+    rnd = lambda v: float(np.floor(v + 0.5)) if v >= 0 else float(np.ceil(v - 0.5))
+    for node in sorted(set(fv1) & set(fv2)):
+        cand = np.asarray(fv2[node], np.int64)
+        if len(cand) == 0:
+            continue
+        dmat = None
+        for q in fv1[node]:
+            q = int(q)
+            if not kf["has_mp"][q]:
+                continue
+            if dmat is None:  # distances of every key-frame feature of the node to every frame feature of the node
+                qs = np.asarray(fv1[node], np.int64)
+                dmat = _POP8[np.bitwise_xor(kf["desc"][qs][:, None, :], fr["desc"][cand][None, :, :])].sum(2).astype(np.int64)
+                row_of = {int(x): i for i, x in enumerate(qs)}
+            d = dmat[row_of[q]]
+            free = match[cand] < 0
+            if not free.any():
+                continue
+            dd, cc = d[free], cand[free]
+            order = np.argsort(dd, kind="stable")
+            b1 = int(dd[order[0]])
+            b2 = int(dd[order[1]]) if len(order) > 1 else 256
+            bidx = int(cc[order[0]])
+            if b1 <= 50 and f32(b1) < f32(nn_ratio) * f32(b2):
+                match[bidx] = q
+                if check_orientation:
+                    rot = f32(f32(kf["angle"][q]) - f32(fr["angle"][bidx]))
+                    if rot < 0.0:
+                        rot = f32(rot + f32(360.0))
+                    bb = int(rnd(float(f32(rot * f32(f32(30) / f32(360.0))))))
+                    rot_bin[bidx] = 0 if bb == 30 else bb
+    if check_orientation and rot_bin:
+        cnt = np.bincount(np.array(list(rot_bin.values())), minlength=30)
+        m1 = m2 = m3 = 0
+        i1 = i2 = i3 = -1
+        for bb in range(30):
+            c = int(cnt[bb])
+            if c > m1:
+                m3, m2, m1, i3, i2, i1 = m2, m1, c, i2, i1, bb
+            elif c > m2:
+                m3, m2, i3, i2 = m2, c, i2, bb
+            elif c > m3:
+                m3, i3 = c, bb
+        if m2 < f32(0.1) * f32(m1):
+            i2 = i3 = -1
+        elif m3 < f32(0.1) * f32(m1):
+            i3 = -1
+        for idx, bb in rot_bin.items():
+            if bb not in (i1, i2, i3):
+                match[idx] = -1
+    return match, int((match >= 0).sum())

@@ -243,6 +243,20 @@ class Oracle:
                                                   int(bool(check_orientation)), _p(out))
         return out, int(n)
 
+    def search_by_bow(self, kf, fr, nn_ratio=0.7, check_orientation=True):
+        """ORBmatcher::searchByBoW on one key-frame / frame pair (dicts: angle, desc, has_mp (key-frame: valid map point),
+        node_id, node_ptr, node_idx) -> (match21 [N2]: key-frame feature or -1, nmatches)."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        a1 = [f32(kf["angle"]), u8(kf["desc"]), u8(kf["has_mp"]), _i32(kf["node_id"]), _i32(kf["node_ptr"]), _i32(kf["node_idx"])]
+        a2 = [f32(fr["angle"]), u8(fr["desc"]), _i32(fr["node_id"]), _i32(fr["node_ptr"]), _i32(fr["node_idx"])]
+        out = np.zeros(len(a2[0]), np.int32)
+        self.lib.orc_search_by_bow.restype = C.c_int
+        n = self.lib.orc_search_by_bow(C.c_float(nn_ratio), int(bool(check_orientation)), len(a1[0]), _p(a1[0]), _p(a1[1]), _p(a1[2]),
+                                       len(a1[3]), _p(a1[3]), _p(a1[4]), _p(a1[5]), len(a2[0]), _p(a2[0]), _p(a2[1]), len(a2[2]),
+                                       _p(a2[2]), _p(a2[3]), _p(a2[4]), _p(out))
+        return out, int(n)
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

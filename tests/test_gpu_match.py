@@ -255,3 +255,74 @@ def test_search_gather_create_map_points_chain_on_device(gpu, oracle, map_v1):
             np.testing.assert_allclose(x[pos:pos + n_ref][sane], x_ref[sane], rtol=0, atol=1e-8)
         pos += n_ref
     oracle.gmm_destroy(h)
+
+
+def _pack_bow(torch, pairs):
+    """list of (kf, fr) dicts -> the batched CUDA tensors of api.search_by_bow (strides = the maxima, padding slots: no map point /
+    not in any list)"""
+    out = []
+    for side in (0, 1):
+        N = max(len(p[side]["angle"]) for p in pairs)
+        NN = max(len(p[side]["node_id"]) for p in pairs)
+        B = len(pairs)
+        t = dict(angle=np.zeros((B, N), np.float32), desc=np.zeros((B, N, 32), np.uint8), has_mp=np.zeros((B, N), np.uint8),
+                 nnode=np.zeros(B, np.int32), node_id=np.zeros((B, NN), np.int32), node_ptr=np.zeros((B, NN + 1), np.int32),
+                 node_idx=np.zeros((B, N), np.int32))
+        for b, p in enumerate(pairs):
+            k = p[side]
+            n, nn = len(k["angle"]), len(k["node_id"])
+            t["angle"][b, :n] = k["angle"]
+            t["desc"][b, :n] = k["desc"]
+            if side == 0:
+                t["has_mp"][b, :n] = k["has_mp"]
+            t["nnode"][b] = nn
+            t["node_id"][b, :nn] = k["node_id"]
+            t["node_ptr"][b, :nn + 1] = k["node_ptr"]
+            t["node_ptr"][b, nn + 1:] = k["node_ptr"][-1]
+            t["node_idx"][b, :len(k["node_idx"])] = k["node_idx"]
+        out.append({name: torch.from_numpy(v).cuda() for name, v in t.items()})
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("nn_ratio,check_orientation", [(0.7, True), (0.9, True), (0.6, False)])
+def test_search_by_bow_matches_oracle(gpu, oracle, nn_ratio, check_orientation):
+    """gl_search_by_bow (ORBmatcher::searchByBoW, orb_matcher.cpp:295-408) against the sequential oracle: matches bit for bit -
+    crowded nodes with rival key-frame features (the order-dependent hand-over, which also changes a later feature's second-best
+    distance), equal best distances (the ratio test fails), features without a map point, pairs of different sizes in one batch,
+    the rotation histogram."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    pairs = [synth.synth_bow_pair(N1, N2, 600 + i, cam, n_nodes=nodes)
+             for i, (N1, N2, nodes) in enumerate(((300, 350, 60), (1200, 1100, 200), (700, 900, 25), (64, 70, 5), (2000, 1900, 300), (500, 40, 80)))]
+    kf, fr = _pack_bow(torch, pairs)
+    match, nm = api.search_by_bow(ctx, kf, fr, nn_ratio, check_orientation)
+    torch.cuda.synchronize()
+    match, nm = match.cpu().numpy(), nm.cpu().numpy()
+    total = 0
+    for b, p in enumerate(pairs):
+        m_ref, n_ref = oracle.search_by_bow(p[0], p[1], nn_ratio, check_orientation)
+        n2 = len(m_ref)
+        assert np.array_equal(match[b, :n2], m_ref), (b, int((match[b, :n2] != m_ref).sum()))
+        assert (match[b, n2:] == -1).all() and nm[b] == n_ref
+        total += n_ref
+    assert total > 100
+
+
+def test_search_by_bow_soak(gpu, oracle):
+    """200 random key-frame / frame pairs (sizes, node counts, map-point fractions): every match equal to the oracle's."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    rng = np.random.default_rng(78)
+    pairs = [synth.synth_bow_pair(int(rng.integers(20, 1400)), int(rng.integers(20, 1400)), 7000 + i, cam, n_nodes=int(rng.integers(3, 250)),
+                                  mp_frac=float(rng.uniform(0.1, 1.0))) for i in range(200)]
+    kf, fr = _pack_bow(torch, pairs)
+    checked = 0
+    for ratio, chk in ((0.7, True), (0.85, False)):
+        match, nm = api.search_by_bow(ctx, kf, fr, ratio, chk)
+        torch.cuda.synchronize()
+        match, nm = match.cpu().numpy(), nm.cpu().numpy()
+        for b, p in enumerate(pairs):
+            m_ref, n_ref = oracle.search_by_bow(p[0], p[1], ratio, chk)
+            assert np.array_equal(match[b, :len(m_ref)], m_ref) and nm[b] == n_ref, (b, ratio, chk)
+            checked += n_ref
+    assert checked > 3000

@@ -245,6 +245,17 @@ def main():
         out["t%d_match" % i] = m
         out["t%d_n" % i] = np.array(n)
     np.savez_compressed(os.path.join(G, "golden_tri_match.npz"), **out)
+
+    # ---- searchByBoW: key-frame / frame pairs through the independent numpy restatement (inputs regenerated from the seeds)
+    out = {}
+    for i, (N1, N2, seed, ratio100, chk, nodes) in enumerate(((300, 350, 301, 70, 1, 60), (900, 800, 302, 70, 1, 150), (500, 520, 303, 90, 1, 25),
+                                                              (400, 450, 304, 60, 0, 40))):
+        kf, fr = synth.synth_bow_pair(N1, N2, seed, CamF, n_nodes=nodes)
+        m, n = nr.search_by_bow(kf, fr, ratio100 / 100.0, bool(chk))
+        out["b%d_args" % i] = np.array([N1, N2, seed, ratio100, chk, nodes])
+        out["b%d_match" % i] = m
+        out["b%d_n" % i] = np.array(n)
+    np.savez_compressed(os.path.join(G, "golden_bow_match.npz"), **out)
     print("golden vectors written to", G)
 
 

@@ -346,6 +346,21 @@ def config_match(torch, ctx, out):
     out({"config": "searchForTriangulation: %d key-frame pairs x 1200 + 1200 features, ~240 vocabulary nodes each" % B,
          "pairs_per_s": B / t3, "single_pair_latency_us": 1e6 * t3l, "algorithmic_bytes_per_pair": bytes_pair,
          "algorithmic_GBs": B * bytes_pair / t3 / 1e9, "cpu_oracle_1thread_pairs_per_s": 1.0 / tc3})
+    # searchByBoW (trackReferenceKeyFrame): reference key-frame of 1 200 features, 70 % of them with a map point, against a frame of 1 200
+    from tests.test_gpu_match import _pack_bow
+    ub = [synth.synth_bow_pair(1200, 1200, 1500 + b, api.Camera(), n_nodes=240) for b in range(64)]
+    bk, bf = _pack_bow(torch, [ub[b % 64] for b in range(B)])
+    t4 = ev_time(torch, lambda: api.search_by_bow(ctx, bk, bf, 0.7, True), 5, ctx.stream)
+    one_b = _pack_bow(torch, ub[:1])
+    t4l = ev_time(torch, lambda: api.search_by_bow(ctx, *one_b, 0.7, True), 50, ctx.stream)
+    t0 = time.perf_counter()
+    for p in ub:
+        orc.search_by_bow(p[0], p[1], 0.7, True)
+    tc4 = (time.perf_counter() - t0) / len(ub)
+    bytes_bow = 2 * 1200 * (4 + 32 + 4) + 1200 + 2 * 240 * 8 + 1200 * 4
+    out({"config": "searchByBoW: %d key-frame / frame pairs x 1200 + 1200 features, ~240 vocabulary nodes each" % B,
+         "pairs_per_s": B / t4, "single_pair_latency_us": 1e6 * t4l, "algorithmic_bytes_per_pair": bytes_bow,
+         "algorithmic_GBs": B * bytes_bow / t4 / 1e9, "cpu_oracle_1thread_pairs_per_s": 1.0 / tc4})
     out({"config": "searchByProjection(CurrentFrame, LastFrame): %d frame pairs x %d features x %d last-frame map points, th=7" % (B, NF, NL),
          "frames_per_s": B / t2, "cpu_oracle_1thread_frames_per_s": 1.0 / tc2})
     out({"config": "searchByProjection: %d frames x %d features x %d map points, th=3" % (B, NF, NP),
