@@ -2000,6 +2000,24 @@ GL_DEV void pipe_adv_open(const PipeA& a, GenP& G, PipeSt* st, int f, int* s_cnt
 
 // ---- set-up: k_ba_gen's, as parallel kernels (one workgroup builds the pose-major lists of 58 000 observations in 4 ms) ----
 // (1) per-pose / per-point / per-observation initial state, the partner table cleared
+// Workgroup -> (window f, part pb of its nper workgroups) of the per-window kernels, XCD-aware from 8 windows on: consecutive
+// workgroup ids go round the 8 XCDs, so window f takes the ids congruent to f modulo 8 - what kp_lin writes for a window (its
+// linearised observation records) is then in the L2 of the XCD on which kp_schur gathers it, and kp_trial finds the points there.
+// A matter of speed only (the placement is observed, not promised).  Grid: pipe_grid(B, nper) workgroups.
+GL_DEV bool pipe_wg(int B, int nper, int& f, int& pb) {
+  const int b = (int)blockIdx.x;
+  if (B >= 8) {
+    const int sl = b >> 3;
+    f = (b & 7) + 8 * (sl / nper);
+    pb = sl % nper;
+  } else {
+    f = b / nper;
+    pb = b % nper;
+  }
+  return f < B;
+}
+static inline int pipe_grid(int B, int nper) { return (B >= 8 ? 8 * ((B + 7) / 8) : B) * nper; }
+
 __global__ __launch_bounds__(T_BA) void kp_setup_init(PipeA a) {
   const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, tid = threadIdx.x, P = a.P, F = a.F, L = a.L;
   GenP G;
@@ -2221,7 +2239,9 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   __shared__ double s_Rt[32 * 12];
   __shared__ PipeSt s_q;
   __shared__ int s_accept, s_next;
-  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba, tid = threadIdx.x, P = a.P, F = a.F, n = 6 * P;
+  int f, pb;
+  if (!pipe_wg(a.B, a.nba, f, pb)) return;
+  const int tid = threadIdx.x, P = a.P, F = a.F, n = 6 * P;
   const PipeSt* sp = st_prev(a, f);
   PipeSt* sc = st_cur(a, f);
   const PipeCtl ctl = pipe_ctl(sp);
@@ -2338,12 +2358,14 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
 // ---- P2: one wave per (block (j1 <= j2) of the reduced camera system, chunk of pose j1's list: 1 / nchunk of the longest) ----------
 __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
   const int lane = threadIdx.x & 63;
-  // (the wave index as a SCALAR: block, chunk and the two poses' {R, t} are then scalar loads into SGPRs - as per-lane values the
-  // 24 doubles were loaded into VGPRs one dependent round trip after the other and spilled at once: most of a wave's 12 us)
-  const long gwave = (long)blockIdx.x * NW_BA + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // Workgroup -> (window, four of its waves) through the XCD-aware map (pipe_wg): an XCD then works on one or two windows at a time and
+  // the records its blocks share (every observation record is read by up to P blocks) stay in ITS 4 MB L2 instead of streaming
+  // through all eight: 64 windows 0.191 -> 0.175 ms per window.  per_prob is a multiple of 4 (nchunk is).
   const int per_prob = a.nblk * a.nchunk;
-  const int f = (int)(gwave / per_prob), w = (int)(gwave % per_prob);
-  if (f >= a.B) return;
+  int f, wq;
+  if (!pipe_wg(a.B, per_prob / NW_BA, f, wq)) return;
+  // (the wave index as a SCALAR: block, chunk and the two poses' {R, t} - scalar loads - are then SGPR values, not 48 VGPRs)
+  const int w = wq * NW_BA + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const PipeSt* st = st_cur(a, f);
   const PipeCtl ctl = pipe_ctl(st);
   if (ctl.stage >= 3) return;
@@ -2385,24 +2407,104 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
       sym_to_full(l1 + 3, A1);
       sym_to_full(l2 + 3, A2);
       sym_to_full(pw, Dv);
-      double blk[36];
+      // The 6 x 6 block G1^T M G2 = [[-Q1 M Q2, Q1 M], [-M Q2, M]] (gmg) is formed and added QUADRANT BY QUADRANT - with the whole block
+      // (and, on the diagonal, the whole of G1^T A1 G1 beside it) live at once the 48 accumulators did not fit the 256 registers and
+      // were spilled around every entry (247 MB of scratch writes per 64-window launch).  Same expressions, same values.
+      double M[9];
       if (schur) {  // M = A1 R1 D^-1 R2^T A2
-        double X[9], Y[9], Z[9], M[9];
+        double X[9], Y[9], Z[9];
         mm3(A1, R1, X);
         mm3(X, Dv, Y);
         mm3t(Y, R2, Z);
         mm3(Z, A2, M);
-        gmg(l1, M, l2, blk);
       } else {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
+        for (int i = 0; i < 9; ++i) M[i] = 0.0;
       }
-      double gq[6] = {0, 0, 0, 0, 0, 0}, bq[6] = {0, 0, 0, 0, 0, 0};
-      if (j1 == j2) {
-        double hpp[36];
-        gmg(l1, A1, l1, hpp);
+      const bool diag = j1 == j2;
+      double Q1M[9], Q1A[9];  // column j of Q1 M = q1 x M[:, j]; the same of A1 for the diagonal block's G1^T A1 G1
 #pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = hpp[i] - blk[i];
+      for (int j = 0; j < 3; ++j) {
+        const double col[3] = {M[j], M[3 + j], M[6 + j]};
+        double r[3];
+        cross(l1, col, r);
+        Q1M[j] = r[0];
+        Q1M[3 + j] = r[1];
+        Q1M[6 + j] = r[2];
+      }
+      if (!schur) {  // (gmg of the zero block gave zeros, not the -0.0 a cross product of zeros may)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Q1M[i] = 0.0;
+      }
+      if (diag) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double col[3] = {A1[j], A1[3 + j], A1[6 + j]};
+          double r[3];
+          cross(l1, col, r);
+          Q1A[j] = r[0];
+          Q1A[3 + j] = r[1];
+          Q1A[6 + j] = r[2];
+        }
+      }
+      // quadrant (R0, C0) of the block: bq[] its entries from M, hq[] the same of A1 (diagonal block); v += hq - bq  or  v += -bq
+      auto fold = [&](const int R0, const int C0, const double* bq, const double* hq) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int idx = (R0 + i) * 6 + C0 + j;
+            const double t = diag ? hq[i * 3 + j] - bq[i * 3 + j] : -bq[i * 3 + j];
+            if (idx < 32) v1[idx] += t;
+            else v2[idx - 32] += t;
+          }
+      };
+      {  // bottom right: M;  top right: Q1 M
+        fold(3, 3, M, A1);
+        fold(0, 3, Q1M, Q1A);
+      }
+      {  // bottom left: -M Q2, row i = q2 x M[i, :] after the two sign changes of gmg;  top left: -Q1 M Q2 likewise from Q1 M
+        double bl[9], hl[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          double r[3];
+          cross(l2, &M[i * 3], r);
+          bl[i * 3] = r[0];
+          bl[i * 3 + 1] = r[1];
+          bl[i * 3 + 2] = r[2];
+          if (diag) {
+            cross(l1, &A1[i * 3], r);
+            hl[i * 3] = r[0];
+            hl[i * 3 + 1] = r[1];
+            hl[i * 3 + 2] = r[2];
+          }
+        }
+        if (!schur) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) bl[i] = 0.0;
+        }
+        fold(3, 0, bl, hl);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          double r[3];
+          cross(l2, &Q1M[i * 3], r);
+          bl[i * 3] = r[0];
+          bl[i * 3 + 1] = r[1];
+          bl[i * 3 + 2] = r[2];
+          if (diag) {
+            cross(l1, &Q1A[i * 3], r);
+            hl[i * 3] = r[0];
+            hl[i * 3 + 1] = r[1];
+            hl[i * 3 + 2] = r[2];
+          }
+        }
+        if (!schur) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) bl[i] = 0.0;
+        }
+        fold(0, 0, bl, hl);
+      }
+      if (diag) {
         const double* aa = l1 + 9;  // bp = G^T a ; g = G^T (a - A1 R1 u)
         double c[3] = {aa[0], aa[1], aa[2]};
         if (schur) {
@@ -2420,23 +2522,11 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
         cross(l1, aa, qa);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          gq[i] = qc[i];
-          gq[3 + i] = c[i];
-          bq[i] = qa[i];
-          bq[3 + i] = aa[i];
+          v2[4 + i] += qc[i];
+          v2[7 + i] += c[i];
+          v2[10 + i] += qa[i];
+          v2[13 + i] += aa[i];
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = -blk[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 32; ++i) v1[i] += blk[i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v2[i] += blk[32 + i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        v2[4 + i] += gq[i];
-        v2[10 + i] += bq[i];
       }
     }
   }
@@ -2637,7 +2727,8 @@ __global__ __launch_bounds__(T_SOLVE) void kp_solve(PipeA a) {
 // ---- P3: back-substitution of the points, trial points, their chi2 -------------------------------------------------
 __global__ __launch_bounds__(T_BA) void kp_trial(PipeA a) {
   __shared__ double red[NW_BA * 32 + 8];
-  const int f = blockIdx.x / a.nba, pb = blockIdx.x % a.nba;
+  int f, pb;
+  if (!pipe_wg(a.B, a.nba, f, pb)) return;
   const PipeSt* st = st_cur(a, f);
   const PipeCtl ctl = pipe_ctl(st);
   const double lambda = st->lambda;
@@ -2825,8 +2916,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
     kp_setup_lists<1><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
     kp_setup_partner<<<B * a.nba, T_BA, 0, c->stream>>>(a);
   }
-  const long schur_waves = (long)B * a.nblk * a.nchunk;
-  const int schur_blocks = (int)((schur_waves + NW_BA - 1) / NW_BA);
+  const int schur_blocks = pipe_grid(B, a.nblk * a.nchunk / NW_BA);  // (XCD-aware workgroup map: pipe_wg)
   // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
   // one) + 4 cycles that open / change the stage + the one that judges the last trial: enough cycles for the common case are enqueued before the
   // first look at the counter, fewer per look afterwards
@@ -2838,11 +2928,11 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
       a.par = par;
       a.cyc = total + cyc;
       par ^= 1;
-      kp_lin<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+      kp_lin<<<pipe_grid(B, a.nba), T_BA, 0, c->stream>>>(a);
       kp_schur<<<schur_blocks, T_BA, 0, c->stream>>>(a);
       kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, c->stream>>>(a);
       kp_solve<<<B, T_SOLVE, s_bytes, c->stream>>>(a);
-      kp_trial<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+      kp_trial<<<pipe_grid(B, a.nba), T_BA, 0, c->stream>>>(a);
     }
     GL_HIP(hipGetLastError());
     GL_HIP(hipMemcpyAsync(c->host_word, a.unfinished, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
