@@ -522,6 +522,138 @@ GL_DEV void pass_trial_pipe(int lpp, const BaK& k, const GmmDev& gm, const GenP&
   return pass_trial<4>(k, gm, G, robust, lambda, P, acc);
 }
 
+// One entry of the Schur pass - the observation pair (o1 in pose j1, o2 in pose j2) of one point: its 6 x 6 block of the reduced camera
+// system, - G1^T (A1 R1 D^-1 R2^T A2) G2 off the diagonal, G1^T A1 G1 minus that on it, and on the diagonal the six + six entries of
+// g and b_p, added to the lane's 36 + 12 sums (v1[0..31], v2[0..15]: the block row-major, then g, then b_p).  l1 / l2: the two
+// observations' records {q, A (sym6), a}, pw: the point's {D^-1 (sym6), u}.  Shared by the persistent kernel and kp_schur.
+GL_DEV void schur_entry(const double* l1, const double* l2, const double* pw, const double* R1, const double* R2, bool schur, bool diag,
+                        double* v1, double* v2) {
+  double A1[9], A2[9], Dv[9];
+  sym_to_full(l1 + 3, A1);
+  sym_to_full(l2 + 3, A2);
+  sym_to_full(pw, Dv);
+  // The 6 x 6 block G1^T M G2 = [[-Q1 M Q2, Q1 M], [-M Q2, M]] (gmg) is formed and added QUADRANT BY QUADRANT - with the whole block
+  // (and, on the diagonal, the whole of G1^T A1 G1 beside it) live at once the 48 accumulators did not fit the 256 registers and
+  // were spilled around every entry (247 MB of scratch writes per 64-window launch).  Same expressions, same values.
+  double M[9];
+  if (schur) {  // M = A1 R1 D^-1 R2^T A2
+    double X[9], Y[9], Z[9];
+    mm3(A1, R1, X);
+    mm3(X, Dv, Y);
+    mm3t(Y, R2, Z);
+    mm3(Z, A2, M);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = 0.0;
+  }
+    double Q1M[9], Q1A[9];  // column j of Q1 M = q1 x M[:, j]; the same of A1 for the diagonal block's G1^T A1 G1
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double col[3] = {M[j], M[3 + j], M[6 + j]};
+    double r[3];
+    cross(l1, col, r);
+    Q1M[j] = r[0];
+    Q1M[3 + j] = r[1];
+    Q1M[6 + j] = r[2];
+  }
+  if (!schur) {  // (gmg of the zero block gave zeros, not the -0.0 a cross product of zeros may)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Q1M[i] = 0.0;
+  }
+  if (diag) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double col[3] = {A1[j], A1[3 + j], A1[6 + j]};
+      double r[3];
+      cross(l1, col, r);
+      Q1A[j] = r[0];
+      Q1A[3 + j] = r[1];
+      Q1A[6 + j] = r[2];
+    }
+  }
+  // quadrant (R0, C0) of the block: bq[] its entries from M, hq[] the same of A1 (diagonal block); v += hq - bq  or  v += -bq
+  auto fold = [&](const int R0, const int C0, const double* bq, const double* hq) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int idx = (R0 + i) * 6 + C0 + j;
+        const double t = diag ? hq[i * 3 + j] - bq[i * 3 + j] : -bq[i * 3 + j];
+        if (idx < 32) v1[idx] += t;
+        else v2[idx - 32] += t;
+      }
+  };
+  {  // bottom right: M;  top right: Q1 M
+    fold(3, 3, M, A1);
+    fold(0, 3, Q1M, Q1A);
+  }
+  {  // bottom left: -M Q2, row i = q2 x M[i, :] after the two sign changes of gmg;  top left: -Q1 M Q2 likewise from Q1 M
+    double bl[9], hl[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double r[3];
+      cross(l2, &M[i * 3], r);
+      bl[i * 3] = r[0];
+      bl[i * 3 + 1] = r[1];
+      bl[i * 3 + 2] = r[2];
+      if (diag) {
+        cross(l1, &A1[i * 3], r);
+        hl[i * 3] = r[0];
+        hl[i * 3 + 1] = r[1];
+        hl[i * 3 + 2] = r[2];
+      }
+    }
+    if (!schur) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) bl[i] = 0.0;
+    }
+    fold(3, 0, bl, hl);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double r[3];
+      cross(l2, &Q1M[i * 3], r);
+      bl[i * 3] = r[0];
+      bl[i * 3 + 1] = r[1];
+      bl[i * 3 + 2] = r[2];
+      if (diag) {
+        cross(l1, &Q1A[i * 3], r);
+        hl[i * 3] = r[0];
+        hl[i * 3 + 1] = r[1];
+        hl[i * 3 + 2] = r[2];
+      }
+    }
+    if (!schur) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) bl[i] = 0.0;
+    }
+    fold(0, 0, bl, hl);
+  }
+  if (diag) {
+    const double* aa = l1 + 9;  // bp = G^T a ; g = G^T (a - A1 R1 u)
+    double c[3] = {aa[0], aa[1], aa[2]};
+    if (schur) {
+      const double* u = pw + 6;
+      double Ru[3], ARu[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Ru[i] = R1[i * 3] * u[0] + R1[i * 3 + 1] * u[1] + R1[i * 3 + 2] * u[2];
+      sym3_mul_vec(l1 + 3, Ru, ARu);
+      c[0] -= ARu[0];
+      c[1] -= ARu[1];
+      c[2] -= ARu[2];
+    }
+    double qc[3], qa[3];
+    cross(l1, c, qc);
+    cross(l1, aa, qa);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v2[4 + i] += qc[i];
+      v2[7 + i] += c[i];
+      v2[10 + i] += qa[i];
+      v2[13 + i] += aa[i];
+    }
+  }
+}
+
 // ---- P2 -------------------------------------------------------------------------------------
 // One wave per block (j1 <= j2) of the reduced camera system, its lanes over the observations of pose j1; when
 // the problem's workgroups have at least 2 (4) waves per block, 2 (4) waves of a workgroup share a block (the
@@ -616,65 +748,7 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
       }
       if (o2 < 0) continue;
 #endif
-      double A1[9], A2[9], Dv[9];
-      sym_to_full(l1 + 3, A1);
-      sym_to_full(l2 + 3, A2);
-      sym_to_full(pw, Dv);
-      double blk[36];
-      if (schur) {
-        // M = A1 R1 D^-1 R2^T A2
-        double X[9], Y[9], Z[9], M[9];
-        mm3(A1, R1, X);
-        mm3(X, Dv, Y);
-        mm3t(Y, R2, Z);
-        mm3(Z, A2, M);
-        gmg(l1, M, l2, blk);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = 0.0;
-      }
-      double gq[6] = {0, 0, 0, 0, 0, 0}, bq[6] = {0, 0, 0, 0, 0, 0};
-      if (j1 == j2) {
-        double hpp[36];
-        gmg(l1, A1, l1, hpp);
-#pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = hpp[i] - blk[i];
-        // bp = G^T a ; g = G^T (a - A1 R1 u)
-        const double* a = l1 + 9;
-        double c[3] = {a[0], a[1], a[2]};
-        if (schur) {
-          const double* u = pw + 6;
-          double Ru[3], ARu[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) Ru[i] = R1[i * 3] * u[0] + R1[i * 3 + 1] * u[1] + R1[i * 3 + 2] * u[2];
-          sym3_mul_vec(l1 + 3, Ru, ARu);
-          c[0] -= ARu[0];
-          c[1] -= ARu[1];
-          c[2] -= ARu[2];
-        }
-        double qc[3], qa[3];
-        cross(l1, c, qc);
-        cross(l1, a, qa);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          gq[i] = qc[i];
-          gq[3 + i] = c[i];
-          bq[i] = qa[i];
-          bq[3 + i] = a[i];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) blk[i] = -blk[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 32; ++i) v1[i] += blk[i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v2[i] += blk[32 + i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        v2[4 + i] += gq[i];
-        v2[10 + i] += bq[i];
-      }
+      schur_entry(l1, l2, pw, R1, R2, schur, j1 == j2, v1, v2);
     }
     double r1 = wave_reduce_scatter32(v1);
     double r2 = wave_reduce_scatter32(v2);
@@ -2403,131 +2477,7 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
       const double* l1 = G.lin + (size_t)o1 * 12;
       const double* l2 = G.lin + (size_t)o2 * 12;
       const double* pw = G.ptw + (size_t)l * 12;
-      double A1[9], A2[9], Dv[9];
-      sym_to_full(l1 + 3, A1);
-      sym_to_full(l2 + 3, A2);
-      sym_to_full(pw, Dv);
-      // The 6 x 6 block G1^T M G2 = [[-Q1 M Q2, Q1 M], [-M Q2, M]] (gmg) is formed and added QUADRANT BY QUADRANT - with the whole block
-      // (and, on the diagonal, the whole of G1^T A1 G1 beside it) live at once the 48 accumulators did not fit the 256 registers and
-      // were spilled around every entry (247 MB of scratch writes per 64-window launch).  Same expressions, same values.
-      double M[9];
-      if (schur) {  // M = A1 R1 D^-1 R2^T A2
-        double X[9], Y[9], Z[9];
-        mm3(A1, R1, X);
-        mm3(X, Dv, Y);
-        mm3t(Y, R2, Z);
-        mm3(Z, A2, M);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) M[i] = 0.0;
-      }
-      const bool diag = j1 == j2;
-      double Q1M[9], Q1A[9];  // column j of Q1 M = q1 x M[:, j]; the same of A1 for the diagonal block's G1^T A1 G1
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double col[3] = {M[j], M[3 + j], M[6 + j]};
-        double r[3];
-        cross(l1, col, r);
-        Q1M[j] = r[0];
-        Q1M[3 + j] = r[1];
-        Q1M[6 + j] = r[2];
-      }
-      if (!schur) {  // (gmg of the zero block gave zeros, not the -0.0 a cross product of zeros may)
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Q1M[i] = 0.0;
-      }
-      if (diag) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double col[3] = {A1[j], A1[3 + j], A1[6 + j]};
-          double r[3];
-          cross(l1, col, r);
-          Q1A[j] = r[0];
-          Q1A[3 + j] = r[1];
-          Q1A[6 + j] = r[2];
-        }
-      }
-      // quadrant (R0, C0) of the block: bq[] its entries from M, hq[] the same of A1 (diagonal block); v += hq - bq  or  v += -bq
-      auto fold = [&](const int R0, const int C0, const double* bq, const double* hq) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const int idx = (R0 + i) * 6 + C0 + j;
-            const double t = diag ? hq[i * 3 + j] - bq[i * 3 + j] : -bq[i * 3 + j];
-            if (idx < 32) v1[idx] += t;
-            else v2[idx - 32] += t;
-          }
-      };
-      {  // bottom right: M;  top right: Q1 M
-        fold(3, 3, M, A1);
-        fold(0, 3, Q1M, Q1A);
-      }
-      {  // bottom left: -M Q2, row i = q2 x M[i, :] after the two sign changes of gmg;  top left: -Q1 M Q2 likewise from Q1 M
-        double bl[9], hl[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          double r[3];
-          cross(l2, &M[i * 3], r);
-          bl[i * 3] = r[0];
-          bl[i * 3 + 1] = r[1];
-          bl[i * 3 + 2] = r[2];
-          if (diag) {
-            cross(l1, &A1[i * 3], r);
-            hl[i * 3] = r[0];
-            hl[i * 3 + 1] = r[1];
-            hl[i * 3 + 2] = r[2];
-          }
-        }
-        if (!schur) {
-#pragma unroll
-          for (int i = 0; i < 9; ++i) bl[i] = 0.0;
-        }
-        fold(3, 0, bl, hl);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          double r[3];
-          cross(l2, &Q1M[i * 3], r);
-          bl[i * 3] = r[0];
-          bl[i * 3 + 1] = r[1];
-          bl[i * 3 + 2] = r[2];
-          if (diag) {
-            cross(l1, &Q1A[i * 3], r);
-            hl[i * 3] = r[0];
-            hl[i * 3 + 1] = r[1];
-            hl[i * 3 + 2] = r[2];
-          }
-        }
-        if (!schur) {
-#pragma unroll
-          for (int i = 0; i < 9; ++i) bl[i] = 0.0;
-        }
-        fold(0, 0, bl, hl);
-      }
-      if (diag) {
-        const double* aa = l1 + 9;  // bp = G^T a ; g = G^T (a - A1 R1 u)
-        double c[3] = {aa[0], aa[1], aa[2]};
-        if (schur) {
-          const double* u = pw + 6;
-          double Ru[3], ARu[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) Ru[i] = R1[i * 3] * u[0] + R1[i * 3 + 1] * u[1] + R1[i * 3 + 2] * u[2];
-          sym3_mul_vec(l1 + 3, Ru, ARu);
-          c[0] -= ARu[0];
-          c[1] -= ARu[1];
-          c[2] -= ARu[2];
-        }
-        double qc[3], qa[3];
-        cross(l1, c, qc);
-        cross(l1, aa, qa);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          v2[4 + i] += qc[i];
-          v2[7 + i] += c[i];
-          v2[10 + i] += qa[i];
-          v2[13 + i] += aa[i];
-        }
-      }
+      schur_entry(l1, l2, pw, R1, R2, schur, j1 == j2, v1, v2);
     }
   }
   const double r1 = wave_reduce_scatter32(v1), r2 = wave_reduce_scatter16(v2);  // (the 16 further sums: same tree, same bits)
