@@ -513,6 +513,22 @@ def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, ch
     return match, nm
 
 
+def fuse_search(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, mp_uvr, mp_level, mp_valid, mp_desc, th=3.0, scale_factor=1.2):
+    """Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: CUDA tensors feat_uv (B,NF,2)
+    f64, feat_ur (B,NF) f32, feat_oct (B,NF) i32, feat_desc (B,NF,32) u8; mp_uvr (B,NP,3) f64, mp_level (B,NP) i32, mp_valid (B,NP)
+    u8, mp_desc (B,NP,32) u8 -> (best_idx int32 (B,NP) or -1, best_dist int32 (B,NP))."""
+    import torch
+    B, NF = feat_oct.shape
+    NP = mp_level.shape[1]
+    bi = torch.empty((B, NP), dtype=torch.int32, device=feat_oct.device)
+    bd = torch.empty((B, NP), dtype=torch.int32, device=feat_oct.device)
+    ctx._enter()
+    _check(ctx.lib.gl_fuse_search(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
+                                  _ptr(feat_desc), _ptr(mp_uvr), _ptr(mp_level), _ptr(mp_valid), _ptr(mp_desc), float(th), _ptr(bi), _ptr(bd)))
+    ctx._exit()
+    return bi, bd
+
+
 def search_by_bow(ctx, kf, fr, nn_ratio=0.7, check_orientation=True):
     """ORBmatcher::searchByBoW (orb_matcher.cpp:295-408) for B key-frame / frame pairs.  kf: dict of CUDA tensors angle (B,N1) f32,
     desc (B,N1,32) u8, has_mp (B,N1) u8 (valid map point) and the feature vector as CSR (nnode, node_id, node_ptr, node_idx, as in

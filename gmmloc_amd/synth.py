@@ -378,3 +378,43 @@ def synth_bow_pair(N1, N2, seed, cam, n_nodes=160, mp_frac=0.7):
     rng = np.random.default_rng(seed + 77777)
     kf["has_mp"] = (rng.uniform(size=len(kf["oct"])) < mp_frac).astype(np.uint8)
     return kf, fr
+
+
+def synth_fuse_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2):
+    """Inputs of the matching half of Localization::fuseObservations for one key-frame: NF features (clustered, so that windows
+    hold several candidates; some with the SAME descriptor: ties) and NP projected map points - 75 % made from a feature with a
+    pixel error around the chi2 gates (5.99 / 7.8 at the feature's level, so that some pass and some do not), level = the feature's
+    octave or one above, descriptor with 0 .. 70 flipped bits (TH_LOW = 50 in between), the rest distractors; padding slots, points
+    outside the image, invalid points."""
+    rng = np.random.default_rng(seed)
+    sf = scale_factor ** np.arange(8)
+    ncl = max(1, NF // 6)
+    centres = np.stack([rng.uniform(0, width, ncl), rng.uniform(0, height, ncl)], 1)
+    uv = centres[rng.integers(0, ncl, NF)] + rng.normal(0, 4.0, (NF, 2))
+    octv = rng.integers(0, 8, NF).astype(np.int32)
+    octv[rng.uniform(size=NF) < 0.03] = -1
+    ur = np.where(rng.uniform(size=NF) < 0.7, uv[:, 0] - rng.uniform(2, 60, NF), -1.0).astype(np.float32)
+    desc = rng.integers(0, 256, (NF, 32), dtype=np.uint8)
+    twin = rng.integers(0, NF, NF // 10)  # equal descriptors on neighbouring features: equal distances
+    desc[twin] = desc[(twin + 1) % NF]
+    src = rng.integers(0, NF, NP)
+    from_feat = rng.uniform(size=NP) < 0.75
+    level = np.clip(np.maximum(octv[src], 0) + rng.integers(0, 2, NP), 0, 7).astype(np.int32)
+    level = np.where(from_feat, level, rng.integers(0, 8, NP)).astype(np.int32)
+    sig = sf[np.maximum(octv[src], 0)]
+    err = rng.normal(0, 1.2, (NP, 3)) * sig[:, None]
+    mp_uv = np.where(from_feat[:, None], uv[src] + err[:, :2],
+                     np.stack([rng.uniform(-30, width + 30, NP), rng.uniform(-30, height + 30, NP)], 1))
+    mp_ur = np.where(ur[src] >= 0, ur[src] + err[:, 2], mp_uv[:, 0] - rng.uniform(2, 60, NP))
+    mp_uvr = np.concatenate([mp_uv, mp_ur[:, None]], 1)
+    valid = (rng.uniform(size=NP) < 0.9).astype(np.uint8)
+    mp_desc = desc[src].copy()
+    nflip = rng.integers(0, 71, NP)
+    for m in range(NP):
+        if from_feat[m]:
+            bits = rng.choice(256, nflip[m], replace=False)
+            np.bitwise_xor.at(mp_desc[m], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+        else:
+            mp_desc[m] = rng.integers(0, 256, 32, dtype=np.uint8)
+    return dict(width=width, height=height, feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_desc=desc, mp_uvr=mp_uvr, mp_level=level,
+                mp_valid=valid, mp_desc=mp_desc)

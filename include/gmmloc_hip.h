@@ -295,6 +295,19 @@ int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1
                                 const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
                                 const double* fmat_dev, const float* epipole_dev, int only_stereo, int check_orientation,
                                 int32_t* match12_dev, int32_t* nmatches_dev);
+/* Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: per candidate map point the most
+ * similar feature inside Frame::getFeaturesInArea(u, v, th * scale_factors[level]) (frame.cpp:121-177) with octave level - 1 or
+ * level and Feature::error(uvr) * sigma2_inv[octave] within 5.99 (mono) / 7.8 (stereo).  Features as in gl_search_by_projection
+ * (feat_uv B x NF x 2, feat_ur B x NF float (< 0: mono), feat_oct B x NF (< 0: padding slot), feat_desc B x NF x 32); map points:
+ * mp_uvr B x NP x 3 = Frame::project3's (u, v, u_right), mp_level B x NP int32 = ProjStat::scale_pred, mp_valid B x NP uint8 = the
+ * host's tests of :238-254 (non-null, valid, not observed by the key-frame, project3 and checkScaleAndVisible passed), mp_desc
+ * B x NP x 32.  Out: best_idx B x NP int32 (the feature, if its distance is <= TH_LOW = 50, else -1) and best_dist B x NP int32 (256:
+ * no candidate).  The map points do not interact in this loop; what the reference does with a match (:296-312: addObservation, or
+ * replaceMapPoint by observation count) stays with the host, in list order.  cam supplies width / height (the 64 x 48 grid). */
+int gl_fuse_search(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NP, const double* feat_uv_dev,
+                   const float* feat_ur_dev, const int32_t* feat_oct_dev, const uint8_t* feat_desc_dev, const double* mp_uvr_dev,
+                   const int32_t* mp_level_dev, const uint8_t* mp_valid_dev, const uint8_t* mp_desc_dev, float th,
+                   int32_t* best_idx_dev, int32_t* best_dist_dev);
 /* ORBmatcher::searchByBoW (orb_matcher.cpp:295-408; computeThreeMaxima :544-578) for B key-frame / frame pairs: the matcher of
  * Tracking::trackReferenceKeyFrame (tracking.cpp:303), the last function of the reference's ORBmatcher.  Side 1 = the reference
  * key-frame: angle B x N1 float, desc B x N1 x 32, has_mp B x N1 uint8 (the feature holds a map point that is valid: `pMP &&

@@ -1654,6 +1654,94 @@ int orc_search_by_bow(float nn_ratio, int check_orientation, int N1, const float
   return nmatches;
 }
 
+// Localization::fuseObservations (localization.cpp:226-318), the matching half, one key-frame: for every candidate map point
+// (mp_valid: non-null, valid, not yet observed by the key-frame, project3 and checkScaleAndVisible passed - the host's part; mp_uvr
+// = project3's (u, v, u_right), mp_level = ProjStat::scale_pred) the most similar feature of Frame::getFeaturesInArea(u, v,
+// th * scale_factors[level]) (frame.cpp:121-177, no level arguments) whose octave is level - 1 or level and whose
+// Feature::error(uvr) * sigma2_inv[octave] (feature.h:17-28) is within 5.99 (mono) / 7.8 (stereo).  best_idx = the feature if its
+// distance is <= TH_LOW = 50, else -1; best_dist = the distance found (256: none).  What the reference does with the match
+// (addObservation / replaceMapPoint, :296-312) is the host's graph work.  Returns the number of map points with a match.
+int orc_fuse_search(int width, int height, float scale_factor, int NF, const double* feat_uv, const float* feat_ur, const int32_t* feat_oct,
+                    const uint8_t* feat_desc, int NP, const double* mp_uvr, const int32_t* mp_level, const uint8_t* mp_valid,
+                    const uint8_t* mp_desc, float th, int32_t* best_idx_out, int32_t* best_dist_out) {
+  const int grid_cols = 64, grid_rows = 48;
+  const float col_inv = static_cast<float>(grid_cols) / width, row_inv = static_cast<float>(grid_rows) / height;
+  float sf[8], sigma2_inv[8];
+  sf[0] = 1.0f;
+  sigma2_inv[0] = 1.0f;
+  for (int i = 1; i < 8; ++i) {
+    sf[i] = sf[i - 1] * scale_factor;
+    const float sigma2 = sf[i] * sf[i];
+    sigma2_inv[i] = 1.0f / sigma2;
+  }
+  std::vector<std::vector<int>> grid((size_t)grid_cols * grid_rows);
+  for (int i = 0; i < NF; ++i) {
+    if (feat_oct[i] < 0) continue;  // padding slot, not a feature
+    const int px = (int)round((feat_uv[2 * i] - 0.0f) * col_inv), py = (int)round((feat_uv[2 * i + 1] - 0.0f) * row_inv);
+    if (px < 0 || px >= grid_cols || py < 0 || py >= grid_rows) continue;
+    grid[(size_t)px * grid_rows + py].push_back(i);
+  }
+  int num = 0;
+  for (int m = 0; m < NP; ++m) {
+    best_idx_out[m] = -1;
+    best_dist_out[m] = 256;
+    if (!mp_valid[m]) continue;
+    const double uvr[3] = {mp_uvr[3 * m], mp_uvr[3 * m + 1], mp_uvr[3 * m + 2]};
+    const int lvl_pred = mp_level[m];
+    const float radius = th * sf[lvl_pred];
+    const float x = uvr[0], y = uvr[1], r = radius;  // getFeaturesInArea(const float&, const float&, const float&)
+    const int x0 = std::max(0, (int)floor((x - 0.0f - r) * col_inv));
+    if (x0 >= grid_cols) continue;
+    const int x1 = std::min(grid_cols - 1, (int)ceil((x - 0.0f + r) * col_inv));
+    if (x1 < 0) continue;
+    const int y0 = std::max(0, (int)floor((y - 0.0f - r) * row_inv));
+    if (y0 >= grid_rows) continue;
+    const int y1 = std::min(grid_rows - 1, (int)ceil((y - 0.0f + r) * row_inv));
+    if (y1 < 0) continue;
+    int best_dist = 256, best_idx = -1;
+    for (int ix = x0; ix <= x1; ++ix)
+      for (int iy = y0; iy <= y1; ++iy)
+        for (int idx : grid[(size_t)ix * grid_rows + iy]) {
+          const float distx = feat_uv[2 * idx] - x, disty = feat_uv[2 * idx + 1] - y;
+          if (!(fabs(distx) < r && fabs(disty) < r)) continue;
+          const int kpLevel = feat_oct[idx];
+          if (kpLevel < lvl_pred - 1 || kpLevel > lvl_pred) continue;
+          double err;
+          {
+            const double dx = feat_uv[2 * idx] - uvr[0], dy = feat_uv[2 * idx + 1] - uvr[1];
+            if (feat_ur[idx] < 0.0f) {
+              err = dx * dx + dy * dy;
+            } else {
+              const double dz = (double)feat_ur[idx] - uvr[2];
+              err = dx * dx + dy * dy + dz * dz;
+            }
+          }
+          err *= sigma2_inv[kpLevel];
+          const double thresh = feat_ur[idx] >= 0 ? 7.8 : 5.99;
+          if (err > thresh) continue;
+          const int32_t* pa = (const int32_t*)(mp_desc + (size_t)m * 32);
+          const int32_t* pb = (const int32_t*)(feat_desc + (size_t)idx * 32);
+          int dist = 0;
+          for (int w = 0; w < 8; ++w) {
+            unsigned int v = pa[w] ^ pb[w];
+            v = v - ((v >> 1) & 0x55555555);
+            v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+            dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+          }
+          if (dist < best_dist) {
+            best_dist = dist;
+            best_idx = idx;
+          }
+        }
+    best_dist_out[m] = best_dist;
+    if (best_dist <= 50) {  // TH_LOW
+      best_idx_out[m] = best_idx;
+      num++;
+    }
+  }
+  return num;
+}
+
 void orc_se3_exp(const double* u, double* pose) { from_se3(se3_exp(u), pose); }
 void orc_se3_log(const double* pose, double* u) { se3_log(to_se3(pose), u); }
 void orc_se3_mul(const double* a, const double* b, double* out) { from_se3(se3_mul(to_se3(a), to_se3(b)), out); }

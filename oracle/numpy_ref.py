@@ -1041,3 +1041,59 @@ def search_by_bow(kf, fr, nn_ratio=0.7, check_orientation=True):
             if bb not in (i1, i2, i3):
                 match[idx] = -1
     return match, int((match >= 0).sum())
+
+
+def fuse_search(width, height, feat_uv, feat_ur, feat_oct, feat_desc, mp_uvr, mp_level, mp_valid, mp_desc, th=3.0, scale_factor=1.2):
+    """Localization::fuseObservations (localization.cpp:226-318), the matching half, independent restatement: all features at once
+    as vectors (window test in float, level band, the pixel / disparity chi2 against 5.99 / 7.8, byte-table popcount); the grid of
+    the reference only fixes the visiting ORDER (cell column, cell row, feature index), which decides ties: the minimum is taken
+    over the candidates in that order with a stable argmin.  -> (best_idx [NP] or -1, best_dist [NP], matched)."""
+    f32 = np.float32
+    col_inv, row_inv = f32(64) / f32(width), f32(48) / f32(height)
+    sf = [f32(1.0)]
+    for _ in range(7):
+        sf.append(f32(sf[-1] * f32(scale_factor)))
+    s2i = np.array([f32(1.0)] + [f32(f32(1.0) / f32(v * v)) for v in sf[1:]], f32)
+    NF, NP = len(feat_oct), len(mp_valid)
+    rnd = lambda v: np.where(v >= 0, np.floor(v + 0.5), np.ceil(v - 0.5)).astype(np.int64)
+    px = rnd(feat_uv[:, 0] * np.float64(col_inv))
+    py = rnd(feat_uv[:, 1] * np.float64(row_inv))
+    in_grid = (feat_oct >= 0) & (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    order = np.lexsort((np.arange(NF), py, px))
+    order = order[in_grid[order]]
+    fu, fv, fr, fo = feat_uv[order, 0], feat_uv[order, 1], feat_ur[order].astype(f32), feat_oct[order]
+    best_idx = -np.ones(NP, np.int32)
+    best_dist = np.full(NP, 256, np.int32)
+    n = 0
+    for m in range(NP):
+        if not mp_valid[m]:
+            continue
+        lvl = int(mp_level[m])
+        rr = f32(f32(th) * sf[lvl])
+        x, y = f32(mp_uvr[m, 0]), f32(mp_uvr[m, 1])
+        if int(np.floor(f32(f32(x - rr) * col_inv))) >= 64 or int(np.ceil(f32(f32(x + rr) * col_inv))) < 0:
+            continue
+        if int(np.floor(f32(f32(y - rr) * row_inv))) >= 48 or int(np.ceil(f32(f32(y + rr) * row_inv))) < 0:
+            continue
+        # the cell window of getFeaturesInArea (a feature outside it cannot pass the float window test: its cell is its rounded position)
+        cx0 = max(0, int(np.floor(f32(f32(x - rr) * col_inv)))); cx1 = min(63, int(np.ceil(f32(f32(x + rr) * col_inv))))
+        cy0 = max(0, int(np.floor(f32(f32(y - rr) * row_inv)))); cy1 = min(47, int(np.ceil(f32(f32(y + rr) * row_inv))))
+        pxo, pyo = px[order], py[order]
+        win = (pxo >= cx0) & (pxo <= cx1) & (pyo >= cy0) & (pyo <= cy1)
+        dxf = (fu - np.float64(x)).astype(f32)
+        dyf = (fv - np.float64(y)).astype(f32)
+        win &= (np.abs(dxf) < rr) & (np.abs(dyf) < rr)
+        win &= (fo >= lvl - 1) & (fo <= lvl)
+        dx, dy, dz = fu - mp_uvr[m, 0], fv - mp_uvr[m, 1], fr.astype(np.float64) - mp_uvr[m, 2]
+        err = np.where(fr < 0, dx * dx + dy * dy, dx * dx + dy * dy + dz * dz) * s2i[np.clip(fo, 0, 7)].astype(np.float64)
+        win &= ~(err > np.where(fr >= 0, 7.8, 5.99))
+        if not win.any():
+            continue
+        cand = np.nonzero(win)[0]
+        d = _POP8[np.bitwise_xor(mp_desc[m][None, :], feat_desc[order[cand]])].sum(1)
+        k = int(np.argmin(d))  # first minimum in visiting order
+        best_dist[m] = int(d[k])
+        if d[k] <= 50:
+            best_idx[m] = int(order[cand[k]])
+            n += 1
+    return best_idx, best_dist, n

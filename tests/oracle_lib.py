@@ -257,6 +257,18 @@ class Oracle:
                                        _p(a2[2]), _p(a2[3]), _p(a2[4]), _p(out))
         return out, int(n)
 
+    def fuse_search(self, width, height, feat_uv, feat_ur, feat_oct, feat_desc, mp_uvr, mp_level, mp_valid, mp_desc, th=3.0, scale_factor=1.2):
+        """Localization::fuseObservations, matching half, one key-frame -> (best_idx [NP], best_dist [NP], matched)."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        a = [_f64(feat_uv), f32(feat_ur), _i32(feat_oct), u8(feat_desc), _f64(mp_uvr), _i32(mp_level), u8(mp_valid), u8(mp_desc)]
+        NF, NP = len(a[2]), len(a[5])
+        bi, bd = np.zeros(NP, np.int32), np.zeros(NP, np.int32)
+        self.lib.orc_fuse_search.restype = C.c_int
+        n = self.lib.orc_fuse_search(int(width), int(height), C.c_float(scale_factor), NF, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), NP,
+                                     _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), C.c_float(th), _p(bi), _p(bd))
+        return bi, bd, int(n)
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

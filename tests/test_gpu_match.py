@@ -326,3 +326,56 @@ def test_search_by_bow_soak(gpu, oracle):
             assert np.array_equal(match[b, :len(m_ref)], m_ref) and nm[b] == n_ref, (b, ratio, chk)
             checked += n_ref
     assert checked > 3000
+
+
+FUSE_KEYS = ("feat_uv", "feat_ur", "feat_oct", "feat_desc", "mp_uvr", "mp_level", "mp_valid", "mp_desc")
+
+
+def _pack_fuse(torch, frames):
+    NF = max(len(f["feat_oct"]) for f in frames)
+    NP = max(len(f["mp_level"]) for f in frames)
+    B = len(frames)
+    t = dict(feat_uv=np.zeros((B, NF, 2)), feat_ur=np.full((B, NF), -1.0, np.float32), feat_oct=np.full((B, NF), -1, np.int32),
+             feat_desc=np.zeros((B, NF, 32), np.uint8), mp_uvr=np.zeros((B, NP, 3)), mp_level=np.zeros((B, NP), np.int32),
+             mp_valid=np.zeros((B, NP), np.uint8), mp_desc=np.zeros((B, NP, 32), np.uint8))
+    for b, f in enumerate(frames):
+        nf, npn = len(f["feat_oct"]), len(f["mp_level"])
+        for k in ("feat_uv", "feat_ur", "feat_oct", "feat_desc"):
+            t[k][b, :nf] = f[k]
+        for k in ("mp_uvr", "mp_level", "mp_valid", "mp_desc"):
+            t[k][b, :npn] = f[k]
+    return [torch.from_numpy(t[k]).cuda() for k in FUSE_KEYS]
+
+
+def test_fuse_search_matches_oracle(gpu, oracle):
+    """gl_fuse_search (Localization::fuseObservations, localization.cpp:226-318, the matching half) against the sequential oracle:
+    best feature and best distance of every map point bit for bit - crowded windows, equal distances (the first in the grid's
+    visiting order), the level band, the chi2 gates, points outside the image, padding slots, key-frames of different sizes in one
+    batch; then 120 random key-frames."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    cam.width, cam.height = 752, 480
+    frames = [synth.synth_fuse_frame(NF, NP, 800 + i) for i, (NF, NP) in enumerate(((300, 260), (1200, 1500), (2000, 3000), (40, 900), (700, 30), (5, 5)))]
+    for th in (3.0, 5.0):
+        bi, bd = api.fuse_search(ctx, cam, *_pack_fuse(torch, frames), th=th)
+        torch.cuda.synchronize()
+        bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+        tot = 0
+        for b, f in enumerate(frames):
+            ri, rd, n = oracle.fuse_search(f["width"], f["height"], *[f[k] for k in FUSE_KEYS], th=th)
+            npn = len(ri)
+            assert np.array_equal(bi[b, :npn], ri) and np.array_equal(bd[b, :npn], rd), (b, th, int((bi[b, :npn] != ri).sum()))
+            assert (bi[b, npn:] == -1).all()
+            tot += n
+        assert tot > 1000
+    rng = np.random.default_rng(79)
+    frames = [synth.synth_fuse_frame(int(rng.integers(5, 1800)), int(rng.integers(5, 2200)), 9000 + i) for i in range(120)]
+    bi, bd = api.fuse_search(ctx, cam, *_pack_fuse(torch, frames), th=3.0)
+    torch.cuda.synchronize()
+    bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+    tot = 0
+    for b, f in enumerate(frames):
+        ri, rd, n = oracle.fuse_search(f["width"], f["height"], *[f[k] for k in FUSE_KEYS], th=3.0)
+        assert np.array_equal(bi[b, :len(ri)], ri) and np.array_equal(bd[b, :len(ri)], rd), b
+        tot += n
+    assert tot > 20000

@@ -19,6 +19,7 @@ python tools/fixed_time.py 4096 300 2 > gpurun_out/${TAG}_fixed_time.txt 2>/dev/
 python tools/fixed_time.py 2048 1000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/fixed_time.py 1024 2000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 ./build_tmp/bench_mfma_reduce > gpurun_out/${TAG}_mfma_reduce.txt 2>/dev/null
+python tools/soak_match.py ${SOAK_MATCH:-300} 2>/dev/null | tail -3 > gpurun_out/${TAG}_soak_match.txt
 python tools/soak.py 2000 > gpurun_out/${TAG}_soak_strict.txt 2>&1
 tail -2 gpurun_out/${TAG}_soak_strict.txt | cut -c1-500
 python tools/soak_track.py ${SOAK_TRACK:-86000} > gpurun_out/${TAG}_soak_track.txt 2>&1

@@ -256,6 +256,18 @@ def main():
         out["b%d_match" % i] = m
         out["b%d_n" % i] = np.array(n)
     np.savez_compressed(os.path.join(G, "golden_bow_match.npz"), **out)
+
+    # ---- fuseObservations, matching half: key-frames through the independent numpy restatement (inputs regenerated from the seeds)
+    out = {}
+    FK = ("width", "height", "feat_uv", "feat_ur", "feat_oct", "feat_desc", "mp_uvr", "mp_level", "mp_valid", "mp_desc")
+    for i, (NF, NP, seed, th10) in enumerate(((300, 260, 401, 30), (1200, 1500, 402, 30), (700, 900, 403, 50), (150, 600, 404, 25))):
+        f = synth.synth_fuse_frame(NF, NP, seed)
+        bi, bd, n = nr.fuse_search(*[f[k] for k in FK], th=th10 / 10.0)
+        out["u%d_args" % i] = np.array([NF, NP, seed, th10])
+        out["u%d_idx" % i] = bi
+        out["u%d_dist" % i] = bd
+        out["u%d_n" % i] = np.array(n)
+    np.savez_compressed(os.path.join(G, "golden_fuse.npz"), **out)
     print("golden vectors written to", G)
 
 

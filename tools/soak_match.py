@@ -1,6 +1,7 @@
-"""Randomised parity soak of the two matchers (gl_search_by_projection: ORBmatcher::searchByProjection of
+"""Randomised parity soak of the four matchers (gl_search_by_projection: ORBmatcher::searchByProjection of
 searchLocalPoints, orb_matcher.cpp:27-110; gl_search_by_projection_frame: the trackWithMotionModel overload,
-orb_matcher.cpp:410-542) against the oracle's sequential restatement: integer work, every index and count must be equal.
+orb_matcher.cpp:410-542; gl_search_for_triangulation :141-293; gl_search_by_bow :295-408) against the oracle's sequential
+restatement: integer work, every index and count must be equal.
     python tools/soak_match.py [rounds]"""
 import os
 import sys
@@ -13,14 +14,14 @@ import torch
 import gmmloc_amd
 from gmmloc_amd import api, synth
 from tests import oracle_lib
-from tests.test_gpu_match import CamF, run_gpu, run_gpu_frame
+from tests.test_gpu_match import CamF, run_gpu, run_gpu_frame, _pack_pairs, _pack_bow
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 orc = oracle_lib.load()
 ctx = gmmloc_amd.Context(0)
-bad = dict(local=0, frame=0)
-n_checked = dict(local=0, frame=0)
-matched = dict(local=0, frame=0)
+bad = dict(local=0, frame=0, tri=0, bow=0)
+n_checked = dict(local=0, frame=0, tri=0, bow=0)
+matched = dict(local=0, frame=0, tri=0, bow=0)
 t0 = time.time()
 for r in range(rounds):
     rng = np.random.default_rng(90000 + r)
@@ -54,6 +55,37 @@ for r in range(rounds):
             bad["frame"] += 1
             print("MISMATCH frame  round %d frame %d NF %d NL %d th %.0f %s mono %s chk %s: %d vs %d matches, %d indices differ"
                   % (r, b, NF, NL, th, motion, mono, chk, int(n[b]), n_ref, int((m[b] != m_ref).sum())), flush=True)
+    # searchForTriangulation and searchByBoW on the same kind of key-frame pairs
+    cam = api.Camera()
+    pairs = [synth.synth_tri_search_pair(int(rng.integers(20, 1500)), int(rng.integers(20, 1500)), 31337 * r + b, cam,
+                                         n_nodes=int(rng.integers(3, 260)), only_stereo_frac=float(rng.uniform(0, 1)), pad=int(rng.integers(0, 2)))
+             for b in range(B)]
+    k1, k2, fm, ep = _pack_pairs(torch, pairs)
+    only_stereo, chk = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    m, n = api.search_for_triangulation(ctx, k1, k2, fm, ep, only_stereo, chk)
+    torch.cuda.synchronize()
+    m, n = m.cpu().numpy(), n.cpu().numpy()
+    for b, p in enumerate(pairs):
+        m_ref, n_ref = orc.search_for_triangulation(p["kf1"], p["kf2"], p["fmat"], p["epipole"], only_stereo, chk)
+        n_checked["tri"] += 1
+        matched["tri"] += int(n_ref)
+        if n[b] != n_ref or not np.array_equal(m[b, :len(m_ref)], m_ref):
+            bad["tri"] += 1
+            print("MISMATCH tri    round %d pair %d: %d vs %d matches" % (r, b, int(n[b]), n_ref), flush=True)
+    bows = [synth.synth_bow_pair(int(rng.integers(20, 1500)), int(rng.integers(20, 1500)), 27644437 + 977 * r + b, cam,
+                                 n_nodes=int(rng.integers(3, 260)), mp_frac=float(rng.uniform(0.05, 1))) for b in range(B)]
+    kf, fr = _pack_bow(torch, bows)
+    ratio = float(rng.choice([0.6, 0.7, 0.8, 0.9]))
+    m, n = api.search_by_bow(ctx, kf, fr, ratio, chk)
+    torch.cuda.synchronize()
+    m, n = m.cpu().numpy(), n.cpu().numpy()
+    for b, p in enumerate(bows):
+        m_ref, n_ref = orc.search_by_bow(p[0], p[1], ratio, chk)
+        n_checked["bow"] += 1
+        matched["bow"] += int(n_ref)
+        if n[b] != n_ref or not np.array_equal(m[b, :len(m_ref)], m_ref):
+            bad["bow"] += 1
+            print("MISMATCH bow    round %d pair %d ratio %.1f chk %s: %d vs %d matches" % (r, b, ratio, chk, int(n[b]), n_ref), flush=True)
 ctx.set_option("match_desc_lds", -1)
 print("matcher soak: %d rounds; frames checked %s, matches compared %s; mismatching frames %s; %.0f s"
       % (rounds, n_checked, matched, bad, time.time() - t0))
