@@ -78,6 +78,8 @@ def load():
         "gl_search_for_triangulation": (i32, [vp, C.c_float, i32, i32, i32, i32, i32] + [vp] * 22 + [i32, i32, vp, vp]),
         "gl_search_by_bow": (i32, [vp, C.c_float, i32, i32, i32, i32, i32, i32] + [vp] * 15),
         "gl_fuse_search": (i32, [vp, vp, C.c_float, i32, i32, i32] + [vp] * 8 + [C.c_float, vp, vp]),
+        "gl_project_map_points": (i32, [vp, vp, C.c_float, i32, i32] + [vp] * 12),
+        "gl_level_steps": (i32, [C.c_float, vp]),
         "gl_gather_triangulation_matches": (i32, [vp, i32, i32, i32, i32, i32] + [vp] * 32),
         "gl_optimize_point": (i32, [vp, vp, P(gl_camera), P(gl_params), i32] + [vp] * 10),
         "gl_check_map_association": (i32, [vp, vp, P(gl_camera), P(gl_params), i32, i32] + [vp] * 6 + [i32, vp]),

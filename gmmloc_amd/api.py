@@ -513,6 +513,33 @@ def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, ch
     return match, nm
 
 
+def level_steps(scale_factor=1.2):
+    """The seven steps of the predicted level (mappoint.cpp:289-293) with the host's logf: step[L] = largest ratio with level <= L."""
+    out = np.zeros(7, np.float32)
+    _check(_lib.load().gl_level_steps(float(scale_factor), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def project_map_points(ctx, cam, pose_cw, t_wc, pos, normal, max_dist, min_dist, cand, scale_factor=1.2):
+    """Frame::project3 + MapPoint::checkScaleAndVisible for B frames x NP map points (tracking.cpp:233-256): CUDA tensors pose_cw (B,7),
+    t_wc (B,3), pos / normal (B,NP,3) f64, max_dist / min_dist (B,NP) f32, cand (B,NP) u8 -> (uvr (B,NP,3), level int32 (B,NP),
+    viewcos (B,NP), dist (B,NP), inview u8 (B,NP)): the mp_* inputs of search_by_projection / fuse_search."""
+    import torch
+    B, NP = cand.shape
+    dev = cand.device
+    uvr = torch.empty((B, NP, 3), dtype=torch.float64, device=dev)
+    level = torch.empty((B, NP), dtype=torch.int32, device=dev)
+    viewcos = torch.empty((B, NP), dtype=torch.float64, device=dev)
+    dist = torch.empty((B, NP), dtype=torch.float64, device=dev)
+    inview = torch.empty((B, NP), dtype=torch.uint8, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_project_map_points(ctx.h, C.byref(cam.c()), float(scale_factor), B, NP, _ptr(pose_cw), _ptr(t_wc), _ptr(pos), _ptr(normal),
+                                         _ptr(max_dist), _ptr(min_dist), _ptr(cand), _ptr(uvr), _ptr(level), _ptr(viewcos), _ptr(dist),
+                                         _ptr(inview)))
+    ctx._exit()
+    return uvr, level, viewcos, dist, inview
+
+
 def fuse_search(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, mp_uvr, mp_level, mp_valid, mp_desc, th=3.0, scale_factor=1.2):
     """Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: CUDA tensors feat_uv (B,NF,2)
     f64, feat_ur (B,NF) f32, feat_oct (B,NF) i32, feat_desc (B,NF,32) u8; mp_uvr (B,NP,3) f64, mp_level (B,NP) i32, mp_valid (B,NP)

@@ -312,8 +312,9 @@ GL_DEV double group_sum(double v) {
 }
 // LPP adjacent lanes per point (1, 2 or 4: as many as the problem's workgroups have threads for): the
 // observations of the point are dealt round them, the 3x3 point block and its rhs are summed over the group
-template <int LPP>
-GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
+// (KEEP: the undamped point block goes to pth - L x 6 - as well: what point_relambda needs)
+template <int LPP, bool KEEP = false>
+GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag, double* pth = nullptr) {
   double chi = 0.0;
   const int sub = (int)threadIdx.x & (LPP - 1);
   for (int l = GSTART / LPP; l < G.L; l += GSTRIDE / LPP) {
@@ -398,6 +399,10 @@ GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool ro
     double D[6] = {H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda}, Dinv[6], u[3];
     sym3_inv(D, Dinv);
     sym3_mul_vec(Dinv, bl, u);
+    if (KEEP && sub == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pth[(size_t)l * 6 + i] = H[i];
+    }
     if (sub == 0) {
       double* pw = G.ptw + (size_t)l * 12;
 #pragma unroll
@@ -419,9 +424,31 @@ GL_DEV double pass_points_lpp(int lpp, const BaK& k, const GmmDev& gm, const Gen
 
 // (the kernels of the pipelined shape: 4 lanes per point, 8 where a point has six or more observations on average - half
 // the dependent loads per lane; instances of their own, so that the persistent kernel's code is what it was)
-GL_DEV double pass_points_pipe(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
-  if (lpp == 8) return pass_points<8>(k, gm, G, robust, lambda, mdiag);
-  return pass_points<4>(k, gm, G, robust, lambda, mdiag);
+GL_DEV double pass_points_pipe(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag, double* pth) {
+  if (lpp == 8) return pass_points<8, true>(k, gm, G, robust, lambda, mdiag, pth);
+  return pass_points<4, true>(k, gm, G, robust, lambda, mdiag, pth);
+}
+// The point pass of a trial whose state is the one the previous point pass linearised at (a rejected trial's successor, the first
+// trial after the lambda-init pass): only lambda has changed, and of everything the pass writes only {D^-1, u} = {(H + lambda I)^-1,
+// D^-1 b} of the points depends on it - the observation records, b, chi2 and the largest diagonal entry are what they were.  The
+// same expressions on the same values as the tail of pass_points: the same bits.  A thread per point.
+GL_DEV void point_relambda(const GenP& G, double lambda, const double* pth) {
+  for (int l = GSTART; l < G.L; l += GSTRIDE) {
+    if (!G.lact[l]) continue;
+    double* pw = G.ptw + (size_t)l * 12;
+    double H[6], bl[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) H[i] = pth[(size_t)l * 6 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bl[i] = pw[9 + i];
+    double D[6] = {H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda}, Dinv[6], u[3];
+    sym3_inv(D, Dinv);
+    sym3_mul_vec(Dinv, bl, u);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pw[i] = Dinv[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pw[6 + i] = u[i];
+  }
 }
 
 // ---- P3: back-substitution of the points, trial points, their chi2 (LPP lanes per point like P1) ------------
@@ -1865,6 +1892,7 @@ struct PipeA {  // kernel arguments (by value)
   double* partA;      // B x nba x 2   {robust chi2, max point diagonal} per workgroup of the point pass
   double* partD;      // B x nba x 2   {scale part, chi2 at the trial state}
   double* partS;      // B x nblk x nchunk x 48
+  double* pth;        // B x L x 6: the points' undamped blocks of the last full point pass (point_relambda)
   int* unfinished;    // problems not at stage 3
   int nba, lpp, nblk, nchunk;
 };
@@ -2415,11 +2443,19 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
     pipe_adv_points(a, G, s_q, f, pb);
     return;
   }
+  double* pth = a.pth + (size_t)f * a.L * 6;
+  // Nothing has moved since the last point pass (the trial was rejected, or this is the first trial after the stage's lambda-init
+  // pass): only the damping is new - 20 of the 33 trials of the 8 + 4 test window
+  // (not judged, not a lambda-init pass, stage open: the cycle after the lambda-init pass, whose solve kernel clears `init`)
+  if (!s_q.init && !accept) {
+    point_relambda(G, s_q.lambda, pth);
+    return;
+  }
   G.Rt = s_Rt;
   double acc[32], md = 0.0;
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  acc[0] = pass_points_pipe(a.lpp, a.k, a.gm, G, s_q.stage < 2, s_q.init ? 0.0 : s_q.lambda, md);
+  acc[0] = pass_points_pipe(a.lpp, a.k, a.gm, G, s_q.stage < 2, s_q.init ? 0.0 : s_q.lambda, md, pth);
   block_reduce<1, NW_BA>(acc, red);
   md = block_max(md, red);
   if (threadIdx.x == 0) {
@@ -2804,7 +2840,7 @@ size_t ba_pipe_scratch_bytes(int B, int P, int F, int L, int NOBS) {
   pipe_shape(P, L, NOBS, &nba, &lpp, &nblk, &nchunk);
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
   return ba_gen_scratch_bytes(B, P, F, L, NOBS) + up((size_t)2 * B * sizeof(PipeSt)) + 2 * up((size_t)B * nba * 16) +
-         up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * nblk * 4) + 1024;
+         up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * L * 6 * 8) + up((size_t)B * nblk * 4) + 1024;
 }
 
 int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
@@ -2846,6 +2882,8 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   s += up((size_t)B * a.nba * 16);
   a.partS = (double*)s;
   s += up((size_t)B * a.nblk * a.nchunk * 48 * 8);
+  a.pth = (double*)s;
+  s += up((size_t)B * L * 6 * 8);
   a.unfinished = (int*)s;  // [0] problems not finished, [1] cycles the slowest of them needed
   const size_t n = 6 * (size_t)P;
   const size_t s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;

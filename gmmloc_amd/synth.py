@@ -418,3 +418,37 @@ def synth_fuse_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2):
             mp_desc[m] = rng.integers(0, 256, 32, dtype=np.uint8)
     return dict(width=width, height=height, feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_desc=desc, mp_uvr=mp_uvr, mp_level=level,
                 mp_valid=valid, mp_desc=mp_desc)
+
+
+def synth_project_frame(NP, seed, cam, scale_factor=1.2):
+    """Inputs of the projection / visibility loop of Tracking::searchLocalPoints for one frame: a camera somewhere in a room, NP map
+    points around it - most in front (a share behind it, outside the image, exactly on the image border), each with the normal and the
+    distance band of a reference key-frame that saw it: normal = direction from that key-frame (so that view_cos lands on both sides
+    of 0.5), max_dist_ = its distance x 1.2 ^ level, min_dist_ = max_dist_ / 1.2 ^ 7 (ORB-SLAM's update of normal and depth) - the
+    reference key-frame at 0.3 .. 4 times the camera's distance, so that the band test rejects some and the predicted level covers
+    0 .. 7 with clamping at both ends; a share of non-candidates."""
+    rng = np.random.default_rng(seed)
+    eye = rng.uniform(-3, 3, 3)
+    unit = lambda n: (lambda g: g / np.linalg.norm(g, axis=1)[:, None])(rng.standard_normal((n, 3)))
+    target = eye + unit(1)[0] * 3.0
+    pose = look_at_pose(eye, target, up=unit(1)[0])
+    R = quat_to_R(pose[:4])
+    t_wc = -R.T @ pose[4:]
+    depth = rng.uniform(0.3, 12.0, NP)
+    depth[rng.uniform(size=NP) < 0.08] *= -1.0
+    u = rng.uniform(-0.15 * cam.width, 1.15 * cam.width, NP)
+    v = rng.uniform(-0.15 * cam.height, 1.15 * cam.height, NP)
+    pc = np.stack([(u - cam.cx) / cam.fx * depth, (v - cam.cy) / cam.fy * depth, depth], 1)
+    pos = (pc - pose[4:]) @ R  # R^T (pc - t)
+    ref_dir = -(pos - t_wc) / np.linalg.norm(pos - t_wc, axis=1)[:, None]
+    ang = rng.uniform(0, np.deg2rad(80), NP)  # the key-frame that saw the point: 0 .. 80 degrees away from the camera's ray
+    axis = np.cross(ref_dir, unit(NP))
+    axis /= np.linalg.norm(axis, axis=1)[:, None]
+    ref_ray = ref_dir * np.cos(ang)[:, None] + np.cross(axis, ref_dir) * np.sin(ang)[:, None]
+    normal = -ref_ray  # from the key-frame towards the point
+    ref_dist = np.abs(depth) * np.exp(rng.uniform(np.log(0.3), np.log(4.0), NP))
+    level = rng.integers(0, 8, NP)
+    max_dist = (ref_dist * scale_factor ** level).astype(np.float32)
+    min_dist = (max_dist / np.float32(scale_factor ** 7)).astype(np.float32)
+    cand = (rng.uniform(size=NP) < 0.9).astype(np.uint8)
+    return dict(pose_cw=pose, t_wc=t_wc, pos=pos, normal=normal, max_dist=max_dist, min_dist=min_dist, cand=cand)

@@ -295,6 +295,22 @@ int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, int B, int N1
                                 const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
                                 const double* fmat_dev, const float* epipole_dev, int only_stereo, int check_orientation,
                                 int32_t* match12_dev, int32_t* nmatches_dev);
+/* The projection / visibility loop in front of gl_search_by_projection and gl_fuse_search - Tracking::searchLocalPoints
+ * (tracking.cpp:233-256), Localization::fuseObservations (localization.cpp:242-254): per map point Frame::project3 (frame.cpp:98-119,
+ * pinhole_camera.cpp:46-66, 128-150) and MapPoint::checkScaleAndVisible (mappoint.cpp:257-303).  B frames x NP map points: pose_cw
+ * B x 7 (getTcw), t_wc B x 3 (T_w_c_->translation()), pos / normal B x NP x 3 (getPosition, normal_), max_dist / min_dist B x NP float
+ * (max_dist_, min_dist_), cand B x NP uint8 (the host's tests in front: non-null, valid, not seen / observed already).  Out: uvr
+ * B x NP x 3, level B x NP int32 (ProjStat::scale_pred), viewcos / dist B x NP double (ProjStat), inview B x NP uint8 (is_in_view_ =
+ * project3 && checkScaleAndVisible): exactly the mp_* inputs of the two matchers.  cam: fx fy cx cy bf as the float config scalars,
+ * width / height. */
+/* Host only (no device work): the seven steps of the predicted level of MapPoint::checkScaleAndVisible (mappoint.cpp:289-293) as
+ * the HOST's libm gives them - step7[L] = the largest float ratio with ceil(logf(ratio) / logf(scale_factor)) <= L - which
+ * gl_project_map_points compares against on the device.  scale_factor in (1, 1.7]. */
+int gl_level_steps(float scale_factor, float* step7);
+int gl_project_map_points(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NP, const double* pose_cw_dev,
+                          const double* t_wc_dev, const double* pos_dev, const double* normal_dev, const float* max_dist_dev,
+                          const float* min_dist_dev, const uint8_t* cand_dev, double* uvr_dev, int32_t* level_dev,
+                          double* viewcos_dev, double* dist_dev, uint8_t* inview_dev);
 /* Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: per candidate map point the most
  * similar feature inside Frame::getFeaturesInArea(u, v, th * scale_factors[level]) (frame.cpp:121-177) with octave level - 1 or
  * level and Feature::error(uvr) * sigma2_inv[octave] within 5.99 (mono) / 7.8 (stereo).  Features as in gl_search_by_projection

@@ -17,6 +17,7 @@
 // chi2() which define the canonical Mahalanobis evaluation shared with the
 // HIP kernels (bit-exact index parity).
 // ============================================================================
+#include <climits>
 #include <cmath>
 #include <functional>
 #include <cstdint>
@@ -1740,6 +1741,62 @@ int orc_fuse_search(int width, int height, float scale_factor, int NF, const dou
     }
   }
   return num;
+}
+
+// Frame::project3(pt, &uvr) (frame.cpp:98-119; g2o SE3Quat::map; PinholeCamera::project3 + evaluateProjectionResult,
+// pinhole_camera.cpp:46-66, 128-150, kMinimumDepth = 0) followed by MapPoint::checkScaleAndVisible (mappoint.cpp:257-303), one frame,
+// NP map points - the loop of Tracking::searchLocalPoints (tracking.cpp:233-256) / Localization::fuseObservations (:242-254).
+// cam: fx fy cx cy bf as the float config scalars.  cand[m]: the host's tests in front of the projection.  Returns the in-view count.
+int orc_project_map_points(const orc_camera* cam, float scale_factor, const double* pose_cw, const double* t_wc, int NP, const double* pos,
+                           const double* normal, const float* max_dist_, const float* min_dist_, const uint8_t* cand, double* uvr_out,
+                           int32_t* level_out, double* viewcos_out, double* dist_out, uint8_t* inview_out) {
+  const double fu = (float)cam->fx, fv = (float)cam->fy, cu = (float)cam->cx, cv = (float)cam->cy;
+  const float mbf = (float)cam->bf;
+  const float scale_factor_log = std::log(scale_factor);  // config.cpp:57
+  const int num_levels = 8;
+  int n = 0;
+  for (int m = 0; m < NP; ++m) {
+    uvr_out[3 * m] = uvr_out[3 * m + 1] = uvr_out[3 * m + 2] = 0.0;
+    level_out[m] = 0;
+    viewcos_out[m] = dist_out[m] = 0.0;
+    inview_out[m] = 0;
+    if (!cand[m]) continue;
+    double ptc[3];
+    quat_rot(pose_cw, pos + 3 * m, ptc);
+    ptc[0] += pose_cw[4];
+    ptc[1] += pose_cw[5];
+    ptc[2] += pose_cw[6];
+    if (ptc[2] < 0.0) continue;
+    const double rz = static_cast<double>(1.0) / ptc[2];
+    const double kx = ptc[0] * rz, ky = ptc[1] * rz;
+    const double u = fu * kx + cu, v = fv * ky + cv;
+    const bool visibility = u >= 0.0 && v >= 0.0 && u < static_cast<double>(cam->width) && v < static_cast<double>(cam->height);
+    if (!(visibility && ptc[2] > 0.0)) continue;
+    const double ur = u - mbf / ptc[2];
+    // checkScaleAndVisible
+    const float max_dist = 1.2f * max_dist_[m], min_dist = 0.8f * min_dist_[m];
+    const double vx = pos[3 * m] - t_wc[0], vy = pos[3 * m + 1] - t_wc[1], vz = pos[3 * m + 2] - t_wc[2];
+    const float dist = std::sqrt(vx * vx + vy * vy + vz * vz);
+    if (dist < min_dist || dist > max_dist) continue;
+    const float view_cos = (vx * normal[3 * m] + vy * normal[3 * m + 1] + vz * normal[3 * m + 2]) / dist;
+    if (view_cos < 0.5f) continue;
+    const float ratio = max_dist_[m] / dist;
+    // std::log(float), std::ceil(float): mappoint.cpp has using namespace std.  inf / NaN (dist == 0): the int conversion is undefined,
+    // x86 gives INT_MIN (-> level 0)
+    const float lq = std::ceil(std::log(ratio) / scale_factor_log);
+    int lvl_scale = std::isfinite(lq) ? (int)lq : INT_MIN;
+    if (lvl_scale < 0) lvl_scale = 0;
+    else if (lvl_scale >= num_levels) lvl_scale = num_levels - 1;
+    uvr_out[3 * m] = u;
+    uvr_out[3 * m + 1] = v;
+    uvr_out[3 * m + 2] = ur;
+    level_out[m] = lvl_scale;
+    viewcos_out[m] = view_cos;
+    dist_out[m] = dist;
+    inview_out[m] = 1;
+    ++n;
+  }
+  return n;
 }
 
 void orc_se3_exp(const double* u, double* pose) { from_se3(se3_exp(u), pose); }

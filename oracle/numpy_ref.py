@@ -1097,3 +1097,49 @@ def fuse_search(width, height, feat_uv, feat_ur, feat_oct, feat_desc, mp_uvr, mp
             best_idx[m] = int(order[cand[k]])
             n += 1
     return best_idx, best_dist, n
+
+
+def _libm_logf():
+    import ctypes
+    import ctypes.util
+    m = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    m.logf.restype = ctypes.c_float
+    m.logf.argtypes = [ctypes.c_float]
+    return m.logf
+
+
+def project_map_points(cam, pose_cw, t_wc, pos, normal, max_dist, min_dist, cand, scale_factor=1.2):
+    """Frame::project3 (frame.cpp:98-119, pinhole_camera.cpp:46-66, 128-150) + MapPoint::checkScaleAndVisible (mappoint.cpp:257-303),
+    independent restatement: every test as a mask over all points at once; the float logarithm of the level is the host libm's logf
+    (what std::log(float) calls), one call per surviving point.  -> (uvr [NP,3], level [NP], view_cos [NP], dist [NP], in_view [NP])."""
+    f32 = np.float32
+    fx, fy, cx, cy = (np.float64(f32(v)) for v in (cam.fx, cam.fy, cam.cx, cam.cy))
+    mbf = np.float64(f32(cam.bf))
+    logf = _libm_logf()
+    sfl = f32(logf(f32(scale_factor)))
+    pos, normal = np.asarray(pos, float), np.asarray(normal, float)
+    NP = len(cand)
+    q, t = np.asarray(pose_cw[:4], float), np.asarray(pose_cw[4:], float)
+    uv = np.cross(q[None, :3], pos)
+    uv = uv + uv
+    ptc = pos + q[3] * uv + np.cross(q[None, :3], uv) + t[None, :]
+    with np.errstate(all="ignore"):
+        z = ptc[:, 2]
+        rz = 1.0 / z
+        u = fx * (ptc[:, 0] * rz) + cx
+        v = fy * (ptc[:, 1] * rz) + cy
+        ok = np.asarray(cand, bool) & ~(z < 0) & (u >= 0) & (v >= 0) & (u < float(cam.width)) & (v < float(cam.height)) & (z > 0)
+        ur = u - mbf / z
+        vec = pos - np.asarray(t_wc, float)[None, :]
+        dist = np.sqrt(vec[:, 0] * vec[:, 0] + vec[:, 1] * vec[:, 1] + vec[:, 2] * vec[:, 2]).astype(f32)
+        mx, mn = np.asarray(max_dist, f32), np.asarray(min_dist, f32)
+        ok &= ~((dist < f32(0.8) * mn) | (dist > f32(1.2) * mx))
+        vcos = ((vec[:, 0] * normal[:, 0] + vec[:, 1] * normal[:, 1] + vec[:, 2] * normal[:, 2]) / dist.astype(np.float64)).astype(f32)
+        ok &= ~(vcos < f32(0.5))
+        ratio = mx / dist
+    level = np.zeros(NP, np.int32)
+    for m in np.nonzero(ok)[0]:
+        lq = np.ceil(f32(f32(logf(ratio[m])) / sfl))
+        level[m] = int(min(max(lq, 0), 7)) if np.isfinite(lq) else 0
+    uvr = np.where(ok[:, None], np.stack([u, v, ur], 1), 0.0)
+    return uvr, level, np.where(ok, vcos.astype(np.float64), 0.0), np.where(ok, dist.astype(np.float64), 0.0), ok.astype(np.uint8)

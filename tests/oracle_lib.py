@@ -269,6 +269,17 @@ class Oracle:
                                      _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), C.c_float(th), _p(bi), _p(bd))
         return bi, bd, int(n)
 
+    def project_map_points(self, cam, pose_cw, t_wc, pos, normal, max_dist, min_dist, cand, scale_factor=1.2):
+        """Frame::project3 + MapPoint::checkScaleAndVisible, one frame -> (uvr, level, view_cos, dist, in_view, count)."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        a = [_f64(pose_cw), _f64(t_wc), _f64(pos), _f64(normal), f32(max_dist), f32(min_dist), np.ascontiguousarray(cand, dtype=np.uint8)]
+        NP = len(a[6])
+        uvr, lvl, vc, dd, iv = np.zeros((NP, 3)), np.zeros(NP, np.int32), np.zeros(NP), np.zeros(NP), np.zeros(NP, np.uint8)
+        self.lib.orc_project_map_points.restype = C.c_int
+        n = self.lib.orc_project_map_points(C.byref(self.camera(cam)), C.c_float(scale_factor), _p(a[0]), _p(a[1]), NP, _p(a[2]), _p(a[3]), _p(a[4]),
+                                            _p(a[5]), _p(a[6]), _p(uvr), _p(lvl), _p(vc), _p(dd), _p(iv))
+        return uvr, lvl, vc, dd, iv, int(n)
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

@@ -379,3 +379,75 @@ def test_fuse_search_matches_oracle(gpu, oracle):
         assert np.array_equal(bi[b, :len(ri)], ri) and np.array_equal(bd[b, :len(ri)], rd), b
         tot += n
     assert tot > 20000
+
+
+def _pack_project(torch, frames):
+    B, NP = len(frames), max(len(f["cand"]) for f in frames)
+    t = dict(pose_cw=np.zeros((B, 7)), t_wc=np.zeros((B, 3)), pos=np.zeros((B, NP, 3)), normal=np.zeros((B, NP, 3)),
+             max_dist=np.zeros((B, NP), np.float32), min_dist=np.zeros((B, NP), np.float32), cand=np.zeros((B, NP), np.uint8))
+    for b, f in enumerate(frames):
+        n = len(f["cand"])
+        t["pose_cw"][b], t["t_wc"][b] = f["pose_cw"], f["t_wc"]
+        for k in ("pos", "normal", "max_dist", "min_dist", "cand"):
+            t[k][b, :n] = f[k]
+    return [torch.from_numpy(t[k]).cuda() for k in ("pose_cw", "t_wc", "pos", "normal", "max_dist", "min_dist", "cand")]
+
+
+def test_project_map_points_matches_oracle(gpu, oracle):
+    """gl_project_map_points (Frame::project3, frame.cpp:98-119 + MapPoint::checkScaleAndVisible, mappoint.cpp:257-303; the loop of
+    tracking.cpp:233-256) against the sequential oracle, EVERY output bit for bit (uvr, view_cos, dist as doubles; level; flag):
+    frames of different sizes in one batch (padding = non-candidates), points behind the camera / outside the image / outside the
+    distance band / seen too obliquely; the known answers; the level at its seven steps (ratios 40 float steps either side of
+    1.2f ^ k: the oracle's level is the host libm's, the device compares against the steps the host found with the same libm);
+    then 150 random frames; then the output feeds gl_fuse_search as it is."""
+    torch, ctx = gpu
+    cam = api.Camera()
+
+    def check(frames, scale_factor=1.2):
+        out = api.project_map_points(ctx, cam, *_pack_project(torch, frames), scale_factor=scale_factor)
+        torch.cuda.synchronize()
+        out = [o.cpu().numpy() for o in out]
+        tot = 0
+        for b, f in enumerate(frames):
+            ref = oracle.project_map_points(cam, scale_factor=scale_factor, **f)
+            n = len(f["cand"])
+            for o, r, name in zip(out, ref[:5], ("uvr", "level", "viewcos", "dist", "inview")):
+                assert np.array_equal(o[b, :n], r), (b, name, int((o[b, :n] != r).sum()))
+                assert (o[b, n:] == 0).all()
+            tot += ref[5]
+        return tot, out
+
+    frames = [synth.synth_project_frame(NP, 600 + i, cam) for i, NP in enumerate((400, 3000, 1500, 40, 1, 7000, 2500, 64))]
+    assert check(frames)[0] > 3000
+    assert check(frames[:3], scale_factor=1.1)[0] > 800
+    # known answers + the level steps
+    from tests.test_oracle_golden import _project_kat_inputs
+    _, pose, pos, nrm, mx, mn, cand = _project_kat_inputs()
+    kat = dict(pose_cw=pose, t_wc=np.zeros(3), pos=pos, normal=nrm, max_dist=mx, min_dist=mn, cand=cand)
+    r = []
+    for k in range(0, 9):
+        x = np.float32(np.float32(1.2) ** k)
+        for _ in range(40):
+            x = np.nextafter(x, np.float32(0))
+        for _ in range(81):
+            r.append(x)
+            x = np.nextafter(x, np.float32(100))
+    r = np.array(r, np.float32)
+    P = np.tile([0.0, 0.0, 1.0], (len(r), 1))
+    steps = dict(pose_cw=pose, t_wc=np.zeros(3), pos=P, normal=P, max_dist=r, min_dist=np.full(len(r), 0.01, np.float32), cand=np.ones(len(r), np.uint8))
+    tot, out = check([kat, steps])
+    assert out[4][0, :11].tolist() == [1, 0, 0, 0, 0, 1, 0, 1, 0, 1, 1] and out[1][0, :11].tolist() == [0, 0, 0, 0, 0, 0, 0, 7, 0, 4, 3]
+    assert len(np.nonzero(np.diff(out[1][1]))[0]) == 7
+    rng = np.random.default_rng(83)
+    frames = [synth.synth_project_frame(int(rng.integers(1, 6000)), 12000 + i, cam) for i in range(150)]
+    assert check(frames)[0] > 60000
+    # the outputs are the matcher's inputs: B x NP x 3 uvr, int32 level, uint8 flag
+    f = synth.synth_fuse_frame(500, 400, 77)
+    pr = synth.synth_project_frame(400, 78, cam)
+    uvr, level, viewcos, dist, inview = api.project_map_points(ctx, cam, *_pack_project(torch, [pr]))
+    fe = [torch.from_numpy(np.ascontiguousarray(f[k][None])).cuda() for k in ("feat_uv", "feat_ur", "feat_oct", "feat_desc")]
+    bi, bd = api.fuse_search(ctx, cam, *fe, uvr, level, inview, torch.from_numpy(f["mp_desc"][None]).cuda(), th=3.0)
+    torch.cuda.synchronize()
+    ref = oracle.project_map_points(cam, **pr)
+    ri, rd, n = oracle.fuse_search(752, 480, f["feat_uv"], f["feat_ur"], f["feat_oct"], f["feat_desc"], ref[0], ref[1], ref[4], f["mp_desc"], th=3.0)
+    assert np.array_equal(bi.cpu().numpy()[0], ri) and np.array_equal(bd.cpu().numpy()[0], rd)

@@ -268,6 +268,15 @@ def main():
         out["u%d_dist" % i] = bd
         out["u%d_n" % i] = np.array(n)
     np.savez_compressed(os.path.join(G, "golden_fuse.npz"), **out)
+    # ---- projection / visibility loop in front of the matchers: frames through the independent numpy restatement
+    out = {}
+    cam_px = cam_v1()
+    for i, (NP, seed) in enumerate(((400, 501), (3000, 502), (1500, 503), (40, 504))):
+        f = synth.synth_project_frame(NP, seed, cam_px)
+        uvr, lvl, vc, dd, iv = nr.project_map_points(cam_px, **f)
+        out["p%d_args" % i] = np.array([NP, seed])
+        out["p%d_uvr" % i], out["p%d_level" % i], out["p%d_viewcos" % i], out["p%d_dist" % i], out["p%d_inview" % i] = uvr, lvl, vc, dd, iv
+    np.savez_compressed(os.path.join(G, "golden_project.npz"), **out)
     print("golden vectors written to", G)
 
 
