@@ -1895,6 +1895,8 @@ struct PipeA {  // kernel arguments (by value)
   double* pth;        // B x L x 6: the points' undamped blocks of the last full point pass (point_relambda)
   int* unfinished;    // problems not at stage 3
   int nba, lpp, nblk, nchunk;
+  int kper;           // chunks of a block per wave of the Schur pass (1; 2 in batches: the wave's set-up once for two chunks - the
+                      // partial sums stay per chunk, so the bits do not depend on it)
 };
 struct PipeCtl {
   int stage, init, pend, adv;
@@ -2471,56 +2473,115 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
   // Workgroup -> (window, four of its waves) through the XCD-aware map (pipe_wg): an XCD then works on one or two windows at a time and
   // the records its blocks share (every observation record is read by up to P blocks) stay in ITS 4 MB L2 instead of streaming
   // through all eight: 64 windows 0.191 -> 0.175 ms per window.  per_prob is a multiple of 4 (nchunk is).
-  const int per_prob = a.nblk * a.nchunk;
+  const int per_prob = a.nblk * a.nchunk / a.kper;  // waves of a window
   int f, wq;
   if (!pipe_wg(a.B, per_prob / NW_BA, f, wq)) return;
   // (the wave index as a SCALAR: block, chunk and the two poses' {R, t} - scalar loads - are then SGPR values, not 48 VGPRs)
   const int w = wq * NW_BA + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const PipeSt* st = st_cur(a, f);
-  const PipeCtl ctl = pipe_ctl(st);
-  if (ctl.stage >= 3) return;
-  const bool schur = !ctl.init;
   GenP G;
   genp_init(G, a, f, 1, 0);
-  if (ctl.adv) {
-    pipe_adv_obs(a, G, *st, f, w, per_prob);
-    return;
-  }
-  const int P = a.P, b = w / a.nchunk, chunk = w % a.nchunk;
+  const int P = a.P, wpb = a.nchunk / a.kper, b = w / wpb, chunk0 = (w % wpb) * a.kper;
   int j1 = 0, rem = b;
   while (rem >= P - j1) {
     rem -= P - j1;
     ++j1;
   }
   const int j2 = j1 + rem;
-  const bool act = G.pact[j1] && G.pact[j2] && (schur || j1 == j2);
-  double v1[32], v2[16];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) v1[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) v2[i] = 0.0;
-  if (act) {
-    double R1[9], t1[3], R2[9], t2[3];
-    load_Rt_k((const cdouble_k*)(G.Rt + (size_t)j1 * 12), R1, t1);  // (written by an earlier kernel of the cycle, read-only here)
-    load_Rt_k((const cdouble_k*)(G.Rt + (size_t)j2 * 12), R2, t2);
-    const int e0 = G.pl_ptr[j1] + chunk * st->chunk_len, e1 = min(G.pl_ptr[j1 + 1], e0 + st->chunk_len);
-    for (int e = e0 + lane; e < e1; e += 64) {
-      const int o2 = G.plm[(size_t)e * P + j2];
-      const int o1 = G.pl_obs[e];
-      const int l = G.pl_pt[e];
-      if (o2 < 0) continue;
-      if (G.lev_o[o1] | G.lev_o[o2]) continue;  // an edge at level 1 (k_ba_gen folds these flags into the partner table)
-      const double* l1 = G.lin + (size_t)o1 * 12;
-      const double* l2 = G.lin + (size_t)o2 * 12;
-      const double* pw = G.ptw + (size_t)l * 12;
-      schur_entry(l1, l2, pw, R1, R2, schur, j1 == j2, v1, v2);
+  // A wave of this kernel lives for two entries per lane, so its life is the LENGTH OF ITS CHAIN OF DEPENDENT LOADS (the ISA of the
+  // first version: eight scalar round trips one after the other before the loop, five to six vector ones per entry inside it - state
+  // word, then the lists' bounds, then the partner, then the own observation, then the two level flags, then the point, then the
+  // records piece by piece as the block algebra asked for them).  Here: everything that depends on the launch arguments alone in ONE
+  // round trip - the state word, the chunk length, the list's bounds, the two poses (scalar loads; all of it written by earlier
+  // kernels), the two activity flags - then per entry one round trip for its three indices (requested one entry ahead) and one for
+  // the level flags, both observation records and the point's block together.
+  typedef const int __attribute__((address_space(4))) cint_k;
+  const cint_k* stw = (const cint_k*)st;
+  const int c_stage = stw[0], c_init = stw[1], c_adv = stw[3];
+  const int chunk_len = *(const cint_k*)&st->chunk_len;
+  const int p_beg = ((const cint_k*)G.pl_ptr)[j1], p_end = ((const cint_k*)G.pl_ptr)[j1 + 1];
+  double R1[9], t1[3], R2[9], t2[3];
+  load_Rt_k((const cdouble_k*)(G.Rt + (size_t)j1 * 12), R1, t1);  // (written by an earlier kernel of the cycle, read-only here)
+  load_Rt_k((const cdouble_k*)(G.Rt + (size_t)j2 * 12), R2, t2);
+  const int pa1 = G.pact[j1], pa2 = G.pact[j2];
+  struct Idx {
+    int o1, o2, l;
+  };
+  // (requested before the state word is tested: a window that finished before its set-up - the stop word - has no lists, and
+  // whatever its bounds say the addresses stay inside the window's arrays)
+  auto fetch_idx = [&](int e, int e_end, Idx& x) {
+    x.o1 = 0;
+    x.o2 = -1;
+    x.l = 0;
+    if (e < e_end && e >= 0 && e < a.NOBS) {
+      x.o2 = G.plm[(size_t)e * P + j2];
+      x.o1 = G.pl_obs[e];
+      x.l = G.pl_pt[e];
     }
+  };
+  Idx cur;
+  {
+    const int e0 = p_beg + chunk0 * chunk_len;
+    fetch_idx(e0 + lane, min(p_end, e0 + chunk_len), cur);  // (the bounds are scalars of the same round trip: the first entry's indices follow it at once)
   }
-  const double r1 = wave_reduce_scatter32(v1), r2 = wave_reduce_scatter16(v2);  // (the 16 further sums: same tree, same bits)
+  asm volatile("" ::"s"(c_stage), "s"(c_init), "s"(c_adv));
+  pin(pa1);
+  pin(pa2);
+  if (c_stage >= 3) return;
+  const bool schur = !c_init;
+  if (c_adv) {
+    pipe_adv_obs(a, G, *st, f, w, per_prob);
+    return;
+  }
+  const bool act = pa1 && pa2 && (schur || j1 == j2);
   double* const pblk = a.partS + ((size_t)f * a.nblk + b) * a.nchunk * 48;
-  double* const ps = pblk + (size_t)chunk * 48;  // 48 sums of this chunk: [0..35] the block, [36..41] g, [42..47] b_p (diagonal blocks)
-  if (wave_slot_owner(lane)) ps[wave_slot(lane)] = r1;
-  if (wave_slot16_owner(lane)) ps[32 + wave_slot16(lane)] = r2;
+  for (int sc = 0; sc < a.kper; ++sc) {
+    const int chunk = chunk0 + sc;
+    const int e0 = p_beg + chunk * chunk_len, e1 = min(p_end, e0 + chunk_len);
+    double v1[32], v2[16];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v1[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v2[i] = 0.0;
+    if (act) {
+      for (int e = e0 + lane; e < e1; e += 64) {
+        Idx nxt;
+        fetch_idx(e + 64, e1, nxt);
+        const int o1 = cur.o1, o2 = cur.o2, l = cur.l;
+        const int o2c = o2 < 0 ? o1 : o2;  // (no partner: the own record again - a valid address, no further line)
+        const int lv = G.lev_o[o1] | G.lev_o[o2c];  // an edge at level 1 (k_ba_gen folds these flags into the partner table)
+        double r1[12], r2[12], pw[9];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r1[i] = G.lin[(size_t)o1 * 12 + i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r2[i] = G.lin[(size_t)o2c * 12 + i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pw[i] = G.ptw[(size_t)l * 12 + i];
+        pin(lv);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pin(r1[i]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pin(r2[i]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pin(pw[i]);
+        cur = nxt;
+        if (o2 < 0 || lv) continue;
+        schur_entry(r1, r2, pw, R1, R2, schur, j1 == j2, v1, v2);
+      }
+    }
+    if (sc + 1 < a.kper) {  // the next chunk's first indices travel during the reduction
+      const int n0 = e0 + chunk_len;
+      fetch_idx(n0 + lane, min(p_end, n0 + chunk_len), cur);
+    }
+    double* const ps = pblk + (size_t)chunk * 48;  // 48 sums of this chunk: [0..35] the block, [36..41] g, [42..47] b_p (diagonal blocks)
+    if (!act || e0 >= e1) {  // nothing added (a chunk beyond the end of this pose's list): the sums of zeros
+      if (lane < 48) ps[lane] = 0.0;
+      continue;
+    }
+    const double s1 = wave_reduce_scatter32(v1), s2 = wave_reduce_scatter16(v2);  // (the 16 further sums: same tree, same bits)
+    if (wave_slot_owner(lane)) ps[wave_slot(lane)] = s1;
+    if (wave_slot16_owner(lane)) ps[32 + wave_slot16(lane)] = s2;
+  }
 }
 
 // ---- P2b: the chunks of a block added in chunk order -> the assembled system (a thread per (block, sum); the solve kernel
@@ -2904,7 +2965,23 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
     kp_setup_lists<1><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
     kp_setup_partner<<<B * a.nba, T_BA, 0, c->stream>>>(a);
   }
-  const int schur_blocks = pipe_grid(B, a.nblk * a.nchunk / NW_BA);  // (XCD-aware workgroup map: pipe_wg)
+  // Chunks of a block per wave of the Schur pass: a wave's set-up (its chain of scalar loads, the poses) is a third of its life at
+  // one chunk - two entries per lane - so in batches a wave takes 2, 4 or 8 chunks one after the other, as many as leave the call
+  // one full round of waves on the chip (256 CUs x 8).  The partial sums stay per chunk: the bits do not depend on it
+  // (64 windows of 8 + 4 key-frames 0.164 -> 0.132 ms per window, 256 windows 0.166 -> 0.117; GL_SCHUR_KPER overrides, for A/B runs).
+  auto kper_ok = [&](int k) { return k >= 1 && a.nchunk % k == 0 && (a.nblk * a.nchunk / k) % NW_BA == 0; };
+  a.kper = 1;
+  if (const char* ek = getenv("GL_SCHUR_KPER")) {
+    a.kper = atoi(ek);
+  } else {
+    for (int k = 8; k > 1; k /= 2)
+      if (kper_ok(k) && (long)B * a.nblk * a.nchunk / k >= 2048) {
+        a.kper = k;
+        break;
+      }
+  }
+  if (!kper_ok(a.kper)) a.kper = 1;
+  const int schur_blocks = pipe_grid(B, a.nblk * a.nchunk / a.kper / NW_BA);  // (XCD-aware workgroup map: pipe_wg)
   // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
   // one) + 4 cycles that open / change the stage + the one that judges the last trial: enough cycles for the common case are enqueued before the
   // first look at the counter, fewer per look afterwards
