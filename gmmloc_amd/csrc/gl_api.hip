@@ -163,6 +163,11 @@ int gl_ctx_destroy(gl_ctx_t* ctx) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->counters) (void)hipFree(c->counters);
   if (c->host_word) (void)hipHostFree(c->host_word);
+  for (int k = 0; k < 3; ++k) {
+    if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
+    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->dev_stage) (void)hipFree(c->dev_stage);
   if (c->host_stage) (void)hipHostFree(c->host_stage);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

@@ -2904,12 +2904,21 @@ size_t ba_pipe_scratch_bytes(int B, int P, int F, int L, int NOBS) {
          up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * L * 6 * 8) + up((size_t)B * nblk * 4) + 1024;
 }
 
-int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+// One LANE of the pipelined local BA: a sub-batch of the call's windows with its own kernel arguments, scratch area and stream.
+struct PipeLane {
+  PipeA a;
+  hipStream_t s = nullptr;
+  int B = 0, schur_blocks = 0, par = 0, first = 0;
+  size_t s_bytes = 0;
+  int* hw = nullptr;
+  bool done = false;
+};
+static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
                    double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
                    const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
                    const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
                    const int32_t* stop_dev, void* scratch) {
-  PipeA a;
+  PipeA& a = ln.a;
   a.k = make_bak(cam, prm, -1.0);
   a.gm = GmmDev{g->rec12, g->axis, g->sqrt_info, g->hgw, g->flags, g->plane4};
   a.B = B;
@@ -2928,7 +2937,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   a.dropped = assoc_dropped_dev;
   a.erase = obs_erase_dev;
   a.iters = iters_dev;
-  a.trials_out = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
+  a.trials_out = (c->stats && c->stats_n >= stats_off + B) ? c->stats + stats_off : nullptr;
   a.stop = stop_dev;
   a.scratch = (char*)scratch;
   a.per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
@@ -2947,23 +2956,23 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   s += up((size_t)B * L * 6 * 8);
   a.unfinished = (int*)s;  // [0] problems not finished, [1] cycles the slowest of them needed
   const size_t n = 6 * (size_t)P;
-  const size_t s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;
-  if (s_bytes) GL_HIP(ensure_dynamic_lds(c, (const void*)kp_solve, s_bytes));
-  // page-locked word the device's count of unfinished problems is copied to between chunks of cycles
-  if (!c->host_word) GL_HIP(hipHostMalloc((void**)&c->host_word, 64, hipHostMallocDefault));
-  TimerScope ts(c, GL_TIMER_BA);
-  c->host_word[0] = B;
-  c->host_word[1] = 0;
-  GL_HIP(hipMemcpyAsync(a.unfinished, c->host_word, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  ln.s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;
+  if (ln.s_bytes) GL_HIP(ensure_dynamic_lds(c, (const void*)kp_solve, ln.s_bytes));
+  // (ln.hw: page-locked words of this lane - [0..1] the device's count of unfinished problems and the cycles of the slowest as copied
+  // back between chunks of cycles, [2..3] their initial values)
+  ln.hw[2] = B;
+  ln.hw[3] = 0;
+  GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 512, ln.s));
+  GL_HIP(hipMemcpyAsync(a.unfinished, ln.hw + 2, 2 * sizeof(int), hipMemcpyHostToDevice, ln.s));
   {
     const int nws = std::max(1, (NOBS + SORT_SPAN - 1) / SORT_SPAN);
     const int lblocks = (int)(((long)B * nws + NW_BA - 1) / NW_BA);
     a.par = 1;  // the set-up writes state buffer 0
-    kp_setup_init<<<B * a.nba, T_BA, 0, c->stream>>>(a);
-    kp_setup_lists<0><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
-    kp_setup_scan<<<B, T_BA, 0, c->stream>>>(a, nws);
-    kp_setup_lists<1><<<lblocks, T_BA, 0, c->stream>>>(a, nws);
-    kp_setup_partner<<<B * a.nba, T_BA, 0, c->stream>>>(a);
+    kp_setup_init<<<B * a.nba, T_BA, 0, ln.s>>>(a);
+    kp_setup_lists<0><<<lblocks, T_BA, 0, ln.s>>>(a, nws);
+    kp_setup_scan<<<B, T_BA, 0, ln.s>>>(a, nws);
+    kp_setup_lists<1><<<lblocks, T_BA, 0, ln.s>>>(a, nws);
+    kp_setup_partner<<<B * a.nba, T_BA, 0, ln.s>>>(a);
   }
   // Chunks of a block per wave of the Schur pass: a wave's set-up (its chain of scalar loads, the poses) is a third of its life at
   // one chunk - two entries per lane - so in batches a wave takes 2, 4 or 8 chunks one after the other, as many as leave the call
@@ -2981,35 +2990,128 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
       }
   }
   if (!kper_ok(a.kper)) a.kper = 1;
-  const int schur_blocks = pipe_grid(B, a.nblk * a.nchunk / a.kper / NW_BA);  // (XCD-aware workgroup map: pipe_wg)
+  ln.schur_blocks = pipe_grid(B, a.nblk * a.nchunk / a.kper / NW_BA);  // (XCD-aware workgroup map: pipe_wg)
+  ln.B = B;
+  return GL_OK;
+}
+
+
+// the kernels of `n` cycles of a lane, from cycle `first_cyc` of the call
+static void pipe_lane_cycle(PipeLane& ln, int cyc) {
+  PipeA& a = ln.a;
+  a.par = ln.par;
+  a.cyc = cyc;
+  ln.par ^= 1;
+  const int B = ln.B;
+  kp_lin<<<pipe_grid(B, a.nba), T_BA, 0, ln.s>>>(a);
+  kp_schur<<<ln.schur_blocks, T_BA, 0, ln.s>>>(a);
+  kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, ln.s>>>(a);
+  kp_solve<<<B, T_SOLVE, ln.s_bytes, ln.s>>>(a);
+  kp_trial<<<pipe_grid(B, a.nba), T_BA, 0, ln.s>>>(a);
+}
+
+// Lanes of a call.  Every kernel of a cycle is bound by the LENGTH of its workgroups' chains of dependent loads times the rounds of
+// workgroups the chip needs for the batch, not by issue slots or bandwidth, and a cycle is a chain of five such kernels (the solve
+// with one workgroup per window).  A call of 16 or more windows (up to 2.5 M observations together: beyond that the kernels keep the
+// chip busy by themselves) is cut into two halves that run their cycles on two streams: the kernels of one half fill the gaps of the
+// other's.  Windows do not interact, so the bits are those of any other split.  (GL_PIPE_LANES = 1 .. 4 overrides, for A/B runs.)
+constexpr int PIPE_LANES_MAX = 4;
+int pipe_lanes(int B, int NOBS) {
+  if (const char* e = getenv("GL_PIPE_LANES")) return std::max(1, std::min(std::min(atoi(e), PIPE_LANES_MAX), B));
+  return (B >= 16 && (long)B * NOBS <= 2500000) ? 2 : 1;
+}
+// windows [first, first + count) of lane k (every lane but the last a multiple of 8 windows: the XCD-aware workgroup map)
+static void pipe_lane_windows(int B, int nl, int k, int* first, int* count) {
+  const int per = nl == 1 ? B : (B >= 8 * nl ? ((B / nl + 7) / 8) * 8 : (B + nl - 1) / nl);
+  *first = std::min(B, k * per);
+  *count = std::max(0, std::min(B, (k + 1) * per) - *first);
+  if (k == nl - 1) *count = B - *first;
+}
+static size_t pipe_lane_scratch_off(int B, int nl, int k, int P, int F, int L, int NOBS) {
+  auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+  size_t off = 0;
+  for (int i = 0; i < k; ++i) {
+    int f0, cnt;
+    pipe_lane_windows(B, nl, i, &f0, &cnt);
+    off += up(ba_pipe_scratch_bytes(std::max(cnt, 1), P, F, L, NOBS));
+  }
+  return off;
+}
+size_t ba_pipe_scratch_total(int B, int P, int F, int L, int NOBS) {
+  const int nl = pipe_lanes(B, NOBS);
+  return pipe_lane_scratch_off(B, nl, nl, P, F, L, NOBS);
+}
+
+int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+                   double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
+                   const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                   const int32_t* stop_dev, void* scratch) {
+  // page-locked words the devices' counts of unfinished problems are copied to between chunks of cycles (4 per lane)
+  if (!c->host_word) GL_HIP(hipHostMalloc((void**)&c->host_word, 64, hipHostMallocDefault));
+  const int nl = pipe_lanes(B, NOBS);
+  if (nl > 1 && !c->ev_fork) GL_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  for (int k = 1; k < nl; ++k)
+    if (!c->lane_stream[k - 1]) {
+      GL_HIP(hipStreamCreateWithFlags(&c->lane_stream[k - 1], hipStreamNonBlocking));
+      GL_HIP(hipEventCreateWithFlags(&c->ev_join[k - 1], hipEventDisableTiming));
+    }
+  TimerScope ts(c, GL_TIMER_BA);
+  PipeLane lane[PIPE_LANES_MAX];
+  if (nl > 1) GL_HIP(hipEventRecord(c->ev_fork, c->stream));  // the further streams start behind what the caller has enqueued so far
+  for (int k = 0; k < nl; ++k) {
+    int w0, Bk;
+    pipe_lane_windows(B, nl, k, &w0, &Bk);
+    if (Bk == 0) {
+      lane[k].done = true;
+      continue;
+    }
+    lane[k].s = k == 0 ? c->stream : c->lane_stream[k - 1];
+    if (k > 0) GL_HIP(hipStreamWaitEvent(lane[k].s, c->ev_fork, 0));
+    lane[k].hw = c->host_word + 4 * k;
+    char* sk = (char*)scratch + pipe_lane_scratch_off(B, nl, k, P, F, L, NOBS);
+    const size_t w = (size_t)w0;
+    const int rc = pipe_lane_setup(c, lane[k], w0, g, cam, prm, Bk, P, F, L, NOBS, poses_dev + w * (P + F) * 7, prior_dev + w * P,
+                                   points_dev + w * L * 3, assoc_dev + w * L, obs_ptr_dev + w * (L + 1), obs_pose_dev + w * NOBS,
+                                   obs_uvr_dev + w * NOBS * 3, obs_oct_dev + w * NOBS, assoc_dropped_dev ? assoc_dropped_dev + w * L : nullptr,
+                                   obs_erase_dev ? obs_erase_dev + w * NOBS : nullptr, iters_dev ? iters_dev + w : nullptr, stop_dev, sk);
+    if (rc != GL_OK) return rc;
+  }
   // a run needs 3 lambda-init cycles + its Levenberg trials (28 - 35 on the windows measured; every rejected trial adds
   // one) + 4 cycles that open / change the stage + the one that judges the last trial: enough cycles for the common case are enqueued before the
   // first look at the counter, fewer per look afterwards
   // (the look-ahead of a call is what the context's previous window needed, + 2: windows follow each other with similar trial
   // counts; a cycle beyond the end costs five empty launches, a cycle short a host round trip)
-  int chunk = c->pipe_hint > 0 ? std::min(std::max(c->pipe_hint + 2, 12), 80) : 44, par = 0;
+  int chunk = c->pipe_hint > 0 ? std::min(std::max(c->pipe_hint + 2, 12), 80) : 44, hint = 0;
   for (int total = 0;; total += chunk, chunk = 8) {
-    for (int cyc = 0; cyc < chunk; ++cyc) {
-      a.par = par;
-      a.cyc = total + cyc;
-      par ^= 1;
-      kp_lin<<<pipe_grid(B, a.nba), T_BA, 0, c->stream>>>(a);
-      kp_schur<<<schur_blocks, T_BA, 0, c->stream>>>(a);
-      kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, c->stream>>>(a);
-      kp_solve<<<B, T_SOLVE, s_bytes, c->stream>>>(a);
-      kp_trial<<<pipe_grid(B, a.nba), T_BA, 0, c->stream>>>(a);
-    }
+    for (int cyc = 0; cyc < chunk; ++cyc)
+      for (int k = 0; k < nl; ++k)
+        if (!lane[k].done) pipe_lane_cycle(lane[k], total + cyc);
     GL_HIP(hipGetLastError());
-    GL_HIP(hipMemcpyAsync(c->host_word, a.unfinished, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    GL_HIP(hipStreamSynchronize(c->stream));
-    if (c->host_word[0] <= 0) {
-      if (c->host_word[1] > 0) c->pipe_hint = c->host_word[1];
-      break;
+    for (int k = 0; k < nl; ++k)
+      if (!lane[k].done) GL_HIP(hipMemcpyAsync(lane[k].hw, lane[k].a.unfinished, 2 * sizeof(int), hipMemcpyDeviceToHost, lane[k].s));
+    bool all = true;
+    for (int k = 0; k < nl; ++k) {
+      if (lane[k].done) continue;
+      GL_HIP(hipStreamSynchronize(lane[k].s));
+      if (lane[k].hw[0] <= 0) {
+        lane[k].done = true;
+        hint = std::max(hint, lane[k].hw[1]);
+      } else {
+        all = false;
+      }
     }
+    if (all) break;
     if (total > 600) {  // 3 x (40 iterations x 10 trials) is the schedule's bound; this is a defect, not a slow problem
-      set_error("launch_ba_pipe: %d problem(s) did not finish in %d cycles", *c->host_word, total + chunk);
+      set_error("launch_ba_pipe: problems did not finish in %d cycles", total + chunk);
       return GL_ERR_DEVICE;
     }
+  }
+  if (hint > 0) c->pipe_hint = hint;
+  for (int k = 1; k < nl; ++k) {  // what follows on the caller's stream follows the other lanes too (they have finished: the host has seen their counters)
+    if (!lane[k].s) continue;
+    GL_HIP(hipEventRecord(c->ev_join[k - 1], lane[k].s));
+    GL_HIP(hipStreamWaitEvent(c->stream, c->ev_join[k - 1], 0));
   }
   return GL_OK;
 }
@@ -3042,10 +3144,9 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   // (mode 0 chooses from the WINDOW alone - never from B: the two shapes add their partial sums in different orders, and a
   // window must not change its bits, or the call its blocking behaviour, with the number of windows that ride along)
   const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && NOBS >= 5000));
-  int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_bytes(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
+  int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_total(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
   if (pipe) {
-    GL_HIP(hipMemsetAsync(scratch, 0, (size_t)B * 512, c->stream));
     return gl::launch_ba_pipe(c, g, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
                               obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, stop_dev, scratch);
   }

@@ -129,7 +129,9 @@ struct Ctx {
   size_t stage_bytes = 0;
   // device counters (gl_ctx_counter_read): [0] frames of latency-shape launches redone by the follow-up kernel
   int32_t* counters = nullptr;
-  int* host_word = nullptr;  // page-locked word (the pipelined local BA's count of unfinished problems)
+  int* host_word = nullptr;  // page-locked words (the pipelined local BA's counts of unfinished problems, per lane)
+  hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};  // further lanes of the pipelined local BA in batches (launch_ba_pipe)
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int pipe_hint = 0;         // cycles the last pipelined local BA needed (the next call enqueues that many + 2 ahead)
   // optional statistics buffer (gl_ctx_set_stats_buffer)
   int32_t* stats = nullptr;
