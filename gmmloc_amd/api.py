@@ -468,6 +468,26 @@ def search_by_projection(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_t
     return match, nm
 
 
+def search_local_points(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, pose_cw, t_wc, mp_pos, mp_normal, mp_max_dist,
+                        mp_min_dist, mp_cand, mp_desc, th=3.0, nn_ratio=0.8, scale_factor=1.2):
+    """Tracking::searchLocalPoints (tracking.cpp:213-270), the device part in one call: project_map_points, then
+    search_by_projection on its outputs -> (feat_match int32 (B,NF), nmatches int32 (B,), inview u8 (B,NP))."""
+    import torch
+    B, NF = feat_oct.shape
+    NP = mp_cand.shape[1]
+    dev = feat_oct.device
+    match = torch.empty((B, NF), dtype=torch.int32, device=dev)
+    nm = torch.empty(B, dtype=torch.int32, device=dev)
+    inview = torch.empty((B, NP), dtype=torch.uint8, device=dev)
+    ctx._enter()
+    _check(ctx.lib.gl_search_local_points(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
+                                          _ptr(feat_desc), _ptr(feat_taken), _ptr(pose_cw), _ptr(t_wc), _ptr(mp_pos), _ptr(mp_normal),
+                                          _ptr(mp_max_dist), _ptr(mp_min_dist), _ptr(mp_cand), _ptr(mp_desc), float(th), float(nn_ratio),
+                                          _ptr(match), _ptr(nm), _ptr(inview)))
+    ctx._exit()
+    return match, nm, inview
+
+
 def search_by_projection_frame(ctx, cam, pose_cw, pose_lw, feat_uv, feat_ur, feat_oct, feat_angle, feat_desc, feat_taken,
                                last_pt, last_valid, last_oct, last_angle, last_desc, th=7.0, mono=False,
                                check_orientation=True, scale_factor=1.2):

@@ -175,3 +175,39 @@ extern "C" int gl_project_map_points(gl_ctx_t* ctx, const gl_camera* cam, float 
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
+
+// Tracking::searchLocalPoints, the device part in one call (tracking.cpp:233-270): the projection / visibility loop above, then
+// ORBmatcher(0.8).searchByProjection(curr_frame_, local_mappoints_, mappoints_proj_stat, th) (orb_matcher.cpp:27-110) on its
+// outputs, which stay in the context's scratch.  inview_dev (optional): is_in_view_ per map point, for the host's num_visible_++.
+extern "C" int gl_search_local_points(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NP, const double* feat_uv_dev,
+                                      const float* feat_ur_dev, const int32_t* feat_oct_dev, const uint8_t* feat_desc_dev,
+                                      const uint8_t* feat_taken_dev, const double* pose_cw_dev, const double* t_wc_dev, const double* mp_pos_dev,
+                                      const double* mp_normal_dev, const float* mp_max_dist_dev, const float* mp_min_dist_dev,
+                                      const uint8_t* mp_cand_dev, const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
+                                      int32_t* nmatches_dev, uint8_t* inview_dev) {
+  GL_REQUIRE(ctx && cam, "null argument");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && NP >= 1 && NF >= 1, "bad B / NF / NP");
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  const size_t n = (size_t)B * NP;
+  auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+  void* scratch = nullptr;
+  const int rc0 = gl::ctx_scratch(c, up(n * 24) + 2 * up(n * 8) + up(n * 4) + up(n), &scratch);
+  if (rc0 != GL_OK) return rc0;
+  char* s = (char*)scratch;
+  double* uvr = (double*)s;
+  s += up(n * 24);
+  double* viewcos = (double*)s;
+  s += up(n * 8);
+  double* dist = (double*)s;
+  s += up(n * 8);
+  int32_t* level = (int32_t*)s;
+  s += up(n * 4);
+  uint8_t* inview = inview_dev ? inview_dev : (uint8_t*)s;
+  int rc = gl_project_map_points(ctx, cam, scale_factor, B, NP, pose_cw_dev, t_wc_dev, mp_pos_dev, mp_normal_dev, mp_max_dist_dev, mp_min_dist_dev,
+                                 mp_cand_dev, uvr, level, viewcos, dist, inview);
+  if (rc != GL_OK) return rc;
+  return gl_search_by_projection(ctx, cam, scale_factor, B, NF, NP, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev, feat_taken_dev, uvr, level,
+                                 viewcos, inview, mp_desc_dev, th, nn_ratio, feat_match_dev, nmatches_dev);
+}

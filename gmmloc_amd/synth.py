@@ -452,3 +452,39 @@ def synth_project_frame(NP, seed, cam, scale_factor=1.2):
     min_dist = (max_dist / np.float32(scale_factor ** 7)).astype(np.float32)
     cand = (rng.uniform(size=NP) < 0.9).astype(np.uint8)
     return dict(pose_cw=pose, t_wc=t_wc, pos=pos, normal=normal, max_dist=max_dist, min_dist=min_dist, cand=cand)
+
+
+def synth_local_points_frame(NF, NP, seed, cam, scale_factor=1.2):
+    """One frame of Tracking::searchLocalPoints: the map points of synth_project_frame and NF ORB-like features, 70 % of them at the
+    (approximately) projected position of a map point in front of the camera - a few pixels off, at the octave of the point's
+    predicted level or one below, descriptor = the point's with 0 .. 70 flipped bits - so that the chain project -> searchByProjection
+    has matches, contested features, ratio-test failures and points whose window holds nothing.  The rest of the features are clutter."""
+    rng = np.random.default_rng(seed)
+    f = synth_project_frame(NP, seed, cam, scale_factor)
+    R, t = quat_to_R(f["pose_cw"][:4]), f["pose_cw"][4:]
+    pc = f["pos"] @ R.T + t
+    z = np.where(np.abs(pc[:, 2]) < 1e-6, 1e-6, pc[:, 2])
+    uv = np.stack([cam.fx * pc[:, 0] / z + cam.cx, cam.fy * pc[:, 1] / z + cam.cy], 1)
+    dist = np.linalg.norm(f["pos"] - f["t_wc"], axis=1)
+    lvl = np.clip(np.ceil(np.log(np.maximum(f["max_dist"] / np.maximum(dist, 1e-9), 1e-9)) / np.log(scale_factor)), 0, 7).astype(np.int32)
+    front = np.nonzero((z > 0) & (uv[:, 0] > 0) & (uv[:, 0] < cam.width) & (uv[:, 1] > 0) & (uv[:, 1] < cam.height))[0]
+    mp_desc = rng.integers(0, 256, (NP, 32), dtype=np.uint8)
+    feat_uv = np.stack([rng.uniform(0, cam.width, NF), rng.uniform(0, cam.height, NF)], 1)
+    feat_oct = rng.integers(0, 8, NF).astype(np.int32)
+    feat_desc = rng.integers(0, 256, (NF, 32), dtype=np.uint8)
+    if len(front):
+        src = front[rng.integers(0, len(front), NF)]
+        near = rng.uniform(size=NF) < 0.7
+        sig = scale_factor ** lvl[src]
+        feat_uv = np.where(near[:, None], uv[src] + rng.normal(0, 1.5, (NF, 2)) * sig[:, None], feat_uv)
+        feat_oct = np.where(near, np.clip(lvl[src] - rng.integers(0, 2, NF), 0, 7), feat_oct).astype(np.int32)
+        nflip = rng.integers(0, 71, NF)
+        for i in np.nonzero(near)[0]:
+            d = mp_desc[src[i]].copy()
+            bits = rng.choice(256, nflip[i], replace=False)
+            np.bitwise_xor.at(d, bits // 8, (1 << (bits % 8)).astype(np.uint8))
+            feat_desc[i] = d
+    feat_ur = np.where(rng.uniform(size=NF) < 0.7, feat_uv[:, 0] - rng.uniform(2, 60, NF), -1.0).astype(np.float32)
+    feat_taken = (rng.uniform(size=NF) < 0.05).astype(np.uint8)
+    f.update(feat_uv=feat_uv, feat_ur=feat_ur, feat_oct=feat_oct, feat_desc=feat_desc, feat_taken=feat_taken, mp_desc=mp_desc)
+    return f

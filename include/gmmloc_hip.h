@@ -311,6 +311,17 @@ int gl_project_map_points(gl_ctx_t* ctx, const gl_camera* cam, float scale_facto
                           const double* t_wc_dev, const double* pos_dev, const double* normal_dev, const float* max_dist_dev,
                           const float* min_dist_dev, const uint8_t* cand_dev, double* uvr_dev, int32_t* level_dev,
                           double* viewcos_dev, double* dist_dev, uint8_t* inview_dev);
+/* Tracking::searchLocalPoints (tracking.cpp:213-270), the device part in one call: gl_project_map_points followed by
+ * gl_search_by_projection (ORBmatcher(0.8), th 3 - or 5 for the first two frames) on its outputs, which stay in the context's
+ * scratch.  Arguments as in the two calls; inview_dev (B x NP uint8, may be null): is_in_view_ per map point for the host's
+ * num_visible_++ (tracking.cpp:251). */
+int gl_search_local_points(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NP, const double* feat_uv_dev,
+                           const float* feat_ur_dev, const int32_t* feat_oct_dev, const uint8_t* feat_desc_dev,
+                           const uint8_t* feat_taken_dev, const double* pose_cw_dev, const double* t_wc_dev, const double* mp_pos_dev,
+                           const double* mp_normal_dev, const float* mp_max_dist_dev, const float* mp_min_dist_dev,
+                           const uint8_t* mp_cand_dev, const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
+                           int32_t* nmatches_dev, uint8_t* inview_dev);
+
 /* Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: per candidate map point the most
  * similar feature inside Frame::getFeaturesInArea(u, v, th * scale_factors[level]) (frame.cpp:121-177) with octave level - 1 or
  * level and Feature::error(uvr) * sigma2_inv[octave] within 5.99 (mono) / 7.8 (stereo).  Features as in gl_search_by_projection

@@ -451,3 +451,40 @@ def test_project_map_points_matches_oracle(gpu, oracle):
     ref = oracle.project_map_points(cam, **pr)
     ri, rd, n = oracle.fuse_search(752, 480, f["feat_uv"], f["feat_ur"], f["feat_oct"], f["feat_desc"], ref[0], ref[1], ref[4], f["mp_desc"], th=3.0)
     assert np.array_equal(bi.cpu().numpy()[0], ri) and np.array_equal(bd.cpu().numpy()[0], rd)
+
+
+def test_search_local_points_chain_matches_oracle(gpu, oracle):
+    """gl_search_local_points = Tracking::searchLocalPoints on the device (tracking.cpp:213-270): the projection / visibility loop and
+    ORBmatcher(0.8).searchByProjection on its outputs in one call, against the oracle's two functions one after the other: matches,
+    counts and in-view flags bit for bit, frames of different sizes in a batch, th 3 and 5 (the first two frames)."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    PK = ("pose_cw", "t_wc", "pos", "normal", "max_dist", "min_dist", "cand")
+    rng = np.random.default_rng(91)
+    frames = [synth.synth_local_points_frame(NF, NP, 3000 + i, cam) for i, (NF, NP) in enumerate(((900, 2500), (1200, 4000), (300, 700), (50, 3000), (1000, 60)))]
+    frames += [synth.synth_local_points_frame(int(rng.integers(20, 1500)), int(rng.integers(20, 4096)), 3100 + i, cam) for i in range(40)]
+    B, NF, NP = len(frames), max(len(f["feat_oct"]) for f in frames), max(len(f["cand"]) for f in frames)
+    t = dict(feat_uv=np.zeros((B, NF, 2)), feat_ur=np.full((B, NF), -1.0, np.float32), feat_oct=np.full((B, NF), -1, np.int32),
+             feat_desc=np.zeros((B, NF, 32), np.uint8), feat_taken=np.zeros((B, NF), np.uint8), mp_desc=np.zeros((B, NP, 32), np.uint8))
+    for b, f in enumerate(frames):
+        for k in ("feat_uv", "feat_ur", "feat_oct", "feat_desc", "feat_taken"):
+            t[k][b, :len(f["feat_oct"])] = f[k]
+        t["mp_desc"][b, :len(f["cand"])] = f["mp_desc"]
+    T = lambda a: torch.from_numpy(a).cuda()
+    proj = _pack_project(torch, frames)
+    tot = 0
+    for th in (3.0, 5.0):
+        match, nm, inview = api.search_local_points(ctx, cam, T(t["feat_uv"]), T(t["feat_ur"]), T(t["feat_oct"]), T(t["feat_desc"]), T(t["feat_taken"]),
+                                                    *proj, T(t["mp_desc"]), th=th)
+        torch.cuda.synchronize()
+        match, nm, inview = match.cpu().numpy(), nm.cpu().numpy(), inview.cpu().numpy()
+        for b, f in enumerate(frames):
+            uvr, lvl, vc, dd, iv, n = oracle.project_map_points(cam, **{k: f[k] for k in PK})
+            ref, nref = oracle.search_by_projection(cam.width, cam.height, f["feat_uv"], f["feat_ur"], f["feat_oct"], f["feat_desc"], f["feat_taken"],
+                                                    uvr, lvl, vc, iv, f["mp_desc"], th=th)
+            nf, npn = len(ref), len(iv)
+            assert np.array_equal(inview[b, :npn], iv) and (inview[b, npn:] == 0).all(), b
+            assert np.array_equal(match[b, :nf], ref) and nm[b] == nref, (b, th, int((match[b, :nf] != ref).sum()))
+            assert (match[b, nf:] == -1).all()
+            tot += nref
+    assert tot > 5000, tot
