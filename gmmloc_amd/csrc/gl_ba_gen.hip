@@ -1895,6 +1895,9 @@ struct PipeA {  // kernel arguments (by value)
   double* pth;        // B x L x 6: the points' undamped blocks of the last full point pass (point_relambda)
   int* unfinished;    // problems not at stage 3
   int nba, lpp, nblk, nchunk;
+  PipeSt* stJ;        // B: the judged state and {accept, next} per window, when the verdict is a kernel of its own (ext_judge: kp_judge)
+  int* verd;
+  int ext_judge;
   int kper;           // chunks of a block per wave of the Schur pass (1; 2 in batches: the wave's set-up once for two chunks - the
                       // partial sums stay per chunk, so the bits do not depend on it)
 };
@@ -2337,6 +2340,32 @@ GL_DEV void pipe_judge(const PipeA& a, const GenP& G, const PipeSt& in, PipeSt& 
   *next = nx;
 }
 constexpr int PIPE_JUDGE_MAX = 2 * 256 + 2 * 132 + 24;  // partials of <= 256 workgroups, dx and b_p of <= 22 poses, their prior chi2
+// the verdict on the trial this cycle has evaluated, once per window (ext_judge; see launch_ba_pipe): what the head of the next
+// cycle's kp_lin would compute in each of its workgroups
+__global__ __launch_bounds__(64) void kp_judge(PipeA a) {
+  __shared__ double s_d[PIPE_JUDGE_MAX];
+  const int f = blockIdx.x, tid = threadIdx.x, P = a.P, n = 6 * P;
+  const PipeSt* st = st_cur(a, f);
+  const PipeCtl ctl = pipe_ctl(st);
+  if ((ctl.stage >= 3) | !ctl.pend) return;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  for (int i = tid; i < 2 * a.nba; i += 64) s_d[i] = a.partD[(size_t)f * a.nba * 2 + i];
+  for (int i = tid; i < n; i += 64) {
+    s_d[2 * a.nba + i] = G.dxv[i];
+    s_d[2 * a.nba + n + i] = G.bp[i];
+  }
+  if (tid < P) s_d[2 * a.nba + 2 * n + tid] = G.pchi2[tid];
+  __syncthreads();
+  if (tid == 0) {
+    PipeSt q;
+    int acc, nx;
+    pipe_judge(a, G, *st, q, s_d, &acc, &nx);
+    a.stJ[f] = q;
+    a.verd[2 * f] = acc;
+    a.verd[2 * f + 1] = nx;
+  }
+}
 __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   __shared__ double red[NW_BA * 32 + 8];
   __shared__ double s_d[PIPE_JUDGE_MAX];
@@ -2357,7 +2386,8 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   genp_init(G, a, f, a.nba, pb);
   const bool judge = ctl.pend != 0;
   const bool lds_ok = 2 * a.nba + 2 * n + P <= PIPE_JUDGE_MAX && P + F <= 32;  // (launch_ba_pipe only takes such windows)
-  if (judge && lds_ok) {  // every term of the two sums requested at once
+  const bool own_judge = judge && !a.ext_judge;
+  if (own_judge && lds_ok) {  // every term of the two sums requested at once
     for (int i = tid; i < 2 * a.nba; i += T_BA) s_d[i] = a.partD[(size_t)f * a.nba * 2 + i];
     for (int i = tid; i < n; i += T_BA) {
       s_d[2 * a.nba + i] = G.dxv[i];
@@ -2368,7 +2398,16 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
   // what the verdict will be applied to is requested in the same round trip as the terms it is made from: both versions of
   // the poses (two elements per thread) and the trial state of the thread's point
   PipeSt qin;
-  if (tid == 0) qin = *sp;
+  int v_acc = 0, v_next = -1;
+  if (tid == 0) {
+    if (judge && a.ext_judge) {  // judged behind the trial (kp_judge)
+      qin = a.stJ[f];
+      v_acc = a.verd[2 * f];
+      v_next = a.verd[2 * f + 1];
+    } else {
+      qin = *sp;
+    }
+  }
   double rt_cur[2] = {0.0, 0.0}, rt_new[2] = {0.0, 0.0};
   int rt_act[2] = {0, 0};
 #pragma unroll
@@ -2392,13 +2431,13 @@ __global__ __launch_bounds__(T_BA) void kp_lin(PipeA a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) pn0[i] = G.pn[(size_t)l0 * 3 + i];
   }
-  if (tid == 0 && !judge) {
+  if (tid == 0 && !own_judge) {
     s_q = qin;
-    s_accept = 0;
-    s_next = -1;
+    s_accept = v_acc;
+    s_next = v_next;
   }
   __syncthreads();
-  if (tid == 0 && judge) {
+  if (tid == 0 && own_judge) {
     PipeSt q;
     int acc, nx;
     pipe_judge(a, G, qin, q, s_d, &acc, &nx);
@@ -2901,7 +2940,7 @@ size_t ba_pipe_scratch_bytes(int B, int P, int F, int L, int NOBS) {
   pipe_shape(P, L, NOBS, &nba, &lpp, &nblk, &nchunk);
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
   return ba_gen_scratch_bytes(B, P, F, L, NOBS) + up((size_t)2 * B * sizeof(PipeSt)) + 2 * up((size_t)B * nba * 16) +
-         up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * L * 6 * 8) + up((size_t)B * nblk * 4) + 1024;
+         up((size_t)B * nblk * nchunk * 48 * 8) + up((size_t)B * L * 6 * 8) + up((size_t)B * sizeof(PipeSt)) + up((size_t)B * 8) + up((size_t)B * nblk * 4) + 1024;
 }
 
 // One LANE of the pipelined local BA: a sub-batch of the call's windows with its own kernel arguments, scratch area and stream.
@@ -2954,6 +2993,15 @@ static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, const Gmm* g, co
   s += up((size_t)B * a.nblk * a.nchunk * 48 * 8);
   a.pth = (double*)s;
   s += up((size_t)B * L * 6 * 8);
+  a.stJ = (PipeSt*)s;
+  s += up((size_t)B * sizeof(PipeSt));
+  a.verd = (int*)s;
+  s += up((size_t)B * 8);
+  // The verdict on a trial as a kernel of its own behind kp_trial (one small workgroup per window) instead of in every one of the
+  // window's 24 - 47 point-pass workgroups: in batches the judging head is 14 of kp_lin's 28 us (64 windows); alone it is a launch
+  // more on a single window's critical path (break-even at 16 - 24 windows per lane: from 32 on; GL_PIPE_JUDGE = 0 / 1 overrides,
+  // for A/B runs).  The same function on the same values: the same bits.  64 windows 0.122 -> 0.114 ms per window, 256 0.118 -> 0.113.
+  a.ext_judge = getenv("GL_PIPE_JUDGE") ? atoi(getenv("GL_PIPE_JUDGE")) : (B >= 32 ? 1 : 0);
   a.unfinished = (int*)s;  // [0] problems not finished, [1] cycles the slowest of them needed
   const size_t n = 6 * (size_t)P;
   ln.s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;
@@ -3008,6 +3056,7 @@ static void pipe_lane_cycle(PipeLane& ln, int cyc) {
   kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, ln.s>>>(a);
   kp_solve<<<B, T_SOLVE, ln.s_bytes, ln.s>>>(a);
   kp_trial<<<pipe_grid(B, a.nba), T_BA, 0, ln.s>>>(a);
+  if (a.ext_judge) kp_judge<<<B, 64, 0, ln.s>>>(a);
 }
 
 // Lanes of a call.  Every kernel of a cycle is bound by the LENGTH of its workgroups' chains of dependent loads times the rounds of
