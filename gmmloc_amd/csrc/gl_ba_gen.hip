@@ -2587,15 +2587,21 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
         Idx nxt;
         fetch_idx(e + 64, e1, nxt);
         const int o1 = cur.o1, o2 = cur.o2, l = cur.l;
-        const int o2c = o2 < 0 ? o1 : o2;  // (no partner: the own record again - a valid address, no further line)
-        const int lv = G.lev_o[o1] | G.lev_o[o2c];  // an edge at level 1 (k_ba_gen folds these flags into the partner table)
+        int lv = 0;
         double r1[12], r2[12], pw[9];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) r1[i] = G.lin[(size_t)o1 * 12 + i];
+        for (int i = 0; i < 12; ++i) r1[i] = r2[i] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) r2[i] = G.lin[(size_t)o2c * 12 + i];
+        for (int i = 0; i < 9; ++i) pw[i] = 0.0;
+        if (o2 >= 0) {  // (the lanes without a partner - half of them - request nothing: at 256 windows the pass moves terabytes per second)
+          lv = G.lev_o[o1] | G.lev_o[o2];  // an edge at level 1 (k_ba_gen folds these flags into the partner table)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) pw[i] = G.ptw[(size_t)l * 12 + i];
+          for (int i = 0; i < 12; ++i) r1[i] = G.lin[(size_t)o1 * 12 + i];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) r2[i] = G.lin[(size_t)o2 * 12 + i];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) pw[i] = G.ptw[(size_t)l * 12 + i];
+        }
         pin(lv);
 #pragma unroll
         for (int i = 0; i < 12; ++i) pin(r1[i]);
