@@ -361,6 +361,46 @@ def config_match(torch, ctx, out):
     out({"config": "searchByBoW: %d key-frame / frame pairs x 1200 + 1200 features, ~240 vocabulary nodes each" % B,
          "pairs_per_s": B / t4, "single_pair_latency_us": 1e6 * t4l, "algorithmic_bytes_per_pair": bytes_bow,
          "algorithmic_GBs": B * bytes_bow / t4 / 1e9, "cpu_oracle_1thread_pairs_per_s": 1.0 / tc4})
+    # the projection / visibility loop in front of the matcher, and the two as Tracking::searchLocalPoints in one call: 1 200 features,
+    # a local map of 3 000 points of which a fifth to a quarter is in view
+    from tests.test_gpu_match import _pack_project
+    PK = ("pose_cw", "t_wc", "pos", "normal", "max_dist", "min_dist", "cand")
+    NPL = 3000
+    ul = [synth.synth_local_points_frame(NF, NPL, 1700 + b, api.Camera()) for b in range(64)]
+    fl = [ul[b % 64] for b in range(B)]
+    proj = _pack_project(torch, fl)
+    TL = lambda k: torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in fl]))).cuda()
+    feat = [TL(k) for k in ("feat_uv", "feat_ur", "feat_oct", "feat_desc", "feat_taken")]
+    mpd = TL("mp_desc")
+    t5 = ev_time(torch, lambda: api.project_map_points(ctx, api.Camera(), *proj), 5, ctx.stream)
+    t6 = ev_time(torch, lambda: api.search_local_points(ctx, api.Camera(), *feat, *proj, mpd, th=3.0), 5, ctx.stream)
+    t6l = ev_time(torch, lambda: api.search_local_points(ctx, api.Camera(), *[x[:1] for x in feat], *[x[:1] for x in proj], mpd[:1], th=3.0), 50, ctx.stream)
+    t0 = time.perf_counter()
+    for f in ul:
+        orc.project_map_points(api.Camera(), **{k: f[k] for k in PK})
+    tc5 = (time.perf_counter() - t0) / len(ul)
+    t0 = time.perf_counter()
+    for f in ul:
+        uvr, lvl, vc, dd, iv, n = orc.project_map_points(api.Camera(), **{k: f[k] for k in PK})
+        orc.search_by_projection(752, 480, f["feat_uv"], f["feat_ur"], f["feat_oct"], f["feat_desc"], f["feat_taken"], uvr, lvl, vc, iv, f["mp_desc"], th=3.0)
+    tc6 = (time.perf_counter() - t0) / len(ul)
+    bytes_proj = NPL * (57 + 45) + 80
+    out({"config": "projection / visibility loop (Frame::project3 + checkScaleAndVisible): %d frames x %d map points" % (B, NPL),
+         "frames_per_s": B / t5, "points_per_s": B * NPL / t5, "algorithmic_bytes_per_frame": bytes_proj, "algorithmic_GBs": B * bytes_proj / t5 / 1e9,
+         "cpu_oracle_1thread_frames_per_s": 1.0 / tc5})
+    out({"config": "searchLocalPoints (projection loop + searchByProjection in one call): %d frames x %d features x %d map points, th=3" % (B, NF, NPL),
+         "frames_per_s": B / t6, "single_frame_latency_us": 1e6 * t6l, "cpu_oracle_1thread_frames_per_s": 1.0 / tc6})
+    # fuseObservations, the matching half: 1 200 features of a neighbour key-frame x 1 500 projected map points
+    from tests.test_gpu_match import _pack_fuse, FUSE_KEYS
+    uf = [synth.synth_fuse_frame(NF, NP, 1900 + b) for b in range(64)]
+    fa = _pack_fuse(torch, [uf[b % 64] for b in range(B)])
+    t7 = ev_time(torch, lambda: api.fuse_search(ctx, cam, *fa, th=3.0), 5, ctx.stream)
+    t0 = time.perf_counter()
+    for f in uf:
+        orc.fuse_search(f["width"], f["height"], *[f[k] for k in FUSE_KEYS], th=3.0)
+    tc7 = (time.perf_counter() - t0) / len(uf)
+    out({"config": "fuseObservations, matching half: %d key-frames x %d features x %d map points, th=3" % (B, NF, NP),
+         "frames_per_s": B / t7, "cpu_oracle_1thread_frames_per_s": 1.0 / tc7})
     out({"config": "searchByProjection(CurrentFrame, LastFrame): %d frame pairs x %d features x %d last-frame map points, th=7" % (B, NF, NL),
          "frames_per_s": B / t2, "cpu_oracle_1thread_frames_per_s": 1.0 / tc2})
     out({"config": "searchByProjection: %d frames x %d features x %d map points, th=3" % (B, NF, NP),
