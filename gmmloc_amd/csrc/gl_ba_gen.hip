@@ -3198,7 +3198,9 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   const bool pipe_fits = P <= 22 && P + F <= 32 && (size_t)L * (NOBS >= 6 * L ? 8 : 4) <= 65536;  // (the judging workgroups hold <= 256 partial sums and the poses in LDS)
   // (mode 0 chooses from the WINDOW alone - never from B: the two shapes add their partial sums in different orders, and a
   // window must not change its bits, or the call its blocking behaviour, with the number of windows that ride along)
-  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && NOBS >= 5000));
+  // (from 3 000 observations since the end of round 4 - 5 000 before: profiles/r4f_ba_modes.txt has the pipelined shape ahead from
+  // 3 300 observations at every batch size, 9 % on one window and 30 % on eight, and per trial already at 2 100)
+  const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && NOBS >= 3000));
   int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_total(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
   if (pipe) {

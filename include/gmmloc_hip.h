@@ -101,7 +101,7 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   bagen_mode (0): launch shape of gl_joint_optimization.  A window's RESULT BITS and the call's BLOCKING BEHAVIOUR are a
  *     function of the window shape (P, F, L, NOBS) and this option alone - never of B:
  *       0  by window: the pipelined shape (a kernel per phase, cycles enqueued ahead; 1.4 - 2 x less per Levenberg trial) for
- *          windows of >= 5 000 observations (NOBS), the persistent cooperative kernel below that;
+ *          windows of >= 3 000 observations (NOBS), the persistent cooperative kernel below that;
  *       1  the persistent kernel for every window: ASYNCHRONOUS on the context's stream (stream-capturable; the caller
  *          synchronises).  Its workgroup count per window follows NOBS; a batch too large to keep B x that many workgroups
  *          co-resident is launched in sub-batches, in stream order;
