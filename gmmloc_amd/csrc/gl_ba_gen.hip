@@ -57,6 +57,7 @@ struct GenP {
   double* pn;      // L x 3 trial points
   double* lin;     // nobs x 12: q3 A6 a3
   double* ptw;     // L x 12: Dinv6 u3 bl3
+  double* pth;     // L x 6: the points' undamped blocks of the last full point pass (point_relambda; the persistent kernel's carve)
   double* chi_o;   // nobs
   double* S;       // n x n
   double* gv;      // n
@@ -417,9 +418,9 @@ GL_DEV double pass_points(const BaK& k, const GmmDev& gm, const GenP& G, bool ro
   return chi;
 }
 GL_DEV double pass_points_lpp(int lpp, const BaK& k, const GmmDev& gm, const GenP& G, bool robust, double lambda, double& mdiag) {
-  if (lpp == 4) return pass_points<4>(k, gm, G, robust, lambda, mdiag);
-  if (lpp == 2) return pass_points<2>(k, gm, G, robust, lambda, mdiag);
-  return pass_points<1>(k, gm, G, robust, lambda, mdiag);
+  if (lpp == 4) return pass_points<4, true>(k, gm, G, robust, lambda, mdiag, G.pth);
+  if (lpp == 2) return pass_points<2, true>(k, gm, G, robust, lambda, mdiag, G.pth);
+  return pass_points<1, true>(k, gm, G, robust, lambda, mdiag, G.pth);
 }
 
 // (the kernels of the pipelined shape: 4 lanes per point, 8 where a point has six or more observations on average - half
@@ -1429,6 +1430,8 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
 
   double lambda = 0.0, ni = 2.0;
   int cj = 0;
+  bool fresh = false;     // the records of the last point pass are those of the current state (point_relambda)
+  double chi_keep = 0.0;  // this thread's part of the robust chi2 of that pass
   for (int it = 0; it < iters; ++it) {
     if (stop_now(G)) break;  // SparseOptimizer::optimize: `i < iterations && !terminate()`
     // Prior edges at the current state: that state changes once per outer iteration (an accepted trial ends the
@@ -1450,7 +1453,8 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
     }
     if (it == 0) {  // computeLambdaInit
       double md = 0.0;
-      pass_points_lpp(lpp, k, gm, G, robust, 0.0, md);
+      chi_keep = pass_points_lpp(lpp, k, gm, G, robust, 0.0, md);
+      fresh = true;
       for (int i = GSTART; i < n * ld; i += GSTRIDE) S[i] = 0.0;
       prob_sync(G);
       pass_blocks(G, false, p2part);
@@ -1471,7 +1475,11 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       GP_T(t0);
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-      acc[0] = pass_points_lpp(lpp, k, gm, G, robust, lambda, md_unused);
+      // (nothing has moved since the last point pass - a rejected trial's successor, the first trial after the lambda-init pass:
+      // only the damped point blocks are rebuilt, like kp_lin; the thread's part of chi2 is the one it kept)
+      if (fresh) point_relambda(G, lambda, G.pth);
+      else chi_keep = pass_points_lpp(lpp, k, gm, G, robust, lambda, md_unused);
+      acc[0] = chi_keep;
       for (int i = GSTART; i < n * ld; i += GSTRIDE) S[i] = 0.0;
       for (int i = GSTART; i < n; i += GSTRIDE) {
         G.gv[i] = 0.0;
@@ -1572,6 +1580,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         lambda *= fmax(1. / 3., alpha);
         ni = 2;
         currentChi = tempChi;
+        fresh = false;
         for (int j = GSTART; j < P; j += GSTRIDE) {
           if (!G.pact[j]) continue;
           for (int r = 0; r < 7; ++r) G.poses[(size_t)j * 7 + r] = G.qN[(size_t)j * 7 + r];
@@ -1585,6 +1594,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       } else {
         lambda *= ni;
         ni *= 2;
+        fresh = true;
       }
       prob_sync(G);
       qmax++;
@@ -1672,6 +1682,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.pchi2 = takeD(P);
   G.prH = takeD((size_t)P * 36);
   G.prb = takeD((size_t)P * 6);
+  G.pth = takeD((size_t)L * 6);
   auto takeI = [&](size_t cnt) {
     int32_t* p = (int32_t*)s;
     s += ((cnt * 4 + 7) / 8) * 8;
@@ -1825,7 +1836,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
 size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
   const size_t n = 6 * (size_t)P;
   size_t d = (size_t)(P + F) * 12 + (size_t)P * 12 + (size_t)P * 7 * 2 + (size_t)L * 3 + (size_t)NOBS * 12 +
-             (size_t)L * 12 + NOBS + n * (n + 2) + 512 + 3 * n + 2 * P + 42 * (size_t)P;
+             (size_t)L * 12 + NOBS + n * (n + 2) + 512 + 3 * n + 2 * P + 42 * (size_t)P + (size_t)L * 6;
   size_t i = (size_t)NOBS * 4 + (P + 1) + (size_t)NOBS * P + 32;
   size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
   return d * 8 + i * 4 + b + 256;
@@ -1959,6 +1970,7 @@ GL_DEV void genp_init(GenP& G, const PipeA& a, int f, int NB, int pb) {
   G.pchi2 = takeD(P);
   G.prH = takeD((size_t)P * 36);
   G.prb = takeD((size_t)P * 6);
+  G.pth = takeD((size_t)L * 6);  // (the persistent kernel's carve; this shape keeps its own in PipeA)
   auto takeI = [&](size_t cnt) {
     int32_t* p = (int32_t*)s;
     s += ((cnt * 4 + 7) / 8) * 8;
