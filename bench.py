@@ -219,11 +219,23 @@ def cpu_baseline(seed0, budget_s=24.0):
 
 def stub_bench(args, ranks):
     """CPU test of the launch plumbing (tests/test_bench_contract.py): the same spawn, barrier, timing and MAX-over-ranks
-    code as the real bench over gloo, with a stand-in step.  Not a measurement."""
-    state = {"n": 0}
+    code as the real bench over gloo, with a stand-in step.  Not a measurement.  GMMLOC_STUB_STEP_MS > 0 makes the stand-in
+    ASYNCHRONOUS like a kernel launch: a step only moves the time at which the stand-in device will be idle, and the rank's
+    device synchronise (launch.Ranks.sync) waits for it - a clock read before that synchronise times the enqueue, not the work."""
+    state = {"n": 0, "idle_at": 0.0}
+    step_s = float(os.environ.get("GMMLOC_STUB_STEP_MS", "0")) / 1e3
 
     def step():
         state["n"] += int(np.arange(1000).sum() > 0)
+        if step_s > 0:
+            state["idle_at"] = max(state["idle_at"], time.perf_counter()) + step_s
+
+    def device_sync():
+        wait = state["idle_at"] - time.perf_counter()
+        if wait > 0:
+            time.sleep(wait)
+    if step_s > 0 and ranks.backend == "gloo":
+        ranks.device_sync = device_sync
     dt = launch.timed_steps(step, args.steps, args.warmup, ranks)
     total = ranks.sum(float(state["n"]))
     per_rank = ranks.gather(args.steps / max(ranks.last_own_dt, 1e-9))
@@ -577,8 +589,10 @@ def main():
                           "host_to_host_what": "gl_track_frame_host: host buffers -> the context's page-locked staging -> one H2D + "
                                                "gl_track_frames + one D2H on its stream -> one synchronize -> host buffers (what the "
                                                "adapter's trackFrame calls), ctypes caller, median of 20"}
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(20200901 + 100000 * rank)
+        if not args.no_cpu_baseline:
+            # rank 0, after the timed region (at N > 1 the other ranks wait in the closing barrier meanwhile: the 1-thread figure
+            # of the same host stays beside every line; a shorter sample there)
+            cb = cpu_baseline(20200901 + 100000 * rank, 24.0 if world == 1 else 10.0)
             out["cpu_baseline"] = cb
             lat = out["latency"]
             lat["cpu_same_math_brute_ms_per_frame"] = cb["same_math_brute"]["ms_per_frame"]

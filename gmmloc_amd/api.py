@@ -19,6 +19,7 @@ ASSOC_EXHAUSTIVE = 2
 
 F_MEAN, F_COV, F_COV_INV, F_DET, F_SCALE, F_AXIS, F_SQRT_INFO, F_FLAGS, F_NBS_PTR, F_NBS_IDX, F_NBS_DIST = range(11)
 TIMER_ASSOC, TIMER_REFINE_POSE, TIMER_BA, TIMER_BA_PREP = 0, 1, 2, 3
+COUNTER_BA_REDONE, COUNTER_MATCH_ROUNDS, COUNTER_MATCH_UNITS = 0, 1, 2
 
 
 class GLError(RuntimeError):
@@ -123,7 +124,8 @@ class Context:
         return ms.value, n.value
 
     def counter_read(self, counter=0, reset=True):
-        """gl_ctx_counter_read: 0 = GL_COUNTER_BA_REDONE (frames of latency-shape launches redone by the follow-up kernel)."""
+        """gl_ctx_counter_read: 0 = GL_COUNTER_BA_REDONE (frames of latency-shape launches redone by the follow-up kernel),
+        1 / 2 = GL_COUNTER_MATCH_ROUNDS / _UNITS (rounds of the matchers' owner fixed point, and the frames / pairs they ran on)."""
         v = C.c_int64(0)
         _check(self.lib.gl_ctx_counter_read(self.h, counter, C.byref(v), 1 if reset else 0))
         return v.value

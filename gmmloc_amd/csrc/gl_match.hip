@@ -81,7 +81,7 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     const uint8_t* __restrict__ mp_valid_all, const uint8_t* __restrict__ mp_desc_all,
     int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all,
     const double* __restrict__ pose_cw_all, const double* __restrict__ pose_lw_all,
-    const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all) {
+    const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all, int32_t* __restrict__ counters) {
   constexpr int TM = DL ? 1024 : T_M;  // threads per frame: the latency shape doubles them
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* cell_ptr = lds;                   // NCELL + 1
@@ -425,6 +425,10 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     int tot = 0;
     for (int w = 0; w < TM / 64; ++w) tot += s_scan[w];
     nmatches_all[f] = tot;
+    if (counters) {  // GL_COUNTER_MATCH_ROUNDS / _UNITS: rounds of the owner fixed point, frames
+      atomicAdd(&counters[1], rounds);
+      atomicAdd(&counters[2], 1);
+    }
 #ifdef GL_MATCH_PROF
     feat_match[0] = (int)((tp1 - tp0) >> 4);
     feat_match[1] = (int)((tp2 - tp1) >> 4);
@@ -477,7 +481,7 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
                         : (dl ? k_search_by_projection<1, true> : k_search_by_projection<1, false>);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)kern, lds));
   kern<<<B, dl ? 1024 : T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
-                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle);
+                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle, c->counters);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

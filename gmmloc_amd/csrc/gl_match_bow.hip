@@ -45,7 +45,7 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
                                                        const uint8_t* __restrict__ desc2_all, const int32_t* __restrict__ nn2_all,
                                                        const int32_t* __restrict__ nid2_all, const int32_t* __restrict__ nptr2_all,
                                                        const int32_t* __restrict__ nidx2_all, int32_t* __restrict__ match_all,
-                                                       int32_t* __restrict__ nmatches_all) {
+                                                       int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* owner = lds;            // N2: lowest query that claimed the frame feature in the previous round (INT_MAX: nobody)
   int32_t* owner_n = owner + N2;   // N2: being rebuilt
@@ -220,6 +220,10 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
     int tot = 0;
     for (int w = 0; w < T_B / 64; ++w) tot += s_cnt[w];
     nmatches_all[f] = tot;
+    if (counters) {  // GL_COUNTER_MATCH_ROUNDS / _UNITS
+      atomicAdd(&counters[1], rounds);
+      atomicAdd(&counters[2], 1);
+    }
   }
 }
 
@@ -243,7 +247,7 @@ extern "C" int gl_search_by_bow(gl_ctx_t* ctx, float nn_ratio, int check_orienta
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_by_bow, lds));
   k_search_by_bow<<<B, T_B, lds, c->stream>>>(B, N1, N2, NN1, NN2, nn_ratio, check_orientation, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                               node_id1_dev, node_ptr1_dev, node_idx1_dev, angle2_dev, desc2_dev, nnode2_dev, node_id2_dev,
-                                              node_ptr2_dev, node_idx2_dev, match21_dev, nmatches_dev);
+                                              node_ptr2_dev, node_idx2_dev, match21_dev, nmatches_dev, c->counters);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

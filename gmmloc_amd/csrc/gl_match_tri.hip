@@ -55,7 +55,7 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
     const int32_t* __restrict__ oct2_all, const float* __restrict__ angle2_all, const uint8_t* __restrict__ desc2_all,
     const uint8_t* __restrict__ mp2_all, const int32_t* __restrict__ nn2_all, const int32_t* __restrict__ nid2_all,
     const int32_t* __restrict__ nptr2_all, const int32_t* __restrict__ nidx2_all, const double* __restrict__ fmat_all,
-    const float* __restrict__ epi_all, int32_t* __restrict__ match_all, int32_t* __restrict__ nmatches_all) {
+    const float* __restrict__ epi_all, int32_t* __restrict__ match_all, int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int N1 = P.N1, N2 = P.N2;
   int32_t* owner = lds;             // N2: lowest query that picked the feature in the previous round (-1: not available at all)
@@ -255,6 +255,10 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
     int tot = 0;
     for (int w = 0; w < T_T / 64; ++w) tot += s_cnt[w];
     nmatches_all[f] = tot;
+    if (counters) {  // GL_COUNTER_MATCH_ROUNDS / _UNITS
+      atomicAdd(&counters[1], rounds);
+      atomicAdd(&counters[2], 1);
+    }
   }
 }
 
@@ -427,7 +431,7 @@ extern "C" int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, in
   k_search_for_triangulation<<<B, T_T, lds, c->stream>>>(P, B, uv1_dev, ur1_dev, oct1_dev, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                                         node_id1_dev, node_ptr1_dev, node_idx1_dev, uv2_dev, ur2_dev, oct2_dev, angle2_dev,
                                                         desc2_dev, has_mp2_dev, nnode2_dev, node_id2_dev, node_ptr2_dev, node_idx2_dev, fmat_dev,
-                                                        epipole_dev, match12_dev, nmatches_dev);
+                                                        epipole_dev, match12_dev, nmatches_dev, c->counters);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

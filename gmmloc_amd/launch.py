@@ -52,6 +52,7 @@ class Ranks:
         self.dist = None
         self.device = None
         self.last_own_dt = None  # timed_steps: this rank's own elapsed seconds (the barrier-to-barrier time is the MAX over ranks)
+        self.device_sync = None  # gloo stub only: stand-in for the device synchronise (tests of the timing with an asynchronous step)
 
     def init(self, always=False):
         """Join the process group (world > 1, or always=True to run the collectives with one rank too)."""
@@ -71,14 +72,19 @@ class Ranks:
             self.dist = dist
         return self
 
-    def barrier(self):
-        import torch
+    def sync(self):
+        """wait for everything this rank has enqueued on its device (steps are asynchronous launches)"""
         if self.backend == "nccl":
+            import torch
             torch.cuda.synchronize()
+        elif self.device_sync is not None:
+            self.device_sync()
+
+    def barrier(self):
+        self.sync()
         if self.dist is not None:
             self.dist.barrier()
-        if self.backend == "nccl":
-            torch.cuda.synchronize()
+        self.sync()
 
     def max(self, value):
         """MAX over the ranks of one float."""
@@ -128,7 +134,8 @@ def timed_steps(step, steps, warmup, ranks, before_timed=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    own = time.perf_counter() - t0  # this rank's own steps, before it waits for the others
+    ranks.sync()                    # the steps only ENQUEUE work: the rank's own time ends when its device is done,
+    own = time.perf_counter() - t0  # ... and before it waits for the other ranks
     ranks.barrier()
     ranks.last_own_dt = own
     return ranks.max(time.perf_counter() - t0)

@@ -133,6 +133,9 @@ int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* laun
 /* Event counters of a context (device-side, read with one small synchronous copy on the context's stream). */
 enum gl_counter {
   GL_COUNTER_BA_REDONE = 0, /* frames of latency-shape launches of gl_track_frames that gave up and were recomputed by the follow-up kernel */
+  GL_COUNTER_MATCH_ROUNDS = 1, /* rounds of the owner fixed point, summed over the frames / pairs of gl_search_by_projection{,_frame},
+                                  gl_search_for_triangulation, gl_search_by_bow (what the reference's order-dependent loop costs here) */
+  GL_COUNTER_MATCH_UNITS = 2,  /* ... and the number of those frames / pairs */
   GL_COUNTER_COUNT = 4
 };
 int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset);

@@ -56,6 +56,21 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert d["steps_run_all_ranks"] == 2 * (7 + 2)  # both ranks ran every step (all_reduce SUM over the group)
 
 
+def test_per_rank_rate_is_a_throughput_not_an_enqueue_time():
+    """The steps of the real bench only ENQUEUE kernels.  A rank's own rate must be taken after its device is idle: with an
+    asynchronous stand-in step (60 ms of 'device' work per step) every rank's rate has to sit within 5 % of its share of the
+    headline (the headline is the MAX over ranks; the ranks do the same work) - a clock read before the synchronise reports the
+    microseconds of the enqueue instead (round 4: 122 702 326 frames/s beside a headline of 367 633)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GMMLOC_STUB_STEP_MS"] = "60"
+    d = _stub_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--stub", "gloo"], env)
+    share = 1e3 / d["ms_per_step"]  # steps/s of one rank by the headline's clock (the stub's `value` also counts the warm-up steps)
+    assert 1e3 * 5 * 0.060 <= d["ms_per_step"] * 5 < 1e3 * 5 * 0.060 * 1.25  # the timed region holds the asynchronous work
+    assert len(d["per_rank_rate"]) == 2
+    for r in d["per_rank_rate"]:
+        assert share * 0.999 <= r <= 1.05 * share, (r, share)
+
+
 def test_bench_under_torchrun_is_a_rank():
     """The documented form: the launcher starts the ranks, bench.py must NOT spawn again."""
     from gmmloc_amd import launch
