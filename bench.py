@@ -254,6 +254,13 @@ def refine_flop(points, trials, outer):
     return points * (FLOP_PER_POINT_TRIAL * outer + FLOP_PER_POINT_RETRIAL * max(trials - outer, 0.0))
 
 
+def refine_flop_active(edge_trials, edge_outer):
+    """the same model on the edges that are really in the graph: `edge_outer` / `edge_trials` = level-0 reprojection edges summed
+    over the outer iterations / over all trials (gl_ctx_set_edge_stats_buffer).  An edge the gating rounds put at level 1
+    (localization_opt.cpp:799-825) is in no later linearisation and costs nothing algorithmically."""
+    return FLOP_PER_POINT_TRIAL * edge_outer + FLOP_PER_POINT_RETRIAL * max(edge_trials - edge_outer, 0.0)
+
+
 def extra_legs(args, ranks, ctx, gmm, cam, prm, mean, cov, pose0, Xw0, obs, octv, pose, Xw, step, start_timers, trials, outer, B, world, local, dev):
     """the legs reported beside the headline (sweep step, two streams, 1000-point class, anchored step): outside the timed region"""
     import torch
@@ -381,6 +388,8 @@ def main():
     trials = torch.zeros(B, dtype=torch.int32, device=dev)
     outer = torch.zeros(B, dtype=torch.int32, device=dev)
     ctx.set_stats_buffer(trials, outer)  # per-frame Levenberg trials and outer iterations of the last step (algorithmic work of k_ba1_fast)
+    edges = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    ctx.set_edge_stats_buffer(edges)     # ... and the level-0 reprojection edges those trials / iterations ran on
 
     def step():
         pose.copy_(pose0)
@@ -398,6 +407,7 @@ def main():
     per_rank_rate = ranks.gather(B * args.steps / ranks.last_own_dt)  # each rank's own clock around its own steps (the headline uses the MAX)
     n_trials = float(trials.sum().item())  # (of the last timed step; the legs below reuse the buffers)
     n_outer = float(outer.sum().item())
+    n_edge_trials, n_edge_outer = [float(v) for v in edges.sum(dim=0).tolist()]
     assoc_ms, assoc_n = ctx.timing_read(api.TIMER_ASSOC)
     ba_ms, ba_n = ctx.timing_read(api.TIMER_BA)
     prep_ms, prep_n = ctx.timing_read(api.TIMER_BA_PREP)
@@ -480,7 +490,8 @@ def main():
         alg_bytes = B * N_PTS * 24 + K_GAUSS * 96 + B * N_PTS * 12
         info = gmm.index_info()
         ba_s = ba_ms / 1e3 / max(ba_n, 1)
-        ba_flop = refine_flop(N_PTS, n_trials, n_outer)
+        ba_flop_all_points = refine_flop(N_PTS, n_trials, n_outer)    # rounds 1-4: every point priced in every trial
+        ba_flop = refine_flop_active(n_edge_trials, n_edge_outer)      # round 5: the level-0 edges only
         ba_flop_every_trial = FLOP_PER_POINT_TRIAL * N_PTS * n_trials  # (what rounds 1-3 reported: every trial priced as a linearisation)
         ba_tflops = ba_flop / ba_s / 1e12 if ba_n else None
         ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8 + 24 + 4) + 2 * 56)  # Xw, obs, octave, assoc, d2 in; points, final assoc out; pose in/out
@@ -523,8 +534,14 @@ def main():
                 "traffic_setup_kernel": measured_traffic("k_ba1_prep", B)[0],  # k_ba1_prep: gate, flags, order, normalised observations
                 "avg_launch_ms": 1e3 * ba_s,
                 "flop_per_launch": ba_flop,
-                "units": "%d frames x %d points x (%.1f outer iterations/frame x %d flop + %.1f further trials/frame x %d flop)"
-                         % (B, N_PTS, n_outer / B, FLOP_PER_POINT_TRIAL, (n_trials - n_outer) / B, FLOP_PER_POINT_RETRIAL),
+                "units": "%d frames x (%.0f level-0 reprojection edges x outer iterations per frame x %d flop + %.0f edges x further trials "
+                         "per frame x %d flop); %d points per frame, %.1f outer iterations + %.1f further trials"
+                         % (B, n_edge_outer / B, FLOP_PER_POINT_TRIAL, (n_edge_trials - n_edge_outer) / B, FLOP_PER_POINT_RETRIAL,
+                            N_PTS, n_outer / B, (n_trials - n_outer) / B),
+                "active_edge_share": n_edge_trials / max(N_PTS * n_trials, 1.0),
+                "frac_all_points_model": (ba_flop_all_points / ba_s / 1e12 / PEAK_FP64_VALU_TFLOPS) if ba_n else None,
+                "frac_all_points_model_what": "rounds 1-4 priced every one of the %d points in every trial; since round 5 `frac` prices the "
+                                              "level-0 reprojection edges only (edges gated out at :799-825 are in no linearisation)" % N_PTS,
                 "trials_per_frame": n_trials / B,
                 "outer_iterations_per_frame": n_outer / B,
                 "frac_pricing_every_trial_as_a_linearisation": (ba_flop_every_trial / ba_s / 1e12 / PEAK_FP64_VALU_TFLOPS) if ba_n else None,

@@ -56,6 +56,7 @@ def load():
         "gl_ctx_timing_read": (i32, [vp, i32, P(C.c_double), P(i64), i32]),
         "gl_ctx_set_stats_buffer": (i32, [vp, vp, i32]),
         "gl_ctx_set_stats_buffers": (i32, [vp, vp, vp, i32]),
+        "gl_ctx_set_edge_stats_buffer": (i32, [vp, vp, i32]),
         "gl_ctx_counter_read": (i32, [vp, i32, P(i64), i32]),
         "gl_gmm_create": (i32, [vp, vp, vp, i32, P(gl_params), P(vp)]),
         "gl_gmm_load_file": (i32, [vp, C.c_char_p, P(gl_params), P(vp)]),

@@ -138,6 +138,14 @@ class Context:
         assert iters is None or iters.numel() >= n
         _check(self.lib.gl_ctx_set_stats_buffers(self.h, _ptr(trials), _ptr(iters), n))
 
+    def set_edge_stats_buffer(self, edges):
+        """Register (or clear with None) an int32 CUDA tensor (n, 2): per frame of the on-chip refine the level-0 reprojection edges
+        summed over its Levenberg trials / over its outer iterations (gl_ctx_set_edge_stats_buffer)."""
+        self._edge_stats = edges
+        n = edges.shape[0] if edges is not None else 0
+        assert edges is None or (edges.dim() == 2 and edges.shape[1] == 2 and edges.is_contiguous())
+        _check(self.lib.gl_ctx_set_edge_stats_buffer(self.h, _ptr(edges), n))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.gl_ctx_destroy(self.h)

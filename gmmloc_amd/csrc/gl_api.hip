@@ -60,6 +60,27 @@ int ctx_scratch(Ctx* c, size_t bytes, void** out) {
   return GL_OK;
 }
 
+// second block, for entry points that are themselves called with their inputs in the first one (the matchers' candidate cache:
+// gl_search_local_points keeps the projection loop's outputs in `scratch` and hands them to gl_search_by_projection)
+int ctx_scratch_b(Ctx* c, size_t bytes, void** out) {
+  if (bytes > c->scratch_b_bytes) {
+    if (c->scratch_b) {
+      GL_HIP(hipStreamSynchronize(c->stream));
+      GL_HIP(hipFree(c->scratch_b));
+      c->scratch_b = nullptr;
+      c->scratch_b_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 2;
+    if (hipMalloc(&c->scratch_b, want) != hipSuccess) {
+      set_error("scratch hipMalloc(%zu) failed", want);
+      return GL_ERR_NOMEM;
+    }
+    c->scratch_b_bytes = want;
+  }
+  *out = c->scratch_b;
+  return GL_OK;
+}
+
 TimerScope::TimerScope(Ctx* ctx, int timer) : c(ctx), id(timer) {
   if (!c->timing) return;
   if (!c->pool.empty()) {
@@ -161,6 +182,7 @@ int gl_ctx_destroy(gl_ctx_t* ctx) {
     (void)hipEventDestroy(p.second);
   }
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->scratch_b) (void)hipFree(c->scratch_b);
   if (c->counters) (void)hipFree(c->counters);
   if (c->host_word) (void)hipHostFree(c->host_word);
   for (int k = 0; k < 3; ++k) {
@@ -246,6 +268,12 @@ int gl_ctx_set_stats_buffers(gl_ctx_t* ctx, int32_t* trials_dev, int32_t* iters_
   return GL_OK;
 }
 int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n) { return gl_ctx_set_stats_buffers(ctx, trials_dev, nullptr, n); }
+int gl_ctx_set_edge_stats_buffer(gl_ctx_t* ctx, int32_t* edges_dev, int n) {
+  GL_REQUIRE(ctx, "null context");
+  gl::C(ctx)->stats_edges = n > 0 ? edges_dev : nullptr;
+  gl::C(ctx)->stats_edges_n = edges_dev ? n : 0;
+  return GL_OK;
+}
 
 int gl_malloc(gl_ctx_t* ctx, size_t bytes, void** dev_out) {
   GL_REQUIRE(ctx && dev_out, "null argument");

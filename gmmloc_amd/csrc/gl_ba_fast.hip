@@ -416,7 +416,7 @@ static void canon_order(int L, int* G, int* S) {
 }
 
 typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*, int*, long long, int, const int32_t*, const uint8_t*, const double*, double*, int, int32_t*, int32_t*, FixedV);
+                          unsigned long long*, int*, long long, int, const int32_t*, const uint8_t*, const double*, double*, int, int32_t*, int32_t*, FixedV, int32_t*);
 
 struct BafArgs {
   BaK k;
@@ -432,6 +432,7 @@ struct BafArgs {
   double* pn;
   int32_t* stats;
   int32_t* stats_iters = nullptr;
+  int32_t* stats_edges = nullptr;
   int NB;
   unsigned long long* parts;
   int* ctl = nullptr;  // per frame {abort, done} of a latency-shape launch (the follow-up DENSE launch skips the done ones)
@@ -460,7 +461,7 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   a.NB = 1;
   a.parts = nullptr;
   kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior, a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx);
+                                          a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior, a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx, a.stats_edges);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -499,7 +500,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
   kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx);
+                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx, a.stats_edges);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }
@@ -540,6 +541,7 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
   a.pn = (double*)scratch;
   a.stats = (c->stats && c->stats_n >= B) ? c->stats : nullptr;
   a.stats_iters = a.stats ? c->stats_iters : nullptr;
+  a.stats_edges = (c->stats_edges && c->stats_edges_n >= B) ? c->stats_edges : nullptr;
   a.counters = c->counters;
   bool spread = (long)B * a.G <= 2 * c->ncu;  // two workgroups of 256 threads fit a CU (LDS 2 x 80 KB, 2 waves per SIMD; checked in launch_spread)
   if (c->opt.ba_shape == 0) spread = false;

@@ -1548,6 +1548,13 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     }
   }
   reduce2<2>(acc, R, C);
+  // gl_ctx_set_edge_stats_buffer: the level-0 reprojection edges of this optimize() call (the levels only change between the calls)
+  // and the trial count on entry wait in LDS for the end of the call - nothing of the statistic is live across the trial loops
+  int* const est = (int*)(R.tot + 62);  // {edges x trials, edges x outer iterations, edges of this call, trials on entry}
+  if (threadIdx.x == 0) {
+    est[2] = (int)acc[0];
+    est[3] = trials;
+  }
   const bool pose_active = kPrior ? !An.pose_fixed && (acc[0] > 0.0 || An.has_prior) : acc[0] > 0.0;
   const bool prior_on = kPrior && An.has_prior && pose_active;
   if (!pose_active && !(acc[1] > 0.0)) return -1;
@@ -1694,6 +1701,10 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     ++cj;
     if (qmax == 10 || rho == 0) break;
   }
+  if (threadIdx.x == 0) {
+    est[0] += est[2] * (trials - est[3]);
+    est[1] += est[2] * cj;
+  }
   return cj;
 }
 
@@ -1708,7 +1719,8 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
                                                   int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted,
                                                   const int32_t* __restrict__ oct_all,
                                                   const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi, double* __restrict__ stage, int nb_prev,
-                                                  int32_t* __restrict__ counters, int32_t* __restrict__ outer_out, FixedV fxv) {
+                                                  int32_t* __restrict__ counters, int32_t* __restrict__ outer_out, FixedV fxv,
+                                                  int32_t* __restrict__ edges_out) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Lds D;
   D.sp = smem;                      // 3 * MCAP
@@ -1813,6 +1825,7 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   if (tid == 0) {
     *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
     *(int*)(R.tot + 61) = 0;  // a poll of the exchange gave up (SPREAD)
+    R.tot[62] = 0.0;          // edge statistics {edges x trials, edges x outer iterations} as two ints (optimize_fast)
   }
   {
     const int ns = kSpread ? 1 : mp.S;
@@ -1975,6 +1988,11 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
     if (outer_out) outer_out[f] = outer;
+    if (edges_out) {  // gl_ctx_set_edge_stats_buffer: level-0 reprojection edges x trials, x outer iterations
+      const int* est = (const int*)(R.tot + 62);
+      edges_out[2 * f] = est[0];
+      edges_out[2 * f + 1] = est[1];
+    }
 #ifdef GL_BA_TRACE
     if (f == 0)
       for (int i = 0; i < 10 * 128 && i < L * 3; ++i) pts_io[i] = g_trace[i];

@@ -123,6 +123,8 @@ struct Ctx {
   // scratch (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  void* scratch_b = nullptr;  // second block (ctx_scratch_b): the matchers' candidate cache
+  size_t scratch_b_bytes = 0;
   // staging of the frame-at-a-time host entry point (gl_track_frame_host): page-locked + device mirror, grown on demand
   void* host_stage = nullptr;
   void* dev_stage = nullptr;
@@ -137,6 +139,8 @@ struct Ctx {
   int32_t* stats = nullptr;
   int32_t* stats_iters = nullptr;  // (gl_ctx_set_stats_buffers) outer Levenberg iterations per frame
   int stats_n = 0;
+  int32_t* stats_edges = nullptr;  // (gl_ctx_set_edge_stats_buffer) n x 2: level-0 reprojection edges x trials / x outer iterations
+  int stats_edges_n = 0;
   // timing
   bool timing = false;
   double timer_ms[GL_TIMER_COUNT] = {0};
@@ -146,6 +150,7 @@ struct Ctx {
 };
 
 int ctx_scratch(Ctx* c, size_t bytes, void** out);
+int ctx_scratch_b(Ctx* c, size_t bytes, void** out);
 bool probe_xcc_ids(Ctx* c);  // gl_ba_fast.hip
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE and costs a driver call: a context (one device,
 // one host thread) remembers the limit it has set for each kernel and raises it only when it grows.  The caller

@@ -13,6 +13,17 @@
 // is rebuilt with LDS atomics; by induction the choices of map points 0..r-1 are final after round
 // r, and the iteration stops when the owner table repeats (2-5 rounds on realistic frames).
 //
+// Round 5: a round no longer repeats the window walk.  What a query can ever choose from is fixed by the filters that do not
+// depend on the owners (level, window, u_right, taken on entry); the owners only REMOVE candidates.  So round 1 walks the window
+// once - the CSR entries of all covered columns as ONE flattened loop, the surviving candidates collected four at a time and their
+// descriptors requested together - and leaves each query's three best candidates as sorted keys
+//     dist << 24 | position among its candidates << 16 | octave << 12 | feature
+// (64-bit keys with wider fields while walking; a query whose candidates do not fit the packed form just walks again)
+// (the reference's best / second-best bookkeeping is "first of the smallest distance, then first of the smallest of the rest" in
+// visiting order = the two smallest keys) plus the number of candidates in a 16-byte record; every later round reads the record,
+// drops the keys whose feature a lower query owns, and decides - exactly - whenever two keys survive or the record held all the
+// candidates; only a query that lost two of its three best AND had more walks again.
+//
 // One workgroup per frame (512 threads in batches; 1 024 and the descriptors in LDS as well when there are no more
 // frames than CUs); grid CSR, owner tables and choices live in LDS.  Every float / double
 // conversion of the reference (float window, float grid scale, double feature coordinates) is kept
@@ -36,6 +47,9 @@ struct MatchP {
   float mbf, mb;
   int width, height, mono, check_orientation;
 };
+
+// 32-bit words of the kernel's LDS in front of the per-entry records: cell_ptr, cursor, cell_idx, owner, owner_n, choice, qorder (u16)
+__host__ __device__ inline int lds_ints(int NF, int NP) { return (2 * NCELL + 1 + 3 * NF + NP + (NP + 1) / 2 + 3) & ~3; }
 
 // what one query point (a projected map point) asks of the feature grid
 struct Query {
@@ -81,7 +95,8 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     const uint8_t* __restrict__ mp_valid_all, const uint8_t* __restrict__ mp_desc_all,
     int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all,
     const double* __restrict__ pose_cw_all, const double* __restrict__ pose_lw_all,
-    const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all, int32_t* __restrict__ counters) {
+    const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all, int32_t* __restrict__ counters,
+    uint4* __restrict__ cache_all) {
   constexpr int TM = DL ? 1024 : T_M;  // threads per frame: the latency shape doubles them
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* cell_ptr = lds;                   // NCELL + 1
@@ -91,12 +106,14 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
   int32_t* owner_n = owner + P.NF;           // NF   being rebuilt
   int32_t* choice = owner_n + P.NF;          // NP
   // per CSR entry, so that the window walk touches LDS only: {u, v} double, {u_right bits, octave}
-  double2* rec_uv = (double2*)(lds + ((2 * NCELL + 1 + 3 * P.NF + P.NP + 3) & ~3));  // 16-byte aligned
+  uint16_t* qorder = (uint16_t*)(choice + P.NP);  // NP: the queries sorted by window class (round 5: equal work per lane)
+  double2* rec_uv = (double2*)(lds + lds_ints(P.NF, P.NP));  // 16-byte aligned
   int2* rec_ro = (int2*)(rec_uv + P.NF);
   // DL (few frames: one workgroup per CU anyway): the 256-bit descriptors too, in CSR order - a candidate that
   // survives the window test otherwise costs a dependent global load of 32 bytes
   uint4* rec_desc = (uint4*)(rec_ro + ((P.NF + 1) & ~1));  // 2 x uint4 per entry, 16-byte aligned
-  __shared__ int s_changed, s_scan[TM], s_hist[32], s_keep[4];
+  __shared__ int s_changed, s_scan[32], s_hist[32], s_keep[4];
+  __shared__ int s_fast, s_cls[17];
   __shared__ double s_pose[8];
   __shared__ int s_dir;
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -119,6 +136,8 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
 
   // ---- assignFeaturesToGrid: CSR by cell (ix * GR + iy), ascending feature index inside a cell ----
   for (int c = tid; c <= NCELL; c += TM) cell_ptr[c] = 0;
+  if (tid == 0) s_fast = 1;
+  if (tid < 17) s_cls[tid] = 0;
   __syncthreads();
   auto cell_of = [&](int i) -> int {
     if (feat_oct[i] < 0) return -1;  // padding slot
@@ -126,9 +145,20 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     if (!(px >= 0 && px < GC && py >= 0 && py < GR)) return -1;  // also rejects NaN
     return (int)px * GR + (int)py;
   };
-  for (int i = tid; i < NF; i += TM) {
-    const int c = cell_of(i);
-    if (c >= 0) atomicAdd(&cell_ptr[c + 1], 1);
+  {
+    // the fast walk (32-bit window test, one 16-byte record per entry) is exact iff every feature coordinate is a float value - the
+    // reference's (float)(double u - (double)x) is then the correctly rounded float difference, which is what u - x in float is
+    // (a double has more than 2 x 24 + 2 bits) - and the octaves fit the level mask
+    bool fok = true;
+    for (int i = tid; i < NF; i += TM) {
+      const int c = cell_of(i);
+      if (c >= 0) {
+        atomicAdd(&cell_ptr[c + 1], 1);
+        const double u = feat_uv[2 * i], v = feat_uv[2 * i + 1];
+        fok = fok && (double)(float)u == u && (double)(float)v == v && feat_oct[i] <= 15;
+      }
+    }
+    if (!fok) s_fast = 0;
   }
   __syncthreads();
   {  // exclusive scan of NCELL counts: each thread scans a contiguous chunk, then the chunk sums
@@ -179,8 +209,9 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
   __syncthreads();
   for (int e = tid; e < cell_ptr[NCELL]; e += TM) {
     const int i = cell_idx[e];
-    rec_uv[e] = make_double2(feat_uv[2 * i], feat_uv[2 * i + 1]);
-    rec_ro[e] = make_int2(__float_as_int(feat_ur[i]), feat_oct[i]);
+    if (s_fast) ((float4*)rec_uv)[e] = make_float4((float)feat_uv[2 * i], (float)feat_uv[2 * i + 1], feat_ur[i], __int_as_float((feat_oct[i] & 0xff) | (i << 8)));
+    else rec_uv[e] = make_double2(feat_uv[2 * i], feat_uv[2 * i + 1]);
+    rec_ro[e] = make_int2(__float_as_int(feat_ur[i]), (feat_oct[i] & 0xff) | (i << 8));  // {u_right, octave | feature << 8}
     if (DL) {
       const uint4* src = (const uint4*)(feat_desc + (size_t)i * 8);
       rec_desc[2 * e] = src[0];
@@ -266,66 +297,267 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
 #ifdef GL_MATCH_PROF
   const long long tp1 = clock64();
 #endif
+  // queries by window class (half size of the window = a factor x the scale of the level: 16 classes), so that the lanes of a wave
+  // walk windows of like size: counting sort, stable within a class up to the order of the atomics (the order only decides
+  // which thread takes which query - never a result)
+  {
+    auto cls_of = [&](int m) -> int {
+      if (!mp_valid[m]) return 16;
+      const int lvl = mp_level[m] & 7;
+      return MODE == 0 ? (lvl | (((float)mp_viewcos[m] > 0.998) ? 0 : 8)) : lvl;
+    };
+    for (int m = tid; m < NP; m += TM) atomicAdd(&s_cls[cls_of(m)], 1);
+    __syncthreads();
+    if (tid == 0) {  // exclusive scan, the LARGEST windows first (they set the pace of a wave), the invalid ones last
+      const int ord[17] = {15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 16};
+      int run = 0;
+      for (int k = 0; k < 17; ++k) {
+        const int n = s_cls[ord[k]];
+        s_cls[ord[k]] = run;
+        run += n;
+      }
+    }
+    __syncthreads();
+    for (int m = tid; m < NP; m += TM) qorder[atomicAdd(&s_cls[cls_of(m)], 1)] = (uint16_t)m;
+    __syncthreads();
+  }
+  constexpr uint32_t EMPTY = 0xffffffffu;
+  uint16_t* lst = (uint16_t*)cursor;  // 4 x TM entry indices: a thread's collected candidates (the cursors are dead after the grid build)
+  uint4* cache = cache_all + (size_t)f * NP;
+
+  // the window walk of query m (all lanes of a wave walk together: the loop and the flushes are wave-uniform): the three smallest
+  // keys among its candidates NOT owned by a lower query (k0 <= k1 <= k2), their number, and `bad` when a key cannot hold them
+  // key while walking: dist << 48 | position << 20 | octave << 12 | feature
+  constexpr unsigned long long EMPTY64 = ~0ull;
+  auto walk = [&](bool act, int m, const Query& q, unsigned long long& k0, unsigned long long& k1, unsigned long long& k2, uint32_t& npass, bool& bad) {
+    k0 = k1 = k2 = EMPTY64;
+    npass = 0;
+    bad = false;
+    uint32_t seq = 0;
+    const float rr = q.rr, x = q.x, y = q.y;
+    int x0 = 1, x1 = 0, y0 = 0, y1 = 0;
+    if (act) {
+      x0 = max(0, (int)floorf((x - 0.0f - rr) * P.col_inv));
+      x1 = min(GC - 1, (int)ceilf((x - 0.0f + rr) * P.col_inv));
+      y0 = max(0, (int)floorf((y - 0.0f - rr) * P.row_inv));
+      y1 = min(GR - 1, (int)ceilf((y - 0.0f + rr) * P.row_inv));
+      if (!(x0 < GC && x1 >= 0 && y0 < GR && y1 >= 0) || y0 > y1) x1 = x0 - 1;  // nothing to visit
+    }
+    const int minLevel = q.minLevel, maxLevel = q.maxLevel;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    uint32_t dm[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dm[w] = act ? mp_desc[(size_t)m * 8 + w] : 0u;
+    int cnt = 0;
+    auto flush = [&]() {  // Hamming distances of the <= 4 collected candidates, their descriptors requested together
+      uint4 da[4], db[4];
+      int roy[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        roy[j] = 0;
+        da[j] = db[j] = make_uint4(0, 0, 0, 0);
+        if (j < cnt) {
+          const int ej = lst[j * TM + tid];
+          roy[j] = rec_ro[ej].y;
+          if (DL) {
+            da[j] = rec_desc[2 * ej];
+            db[j] = rec_desc[2 * ej + 1];
+          } else {
+            const uint4* src = (const uint4*)(feat_desc + (size_t)(roy[j] >> 8) * 8);
+            da[j] = src[0];
+            db[j] = src[1];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < cnt) {
+          const int dist = __popc(dm[0] ^ da[j].x) + __popc(dm[1] ^ da[j].y) + __popc(dm[2] ^ da[j].z) + __popc(dm[3] ^ da[j].w) +
+                           __popc(dm[4] ^ db[j].x) + __popc(dm[5] ^ db[j].y) + __popc(dm[6] ^ db[j].z) + __popc(dm[7] ^ db[j].w);
+          const int oc = roy[j] & 0xff, idx = roy[j] >> 8;
+          if (seq > 255u || oc > 15) bad = true;  // does not fit the packed record: this query walks in every round
+          if (dist < 256) {  // (a distance of 256 never beats the initial best / second best of the reference's loop)
+            const unsigned long long kx = ((unsigned long long)dist << 48) | ((unsigned long long)seq << 20) | ((unsigned long long)oc << 12) | (unsigned long long)idx;
+            ++npass;
+            if (kx < k2) {
+              k2 = kx;
+              if (k2 < k1) {
+                const unsigned long long t = k1;
+                k1 = k2;
+                k2 = t;
+              }
+              if (k1 < k0) {
+                const unsigned long long t = k0;
+                k0 = k1;
+                k1 = t;
+              }
+            }
+          }
+          ++seq;
+        }
+      }
+      cnt = 0;
+    };
+    int ix = x0 - 1, e = 0, e1 = 0;
+    bool more = act && x0 <= x1;
+    if (s_fast) {
+      // level filter as a bit mask over the octaves 0..15 (getFeaturesInArea: minLevel / maxLevel, frame.cpp:121-177)
+      uint32_t lm = 0xffffu;
+      if (bCheckLevels) {
+        lm = 0;
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (!(o < minLevel) && !(maxLevel >= 0 && o > maxLevel)) lm |= 1u << o;
+      }
+      const float4* rec16 = (const float4*)rec_uv;
+      while (__any(more)) {
+        if (more && e >= e1) {  // next column: cells (ix, y0..y1) are contiguous in the CSR
+          ++ix;
+          if (ix > x1) {
+            more = false;
+          } else {
+            e = cell_ptr[ix * GR + y0];
+            e1 = cell_ptr[ix * GR + y1 + 1];
+          }
+        }
+        if (more && e < e1) {
+          const float4 r = rec16[e];
+          const int pk = __float_as_int(r.w);
+          bool ok = ((lm >> (pk & 0xff)) & 1u) != 0 && fabsf(r.x - x) < rr && fabsf(r.y - y) < rr;
+          if (ok) ok = owner[pk >> 8] >= m;  // not taken on entry (-1), not owned by an earlier map point
+          if (ok && r.z > 0) {
+            const float er = q.ur_float ? fabsf(q.ur_f - r.z) : (float)fabs(q.ur_d - (double)r.z);
+            if (er > rr) ok = false;
+          }
+          if (ok) {
+            lst[cnt * TM + tid] = (uint16_t)e;
+            ++cnt;
+          }
+          ++e;
+        }
+        if (__any(cnt == 4)) flush();
+      }
+    } else {
+      while (__any(more)) {
+        bool have = false;
+        int ecur = 0;
+        if (more) {
+          if (e >= e1) {  // next column: cells (ix, y0..y1) are contiguous in the CSR
+            ++ix;
+            if (ix > x1) {
+              more = false;
+            } else {
+              e = cell_ptr[ix * GR + y0];
+              e1 = cell_ptr[ix * GR + y1 + 1];
+            }
+          }
+          if (more && e < e1) {
+            ecur = e++;
+            have = true;
+          }
+        }
+        if (have) {
+          const int2 ro = rec_ro[ecur];
+          const double2 fuv = rec_uv[ecur];
+          const int oc = ro.y & 0xff;
+          bool ok = true;
+          if (bCheckLevels) {
+            if (oc < minLevel) ok = false;
+            if (maxLevel >= 0 && oc > maxLevel) ok = false;
+          }
+          const float distx = (float)(fuv.x - (double)x), disty = (float)(fuv.y - (double)y);
+          if (!(fabsf(distx) < rr && fabsf(disty) < rr)) ok = false;
+          if (ok && owner[ro.y >> 8] < m) ok = false;  // taken on entry (-1) or by an earlier map point
+          if (ok) {
+            const float ur = __int_as_float(ro.x);
+            if (ur > 0) {
+              const float er = q.ur_float ? fabsf(q.ur_f - ur) : (float)fabs(q.ur_d - (double)ur);
+              if (er > rr) ok = false;
+            }
+          }
+          if (ok) {
+            lst[cnt * TM + tid] = (uint16_t)ecur;
+            ++cnt;
+          }
+        }
+        if (__any(cnt == 4)) flush();
+      }
+    }
+    if (__any(cnt > 0)) flush();
+  };
+  // the reference's verdict on (best, second best) = the two smallest keys
+  auto pack = [&](unsigned long long k) -> uint32_t {
+    return k == EMPTY64 ? EMPTY : (uint32_t)((k >> 48) << 24) | (uint32_t)(((k >> 20) & 255u) << 16) | (uint32_t)(k & 0xffffu);
+  };
+  auto unpack = [&](uint32_t k) -> unsigned long long {
+    return k == EMPTY ? EMPTY64 : ((unsigned long long)(k >> 24) << 48) | ((unsigned long long)((k >> 16) & 255u) << 20) | (unsigned long long)(k & 0xffffu);
+  };
+  auto decide = [&](unsigned long long a, unsigned long long b, bool ratio_test) -> int {
+    if (a == EMPTY64) return -1;
+    const int bestDist = (int)(a >> 48), bestLevel = (int)((a >> 12) & 255u), bestIdx = (int)(a & 0xfffu);
+    const int bestDist2 = b == EMPTY64 ? 256 : (int)(b >> 48), bestLevel2 = b == EMPTY64 ? -1 : (int)((b >> 12) & 255u);
+    if (!(bestDist <= 100)) return -1;  // TH_HIGH
+    if (ratio_test && bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2) return -1;
+    return bestIdx;
+  };
+
   int rounds = 0;
+#ifdef GL_MATCH_PROF
+  int rewalks = 0;
+#endif
+  const int nq_rounds = ((NP + TM - 1) / TM) * TM;  // every thread makes the same number of trips (the walk is wave-uniform)
   while (true) {
     for (int i = tid; i < NF; i += TM) owner_n[i] = feat_taken[i] ? -1 : INT_MAX;
     if (tid == 0) s_changed = 0;
     __syncthreads();
-    for (int m = tid; m < NP; m += TM) {
+    for (int sq = tid; sq < nq_rounds; sq += TM) {
+      const bool in = sq < NP;
+      const int m = in ? (int)qorder[sq] : NP;  // (the same thread has the query in every round: it reads its own record)
       int bestIdx = -1;
-      const Query q = make_query(m);
-      if (q.valid) {
-        const float rr = q.rr, x = q.x, y = q.y;
-        const int x0 = max(0, (int)floorf((x - 0.0f - rr) * P.col_inv));
-        const int x1 = min(GC - 1, (int)ceilf((x - 0.0f + rr) * P.col_inv));
-        const int y0 = max(0, (int)floorf((y - 0.0f - rr) * P.row_inv));
-        const int y1 = min(GR - 1, (int)ceilf((y - 0.0f + rr) * P.row_inv));
-        if (x0 < GC && x1 >= 0 && y0 < GR && y1 >= 0) {
-          const int minLevel = q.minLevel, maxLevel = q.maxLevel;
-          const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-          uint32_t dm[8];
+      bool need_walk = in && rounds == 0;
+      uint4 rec = make_uint4(EMPTY, EMPTY, EMPTY, 0);
+      if (in && rounds > 0) {  // the record of round 1 minus what lower queries own now
+        rec = cache[m];
+        uint32_t a = EMPTY, b = EMPTY;
+        int nav = 0;
+        const uint32_t ks[3] = {rec.x, rec.y, rec.z};
 #pragma unroll
-          for (int w = 0; w < 8; ++w) dm[w] = mp_desc[(size_t)m * 8 + w];
-          int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
-          for (int ix = x0; ix <= x1; ++ix) {
-            // cells (ix, y0..y1) are contiguous in the CSR
-            const int e0 = cell_ptr[ix * GR + y0], e1 = cell_ptr[ix * GR + y1 + 1];
-            for (int e = e0; e < e1; ++e) {
-              const int2 ro = rec_ro[e];
-              const int oc = ro.y;
-              if (bCheckLevels) {
-                if (oc < minLevel) continue;
-                if (maxLevel >= 0 && oc > maxLevel) continue;
-              }
-              const double2 fuv = rec_uv[e];
-              const float distx = (float)(fuv.x - (double)x), disty = (float)(fuv.y - (double)y);
-              if (!(fabsf(distx) < rr && fabsf(disty) < rr)) continue;
-              const int idx = cell_idx[e];
-              if (owner[idx] < m) continue;  // taken on entry (-1) or by an earlier map point
-              const float ur = __int_as_float(ro.x);
-              if (ur > 0) {
-                const float er = q.ur_float ? fabsf(q.ur_f - ur) : (float)fabs(q.ur_d - (double)ur);
-                if (er > rr) continue;
-              }
-              const int dist = DL ? hamming256(dm, (const uint32_t*)(rec_desc + 2 * e)) : hamming256(dm, feat_desc + (size_t)idx * 8);
-              if (dist < bestDist) {
-                bestDist2 = bestDist;
-                bestDist = dist;
-                bestLevel2 = bestLevel;
-                bestLevel = oc;
-                bestIdx = idx;
-              } else if (dist < bestDist2) {
-                bestLevel2 = oc;
-                bestDist2 = dist;
-              }
-            }
+        for (int j = 0; j < 3; ++j) {
+          if (ks[j] != EMPTY && owner[ks[j] & 0xfffu] >= m) {
+            if (nav == 0) a = ks[j];
+            else if (nav == 1) b = ks[j];
+            ++nav;
           }
-          if (!(bestDist <= 100)) bestIdx = -1;  // TH_HIGH
-          else if (q.ratio_test && bestLevel == bestLevel2 && (float)bestDist > P.nn_ratio * (float)bestDist2) bestIdx = -1;
+        }
+        if (rec.w != EMPTY && (nav >= 2 || rec.w <= 3u)) bestIdx = decide(unpack(a), unpack(b), MODE == 0);
+        else need_walk = true;
+      }
+      if (__any(need_walk)) {
+        Query q;
+        q.valid = false;
+        q.x = q.y = q.rr = 0.f;
+        q.minLevel = q.maxLevel = -1;
+        q.ratio_test = MODE == 0;
+        q.ur_float = MODE == 1;
+        q.ur_d = 0.0;
+        q.ur_f = 0.f;
+        if (need_walk) q = make_query(m);
+        unsigned long long k0, k1, k2;
+        uint32_t npass;
+        bool bad;
+        walk(need_walk && q.valid, m, q, k0, k1, k2, npass, bad);
+        if (need_walk) {
+          bestIdx = decide(k0, k1, MODE == 0);
+          if (rounds == 0) cache[m] = make_uint4(pack(k0), pack(k1), pack(k2), bad ? EMPTY : npass);
+#ifdef GL_MATCH_PROF
+          else ++rewalks;
+#endif
         }
       }
-      choice[m] = bestIdx;
-      if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
+      if (in) {
+        choice[m] = bestIdx;
+        if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
+      }
     }
     __syncthreads();
     int ch = 0;
@@ -471,7 +703,7 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
   P.height = cam->height;
   P.mono = mono;
   P.check_orientation = check_orientation;
-  size_t lds = (((size_t)2 * NCELL + 1 + 3 * (size_t)NF + NP + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 24;
+  size_t lds = (size_t)lds_ints(NF, NP) * sizeof(int32_t) + (size_t)NF * 24;
   // latency shape (no more frames than CUs): descriptors in LDS as well, if they fit
   const size_t lds_dl = lds + 8 + (size_t)NF * 32;
   bool dl = B <= c->ncu && lds_dl <= 160 * 1024 - 8 * 1024;
@@ -480,8 +712,13 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
   auto kern = mode == 0 ? (dl ? k_search_by_projection<0, true> : k_search_by_projection<0, false>)
                         : (dl ? k_search_by_projection<1, true> : k_search_by_projection<1, false>);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)kern, lds));
+  void* cache = nullptr;  // 16 bytes per query: its three best candidates of round 1 (the kernel's header)
+  {
+    const int rc = gl::ctx_scratch_b(c, (size_t)B * NP * sizeof(uint4), &cache);
+    if (rc != GL_OK) return rc;
+  }
   kern<<<B, dl ? 1024 : T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
-                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle, c->counters);
+                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle, c->counters, (uint4*)cache);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -146,7 +146,14 @@ def look_at_pose(eye, target, up=(0.0, 0.0, 1.0)):
     return np.concatenate([R_to_quat(Rcw), -Rcw @ np.asarray(eye, float)])
 
 
-def synth_match_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2, dup_frac=0.25):
+def _key_point_uv(uv, float_uv):
+    """The reference's Feature::uv is a Vector2d built from a cv::KeyPoint's FLOAT coordinates (types/feature.h:11): realistic
+    inputs are float values held in doubles (float_uv, the default; what the matchers' 32-bit window walk is exact for); arbitrary
+    doubles (float_uv = False) take the matchers' general path."""
+    return uv.astype(np.float32).astype(np.float64) if float_uv else uv
+
+
+def synth_match_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2, dup_frac=0.25, float_uv=True):
     """Inputs of ORBmatcher::searchByProjection for one frame: NF ORB-like features (uv, u_right, octave,
     256-bit descriptor, taken flag) and NP projected map points (uvr, predicted level, viewing cosine, valid,
     descriptor).  70 % of the map points are generated from a feature (projection within the search window,
@@ -181,11 +188,12 @@ def synth_match_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2, dup
             np.bitwise_xor.at(mp_desc[m], bits // 8, (1 << (bits % 8)).astype(np.uint8))
         else:
             mp_desc[m] = rng.integers(0, 256, 32, dtype=np.uint8)
+    uv = _key_point_uv(uv, float_uv)
     return dict(width=width, height=height, feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_desc=desc, feat_taken=taken,
                 mp_uvr=mp_uvr, mp_level=level, mp_viewcos=viewcos, mp_valid=valid, mp_desc=mp_desc)
 
 
-def synth_motion_frames(NF, NL, seed, cam, motion="none", rot_deg=8.0):
+def synth_motion_frames(NF, NL, seed, cam, motion="none", rot_deg=8.0, float_uv=True):
     """Inputs of ORBmatcher::searchByProjection(CurrentFrame, LastFrame, th, bMono): a last frame with NL
     features carrying map points and a current frame with NF features that re-observes ~70 % of them
     (pixel noise, descriptor bit flips, in-plane rotation `rot_deg` so that the orientation histogram has a
@@ -229,6 +237,7 @@ def synth_motion_frames(NF, NL, seed, cam, motion="none", rot_deg=8.0):
         else:
             desc[i] = rng.integers(0, 256, 32, dtype=np.uint8)
     taken = (rng.uniform(size=NF) < 0.05).astype(np.uint8)
+    uv = _key_point_uv(uv, float_uv)
     return dict(pose_cw=pose_cw, pose_lw=pose_lw, feat_uv=uv, feat_ur=ur, feat_oct=octv,
                 feat_angle=angle.astype(np.float32), feat_desc=desc, feat_taken=taken, last_pt=last_pt,
                 last_valid=last_valid, last_oct=last_oct, last_angle=last_angle, last_desc=last_desc)
@@ -454,7 +463,7 @@ def synth_project_frame(NP, seed, cam, scale_factor=1.2):
     return dict(pose_cw=pose, t_wc=t_wc, pos=pos, normal=normal, max_dist=max_dist, min_dist=min_dist, cand=cand)
 
 
-def synth_local_points_frame(NF, NP, seed, cam, scale_factor=1.2):
+def synth_local_points_frame(NF, NP, seed, cam, scale_factor=1.2, float_uv=True):
     """One frame of Tracking::searchLocalPoints: the map points of synth_project_frame and NF ORB-like features, 70 % of them at the
     (approximately) projected position of a map point in front of the camera - a few pixels off, at the octave of the point's
     predicted level or one below, descriptor = the point's with 0 .. 70 flipped bits - so that the chain project -> searchByProjection
@@ -486,5 +495,5 @@ def synth_local_points_frame(NF, NP, seed, cam, scale_factor=1.2):
             feat_desc[i] = d
     feat_ur = np.where(rng.uniform(size=NF) < 0.7, feat_uv[:, 0] - rng.uniform(2, 60, NF), -1.0).astype(np.float32)
     feat_taken = (rng.uniform(size=NF) < 0.05).astype(np.uint8)
-    f.update(feat_uv=feat_uv, feat_ur=feat_ur, feat_oct=feat_oct, feat_desc=feat_desc, feat_taken=feat_taken, mp_desc=mp_desc)
+    f.update(feat_uv=_key_point_uv(feat_uv, float_uv), feat_ur=feat_ur, feat_oct=feat_oct, feat_desc=feat_desc, feat_taken=feat_taken, mp_desc=mp_desc)
     return f

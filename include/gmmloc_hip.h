@@ -147,6 +147,11 @@ int gl_ctx_set_stats_buffer(gl_ctx_t* ctx, int32_t* trials_dev, int n);
  * (g2o's optimize() iterations: one linearisation each; a trial beyond the first of an iteration re-solves the same
  * linearisation with a larger lambda) into iters_dev (n int32, may be NULL): the two counts bracket the algorithmic work. */
 int gl_ctx_set_stats_buffers(gl_ctx_t* ctx, int32_t* trials_dev, int32_t* iters_dev, int n);
+/* ... and the ACTIVE part of that work (gl_track_frames / gl_track_frames_anchored on the on-chip refine, M <= 2000): per frame
+ * b < n two int32 {sum over its Levenberg trials, sum over its outer iterations} of the number of level-0 reprojection edges the
+ * trial / iteration ran on.  The reference puts gated-out edges at level 1 (localization_opt.cpp:799-825): they are in no
+ * linearisation after that, so a flop model prices these sums, not points x trials.  edges_dev: n x 2 int32; NULL / 0 unregisters. */
+int gl_ctx_set_edge_stats_buffer(gl_ctx_t* ctx, int32_t* edges_dev, int n);
 
 /* ---- GMM map: replaces GMMUtility::loadGMMModel (gmm_utils.cpp:9-67),
  *      GaussianComponent ctor + decompose (gaussian.h:30-39, gaussian.cpp:36-63)

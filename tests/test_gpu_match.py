@@ -27,10 +27,11 @@ def run_gpu(torch, ctx, frames, th, nn_ratio=0.8):
 @pytest.mark.parametrize("NF,NP,th,dup", [(300, 200, 3.0, 0.25), (1200, 800, 3.0, 0.25), (2000, 2500, 5.0, 0.5),
                                           (64, 4000, 3.0, 0.9), (1000, 1000, 1.0, 0.3), (1, 1, 3.0, 0.0)])
 @pytest.mark.parametrize("shape", ["0", "1"])  # batch shape (512 threads) / few-frames shape (1 024, descriptors in LDS)
-def test_search_by_projection_matches_oracle(gpu, oracle, opt, NF, NP, th, dup, shape):
+@pytest.mark.parametrize("fuv", [True, False])  # key-point coordinates that are float values (the reference's: the 32-bit window walk) / arbitrary doubles (general walk)
+def test_search_by_projection_matches_oracle(gpu, oracle, opt, NF, NP, th, dup, shape, fuv):
     torch, ctx = gpu
     opt("match_desc_lds", int(shape))
-    frames = [synth.synth_match_frame(NF, NP, 1000 * NF + 7 * b, dup_frac=dup) for b in range(5)]
+    frames = [synth.synth_match_frame(NF, NP, 1000 * NF + 7 * b, dup_frac=dup, float_uv=fuv) for b in range(5)]
     m, n = run_gpu(torch, ctx, frames, th)
     tot = 0
     for b, f in enumerate(frames):
@@ -41,9 +42,11 @@ def test_search_by_projection_matches_oracle(gpu, oracle, opt, NF, NP, th, dup, 
     assert tot > 0 or NF == 1
 
 
-def test_search_by_projection_conflict_chain(gpu, oracle):
+@pytest.mark.parametrize("fuv", [True, False])
+def test_search_by_projection_conflict_chain(gpu, oracle, fuv):
     """Worst case for the fixed-point iteration: every map point wants the same features, so each one
-    only settles after all earlier ones have (as many rounds as map points)."""
+    only settles after all earlier ones have (as many rounds as map points).  Round 5: every map point has all 40 features as
+    candidates and keeps only its three best of round 1 - from round 3 on the later ones have lost those and walk again."""
     torch, ctx = gpu
     rng = np.random.default_rng(3)
     NF, NP = 40, 60
@@ -57,6 +60,8 @@ def test_search_by_projection_conflict_chain(gpu, oracle):
              feat_taken=np.zeros(NF, np.uint8), mp_uvr=np.tile([[300.0, 200.0, 250.0]], (NP, 1)),
              mp_level=np.zeros(NP), mp_viewcos=np.full(NP, 0.5), mp_valid=np.ones(NP, np.uint8),
              mp_desc=np.tile(desc0, (NP, 1)))
+    if fuv:
+        f["feat_uv"] = f["feat_uv"].astype(np.float32).astype(np.float64)
     m, n = run_gpu(torch, ctx, [f], 3.0, nn_ratio=1.1)  # ratio test off: pure hand-over
     m_ref, n_ref = oracle.search_by_projection(th=3.0, nn_ratio=1.1, **f)
     assert n_ref == NF and n[0] == n_ref and np.array_equal(m[0], m_ref)
@@ -112,7 +117,7 @@ def test_search_by_projection_frame_matches_oracle(gpu, oracle, NF, NL, th, moti
     torch, ctx = gpu
     c = api.Camera()
     assert (c.fx, c.cx, c.bf, c.width, c.height) == (CamF.fx, CamF.cx, CamF.bf, CamF.width, CamF.height)
-    frames = [synth.synth_motion_frames(NF, NL, 77 * NF + b, CamF, motion) for b in range(4)]
+    frames = [synth.synth_motion_frames(NF, NL, 77 * NF + b, CamF, motion, float_uv=b % 2 == 0) for b in range(4)]  # both walks
     m, n = run_gpu_frame(torch, ctx, frames, th, mono, chk)
     tot = 0
     for b, f in enumerate(frames):
@@ -462,7 +467,7 @@ def test_search_local_points_chain_matches_oracle(gpu, oracle):
     PK = ("pose_cw", "t_wc", "pos", "normal", "max_dist", "min_dist", "cand")
     rng = np.random.default_rng(91)
     frames = [synth.synth_local_points_frame(NF, NP, 3000 + i, cam) for i, (NF, NP) in enumerate(((900, 2500), (1200, 4000), (300, 700), (50, 3000), (1000, 60)))]
-    frames += [synth.synth_local_points_frame(int(rng.integers(20, 1500)), int(rng.integers(20, 4096)), 3100 + i, cam) for i in range(40)]
+    frames += [synth.synth_local_points_frame(int(rng.integers(20, 1500)), int(rng.integers(20, 4096)), 3100 + i, cam, float_uv=i % 3 != 0) for i in range(40)]
     B, NF, NP = len(frames), max(len(f["feat_oct"]) for f in frames), max(len(f["cand"]) for f in frames)
     t = dict(feat_uv=np.zeros((B, NF, 2)), feat_ur=np.full((B, NF), -1.0, np.float32), feat_oct=np.full((B, NF), -1, np.int32),
              feat_desc=np.zeros((B, NF, 32), np.uint8), feat_taken=np.zeros((B, NF), np.uint8), mp_desc=np.zeros((B, NP, 32), np.uint8))

@@ -215,7 +215,7 @@ def main():
     #      restatement; inputs are regenerated from the seeds by the tests, only the outputs are stored
     out = {}
     for i, (NF, NP, seed, th) in enumerate(((250, 300, 101, 3.0), (600, 500, 102, 5.0), (400, 700, 103, 1.0))):
-        fr = synth.synth_match_frame(NF, NP, seed)
+        fr = synth.synth_match_frame(NF, NP, seed, float_uv=False)
         m, n = nr.search_by_projection(th=th, **fr)
         out["m%d_args" % i] = np.array([NF, NP, seed, th])
         out["m%d_match" % i] = m
@@ -228,7 +228,7 @@ def main():
     CamF.width, CamF.height = 752, 480
     for i, (NF, NL, seed, th, motion, chk) in enumerate(((260, 220, 111, 7.0, "none", 1), (500, 420, 112, 7.0, "forward", 1),
                                                           (450, 500, 113, 14.0, "backward", 1), (300, 300, 114, 7.0, "none", 0))):
-        fr = synth.synth_motion_frames(NF, NL, seed, CamF, motion)
+        fr = synth.synth_motion_frames(NF, NL, seed, CamF, motion, float_uv=False)
         m, n = nr.search_by_projection_frame(CamF, th=th, check_orientation=bool(chk), **fr)
         out["f%d_args" % i] = np.array([NF, NL, seed, th, {"none": 0, "forward": 1, "backward": 2}[motion], chk])
         out["f%d_match" % i] = m

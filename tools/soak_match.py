@@ -30,7 +30,7 @@ for r in range(rounds):
     th, dup = float(rng.choice([1.0, 3.0, 5.0])), float(rng.uniform(0, 0.9))
     ctx.set_option("match_desc_lds", int(rng.integers(0, 2)))
     B = int(rng.integers(1, 5))
-    frames = [synth.synth_match_frame(NF, NP, 7919 * r + b, dup_frac=dup) for b in range(B)]
+    frames = [synth.synth_match_frame(NF, NP, 7919 * r + b, dup_frac=dup, float_uv=(r + b) % 4 != 0) for b in range(B)]
     m, n = run_gpu(torch, ctx, frames, th)
     for b, f in enumerate(frames):
         m_ref, n_ref = orc.search_by_projection(th=th, **f)
@@ -45,7 +45,7 @@ for r in range(rounds):
     th = float(rng.choice([7.0, 14.0, 15.0]))
     motion = str(rng.choice(["none", "forward", "backward"]))
     mono, chk = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-    frames = [synth.synth_motion_frames(NF, NL, 104729 * r + b, CamF, motion) for b in range(B)]
+    frames = [synth.synth_motion_frames(NF, NL, 104729 * r + b, CamF, motion, float_uv=(r + b) % 4 != 0) for b in range(B)]
     m, n = run_gpu_frame(torch, ctx, frames, th, mono, chk)
     for b, f in enumerate(frames):
         m_ref, n_ref = orc.search_by_projection_frame(CamF, th=th, mono=mono, check_orientation=chk, **f)
