@@ -498,6 +498,47 @@ def search_local_points(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_ta
     return match, nm, inview
 
 
+CHAIN_FIELDS = ("feat_uv", "feat_ur", "feat_oct", "feat_angle", "feat_desc", "feat_taken", "pose_lw", "last_pt", "last_valid", "last_oct",
+                "last_angle", "last_desc", "last_to_local", "mp_pos", "mp_normal", "mp_max_dist", "mp_min_dist", "mp_cand", "mp_desc",
+                "pose_cw", "pose_mm", "match_last", "match_local", "outlier", "counts", "inview")
+CHAIN_DTYPES = {"feat_uv": "float64", "feat_ur": "float32", "feat_oct": "int32", "feat_angle": "float32", "feat_desc": "uint8",
+                "feat_taken": "uint8", "pose_lw": "float64", "last_pt": "float64", "last_valid": "uint8", "last_oct": "int32",
+                "last_angle": "float32", "last_desc": "uint8", "last_to_local": "int32", "mp_pos": "float64", "mp_normal": "float64",
+                "mp_max_dist": "float32", "mp_min_dist": "float32", "mp_cand": "uint8", "mp_desc": "uint8", "pose_cw": "float64"}
+
+
+class _ChainIO(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in CHAIN_FIELDS]
+
+
+def track_frame_chain(ctx, cam, prm, a, th_mm=7.0, th_local=3.0, nn_ratio=0.8, mono=False, scale_factor=1.2):
+    """gl_track_frame_chain: trackWithMotionModel -> searchLocalPoints -> trackLocalMap for B frames, device resident.  `a`: dict of
+    CUDA tensors with the input keys of CHAIN_DTYPES (pose_cw (B,7): the motion-model prediction; it is NOT modified - the result
+    comes back as a new tensor).  Returns dict(pose, pose_mm, match_last, match_local, outlier, counts (B,4), inview)."""
+    import torch
+    for k, dt in CHAIN_DTYPES.items():
+        t = a[k]
+        assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch." + dt, (k, t.dtype, t.is_contiguous())
+    B, NF = a["feat_oct"].shape
+    NL, NP = a["last_oct"].shape[1], a["mp_cand"].shape[1]
+    dev = a["feat_oct"].device
+    out = dict(pose=a["pose_cw"].clone(), pose_mm=torch.empty((B, 7), dtype=torch.float64, device=dev),
+               match_last=torch.empty((B, NF), dtype=torch.int32, device=dev), match_local=torch.empty((B, NF), dtype=torch.int32, device=dev),
+               outlier=torch.empty((B, NF), dtype=torch.uint8, device=dev), counts=torch.zeros((B, 4), dtype=torch.int32, device=dev),
+               inview=torch.empty((B, NP), dtype=torch.uint8, device=dev))
+    io = _ChainIO()
+    for k in CHAIN_FIELDS:
+        t = out["pose"] if k == "pose_cw" else (out[k] if k in out else a[k])
+        setattr(io, k, _ptr(t))
+    ctx._enter()
+    try:
+        _check(ctx.lib.gl_track_frame_chain(ctx.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), B, NF, NL, NP, C.byref(io),
+                                            float(th_mm), float(th_local), float(nn_ratio), int(bool(mono))))
+    finally:
+        ctx._exit()
+    return out
+
+
 def search_by_projection_frame(ctx, cam, pose_cw, pose_lw, feat_uv, feat_ur, feat_oct, feat_angle, feat_desc, feat_taken,
                                last_pt, last_valid, last_oct, last_angle, last_desc, th=7.0, mono=False,
                                check_orientation=True, scale_factor=1.2):

@@ -20,7 +20,7 @@ void set_error(const char* fmt, ...) {
 // option table: name as in gl_ctx_set_option; the environment variable is GMMLOC_<NAME IN CAPITALS>
 #define GL_OPTION_LIST(X) \
   X(ba_shape) X(ba_step32) X(ba_slow) X(ba_fixed_pack) X(ba_rendezvous_us) X(ba_test_abort_seq) X(ba_same_xcd) X(pose_waves) X(pose_regs) X(bagen_nb) X(bagen_mode) X(view_slot_lds) X(view_threads) \
-  X(assoc_index_min) X(assoc_grid) X(assoc_coop) X(assoc_pack_mb) X(assoc_cell) X(assoc_globcells) X(match_desc_lds)
+  X(assoc_index_min) X(assoc_grid) X(assoc_coop) X(assoc_pack_mb) X(assoc_cell) X(assoc_globcells) X(match_desc_lds) X(pipe_lanes) X(pipe_judge) X(schur_kper)
 double* option_slot(Options& o, const char* name) {
 #define X(n) \
   if (strcmp(name, #n) == 0) return &o.n;
@@ -78,6 +78,26 @@ int ctx_scratch_b(Ctx* c, size_t bytes, void** out) {
     c->scratch_b_bytes = want;
   }
   *out = c->scratch_b;
+  return GL_OK;
+}
+
+// third block: gl_track_frame_chain's own intermediates (its stages use the first two)
+int ctx_scratch_c(Ctx* c, size_t bytes, void** out) {
+  if (bytes > c->scratch_c_bytes) {
+    if (c->scratch_c) {
+      GL_HIP(hipStreamSynchronize(c->stream));
+      GL_HIP(hipFree(c->scratch_c));
+      c->scratch_c = nullptr;
+      c->scratch_c_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 2;
+    if (hipMalloc(&c->scratch_c, want) != hipSuccess) {
+      set_error("scratch hipMalloc(%zu) failed", want);
+      return GL_ERR_NOMEM;
+    }
+    c->scratch_c_bytes = want;
+  }
+  *out = c->scratch_c;
   return GL_OK;
 }
 
@@ -158,6 +178,7 @@ int gl_ctx_create(int device, void* hip_stream, gl_ctx_t** out) {
   gl::Ctx* c = new gl::Ctx();
   c->device = device;
   if (hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->ncu <= 0) c->ncu = 256;
+  if (hipDeviceGetAttribute(&c->lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || c->lds_max <= 0) c->lds_max = 64 * 1024;
   c->stream = (hipStream_t)hip_stream;  // NULL = the device's default (null) stream
   gl::options_from_env(c->opt);         // the only place the knobs are read from the environment
   c->xcc_ids_trusted = gl::probe_xcc_ids(c);
@@ -183,6 +204,7 @@ int gl_ctx_destroy(gl_ctx_t* ctx) {
   }
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch_b) (void)hipFree(c->scratch_b);
+  if (c->scratch_c) (void)hipFree(c->scratch_c);
   if (c->counters) (void)hipFree(c->counters);
   if (c->host_word) (void)hipHostFree(c->host_word);
   for (int k = 0; k < 3; ++k) {
@@ -251,6 +273,11 @@ int gl_ctx_timing_read(gl_ctx_t* ctx, int timer, double* total_ms, int64_t* laun
 int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset) {
   GL_REQUIRE(ctx && value && counter >= 0 && counter < GL_COUNTER_COUNT, "bad argument");
   gl::Ctx* c = gl::C(ctx);
+  if (counter == GL_COUNTER_BA_COOP_FALLBACK) {  // kept on the host (the launcher counts it)
+    *value = c->coop_fallbacks;
+    if (reset) c->coop_fallbacks = 0;
+    return GL_OK;
+  }
   GL_HIP(hipSetDevice(c->device));
   int32_t v = 0;
   GL_HIP(hipMemcpyAsync(&v, c->counters + counter, sizeof(v), hipMemcpyDeviceToHost, c->stream));

@@ -58,6 +58,10 @@ constexpr bool kFixed = true;   // instance with fixed observer key-frames (gl_t
 #else                           // edges of the frame's points with FIXED pose vertices (localization_opt.cpp:491-516, 706-760)
 constexpr bool kFixed = false;
 #endif
+#ifndef GL_BAF_ALLSOLVE
+#define GL_BAF_ALLSOLVE 0  // measured (profiles/r5_ab_allsolve.txt): same bits, refine 10.80 -> 11.09 ms per 4 096 frames - seven more waves issuing the ~350 dependent instructions cost more than the hand-over they save
+#endif
+constexpr bool kAllSolve = !kSpread && GL_BAF_ALLSOLVE != 0;  // DENSE: every wave solves the reduced system itself (optimize_fast)
 constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of this LDS class has at most
 constexpr int NRED = kSpread ? 1 : NWC;    // group totals kept in LDS (a SPREAD workgroup is ONE group)
 constexpr int TSP = 256;                   // SPREAD: threads of a workgroup = the <= 4 slot waves of its group
@@ -1069,14 +1073,15 @@ GL_DEV void spread_reduce2_all(double* v, const Red& R, Coop& C) {
 // pass A (29 values, read by the solving wave only): group totals to red[], ONE barrier, then wave 0 adds the blocks
 // itself and hands the totals round its lanes with v_readlane - no `tot` round trip, no second barrier.  The next
 // writer of red[] is the next trial's pass A, two barriers later.
-GL_DEV void reduce29_w0_dense(double* v, const Red& R) {
+// (all_waves: every wave adds the blocks and takes the totals - GL_BAF_ALLSOLVE, the serial section without a hand-over)
+GL_DEV void reduce29_w0_dense(double* v, const Red& R, bool all_waves = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 29; i < 32; ++i) v[i] = 0.0;
   const double r = wave_reduce_scatter32(v);
   if (wave_slot_owner(lane)) R.red[wave * 32 + wave_slot(lane)] = r;
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0 || all_waves) {
     const int t = lane & 31;
     double s = NWC > 1 ? add_nc(R.red[t], R.red[32 + t]) : R.red[t];
 #pragma unroll
@@ -1587,14 +1592,41 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       PROF_T(tA1);
       PROF_W(trials, 0);
       if (kSpread) spread_reduce29_w0(acc, R, C);
-      else reduce29_w0_dense(acc, R);
+      else reduce29_w0_dense(acc, R, kAllSolve);
       PROF_W(trials, 1);
       PROF_T(tA2);
+      double* bc = R.tot + 32;  // 28 doubles: dx[6] R[9] t[3] ok g[6] sum u.b chi2, chi2 of the prior edge at the trial pose
+      volatile int* pnflag = (volatile int*)(R.tot + 60);
+      const int seq = trials + 1;
+      double dx[6], gsc[7];  // the pose step; reduced rhs g and sum u.b, for computeScale
+      bool ok2;
+      Pose Pn = P;
+      bool have_pn = false;
+      if (kAllSolve) {
+        // DENSE: EVERY wave solves the 6 x 6 system from the totals it has just added up itself, and builds the trial pose: the
+        // serial section has no hand-over - no second barrier, no broadcast through LDS, no wait for the trial pose (the
+        // ~350 dependent instructions run on all eight waves at once, two per SIMD, in each other's latencies)
+        double dxs[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = true;
+        if (prior_on) {  // the prior edge at the current pose: H_pp, b_p and chi2 from its record
+          const double* rc = An.rec + An.cur * 32;
+#pragma unroll
+          for (int i = 0; i < 28; ++i) acc[i] += rc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gsc[i] = acc[21 + i];
+        gsc[6] = acc[28];
+        if (qmax == 0) currentChi = acc[27];
+        if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dx[i] = dxs[i];
+        ok2 = ok;
+        if (pose_active && ok2) Pn = pose_uni(pose_update(P, dx));
+        have_pn = true;
+      } else {
       // 6x6 solve by wave 0; the step and the status are broadcast through LDS behind a barrier.  The trial pose
       // exp(dx) P is computed by wave 0 AFTER that barrier, while the other waves are already in pass B (its first use
       // is the evaluation of their first point, ~200 instructions in), and handed over through LDS + a sequence word.
-      double* bc = R.tot + 32;  // 28 doubles: dx[6] R[9] t[3] ok g[6] sum u.b chi2, chi2 of the prior edge at the trial pose
-      volatile int* pnflag = (volatile int*)(R.tot + 60);
       if (threadIdx.x < 64) {
         double dxs[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
@@ -1616,13 +1648,11 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       }
       __syncthreads();
       if (qmax == 0) currentChi = uni(bc[26]);
-      double dx[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) dx[i] = uni(bc[i]);
-      const bool ok2 = uni(bc[18]) != 0.0;
-      const int seq = trials + 1;
-      Pose Pn = P;
-      bool have_pn = false;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) gsc[i] = uni(bc[19 + i]);
+      ok2 = uni(bc[18]) != 0.0;
       if (threadIdx.x < 64) {
         Pose Pw = P;
         if (pose_active && ok2) Pw = pose_update(P, dx);
@@ -1636,6 +1666,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         }
         Pn = pose_uni(Pw);
         have_pn = true;
+      }
       }
       PROF_T(tS);
       PROF_W(trials, 2);
@@ -1665,11 +1696,11 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       PROF_T(tB2);
       // computeScale: sum_l eps.(lambda eps + b_l) + dx.(lambda dx + b_p).  With eps = u - D^-1 A gd the
       // b-terms collapse to  sum u.b + dx.g  (g = reduced rhs of pass A), so pass B needs no b at all.
-      double scale = lambda * acc[0] + uni(bc[25]);
+      double scale = lambda * acc[0] + gsc[6];
       const double tempChi = ok2 ? (prior_on ? acc[1] + uni(An.rec[(An.cur ^ 1) * 32 + 27]) : acc[1]) : 1.7976931348623157e308;
       if (pose_active) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) scale += dx[i] * (lambda * dx[i] + uni(bc[19 + i]));
+        for (int i = 0; i < 6; ++i) scale += dx[i] * (lambda * dx[i] + gsc[i]);
       }
       scale += 1e-3;
       rho = (currentChi - tempChi) / scale;

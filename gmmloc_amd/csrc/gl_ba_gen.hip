@@ -2908,8 +2908,8 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
     BaK kk = make_bak(cam, prm, -1.0);
     int32_t* stats_all = (c->stats && c->stats_n >= B) ? c->stats : nullptr;  // gl_ctx_set_stats_buffer: trials per problem
     size_t per_v = per;
-    for (int b0 = 0; b0 < B; b0 += bsub) {
-      int Bs = std::min(bsub, B - b0);
+    for (int b0 = 0, Bs = 0; b0 < B; b0 += Bs) {
+      Bs = std::min(bsub, B - b0);
       // the sub-batch's slices of the caller's arrays (strides: gmmloc_hip.h); the scratch is re-used, launches are in stream order
       double* poses_s = poses_dev + (size_t)b0 * (P + F) * 7;
       const uint8_t* prior_s = prior_dev + (size_t)b0 * P;
@@ -2926,18 +2926,28 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
       char* scr = (char*)scratch;
       GL_HIP(hipMemsetAsync(scratch, 0, (size_t)Bs * 512, c->stream));
       bool launched = false;
-      if (NB > 1) {
+      // A window's bits are a function of NB (the order of its partial sums): when the cooperative launch is refused - the
+      // workgroups are not co-resident after all, another context holds CUs - the sub-batch is HALVED at the same NB until it
+      // fits.  Only when a single window does not fit does the call fall back to one workgroup per problem (other bits, the same
+      // arithmetic): GL_COUNTER_BA_COOP_FALLBACK counts those windows.
+      while (NB > 1 && !launched) {
         void* args[] = {&kk, &gm, &Bs, &NB, &P, &F, &L, &NOBS, &poses_s, &prior_s, &points_s, &assoc_s, &optr_s,
                         &opose_s, &ouvr_s, &ooct_s, &dropped_s, &erase_s, &iters_s, &scr, &per_v,
                         &s_in_lds, &stop_dev, &stats};
         hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(Bs * NB), dim3(T_BA), args, lds, c->stream);
         launched = e == hipSuccess;
-        if (!launched) (void)hipGetLastError();  // not co-resident after all (another context holds CUs): one workgroup per problem
+        if (!launched) {
+          (void)hipGetLastError();
+          if (Bs == 1) break;
+          Bs = std::max(1, Bs / 2);
+        }
       }
-      if (!launched)
+      if (!launched) {
+        if (NB > 1) c->coop_fallbacks += Bs;
         k_ba_gen<<<Bs, T_BA, lds, c->stream>>>(kk, gm, Bs, 1, P, F, L, NOBS, poses_s, prior_s, points_s, assoc_s, optr_s,
                                                opose_s, ouvr_s, ooct_s, dropped_s, erase_s, iters_s,
                                                scr, per_v, s_in_lds, stop_dev, stats);
+      }
     }
   }
   GL_HIP(hipGetLastError());
@@ -2970,7 +2980,7 @@ struct PipeLane {
   int* hw = nullptr;
   bool done = false;
 };
-static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, bool stats_ok, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
                    double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
                    const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
                    const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
@@ -2994,7 +3004,7 @@ static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, const Gmm* g, co
   a.dropped = assoc_dropped_dev;
   a.erase = obs_erase_dev;
   a.iters = iters_dev;
-  a.trials_out = (c->stats && c->stats_n >= stats_off + B) ? c->stats + stats_off : nullptr;
+  a.trials_out = stats_ok ? c->stats + stats_off : nullptr;  // (checked once for the whole call: all lanes or none)
   a.stop = stop_dev;
   a.scratch = (char*)scratch;
   a.per = ((gen_scratch_bytes(P, F, L, NOBS) + 255) / 256) * 256;
@@ -3017,9 +3027,9 @@ static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, const Gmm* g, co
   s += up((size_t)B * 8);
   // The verdict on a trial as a kernel of its own behind kp_trial (one small workgroup per window) instead of in every one of the
   // window's 24 - 47 point-pass workgroups: in batches the judging head is 14 of kp_lin's 28 us (64 windows); alone it is a launch
-  // more on a single window's critical path (break-even at 16 - 24 windows per lane: from 32 on; GL_PIPE_JUDGE = 0 / 1 overrides,
+  // more on a single window's critical path (break-even at 16 - 24 windows per lane: from 32 on; option pipe_judge = 0 / 1 overrides,
   // for A/B runs).  The same function on the same values: the same bits.  64 windows 0.122 -> 0.114 ms per window, 256 0.118 -> 0.113.
-  a.ext_judge = getenv("GL_PIPE_JUDGE") ? atoi(getenv("GL_PIPE_JUDGE")) : (B >= 32 ? 1 : 0);
+  a.ext_judge = c->opt.pipe_judge >= 0 ? (c->opt.pipe_judge != 0 ? 1 : 0) : (B >= 32 ? 1 : 0);
   a.unfinished = (int*)s;  // [0] problems not finished, [1] cycles the slowest of them needed
   const size_t n = 6 * (size_t)P;
   ln.s_bytes = n <= 128 ? n * (n + GL_LD_PAD) * sizeof(double) : 0;
@@ -3043,11 +3053,11 @@ static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, const Gmm* g, co
   // Chunks of a block per wave of the Schur pass: a wave's set-up (its chain of scalar loads, the poses) is a third of its life at
   // one chunk - two entries per lane - so in batches a wave takes 2, 4 or 8 chunks one after the other, as many as leave the call
   // one full round of waves on the chip (256 CUs x 8).  The partial sums stay per chunk: the bits do not depend on it
-  // (64 windows of 8 + 4 key-frames 0.164 -> 0.132 ms per window, 256 windows 0.166 -> 0.117; GL_SCHUR_KPER overrides, for A/B runs).
+  // (64 windows of 8 + 4 key-frames 0.164 -> 0.132 ms per window, 256 windows 0.166 -> 0.117; option schur_kper overrides, for A/B runs).
   auto kper_ok = [&](int k) { return k >= 1 && a.nchunk % k == 0 && (a.nblk * a.nchunk / k) % NW_BA == 0; };
   a.kper = 1;
-  if (const char* ek = getenv("GL_SCHUR_KPER")) {
-    a.kper = atoi(ek);
+  if (c->opt.schur_kper >= 1) {
+    a.kper = (int)c->opt.schur_kper;
   } else {
     for (int k = 8; k > 1; k /= 2)
       if (kper_ok(k) && (long)B * a.nblk * a.nchunk / k >= 2048) {
@@ -3081,10 +3091,10 @@ static void pipe_lane_cycle(PipeLane& ln, int cyc) {
 // workgroups the chip needs for the batch, not by issue slots or bandwidth, and a cycle is a chain of five such kernels (the solve
 // with one workgroup per window).  A call of 16 or more windows (up to 2.5 M observations together: beyond that the kernels keep the
 // chip busy by themselves) is cut into two halves that run their cycles on two streams: the kernels of one half fill the gaps of the
-// other's.  Windows do not interact, so the bits are those of any other split.  (GL_PIPE_LANES = 1 .. 4 overrides, for A/B runs.)
+// other's.  Windows do not interact, so the bits are those of any other split.  (Option pipe_lanes = 1 .. 4 overrides, for A/B runs.)
 constexpr int PIPE_LANES_MAX = 4;
-int pipe_lanes(int B, int NOBS) {
-  if (const char* e = getenv("GL_PIPE_LANES")) return std::max(1, std::min(std::min(atoi(e), PIPE_LANES_MAX), B));
+int pipe_lanes(const Ctx* c, int B, int NOBS) {
+  if (c->opt.pipe_lanes >= 1) return std::max(1, std::min(std::min((int)c->opt.pipe_lanes, PIPE_LANES_MAX), B));
   return (B >= 16 && (long)B * NOBS <= 2500000) ? 2 : 1;
 }
 // windows [first, first + count) of lane k (every lane but the last a multiple of 8 windows: the XCD-aware workgroup map)
@@ -3104,19 +3114,19 @@ static size_t pipe_lane_scratch_off(int B, int nl, int k, int P, int F, int L, i
   }
   return off;
 }
-size_t ba_pipe_scratch_total(int B, int P, int F, int L, int NOBS) {
-  const int nl = pipe_lanes(B, NOBS);
+size_t ba_pipe_scratch_total(const Ctx* c, int B, int P, int F, int L, int NOBS) {
+  const int nl = pipe_lanes(c, B, NOBS);
   return pipe_lane_scratch_off(B, nl, nl, P, F, L, NOBS);
 }
 
-int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
-                   double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
-                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
-                   const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
-                   const int32_t* stop_dev, void* scratch) {
+static int launch_ba_pipe_lanes(Ctx* c, PipeLane* lane, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+                               double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                               const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
+                               const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                               const int32_t* stop_dev, void* scratch) {
   // page-locked words the devices' counts of unfinished problems are copied to between chunks of cycles (4 per lane)
   if (!c->host_word) GL_HIP(hipHostMalloc((void**)&c->host_word, 64, hipHostMallocDefault));
-  const int nl = pipe_lanes(B, NOBS);
+  const int nl = pipe_lanes(c, B, NOBS);
   if (nl > 1 && !c->ev_fork) GL_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (int k = 1; k < nl; ++k)
     if (!c->lane_stream[k - 1]) {
@@ -3124,7 +3134,6 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
       GL_HIP(hipEventCreateWithFlags(&c->ev_join[k - 1], hipEventDisableTiming));
     }
   TimerScope ts(c, GL_TIMER_BA);
-  PipeLane lane[PIPE_LANES_MAX];
   if (nl > 1) GL_HIP(hipEventRecord(c->ev_fork, c->stream));  // the further streams start behind what the caller has enqueued so far
   for (int k = 0; k < nl; ++k) {
     int w0, Bk;
@@ -3138,7 +3147,7 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
     lane[k].hw = c->host_word + 4 * k;
     char* sk = (char*)scratch + pipe_lane_scratch_off(B, nl, k, P, F, L, NOBS);
     const size_t w = (size_t)w0;
-    const int rc = pipe_lane_setup(c, lane[k], w0, g, cam, prm, Bk, P, F, L, NOBS, poses_dev + w * (P + F) * 7, prior_dev + w * P,
+    const int rc = pipe_lane_setup(c, lane[k], w0, c->stats && c->stats_n >= B, g, cam, prm, Bk, P, F, L, NOBS, poses_dev + w * (P + F) * 7, prior_dev + w * P,
                                    points_dev + w * L * 3, assoc_dev + w * L, obs_ptr_dev + w * (L + 1), obs_pose_dev + w * NOBS,
                                    obs_uvr_dev + w * NOBS * 3, obs_oct_dev + w * NOBS, assoc_dropped_dev ? assoc_dropped_dev + w * L : nullptr,
                                    obs_erase_dev ? obs_erase_dev + w * NOBS : nullptr, iters_dev ? iters_dev + w : nullptr, stop_dev, sk);
@@ -3182,6 +3191,24 @@ int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* 
   }
   return GL_OK;
 }
+
+// The lanes run on further non-blocking streams and share the context's scratch block: whatever way the call ends, nothing of it may
+// still be in flight when it returns - the next call on the context only orders itself behind c->stream and may overwrite or free
+// that scratch.  Every error exit therefore waits for all the lanes' streams first (the regular exit has seen their counters).
+int launch_ba_pipe(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
+                   double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
+                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
+                   const int32_t* obs_oct_dev, uint8_t* assoc_dropped_dev, uint8_t* obs_erase_dev, int32_t* iters_dev,
+                   const int32_t* stop_dev, void* scratch) {
+  PipeLane lane[PIPE_LANES_MAX];
+  const int rc = launch_ba_pipe_lanes(c, lane, g, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,
+                                      obs_uvr_dev, obs_oct_dev, assoc_dropped_dev, obs_erase_dev, iters_dev, stop_dev, scratch);
+  if (rc != GL_OK) {
+    for (int k = 0; k < PIPE_LANES_MAX; ++k)
+      if (lane[k].s) (void)hipStreamSynchronize(lane[k].s);  // (keep the first error's message)
+  }
+  return rc;
+}
 }  // namespace gl
 
 static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_camera* cam, const gl_params* prm,
@@ -3213,7 +3240,7 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   // (from 3 000 observations since the end of round 4 - 5 000 before: profiles/r4f_ba_modes.txt has the pipelined shape ahead from
   // 3 300 observations at every batch size, 9 % on one window and 30 % on eight, and per trial already at 2 100)
   const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && NOBS >= 3000));
-  int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_total(B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
+  int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_total(c, B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);
   if (rc != GL_OK) return rc;
   if (pipe) {
     return gl::launch_ba_pipe(c, g, cam, prm, B, P, F, L, NOBS, poses_dev, prior_dev, points_dev, assoc_dev, obs_ptr_dev, obs_pose_dev,

@@ -30,6 +30,16 @@ void set_error(const char* fmt, ...);
     }                                      \
   } while (0)
 
+// the documented size limits of the matcher-side entry points assume gfx950's 160 KB of LDS: on a device with less the REAL limit is
+// the LDS the shape needs, reported as such instead of as a raw HIP error of the launch
+#define GL_REQUIRE_LDS(c, bytes)                                                                                              \
+  do {                                                                                                                        \
+    if ((size_t)(bytes) > (size_t)(c)->lds_max) {                                                                             \
+      gl::set_error("%s: this shape needs %zu bytes of LDS per workgroup, the device has %d", __func__, (size_t)(bytes), (c)->lds_max); \
+      return GL_ERR_ARG;                                                                                                      \
+    }                                                                                                                         \
+  } while (0)
+
 // Device-resident, immutable GMM (SoA).  Layout (all fp64 unless noted):
 //   rec12   K x 12   {mean[3], cov_inv[9]}  -- the association record, 96 B
 //   cov     K x 9    row-major covariance
@@ -103,6 +113,9 @@ struct Options {
   double assoc_cell = 0;        // > 0: cell size (m) of the index instead of the automatic one (tuning)
   double assoc_globcells = 0;   // > 0: components whose box covers more cells than this are evaluated for every point (tuning)
   double match_desc_lds = -1;   // gl_search_by_projection: descriptors in LDS (-1 auto, 0 / 1)
+  double pipe_lanes = -1;       // pipelined local BA in batches: streams a call's windows are split over (-1 auto: 2 from 16 windows; 1 .. 4; A/B)
+  double pipe_judge = -1;       //   the verdict on a trial as a kernel of its own (-1 auto: from 32 windows per lane; 0 / 1; A/B)
+  double schur_kper = -1;       //   chunks of a block one wave of the Schur pass takes (-1 auto; 1 / 2 / 4 / 8; A/B)
 };
 // name -> member; nullptr if unknown
 double* option_slot(Options& o, const char* name);
@@ -110,6 +123,7 @@ double* option_slot(Options& o, const char* name);
 struct Ctx {
   int device = 0;
   int ncu = 256;  // compute units of the device (shape decisions: frames vs CUs)
+  int lds_max = 160 * 1024;  // LDS a workgroup may have on this device (hipDeviceAttributeMaxSharedMemoryPerBlock: 160 KB on gfx950, 64 KB on gfx942)
   Options opt;
   // per-context (= per device, per host thread) caches of driver queries: the dynamic-LDS limit already set
   // for a kernel (hipFuncSetAttribute is per device) and occupancy answers
@@ -125,12 +139,15 @@ struct Ctx {
   size_t scratch_bytes = 0;
   void* scratch_b = nullptr;  // second block (ctx_scratch_b): the matchers' candidate cache
   size_t scratch_b_bytes = 0;
+  void* scratch_c = nullptr;  // third block (ctx_scratch_c): the intermediates of gl_track_frame_chain, whose stages use the other two
+  size_t scratch_c_bytes = 0;
   // staging of the frame-at-a-time host entry point (gl_track_frame_host): page-locked + device mirror, grown on demand
   void* host_stage = nullptr;
   void* dev_stage = nullptr;
   size_t stage_bytes = 0;
   // device counters (gl_ctx_counter_read): [0] frames of latency-shape launches redone by the follow-up kernel
   int32_t* counters = nullptr;
+  long coop_fallbacks = 0;  // host side (GL_COUNTER_BA_COOP_FALLBACK): windows of gl_joint_optimization run with one workgroup after a refused cooperative launch
   int* host_word = nullptr;  // page-locked words (the pipelined local BA's counts of unfinished problems, per lane)
   hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};  // further lanes of the pipelined local BA in batches (launch_ba_pipe)
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -151,6 +168,7 @@ struct Ctx {
 
 int ctx_scratch(Ctx* c, size_t bytes, void** out);
 int ctx_scratch_b(Ctx* c, size_t bytes, void** out);
+int ctx_scratch_c(Ctx* c, size_t bytes, void** out);
 bool probe_xcc_ids(Ctx* c);  // gl_ba_fast.hip
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE and costs a driver call: a context (one device,
 // one host thread) remembers the limit it has set for each kernel and raises it only when it grows.  The caller
@@ -193,6 +211,12 @@ int launch_build_components(Ctx* c, Gmm* g);
 int launch_build_neighbours(Ctx* c, Gmm* g);
 int build_cell_index(Ctx* c, Gmm* g);
 void free_cell_index(Gmm* g);
+// gl_search_by_projection_frame with a per-frame gate (gl_match.hip): frames with gate_nm[f] >= gate_min are left untouched
+int launch_match_frame_gated(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NL, const double* pose_cw, const double* pose_lw,
+                             const double* feat_uv, const float* feat_ur, const int32_t* feat_oct, const float* feat_angle, const uint8_t* feat_desc,
+                             const uint8_t* feat_taken, const double* last_pt, const uint8_t* last_valid, const int32_t* last_oct, const float* last_angle,
+                             const uint8_t* last_desc, float th, int mono, int check_orientation, int32_t* feat_match, int32_t* nmatches,
+                             const int32_t* gate_nm, int gate_min);
 // association launchers (gl_assoc.hip: all-pairs sweep; gl_grid.hip: cell index + sweep of the rest)
 int launch_assoc_brute(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2);
 int launch_assoc_sweep(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* idx, double* d2, const int32_t* list,

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all,
     const double* __restrict__ pose_cw_all, const double* __restrict__ pose_lw_all,
     const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all, int32_t* __restrict__ counters,
-    uint4* __restrict__ cache_all) {
+    uint4* __restrict__ cache_all, const int32_t* __restrict__ gate_nm, int gate_min) {
   constexpr int TM = DL ? 1024 : T_M;  // threads per frame: the latency shape doubles them
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* cell_ptr = lds;                   // NCELL + 1
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
   __shared__ int s_dir;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
+  if (gate_nm && gate_nm[f] >= gate_min) return;  // (gl_track_frame_chain's wider second search: only the frames that need it)
 #ifdef GL_MATCH_PROF
   const long long tp0 = clock64();
   long long tp_round = 0;
@@ -679,7 +680,7 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
                  const uint8_t* feat_taken, const double* mp_uvr, const int32_t* mp_level, const double* mp_viewcos,
                  const uint8_t* mp_valid, const uint8_t* mp_desc, float th, float nn_ratio, int32_t* feat_match,
                  int32_t* nmatches, const double* pose_cw, const double* pose_lw, const float* feat_angle,
-                 const float* mp_angle, int mono, int check_orientation) {
+                 const float* mp_angle, int mono, int check_orientation, const int32_t* gate_nm = nullptr, int gate_min = 0) {
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   MatchP P;
@@ -706,11 +707,12 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
   size_t lds = (size_t)lds_ints(NF, NP) * sizeof(int32_t) + (size_t)NF * 24;
   // latency shape (no more frames than CUs): descriptors in LDS as well, if they fit
   const size_t lds_dl = lds + 8 + (size_t)NF * 32;
-  bool dl = B <= c->ncu && lds_dl <= 160 * 1024 - 8 * 1024;
-  if (c->opt.match_desc_lds >= 0) dl = c->opt.match_desc_lds != 0 && lds_dl <= 160 * 1024 - 8 * 1024;
+  bool dl = B <= c->ncu && lds_dl + 8 * 1024 <= (size_t)c->lds_max;
+  if (c->opt.match_desc_lds >= 0) dl = c->opt.match_desc_lds != 0 && lds_dl + 8 * 1024 <= (size_t)c->lds_max;
   if (dl) lds = lds_dl;
   auto kern = mode == 0 ? (dl ? k_search_by_projection<0, true> : k_search_by_projection<0, false>)
                         : (dl ? k_search_by_projection<1, true> : k_search_by_projection<1, false>);
+  GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)kern, lds));
   void* cache = nullptr;  // 16 bytes per query: its three best candidates of round 1 (the kernel's header)
   {
@@ -718,7 +720,7 @@ int launch_match(int mode, gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
     if (rc != GL_OK) return rc;
   }
   kern<<<B, dl ? 1024 : T_M, lds, c->stream>>>(P, B, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, mp_uvr, mp_level, mp_viewcos,
-                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle, c->counters, (uint4*)cache);
+                                   mp_valid, mp_desc, feat_match, nmatches, pose_cw, pose_lw, feat_angle, mp_angle, c->counters, (uint4*)cache, gate_nm, gate_min);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -743,6 +745,15 @@ extern "C" int gl_search_by_projection(gl_ctx_t* ctx, const gl_camera* cam, floa
   return launch_match(0, ctx, cam, scale_factor, B, NF, NP, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev,
                       feat_taken_dev, mp_uvr_dev, mp_level_dev, mp_viewcos_dev, mp_valid_dev, mp_desc_dev, th, nn_ratio,
                       feat_match_dev, nmatches_dev, nullptr, nullptr, nullptr, nullptr, 0, 0);
+}
+
+int gl::launch_match_frame_gated(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NL, const double* pose_cw,
+                                 const double* pose_lw, const double* feat_uv, const float* feat_ur, const int32_t* feat_oct, const float* feat_angle,
+                                 const uint8_t* feat_desc, const uint8_t* feat_taken, const double* last_pt, const uint8_t* last_valid,
+                                 const int32_t* last_oct, const float* last_angle, const uint8_t* last_desc, float th, int mono, int check_orientation,
+                                 int32_t* feat_match, int32_t* nmatches, const int32_t* gate_nm, int gate_min) {
+  return launch_match(1, ctx, cam, scale_factor, B, NF, NL, feat_uv, feat_ur, feat_oct, feat_desc, feat_taken, last_pt, last_oct, nullptr, last_valid,
+                      last_desc, th, 0.f, feat_match, nmatches, pose_cw, pose_lw, feat_angle, last_angle, mono, check_orientation, gate_nm, gate_min);
 }
 
 extern "C" int gl_search_by_projection_frame(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF,

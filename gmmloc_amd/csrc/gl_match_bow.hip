@@ -244,6 +244,7 @@ extern "C" int gl_search_by_bow(gl_ctx_t* ctx, float nn_ratio, int check_orienta
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1) * sizeof(int32_t);
+  GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_by_bow, lds));
   k_search_by_bow<<<B, T_B, lds, c->stream>>>(B, N1, N2, NN1, NN2, nn_ratio, check_orientation, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                               node_id1_dev, node_ptr1_dev, node_idx1_dev, angle2_dev, desc2_dev, nnode2_dev, node_id2_dev,

@@ -190,6 +190,7 @@ extern "C" int gl_fuse_search(gl_ctx_t* ctx, const gl_camera* cam, float scale_f
     P.sigma2_inv[i] = 1.0f / s2;
   }
   const size_t lds = ((size_t)2 * NCELL + 1 + NF) * sizeof(int32_t);
+  GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_fuse_search, lds));
   k_fuse_search<<<B, T_F, lds, c->stream>>>(P, B, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev, mp_uvr_dev, mp_level_dev, mp_valid_dev,
                                             mp_desc_dev, best_idx_dev, best_dist_dev);

@@ -427,6 +427,7 @@ extern "C" int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, in
     P.sigma2[i] = P.sf[i] * P.sf[i];
   }
   const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1) * sizeof(int32_t);
+  GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_for_triangulation, lds));
   k_search_for_triangulation<<<B, T_T, lds, c->stream>>>(P, B, uv1_dev, ur1_dev, oct1_dev, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                                         node_id1_dev, node_ptr1_dev, node_idx1_dev, uv2_dev, ur2_dev, oct2_dev, angle2_dev,

@@ -497,3 +497,88 @@ def synth_local_points_frame(NF, NP, seed, cam, scale_factor=1.2, float_uv=True)
     feat_taken = (rng.uniform(size=NF) < 0.05).astype(np.uint8)
     f.update(feat_uv=_key_point_uv(feat_uv, float_uv), feat_ur=feat_ur, feat_oct=feat_oct, feat_desc=feat_desc, feat_taken=feat_taken, mp_desc=mp_desc)
     return f
+
+
+def synth_chain_frame(NF, NL, NP, seed, cam, scale_factor=1.2):
+    """One tracked frame for gl_track_frame_chain (trackWithMotionModel -> searchLocalPoints -> trackLocalMap), geometrically
+    CONSISTENT so that both pose optimisations have inliers: a last frame at the identity with NL map points, a current frame at a
+    small true motion whose features re-observe 60 % of them (sub-pixel noise scaled by the octave, 8 % gross outliers), a
+    motion-model prediction a fraction of a degree / a centimetre off, and a local map of NP points = the last frame's valid map
+    points (last_to_local) + points seen by half of the remaining features (position from the TRUE pose, descriptor = the feature's
+    with flipped bits, distance bounds that predict the feature's octave) + distractors."""
+    rng = np.random.default_rng(seed)
+    W, H = cam.width, cam.height
+    sf = scale_factor ** np.arange(8)
+    rotv = lambda ax, a: np.concatenate([np.asarray(ax, float) / np.linalg.norm(ax) * np.sin(a / 2), [np.cos(a / 2)]])
+    pose_lw = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    pose_true = np.concatenate([rotv(rng.standard_normal(3), np.deg2rad(rng.uniform(0.5, 2.0))), rng.uniform(-0.04, 0.04, 3)])
+    dq = rotv(rng.standard_normal(3), np.deg2rad(rng.uniform(0.05, 0.3)))
+    q0, q1 = pose_true[:4], dq  # prediction = dq * true (Hamilton product on (x, y, z, w))
+    qp = np.concatenate([q1[3] * q0[:3] + q0[3] * q1[:3] + np.cross(q1[:3], q0[:3]), [q1[3] * q0[3] - q1[:3] @ q0[:3]]])
+    pose_pred = np.concatenate([qp / np.linalg.norm(qp), quat_to_R(dq) @ pose_true[4:] + rng.uniform(-0.01, 0.01, 3)])
+    R, t = quat_to_R(pose_true[:4]), pose_true[4:]
+    proj = lambda X: (lambda pc: (cam.fx * pc[:, 0] / pc[:, 2] + cam.cx, cam.fy * pc[:, 1] / pc[:, 2] + cam.cy, pc[:, 2]))(X @ R.T + t)
+    # last frame
+    depth = rng.uniform(1.5, 8.0, NL)
+    u_l, v_l = rng.uniform(20, W - 20, NL), rng.uniform(20, H - 20, NL)
+    last_pt = np.stack([(u_l - cam.cx) / cam.fx * depth, (v_l - cam.cy) / cam.fy * depth, depth], 1)
+    last_valid = (rng.uniform(size=NL) < 0.85).astype(np.uint8)
+    last_oct = rng.integers(0, 8, NL).astype(np.int32)
+    last_angle = rng.uniform(0, 360, NL).astype(np.float32)
+    last_desc = rng.integers(0, 256, (NL, 32), dtype=np.uint8)
+    u_c, v_c, z_c = proj(last_pt)
+    # current frame
+    src = rng.permutation(NL)[:min(NF, NL)] if NL >= NF else rng.integers(0, NL, NF)
+    src = np.resize(src, NF)
+    reobs = rng.uniform(size=NF) < 0.6
+    octv = np.clip(last_oct[src] + rng.integers(-1, 2, NF), 0, 7).astype(np.int32)
+    gross = rng.uniform(size=NF) < 0.08
+    noise = rng.normal(0, 0.6, (NF, 2)) * sf[octv][:, None] + np.where(gross[:, None], rng.uniform(-15, 15, (NF, 2)), 0.0)
+    uv = np.where(reobs[:, None], np.stack([u_c[src], v_c[src]], 1) + noise, np.stack([rng.uniform(5, W - 5, NF), rng.uniform(5, H - 5, NF)], 1))
+    zf = np.where(reobs, z_c[src], rng.uniform(1.5, 8.0, NF))
+    ur = np.where(rng.uniform(size=NF) < 0.7, uv[:, 0] - cam.bf / zf + rng.normal(0, 0.6, NF) * sf[octv], -1.0).astype(np.float32)
+    angle = np.where(rng.uniform(size=NF) < 0.1, rng.uniform(0, 360, NF), (last_angle[src] - 6.0 + rng.normal(0, 3, NF)) % 360.0).astype(np.float32)
+    desc = np.where(reobs[:, None], last_desc[src], rng.integers(0, 256, (NF, 32), dtype=np.uint8)).astype(np.uint8)
+    flips = rng.integers(0, 51, NF)
+    for i in range(NF):
+        bits = rng.choice(256, flips[i], replace=False)
+        np.bitwise_xor.at(desc[i], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+    octv[rng.uniform(size=NF) < 0.02] = -1
+    uv = _key_point_uv(uv, True)
+    taken = (rng.uniform(size=NF) < 0.03).astype(np.uint8)
+    # local map: the last frame's valid map points first
+    t_wc = -R.T @ t
+    shared = np.nonzero(last_valid & (rng.uniform(size=NL) < 0.9))[0][:max(NP // 2, 1)]
+    last_to_local = -np.ones(NL, np.int32)
+    last_to_local[shared] = np.arange(len(shared))
+    mp_pos, mp_desc, mp_lvl = [last_pt[shared]], [last_desc[shared]], [last_oct[shared]]
+    free = np.nonzero(~reobs & (octv >= 0))[0]
+    free = free[rng.uniform(size=len(free)) < 0.5][:max(NP - len(shared) - 1, 0)]
+    zf2 = rng.uniform(1.5, 8.0, len(free))
+    uvn = uv[free] + rng.normal(0, 0.5, (len(free), 2)) * sf[octv[free]][:, None]
+    pc = np.stack([(uvn[:, 0] - cam.cx) / cam.fx * zf2, (uvn[:, 1] - cam.cy) / cam.fy * zf2, zf2], 1)
+    mp_pos.append((pc - t) @ R)
+    d2 = desc[free].copy()
+    for i in range(len(free)):
+        bits = rng.choice(256, int(rng.integers(0, 41)), replace=False)
+        np.bitwise_xor.at(d2[i], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+    mp_desc.append(d2)
+    mp_lvl.append(np.clip(octv[free] + rng.integers(0, 2, len(free)), 0, 7))
+    nrest = NP - len(shared) - len(free)
+    zr = rng.uniform(0.5, 10.0, nrest)
+    pr = np.stack([(rng.uniform(0, W, nrest) - cam.cx) / cam.fx * zr, (rng.uniform(0, H, nrest) - cam.cy) / cam.fy * zr, zr], 1)
+    mp_pos.append((pr - t) @ R)
+    mp_desc.append(rng.integers(0, 256, (nrest, 32), dtype=np.uint8))
+    mp_lvl.append(rng.integers(0, 8, nrest))
+    mp_pos, mp_desc, mp_lvl = np.concatenate(mp_pos), np.concatenate(mp_desc).astype(np.uint8), np.concatenate(mp_lvl).astype(int)
+    dist = np.linalg.norm(mp_pos - t_wc, axis=1)
+    max_dist = (dist * scale_factor ** (mp_lvl - 0.5)).astype(np.float32)  # predicted level = ceil(log(max / dist) / log(1.2)) = the level
+    min_dist = (max_dist / np.float32(scale_factor ** 7) * 0.5).astype(np.float32)
+    ray = (mp_pos - t_wc) / dist[:, None]
+    tilt = rng.standard_normal((NP, 3)) * 0.25
+    normal = ray + tilt
+    normal /= np.linalg.norm(normal, axis=1)[:, None]
+    cand = (rng.uniform(size=NP) < 0.95).astype(np.uint8)
+    return dict(feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_angle=angle, feat_desc=desc, feat_taken=taken, pose_lw=pose_lw, last_pt=last_pt,
+                last_valid=last_valid, last_oct=last_oct, last_angle=last_angle, last_desc=last_desc, last_to_local=last_to_local, mp_pos=mp_pos,
+                mp_normal=normal, mp_max_dist=max_dist, mp_min_dist=min_dist, mp_cand=cand, mp_desc=mp_desc, pose_cw=pose_pred, pose_true=pose_true)

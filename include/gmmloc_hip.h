@@ -115,6 +115,8 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   assoc_pack_mb (512; memory budget in MB of the packed cell table of a GMM created with this context, 0 = none),
  *   assoc_cell, assoc_globcells (> 0: cell size in metres / cell-count threshold of the index instead of the automatic ones),
  *   ba_fixed_pack (1: fixed observers of gl_track_frames_anchored always through the general kernel),
+ *   pipe_lanes, pipe_judge, schur_kper (-1 automatic; A/B switches of the pipelined local BA in batches: streams a call is split over,
+ *     the verdict on a trial as a kernel of its own, chunks per wave of the Schur pass - none changes a bit),
  *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
@@ -136,6 +138,10 @@ enum gl_counter {
   GL_COUNTER_MATCH_ROUNDS = 1, /* rounds of the owner fixed point, summed over the frames / pairs of gl_search_by_projection{,_frame},
                                   gl_search_for_triangulation, gl_search_by_bow (what the reference's order-dependent loop costs here) */
   GL_COUNTER_MATCH_UNITS = 2,  /* ... and the number of those frames / pairs */
+  GL_COUNTER_BA_COOP_FALLBACK = 3, /* windows of gl_joint_optimization (persistent kernel) that ran with ONE workgroup because even a single
+                                      window's cooperative launch was refused (another context holds the CUs): same arithmetic, but the
+                                      window's partial sums are added in another order - the one exception to "a window's bits depend on
+                                      its shape and bagen_mode only" (a refused sub-batch is first halved at the same workgroup count) */
   GL_COUNTER_COUNT = 4
 };
 int gl_ctx_counter_read(gl_ctx_t* ctx, int counter, int64_t* value, int reset);
@@ -329,6 +335,54 @@ int gl_search_local_points(gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
                            const double* mp_normal_dev, const float* mp_max_dist_dev, const float* mp_min_dist_dev,
                            const uint8_t* mp_cand_dev, const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
                            int32_t* nmatches_dev, uint8_t* inview_dev);
+
+/* One tracked frame, device resident (round 5): Tracking::trackWithMotionModel (tracking.cpp:326-376) -> Tracking::searchLocalPoints
+ * (:210-270) -> Tracking::trackLocalMap (:272-299) for B frames as ONE enqueued sequence on the context's stream - no host round trip
+ * between its four stages, every intermediate array stays in the context's scratch:
+ *   1  gl_search_by_projection_frame(th_mm, check_orientation = 1): ORBmatcher(0.9, true).searchByProjection(curr, last, 7); a frame
+ *      with fewer than 20 matches is searched again with 2 x th_mm (:335-342; the second launch skips the other frames)
+ *   2  gl_optimize_current_pose on the matched features (Xw = the last frame's map point), then the outliers lose their map point
+ *      and their is_outlier_ flag (:360-371)
+ *   3  gl_search_local_points from the refined pose (t_wc = -R^T t computed on the device): candidates = mp_cand minus the local map
+ *      points the frame has seen in stage 1 (inliers AND discarded outliers: last_visible_idx_ == idx, :243), features with a map
+ *      point are taken
+ *   4  gl_optimize_current_pose on all features with a map point (trackLocalMap, :276); its outliers are reported, not cleared.
+ * What the host keeps doing: num_visible_ / num_found_ / countObservations bookkeeping, the decision on counts[0] < 20 (tracking
+ * lost: the later stages' outputs of such a frame mean nothing).  All pointers are DEVICE pointers; layouts as in the four calls. */
+typedef struct gl_track_chain_io {
+  /* current frame: B x NF (x 2 / x 32) */
+  const double* feat_uv;
+  const float* feat_ur;
+  const int32_t* feat_oct;
+  const float* feat_angle;
+  const uint8_t* feat_desc;
+  const uint8_t* feat_taken; /* features that may not be matched at all (normally zeros) */
+  /* last frame: B x NL; last_to_local: index of the feature's map point in the local map below, or -1 */
+  const double* pose_lw;
+  const double* last_pt;
+  const uint8_t* last_valid;
+  const int32_t* last_oct;
+  const float* last_angle;
+  const uint8_t* last_desc;
+  const int32_t* last_to_local;
+  /* local map: B x NP */
+  const double* mp_pos;
+  const double* mp_normal;
+  const float* mp_max_dist;
+  const float* mp_min_dist;
+  const uint8_t* mp_cand;
+  const uint8_t* mp_desc;
+  /* in / out */
+  double* pose_cw;      /* B x 7: in the motion-model prediction, out the pose after trackLocalMap                                  */
+  double* pose_mm;      /* B x 7 out (may be NULL): the pose after stage 2                                                          */
+  int32_t* match_last;  /* B x NF out: last-frame feature kept after stage 2, or -1                                                 */
+  int32_t* match_local; /* B x NF out: local map point found in stage 3, or -1                                                      */
+  uint8_t* outlier;     /* B x NF out: is_outlier_ after stage 4                                                                    */
+  int32_t* counts;      /* B x 4 out: matches of stage 1 (after the retry), inliers of stage 2, matches of stage 3, inliers of stage 4 */
+  uint8_t* inview;      /* B x NP out (may be NULL): is_in_view_ of stage 3                                                         */
+} gl_track_chain_io;
+int gl_track_frame_chain(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, float scale_factor, int B, int NF, int NL, int NP,
+                         const gl_track_chain_io* io, float th_mm, float th_local, float nn_ratio, int mono);
 
 /* Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: per candidate map point the most
  * similar feature inside Frame::getFeaturesInArea(u, v, th * scale_factors[level]) (frame.cpp:121-177) with octave level - 1 or

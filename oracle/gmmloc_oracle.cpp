@@ -1747,6 +1747,14 @@ int orc_fuse_search(int width, int height, float scale_factor, int NF, const dou
 // pinhole_camera.cpp:46-66, 128-150, kMinimumDepth = 0) followed by MapPoint::checkScaleAndVisible (mappoint.cpp:257-303), one frame,
 // NP map points - the loop of Tracking::searchLocalPoints (tracking.cpp:233-256) / Localization::fuseObservations (:242-254).
 // cam: fx fy cx cy bf as the float config scalars.  cand[m]: the host's tests in front of the projection.  Returns the in-view count.
+// T_w_c.translation() of a pose T_cw (g2o SE3Quat::inverse: r = conj(q), t = r * (-t); Eigen's quaternion-vector product): what
+// Tracking::searchLocalPoints reads from curr_frame_->T_w_c_ (tracking.cpp:233) after the pose was set
+void orc_pose_twc(const double* pose_cw, double* t_wc) {
+  const double qi[4] = {-pose_cw[0], -pose_cw[1], -pose_cw[2], pose_cw[3]};
+  const double mt[3] = {pose_cw[4] * -1., pose_cw[5] * -1., pose_cw[6] * -1.};
+  quat_rot(qi, mt, t_wc);
+}
+
 int orc_project_map_points(const orc_camera* cam, float scale_factor, const double* pose_cw, const double* t_wc, int NP, const double* pos,
                            const double* normal, const float* max_dist_, const float* min_dist_, const uint8_t* cand, double* uvr_out,
                            int32_t* level_out, double* viewcos_out, double* dist_out, uint8_t* inview_out) {

@@ -280,6 +280,11 @@ class Oracle:
                                             _p(a[5]), _p(a[6]), _p(uvr), _p(lvl), _p(vc), _p(dd), _p(iv))
         return uvr, lvl, vc, dd, iv, int(n)
 
+    def pose_twc(self, pose_cw):
+        out = np.zeros(3)
+        self.lib.orc_pose_twc(_p(_f64(pose_cw)), _p(out))
+        return out
+
     def se3_exp(self, u):
         out = np.zeros(7)
         self.lib.orc_se3_exp(_p(_f64(u)), _p(out))

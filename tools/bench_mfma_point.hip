@@ -34,24 +34,12 @@ __device__ __forceinline__ void mm3_valu(const double* X, const double* Y, doubl
     for (int j = 0; j < 3; ++j) Z[i * 3 + j] = fma(X[i * 3], Y[j], fma(X[i * 3 + 1], Y[3 + j], X[i * 3 + 2] * Y[6 + j]));
 }
 
-// Where the elements of the 4 x 4 operands sit in a block of 16 lanes is not assumed but PROBED on the device: with one 1.0 in A (lane la)
-// and one in B (lane lb) the result has a 1.0 in at most one lane; the 256 combinations give, up to a relabelling of i, j, k that a
-// product does not see, the lane of A[i][k], of B[k][j] and of D[i][j].
-struct Maps {
-  int a[16], b[16], d[16];  // position (lane within the block) of A[i][k] at [i * 4 + k], of B[k][j] at [k * 4 + j], of D[i][j] at [i * 4 + j]
-};
-__global__ void k_probe(int* hit) {  // hit[la * 16 + lb] = lane of block 0 with a non-zero result, or -1
-  const int lane = threadIdx.x;
-  for (int la = 0; la < 16; ++la)
-    for (int lb = 0; lb < 16; ++lb) {
-      const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(lane == la ? 1.0 : 0.0, lane == lb ? 1.0 : 0.0, 0.0, 0, 0, 0);
-      const unsigned long long m = __ballot(d != 0.0) & 0xffffull;
-      if (lane == 0) hit[la * 16 + lb] = m ? __ffsll((long long)m) - 1 : -1;
-    }
-}
-
+// Lane layout of v_mfma_f64_4x4x4_4b_f64, PROBED on an MI355X (tools/probe_mfma_layout.hip, profiles/r5_mfma_layout_probe.txt): the four
+// blocks are NOT four groups of 16 consecutive lanes.  With k = lane / 16, b = (lane / 4) % 4, e = lane % 4:
+//     A_b[i = e][k] and B_b[k][j = e] sit in lane 16 k + 4 b + e;   D_b[i][j] comes out in lane 16 i + 4 b + j.
+// A point's 4 x 4 operand is therefore spread over four lanes in each of the wave's four 16-lane rows.
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void k(double* out, long long* cyc, int iters, int filler, Maps mp) {
+__global__ __launch_bounds__(512, 2) void k(double* out, long long* cyc, int iters, int filler) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // per wave: operands 64 points x 2 x 16 doubles (padded 4 x 4); the results overwrite the first operand (every address is read
   // and written by the same lane)
@@ -102,32 +90,27 @@ __global__ __launch_bounds__(512, 2) void k(double* out, long long* cyc, int ite
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int kk = 0; kk < 3; ++kk) {
-            wX[lane * 16 + mp.a[i * 4 + kk]] = X[i * 3 + kk];
-            wY[lane * 16 + mp.b[kk * 4 + i]] = Y[kk * 3 + i];
+            wX[lane * 16 + i * 4 + kk] = X[i * 3 + kk];   // A[i][k] at [point][i * 4 + k]
+            wY[lane * 16 + kk * 4 + i] = Y[kk * 3 + i];   // B[k][j] at [point][k * 4 + j]  (B = Y: B[k][j] = Y[k][j], here j = i)
           }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // 16 MFMAs, 4 points each: lane (b = lane / 16, e = lane % 16) reads element e of point 4 g + b
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-          const int pt = 4 * g + (lane >> 4), e = lane & 15;
-          const double a = wX[pt * 16 + e], b = wY[pt * 16 + e];
-          const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
-          wZ[pt * 16 + e] = d;
+          const int pt = 4 * g + ((lane >> 2) & 3), e = lane & 3, kq = lane >> 4;
+          const double a = wX[pt * 16 + e * 4 + kq], b = wY[pt * 16 + kq * 4 + e];   // A[i = e][k], B[k][j = e]
+          const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);   // lane holds D[i = kq][j = e] of its point
+          wZ[pt * 16 + kq * 4 + e] = d;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) Z[i * 3 + j] += wZ[lane * 16 + mp.d[i * 4 + j]];
+          for (int j = 0; j < 3; ++j) Z[i * 3 + j] += wZ[lane * 16 + i * 4 + j];
         Y[p] += 1e-9;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // (the results overwrote the first operand's image: its padding - row / column 3 - must read 0.0 again; the 3 x 3 part is
-        // rewritten by the next product)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          wX[lane * 16 + mp.a[3 * 4 + j]] = 0.0;
-          if (j < 3) wX[lane * 16 + mp.a[j * 4 + 3]] = 0.0;
-        }
+        // (the results overwrote the first operand's image in the same [i * 4 + j] layout: row / column 3 of a product of operands
+        // padded with zeros are zero again, nothing to clear)
       }
     } else if (MODE == 2) {
 #pragma unroll
@@ -184,11 +167,11 @@ __global__ __launch_bounds__(512, 2) void k(double* out, long long* cyc, int ite
 }
 
 template <int MODE>
-static void run(const char* name, int iters, int filler, double* out, long long* cyc, double* hout, long long* hcyc, const Maps& mp) {
+static void run(const char* name, int iters, int filler, double* out, long long* cyc, double* hout, long long* hcyc) {
   const int NB = 256;
   const size_t lds = 8 * 64 * 16 * 2 * sizeof(double);  // 128 KB: one workgroup per CU
   (void)hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k<MODE><<<NB, 512, lds>>>(out, cyc, 10, filler, mp);  // warm-up
+  k<MODE><<<NB, 512, lds>>>(out, cyc, 10, filler);  // warm-up
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     printf("launch failed: %s\n", name);
     return;
@@ -197,7 +180,7 @@ static void run(const char* name, int iters, int filler, double* out, long long*
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   hipEventRecord(e0);
-  k<MODE><<<NB, 512, lds>>>(out, cyc, iters, filler, mp);
+  k<MODE><<<NB, 512, lds>>>(out, cyc, iters, filler);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms = 0;
@@ -219,84 +202,15 @@ int main(int argc, char** argv) {
   long long *cyc, *hcyc = (long long*)malloc(256 * 8 * sizeof(long long));
   hipMalloc(&out, sizeof(double) * 256 * 512);
   hipMalloc(&cyc, sizeof(long long) * 256 * 8);
-  Maps mp;
-  {
-    int *dh, hh[256];
-    hipMalloc(&dh, sizeof(hh));
-    k_probe<<<1, 64>>>(dh);
-    hipMemcpy(hh, dh, sizeof(hh), hipMemcpyDeviceToHost);
-    // k-classes of the A lanes (by the set of B lanes they meet); the first class names i (its A lanes, in order) and j (its B lanes)
-    int ka[16], kb[16], nk = 0, ia[16], jb[16];
-    for (int l = 0; l < 16; ++l) ka[l] = kb[l] = ia[l] = jb[l] = -1;
-    for (int la = 0; la < 16; ++la) {
-      if (ka[la] >= 0) continue;
-      for (int l2 = 0; l2 < 16; ++l2) {
-        bool same = true;
-        for (int lb = 0; lb < 16; ++lb) same = same && ((hh[la * 16 + lb] >= 0) == (hh[l2 * 16 + lb] >= 0));
-        if (same) ka[l2] = nk;
-      }
-      for (int lb = 0; lb < 16; ++lb)
-        if (hh[la * 16 + lb] >= 0) kb[lb] = nk;
-      ++nk;
-    }
-    int dlane[4][4], ni = 0, nj = 0;
-    for (int la = 0; la < 16; ++la)
-      if (ka[la] == 0) ia[la] = ni++;
-    for (int lb = 0; lb < 16; ++lb)
-      if (kb[lb] == 0) jb[lb] = nj++;
-    for (int la = 0; la < 16; ++la)
-      for (int lb = 0; lb < 16; ++lb)
-        if (ka[la] == 0 && kb[lb] == 0) dlane[ia[la]][jb[lb]] = hh[la * 16 + lb];
-    for (int la = 0; la < 16; ++la)
-      for (int lb = 0; lb < 16; ++lb) {
-        const int ld = hh[la * 16 + lb];
-        if (ld < 0) continue;
-        for (int i = 0; i < 4; ++i)
-          for (int j = 0; j < 4; ++j)
-            if (dlane[i][j] == ld) {
-              if (ia[la] < 0 && kb[lb] >= 0 && jb[lb] == j) ia[la] = i;
-              if (jb[lb] < 0 && ia[la] == i) jb[lb] = j;
-            }
-      }
-    // (second sweep: lanes whose partner was not labelled yet in the first)
-    for (int rep = 0; rep < 3; ++rep)
-      for (int la = 0; la < 16; ++la)
-        for (int lb = 0; lb < 16; ++lb) {
-          const int ld = hh[la * 16 + lb];
-          if (ld < 0) continue;
-          for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j)
-              if (dlane[i][j] == ld) {
-                if (ia[la] < 0) ia[la] = i;
-                if (jb[lb] < 0) jb[lb] = j;
-              }
-        }
-    bool ok = nk == 4 && ni == 4 && nj == 4;
-    for (int l = 0; l < 16; ++l) ok = ok && ia[l] >= 0 && jb[l] >= 0 && ka[l] >= 0 && kb[l] >= 0;
-    for (int l = 0; l < 16 && ok; ++l) {
-      mp.a[ia[l] * 4 + ka[l]] = l;
-      mp.b[kb[l] * 4 + jb[l]] = l;
-    }
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) mp.d[i * 4 + j] = dlane[i][j];
-    printf("# probed lane layout of v_mfma_f64_4x4x4_4b within a block (%s): A[i][k] at lane", ok ? "consistent" : "INCONSISTENT");
-    for (int e = 0; e < 16; ++e) printf(" %d", mp.a[e]);
-    printf(" | B[k][j] at");
-    for (int e = 0; e < 16; ++e) printf(" %d", mp.b[e]);
-    printf(" | D[i][j] at");
-    for (int e = 0; e < 16; ++e) printf(" %d", mp.d[e]);
-    printf("\n");
-    hipFree(dh);
-  }
   printf("# tools/bench_mfma_point.hip: per 64 points (one wave slot), %d 3 x 3 products per point; 256 workgroups x 8 waves, %d iterations;\n", NPROD, iters);
   printf("# 'filler' = independent fp64 FMA chains of the same wave per iteration (a slot of pass A is ~400 instructions = 100 quads).\n");
   printf("# Columns are WHOLE-ITERATION times; a form that overlaps with the VALU shows as less than filler + its own time at filler 0.\n");
   for (int filler : {0, 100}) {
-    run<0>("VALU: 27 v_fma_f64 per product and lane", iters, filler, out, cyc, hout, hcyc, mp);
-    run<1>("v_mfma_f64_4x4x4_4b + LDS layout change (= results)", iters, filler, out, cyc, hout, hcyc, mp);
-    run<2>("v_mfma_f64_4x4x4_4b pipe alone (16 per product)", iters, filler, out, cyc, hout, hcyc, mp);
-    run<4>("pose block, VALU: pose_terms + 27 adds", iters, filler, out, cyc, hout, hcyc, mp);
-    run<3>("pose block, 48 x v_mfma_f64_4x4x4_4b pipe alone", iters, filler, out, cyc, hout, hcyc, mp);
+    run<0>("VALU: 27 v_fma_f64 per product and lane", iters, filler, out, cyc, hout, hcyc);
+    run<1>("v_mfma_f64_4x4x4_4b + LDS layout change (= results)", iters, filler, out, cyc, hout, hcyc);
+    run<2>("v_mfma_f64_4x4x4_4b pipe alone (16 per product)", iters, filler, out, cyc, hout, hcyc);
+    run<4>("pose block, VALU: pose_terms + 27 adds", iters, filler, out, cyc, hout, hcyc);
+    run<3>("pose block, 48 x v_mfma_f64_4x4x4_4b pipe alone", iters, filler, out, cyc, hout, hcyc);
   }
   return 0;
 }
