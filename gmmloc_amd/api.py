@@ -211,8 +211,10 @@ class GMM:
         idx = torch.empty(N, dtype=torch.int32, device=pts.device)
         d2 = torch.empty(N, dtype=torch.float64, device=pts.device) if want_d2 else None
         self.ctx._enter()
-        _check(self.lib.gl_associate3d(self.ctx.h, self.h, _ptr(pts), N, mode, _ptr(idx), _ptr(d2)))
-        self.ctx._exit()
+        try:
+            _check(self.lib.gl_associate3d(self.ctx.h, self.h, _ptr(pts), N, mode, _ptr(idx), _ptr(d2)))
+        finally:
+            self.ctx._exit()
         return idx, d2
 
     def index_info(self):
@@ -231,8 +233,10 @@ class GMM:
         import torch
         out = torch.zeros(1, dtype=torch.int64, device=pts.device)
         self.ctx._enter()
-        _check(self.lib.gl_assoc_index_work(self.ctx.h, self.h, _ptr(pts), pts.shape[0], _ptr(out)))
-        self.ctx._exit()
+        try:
+            _check(self.lib.gl_assoc_index_work(self.ctx.h, self.h, _ptr(pts), pts.shape[0], _ptr(out)))
+        finally:
+            self.ctx._exit()
         return int(out.item())
 
     def knn3d(self, pts, k=5):
@@ -241,8 +245,10 @@ class GMM:
         idx = torch.empty((N, k), dtype=torch.int32, device=pts.device)
         dist = torch.empty((N, k), dtype=torch.float64, device=pts.device)
         self.ctx._enter()
-        _check(self.lib.gl_knn3d(self.ctx.h, self.h, _ptr(pts), N, k, _ptr(idx), _ptr(dist)))
-        self.ctx._exit()
+        try:
+            _check(self.lib.gl_knn3d(self.ctx.h, self.h, _ptr(pts), N, k, _ptr(idx), _ptr(dist)))
+        finally:
+            self.ctx._exit()
         return idx, dist
 
     def queryPoint(self, pts):
@@ -272,9 +278,11 @@ def optimize_current_pose(ctx, cam, prm, pose, Xw, obs, octave, outlier=None):
         outlier = torch.zeros((B, M), dtype=torch.uint8, device=pose.device)
     nin = torch.zeros(B, dtype=torch.int32, device=pose.device)
     ctx._enter()
-    _check(ctx.lib.gl_optimize_current_pose(ctx.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
-                                            _ptr(obs), _ptr(octave), _ptr(outlier), _ptr(nin)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_optimize_current_pose(ctx.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
+                                                _ptr(obs), _ptr(octave), _ptr(outlier), _ptr(nin)))
+    finally:
+        ctx._exit()
     return outlier, nin
 
 
@@ -288,9 +296,11 @@ def track_frames(ctx, gmm, cam, prm, pose, Xw, obs, octave, want_d2=True):
     assoc = torch.empty((B, M), dtype=torch.int32, device=pose.device)
     d2 = torch.empty((B, M), dtype=torch.float64, device=pose.device) if want_d2 else None
     ctx._enter()
-    _check(ctx.lib.gl_track_frames(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
-                                   _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_track_frames(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
+                                       _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2)))
+    finally:
+        ctx._exit()
     return assoc, d2
 
 
@@ -309,9 +319,11 @@ def track_frames_anchored(ctx, gmm, cam, prm, pose, Xw, obs, octave, prior=None,
     erase = torch.zeros((B, M, F), dtype=torch.uint8, device=pose.device) if (want_erase and F) else None
     an = _lib.gl_track_anchor(_ptr(prior), F, _ptr(fixed_pose), _ptr(fixed_obs), _ptr(fixed_oct), _ptr(erase))
     ctx._enter()
-    _check(ctx.lib.gl_track_frames_anchored(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
-                                            _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2), C.byref(an)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_track_frames_anchored(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, M, _ptr(pose), _ptr(Xw),
+                                                _ptr(obs), _ptr(octave), _ptr(assoc), _ptr(d2), C.byref(an)))
+    finally:
+        ctx._exit()
     return assoc, d2, erase
 
 
@@ -381,9 +393,11 @@ def _gmm_search2d(self, cam, pose, uv, nfeat=None, k=5, view_cap=0):
     vids = torch.empty((B, view_cap), dtype=torch.int32, device=uv.device) if view_cap else None
     nview = torch.empty(B, dtype=torch.int32, device=uv.device) if view_cap else None
     self.ctx._enter()
-    _check(self.lib.gl_search2d(self.ctx.h, self.h, C.byref(cam.c()), B, _ptr(pose), N, _ptr(uv), _ptr(nfeat), k,
-                                _ptr(cand), _ptr(ncand), view_cap, _ptr(vids), _ptr(nview)))
-    self.ctx._exit()
+    try:
+        _check(self.lib.gl_search2d(self.ctx.h, self.h, C.byref(cam.c()), B, _ptr(pose), N, _ptr(uv), _ptr(nfeat), k,
+                                    _ptr(cand), _ptr(ncand), view_cap, _ptr(vids), _ptr(nview)))
+    finally:
+        self.ctx._exit()
     return cand, ncand, vids, nview
 
 
@@ -400,10 +414,12 @@ def optimize_point(ctx, gmm, cam, prm, pts, uvr, octave, pose, comp, proj_z2):
     c2s = torch.empty(N, dtype=torch.float64, device=dev)
     est = torch.empty((N, 3), dtype=torch.float64, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_optimize_point(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), N, _ptr(pts), _ptr(uvr),
-                                     _ptr(octave), _ptr(pose), _ptr(comp), _ptr(proj_z2), _ptr(res), _ptr(c2p),
-                                     _ptr(c2s), _ptr(est)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_optimize_point(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), N, _ptr(pts), _ptr(uvr),
+                                         _ptr(octave), _ptr(pose), _ptr(comp), _ptr(proj_z2), _ptr(res), _ptr(c2p),
+                                         _ptr(c2s), _ptr(est)))
+    finally:
+        ctx._exit()
     return res, c2p, c2s, est
 
 
@@ -414,9 +430,11 @@ def check_map_association(ctx, gmm, cam, prm, pose, pts, uvr, octave, cand, ncan
     B, N, k = cand.shape
     out = torch.empty((B, N), dtype=torch.int32, device=pts.device)
     ctx._enter()
-    _check(ctx.lib.gl_check_map_association(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, N, _ptr(pose),
-                                            _ptr(pts), _ptr(uvr), _ptr(octave), _ptr(cand), _ptr(ncand), k, _ptr(out)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_check_map_association(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, N, _ptr(pose),
+                                                _ptr(pts), _ptr(uvr), _ptr(octave), _ptr(cand), _ptr(ncand), k, _ptr(out)))
+    finally:
+        ctx._exit()
     return out
 
 
@@ -426,10 +444,12 @@ def optimize_triangulation(ctx, gmm, cam, prm, x3d, pose1, uvr1, oct1, pose2, uv
     N, k = cand1.shape
     out = torch.empty(N, dtype=torch.int32, device=x3d.device)
     ctx._enter()
-    _check(ctx.lib.gl_optimize_triangulation(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), N, _ptr(x3d),
-                                             _ptr(pose1), _ptr(uvr1), _ptr(oct1), _ptr(pose2), _ptr(uvr2), _ptr(oct2),
-                                             _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k, _ptr(out)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_optimize_triangulation(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), N, _ptr(x3d),
+                                                 _ptr(pose1), _ptr(uvr1), _ptr(oct1), _ptr(pose2), _ptr(uvr2), _ptr(oct2),
+                                                 _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k, _ptr(out)))
+    finally:
+        ctx._exit()
     return out
 
 
@@ -446,17 +466,19 @@ def joint_optimization(ctx, gmm, cam, prm, P, F, poses, prior, points, assoc, ob
     erase = torch.zeros((B, NOBS), dtype=torch.uint8, device=dev)
     iters = torch.zeros(B, dtype=torch.int32, device=dev)
     ctx._enter()
-    if stop_flag is None:
-        _check(ctx.lib.gl_joint_optimization(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
-                                             _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
-                                             _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
-                                             _ptr(iters)))
-    else:
-        _check(ctx.lib.gl_joint_optimization_stoppable(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
-                                                       _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
-                                                       _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
-                                                       _ptr(iters), _ptr(stop_flag)))
-    ctx._exit()
+    try:
+        if stop_flag is None:
+            _check(ctx.lib.gl_joint_optimization(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
+                                                 _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
+                                                 _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
+                                                 _ptr(iters)))
+        else:
+            _check(ctx.lib.gl_joint_optimization_stoppable(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), B, P, F, L, NOBS,
+                                                           _ptr(poses), _ptr(prior), _ptr(points), _ptr(assoc), _ptr(obs_ptr),
+                                                           _ptr(obs_pose), _ptr(obs_uvr), _ptr(obs_oct), _ptr(dropped), _ptr(erase),
+                                                           _ptr(iters), _ptr(stop_flag)))
+    finally:
+        ctx._exit()
     return dropped, erase, iters
 
 
@@ -470,11 +492,13 @@ def search_by_projection(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_t
     match = torch.empty((B, NF), dtype=torch.int32, device=feat_oct.device)
     nm = torch.empty(B, dtype=torch.int32, device=feat_oct.device)
     ctx._enter()
-    _check(ctx.lib.gl_search_by_projection(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv),
-                                           _ptr(feat_ur), _ptr(feat_oct), _ptr(feat_desc), _ptr(feat_taken), _ptr(mp_uvr),
-                                           _ptr(mp_level), _ptr(mp_viewcos), _ptr(mp_valid), _ptr(mp_desc), float(th),
-                                           float(nn_ratio), _ptr(match), _ptr(nm)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_search_by_projection(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv),
+                                               _ptr(feat_ur), _ptr(feat_oct), _ptr(feat_desc), _ptr(feat_taken), _ptr(mp_uvr),
+                                               _ptr(mp_level), _ptr(mp_viewcos), _ptr(mp_valid), _ptr(mp_desc), float(th),
+                                               float(nn_ratio), _ptr(match), _ptr(nm)))
+    finally:
+        ctx._exit()
     return match, nm
 
 
@@ -490,11 +514,13 @@ def search_local_points(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, feat_ta
     nm = torch.empty(B, dtype=torch.int32, device=dev)
     inview = torch.empty((B, NP), dtype=torch.uint8, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_search_local_points(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
-                                          _ptr(feat_desc), _ptr(feat_taken), _ptr(pose_cw), _ptr(t_wc), _ptr(mp_pos), _ptr(mp_normal),
-                                          _ptr(mp_max_dist), _ptr(mp_min_dist), _ptr(mp_cand), _ptr(mp_desc), float(th), float(nn_ratio),
-                                          _ptr(match), _ptr(nm), _ptr(inview)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_search_local_points(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
+                                              _ptr(feat_desc), _ptr(feat_taken), _ptr(pose_cw), _ptr(t_wc), _ptr(mp_pos), _ptr(mp_normal),
+                                              _ptr(mp_max_dist), _ptr(mp_min_dist), _ptr(mp_cand), _ptr(mp_desc), float(th), float(nn_ratio),
+                                              _ptr(match), _ptr(nm), _ptr(inview)))
+    finally:
+        ctx._exit()
     return match, nm, inview
 
 
@@ -561,6 +587,15 @@ def search_by_projection_frame(ctx, cam, pose_cw, pose_lw, feat_uv, feat_ur, fea
 
 
 KF_KEYS = ("uv", "ur", "oct", "angle", "desc", "has_mp", "nnode", "node_id", "node_ptr", "node_idx")
+KF_DTYPES = {"uv": "float64", "ur": "float32", "oct": "int32", "angle": "float32", "desc": "uint8", "has_mp": "uint8", "nnode": "int32",
+             "node_id": "int32", "node_ptr": "int32", "node_idx": "int32"}
+
+
+def _check_kf(kf, name, keys=KF_KEYS):
+    """the key-frame tensors go to the library as raw pointers: a wrong dtype or a strided view would be read as garbage"""
+    for k in keys:
+        t, dt = kf[k], KF_DTYPES[k]
+        assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch." + dt, "%s[%r]: expected a contiguous CUDA %s tensor, got %s" % (name, k, dt, t.dtype)
 
 
 def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, check_orientation=True, scale_factor=1.2):
@@ -573,14 +608,19 @@ def search_for_triangulation(ctx, kf1, kf2, fmat, epipole, only_stereo=False, ch
     N2 = kf2["oct"].shape[1]
     NN1, NN2 = kf1["node_id"].shape[1], kf2["node_id"].shape[1]
     assert kf1["node_ptr"].shape[1] == NN1 + 1 and kf2["node_ptr"].shape[1] == NN2 + 1
+    _check_kf(kf1, "kf1")
+    _check_kf(kf2, "kf2")
+    assert str(fmat.dtype) == "torch.float64" and str(epipole.dtype) == "torch.float32"
     dev = kf1["oct"].device
     match = torch.empty((B, N1), dtype=torch.int32, device=dev)
     nm = torch.empty(B, dtype=torch.int32, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_search_for_triangulation(ctx.h, float(scale_factor), B, N1, N2, NN1, NN2, *[_ptr(kf1[k]) for k in KF_KEYS],
-                                               *[_ptr(kf2[k]) for k in KF_KEYS], _ptr(fmat), _ptr(epipole), int(bool(only_stereo)),
-                                               int(bool(check_orientation)), _ptr(match), _ptr(nm)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_search_for_triangulation(ctx.h, float(scale_factor), B, N1, N2, NN1, NN2, *[_ptr(kf1[k]) for k in KF_KEYS],
+                                                   *[_ptr(kf2[k]) for k in KF_KEYS], _ptr(fmat), _ptr(epipole), int(bool(only_stereo)),
+                                                   int(bool(check_orientation)), _ptr(match), _ptr(nm)))
+    finally:
+        ctx._exit()
     return match, nm
 
 
@@ -604,10 +644,12 @@ def project_map_points(ctx, cam, pose_cw, t_wc, pos, normal, max_dist, min_dist,
     dist = torch.empty((B, NP), dtype=torch.float64, device=dev)
     inview = torch.empty((B, NP), dtype=torch.uint8, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_project_map_points(ctx.h, C.byref(cam.c()), float(scale_factor), B, NP, _ptr(pose_cw), _ptr(t_wc), _ptr(pos), _ptr(normal),
-                                         _ptr(max_dist), _ptr(min_dist), _ptr(cand), _ptr(uvr), _ptr(level), _ptr(viewcos), _ptr(dist),
-                                         _ptr(inview)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_project_map_points(ctx.h, C.byref(cam.c()), float(scale_factor), B, NP, _ptr(pose_cw), _ptr(t_wc), _ptr(pos), _ptr(normal),
+                                             _ptr(max_dist), _ptr(min_dist), _ptr(cand), _ptr(uvr), _ptr(level), _ptr(viewcos), _ptr(dist),
+                                             _ptr(inview)))
+    finally:
+        ctx._exit()
     return uvr, level, viewcos, dist, inview
 
 
@@ -621,9 +663,11 @@ def fuse_search(ctx, cam, feat_uv, feat_ur, feat_oct, feat_desc, mp_uvr, mp_leve
     bi = torch.empty((B, NP), dtype=torch.int32, device=feat_oct.device)
     bd = torch.empty((B, NP), dtype=torch.int32, device=feat_oct.device)
     ctx._enter()
-    _check(ctx.lib.gl_fuse_search(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
-                                  _ptr(feat_desc), _ptr(mp_uvr), _ptr(mp_level), _ptr(mp_valid), _ptr(mp_desc), float(th), _ptr(bi), _ptr(bd)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_fuse_search(ctx.h, C.byref(cam.c()), float(scale_factor), B, NF, NP, _ptr(feat_uv), _ptr(feat_ur), _ptr(feat_oct),
+                                      _ptr(feat_desc), _ptr(mp_uvr), _ptr(mp_level), _ptr(mp_valid), _ptr(mp_desc), float(th), _ptr(bi), _ptr(bd)))
+    finally:
+        ctx._exit()
     return bi, bd
 
 
@@ -637,15 +681,19 @@ def search_by_bow(ctx, kf, fr, nn_ratio=0.7, check_orientation=True):
     N2 = fr["angle"].shape[1]
     NN1, NN2 = kf["node_id"].shape[1], fr["node_id"].shape[1]
     assert kf["node_ptr"].shape[1] == NN1 + 1 and fr["node_ptr"].shape[1] == NN2 + 1
+    _check_kf(kf, "kf", ("angle", "desc", "has_mp", "nnode", "node_id", "node_ptr", "node_idx"))
+    _check_kf(fr, "fr", ("angle", "desc", "nnode", "node_id", "node_ptr", "node_idx"))
     dev = kf["angle"].device
     match = torch.empty((B, N2), dtype=torch.int32, device=dev)
     nm = torch.empty(B, dtype=torch.int32, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_search_by_bow(ctx.h, float(nn_ratio), int(bool(check_orientation)), B, N1, N2, NN1, NN2,
-                                    *[_ptr(kf[k]) for k in ("angle", "desc", "has_mp", "nnode", "node_id", "node_ptr", "node_idx")],
-                                    *[_ptr(fr[k]) for k in ("angle", "desc", "nnode", "node_id", "node_ptr", "node_idx")],
-                                    _ptr(match), _ptr(nm)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_search_by_bow(ctx.h, float(nn_ratio), int(bool(check_orientation)), B, N1, N2, NN1, NN2,
+                                        *[_ptr(kf[k]) for k in ("angle", "desc", "has_mp", "nnode", "node_id", "node_ptr", "node_idx")],
+                                        *[_ptr(fr[k]) for k in ("angle", "desc", "nnode", "node_id", "node_ptr", "node_idx")],
+                                        _ptr(match), _ptr(nm)))
+    finally:
+        ctx._exit()
     return match, nm
 
 
@@ -657,7 +705,7 @@ def gather_triangulation_matches(ctx, match12, nmatches, side1, side2, cap=None)
     B, N1 = match12.shape
     N2 = side2["oct"].shape[1]
     k = side1["cand"].shape[2]
-    cap = cap or B * min(N1, N2)
+    cap = cap if cap is not None else B * min(N1, N2)
     dev = match12.device
     off = torch.empty(B + 1, dtype=torch.int32, device=dev)
     m = dict(pose1=torch.zeros((cap, 7), dtype=torch.float64, device=dev), uvr1=torch.zeros((cap, 3), dtype=torch.float64, device=dev),
@@ -670,10 +718,12 @@ def gather_triangulation_matches(ctx, match12, nmatches, side1, side2, cap=None)
              idx2=torch.full((cap,), -1, dtype=torch.int32, device=dev))
     keys = ("pose", "uv", "ur", "depth", "oct", "cand", "ncand")
     ctx._enter()
-    _check(ctx.lib.gl_gather_triangulation_matches(
-        ctx.h, B, N1, N2, k, cap, _ptr(match12), _ptr(nmatches), *[_ptr(side1[q]) for q in keys], *[_ptr(side2[q]) for q in keys], _ptr(off),
-        *[_ptr(m[q]) for q in ("pose1", "uvr1", "depth1", "oct1", "cand1", "n1", "pose2", "uvr2", "depth2", "oct2", "cand2", "n2", "pair", "idx1", "idx2")]))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_gather_triangulation_matches(
+            ctx.h, B, N1, N2, k, cap, _ptr(match12), _ptr(nmatches), *[_ptr(side1[q]) for q in keys], *[_ptr(side2[q]) for q in keys], _ptr(off),
+            *[_ptr(m[q]) for q in ("pose1", "uvr1", "depth1", "oct1", "cand1", "n1", "pose2", "uvr2", "depth2", "oct2", "cand2", "n2", "pair", "idx1", "idx2")]))
+    finally:
+        ctx._exit()
     return off, m
 
 
@@ -688,9 +738,11 @@ def create_map_points(ctx, gmm, cam, prm, pose1, uvr1, depth1, oct1, pose2, uvr2
     typ = torch.empty(N, dtype=torch.int32, device=dev)
     comp = torch.empty(N, dtype=torch.int32, device=dev)
     ctx._enter()
-    _check(ctx.lib.gl_create_map_points(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), N,
-                                        _ptr(pose1), _ptr(uvr1), _ptr(depth1), _ptr(oct1), _ptr(pose2), _ptr(uvr2),
-                                        _ptr(depth2), _ptr(oct2), _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k,
-                                        _ptr(x3d), _ptr(typ), _ptr(comp)))
-    ctx._exit()
+    try:
+        _check(ctx.lib.gl_create_map_points(ctx.h, gmm.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), N,
+                                            _ptr(pose1), _ptr(uvr1), _ptr(depth1), _ptr(oct1), _ptr(pose2), _ptr(uvr2),
+                                            _ptr(depth2), _ptr(oct2), _ptr(cand1), _ptr(n1), _ptr(cand2), _ptr(n2), k,
+                                            _ptr(x3d), _ptr(typ), _ptr(comp)))
+    finally:
+        ctx._exit()
     return x3d, typ, comp

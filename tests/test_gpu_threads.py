@@ -119,11 +119,11 @@ def test_two_contexts_oversubscribe_the_latency_shape(gpu, map_v1, gt_sync):
 
 def test_frame_latency_bounded_next_to_local_ba(gpu, map_v1, gt_sync):
     """The reference runs tracking and the local BA on two threads over one GPU-resident map.  Here a second context keeps
-    launching gl_joint_optimization windows back-to-back (8 + 4 key-frames, 1 500 points, the default route: >= 5 000
+    launching gl_joint_optimization windows back-to-back (8 + 4 key-frames, 1 500 points, the default route: >= 3 000
     observations, i.e. the pipelined shape - five kernels per Levenberg cycle that take the whole chip in turn) while this thread calls the frame-at-a-time path (gl_track_frame_host, latency shape) 300
     times.  A frame whose workgroups cannot meet within ba_rendezvous_us (200 us) falls back to the one-workgroup kernel
-    (~0.5 ms): the worst frame stays far below the reference's 50 ms frame budget - p99 < 2 ms - and every answer is the
-    same bits as on an idle GPU."""
+    (~0.5 ms): p99 stays below 2 x the idle latency + the rendezvous limit + one BA window + 1 ms (about 4 ms; 2 ms expected) -
+    far below the reference's 50 ms frame budget - and every answer is the same bits as on an idle GPU."""
     import time
     torch, ctx0 = gpu
     mean, cov = map_v1
@@ -145,6 +145,10 @@ def test_frame_latency_bounded_next_to_local_ba(gpu, map_v1, gt_sync):
     for f in frames:  # warm
         one(f)
     idle = np.array([one(frames[i % 4])[0] for i in range(100)])
+    run_gpu((torch, ctx0), g, cam, prm, [prob], [a])  # one BA window alone (warm, then timed): what a frame can queue behind at most
+    t0 = time.perf_counter()
+    run_gpu((torch, ctx0), g, cam, prm, [prob], [a])
+    ba_alone_s = time.perf_counter() - t0
     stop, errors, windows = threading.Event(), [], [0]
 
     def ba_main():
@@ -177,9 +181,15 @@ def test_frame_latency_bounded_next_to_local_ba(gpu, map_v1, gt_sync):
     print("frame latency ms: idle median %.3f | next to %d BA windows: median %.3f p99 %.3f max %.3f, %d of 300 frames redone by the follow-up kernel"
           % (1e3 * np.median(idle), w, np.median(lat), lat[int(0.99 * len(lat))], lat[-1], redone))
     assert w >= 3  # the BA thread really ran alongside
-    # the bit-equality above is the hard assertion; the latency is a property of THIS box at THIS moment: a hard
-    # bound at the reference's 50 ms frame budget, a warning at the 2 ms that an otherwise idle MI355X shows
-    assert lat[int(0.99 * len(lat))] < 50.0, lat[-10:]
-    if lat[int(0.99 * len(lat))] >= 2.0:
+    # the bit-equality above is the hard assertion.  The latency bound is tied to the MECHANISM: a frame that meets the
+    # local BA either runs beside it (idle latency) or loses its rendezvous - then it waits out the time limit of the exchange
+    # (ba_rendezvous_us) and is redone by the follow-up kernel (another frame's worth) - and in both cases queues behind at most
+    # one persistent BA kernel of this window (measured alone above).  A tenfold regression of any of these parts fails here; a busy
+    # box (other tenants' processes) only warns below that.
+    p99, idle_med = lat[int(0.99 * len(lat))], 1e3 * float(np.median(idle))
+    bound = 2.0 * idle_med + 1e-3 * ctx0.get_option("ba_rendezvous_us") + 1e3 * ba_alone_s + 1.0
+    assert p99 < bound, (p99, bound, lat[-10:])
+    assert redone <= 150  # the fallback is the exception, not the rule (half of the frames at most even next to back-to-back windows)
+    if p99 >= 2.0:
         import warnings
-        warnings.warn("frame latency p99 %.3f ms next to the local BA (2 ms expected on an idle GPU)" % lat[int(0.99 * len(lat))])
+        warnings.warn("frame latency p99 %.3f ms next to the local BA (2 ms expected on an idle GPU)" % p99)
