@@ -32,6 +32,35 @@ struct FixedV {
   double* chif;        // B x F x L
   uint8_t* ferase;     // B x L x F (caller's order) or null
 };
+// the ONE argument of k_ba1_fast (the kernel re-reads its fields from the kernel-argument segment for every frame it draws)
+struct BafKArgs {
+  glba::BaK k;
+  glba::GmmDev gm;
+  int B, L, G, S;
+  double* pose_io;
+  double* pts_io;
+  int32_t* assoc_all;
+  uint8_t* dropped_all;
+  uint8_t* erase_all;
+  int32_t* iters_out;
+  double* pn_all;
+  int32_t* trials_out;
+  int NB;
+  unsigned long long* parts;
+  int* ctl;
+  long long limit;
+  int xcc_trusted;
+  const int32_t* oct_all;
+  const uint8_t* prior_all;
+  const double* prior_mi;
+  double* stage;
+  int nb_prev;
+  int32_t* counters;
+  int32_t* outer_out;
+  FixedV fxv;
+  int32_t* edges_out;
+  int* frame_ctr;
+};
 __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
   PrepView v;
   const size_t n = (size_t)B * L;
@@ -58,10 +87,11 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
                                                     const double* __restrict__ pose_all, const uint8_t* __restrict__ prior_all,
                                                     double* __restrict__ prior_mi, int F, const double* __restrict__ fpose_all,
                                                     const double* __restrict__ fobs_all, const int32_t* __restrict__ foct_all, double* __restrict__ fRt,
-                                                    double* __restrict__ fobn, int32_t* __restrict__ foct, double* __restrict__ chif) {
+                                                    double* __restrict__ fobn, int32_t* __restrict__ foct, double* __restrict__ chif, int* __restrict__ frame_ctr) {
   __shared__ int cnt[PREP_C][PREP_T / 64];  // non-degenerate-component points per (round, wave)
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (f >= B) return;
+  if (frame_ctr && f == 0 && tid == 0) *frame_ctr = 0;  // the queue the refine's persistent workgroups draw their frames from
   if (xwords) {  // latency shape next: this frame's exchange words and {abort, done} start at zero (no separate memset)
     for (int i = tid; i < nxw; i += PREP_T) xwords[(size_t)f * nxw + i] = 0ull;
     if (tid < 2) xctl[2 * f + tid] = 0;
@@ -415,8 +445,7 @@ static void canon_order(int L, int* G, int* S) {
   *S = (nch + *G - 1) / *G;
 }
 
-typedef void (*BafKernel)(BaK, GmmDev, int, int, int, int, double*, double*, int32_t*, uint8_t*, uint8_t*, int32_t*, double*, int32_t*, int,
-                          unsigned long long*, int*, long long, int, const int32_t*, const uint8_t*, const double*, double*, int, int32_t*, int32_t*, FixedV, int32_t*);
+typedef void (*BafKernel)(BafKArgs);
 
 struct BafArgs {
   BaK k;
@@ -433,6 +462,7 @@ struct BafArgs {
   int32_t* stats;
   int32_t* stats_iters = nullptr;
   int32_t* stats_edges = nullptr;
+  int* fctr = nullptr;  // frame queue of the persistent DENSE workgroups (in the launch scratch, zeroed by k_ba1_prep), or null: plain launch
   int NB;
   unsigned long long* parts;
   int* ctl = nullptr;  // per frame {abort, done} of a latency-shape launch (the follow-up DENSE launch skips the done ones)
@@ -460,8 +490,25 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;
-  kern<<<a.B, 64 * a.G, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats,
-                                          a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior, a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx, a.stats_edges);
+  // persistent workgroups (option ba_persist, default on): as many as the device holds at once, drawing frames from a.fctr
+  int grid = a.B;
+  int* fctr = nullptr;
+  if (c->opt.ba_persist != 0 && a.fctr) {
+    const auto key = std::make_pair((const void*)kern, lds + (size_t)(64 * a.G));
+    auto hit = c->occupancy.find(key);
+    if (hit == c->occupancy.end()) {
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * a.G, lds) != hipSuccess) occ = 0;
+      hit = c->occupancy.emplace(key, occ).first;
+    }
+    if (hit->second > 0 && (long)hit->second * c->ncu < (long)a.B) {
+      grid = hit->second * c->ncu;
+      fctr = a.fctr;
+    }
+  }
+  const BafKArgs ka{a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior,
+                    a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx, a.stats_edges, fctr};
+  kern<<<grid, 64 * a.G, lds, c->stream>>>(ka);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -499,8 +546,9 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   if (c->opt.ba_test_abort_seq > 0) limit = -(long long)c->opt.ba_test_abort_seq;  // tests: a give-up in the middle of the schedule
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
-  kern<<<grid, 256, lds, c->stream>>>(a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB,
-                                      a.parts, a.ctl, limit, (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx, a.stats_edges);
+  const BafKArgs ka{a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB, a.parts, a.ctl, limit,
+                    (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx, a.stats_edges, nullptr};
+  kern<<<grid, 256, lds, c->stream>>>(ka);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete
 }
@@ -555,10 +603,11 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
     const int nxw = 2 * a.G * 64;
     // inverse measurements of the prior edges: behind the records, the exchange words and {abort, done} (ba1_scratch_bytes)
     a.prior_mi = (double*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64 + (size_t)B * (8192 + 8) + 64);
+    a.fctr = (int*)((char*)scratch + (((size_t)B * L * 36 + 63) / 64) * 64 + (size_t)B * (8192 + 8));  // (first word of the 64-byte pad in front of them)
     if (spread) a.stage = (double*)(a.prior_mi + (size_t)B * 12);  // {points B x L x 3 | pose B x 8 | association B x L}
     k_ba1_prep<<<B, PREP_T, 0, c->stream>>>(a.k, a.gm, B, L, obs, oct, assoc, d2, (double*)scratch, xw, xw ? (int*)(xw + (size_t)B * nxw) : nullptr, nxw,
                                             pose, prior, (double*)a.prior_mi, F, F ? fixed->pose : nullptr, F ? fixed->obs : nullptr,
-                                            F ? fixed->oct : nullptr, fRt, fobn, foct, chif);
+                                            F ? fixed->oct : nullptr, fRt, fobn, foct, chif, a.fctr);
   }
   GL_HIP(hipGetLastError());
   TimerScope ts(c, GL_TIMER_BA);  // the refine kernel proper

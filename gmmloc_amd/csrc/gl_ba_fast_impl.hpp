@@ -58,6 +58,18 @@ constexpr bool kFixed = true;   // instance with fixed observer key-frames (gl_t
 #else                           // edges of the frame's points with FIXED pose vertices (localization_opt.cpp:491-516, 706-760)
 constexpr bool kFixed = false;
 #endif
+#ifndef GL_BAF_DYNB
+#define GL_BAF_DYNB 0  // measured (profiles/r5_ab_dynb.txt): same bits, the waves end pass B together - and the refine takes 10 % LONGER
+#endif
+#ifndef GL_BAF_DYNB_PRIO
+#define GL_BAF_DYNB_PRIO 1
+#endif
+// DENSE, exact step: the chunks of pass B are dealt DYNAMICALLY (optimize_fast); not with the fp32 cache, whose words fill the slot
+constexpr bool kDynB = !kSpread && !kStep32 && GL_BAF_DYNB != 0;
+#ifndef GL_BAF_ASYM
+#define GL_BAF_ASYM 0
+#endif
+constexpr bool kAsym = GL_BAF_ASYM != 0 && GL_BAF_NW == 8;  // uneven deal of the chunks over the two waves of a SIMD (slot_off)
 #ifndef GL_BAF_ALLSOLVE
 #define GL_BAF_ALLSOLVE 0  // measured (profiles/r5_ab_allsolve.txt): same bits, refine 10.80 -> 11.09 ms per 4 096 frames - seven more waves issuing the ~350 dependent instructions cost more than the hand-over they save
 #endif
@@ -81,11 +93,25 @@ __device__ double g_trace[10 * 128];
 #endif
 #ifdef GL_BA_PROF
 __device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof_k[16];  // a frame in the middle of the launch (block 1024): clock64 at the stations of the kernel; [12] lambda-init cycles
+#define PROF_K(i) if (blockIdx.x == 1024 && threadIdx.x == 0) g_prof_k[i] = (unsigned long long)clock64()
+#define PROF_KADD(i, t0, t1) if (blockIdx.x == 1024 && threadIdx.x == 0) g_prof_k[i] += (unsigned long long)((t1) - (t0))
 __device__ unsigned long long g_prof_w[64 * 8 * 4];  // [trial < 64][wave][marker]: clock64 at pass-A end, after reduce A, pass-B start, pass-B end
 #define PROF_W(trial, marker) \
   if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (trial) < 64) g_prof_w[((trial)*8 + (threadIdx.x >> 6)) * 4 + (marker)] = (unsigned long long)clock64()
+// [trial < 16][wave][pass A / B][slot 0 .. 3 start, pass end]: where inside a pass a wave's time goes (tools/prof_ba.py)
+__device__ unsigned long long g_prof_s[16 * 8 * 2 * 5];
+// [trial < 16][wave][pass][slot][0: the slot's global loads have arrived, 1: step half done (pass B), 2: slot done]
+__device__ unsigned long long g_prof_q[10 * 8 * 2 * 4 * 3];
+#define PROF_Q(trial, pass, slot, m) \
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (trial) >= 6 && (trial) < 16 && (slot) < 4 && (pass) < 2) \
+  g_prof_q[(((((trial) - 6) * 8 + (int)(threadIdx.x >> 6)) * 2 + (pass)) * 4 + (slot)) * 3 + (m)] = (unsigned long long)clock64()
+#define PROF_S(trial, pass, slot) \
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (trial) < 16 && (slot) < 5 && (pass) < 2) g_prof_s[(((trial)*8 + (threadIdx.x >> 6)) * 2 + (pass)) * 5 + (slot)] = (unsigned long long)clock64()
 #else
 #define PROF_W(trial, marker)
+#define PROF_S(trial, pass, slot)
+#define PROF_Q(trial, pass, slot, m)
 #endif
 #ifndef PROF_T
 #ifdef GL_BA_PROF
@@ -94,6 +120,8 @@ __device__ unsigned long long g_prof_w[64 * 8 * 4];  // [trial < 64][wave][marke
 #else
 #define PROF_T(var)
 #define PROF_ADD(slot, t0, t1)
+#define PROF_K(i)
+#define PROF_KADD(i, t0, t1)
 #endif
 #endif
 
@@ -244,16 +272,23 @@ struct Lds {      // per-frame state, SoA over MCAP points (index = local point 
   int F, Lf;
 };
 // per-point flag bits + octave (bits 8..10) live in REGISTERS: 16 bits per point slot of the thread
-typedef unsigned long long FlagW;
-GL_DEV int fw_get(FlagW fw, int i) { return (int)((fw >> (16 * i)) & 0xffffull); }
-GL_DEV void fw_or(FlagW& fw, int i, int bits) { fw |= (FlagW)bits << (16 * i); }
+struct FlagW {  // slots 0..3 in `lo`, slot 4 (the fifth chunk of a big group, GL_BAF_ASYM) in `hi`
+  unsigned long long lo;
+  unsigned hi;
+};
+GL_DEV int fw_get(const FlagW& fw, int i) { return i < 4 ? (int)((fw.lo >> (16 * i)) & 0xffffull) : (int)(fw.hi & 0xffffu); }
+GL_DEV void fw_or(FlagW& fw, int i, int bits) {
+  if (i < 4) fw.lo |= (unsigned long long)bits << (16 * i);
+  else fw.hi |= (unsigned)bits;
+}
 GL_DEV void fw_activity(FlagW& fw, int i) {
   const int fl = fw_get(fw, i);
   int act = 0;
   if ((fl & F_EXISTS) && !(fl & F_LEVR)) act |= F_AR;
   if ((fl & F_EXISTS) && (fl & F_ASSOC) && !(fl & F_LEVG)) act |= F_AG;
   if (kFixed && (fl & F_EXISTS) && ((fl / F_OFFF) & 15) != 15) act |= F_AF;
-  fw = (fw & ~((FlagW)(F_AR | F_AG | F_AF) << (16 * i))) | ((FlagW)act << (16 * i));
+  if (i < 4) fw.lo = (fw.lo & ~((unsigned long long)(F_AR | F_AG | F_AF) << (16 * i))) | ((unsigned long long)act << (16 * i));
+  else fw.hi = (fw.hi & ~(unsigned)(F_AR | F_AG | F_AF)) | (unsigned)act;
 }
 
 // the canonical order of a frame of stride L and this thread's place in it
@@ -263,7 +298,15 @@ struct Map {
   int lbase;  // LDS index of the first point (DENSE: = base; SPREAD: threadIdx.x)
   int step;   // 64 G: the chunks of a group are G apart
   int L;      // points of the frame
+  bool asym;  // GL_BAF_ASYM, frames of 8 groups: the groups 0..3 take five chunks, the groups 4..7 three (slot_off)
 };
+// Offset of slot i from the thread's first point.  Frames of 8 groups (29 .. 32 chunks: the 2 000-point class), GL_BAF_ASYM: the two
+// waves of a SIMD do not run at the same speed - the arbiter serves the older one first, the younger one fills the gaps, and once
+// the older one is through its chunks the younger runs ALONE at half the issue rate (its dependent chains have nobody to hide
+// behind): a third of every pass.  The chunks are therefore dealt unevenly: rounds 0..2 one chunk to each of the 8 groups (chunk
+// 8 r + g), rounds 3 and 4 only to the groups 0..3 (chunk 24 + 4 (r - 3) + g): the older wave of every SIMD has five chunks,
+// the younger three, and they end their passes together (profiles/r5_prof_ba_slots.txt).  Still a function of L alone.
+GL_DEV int slot_off(const Map& mp, int i) { return !mp.asym ? mp.step * i : (i < 3 ? 512 * i : 1536 + 256 * (i - 3)); }
 
 struct Lin {
   double q[3];
@@ -789,6 +832,14 @@ struct SinkSet {
   GL_DEV void put(int i, double v) const { a[i] = v; }
 };
 
+// pass B with the chunks dealt dynamically: a point's two terms wait in the free half of its slot (doubles 3 and 4: the factors have
+// been read, the backup takes 0..2) for the thread that OWNS the point in the canonical order
+struct SinkSlot {
+  double* un;
+  int ll;
+  GL_DEV void put(int i, double v) const { un[(3 + i) * MCAP + ll] = v; }
+};
+
 // terms 0..20 <- upper(G^T C G), 21..26 <- G^T c,  G = [-[q]x | I], C symmetric (sym6)
 template <class Sink>
 GL_DEV void pose_terms(const double* q, const double* C, const double* c, bool with_rhs, const Sink& sk) {
@@ -1249,14 +1300,39 @@ GL_DEV bool load_pt(const Lds& D, const Map& mp, FlagW fw, const double* __restr
                     const int32_t* __restrict__ gassoc, int i, PtCtx& c) {
   c.fl = fw_get(fw, i);
   if (!(c.fl & (F_AR | F_AG | F_AF))) return false;
-  c.l = mp.base + mp.step * i;
-  c.ll = mp.lbase + mp.step * i;
+  c.l = mp.base + slot_off(mp, i);
+  c.ll = mp.lbase + slot_off(mp, i);
 #pragma unroll
   for (int j = 0; j < 3; ++j) c.ob[j] = gobn[(size_t)c.l * 3 + j];
   const int a = gassoc[c.l];
   const int ap = a > 0 ? a : 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];  // plane normal n and n . mean: the map's table, by component
+  c.ar = c.fl & F_AR;
+  c.ag = c.fl & F_AG;
+  c.af = kFixed && (c.fl & F_AF);
+  const int oc = (c.fl >> 8) & 7;
+  c.sx = D.stab[oc];
+  c.sy = D.stab[8 + oc];
+  c.asc = (c.fl & F_ASSOC) && !(c.fl & F_DEG) ? a : -1;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.p[j] = D.sp[j * MCAP + c.ll];
+  return true;
+}
+
+// the same for point l with its flag word from memory (pass B, chunks dealt dynamically)
+GL_DEV bool load_pt_at(const Lds& D, int l, int fl, const double* __restrict__ gobn, const double* __restrict__ gnd,
+                       const int32_t* __restrict__ gassoc, PtCtx& c) {
+  c.fl = fl;
+  if (!(c.fl & (F_AR | F_AG | F_AF))) return false;
+  c.l = l;
+  c.ll = l;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.ob[j] = gobn[(size_t)c.l * 3 + j];
+  const int a = gassoc[c.l];
+  const int ap = a > 0 ? a : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.nd[j] = gnd[(size_t)ap * 4 + j];
   c.ar = c.fl & F_AR;
   c.ag = c.fl & F_AG;
   c.af = kFixed && (c.fl & F_AF);
@@ -1509,12 +1585,28 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 #define GL_BAF_PRIO_PASS_BEGIN() \
   if (NWC == 8 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(2)
 #define GL_BAF_PRIO_SLOT(i) \
-  if (NWC == 8 && (threadIdx.x >> 6) < 4 && (i) == GL_BAF_PRIO_DROP) __builtin_amdgcn_s_setprio(0)
+  if (NWC == 8 && (threadIdx.x >> 6) < 4 && (i) == (mp.asym ? GL_BAF_PRIO_DROP_ASYM : GL_BAF_PRIO_DROP)) __builtin_amdgcn_s_setprio(0)
+#endif
+#if defined(GL_BAF_NO_PRIO)
+#define GL_BAF_PRIO_PASS_END()
+#else
+#define GL_BAF_PRIO_PASS_END() \
+  if (NWC == 8 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(1)  /* a dynamically dealt pass: every wave at the same priority */
+#endif
+#ifndef GL_BAF_PRIO_DROP_ASYM
+#define GL_BAF_PRIO_DROP_ASYM 4
 #endif
 #ifndef GL_BAF_PRIO_DROP
 #define GL_BAF_PRIO_DROP 3
 #endif
 
+#if defined(GL_BA_PROF) && defined(GL_BA_PROF_LOADS)  // (diagnosis only: the wait changes the schedule of the slot's head)
+#define GL_BAF_PROF_LOADS(i)          \
+  __builtin_amdgcn_s_waitcnt(0);      \
+  PROF_Q(trials, prof_pass, i, 0)
+#else
+#define GL_BAF_PROF_LOADS(i)
+#endif
 // one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
 // point's terms there (zeros when the thread has no active point)
 #define GL_BAF_PASS(BODY)                                                     \
@@ -1522,6 +1614,8 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
     _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) acc[i_] = 0.0;          \
     if (kSpread) {                                                            \
       const SinkSet sk{acc};                                                  \
+      const int i = 0;                                                        \
+      (void)i;                                                                \
       PtCtx c;                                                                \
       if (load_pt_const(D, mp, fw, pc, c)) { BODY; }                          \
     } else {                                                                  \
@@ -1529,9 +1623,12 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
       GL_BAF_PRIO_PASS_BEGIN();                                               \
       _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
         GL_BAF_PRIO_SLOT(i);                                                  \
+        PROF_S(trials, prof_pass, i);                                         \
         PtCtx c;                                                              \
         if (!load_pt(D, mp, fw, gobn, gnd, gassoc, i, c)) continue;               \
+        GL_BAF_PROF_LOADS(i);                                                 \
         BODY;                                                                 \
+        PROF_Q(trials, prof_pass, i, 2);                                      \
       }                                                                       \
     }                                                                         \
   }
@@ -1539,7 +1636,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 // SparseOptimizer::optimize(iters), Levenberg
 GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map& mp, FlagW fw, Pose& P,
                          const double* __restrict__ gobn, const int32_t* __restrict__ gassoc, const double* __restrict__ gnd,
-                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, Anchor& An) {
+                         const PtConst& pc, bool robust, int iters, const Red& R, int& trials, Coop& C, Anchor& An, const int32_t* gpfl) {
   double acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -1566,10 +1663,13 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
 
   double lambda = 0.0, ni = 2.0;
   int cj = 0;
+  int prof_pass = 2;  // (GL_BA_PROF: which pass the slot markers belong to; 2 = the lambda initialisation, not recorded)
+  (void)prof_pass;
   for (int it = 0; it < iters; ++it) {
     double rho = 0.0, currentChi = 0.0;
     int qmax = 0;
     if (it == 0) {  // computeLambdaInit
+      PROF_T(tL0);
       double md = 0.0;
       GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
@@ -1584,11 +1684,15 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       md = reduce_max(md, R, C);
       lambda = uni(1e-5 * md);
       ni = 2.0;
+      PROF_T(tL1);
+      PROF_KADD(12, tL0, tL1);
     }
     do {
       PROF_T(tA0);
       // ---- pass A ---------------------------------------------------------------------------
+      prof_pass = 0;
       GL_BAF_PASS(pt_pass_a(U, gm, D, P, c, robust, lambda, sk));
+      PROF_S(trials, 0, 4);
       PROF_T(tA1);
       PROF_W(trials, 0);
       if (kSpread) spread_reduce29_w0(acc, R, C);
@@ -1644,6 +1748,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
           for (int i = 0; i < 6; ++i) bc[19 + i] = acc[21 + i];  // reduced rhs g and sum u.b, for computeScale
           bc[25] = acc[28];
           bc[26] = acc[27];  // robust chi2 at the linearisation point
+          if (kDynB) *(int*)(D.stab + 20) = 0;  // pass B's chunk queue
         }
       }
       __syncthreads();
@@ -1680,13 +1785,58 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) Pn.t[i_] = uni(bc[15 + i_]);                \
     have_pn = true;                                                                              \
   }
+      prof_pass = 1;
+      if (kDynB) {
+        // The chunks of pass B are dealt DYNAMICALLY: a wave that is through a chunk takes the next one from a counter in LDS.  The
+        // two waves of a SIMD do not run at the same speed (the arbiter serves the older one first), and with four fixed chunks each
+        // the older one is done a third of the pass before the younger, which then runs alone at half the issue rate
+        // (profiles/r5_prof_ba_slots.txt).  Which wave evaluates a point does not show in the result: the point's two terms wait in
+        // its slot, and the thread that OWNS the point in the canonical order adds them - in the same order as ever - behind a barrier.
+        // The flag word of a point it does not own comes from the launch scratch (bits 16..31 of pfl, kept current by the owners).
+        const int nch = (mp.L + 63) >> 6;
+        volatile int* qc = (volatile int*)(D.stab + 20);
+#if GL_BAF_DYNB_PRIO == 0
+        GL_BAF_PRIO_PASS_END();
+#else
+        GL_BAF_PRIO_PASS_BEGIN();  // the older wave of a SIMD keeps the higher priority: it just takes more of the chunks
+#endif
+#pragma unroll 1
+        for (;;) {
+          int cq = 0;
+          if ((threadIdx.x & 63) == 0) cq = atomicAdd((int*)qc, 1);
+          cq = __builtin_amdgcn_readfirstlane(cq);
+          if (cq >= nch) break;
+          const int l = cq * 64 + (int)(threadIdx.x & 63);
+          const int fl = l < mp.L ? (int)((unsigned)__hip_atomic_load(gpfl + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) : 0;
+          PtCtx c;
+          if (!load_pt_at(D, l, fl, gobn, gnd, gassoc, c)) continue;
+          const SinkSlot sk{D.un, c.ll};
+          double pn[3];
+          pt_pass_b_step(U, gm, D, P, dx, c, pn, sk);
+          GL_BAF_GET_PN();
+          pt_pass_b_eval(U, gm, D, Pn, c, pn, robust, sk);
+        }
+        GL_BAF_GET_PN();
+        __syncthreads();
+        acc[0] = acc[1] = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < mp.S; ++i) {  // level 1 of the canonical order: the owner adds its points' terms in slot order
+          if (!(fw_get(fw, i) & (F_AR | F_AG | F_AF))) continue;
+          const int ll = mp.lbase + slot_off(mp, i);
+          acc[0] = add_nc(acc[0], D.un[3 * MCAP + ll]);
+          acc[1] = add_nc(acc[1], D.un[4 * MCAP + ll]);
+        }
+      } else {
       GL_BAF_PASS({
         double pn[3];
         pt_pass_b_step(U, gm, D, P, dx, c, pn, sk);
+        PROF_Q(trials, 1, i, 1);
         GL_BAF_GET_PN();
         pt_pass_b_eval(U, gm, D, Pn, c, pn, robust, sk);
       });
       GL_BAF_GET_PN();  // (a wave without an active point still takes the pose: P = Pn on acceptance)
+      }
+      PROF_S(trials, 1, 4);
 #undef GL_BAF_GET_PN
       if (prior_on && (int)(threadIdx.x >> 6) == An.wave) prior_record_wave(An.mi, Pn, An.rec + (An.cur ^ 1) * 32, An.work, An.rezero);
       PROF_T(tB1);
@@ -1721,7 +1871,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
         for (int i = 0; i < ns; ++i) {  // discardTop: restore the backed-up points
-          if (fw_get(fw, i) & (F_AR | F_AG | F_AF)) restore_point(D, mp.lbase + mp.step * i);
+          if (fw_get(fw, i) & (F_AR | F_AG | F_AF)) restore_point(D, mp.lbase + slot_off(mp, i));
         }
       }
       qmax++;
@@ -1743,16 +1893,42 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
 // (cooperative launch when G > 1).  G, S: the canonical order of stride L (launcher: canon_order()).  The frame's points
 // are addressed through the permutation k_ba1_prep made (points associated with a NON-degenerate component last), so
 // "point l" below is the l-th point of that order; pts_io / assoc_all are read and written through perm.
-__global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmDev gm, int B, int L, int G, int S, double* __restrict__ pose_io,
-                                                  double* __restrict__ pts_io, int32_t* __restrict__ assoc_all,
-                                                  uint8_t* __restrict__ dropped_all, uint8_t* __restrict__ erase_all,
-                                                  int32_t* __restrict__ iters_out, double* __restrict__ pn_all,
-                                                  int32_t* __restrict__ trials_out, int NB, unsigned long long* parts, int* ctl, long long limit, int xcc_trusted,
-                                                  const int32_t* __restrict__ oct_all,
-                                                  const uint8_t* __restrict__ prior_all, const double* __restrict__ prior_mi, double* __restrict__ stage, int nb_prev,
-                                                  int32_t* __restrict__ counters, int32_t* __restrict__ outer_out, FixedV fxv,
-                                                  int32_t* __restrict__ edges_out) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+// (the body of the kernel: ONE frame - `fblock` is the block index of the plain launch, or the frame a persistent workgroup has drawn)
+// a struct out of the kernel-argument segment (constant address space), word by word (scalar loads)
+template <class T>
+GL_DEV T ld_karg(const T __attribute__((address_space(4)))* p) {
+  static_assert(sizeof(T) % 4 == 0, "");
+  union U {
+    T v;
+    unsigned w[sizeof(T) / 4];
+    GL_DEV U() {}
+  } u;
+  const unsigned __attribute__((address_space(4)))* q = (const unsigned __attribute__((address_space(4)))*)p;
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) u.w[i] = q[i];
+  return u.v;
+}
+
+typedef const BafKArgs __attribute__((address_space(4))) kargs_t;
+GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
+  // the arguments the set-up and the passes use; the caller's OUTPUT arrays are read from the argument segment again where the
+  // results are written (an opaque copy of the pointer: the compiler may not keep those ten pointers live across the passes)
+  const BaK __attribute__((address_space(4)))& k = ka->k;
+  const GmmDev gm = ld_karg(&ka->gm);
+  const FixedV fxv = ld_karg(&ka->fxv);
+  const int B = ka->B, L = ka->L, G = ka->G, S = ka->S, NB = ka->NB, xcc_trusted = ka->xcc_trusted, nb_prev = ka->nb_prev;
+  double* const pose_io = ka->pose_io;
+  double* const pts_io = ka->pts_io;
+  int32_t* const assoc_all = ka->assoc_all;
+  double* const pn_all = ka->pn_all;
+  unsigned long long* const parts = ka->parts;
+  int* const ctl = ka->ctl;
+  const long long limit = ka->limit;
+  const int32_t* const oct_all = ka->oct_all;
+  const uint8_t* const prior_all = ka->prior_all;
+  const double* const prior_mi = ka->prior_mi;
+  double* const stage = ka->stage;
+  int32_t* const counters = ka->counters;
   Lds D;
   D.sp = smem;                      // 3 * MCAP
   D.chir = D.sp + 3 * MCAP;         // MCAP
@@ -1776,12 +1952,17 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   D.gfoct = nullptr;
   D.gchif = nullptr;
   R.S = S;
-  FlagW fw = 0;
+  FlagW fw = {0ull, 0u};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  PROF_K(0);
+#ifdef GL_BA_PROF
+  if (blockIdx.x == 1024 && threadIdx.x == 0) g_prof_k[12] = 0;
+  const unsigned long long prof_wg_t0 = wall_clock64();  // (100 MHz, the same counter on every CU)
+#endif
   // SPREAD: the workgroups of a frame are given block indices that are equal modulo 8, which is what puts them on ONE XCD
   // on this hardware (observed, not promised: a matter of speed only) - block 8 k + x is group k % 8 of frame x + 8 (k / 8)
-  const int f = kSpread ? (NB > 1 ? (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 6) : (int)blockIdx.x) : (int)blockIdx.x;
-  const int pb_ = kSpread && NB > 1 ? (int)((blockIdx.x >> 3) & 7) : 0;
+  const int f = kSpread ? (NB > 1 ? (int)(fblock & 7) + 8 * (int)(fblock >> 6) : (int)fblock) : (int)fblock;
+  const int pb_ = kSpread && NB > 1 ? (int)((fblock >> 3) & 7) : 0;
   if (f >= B || pb_ >= NB) return;
   // latency-shape launches write to a staging area {points B x L x 3 | pose B x 7 (stride 8) | association B x L}
   double* const st_pts = stage;
@@ -1826,12 +2007,14 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   mp.L = L;
   if (kSpread) {  // workgroup pb = group pb; wave = slot; idle waves beyond S
     mp.S = 1;
+    mp.asym = false;
     mp.base = wave < S && C.pb < G ? (C.pb + G * wave) * 64 + lane : L;  // chunk g + G slot of group g
     mp.lbase = tid;
     mp.step = 0;
   } else {
-    mp.S = S;
-    mp.base = wave * 64 + lane;  // group = wave: chunks wave, wave + G, ...
+    mp.asym = kAsym && G == 8;
+    mp.S = mp.asym ? (wave < 4 ? 5 : 3) : S;
+    mp.base = wave * 64 + lane;  // group = wave: chunks wave, wave + G, ... (slot_off)
     mp.lbase = mp.base;
     mp.step = 64 * G;
   }
@@ -1862,19 +2045,21 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     const int ns = kSpread ? 1 : mp.S;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
-      const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
+      const int l = mp.base + slot_off(mp, i), ll = mp.lbase + slot_off(mp, i);
       if (l >= L) break;
       const size_t g = gbase + gperm[l];
 #pragma unroll
       for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = pts_io[g * 3 + j];
       D.chir[ll] = 0.0;
-      fw_or(fw, i, pv.pfl[gbase + l]);
+      const int pfl0 = pv.pfl[gbase + l] & 0xffff;  // (bits 16..31: the current flag word of an earlier launch on this scratch)
+      fw_or(fw, i, pfl0);
       if (kFixed) {  // edges the point does not have (not observed by that key-frame / no such key-frame) count as inactive
 #pragma unroll
         for (int kf = 0; kf < kMaxFixed; ++kf)
           if (kf >= D.F || D.gfoct[(size_t)kf * L + l] < 0) fw_or(fw, i, F_OFFF << kf);
       }
       fw_activity(fw, i);
+      if (kDynB) pv.pfl[gbase + l] = pfl0 | (fw_get(fw, i) << 16);  // the current flag word, for whichever wave takes the point in pass B
     }
   }
   PtConst pc;
@@ -1919,14 +2104,16 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
   // edges, robust kernels off -> optimize(40).  One rolled phase loop = one copy of the optimiser code.
   int it3 = 0, trials = 0, outer = 0;
   const int ns = kSpread ? 1 : mp.S;
+  PROF_K(1);
 #pragma unroll 1
   for (int phase = 0; phase < 3; ++phase) {
-    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, pc, phase < 2, phase < 2 ? 5 : 40, R, trials, C, An);
+    it3 = optimize_fast(U, gm, D, mp, fw, P, gobn, gassoc, gnd, pc, phase < 2, phase < 2 ? 5 : 40, R, trials, C, An, pv.pfl + gbase);
     outer += it3 > 0 ? it3 : 0;
+    PROF_K(2 + 2 * phase);
     if (phase == 2) break;
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
-      const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
+      const int l = mp.base + slot_off(mp, i), ll = mp.lbase + slot_off(mp, i);
       if (l >= L) break;
       const int fl = fw_get(fw, i);
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
@@ -1952,8 +2139,10 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
         }
       }
       fw_activity(fw, i);
+      if (kDynB) pv.pfl[gbase + l] = (pv.pfl[gbase + l] & 0xffff) | (fw_get(fw, i) << 16);
     }
     __syncthreads();
+    PROF_K(3 + 2 * phase);
   }
 
   if (kSpread && C.NB > 1) {  // a frame whose workgroups lost each other writes nothing: the follow-up launch redoes it
@@ -1961,12 +2150,28 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     C.failed |= *C.lds_fail;
     if (C.failed) return;
   }
+  {  // ---- outputs ----
   const bool staged = kSpread && C.NB > 1;  // (results of a latency-shape launch go through the staging area)
+  kargs_t* kb = ka;
+  asm volatile("" : "+s"(kb));
+  double* const pose_io = kb->pose_io;  // (these shadow the set-up's copies)
+  double* const pts_io = kb->pts_io;
+  int32_t* const assoc_all = kb->assoc_all;
+  uint8_t* const dropped_all = kb->dropped_all;
+  uint8_t* const erase_all = kb->erase_all;
+  int32_t* const iters_out = kb->iters_out;
+  int32_t* const trials_out = kb->trials_out;
+  int32_t* const outer_out = kb->outer_out;
+  int32_t* const edges_out = kb->edges_out;
+  double* const stage_o = kb->stage;
+  double* const st_pts = stage_o;
+  double* const st_pose = stage_o ? stage_o + (size_t)B * L * 3 : nullptr;
+  int32_t* const st_assoc = stage_o ? (int32_t*)(st_pose + (size_t)B * 8) : nullptr;
   double* const pts_out = staged ? st_pts : pts_io;
   int32_t* const assoc_out = staged ? st_assoc : assoc_all;
 #pragma unroll 1
   for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
-    const int l = mp.base + mp.step * i, ll = mp.lbase + mp.step * i;
+    const int l = mp.base + slot_off(mp, i), ll = mp.lbase + slot_off(mp, i);
     if (l >= L) break;
     const size_t g = gbase + gperm[l];  // back to the caller's order
     const int fl = fw_get(fw, i);
@@ -2016,6 +2221,10 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
     } else {
       se3_store(T, staged ? st_pose + (size_t)f * 8 : pose_io + (size_t)f * 7);
     }
+    PROF_K(8);
+#ifdef GL_BA_PROF
+    if (f == 1024) g_prof_k[9] = (unsigned long long)trials;
+#endif
     if (iters_out) iters_out[f] = it3;
     if (trials_out) trials_out[f] = trials;
     if (outer_out) outer_out[f] = outer;
@@ -2031,13 +2240,59 @@ __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BaK k, GmmD
 #ifdef GL_BA_PROF
     if (f == 0) {  // debug build only: phase cycles instead of pose 0, per-wave markers instead of the points of frame 0
       for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections
+    }
+    if (f != 0 && f != 1024 && !kSpread) {  // every other frame: when and where its workgroup ran, in place of its pose (tools/prof_ba.py: CU timelines)
+      pose_io[(size_t)f * 7] = (double)prof_wg_t0;
+      pose_io[(size_t)f * 7 + 1] = (double)wall_clock64();
+      pose_io[(size_t)f * 7 + 2] = (double)((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0xffffff) | ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) << 24));
+      pose_io[(size_t)f * 7 + 3] = (double)trials;
+    }
+    if (f == 1024) {  // (the stations of THIS frame go out in place of its pose and first points)
+      for (int i = 0; i < 7; ++i) pose_io[(size_t)f * 7 + i] = (double)g_prof_k[i];
+      for (int i = 7; i < 13; ++i) pts_io[(size_t)f * L * 3 + (i - 7)] = (double)g_prof_k[i];
+    }
+    if (f == 0) {
       for (int i = 0; i < 64 * 8 * 4 && i < L * 3; ++i) pts_io[i] = (double)g_prof_w[i];
+      for (int i = 0; i < 16 * 8 * 2 * 5 && 2048 + i < L * 3; ++i) pts_io[2048 + i] = (double)g_prof_s[i];
+      for (int i = 0; i < 10 * 8 * 2 * 4 * 3 && 2048 + 1280 + i < L * 3; ++i) pts_io[2048 + 1280 + i] = (double)g_prof_q[i];
     }
 #endif
   }
   if (kSpread && C.ctl) {  // this workgroup's share of the frame is in place: count it done (the follow-up kernel wants all NB)
     __syncthreads();  // (the counter is read by the NEXT kernel on the stream: the kernel boundary publishes the staged results)
     if (tid == 0) __hip_atomic_fetch_add(C.ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  }
+}
+
+// DENSE: <<<min(B, frames the device holds at once), 64 G>>> PERSISTENT workgroups that draw their frames from a counter (frame_ctr,
+// zeroed by k_ba1_prep): a workgroup of the largest class owns a whole CU, and between two workgroups of a plain launch that CU sat
+// idle for 16 us (median; 48 us mean: workgroup timelines of profiles/r5_prof_ba_stations.txt) - 6 % of the launch.  Which workgroup
+// takes a frame shows nowhere in its result.  SPREAD (and frame_ctr == nullptr): the plain launch, one block per (frame, group).
+__global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BafKArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_frame;
+  const bool persistent = !kSpread && A.frame_ctr != nullptr;
+  bool first = true;
+  // The arguments are read from the kernel-argument segment AGAIN for every frame, through a pointer the compiler cannot see through:
+  // hoisted out of the frame loop (they are loop-invariant loads) the ~40 of them stayed live across the whole body and pushed the
+  // pass loops into 37 spilled VGPRs (+ 4 % on the refine); re-read, the body has the register allocation of the plain kernel.
+  kargs_t* ka = (kargs_t*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll 1
+  for (;;) {  // (ONE call site of the body: the plain launch makes a single trip with its block index)
+    asm volatile("" : "+s"(ka));
+    unsigned fr = blockIdx.x;
+    if (persistent) {
+      if (threadIdx.x == 0) s_frame = atomicAdd(ka->frame_ctr, 1);
+      __syncthreads();
+      fr = (unsigned)s_frame;
+      if ((int)fr >= ka->B) break;
+    } else if (!first) {
+      break;
+    }
+    first = false;
+    ba1_fast_frame(smem, fr, ka);
+    if (persistent) __syncthreads();  // (the frame's last readers of the LDS state and of s_frame are through)
   }
 }
 

@@ -81,6 +81,8 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  * initialised ONCE at gl_ctx_create from the environment variable GMMLOC_<NAME IN CAPITALS> and changed only by
  * this call afterwards - no entry point reads the environment.  Names:
  *   ba_shape (-1 auto | 0 one workgroup per frame | 1 one point per thread; same bits either way),
+ *   ba_persist (1; 0: the batch-shaped refine of gl_track_frames as one block per frame instead of persistent workgroups drawing frames
+ *     from a queue - same bits; A/B),
  *   ba_step32 (1: fp32-cached point step in gl_track_frames, faster, NOT bit-compatible with the default),
  *   assoc_grid (0: every association is the plain N x K sweep, never the cell index),
  *   assoc_coop (1; 0: the indexed association gathers a record per lane instead of per six lanes - A/B),
