@@ -338,7 +338,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without a launcher: bench.py starts them itself")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=16384, help="frames per step per GPU (4 096 until round 4: the tail of a launch - CUs idle while the last frames finish - is a quarter as long at 16 384)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="the timed step only (what tools/profile_bench.sh profiles: the two-stream / sweep / class legs launch the same kernels)")

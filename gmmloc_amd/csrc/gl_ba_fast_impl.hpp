@@ -1418,6 +1418,44 @@ GL_DEV void pt_lambda_init(const Uni& U, const GmmDev& gm, const Lds& D, const P
     pose_terms(o.q, o.A, zero, false, sk);
   }
 }
+// the same with only what computeLambdaInit reads of the pose block: its DIAGONAL (terms 0, 6, 11, 15, 18, 20 of pose_terms, the same
+// expressions - the same bits) as terms 0..5
+template <class Sink>
+GL_DEV void pt_lambda_init_diag(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& P, const PtCtx& c, bool robust, double& md, const Sink& sk) {
+  Lin o;
+  if (kFixed && c.af) {
+    double Hx[6], bx[3];
+    fixed_lin(U, D, P, c, robust, Hx, bx, false);
+    lin_fast(U, gm, D, P, c, robust, o);
+    fixed_add(Hx, bx, o);
+  } else {
+    lin_fast(U, gm, D, P, c, robust, o);
+  }
+  const double Hf[9] = {o.D[0], o.D[1], o.D[2], o.D[1], o.D[3], o.D[4], o.D[2], o.D[4], o.D[5]};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s += P.R[a * 3 + j] * Hf[a * 3 + b] * P.R[b * 3 + j];
+    md = fmax(md, fabs(s));
+  }
+  if (c.ar) {
+    const double* q = o.q;
+    const double* C = o.A;
+    const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+    const double M1 = fma(q[1], Cf[7], -q[2] * Cf[4]), M2 = fma(q[1], Cf[8], -q[2] * Cf[5]);
+    const double M3 = fma(q[2], Cf[0], -q[0] * Cf[6]), M5 = fma(q[2], Cf[2], -q[0] * Cf[8]);
+    const double M6 = fma(q[0], Cf[3], -q[1] * Cf[0]), M7 = fma(q[0], Cf[4], -q[1] * Cf[1]);
+    sk.put(0, fma(q[1], M2, -q[2] * M1));
+    sk.put(1, fma(q[2], M3, -q[0] * M5));
+    sk.put(2, fma(q[0], M7, -q[1] * M6));
+    sk.put(3, C[0]);
+    sk.put(4, C[3]);
+    sk.put(5, C[5]);
+  }
+}
 // pass A: linearise, point solve, Schur terms 0..26, robust chi2 (27), sum u.b (28); leaves the factors of D in the slot and the
 // Huber weight rho' of the reprojection edge in the stale-chi2 cell (dead until pass B rewrites it)
 template <class Sink>
@@ -1671,6 +1709,42 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
     if (it == 0) {  // computeLambdaInit
       PROF_T(tL0);
       double md = 0.0;
+      if (!kSpread) {
+        // DENSE: only the six diagonal sums, in the canonical order (level 2 = the butterfly of wave_allreduce_canon, level 3 = the blocks
+        // of two groups), and the maximum of the point blocks beside them through the same LDS row: one barrier instead of five
+        GL_BAF_PASS(pt_lambda_init_diag(U, gm, D, P, c, robust, md, sk));
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        double sd[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sd[i] = wave_allreduce_canon(acc[i]);
+#pragma unroll
+        for (int o_ = 1; o_ < 64; o_ <<= 1) md = fmax(md, shfl_xor_f64(md, o_));
+        __syncthreads();  // (the rows of `red` may still be read: the previous trial's reduction)
+        if (lane_ < 7) {
+          double v = md;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) v = lane_ == i ? sd[i] : v;
+          R.red[wave_ * 32 + lane_] = v;
+        }
+        __syncthreads();
+        double dg[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double s_ = NWC > 1 ? add_nc(R.red[i], R.red[32 + i]) : R.red[i];
+#pragma unroll
+          for (int b = 1; b < NWC / 2; ++b) s_ = add_nc(s_, add_nc(R.red[(2 * b) * 32 + i], R.red[(2 * b + 1) * 32 + i]));
+          dg[i] = s_;
+        }
+        double mx = R.red[6];
+#pragma unroll
+        for (int w_ = 1; w_ < NWC; ++w_) mx = fmax(mx, R.red[w_ * 32 + 6]);
+        md = mx;
+        if (pose_active) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) md = fmax(md, fabs(prior_on ? dg[i] + An.rec[An.cur * 32 + GL_U(i, i)] : dg[i]));
+        }
+        __syncthreads();  // (the rows are rewritten by pass A's reduction)
+      } else {
       GL_BAF_PASS(pt_lambda_init(U, gm, D, P, c, robust, md, sk));
       reduce2<21>(acc, R, C);
       if (pose_active) {
@@ -1682,6 +1756,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         for (int i = 0; i < 6; ++i) md = fmax(md, fabs(acc[GL_U(i, i)]));
       }
       md = reduce_max(md, R, C);
+      }
       lambda = uni(1e-5 * md);
       ni = 2.0;
       PROF_T(tL1);
