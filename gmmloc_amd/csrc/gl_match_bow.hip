@@ -45,7 +45,7 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
                                                        const uint8_t* __restrict__ desc2_all, const int32_t* __restrict__ nn2_all,
                                                        const int32_t* __restrict__ nid2_all, const int32_t* __restrict__ nptr2_all,
                                                        const int32_t* __restrict__ nidx2_all, int32_t* __restrict__ match_all,
-                                                       int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters) {
+                                                       int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters, uint4* __restrict__ cache_all) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* owner = lds;            // N2: lowest query that claimed the frame feature in the previous round (INT_MAX: nobody)
   int32_t* owner_n = owner + N2;   // N2: being rebuilt
@@ -96,6 +96,92 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
   for (int i = tid; i < N2; i += T_B) owner[i] = INT_MAX;
   __syncthreads();
 
+  // Round 5 (as in gl_match.hip / gl_match_tri.hip): a query's partners and their distances do not depend on the owners, which only
+  // REMOVE partners.  best = first of the smallest distance, second best = the smallest of the rest: the two smallest keys
+  //     dist << 22 | position in the partner list << 12 | feature of the frame.
+  // Round 1 evaluates every partner once (descriptors requested four at a time) and leaves the three smallest keys and their number
+  // in a 16-byte record; a later round decides from the keys whose features no lower query owns whenever two are left or the
+  // record held every partner, and walks again otherwise.
+  constexpr uint32_t EMPTY = 0xffffffffu;
+  uint4* cache = cache_all + (size_t)f * N1;
+  auto decide = [&](uint32_t a, uint32_t b) -> int {
+    if (a == EMPTY) return -1;
+    const int bestDist1 = (int)(a >> 22), bestDist2 = b == EMPTY ? 256 : (int)(b >> 22);
+    return (bestDist1 <= 50 && (float)bestDist1 < nn_ratio * (float)bestDist2) ? (int)(a & 0xfffu) : -1;  // TH_LOW, nn_ratio_
+  };
+  auto walk = [&](int m, int idx1, uint32_t& k0, uint32_t& k1, uint32_t& k2, uint32_t& npass) {
+    k0 = k1 = k2 = EMPTY;
+    npass = 0;
+    uint32_t d1[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
+    const int lo = q_lo[m], hi = q_hi[m];
+    for (int b0 = lo; b0 < hi; b0 += 4) {
+      int id[4];
+      uint4 da[4], db[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int idx2 = b0 + j < hi ? nidx2[b0 + j] : -1;
+        if (idx2 >= N2) idx2 = -1;
+        if (idx2 >= 0 && owner[idx2] < m) idx2 = -1;  // matches[realIdxF] is set: taken by an earlier key-frame feature
+        id[j] = idx2;
+        da[j] = db[j] = make_uint4(0, 0, 0, 0);
+        if (idx2 >= 0) {
+          const uint4* src = (const uint4*)(desc2 + (size_t)idx2 * 8);
+          da[j] = src[0];
+          db[j] = src[1];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx2 = id[j];
+        if (idx2 < 0) continue;
+        const int dist = __popc(d1[0] ^ da[j].x) + __popc(d1[1] ^ da[j].y) + __popc(d1[2] ^ da[j].z) + __popc(d1[3] ^ da[j].w) +
+                         __popc(d1[4] ^ db[j].x) + __popc(d1[5] ^ db[j].y) + __popc(d1[6] ^ db[j].z) + __popc(d1[7] ^ db[j].w);
+        if (dist >= 256) continue;  // (never below the initial best / second best)
+        const int ord = b0 + j - lo;
+        if (ord > 1023) {  // (a node of more than 1 024 partners cannot be keyed: the sequential evaluation, in every round)
+          npass = EMPTY;
+          continue;
+        }
+        const uint32_t kx = ((uint32_t)dist << 22) | ((uint32_t)ord << 12) | (uint32_t)idx2;
+        if (npass != EMPTY) ++npass;
+        if (kx < k2) {
+          k2 = kx;
+          if (k2 < k1) {
+            const uint32_t t = k1;
+            k1 = k2;
+            k2 = t;
+          }
+          if (k1 < k0) {
+            const uint32_t t = k0;
+            k0 = k1;
+            k1 = t;
+          }
+        }
+      }
+    }
+  };
+  auto walk_seq = [&](int m, int idx1) -> int {
+    uint32_t d1[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
+    int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+    for (int b = q_lo[m]; b < q_hi[m]; ++b) {
+      const int idx2 = nidx2[b];
+      if (idx2 < 0 || idx2 >= N2) continue;
+      if (owner[idx2] < m) continue;
+      const int dist = hamming256(d1, desc2 + (size_t)idx2 * 8);
+      if (dist < bestDist1) {
+        bestDist2 = bestDist1;
+        bestDist1 = dist;
+        bestIdxF = idx2;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+    return (bestDist1 <= 50 && (float)bestDist1 < nn_ratio * (float)bestDist2) ? bestIdxF : -1;
+  };
   int rounds = 0;
   for (;;) {
     for (int i = tid; i < N2; i += T_B) owner_n[i] = INT_MAX;
@@ -105,24 +191,37 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
       const int idx1 = q_idx1[m];
       int take = -1;
       if (idx1 >= 0) {
-        uint32_t d1[8];
+        bool need_walk = rounds == 0;
+        if (rounds > 0) {
+          const uint4 rec = cache[m];
+          if (rec.w == EMPTY) {
+            need_walk = true;
+          } else {
+            uint32_t a = EMPTY, b2 = EMPTY;
+            int nav = 0;
+            const uint32_t ks[3] = {rec.x, rec.y, rec.z};
 #pragma unroll
-        for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
-        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
-        for (int b = q_lo[m]; b < q_hi[m]; ++b) {
-          const int idx2 = nidx2[b];
-          if (idx2 < 0 || idx2 >= N2) continue;
-          if (owner[idx2] < m) continue;  // matches[realIdxF] is set: taken by an earlier key-frame feature
-          const int dist = hamming256(d1, desc2 + (size_t)idx2 * 8);
-          if (dist < bestDist1) {
-            bestDist2 = bestDist1;
-            bestDist1 = dist;
-            bestIdxF = idx2;
-          } else if (dist < bestDist2) {
-            bestDist2 = dist;
+            for (int j = 0; j < 3; ++j)
+              if (ks[j] != EMPTY && owner[ks[j] & 0xfffu] >= m) {
+                if (nav == 0) a = ks[j];
+                else if (nav == 1) b2 = ks[j];
+                ++nav;
+              }
+            if (nav >= 2 || rec.w <= 3u) take = decide(a, b2);
+            else need_walk = true;
           }
         }
-        if (bestDist1 <= 50 && (float)bestDist1 < nn_ratio * (float)bestDist2) take = bestIdxF;  // TH_LOW, nn_ratio_
+        if (need_walk) {
+          uint32_t k0, k1, k2, npass;
+          walk(m, idx1, k0, k1, k2, npass);
+          if (npass == EMPTY) {
+            take = walk_seq(m, idx1);
+            if (rounds == 0) cache[m] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          } else {
+            take = decide(k0, k1);
+            if (rounds == 0) cache[m] = make_uint4(k0, k1, k2, npass);
+          }
+        }
       }
       choice[m] = take;
       if (take >= 0) atomicMin(&owner_n[take], m);
@@ -246,9 +345,14 @@ extern "C" int gl_search_by_bow(gl_ctx_t* ctx, float nn_ratio, int check_orienta
   const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1) * sizeof(int32_t);
   GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_by_bow, lds));
+  void* cache = nullptr;  // 16 bytes per query: its three best partners of round 1
+  {
+    const int rc = gl::ctx_scratch_b(c, (size_t)B * N1 * sizeof(uint4), &cache);
+    if (rc != GL_OK) return rc;
+  }
   k_search_by_bow<<<B, T_B, lds, c->stream>>>(B, N1, N2, NN1, NN2, nn_ratio, check_orientation, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                               node_id1_dev, node_ptr1_dev, node_idx1_dev, angle2_dev, desc2_dev, nnode2_dev, node_id2_dev,
-                                              node_ptr2_dev, node_idx2_dev, match21_dev, nmatches_dev, c->counters);
+                                              node_ptr2_dev, node_idx2_dev, match21_dev, nmatches_dev, c->counters, (uint4*)cache);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
     const int32_t* __restrict__ oct2_all, const float* __restrict__ angle2_all, const uint8_t* __restrict__ desc2_all,
     const uint8_t* __restrict__ mp2_all, const int32_t* __restrict__ nn2_all, const int32_t* __restrict__ nid2_all,
     const int32_t* __restrict__ nptr2_all, const int32_t* __restrict__ nidx2_all, const double* __restrict__ fmat_all,
-    const float* __restrict__ epi_all, int32_t* __restrict__ match_all, int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters) {
+    const float* __restrict__ epi_all, int32_t* __restrict__ match_all, int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters, uint4* __restrict__ cache_all) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int N1 = P.N1, N2 = P.N2;
   int32_t* owner = lds;             // N2: lowest query that picked the feature in the previous round (-1: not available at all)
@@ -118,6 +118,120 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
   __syncthreads();
 
   // ---- rounds of the fixed point ------------------------------------------------------------------------------------
+  // Round 5: what a query can ever take is fixed by the tests that do not depend on the owners - the partners of its vocabulary node
+  // with a distance <= TH_LOW that pass the epipole / epipolar tests; the owners only REMOVE partners.  The reference keeps, of
+  // those, the smallest distance and among equal distances the LAST in list order: the smallest key
+  //     dist << 26 | (1023 - position in the partner list) << 16 | feature of key-frame 2.
+  // Round 1 evaluates every partner once (descriptors requested four at a time) and leaves the query's three smallest keys and
+  // their number in a 16-byte record; a later round takes the first key whose feature no lower query owns, and walks again only if
+  // all three are gone and there were more.
+  constexpr uint32_t EMPTY = 0xffffffffu;
+  uint4* cache = cache_all + (size_t)f * N1;
+  auto walk = [&](int m, int idx1, uint32_t& k0, uint32_t& k1, uint32_t& k2, uint32_t& npass) {
+    k0 = k1 = k2 = EMPTY;
+    npass = 0;
+    const bool bStereo1 = ur1[idx1] >= 0;
+    const double u1 = uv1[2 * idx1], v1 = uv1[2 * idx1 + 1];
+    // checkEpipolarDist: the line of kp1 in key-frame 2
+    const double ea = u1 * F[0] + v1 * F[3] + F[6];
+    const double eb = u1 * F[1] + v1 * F[4] + F[7];
+    const double ec = u1 * F[2] + v1 * F[5] + F[8];
+    const float den = (float)(ea * ea + eb * eb);
+    uint32_t d1[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
+    const int lo = q_lo[m], hi = q_hi[m];
+    for (int b0 = lo; b0 < hi; b0 += 4) {
+      int id[4];
+      uint4 da[4], db[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int idx2 = b0 + j < hi ? nidx2[b0 + j] : -1;
+        if (idx2 >= N2) idx2 = -1;
+        if (idx2 >= 0 && owner[idx2] < m) idx2 = -1;  // not available at all (-1), or taken by an earlier feature of key-frame 1
+        id[j] = idx2;
+        da[j] = db[j] = make_uint4(0, 0, 0, 0);
+        if (idx2 >= 0) {
+          const uint4* src = (const uint4*)(desc2 + (size_t)idx2 * 8);
+          da[j] = src[0];
+          db[j] = src[1];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx2 = id[j];
+        if (idx2 < 0) continue;
+        const int dist = __popc(d1[0] ^ da[j].x) + __popc(d1[1] ^ da[j].y) + __popc(d1[2] ^ da[j].z) + __popc(d1[3] ^ da[j].w) +
+                         __popc(d1[4] ^ db[j].x) + __popc(d1[5] ^ db[j].y) + __popc(d1[6] ^ db[j].z) + __popc(d1[7] ^ db[j].w);
+        if (dist > 50) continue;  // TH_LOW
+        const double u2 = uv2[2 * idx2], v2 = uv2[2 * idx2 + 1];
+        const int oc2 = oct2[idx2] & 7;
+        if (!bStereo1 && !(ur2[idx2] >= 0)) {
+          const float distex = (float)((double)ex - u2);
+          const float distey = (float)((double)ey - v2);
+          if (distex * distex + distey * distey < 100.0f * P.sf[oc2]) continue;
+        }
+        const float num = (float)(ea * u2 + eb * v2 + ec);
+        if (den == 0) continue;
+        const float dsqr = num * num / den;
+        if (!((double)dsqr < 3.84 * (double)P.sigma2[oc2])) continue;
+        const int ord = b0 + j - lo;
+        if (ord > 1023) {  // (a node with more than 1 024 partners: this query walks in every round)
+          npass = EMPTY;
+          continue;
+        }
+        uint32_t kx = ((uint32_t)dist << 26) | ((uint32_t)(1023 - ord) << 16) | (uint32_t)idx2;
+        if (npass != EMPTY) ++npass;
+        if (kx < k2) {
+          k2 = kx;
+          if (k2 < k1) {
+            const uint32_t t = k1;
+            k1 = k2;
+            k2 = t;
+          }
+          if (k1 < k0) {
+            const uint32_t t = k0;
+            k0 = k1;
+            k1 = t;
+          }
+        }
+      }
+    }
+  };
+  // (a node of more than 1 024 partners cannot be keyed: such a query is evaluated the sequential way, in every round)
+  auto walk_seq = [&](int m, int idx1) -> int {
+    const bool bStereo1 = ur1[idx1] >= 0;
+    const double u1 = uv1[2 * idx1], v1 = uv1[2 * idx1 + 1];
+    const double ea = u1 * F[0] + v1 * F[3] + F[6];
+    const double eb = u1 * F[1] + v1 * F[4] + F[7];
+    const double ec = u1 * F[2] + v1 * F[5] + F[8];
+    const float den = (float)(ea * ea + eb * eb);
+    uint32_t d1[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
+    int bestDist = 50, bestIdx2 = -1;  // TH_LOW
+    for (int b = q_lo[m]; b < q_hi[m]; ++b) {
+      const int idx2 = nidx2[b];
+      if (idx2 < 0 || idx2 >= N2) continue;
+      if (owner[idx2] < m) continue;
+      const int dist = hamming256(d1, desc2 + (size_t)idx2 * 8);
+      if (dist > 50 || dist > bestDist) continue;
+      const double u2 = uv2[2 * idx2], v2 = uv2[2 * idx2 + 1];
+      const int oc2 = oct2[idx2] & 7;
+      if (!bStereo1 && !(ur2[idx2] >= 0)) {
+        const float distex = (float)((double)ex - u2);
+        const float distey = (float)((double)ey - v2);
+        if (distex * distex + distey * distey < 100.0f * P.sf[oc2]) continue;
+      }
+      const float num = (float)(ea * u2 + eb * v2 + ec);
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (!((double)dsqr < 3.84 * (double)P.sigma2[oc2])) continue;
+      bestIdx2 = idx2;
+      bestDist = dist;
+    }
+    return bestIdx2;
+  };
   int rounds = 0;
   for (;;) {
     for (int i = tid; i < N2; i += T_T) owner_n[i] = owner[i] < 0 ? -1 : INT_MAX;
@@ -127,36 +241,34 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
       const int idx1 = q_idx1[m];
       int bestIdx2 = -1;
       if (idx1 >= 0) {
-        const bool bStereo1 = ur1[idx1] >= 0;
-        const double u1 = uv1[2 * idx1], v1 = uv1[2 * idx1 + 1];
-        // checkEpipolarDist: the line of kp1 in key-frame 2
-        const double ea = u1 * F[0] + v1 * F[3] + F[6];
-        const double eb = u1 * F[1] + v1 * F[4] + F[7];
-        const double ec = u1 * F[2] + v1 * F[5] + F[8];
-        const float den = (float)(ea * ea + eb * eb);
-        uint32_t d1[8];
+        uint4 rec = make_uint4(EMPTY, EMPTY, EMPTY, 0);
+        bool need_walk = rounds == 0;
+        if (rounds > 0) {
+          rec = cache[m];
+          if (rec.w == EMPTY) {
+            need_walk = true;
+          } else {
+            const uint32_t ks[3] = {rec.x, rec.y, rec.z};
+            bool found = false;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) d1[w] = desc1[(size_t)idx1 * 8 + w];
-        int bestDist = 50;  // TH_LOW
-        for (int b = q_lo[m]; b < q_hi[m]; ++b) {
-          const int idx2 = nidx2[b];
-          if (idx2 < 0 || idx2 >= N2) continue;
-          if (owner[idx2] < m) continue;  // not available at all (-1), or taken by an earlier feature of key-frame 1
-          const int dist = hamming256(d1, desc2 + (size_t)idx2 * 8);
-          if (dist > 50 || dist > bestDist) continue;
-          const double u2 = uv2[2 * idx2], v2 = uv2[2 * idx2 + 1];
-          const int oc2 = oct2[idx2] & 7;
-          if (!bStereo1 && !(ur2[idx2] >= 0)) {
-            const float distex = (float)((double)ex - u2);
-            const float distey = (float)((double)ey - v2);
-            if (distex * distex + distey * distey < 100.0f * P.sf[oc2]) continue;
+            for (int j = 0; j < 3; ++j)
+              if (!found && ks[j] != EMPTY && owner[ks[j] & 0xffffu] >= m) {
+                bestIdx2 = (int)(ks[j] & 0xffffu);
+                found = true;
+              }
+            if (!found && rec.w > 3u) need_walk = true;  // all three gone and there were more
           }
-          const float num = (float)(ea * u2 + eb * v2 + ec);
-          if (den == 0) continue;
-          const float dsqr = num * num / den;
-          if (!((double)dsqr < 3.84 * (double)P.sigma2[oc2])) continue;
-          bestIdx2 = idx2;
-          bestDist = dist;
+        }
+        if (need_walk) {
+          uint32_t k0, k1, k2, npass;
+          walk(m, idx1, k0, k1, k2, npass);
+          if (npass == EMPTY) {
+            bestIdx2 = walk_seq(m, idx1);
+            if (rounds == 0) cache[m] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+          } else {
+            bestIdx2 = k0 == EMPTY ? -1 : (int)(k0 & 0xffffu);
+            if (rounds == 0) cache[m] = make_uint4(k0, k1, k2, npass);
+          }
         }
       }
       choice[m] = bestIdx2;
@@ -429,10 +541,15 @@ extern "C" int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, in
   const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1) * sizeof(int32_t);
   GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_for_triangulation, lds));
+  void* cache = nullptr;  // 16 bytes per query: its three best partners of round 1 (the kernel's round loop)
+  {
+    const int rc = gl::ctx_scratch_b(c, (size_t)B * N1 * sizeof(uint4), &cache);
+    if (rc != GL_OK) return rc;
+  }
   k_search_for_triangulation<<<B, T_T, lds, c->stream>>>(P, B, uv1_dev, ur1_dev, oct1_dev, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                                         node_id1_dev, node_ptr1_dev, node_idx1_dev, uv2_dev, ur2_dev, oct2_dev, angle2_dev,
                                                         desc2_dev, has_mp2_dev, nnode2_dev, node_id2_dev, node_ptr2_dev, node_idx2_dev, fmat_dev,
-                                                        epipole_dev, match12_dev, nmatches_dev, c->counters);
+                                                        epipole_dev, match12_dev, nmatches_dev, c->counters, (uint4*)cache);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -196,6 +196,10 @@ def config_ba(torch, ctx, out):
     gt = np.load(os.path.join(ROOT, "tests", "golden", "gt_sync.npz"))["V1_01_easy"]
     cam, prm = api.Camera(), api.Params()
     g = gmmloc_amd.GMM(ctx, mean, cov, prm)
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+    hor = orc.gmm_create(mean, cov)
+    cpu_ms = {}
     res = {"config": "local BA (jointOptimization), synthetic multi-view problems on v1.gmm",
            "flop_model": "per Levenberg trial: observations x 337 (P1 linearise 225: transform, residual, Huber, w J^T J, R^T A R; P3 112: "
                          "back-substitution term + error at the trial state) + points x 150 (3x3 inverse, GMM edge, step) + (pose pairs per point, "
@@ -220,6 +224,12 @@ def config_ba(torch, ctx, out):
         t = ev_time(torch, lambda: api.joint_optimization(ctx, g, cam, prm, P, F, poses0.clone(), prior, pts0.clone(), assoc, optr, opose, ouvr, ooct), 3, ctx.stream)
         torch.cuda.synchronize()
         ctx.set_stats_buffer(None)
+        if (P, F, L) not in cpu_ms:  # the oracle (CPU port of the reference's arithmetic, 1 thread) on the window's first problem
+            a0 = assoc[0].cpu().numpy()
+            t0 = time.perf_counter()
+            orc.joint_optimization(hor, cam, P, F, probs[0]["poses"], probs[0]["prior"], probs[0]["points"], a0, probs[0]["obs_ptr"], probs[0]["obs_pose"],
+                                   probs[0]["obs_uvr"], probs[0]["obs_oct"])
+            cpu_ms[(P, F, L)] = 1e3 * (time.perf_counter() - t0)
         flop = 0.0
         tr = trials.cpu().numpy()
         for b in range(B):
@@ -230,10 +240,13 @@ def config_ba(torch, ctx, out):
             flop += per_trial * float(tr[b])
         res["P%d_F%d_L%d_B%d" % (P, F, L, B)] = {"ms_per_call": 1e3 * t, "ms_per_problem": 1e3 * t / B, "observations": int(NOBS),
                                                  "trials_per_problem": float(tr.mean()),
+                                                 "cpu_oracle_1thread_ms_per_problem": cpu_ms[(P, F, L)],
+                                                 "speedup_vs_cpu_oracle_1thread": cpu_ms[(P, F, L)] / (1e3 * t / B),
                                                  "us_per_trial": 1e6 * t / max(float(tr.mean()), 1.0),
                                                  "roofline_ba": {"kernel": "kp_lin + kp_schur + kp_assemble + kp_solve + kp_trial (pipelined shape)" if (B <= 8 and NOBS >= 5000) else "k_ba_gen",
                                                                  "bound": "latency (valu_fp64 peak for reference)", "flop_per_launch": flop,
                                                                  "achieved": flop / t / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": flop / t / 1e12 / 78.6}}
+    orc.gmm_destroy(hor)
     out(res)
 
 
