@@ -64,6 +64,10 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
   int32_t* q_idx1 = choice + N1;    // N1: the query's feature of key-frame 1, or -1 (not a query: map point, mono under only-stereo, node not shared)
   int32_t* q_lo = q_idx1 + N1;      // N1: its partners = node_idx2[q_lo .. q_hi)
   int32_t* q_hi = q_lo + N1;
+  // the three tables the queries are set up from (two binary searches per query: sixteen dependent GLOBAL loads each before round 5)
+  int32_t* s_nptr1 = q_hi + N1;            // NN1 + 1
+  int32_t* s_nid2 = s_nptr1 + P.NN1 + 1;   // NN2
+  int32_t* s_nptr2 = s_nid2 + P.NN2;       // NN2 + 1
   __shared__ int s_changed, s_hist[32], s_keep[4], s_cnt[T_T / 64];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
@@ -89,23 +93,29 @@ __global__ __launch_bounds__(T_T) void k_search_for_triangulation(
   const int nq = nn1 > 0 ? min(nptr1[nn1], N1) : 0;  // list entries of key-frame 1 = queries, in the reference's visiting order
 
   // ---- queries: list entry a of key-frame 1 -> its feature and the partner list of the same node in key-frame 2 ----
+  for (int i = tid; i <= nn1; i += T_T) s_nptr1[i] = nptr1[i];
+  for (int i = tid; i <= nn2; i += T_T) {
+    s_nptr2[i] = nptr2[i];
+    if (i < nn2) s_nid2[i] = nid2[i];
+  }
+  __syncthreads();
   for (int a = tid; a < N1; a += T_T) {
     int idx1 = -1, lo = 0, hi = 0;
     if (a < nq) {
-      const int n1 = node_of(nptr1, nn1, a);
+      const int n1 = node_of(s_nptr1, nn1, a);
       const int id = nid1[n1];
       int l = 0, h = nn2;  // lower_bound of id in nid2
       while (l < h) {
         const int mid = (l + h) >> 1;
-        if (nid2[mid] < id) l = mid + 1;
+        if (s_nid2[mid] < id) l = mid + 1;
         else h = mid;
       }
-      if (l < nn2 && nid2[l] == id) {
+      if (l < nn2 && s_nid2[l] == id) {
         const int i1 = nidx1[a];
         if (i1 >= 0 && i1 < N1 && oct1[i1] >= 0 && !mp1[i1] && !(P.only_stereo && !(ur1[i1] >= 0))) {
           idx1 = i1;
-          lo = nptr2[l];
-          hi = min(nptr2[l + 1], N2);
+          lo = s_nptr2[l];
+          hi = min(s_nptr2[l + 1], N2);
         }
       }
     }
@@ -538,7 +548,7 @@ extern "C" int gl_search_for_triangulation(gl_ctx_t* ctx, float scale_factor, in
     P.sf[i] = P.sf[i - 1] * scale_factor;
     P.sigma2[i] = P.sf[i] * P.sf[i];
   }
-  const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1) * sizeof(int32_t);
+  const size_t lds = ((size_t)2 * N2 + 4 * (size_t)N1 + (size_t)NN1 + 2 * (size_t)NN2 + 2) * sizeof(int32_t);
   GL_REQUIRE_LDS(c, lds);
   GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_search_for_triangulation, lds));
   void* cache = nullptr;  // 16 bytes per query: its three best partners of round 1 (the kernel's round loop)
