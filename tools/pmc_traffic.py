@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel PMC sums of the rocprofv3 --pmc passes tools/profile_bench.sh made (rocpd SQLite, one db per pass) ->
-JSON: counters averaged per launch of the 4 096-frame bench launches, and the HBM-side traffic
+JSON: counters averaged per launch of the bench launches (16 384 frames since round 5), and the HBM-side traffic
 (FETCH_SIZE x 2 on gfx950, see /opt/skills/guides/MI355X_MICROARCH.md: the counter is in KB of 64-B requests that are
 128 B on this chip) + WRITE_SIZE, per launch and per frame.
     python tools/pmc_traffic.py gpurun_out/prof_r2 > profiles/r2_traffic.json"""
@@ -10,7 +10,7 @@ import os
 import sqlite3
 import sys
 
-FRAMES = 4096
+FRAMES = 16384  # frames per launch of the default bench step (4 096 until round 4)
 
 
 def main(root):
@@ -56,7 +56,7 @@ def main(root):
     import bench
     out["kernel_source_sha"] = bench.kernel_source_fingerprint()  # bench.py flags a summary made from other sources as stale
     out["how"] = ("rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline, one run per "
-                  "counter group (tools/profile_bench.sh); averages over the 4096-frame launches")
+                  "counter group (tools/profile_bench.sh); averages over the bench launches")
     print(json.dumps(out, indent=1))
 
 
