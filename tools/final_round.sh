@@ -18,7 +18,10 @@ python tools/ba_modes.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_modes.tx
 python tools/fixed_time.py 4096 300 2 > gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/fixed_time.py 2048 1000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/fixed_time.py 1024 2000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
-./build_tmp/bench_mfma_reduce > gpurun_out/${TAG}_mfma_reduce.txt 2>/dev/null
+./build_tmp/bench_mfma_point 2000 > gpurun_out/${TAG}_mfma_point.txt 2>/dev/null
+python tools/chain_time.py > gpurun_out/${TAG}_chain_time.json 2>/dev/null
+bash tools/pmc_match.sh ${TAG} > gpurun_out/${TAG}_pmc_match.log 2>&1
+rm -rf gpurun_out/pmc_match_${TAG}
 python tools/soak_match.py ${SOAK_MATCH:-300} 2>/dev/null | tail -3 > gpurun_out/${TAG}_soak_match.txt
 python tools/soak.py 2000 > gpurun_out/${TAG}_soak_strict.txt 2>&1
 tail -2 gpurun_out/${TAG}_soak_strict.txt | cut -c1-500
