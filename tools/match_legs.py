@@ -29,7 +29,8 @@ KERNEL = {"proj": "k_search_by_projection<0", "frame": "k_search_by_projection<1
 
 
 def ev_time(torch, fn, reps, stream):
-    fn()
+    for _ in range(40):  # (a fresh process starts at idle clocks: these launches are too short to ramp them inside the timed ones)
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):

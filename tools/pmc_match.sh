@@ -7,7 +7,7 @@ TAG=${1:-r5}
 LEGS=${2:-proj,frame,tri,bow,fuse}
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/pmc_match_$TAG; rm -rf $O; mkdir -p $O
-python tools/match_legs.py --legs $LEGS --reps 5 > gpurun_out/${TAG}_match_legs.jsonl 2> $O/legs.err
+python tools/match_legs.py --legs $LEGS --reps 20 > gpurun_out/${TAG}_match_legs.jsonl 2> $O/legs.err
 i=0
 for CNT in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
