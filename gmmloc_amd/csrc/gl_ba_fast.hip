@@ -223,13 +223,20 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_FIXED
 
 #define GL_BAF_NS bafd2000  // 1 frame per CU
+#if GL_BAF_W3
+#define GL_BAF_MCAP 1984
+#define GL_BAF_NW 12
+#define GL_BAF_THREADS 768
+#else
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
+#endif
 #define GL_BAF_SPREAD 0
 #define GL_BAF_STEP32 0
 #define GL_BAF_PRIOR 0
 #define GL_BAF_FIXED 0
 #include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_THREADS
 #undef GL_BAF_NS
 #undef GL_BAF_MCAP
 #undef GL_BAF_NW
@@ -439,9 +446,12 @@ bool probe_xcc_ids(Ctx* c) {
 bool ba1_fast_supported(int L) { return L <= 2000; }
 
 // the canonical summation order of a frame of stride L (gl_ba_fast_impl.hpp): G groups of S chunks of 64 points
+#ifndef GL_BAF_W3
+#define GL_BAF_W3 0  // EXPERIMENT (profiles/r5_w3_*.txt): the largest class at THREE waves per SIMD - groups of 3 chunks, 12 waves, 168 registers
+#endif
 static void canon_order(int L, int* G, int* S) {
   const int nch = (L + 63) / 64;
-  *G = (nch + 3) / 4;
+  *G = (GL_BAF_W3 && L > 1000) ? (nch + 2) / 3 : (nch + 3) / 4;
   *S = (nch + *G - 1) / *G;
 }
 
@@ -486,7 +496,10 @@ static int launch_dense(Ctx* c, BafArgs& a) {
                          : fixed ? (cap == 496 ? bafd496f::k_ba1_fast : cap == 984 ? bafd1000f::k_ba1_fast : bafd2000f::k_ba1_fast)
                          : a.prior ? (cap == 496 ? bafd496p::k_ba1_fast : cap == 992 ? bafd1000p::k_ba1_fast : bafd2000p::k_ba1_fast)
                                    : (cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast);
-  const size_t lds = (size_t)(10 * cap + (cap == 496 ? 2 : cap <= 1000 ? 4 : 8) * 32 + 64 + 40 + (anch ? 64 + (cap == 496 ? 108 : 0) : 0) + (fixed ? 48 : 0)) * sizeof(double);
+  const bool w3 = GL_BAF_W3 && kern == bafd2000::k_ba1_fast;  // (experiment: 12 groups' totals, MCAP 1984)
+  if (w3 && a.L > 1984) return GL_ERR_ARG;
+  const size_t lds = w3 ? (size_t)(10 * 1984 + 12 * 32 + 64 + 24 + 24) * sizeof(double)
+                        : (size_t)(10 * cap + (cap == 496 ? 2 : cap <= 1000 ? 4 : 8) * 32 + 64 + 40 + (anch ? 64 + (cap == 496 ? 108 : 0) : 0) + (fixed ? 48 : 0)) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
   a.parts = nullptr;

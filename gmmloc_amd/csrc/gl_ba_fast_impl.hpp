@@ -2013,7 +2013,7 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
   R.tot = R.red + NRED * 32;        // 32 (+ 32 broadcast slots)
   D.stab = R.tot + 64;              // 24
   R.red2 = D.stab + 24;             // 16
-  double* const prec = R.red2 + 16; // anchored instances: 2 x 32, the prior edge's records
+  double* const prec = R.red2 + (NWC > 8 ? 2 * NWC : 16); // anchored instances: 2 x 32, the prior edge's records
   // ... and the work area of prior_record_wave: the group totals `red` where they are large enough (4 / 8 groups) - idle
   // during pass B and before the first reduction -, the transpose rows pass B does not use on the latency shape, 108 doubles
   // of its own in the small class (which has LDS to spare)
@@ -2110,7 +2110,7 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
     if (tid < fxv.F * 12) D.frt[tid] = fxv.fRt[(size_t)f * fxv.F * 12 + tid];
   }
   for (int i = tid; i < NRED * 32; i += blockDim.x) R.red[i] = 0.0;
-  if (tid < 16) R.red2[tid] = 0.0;
+  if (tid < (NWC > 8 ? 2 * NWC : 16)) R.red2[tid] = 0.0;
   if (tid == 0) {
     *(int*)(R.tot + 60) = 0;  // sequence word of the trial-pose hand-over
     *(int*)(R.tot + 61) = 0;  // a poll of the exchange gave up (SPREAD)
@@ -2344,7 +2344,11 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
 // zeroed by k_ba1_prep): a workgroup of the largest class owns a whole CU, and between two workgroups of a plain launch that CU sat
 // idle for 16 us (median; 48 us mean: workgroup timelines of profiles/r5_prof_ba_stations.txt) - 6 % of the launch.  Which workgroup
 // takes a frame shows nowhere in its result.  SPREAD (and frame_ctr == nullptr): the plain launch, one block per (frame, group).
+#ifdef GL_BAF_THREADS
+__global__ __launch_bounds__(GL_BAF_THREADS, GL_BAF_THREADS / 256) void k_ba1_fast(BafKArgs A) {
+#else
 __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BafKArgs A) {
+#endif
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int s_frame;
   const bool persistent = !kSpread && A.frame_ctr != nullptr;

@@ -43,3 +43,8 @@ import hashlib
 fp = hashlib.sha256(p.cpu().numpy().tobytes() + x.cpu().numpy().tobytes()).hexdigest()[:16]  # bits of the last launch's poses + points
 print("refine: %d frames x %d points, %.3f ms per launch, %.1f trials/frame, %.2f TFLOP/s = %.4f of the fp64 VALU peak, result bits %s"
       % (NF, M, 1e3 * ks, ntr / NF, tf, tf / bench.PEAK_FP64_VALU_TFLOPS, fp))
+if os.environ.get("REFINE_SAVE"):  # (two builds whose canonical orders differ: compare the poses instead of the bits)
+    np.save(os.environ["REFINE_SAVE"], p.cpu().numpy())
+if os.environ.get("REFINE_COMPARE"):
+    q = np.load(os.environ["REFINE_COMPARE"])
+    print("max |pose - %s| = %.3e" % (os.environ["REFINE_COMPARE"], np.abs(p.cpu().numpy() - q).max()))
