@@ -95,6 +95,30 @@ struct GenP {
 GL_DEV bool stop_now(const GenP& G) { return G.stop_seen > 0 || (G.stop_seen < 0 && G.done_iters >= -G.stop_seen); }
 GL_DEV int stop_word_load(const int32_t* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// k_ba_gen (the persistent kernel) keeps the ~40 addresses of a problem's state in a TABLE at the end of the problem's scratch area
+// (written by the kernel's prologue) and takes them from there again after every problem-wide barrier, as scalar loads through a
+// constant-address-space pointer the compiler cannot see through: computed once at the top they were live across all 85 000
+// instructions of the kernel - 1 310 spilled SGPRs in 21 VGPRs of spill lanes, which in turn pushed 36 VGPRs to scratch.  An address
+// is now live from the barrier in front of its phase to its last use in that phase: 0 spilled VGPRs, same bits.  (The mutable words -
+// toggle, epoch, stop_seen, done_iters, trials -, the sizes and S - which may be a generic pointer into LDS: taken through memory it
+// faulted (memory aperture violation on the first window whose system fits LDS) - stay in registers.  A first version kept the table in LDS: ds_read +
+// v_readfirstlane per address, 2 % slower than the spills it removed.  Re-reading the camera / map constants BaK / GmmDev from the
+// kernel-argument segment the same way changed nothing: what is left - 1 024 spilled SGPRs - are loop-carried scalars of the body, in
+// v_writelane slots, not in memory.)
+typedef const GenP __attribute__((address_space(4))) k_genp;
+constexpr size_t GEN_TABLE_BYTES = 512;
+static_assert(sizeof(GenP) <= GEN_TABLE_BYTES, "the address table of k_ba_gen lives in the last 512 bytes of a problem's scratch area");
+GL_DEV void genp_fresh(GenP& G, k_genp* s) {
+  asm volatile("" : "+s"(s));
+#define GF(x) G.x = s->x
+  GF(poses); GF(prior); GF(pts); GF(assoc); GF(optr); GF(opose); GF(ouvr); GF(ooct);
+  GF(Rt); GF(RtN); GF(qN); GF(pinv); GF(pn); GF(lin); GF(ptw); GF(pth); GF(chi_o); GF(gv); GF(bp); GF(dxv); GF(pchi); GF(pchi2);
+  GF(prH); GF(prb); GF(opoint); GF(pl_ptr); GF(pl_obs); GF(pl_pos); GF(pl_pt); GF(plm); GF(lev_o); GF(lev_g); GF(pfree); GF(pact); GF(lact);
+  GF(bar); GF(part); GF(flagg); GF(stop);
+#undef GF
+}
+#define GFRESH() genp_fresh(G, sG)
+
 // barrier over the NB <= 64 workgroups of one problem (all co-resident: cooperative launch).  One flag word per
 // workgroup (zeroed by the host): a workgroup announces its k-th arrival by storing k into its own word and the lanes
 // of its first wave read everybody's word until all of them say k - plain stores to different words and one 256-byte
@@ -1398,7 +1422,7 @@ GL_DEV bool ldlt_solve_large(double* S, double* g, int n, int ld, int* s_flag) {
   return *s_flag != 0;
 }
 
-GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, int iters, double* red, int* s_flag,
+GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, k_genp* sG, bool robust, int iters, double* red, int* s_flag,
                         double* s_lds, double* p2part) {
   const int P = G.P, n = 6 * P, ld = G.ld, tid = threadIdx.x;
   // lanes per point in the point passes: as many (1, 2, 4) as the problem's threads allow in one round
@@ -1407,6 +1431,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
   // ---- initializeOptimization(0): active poses / points -----------------------------------
   for (int j = GSTART; j < P; j += GSTRIDE) G.pact[j] = (G.pfree[j] && G.prior[j] && k.first_as_prior) ? 1 : 0;
   prob_sync(G);
+  GFRESH();
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
   for (int l = GSTART; l < G.L; l += GSTRIDE) {
@@ -1421,9 +1446,11 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
     if (any) acc[0] += 1.0;
   }
   prob_sync(G);
+  GFRESH();
   for (int j = GSTART; j < P; j += GSTRIDE)
     if (G.pact[j]) acc[1] += 1.0;
   prob_reduce<2>(G, acc, red);
+  GFRESH();
   const bool any_point = acc[0] > 0.0, any_pose = acc[1] > 0.0;
   if (!any_point && !any_pose) return -1;
   double* S = G.S;  // where P2 / priors assemble the reduced system (global when NB > 1)
@@ -1457,13 +1484,16 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       fresh = true;
       for (int i = GSTART; i < n * ld; i += GSTRIDE) S[i] = 0.0;
       prob_sync(G);
+      GFRESH();
       pass_blocks(G, false, p2part);
       prob_sync(G);
+      GFRESH();
       for (int j = GSTART; j < P; j += GSTRIDE) {
         if (!G.pact[j]) continue;
         for (int r = 0; r < 6; ++r) md = fmax(md, fabs(S[(size_t)(6 * j + r) * ld + 6 * j + r] + G.prH[(size_t)j * 36 + r * 6 + r]));
       }
       md = prob_max(G, md, red);
+      GFRESH();
       lambda = 1e-5 * md;
       ni = 2.0;
     }
@@ -1486,11 +1516,13 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         G.bp[i] = 0.0;
       }
       prob_reduce<1>(G, acc, red);  // (its barriers also publish P1's per-point results)
+      GFRESH();
       double chiA = acc[0];
       if (G.NB == 1) __syncthreads();
       GP_T(t1);
       pass_blocks(G, true, p2part);
       prob_sync(G);
+      GFRESH();
       GP_T(t2);
       // ---- workgroup 0: priors / inactive poses, solve, trial poses (P <= ~20 poses: not worth a barrier each)
       bool ok2 = true;
@@ -1558,6 +1590,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         }
       }
       prob_sync(G);
+      GFRESH();
       ok2 = *G.flagg != 0;
       if (G.stop) G.stop_seen = G.flagg[1];
       for (int j = 0; j < P; ++j) chiA += G.pchi[j];
@@ -1567,6 +1600,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
       for (int i = 0; i < 32; ++i) acc[i] = 0.0;
       pass_trial_lpp(lpp, k, gm, G, robust, lambda, P, acc);
       prob_reduce<2>(G, acc, red);
+      GFRESH();
       double scale = acc[0], tempChi = acc[1];
       for (int j = 0; j < P; ++j) tempChi += G.pchi2[j];
       for (int i = 0; i < n; ++i) scale += G.dxv[i] * (lambda * G.dxv[i] + G.bp[i]);
@@ -1597,6 +1631,7 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, bool robust, in
         fresh = true;
       }
       prob_sync(G);
+      GFRESH();
       qmax++;
       ++G.trials;
       GP_T(t5);
@@ -1704,6 +1739,15 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.pfree = takeB(P + F);
   G.pact = takeB(P);
   G.lact = takeB(L);
+  // the address table (header comment of genp_fresh): every workgroup of the problem writes the same words, then reads them back
+  GenP* const tab = (GenP*)(scratch + (size_t)B * 512 + (size_t)(f + 1) * scratch_per_problem - GEN_TABLE_BYTES);
+  k_genp* const sG = (k_genp*)tab;
+  if (tid == 0) {
+    *tab = G;
+    __threadfence();
+  }
+  __syncthreads();
+  GFRESH();
 
   // ---- setup --------------------------------------------------------------------------------------
   for (int j = GSTART; j < P + F; j += GSTRIDE) {
@@ -1724,6 +1768,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   }
   for (size_t i = GSTART; i < (size_t)nobs * P; i += GSTRIDE) G.plm[i] = -1;
   prob_sync(G);
+  GFRESH();
   if (stop_dev) {
     G.stop_seen = G.flagg[1];
     if (G.stop_seen > 0) {  // `if (pbStopFlag) if (*pbStopFlag) return;` (:765-767): nothing is written
@@ -1744,11 +1789,13 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
       if (lane == 0) G.pl_ptr[j + 1] = cnt;
     }
     prob_sync(G);
+    GFRESH();
     if (G.pb == 0 && tid == 0) {
       G.pl_ptr[0] = 0;
       for (int j = 0; j < P; ++j) G.pl_ptr[j + 1] += G.pl_ptr[j];
     }
     prob_sync(G);
+    GFRESH();
     for (int j = gw; j < P; j += gnw) {
       int base = G.pl_ptr[j];
       for (int o0 = 0; o0 < nobs; o0 += 64) {
@@ -1766,6 +1813,7 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
     }
   }
   prob_sync(G);
+  GFRESH();
   // partner table, indexed by list position: entry (e, j2) = the observation of the same point in free pose j2
   for (int l = GSTART; l < L; l += GSTRIDE)
     for (int o1 = G.optr[l]; o1 < G.optr[l + 1]; ++o1) {
@@ -1777,21 +1825,25 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
       }
     }
   prob_sync(G);
+  GFRESH();
   double* s_lds = s_in_lds ? dyn_lds : nullptr;
 
   // ---- schedule (:770-828) ---------------------------------------------------------------------------
   // (three inlined copies of the optimiser, each with its constants folded: a loop over the stages gives a third of
   // the code but other contraction decisions, i.e. other last bits than the validated build)
-  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds, p2part);
+  gen_optimize(k, gm, G, sG, true, 5, red, &s_flag, s_lds, p2part);
   prob_sync(G);
+  GFRESH();
   for (int l = GSTART; l < L; l += GSTRIDE) {
     GmmRef g;
     load_gmm(G.assoc[l], gm.axis, gm.rec12, gm.sqrt_info, gm.flags, g);
     if (g.has && g.deg && gmm_chi2(k, g, G.pts + (size_t)l * 3) > k.str_thresh) G.lev_g[l] = 1;
   }
   prob_sync(G);
-  gen_optimize(k, gm, G, true, 5, red, &s_flag, s_lds, p2part);
+  GFRESH();
+  gen_optimize(k, gm, G, sG, true, 5, red, &s_flag, s_lds, p2part);
   prob_sync(G);
+  GFRESH();
   int it3 = 0;
   if (!stop_now(G)) {  // bDoMore (:791-796)
     for (int l = GSTART; l < L; l += GSTRIDE)
@@ -1803,14 +1855,17 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
         if (G.chi_o[o] > (stereo ? 7.815 : 5.991) || !(z > 0.0)) G.lev_o[o] = 1;
       }
     prob_sync(G);
+    GFRESH();
     // the partner table forgets the edges that are now at level 1
     for (size_t i = GSTART; i < (size_t)G.pl_ptr[P] * P; i += GSTRIDE) {
       const int o2 = G.plm[i];
       if (o2 >= 0 && (G.lev_o[o2] || G.lev_o[G.pl_obs[i / P]])) G.plm[i] = -1;
     }
     prob_sync(G);
-    it3 = gen_optimize(k, gm, G, false, 40, red, &s_flag, s_lds, p2part);
+    GFRESH();
+    it3 = gen_optimize(k, gm, G, sG, false, 40, red, &s_flag, s_lds, p2part);
     prob_sync(G);
+    GFRESH();
   }
   // ---- outputs (:837-879) ---------------------------------------------------------------------------
   for (int l = GSTART; l < L; l += GSTRIDE) {
@@ -1839,7 +1894,7 @@ size_t gen_scratch_bytes(int P, int F, int L, int NOBS) {
              (size_t)L * 12 + NOBS + n * (n + 2) + 512 + 3 * n + 2 * P + 42 * (size_t)P + (size_t)L * 6;
   size_t i = (size_t)NOBS * 4 + (P + 1) + (size_t)NOBS * P + 32;
   size_t b = (size_t)NOBS + 2 * (size_t)L + (P + F) + P + 64;
-  return d * 8 + i * 4 + b + 256;
+  return d * 8 + i * 4 + b + 256 + 2 * GEN_TABLE_BYTES;  // (+ k_ba_gen's address table in the last 512 bytes of the 256-aligned area)
 }
 
 }  // namespace
