@@ -277,7 +277,7 @@ __global__ void k_nearest_chi2(const int32_t* __restrict__ knn_idx, int knn, con
 
 namespace gl {
 
-// Launch shape (tools/tune_assoc.py sweep on MI355X, profiles/r1_assoc_tuning.txt):
+// Launch shape (tools/tune_assoc.py sweep on MI355X, profiles/history/r1_assoc_tuning.txt):
 //  * points per thread: 4 amortises the broadcast LDS reads best once there are enough points;
 //  * K splits: aim for ~4096 workgroups so the tail is short; a single 2 000-point frame still
 //    gets 8 x 64 workgroups.

@@ -754,7 +754,7 @@ GL_DEV double prior_lin(const cdouble_k* mi, const Pose& P, double* H, double* b
 // The 6 x 6 products run lane-parallel out of an LDS work area (108 doubles: Jr, Adj, J = Jr Adj; lane (i, j) owns one
 // element): evaluated in registers (prior_lin: J[36] and ~120 live values) the edge took the register allocation of the
 // PASS LOOPS from 36 to 181 spilled VGPRs - inlined - or forced everything that lives across a call into the callee-saved
-// registers - as a function - and the whole anchored kernel ran at 0.4 - 0.6 of the plain one (profiles/r3_prior_cost.txt).
+// registers - as a function - and the whole anchored kernel ran at 0.4 - 0.6 of the plain one (profiles/history/r3_prior_cost.txt).
 GL_DEV void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 GL_DEV void prior_record_wave(const cdouble_k* mi, const Pose& P, double* rec, double* work, bool rezero) {
   const int lane = threadIdx.x & 63;
@@ -1498,7 +1498,7 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
     // ~1e4: the subtracted form keeps ~5 of its 16 digits there, and on a frame whose reduced system is itself near
     // singular (gauge direction held by lambda alone, cond ~1e11) that noise decides accept / reject steps of the
     // Levenberg path (soak frame v1 r19656: 1.75e-5 m off an oracle that 400 perturbed runs do not move; with this form HIP
-    // follows the oracle's path step for step, profiles/r2f_track_v1_r19656_trace_*.txt).
+    // follows the oracle's path step for step, profiles/history/r2f_track_v1_r19656_trace_*.txt).
     {
       const double M[9] = {(o.D[0] - o.A[0]) + lambda, o.D[1] - o.A[1], o.D[2] - o.A[2],
                            o.D[1] - o.A[1], (o.D[3] - o.A[3]) + lambda, o.D[4] - o.A[4],

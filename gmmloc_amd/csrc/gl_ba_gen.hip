@@ -739,7 +739,7 @@ GL_DEV void pass_blocks(const GenP& G, bool schur, double* p2part) {
     load_Rt(G.Rt + (size_t)j1 * 12, R1, t1);
     load_Rt(G.Rt + (size_t)j2 * 12, R2, t2);
     // Software-pipelined variant (-DGL_BAGEN_PIPE, round 3: the indices and the three records of entry e + step are
-    // requested while entry e is worked on) measured against this loop on one box (tools/ab_gen.sh, profiles/r3_bagen_ab.txt):
+    // requested while entry e is worked on) measured against this loop on one box (tools/ab_gen.sh, profiles/history/r3_bagen_ab.txt):
     // 20 + 8 key-frames 6.51 -> 6.41 ms, 256-problem batches 0.113 -> 0.107 ms per problem, but 8 + 4 key-frames
     // 2.89 -> 3.53 ms and 12 + 4 4.70 -> 5.57 ms - there 2 waves share a block, a lane has 8 entries, and the 33 live
     // prefetch registers take the kernel from 337 to 536 spilled VGPRs.  Not the default.
@@ -1319,7 +1319,7 @@ GL_DEV bool ldlt_solve_teams(const GenP& G, const BaK& k, double lambda, const d
 // v_readlane broadcasts (A[j][k] is register k of lane j - static indices in the unrolled code) and every lane updates its own
 // row, S[r][j] -= l_rk S[j][k] in ascending k like the scalar loop; the forward substitution rides along, z = D^-1 y by
 // division, L^T x = z as 48 wave sums.  ~4 300 instructions on one wave against the blocked algorithm's 8 x (3 barriers +
-// a one-wave diagonal block + panel + register-tile update).  MEASURED (profiles/r3_bagen_shapes.txt), NOT ENABLED (-DGL_BAGEN_WAVE_LDLT): in
+// a one-wave diagonal block + panel + register-tile update).  MEASURED (profiles/history/r3_bagen_shapes.txt), NOT ENABLED (-DGL_BAGEN_WAVE_LDLT): in
 // the pipelined shape's solve kernel a window of 8 + 4 key-frames goes 2.96 -> 2.90 ms; inlined into the persistent kernel the
 // 48-register rows take it from 272 to 809 spilled VGPRs and the same window from 2.87 to 3.65 ms.
 // Rows n .. NMAX-1 are identity padding (they cost their share of the unrolled code: two instances, 24 and 48).
@@ -3284,7 +3284,7 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   GL_HIP(hipSetDevice(c->device));
   void* scratch = nullptr;
   // Shape (option bagen_mode: 0 by size, 1 the persistent kernel, 2 the pipelined shape).  Measured per Levenberg trial
-  // (profiles/r3c_ba_modes.txt; the two shapes add their partial sums in different orders, so a window can take a different
+  // (profiles/history/r3c_ba_modes.txt; the two shapes add their partial sums in different orders, so a window can take a different
   // NUMBER of trials in each - 22 against 33 on the 20 + 8 window - which says nothing about either): 8 + 4 key-frames / 12 600
   // observations 73 us pipelined against 103 persistent, 12 + 4 / 22 400 103 against 149, 20 + 8 / 58 600 155 against 299; equal
   // at 3 - 4 free poses (57 us), the persistent kernel ahead below (1 pose: 32 against 49) and in batches (64 windows of 8 + 4:
@@ -3292,7 +3292,7 @@ static int joint_optimization_impl(gl_ctx_t* ctx, const gl_gmm_t* gmm, const gl_
   const bool pipe_fits = P <= 22 && P + F <= 32 && (size_t)L * (NOBS >= 6 * L ? 8 : 4) <= 65536;  // (the judging workgroups hold <= 256 partial sums and the poses in LDS)
   // (mode 0 chooses from the WINDOW alone - never from B: the two shapes add their partial sums in different orders, and a
   // window must not change its bits, or the call its blocking behaviour, with the number of windows that ride along)
-  // (from 3 000 observations since the end of round 4 - 5 000 before: profiles/r4f_ba_modes.txt has the pipelined shape ahead from
+  // (from 3 000 observations since the end of round 4 - 5 000 before: profiles/history/r4f_ba_modes.txt has the pipelined shape ahead from
   // 3 300 observations at every batch size, 9 % on one window and 30 % on eight, and per trial already at 2 100)
   const bool pipe = pipe_fits && (c->opt.bagen_mode == 2 || (c->opt.bagen_mode == 0 && NOBS >= 3000));
   int rc = gl::ctx_scratch(c, pipe ? gl::ba_pipe_scratch_total(c, B, P, F, L, NOBS) : gl::ba_gen_scratch_bytes(B, P, F, L, NOBS), &scratch);

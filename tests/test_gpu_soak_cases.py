@@ -1,4 +1,4 @@
-"""The deviations the strict randomised soak found (tools/soak.py, 2 000 rounds per map; profiles/r2_soak_*.txt),
+"""The deviations the strict randomised soak found (tools/soak.py, 2 000 rounds per map; profiles/history/r2_soak_*.txt),
 each held as a three-way test: HIP vs the C++ oracle vs the independent numpy restatement
 (tests/golden/soak_numpy_ref.npz, tools/make_soak_golden.py), together with the oracle's OWN sensitivity to changes
 that leave the mathematics untouched (inputs moved by an ulp, points re-ordered).  A case counts as ill-conditioned
@@ -97,7 +97,7 @@ def test_soak_track_near_singular_reduced_system(env, oracle, opt):
     detour and ran out of the iteration budget 1.75e-5 m from an optimum that the oracle, its FMA-contracted build, the
     numpy restatement and 400 perturbed oracle runs all reach - a real weakness, not an ill-conditioned input.  Evaluated
     as M D^-1 A (gl_ba_fast_impl.hpp, gl_ba.hip) every kernel follows the oracle's path: strict tolerance here, for the
-    batch shape, the latency shape and the general kernel.  profiles/r2f_track_v1_r19656_trace*.txt"""
+    batch shape, the latency shape and the general kernel.  profiles/history/r2f_track_v1_r19656_trace*.txt"""
     e = env
     mean, cov, g, h = e["maps"]["map_v1"]
     f = sc.gen("map_v1", 19656, mean, cov, e["gts"], e["cam"])["track"]
@@ -254,7 +254,7 @@ def test_soak_create_map_points_rejected_match(env, oracle, mapname, r, j):
 
 
 # ---- round 3: the deviations of the 20 000-round soak on the anchored per-frame path and on the pipelined local BA ----------
-TRACK_PRIOR = [("map_v1", 16708), ("map_v2", 292), ("map_v2", 4632)]   # profiles/r3_soak_strict_20000.txt: 3 of 10 000 frames
+TRACK_PRIOR = [("map_v1", 16708), ("map_v2", 292), ("map_v2", 4632)]   # profiles/history/r3_soak_strict_20000.txt: 3 of 10 000 frames
 BA_PIPE = [333, 3893]                                                    # 2 of 2 500 windows on the pipelined shape
 
 
@@ -340,7 +340,7 @@ def test_soak_ba_pipelined_gauge_free_window(env, oracle, opt, r):
         assert np.array_equal(out[2][0], ref[2]) and np.array_equal(out[3][0][:nobs], ref[3])
 
 
-# ---- round 3, 50 000-round soak (profiles/r3c_soak_strict_50000.txt): ONE decision of createMapPoints in 48 M matches ------------
+# ---- round 3, 50 000-round soak (profiles/history/r3c_soak_strict_50000.txt): ONE decision of createMapPoints in 48 M matches ------------
 def test_soak_create_map_points_parallax_knife_edge(env, oracle):
     """createMapPoints decides between the two-view triangulation and the stereo un-projection with
     `cosParallaxRays < cos(2 atan2(mb / 2, depth))`, both sides FLOAT (localization_opt.cpp:306-321).  On match 270 of

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Outputs of the independent numpy restatement (oracle/numpy_ref.py) on the soak cases that
-tests/test_gpu_soak_cases.py holds (the deviations the strict randomised soak found, profiles/r2_soak_*.txt):
+tests/test_gpu_soak_cases.py holds (the deviations the strict randomised soak found, profiles/history/r2_soak_*.txt):
 the third leg of the HIP / C++ oracle / numpy comparison.  The dense un-reduced numpy LM takes ~20 s per frame, so its
 answers are committed as a fixture; inputs are regenerated from the (map, round) label by tools/soak_cases.py.
     python tools/make_soak_golden.py        # rewrites tests/golden/soak_numpy_ref.npz (CPU only, ~2 min)"""

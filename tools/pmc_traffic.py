@@ -3,7 +3,7 @@
 JSON: counters averaged per launch of the bench launches (16 384 frames since round 5), and the HBM-side traffic
 (FETCH_SIZE x 2 on gfx950, see /opt/skills/guides/MI355X_MICROARCH.md: the counter is in KB of 64-B requests that are
 128 B on this chip) + WRITE_SIZE, per launch and per frame.
-    python tools/pmc_traffic.py gpurun_out/prof_r2 > profiles/r2_traffic.json"""
+    python tools/pmc_traffic.py gpurun_out/prof_r2 > profiles/history/r2_traffic.json"""
 import glob
 import json
 import os
