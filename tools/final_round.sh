@@ -23,6 +23,7 @@ python tools/chain_time.py > gpurun_out/${TAG}_chain_time.json 2>/dev/null
 bash tools/pmc_match.sh ${TAG} > gpurun_out/${TAG}_pmc_match.log 2>&1
 rm -rf gpurun_out/pmc_match_${TAG}
 python tools/soak_match.py ${SOAK_MATCH:-300} 2>/dev/null | tail -3 > gpurun_out/${TAG}_soak_match.txt
+python tools/soak_chain.py ${SOAK_CHAIN:-1500} 2>/dev/null | tail -12 > gpurun_out/${TAG}_soak_chain.txt; tail -1 gpurun_out/${TAG}_soak_chain.txt | cut -c1-400
 python tools/soak.py 2000 > gpurun_out/${TAG}_soak_strict.txt 2>&1
 tail -2 gpurun_out/${TAG}_soak_strict.txt | cut -c1-500
 python tools/soak_track.py ${SOAK_TRACK:-86000} > gpurun_out/${TAG}_soak_track.txt 2>&1
