@@ -7,6 +7,7 @@ python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.tx
 # (tools/kernel_meta.py reads the object files of the build container: run it there -> profiles/<tag>_kernel_meta.txt)
 bash tools/profile_bench.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
 rm -rf gpurun_out/prof_$TAG   # (the rocprofv3 databases: summarised above; gpurun copies at most 64 MiB back)
+cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_traffic.json   # (on the box: bench.py's `roofline.traffic` reads the latest profiles/r*_traffic.json - this run's own, same sources)
 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 python tools/run_configs.py --configs 2,3,4,5,ba,kf,match > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err
 python tools/latency.py > gpurun_out/${TAG}_latency.txt 2>/dev/null
