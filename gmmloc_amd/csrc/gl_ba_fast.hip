@@ -60,6 +60,7 @@ struct BafKArgs {
   FixedV fxv;
   int32_t* edges_out;
   int* frame_ctr;
+  double* un_scratch;  // the two-groups-per-wave instance: 6 x 2000 doubles per workgroup of the launch (the points' hand-over slots)
 };
 __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
   PrepView v;
@@ -295,6 +296,26 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_FIXED
 
 // anchored instances (gl_track_frames_anchored: prior edge on the frame's pose, or fixed pose), exact step
+#define GL_BAF_NS bafd2000x  // 2 frames per CU: two groups of the canonical order per wave, the hand-over slots in global memory (GL_BAF_GPW)
+#define GL_BAF_MCAP 2000
+#define GL_BAF_NW 8
+#define GL_BAF_SPREAD 0
+#define GL_BAF_STEP32 0
+#define GL_BAF_PRIOR 0
+#define GL_BAF_FIXED 0
+#undef GL_BAF_GPW
+#define GL_BAF_GPW 2
+#include "gl_ba_fast_impl.hpp"
+#undef GL_BAF_GPW
+#define GL_BAF_GPW 1
+#undef GL_BAF_NS
+#undef GL_BAF_MCAP
+#undef GL_BAF_NW
+#undef GL_BAF_SPREAD
+#undef GL_BAF_STEP32
+#undef GL_BAF_PRIOR
+#undef GL_BAF_FIXED
+
 #define GL_BAF_NS bafd496p  // 
 #define GL_BAF_MCAP 496
 #define GL_BAF_NW 2
@@ -492,13 +513,18 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   // (the anchored middle classes give 8 / 16 points for the prior edge's LDS records and the key-frames' poses)
   const int mid = fixed ? 984 : a.prior ? 992 : 1000;
   const int cap = s32 ? 2000 : (a.L <= 496 ? 496 : a.L <= mid ? mid : 2000);
-  const BafKernel kern = s32 ? bafd2000s32::k_ba1_fast
+  const BafKernel kern0 = s32 ? bafd2000s32::k_ba1_fast
                          : fixed ? (cap == 496 ? bafd496f::k_ba1_fast : cap == 984 ? bafd1000f::k_ba1_fast : bafd2000f::k_ba1_fast)
                          : a.prior ? (cap == 496 ? bafd496p::k_ba1_fast : cap == 992 ? bafd1000p::k_ba1_fast : bafd2000p::k_ba1_fast)
                                    : (cap == 496 ? bafd496::k_ba1_fast : cap == 1000 ? bafd1000::k_ba1_fast : bafd2000::k_ba1_fast);
+  // the largest class, plain refine: two frames per CU (bafd2000x: two groups per wave, hand-over slots in global memory; same bits)
+  const bool two = !GL_BAF_W3 && c->opt.ba_two_frames != 0 && kern0 == bafd2000::k_ba1_fast && !a.ctl;
+  const BafKernel kern = two ? bafd2000x::k_ba1_fast : kern0;
+  const int threads = two ? 64 * std::min(a.G, 4) : 64 * a.G;
   const bool w3 = GL_BAF_W3 && kern == bafd2000::k_ba1_fast;  // (experiment: 12 groups' totals, MCAP 1984)
   if (w3 && a.L > 1984) return GL_ERR_ARG;
   const size_t lds = w3 ? (size_t)(10 * 1984 + 12 * 32 + 64 + 24 + 24) * sizeof(double)
+                     : two ? (size_t)(4 * cap + 8 * 32 + 64 + 40) * sizeof(double)
                         : (size_t)(10 * cap + (cap == 496 ? 2 : cap <= 1000 ? 4 : 8) * 32 + 64 + 40 + (anch ? 64 + (cap == 496 ? 108 : 0) : 0) + (fixed ? 48 : 0)) * sizeof(double);
   GL_HIP(ensure_dynamic_lds(c, (const void*)kern, lds));
   a.NB = 1;
@@ -507,11 +533,11 @@ static int launch_dense(Ctx* c, BafArgs& a) {
   int grid = a.B;
   int* fctr = nullptr;
   if (c->opt.ba_persist != 0 && a.fctr) {
-    const auto key = std::make_pair((const void*)kern, lds + (size_t)(64 * a.G));
+    const auto key = std::make_pair((const void*)kern, lds + (size_t)threads);
     auto hit = c->occupancy.find(key);
     if (hit == c->occupancy.end()) {
       int occ = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * a.G, lds) != hipSuccess) occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, threads, lds) != hipSuccess) occ = 0;
       hit = c->occupancy.emplace(key, occ).first;
     }
     if (hit->second > 0 && (long)hit->second * c->ncu < (long)a.B) {
@@ -519,9 +545,14 @@ static int launch_dense(Ctx* c, BafArgs& a) {
       fctr = a.fctr;
     }
   }
+  void* un = nullptr;  // (bafd2000x: 96 KB of hand-over slots per workgroup of the launch, in the context's second scratch block)
+  if (two) {
+    const int rc = gl::ctx_scratch_b(c, (size_t)grid * 6 * 2000 * sizeof(double), &un);
+    if (rc != GL_OK) return rc;
+  }
   const BafKArgs ka{a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB, a.parts, a.ctl, 0ll, 0, a.oct, a.prior,
-                    a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx, a.stats_edges, fctr};
-  kern<<<grid, 64 * a.G, lds, c->stream>>>(ka);
+                    a.prior_mi, a.stage, a.nb_prev, a.counters, a.stats_iters, a.fx, a.stats_edges, fctr, (double*)un};
+  kern<<<grid, threads, lds, c->stream>>>(ka);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -560,7 +591,7 @@ static int launch_spread(Ctx* c, BafArgs& a, void* scratch) {
   // (NB > 1: 64 block indices per 8 frames, the kernel's map from block to (frame, group) keeps a frame on one XCD)
   const int grid = a.NB > 1 ? 64 * ((a.B + 7) / 8) : a.B;
   const BafKArgs ka{a.k, a.gm, a.B, a.L, a.G, a.S, a.pose, a.pts, a.assoc, a.dropped, a.erase, a.iters, a.pn, a.stats, a.NB, a.parts, a.ctl, limit,
-                    (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx, a.stats_edges, nullptr};
+                    (c->xcc_ids_trusted && c->opt.ba_same_xcd != 0) ? 1 : 0, a.oct, a.prior, a.prior_mi, a.stage, 0, a.counters, a.stats_iters, a.fx, a.stats_edges, nullptr, nullptr};
   kern<<<grid, 256, lds, c->stream>>>(ka);
   GL_HIP(hipGetLastError());
   return a.NB > 1 ? 2 : GL_OK;  // 2: follow up with DENSE for the frames that did not complete

@@ -74,7 +74,19 @@ constexpr bool kAsym = GL_BAF_ASYM != 0 && GL_BAF_NW == 8;  // uneven deal of th
 #define GL_BAF_ALLSOLVE 0  // measured (profiles/r5_ab_allsolve.txt): same bits, refine 10.80 -> 11.09 ms per 4 096 frames - seven more waves issuing the ~350 dependent instructions cost more than the hand-over they save
 #endif
 constexpr bool kAllSolve = !kSpread && GL_BAF_ALLSOLVE != 0;  // DENSE: every wave solves the reduced system itself (optimize_fast)
-constexpr int NWC = GL_BAF_NW;             // DENSE: waves (= groups) a frame of this LDS class has at most
+constexpr int NWC = GL_BAF_NW;             // DENSE: GROUPS of the canonical order a frame of this LDS class has at most (= its waves, but see GPW)
+#ifndef GL_BAF_GPW
+#define GL_BAF_GPW 1
+#endif
+// GPW = 2 (the `x` instance of the largest class): a wave owns TWO groups of the canonical order - g and g + 4, four slots each, a
+// reduce-scatter after each group's slots, so every sum is added exactly as by eight waves - and the 48-byte hand-over slot of a
+// point (factors of pass A / backup of pass B) lives in GLOBAL memory, written and read back by the thread that owns the point.
+// The frame then needs 4 waves and 32 B of LDS per point: TWO frames per CU like the 1 000-point class, one wave of each per SIMD
+// (no older / younger wave of the same frame, one frame's solve behind the other's passes).
+constexpr int GPW = GL_BAF_GPW;
+constexpr bool kTwo = GPW == 2;
+constexpr int NWV = NWC / GPW;             // waves of a frame at most
+static_assert(GPW == 1 || (GPW == 2 && NWC == 8 && !kSpread && !kStep32), "two groups per wave: the plain batch instance of the 2 000-point class");
 constexpr int NRED = kSpread ? 1 : NWC;    // group totals kept in LDS (a SPREAD workgroup is ONE group)
 constexpr int TSP = 256;                   // SPREAD: threads of a workgroup = the <= 4 slot waves of its group
 
@@ -272,13 +284,25 @@ struct Lds {      // per-frame state, SoA over MCAP points (index = local point 
   int F, Lf;
 };
 // per-point flag bits + octave (bits 8..10) live in REGISTERS: 16 bits per point slot of the thread
-struct FlagW {  // slots 0..3 in `lo`, slot 4 (the fifth chunk of a big group, GL_BAF_ASYM) in `hi`
-  unsigned long long lo;
-  unsigned hi;
+template <bool TWO>
+struct FwHi {
+  typedef unsigned type;
 };
-GL_DEV int fw_get(const FlagW& fw, int i) { return i < 4 ? (int)((fw.lo >> (16 * i)) & 0xffffull) : (int)(fw.hi & 0xffffu); }
+template <>
+struct FwHi<true> {
+  typedef unsigned long long type;
+};
+struct FlagW {  // slots 0..3 in `lo`, slot 4 (the fifth chunk of a big group, GL_BAF_ASYM) in `hi`; GPW = 2: the second group's slots 4..7 in `hi`
+  unsigned long long lo;
+  FwHi<kTwo>::type hi;
+};
+GL_DEV int fw_get(const FlagW& fw, int i) {
+  if (kTwo) return (int)(((i < 4 ? fw.lo : (unsigned long long)fw.hi) >> (16 * (i & 3))) & 0xffffull);
+  return i < 4 ? (int)((fw.lo >> (16 * i)) & 0xffffull) : (int)(fw.hi & 0xffffu);
+}
 GL_DEV void fw_or(FlagW& fw, int i, int bits) {
   if (i < 4) fw.lo |= (unsigned long long)bits << (16 * i);
+  else if (kTwo) fw.hi |= (FwHi<kTwo>::type)((unsigned long long)bits << (16 * (i & 3)));
   else fw.hi |= (unsigned)bits;
 }
 GL_DEV void fw_activity(FlagW& fw, int i) {
@@ -288,9 +312,26 @@ GL_DEV void fw_activity(FlagW& fw, int i) {
   if ((fl & F_EXISTS) && (fl & F_ASSOC) && !(fl & F_LEVG)) act |= F_AG;
   if (kFixed && (fl & F_EXISTS) && ((fl / F_OFFF) & 15) != 15) act |= F_AF;
   if (i < 4) fw.lo = (fw.lo & ~((unsigned long long)(F_AR | F_AG | F_AF) << (16 * i))) | ((unsigned long long)act << (16 * i));
+  else if (kTwo) fw.hi = (FwHi<kTwo>::type)(((unsigned long long)fw.hi & ~((unsigned long long)(F_AR | F_AG | F_AF) << (16 * (i & 3)))) | ((unsigned long long)act << (16 * (i & 3))));
   else fw.hi = (fw.hi & ~(unsigned)(F_AR | F_AG | F_AF)) | (unsigned)act;
 }
 
+// the hand-over slot of a point (Lds::un).  GPW = 2: global memory, streamed (-DGL_BAF_UN_NT: non-temporal accesses)
+GL_DEV void un_st(double* p, double v) {
+#ifdef GL_BAF_UN_NT
+  if (kTwo) {
+    __builtin_nontemporal_store(v, p);
+    return;
+  }
+#endif
+  *p = v;
+}
+GL_DEV double un_ld(const double* p) {
+#ifdef GL_BAF_UN_NT
+  if (kTwo) return __builtin_nontemporal_load(p);
+#endif
+  return *p;
+}
 // the canonical order of a frame of stride L and this thread's place in it
 struct Map {
   int S;      // point slots of this thread (DENSE: chunks of its group; SPREAD: 1)
@@ -299,6 +340,7 @@ struct Map {
   int step;   // 64 G: the chunks of a group are G apart
   int L;      // points of the frame
   bool asym;  // GL_BAF_ASYM, frames of 8 groups: the groups 0..3 take five chunks, the groups 4..7 three (slot_off)
+  bool g2;    // GPW = 2: the wave's second group (wave + 4) exists in this frame (G > wave + 4): its slots 4..7 are points of the frame
 };
 // Offset of slot i from the thread's first point.  Frames of 8 groups (29 .. 32 chunks: the 2 000-point class), GL_BAF_ASYM: the two
 // waves of a SIMD do not run at the same speed - the arbiter serves the older one first, the younger one fills the gaps, and once
@@ -306,7 +348,12 @@ struct Map {
 // behind): a third of every pass.  The chunks are therefore dealt unevenly: rounds 0..2 one chunk to each of the 8 groups (chunk
 // 8 r + g), rounds 3 and 4 only to the groups 0..3 (chunk 24 + 4 (r - 3) + g): the older wave of every SIMD has five chunks,
 // the younger three, and they end their passes together (profiles/r5_prof_ba_slots.txt).  Still a function of L alone.
-GL_DEV int slot_off(const Map& mp, int i) { return !mp.asym ? mp.step * i : (i < 3 ? 512 * i : 1536 + 256 * (i - 3)); }
+GL_DEV int slot_off(const Map& mp, int i) {
+  if (kTwo) return mp.step * (i & 3) + 64 * NWV * (i >> 2);  // slots 4..7: the chunks of group wave + 4
+  return !mp.asym ? mp.step * i : (i < 3 ? 512 * i : 1536 + 256 * (i - 3));
+}
+// (GPW = 2) slot i belongs to a group this frame does not have: its chunk index would alias another group's
+GL_DEV bool slot_absent(const Map& mp, int i) { return kTwo && i >= 4 && !mp.g2; }
 
 struct Lin {
   double q[3];
@@ -938,7 +985,11 @@ GL_DEV void reduce_to_tot(double* v, const Red& R, Coop& C) {
     const double r = wave_reduce_scatter32(v);
     // no barrier needed before writing `red`: its last readers (threads < 32) finished before the
     // closing barrier of the previous reduction, which every thread has passed
-    if (wave_slot_owner(lane)) R.red[wave * 32 + wave_slot(lane)] = r;
+    if (wave_slot_owner(lane)) {
+      R.red[wave * 32 + wave_slot(lane)] = r;
+      // (GPW = 2: both groups of the wave in one row - only exact sums go this way: counts, XCC ids -, the second group's row reads 0.0)
+      if (kTwo) R.red[(wave + NWV) * 32 + wave_slot(lane)] = 0.0;
+    }
     __syncthreads();
     if (threadIdx.x < 32) {  // absent groups hold zeros (never written after the initial clear); a class
       // with fewer groups than 8 just has no further (all-zero) blocks to add
@@ -1125,12 +1176,23 @@ GL_DEV void spread_reduce2_all(double* v, const Red& R, Coop& C) {
 // itself and hands the totals round its lanes with v_readlane - no `tot` round trip, no second barrier.  The next
 // writer of red[] is the next trial's pass A, two barriers later.
 // (all_waves: every wave adds the blocks and takes the totals - GL_BAF_ALLSOLVE, the serial section without a hand-over)
-GL_DEV void reduce29_w0_dense(double* v, const Red& R, bool all_waves = false) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// (GPW = 2) the totals of the group whose slots the wave has just finished -> row `row` of red[]; the accumulators start again at zero
+GL_DEV void group_flush29(double* v, const Red& R, int row) {
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 29; i < 32; ++i) v[i] = 0.0;
   const double r = wave_reduce_scatter32(v);
-  if (wave_slot_owner(lane)) R.red[wave * 32 + wave_slot(lane)] = r;
+  if (wave_slot_owner(lane)) R.red[row * 32 + wave_slot(lane)] = r;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = 0.0;
+}
+GL_DEV void reduce29_w0_dense(double* v, const Red& R, bool all_waves = false) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = kTwo ? wave + NWV : wave;  // (GPW = 2: v[] holds the wave's SECOND group; the first went to its row at slot 4)
+#pragma unroll
+  for (int i = 29; i < 32; ++i) v[i] = 0.0;
+  const double r = wave_reduce_scatter32(v);
+  if (wave_slot_owner(lane)) R.red[row * 32 + wave_slot(lane)] = r;
   __syncthreads();
   if (wave == 0 || all_waves) {
     const int t = lane & 31;
@@ -1181,8 +1243,16 @@ GL_DEV double wave_allreduce_canon(double x) {
 }
 // pass B (2 values, needed by every thread): wave totals to the small buffer red2, ONE barrier, every thread
 // adds the blocks itself.  The buffer is rewritten one trial later, with the barriers of pass A in between.
+GL_DEV void group_flush2(double* v, const Red& R, int row) {  // (GPW = 2: like group_flush29, for pass B's two sums)
+  const double s0 = wave_allreduce_canon(v[0]), s1 = wave_allreduce_canon(v[1]);
+  if ((threadIdx.x & 63) == 0) {
+    R.red2[row * 2] = s0;
+    R.red2[row * 2 + 1] = s1;
+  }
+  v[0] = v[1] = 0.0;
+}
 GL_DEV void reduce2_dense(double* v, const Red& R) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = kTwo ? (int)(threadIdx.x >> 6) + NWV : (int)(threadIdx.x >> 6);
   const double s0 = wave_allreduce_canon(v[0]), s1 = wave_allreduce_canon(v[1]);
   if (lane == 0) {
     R.red2[wave * 2] = s0;
@@ -1277,7 +1347,7 @@ GL_DEV void backup_point(const Lds& D, int ll, const double* p) {
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) D.un[j * MCAP + ll] = p[j];
+    for (int j = 0; j < 3; ++j) un_st(D.un + (unsigned)(j * MCAP + ll), p[j]);
   }
 }
 GL_DEV void restore_point(const Lds& D, int ll) {
@@ -1287,7 +1357,7 @@ GL_DEV void restore_point(const Lds& D, int ll) {
     for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = __hiloint2double(un[(2 * j + 1) * MCAP + ll], un[(2 * j) * MCAP + ll]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = D.un[j * MCAP + ll];
+    for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = un_ld(D.un + (unsigned)(j * MCAP + ll));
   }
 }
 
@@ -1481,7 +1551,7 @@ GL_DEV void pt_pass_a(const Uni& U, const GmmDev& gm, const Lds& D, const Pose& 
     for (int j = 0; j < 3; ++j) un[j * MCAP + c.ll] = __float_as_int((float)u[j]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) D.un[j * MCAP + c.ll] = Df[j];
+    for (int j = 0; j < 6; ++j) un_st(D.un + (unsigned)(j * MCAP + c.ll), Df[j]);
   }
   if (c.ar) {
     if (!kStep32) D.chir[c.ll] = o.rho1;
@@ -1581,7 +1651,7 @@ GL_DEV void pt_pass_b_step(const Uni& U, const GmmDev& gm, const Lds& D, const P
     }
     double Df[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) Df[j] = D.un[j * MCAP + c.ll];
+    for (int j = 0; j < 6; ++j) Df[j] = un_ld(D.un + (unsigned)(j * MCAP + c.ll));
     ldl3_solve_fast(Df, rhs, eps);
   }
   sk.put(0, eps[0] * eps[0] + eps[1] * eps[1] + eps[2] * eps[2]);
@@ -1621,15 +1691,15 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 #define GL_BAF_PRIO_SLOT(i)
 #else
 #define GL_BAF_PRIO_PASS_BEGIN() \
-  if (NWC == 8 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(2)
+  if (NWC == 8 && !kTwo && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(2)
 #define GL_BAF_PRIO_SLOT(i) \
-  if (NWC == 8 && (threadIdx.x >> 6) < 4 && (i) == (mp.asym ? GL_BAF_PRIO_DROP_ASYM : GL_BAF_PRIO_DROP)) __builtin_amdgcn_s_setprio(0)
+  if (NWC == 8 && !kTwo && (threadIdx.x >> 6) < 4 && (i) == (mp.asym ? GL_BAF_PRIO_DROP_ASYM : GL_BAF_PRIO_DROP)) __builtin_amdgcn_s_setprio(0)
 #endif
 #if defined(GL_BAF_NO_PRIO)
 #define GL_BAF_PRIO_PASS_END()
 #else
 #define GL_BAF_PRIO_PASS_END() \
-  if (NWC == 8 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(1)  /* a dynamically dealt pass: every wave at the same priority */
+  if (NWC == 8 && !kTwo && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(1)  /* a dynamically dealt pass: every wave at the same priority */
 #endif
 #ifndef GL_BAF_PRIO_DROP_ASYM
 #define GL_BAF_PRIO_DROP_ASYM 4
@@ -1647,7 +1717,9 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
 #endif
 // one pass over the thread's points: DENSE accumulates the terms in acc[] (level 1), SPREAD leaves the single
 // point's terms there (zeros when the thread has no active point)
-#define GL_BAF_PASS(BODY)                                                     \
+#define GL_BAF_PASS(BODY) GL_BAF_PASS2(BODY, )
+// (MID: GPW = 2, what happens between the slots of the wave's first and second group - the first group's totals leave the accumulators)
+#define GL_BAF_PASS2(BODY, MID)                                               \
   {                                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) acc[i_] = 0.0;          \
     if (kSpread) {                                                            \
@@ -1660,6 +1732,7 @@ GL_DEV void pt_pass_b_eval(const Uni& U, const GmmDev& gm, const Lds& D, const P
       const SinkAcc sk{acc};                                                  \
       GL_BAF_PRIO_PASS_BEGIN();                                               \
       _Pragma("unroll 1") for (int i = 0; i < mp.S; ++i) {                    \
+        if (kTwo && i == 4) { MID; }                                          \
         GL_BAF_PRIO_SLOT(i);                                                  \
         PROF_S(trials, prof_pass, i);                                         \
         PtCtx c;                                                              \
@@ -1712,8 +1785,23 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       if (!kSpread) {
         // DENSE: only the six diagonal sums, in the canonical order (level 2 = the butterfly of wave_allreduce_canon, level 3 = the blocks
         // of two groups), and the maximum of the point blocks beside them through the same LDS row: one barrier instead of five
-        GL_BAF_PASS(pt_lambda_init_diag(U, gm, D, P, c, robust, md, sk));
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        // (GPW = 2: the first group's six sums and the maximum so far go to the wave's first row between the two groups' slots - behind
+        // the same barrier, which every wave reaches: the hook sits in front of the slot's activity test)
+        GL_BAF_PASS2(pt_lambda_init_diag(U, gm, D, P, c, robust, md, sk), {
+          double sd0[6];
+          _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) sd0[i_] = wave_allreduce_canon(acc[i_]);
+          double m0 = md;
+          _Pragma("unroll") for (int o_ = 1; o_ < 64; o_ <<= 1) m0 = fmax(m0, shfl_xor_f64(m0, o_));
+          __syncthreads();
+          const int l0_ = threadIdx.x & 63;
+          if (l0_ < 7) {
+            double v0 = m0;
+            _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) v0 = l0_ == i_ ? sd0[i_] : v0;
+            R.red[(threadIdx.x >> 6) * 32 + l0_] = v0;
+          }
+          _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) acc[i_] = 0.0;
+        });
+        const int lane_ = threadIdx.x & 63, wave_ = kTwo ? (int)(threadIdx.x >> 6) + NWV : (int)(threadIdx.x >> 6);
         double sd[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) sd[i] = wave_allreduce_canon(acc[i]);
@@ -1766,7 +1854,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
       PROF_T(tA0);
       // ---- pass A ---------------------------------------------------------------------------
       prof_pass = 0;
-      GL_BAF_PASS(pt_pass_a(U, gm, D, P, c, robust, lambda, sk));
+      GL_BAF_PASS2(pt_pass_a(U, gm, D, P, c, robust, lambda, sk), group_flush29(acc, R, (int)(threadIdx.x >> 6)));
       PROF_S(trials, 0, 4);
       PROF_T(tA1);
       PROF_W(trials, 0);
@@ -1902,13 +1990,13 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
           acc[1] = add_nc(acc[1], D.un[4 * MCAP + ll]);
         }
       } else {
-      GL_BAF_PASS({
+      GL_BAF_PASS2({
         double pn[3];
         pt_pass_b_step(U, gm, D, P, dx, c, pn, sk);
         PROF_Q(trials, 1, i, 1);
         GL_BAF_GET_PN();
         pt_pass_b_eval(U, gm, D, Pn, c, pn, robust, sk);
-      });
+      }, group_flush2(acc, R, (int)(threadIdx.x >> 6)));
       GL_BAF_GET_PN();  // (a wave without an active point still takes the pose: P = Pn on acceptance)
       }
       PROF_S(trials, 1, 4);
@@ -2007,9 +2095,10 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
   Lds D;
   D.sp = smem;                      // 3 * MCAP
   D.chir = D.sp + 3 * MCAP;         // MCAP
-  D.un = D.chir + MCAP;             // 6 * MCAP
+  // (GPW = 2: the hand-over slots of this workgroup's frame in global memory - one region per workgroup of the launch)
+  D.un = kTwo ? ka->un_scratch + (size_t)blockIdx.x * 6 * MCAP : D.chir + MCAP;  // 6 * MCAP
   Red R;
-  R.red = D.chir + 7 * MCAP;        // NRED * 32
+  R.red = D.chir + (kTwo ? 1 : 7) * MCAP;  // NRED * 32
   R.tot = R.red + NRED * 32;        // 32 (+ 32 broadcast slots)
   D.stab = R.tot + 64;              // 24
   R.red2 = D.stab + 24;             // 16
@@ -2083,12 +2172,14 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
   if (kSpread) {  // workgroup pb = group pb; wave = slot; idle waves beyond S
     mp.S = 1;
     mp.asym = false;
+    mp.g2 = false;
     mp.base = wave < S && C.pb < G ? (C.pb + G * wave) * 64 + lane : L;  // chunk g + G slot of group g
     mp.lbase = tid;
     mp.step = 0;
   } else {
     mp.asym = kAsym && G == 8;
-    mp.S = mp.asym ? (wave < 4 ? 5 : 3) : S;
+    mp.S = kTwo ? 8 : mp.asym ? (wave < 4 ? 5 : 3) : S;  // (GPW = 2: four slots per group; a slot beyond the frame's S chunks per group lies behind L)
+    mp.g2 = kTwo && wave + NWV < G;
     mp.base = wave * 64 + lane;  // group = wave: chunks wave, wave + G, ... (slot_off)
     mp.lbase = mp.base;
     mp.step = 64 * G;
@@ -2121,7 +2212,11 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
       const int l = mp.base + slot_off(mp, i), ll = mp.lbase + slot_off(mp, i);
-      if (l >= L) break;
+      if (slot_absent(mp, i)) continue;
+      if (l >= L) {
+        if (kTwo) continue;  // (the second group's slots follow)
+        break;
+      }
       const size_t g = gbase + gperm[l];
 #pragma unroll
       for (int j = 0; j < 3; ++j) D.sp[j * MCAP + ll] = pts_io[g * 3 + j];
@@ -2189,7 +2284,11 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
 #pragma unroll 1
     for (int i = 0; i < ns; ++i) {
       const int l = mp.base + slot_off(mp, i), ll = mp.lbase + slot_off(mp, i);
-      if (l >= L) break;
+      if (slot_absent(mp, i)) continue;
+      if (l >= L) {
+        if (kTwo) continue;  // (the second group's slots follow)
+        break;
+      }
       const int fl = fw_get(fw, i);
       if (phase == 0) {  // fresh error of the degenerate GMM edges (:773-786)
         if ((fl & (F_ASSOC | F_DEG)) == (F_ASSOC | F_DEG)) {
@@ -2247,7 +2346,11 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
 #pragma unroll 1
   for (int i = 0; i < ns; ++i) {  // outputs (:837-879, :898-922)
     const int l = mp.base + slot_off(mp, i), ll = mp.lbase + slot_off(mp, i);
-    if (l >= L) break;
+    if (slot_absent(mp, i)) continue;
+    if (l >= L) {
+      if (kTwo) continue;
+      break;
+    }
     const size_t g = gbase + gperm[l];  // back to the caller's order
     const int fl = fw_get(fw, i);
     uint8_t dr = 0, er = 0;
@@ -2346,6 +2449,8 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
 // takes a frame shows nowhere in its result.  SPREAD (and frame_ctr == nullptr): the plain launch, one block per (frame, group).
 #ifdef GL_BAF_THREADS
 __global__ __launch_bounds__(GL_BAF_THREADS, GL_BAF_THREADS / 256) void k_ba1_fast(BafKArgs A) {
+#elif GL_BAF_GPW == 2
+__global__ __launch_bounds__(64 * NWV, 2) void k_ba1_fast(BafKArgs A) {
 #else
 __global__ __launch_bounds__(kSpread ? TSP : 512, 2) void k_ba1_fast(BafKArgs A) {
 #endif

@@ -95,6 +95,7 @@ struct Options {
   double ba_shape = -1;         // gl_track_frames refine: -1 auto, 0 one workgroup per frame, 1 one point per thread
   double ba_step32 = 0;         // 1: point step from an fp32 cache of the pass-A solve (faster, not the default)
   double ba_persist = 1;        // 1: the batch-shaped refine runs as persistent workgroups that draw their frames from a queue (0: one block per frame; A/B)
+  double ba_two_frames = 0;     // 1: 2 000-point class of the plain batch refine as TWO frames per CU (bafd2000x: two groups per wave, hand-over slots in global memory; same bits)
   double ba_slow = 0;           // 1: general kernel k_ba1 also for M <= 2000 (A/B)
   double ba_fixed_pack = 0;     // 1: gl_track_frames_anchored with fixed observers always through the general kernel (k_track_pack -> k_ba_gen; A/B, tests)
   double pose_waves = 0;        // gl_optimize_current_pose: 0 auto, 1 / 4 / 8 waves per frame

@@ -83,6 +83,8 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   ba_shape (-1 auto | 0 one workgroup per frame | 1 one point per thread; same bits either way),
  *   ba_persist (1; 0: the batch-shaped refine of gl_track_frames as one block per frame instead of persistent workgroups drawing frames
  *     from a queue - same bits; A/B),
+ *   ba_two_frames (0; 1: the 2 000-point class of the plain batch refine as two frames per CU - two groups of the summation order per
+ *     wave, the points' hand-over slots in global memory; same bits, measured 21 % slower: an experiment kept with its test),
  *   ba_step32 (1: fp32-cached point step in gl_track_frames, faster, NOT bit-compatible with the default),
  *   assoc_grid (0: every association is the plain N x K sweep, never the cell index),
  *   assoc_coop (1; 0: the indexed association gathers a record per lane instead of per six lanes - A/B),

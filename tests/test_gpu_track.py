@@ -207,6 +207,32 @@ def test_track_frames_bit_identical_across_shapes(gpu, map_v1, gt_sync, opt):
         opt("ba_same_xcd", 0)
 
 
+def test_track_frames_two_frames_per_cu_same_bits(gpu, map_v1, gt_sync, opt):
+    """Option ba_two_frames: the 2 000-point class of the plain batch refine as two frames per CU (bafd2000x - a wave owns TWO
+    groups of the canonical order, the points' hand-over slots live in global memory).  Same summation order, so the same BITS as
+    the eight-wave shape: every group count of the class (G = 4 ... 8: the wave's second group absent, short, full), a last group
+    of a few points, padding rows, and a batch with more frames than the device holds workgroups (the persistent frame queue)."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    g = api.GMM(ctx, mean, cov)
+    rng = np.random.default_rng(78)
+    opt("ba_shape", 0)
+    for M, B in [(1001, 3), (1024, 2), (1025, 2), (1280, 3), (1300, 2), (1537, 5), (1793, 2), (1999, 3), (2000, 4), (2000, 1100)]:
+        U = min(B, 6)
+        uniq = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, U, M, 5000 + M, outlier_frac=0.05)
+        for f in uniq:
+            f["octave"][rng.uniform(size=M) < 0.1] = -1
+        frames = [uniq[b % U] for b in range(B)]
+        res = {}
+        for two in (0, 1):
+            opt("ba_two_frames", two)
+            res[two] = _run_track(torch, ctx, g, cam, prm, frames)
+        opt("ba_two_frames", 0)
+        for a, b, what in zip(res[0], res[1], ("pose", "points", "assoc", "chi2")):
+            assert np.array_equal(a, b, equal_nan=True), (M, B, what, np.abs(a - b).max())
+
+
 def test_track_frames_rendezvous_gives_up_cleanly(gpu, map_v1, gt_sync, opt):
     """The latency shape is launched plainly (a cooperative launch costs 31 us per call): every exchange between the
     workgroups of a frame has a time limit, the workgroups write to a staging area, and the one-workgroup kernel that
