@@ -29,32 +29,60 @@ using namespace gld;
 
 namespace {
 
+// The residuals are kept in NORMALISED image coordinates (round 5; the structure refine's form, gl_ba_fast_impl.hpp): an observation
+// enters as on = ((u - cx) / fx, (v - cy) / fy, (u_right - cx) / fx) - one fma per coordinate, the same expression in every launch
+// shape -, so e_n = on - (x/z, y/z, (x - bn)/z) needs no intrinsics and chi2 = sx (e0^2 + e2^2) + sy e1^2 with sx = fx^2 / sigma^2,
+// sy = fy^2 / sigma^2 per octave: the quadratic form s |obs - K pi(q)|^2 of EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose.
 struct PoseKParams {
-  double fx, fy, cx, cy, bf;
-  double s2inv[8];
+  double ifx, ify, ncx, ncy;  // 1 / fx, 1 / fy, -cx / fx, -cy / fy
+  double bn;                  // bf / fx: the baseline in normalised image units
+  double sx[8], sy[8];
   double delta_mono, delta_stereo;
 };
-
-// un-robustified chi2 of one edge at pose (R,t) (e->computeError(); e->chi2())
-GL_DEV double pose_edge_chi2(const PoseKParams& kp, const double* R, const double* t, const double* Xw,
-                             const double* obs, int oc) {
-  const double x = R[0] * Xw[0] + R[1] * Xw[1] + R[2] * Xw[2] + t[0];
-  const double y = R[3] * Xw[0] + R[4] * Xw[1] + R[5] * Xw[2] + t[1];
-  const double z = R[6] * Xw[0] + R[7] * Xw[1] + R[8] * Xw[2] + t[2];
-  const double invz = 1.0 / z;
-  const double pu = x * invz * kp.fx + kp.cx, pv = y * invz * kp.fy + kp.cy;
-  const bool stereo = !(obs[2] < 0);
-  const double e0 = obs[0] - pu, e1 = obs[1] - pv;
-  const double e2 = stereo ? (obs[2] - (pu - kp.bf * invz)) : 0.0;
-  const double s = kp.s2inv[oc];
-  return e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2);
-}
 
 GL_DEV double rcp_nr(double a) {
   double x = __builtin_amdgcn_rcp(a);
   x = fma(fma(-a, x, 1.0), x, x);
   x = fma(fma(-a, x, 1.0), x, x);
   return x;
+}
+GL_DEV double rsq_nr(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+// branch-free g2o::RobustKernelHuber (rho, rho'): no square root, no division, no divergent region in the edge's chain
+GL_DEV void huber_bf(double e, double delta, double& rho0, double& rho1) {
+  const double dsqr = delta * delta;
+  const double r = rsq_nr(fmax(e, 1e-300));
+  const bool in = e <= dsqr;
+  rho1 = in ? 1.0 : delta * r;
+  rho0 = in ? e : (2.0 * delta * (e * r) - dsqr);
+}
+// camera-frame point q = R X + t, 1 / z, the normalised residual and the un-robustified chi2 of one edge (e->computeError();
+// e->chi2()); on = the normalised observation, s2tab = {sx[8], sy[8]}
+// (act = false: an edge that is absent or at level 1, evaluated all the same so that a thread's edges are ONE straight line of code
+// the scheduler can interleave - 1 / z and the weights are zero for it, every term it adds to a sum is an exact +-0.0)
+GL_DEV double pose_edge_res(const double* R, const double* t, double bn, const double* __restrict__ s2tab, int oc, bool stereo,
+                            double X, double Y, double Z, double o0, double o1, double o2, double* q, double& iz, double* e,
+                            double& sx, double& sy, bool act = true) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = fma(R[k * 3], X, fma(R[k * 3 + 1], Y, fma(R[k * 3 + 2], Z, t[k])));
+  iz = rcp_nr(q[2]);
+  iz = act ? iz : 0.0;
+  e[0] = fma(-q[0], iz, o0);
+  e[1] = fma(-q[1], iz, o1);
+  e[2] = stereo ? fma(bn - q[0], iz, o2) : 0.0;  // u_right - (x - b) / z
+  sx = act ? s2tab[oc] : 0.0;
+  sy = act ? s2tab[8 + oc] : 0.0;
+  return fma(sy * e[1], e[1], sx * fma(e[2], e[2], e[0] * e[0]));
+}
+GL_DEV double pose_edge_chi2(const PoseKParams& kp, const double* __restrict__ s2tab, const double* R, const double* t, const double* Xw,
+                             const double* on, int oc, bool stereo) {
+  double q[3], e[3], iz, sx, sy;
+  return pose_edge_res(R, t, kp.bn, s2tab, oc, stereo, Xw[0], Xw[1], Xw[2], on[0], on[1], on[2], q, iz, e, sx, sy);
 }
 GL_DEV double uni(double v) {  // wave-uniform value -> SGPR pair
   union {
@@ -139,15 +167,30 @@ GL_DEV PoseRt rt_update(const PoseRt& P, const double* u) {
     b = (1 - ct) * it * it;
     c = (theta - st) * it * it * it;
   }
-  double Om[9], Om2[9], dR[9], V[9];
-  skew(u, Om);
-  mm3(Om, Om, Om2);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const double I = (i % 4 == 0) ? 1.0 : 0.0;
-    dR[i] = I + a * Om[i] + b * Om2[i];
-    V[i] = I + b * Om[i] + c * Om2[i];
-  }
+  // dR = I + a [w]x + b [w]x^2,  V = I + b [w]x + c [w]x^2  with  [w]x^2 = w w^T - |w|^2 I  written out (the generic 3 x 3 products
+  // multiply by the zeros of the skew matrix: the serial part of every pass)
+  const double w0 = u[0], w1 = u[1], w2 = u[2];
+  const double s00 = w0 * w0 - th2, s11 = w1 * w1 - th2, s22 = w2 * w2 - th2;
+  const double s01 = w0 * w1, s02 = w0 * w2, s12 = w1 * w2;
+  double dR[9], V[9];
+  dR[0] = fma(b, s00, 1.0);
+  dR[4] = fma(b, s11, 1.0);
+  dR[8] = fma(b, s22, 1.0);
+  dR[1] = fma(b, s01, -a * w2);
+  dR[3] = fma(b, s01, a * w2);
+  dR[2] = fma(b, s02, a * w1);
+  dR[6] = fma(b, s02, -a * w1);
+  dR[5] = fma(b, s12, -a * w0);
+  dR[7] = fma(b, s12, a * w0);
+  V[0] = fma(c, s00, 1.0);
+  V[4] = fma(c, s11, 1.0);
+  V[8] = fma(c, s22, 1.0);
+  V[1] = fma(c, s01, -b * w2);
+  V[3] = fma(c, s01, b * w2);
+  V[2] = fma(c, s02, b * w1);
+  V[6] = fma(c, s02, -b * w1);
+  V[5] = fma(c, s12, -b * w0);
+  V[7] = fma(c, s12, b * w0);
   PoseRt N;
   mm3(dR, P.R, N.R);
 #pragma unroll
@@ -200,58 +243,58 @@ GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, do
   return ok;
 }
 
-// one edge: residual, chi2, Huber weight, Jacobian; accumulates into acc[0..27]
-GL_DEV void pose_edge_v(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int oc, double X,
-                        double Y, double Z, double ou, double ov, double our, double& chi2_out, double* acc) {
-  {
-    const bool stereo = !(our < 0);
-    const double x = P.R[0] * X + P.R[1] * Y + P.R[2] * Z + P.t[0];
-    const double y = P.R[3] * X + P.R[4] * Y + P.R[5] * Z + P.t[1];
-    const double z = P.R[6] * X + P.R[7] * Y + P.R[8] * Z + P.t[2];
-    const double invz = rcp_nr(z), invz2 = invz * invz;
-    const double pu = x * invz * kp.fx + kp.cx;
-    const double pv = y * invz * kp.fy + kp.cy;
-    const double e0 = ou - pu, e1 = ov - pv;
-    const double e2 = stereo ? (our - (pu - kp.bf * invz)) : 0.0;
-    const double s = s2tab[oc];
-    const double chi2 = e0 * (s * e0) + e1 * (s * e1) + e2 * (s * e2);
-    chi2_out = chi2;
-    double rho0 = chi2, rho1 = 1.0;
-    if (robust) huber(chi2, stereo ? kp.delta_stereo : kp.delta_mono, rho0, rho1);
-    const double w = rho1 * s;
-    double J0[6], J1[6], J2[6];
-    J0[0] = x * y * invz2 * kp.fx;
-    J0[1] = -(1 + (x * x * invz2)) * kp.fx;
-    J0[2] = y * invz * kp.fx;
-    J0[3] = -invz * kp.fx;
-    J0[4] = 0;
-    J0[5] = x * invz2 * kp.fx;
-    J1[0] = (1 + y * y * invz2) * kp.fy;
-    J1[1] = -x * y * invz2 * kp.fy;
-    J1[2] = -x * invz * kp.fy;
-    J1[3] = 0;
-    J1[4] = -invz * kp.fy;
-    J1[5] = y * invz2 * kp.fy;
-    const double sb = stereo ? 1.0 : 0.0;
-    J2[0] = sb * (J0[0] - kp.bf * y * invz2);
-    J2[1] = sb * (J0[1] + kp.bf * x * invz2);
-    J2[2] = sb * J0[2];
-    J2[3] = sb * J0[3];
-    J2[4] = 0;
-    J2[5] = sb * (J0[5] - kp.bf * invz2);
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double w0 = w * J0[i], w1 = w * J1[i], w2 = w * J2[i];
-#pragma unroll
-      for (int j = i; j < 6; ++j) {
-        acc[q] = fma(w0, J0[j], fma(w1, J1[j], fma(w2, J2[j], acc[q])));
-        ++q;
-      }
-      acc[21 + i] = fma(-w0, e0, fma(-w1, e1, fma(-w2, e2, acc[21 + i])));
-    }
-    acc[27] += rho0;
-  }
+// one edge: residual, chi2, Huber weight, and its terms of the pose system into acc[0..27].  With j_r the rows of the projection
+// Jacobian in normalised coordinates - (iz, 0, c0), (0, iz, c1) and, stereo, (iz, 0, c2) - the edge's Jacobian is -j G,
+// G = dq / dxi = [-[q]x | I] (VertexSE3Expmap: exp(xi) q), so  H += G^T A G,  b += G^T a  with the 3 x 3 block
+// A = sum_r w_r j_r^T j_r (A(0,1) = 0: no row touches x and y) and a = sum_r w_r j_r e_r: 119 instructions where the three 6-vectors
+// J_r and 27 x 3 multiply-adds were 232.  acc: H upper triangle row-major (21), b (6), robust chi2 (27).
+GL_DEV void pose_edge_v(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int oc, bool stereo, double X,
+                        double Y, double Z, double o0, double o1, double o2, double& chi2_out, double* acc, bool act = true) {
+  double q[3], e[3], iz, sx, sy;
+  const double chi2 = pose_edge_res(P.R, P.t, kp.bn, s2tab, oc, stereo, X, Y, Z, o0, o1, o2, q, iz, e, sx, sy, act);
+  chi2_out = act ? chi2 : chi2_out;
+  double rho0 = chi2, rho1 = 1.0;
+  if (robust) huber_bf(chi2, stereo ? kp.delta_stereo : kp.delta_mono, rho0, rho1);
+  const double wx = rho1 * sx, wy = rho1 * sy, t = stereo ? wx : 0.0;
+  const double iz2 = iz * iz;
+  const double c0 = -q[0] * iz2, c1 = -q[1] * iz2, c2 = fma(kp.bn, iz2, c0);
+  const double wxc0 = wx * c0, wyc1 = wy * c1, tc2 = t * c2, wyiz = wy * iz;
+  const double A0 = (wx + t) * iz2, A2 = iz * (wxc0 + tc2), A3 = wy * iz2, A4 = wyiz * c1;
+  const double A5 = fma(tc2, c2, fma(wyc1, c1, wxc0 * c0));
+  const double a0 = iz * fma(t, e[2], wx * e[0]), a1 = wyiz * e[1], a2 = fma(tc2, e[2], fma(wyc1, e[1], wxc0 * e[0]));
+  // M = [q]x A (row r, column j) = (q x A[:, j])[r], A = {A0 0 A2; 0 A3 A4; A2 A4 A5}
+  const double M0 = q[1] * A2, M1 = fma(q[1], A4, -q[2] * A3), M2 = fma(q[1], A5, -q[2] * A4);
+  const double M3 = fma(q[2], A0, -q[0] * A2), M4 = -q[0] * A4, M5 = fma(q[2], A2, -q[0] * A5);
+  const double M6 = -q[1] * A0, M7 = q[0] * A3, M8 = fma(q[0], A4, -q[1] * A2);
+  // every term is rounded on its own before it enters its sum (add_nc): the same bits in every launch shape
+  acc[0] = add_nc(acc[0], fma(q[1], M2, -q[2] * M1));
+  acc[1] = add_nc(acc[1], fma(q[2], M0, -q[0] * M2));
+  acc[2] = add_nc(acc[2], fma(q[0], M1, -q[1] * M0));
+  acc[3] = add_nc(acc[3], M0);
+  acc[4] = add_nc(acc[4], M1);
+  acc[5] = add_nc(acc[5], M2);
+  acc[6] = add_nc(acc[6], fma(q[2], M3, -q[0] * M5));
+  acc[7] = add_nc(acc[7], fma(q[0], M4, -q[1] * M3));
+  acc[8] = add_nc(acc[8], M3);
+  acc[9] = add_nc(acc[9], M4);
+  acc[10] = add_nc(acc[10], M5);
+  acc[11] = add_nc(acc[11], fma(q[0], M7, -q[1] * M6));
+  acc[12] = add_nc(acc[12], M6);
+  acc[13] = add_nc(acc[13], M7);
+  acc[14] = add_nc(acc[14], M8);
+  acc[15] = add_nc(acc[15], A0);
+  // (acc[16] = H(3,4): A(0,1) = 0 - nothing to add)
+  acc[17] = add_nc(acc[17], A2);
+  acc[18] = add_nc(acc[18], A3);
+  acc[19] = add_nc(acc[19], A4);
+  acc[20] = add_nc(acc[20], A5);
+  acc[21] = add_nc(acc[21], fma(q[1], a2, -q[2] * a1));
+  acc[22] = add_nc(acc[22], fma(q[2], a0, -q[0] * a2));
+  acc[23] = add_nc(acc[23], fma(q[0], a1, -q[1] * a0));
+  acc[24] = add_nc(acc[24], a0);
+  acc[25] = add_nc(acc[25], a1);
+  acc[26] = add_nc(acc[26], a2);
+  acc[27] = add_nc(acc[27], rho0);
 }
 
 // the same from global memory (the shapes whose waves own more edges than registers hold)
@@ -261,8 +304,9 @@ GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, c
   const int oc = octave[e];
   if (oc < 0 || level[e] != 0) return;
   double c2;
-  pose_edge_v(kp, s2tab, P, robust, oc, Xw[(size_t)e * 3 + 0], Xw[(size_t)e * 3 + 1], Xw[(size_t)e * 3 + 2], obs[(size_t)e * 3 + 0],
-              obs[(size_t)e * 3 + 1], obs[(size_t)e * 3 + 2], c2, acc);
+  const double our = obs[(size_t)e * 3 + 2];
+  pose_edge_v(kp, s2tab, P, robust, oc, !(our < 0), Xw[(size_t)e * 3 + 0], Xw[(size_t)e * 3 + 1], Xw[(size_t)e * 3 + 2],
+              fma(obs[(size_t)e * 3 + 0], kp.ifx, kp.ncx), fma(obs[(size_t)e * 3 + 1], kp.ify, kp.ncy), fma(our, kp.ifx, kp.ncx), c2, acc);
   chi2_e[e] = c2;
 }
 
@@ -272,9 +316,18 @@ GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, c
 // (Eight waves = two per SIMD have 256 registers each, not enough for four edges' coordinates next to the 28 sums:
 // that instance keeps map point and observation in LDS - [slot][coordinate][thread], conflict-free - and the rest in
 // registers.)
+#ifdef GL_POSE_PROF  // diagnosis build (tools/pose_prof.py): thread 0's clock64() deltas per phase, returned in the frame's pose
+#define POSE_PT(v) const long long v = clock64()
+#define POSE_PADD(i, a, b) g_pf[i] += (b) - (a)
+#define POSE_PARG , g_pf
+#else
+#define POSE_PT(v)
+#define POSE_PADD(i, a, b)
+#define POSE_PARG
+#endif
 struct EdgeRegs {
   double X[4][3], O[4][3], c2[4];
-  int oc[4];   // octave, < 0: no edge in the slot (no map point, or beyond the frame)
+  int oc[4];   // octave | stereo << 4, < 0: no edge in the slot (no map point, or beyond the frame); O = the NORMALISED observation
   int lv[4];   // level = is_outlier_
 };
 template <int MODE>
@@ -287,24 +340,51 @@ GL_DEV void edge_xo(const EdgeRegs& E, const double* xo, int i, double* X, doubl
   }
 }
 template <int MODE>
-GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int G, EdgeRegs& E,
-                           const double* xo, double* red, double* dst) {
+GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2tab, const PoseRt& P, bool robust, int G, int S, EdgeRegs& E,
+                           const double* xo, double* red, double* dst
+#ifdef GL_POSE_PROF
+                           , long long* g_pf
+#endif
+                           ) {
   const int wave = threadIdx.x >> 6;
   double acc[32];
+  POSE_PT(tq0);
   __syncthreads();
+  POSE_PT(tq1);
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  if (S == 4) {
+    // the frame's groups have four chunks (every frame of more than 768 edges): the thread's four edges as ONE basic block - no region
+    // per edge -, so that the scheduler interleaves their dependent chains (a wave of these shapes has its SIMD to itself); an
+    // absent / level-1 edge adds exact zeros (pose_edge_res): the same bits as the loop below
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (E.oc[i] >= 0 && E.lv[i] == 0) {
+    for (int i = 0; i < 4; ++i) {
       double X[3], O[3];
       edge_xo<MODE>(E, xo, i, X, O);
-      pose_edge_v(kp, s2tab, P, robust, E.oc[i], X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc);
+      pose_edge_v(kp, s2tab, P, robust, E.oc[i] & 15, (E.oc[i] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc,
+                  E.oc[i] >= 0 && E.lv[i] == 0);
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (E.oc[i] >= 0 && E.lv[i] == 0) {
+        double X[3], O[3];
+        edge_xo<MODE>(E, xo, i, X, O);
+        pose_edge_v(kp, s2tab, P, robust, E.oc[i] & 15, (E.oc[i] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc);
+      }
+  }
+  POSE_PT(tq2);
   group_totals28(acc, red, wave);
+  POSE_PT(tq3);
   __syncthreads();
   if (wave == 0) frame_totals28(red, dst, G);
   __syncthreads();
+  POSE_PT(tq4);
+  POSE_PADD(0, tq0, tq1);  // entry barrier
+  POSE_PADD(1, tq1, tq2);  // the thread's edges
+  POSE_PADD(2, tq2, tq3);  // reduce-scatter of the group
+  POSE_PADD(3, tq3, tq4);  // two barriers + the blocks
+  POSE_PADD(6, 0, 1);      // passes
 }
 
 // one pass over the frame's edges at pose P -> dst[0..27] (LDS): H upper triangle (21), b (6), robust chi2.
@@ -346,8 +426,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
                                                                  uint8_t* __restrict__ outlier_all,
                                                                  int32_t* __restrict__ ninlier,
                                                                  double* __restrict__ chi2_all) {
-  __shared__ double s2tab[8];
-  __shared__ double H[32], Hn[32];  // current / trial system {H upper (21), b (6), chi2}
+  __shared__ double s2tab[16];  // {sx[8], sy[8]}
+  __shared__ double Hbuf[64];       // current / trial system {H upper (21), b (6), chi2}: two rows that swap roles when a trial is accepted
+  double* H = Hbuf;                 // (no copy, no barrier pair: the next writer of the row that was current is wave 0 behind the next
+  double* Hn = Hbuf + 32;           //  evaluation's two barriers, every reader of it is through by then)
   __shared__ double part[NW];       // per-wave counts
   extern __shared__ double red[];   // G x 32 group totals (then, REGS == 2: 4 slots x 6 coordinates x threads)
   double* xo = red + G * 32;
@@ -356,7 +438,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   const int e0 = lane, es = blockDim.x;  // counting / gating loops: any order (integers, per-edge decisions)
   if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s2tab[j] = kp.s2inv[j];
+    for (int j = 0; j < 8; ++j) {
+      s2tab[j] = kp.sx[j];
+      s2tab[8 + j] = kp.sy[j];
+    }
   }
   __syncthreads();  // single wave: orders the table write before the reads
   const double* Xw = Xw_all + (size_t)f * M * 3;
@@ -376,20 +461,25 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
       E.lv[i] = 0;  // is_outlier_[i] is reset only where mappoints_[i] exists (:63-69): written back for those only
       E.c2[i] = 0.0;
       if (E.oc[i] >= 0) {
+        if (!(obs[(size_t)e * 3 + 2] < 0)) E.oc[i] |= 16;  // stereo
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+          const double on = fma(obs[(size_t)e * 3 + j], j == 1 ? kp.ify : kp.ifx, j == 1 ? kp.ncy : kp.ncx);
           if (REGS == 1) {
             E.X[i][j] = Xw[(size_t)e * 3 + j];
-            E.O[i][j] = obs[(size_t)e * 3 + j];
+            E.O[i][j] = on;
           } else {
             xo[(i * 6 + j) * es + lane] = Xw[(size_t)e * 3 + j];
-            xo[(i * 6 + 3 + j) * es + lane] = obs[(size_t)e * 3 + j];
+            xo[(i * 6 + 3 + j) * es + lane] = on;
           }
         }
         cnt += 1.0;
       } else if (REGS == 1) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) E.X[i][j] = E.O[i][j] = 0.0;
+      } else {  // (an absent edge is evaluated with zero weights: its coordinates must be finite)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xo[(i * 6 + j) * es + lane] = 0.0;
       }
     }
   } else {
@@ -424,6 +514,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   PoseRt P = P0;
   bool robust = true;
   int nbad = 0;
+#ifdef GL_POSE_PROF
+  long long g_pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long tk0 = clock64();
+#endif
 #pragma unroll 1
   for (int round = 0; round < 4; ++round) {
     P = P0;  // vertex_se3->setEstimate(curr_frame_->getTcw())  (:152)
@@ -439,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     }
     const int nactive = (int)block_total1(cnt, part);
     if (nactive > 0) {  // optimize(10); returns -1 untouched when nothing is active
-      if (REGS) pose_eval_regs<REGS>(kp, s2tab, P, robust, G, E, xo, red, H);
+      if (REGS) pose_eval_regs<REGS>(kp, s2tab, P, robust, G, S, E, xo, red, H POSE_PARG);
       else pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
       double currentChi = uni(H[27]);
       bool sys_valid = true;
@@ -447,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
 #pragma unroll 1
       for (int it = 0; it < 10; ++it) {
         if (!sys_valid) {  // computeActiveErrors + buildSystem at the (restored) estimate
-          if (REGS) pose_eval_regs<REGS>(kp, s2tab, P, robust, G, E, xo, red, H);
+          if (REGS) pose_eval_regs<REGS>(kp, s2tab, P, robust, G, S, E, xo, red, H POSE_PARG);
           else pose_eval(kp, s2tab, P, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, H);
           currentChi = uni(H[27]);
           sys_valid = true;
@@ -463,12 +557,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
         int qmax = 0;
         do {
           double dx[6];
+          POSE_PT(ts0);
           const bool ok2 = ldlt6_packed_pos(H, H + 21, lambda, dx);
+          POSE_PT(ts1);
+          POSE_PADD(4, ts0, ts1);  // 6 x 6 solve
           PoseRt Pn = P;
           double tempChi;
           if (ok2) {
             Pn = rt_update(P, dx);
-            if (REGS) pose_eval_regs<REGS>(kp, s2tab, Pn, robust, G, E, xo, red, Hn);
+            POSE_PT(ts2);
+            POSE_PADD(5, ts1, ts2);  // exp(dx) P
+            if (REGS) pose_eval_regs<REGS>(kp, s2tab, Pn, robust, G, S, E, xo, red, Hn POSE_PARG);
             else pose_eval(kp, s2tab, Pn, robust, G, S, M, Xw, obs, octave, level, chi2_e, red, Hn);
             tempChi = uni(Hn[27]);
           } else {
@@ -487,9 +586,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
             ni = 2;
             currentChi = tempChi;
             P = Pn;
-            __syncthreads();
-            if (lane < 27) H[lane] = Hn[lane];
-            __syncthreads();
+            double* const Hs = H;
+            H = Hn;
+            Hn = Hs;
           } else {
             lambda *= ni;
             ni *= 2;
@@ -512,8 +611,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
         if (E.oc[i] < 0) continue;
         double X[3], O[3];
         edge_xo<REGS == 2 ? 2 : 1>(E, xo, i, X, O);
-        const double c2 = E.lv[i] != 0 ? pose_edge_chi2(kp, P.R, P.t, X, O, E.oc[i]) : E.c2[i];
-        const float thr = !(O[2] < 0) ? 7.815f : 5.991f;
+        const bool stereo = (E.oc[i] & 16) != 0;
+        const double c2 = E.lv[i] != 0 ? pose_edge_chi2(kp, s2tab, P.R, P.t, X, O, E.oc[i] & 15, stereo) : E.c2[i];
+        const float thr = stereo ? 7.815f : 5.991f;
         const bool bad = (float)c2 > thr;
         E.lv[i] = bad ? 1 : 0;
         if (bad) cnt += 1.0;
@@ -523,11 +623,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
       const int oc = octave[e];
       if (oc < 0) continue;
       double c2;
-      if (level[e] != 0)
-        c2 = pose_edge_chi2(kp, P.R, P.t, Xw + (size_t)e * 3, obs + (size_t)e * 3, oc);
-      else
-        c2 = chi2_e[e];
       const bool stereo = !(obs[(size_t)e * 3 + 2] < 0);
+      if (level[e] != 0) {
+        const double on[3] = {fma(obs[(size_t)e * 3 + 0], kp.ifx, kp.ncx), fma(obs[(size_t)e * 3 + 1], kp.ify, kp.ncy),
+                              fma(obs[(size_t)e * 3 + 2], kp.ifx, kp.ncx)};
+        c2 = pose_edge_chi2(kp, s2tab, P.R, P.t, Xw + (size_t)e * 3, on, oc, stereo);
+      } else {
+        c2 = chi2_e[e];
+      }
       const float thr = stereo ? 7.815f : 5.991f;
       const bool bad = (float)c2 > thr;
       level[e] = bad ? 1 : 0;
@@ -551,6 +654,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     normalize_rotation(T);
     se3_store(T, pose_io + (size_t)f * 7);
     ninlier[f] = n_init - nbad;
+#ifdef GL_POSE_PROF
+    if (REGS) {  // {entry barrier, edges, reduce-scatter, barriers + blocks, solve, pose update, kernel total}; ninlier = passes
+      g_pf[7] = clock64() - tk0;
+      for (int i = 0; i < 6; ++i) pose_io[(size_t)f * 7 + i] = (double)g_pf[i];
+      pose_io[(size_t)f * 7 + 6] = (double)g_pf[7];
+      ninlier[f] = (int)g_pf[6];
+    }
+#endif
   }
 }
 
@@ -566,12 +677,15 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   PoseKParams kp;
-  kp.fx = cam->fx;
-  kp.fy = cam->fy;
-  kp.cx = cam->cx;
-  kp.cy = cam->cy;
-  kp.bf = cam->bf;
-  for (int i = 0; i < 8; ++i) kp.s2inv[i] = (double)prm->sigma2_inv[i];
+  kp.ifx = 1.0 / cam->fx;
+  kp.ify = 1.0 / cam->fy;
+  kp.ncx = -cam->cx / cam->fx;
+  kp.ncy = -cam->cy / cam->fy;
+  kp.bn = cam->bf / cam->fx;
+  for (int i = 0; i < 8; ++i) {
+    kp.sx[i] = (double)prm->sigma2_inv[i] * (cam->fx * cam->fx);
+    kp.sy[i] = (double)prm->sigma2_inv[i] * (cam->fy * cam->fy);
+  }
   kp.delta_mono = (double)(float)sqrt(5.991);    // const float delta_mono = sqrt(5.991)   (:57)
   kp.delta_stereo = (double)(float)sqrt(7.815);  // const float delta_stereo = sqrt(7.815) (:58)
   GL_REQUIRE(M <= 64 * 4 * 512, "M above 131 072 edges per frame");
