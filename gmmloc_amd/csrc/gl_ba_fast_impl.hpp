@@ -951,21 +951,8 @@ GL_DEV void ad_solve(const double* A, const double* f, double* AD) {
 }
 
 // ---- reductions in the canonical order ---------------------------------------------------------------------
-// 8-value variant of gld::wave_reduce_scatter32 with the same lane pairings in the same order (32, 16, 1, 2, 4, 8):
-// in: v[0..7] per lane; out: every lane holds the wave total of value ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + (l0^l2)
-GL_DEV double wave_reduce_scatter8(double* v) {
-  const int lane = threadIdx.x & 63;
-  const int l0 = lane & 1, l2 = (lane >> 2) & 1;
-  rs_swap_stage<4, 32>(v);
-  rs_swap_stage<2, 16>(v);
-  rs_stage<1, 0>(v, l0 ^ l2);
-  double r = v[0];
-  r = r + dpp_f64<0x4E>(r);   // quad_perm [2,3,0,1]: lane ^ 2
-  r = r + dpp_f64<0x141>(r);  // row_half_mirror:     lane ^ 7
-  r = r + dpp_f64<0x140>(r);  // row_mirror:          lane ^ 15
-  return r;
-}
-
+// (wave_reduce_scatter8 - the 8-value variant of gld::wave_reduce_scatter32 with the same lane pairings in the same order - lives in
+// gl_device.hpp: the pose kernel's split shape uses it too)
 struct Red {
   double* red;   // NRED x 32: per group (DENSE: wave) totals
   double* tot;   // 32 totals (+ 32 broadcast slots)

@@ -553,6 +553,22 @@ GL_DEV double wave_reduce_scatter16(double* v) {
   return r;
 }
 
+// 8-value variant of wave_reduce_scatter32 with the same lane pairings in the same order (32, 16, 1, 2, 4, 8):
+// in: v[0..7] per lane; out: every lane holds the wave total of value ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + (l0^l2)
+GL_DEV double wave_reduce_scatter8(double* v) {
+  const int lane = threadIdx.x & 63;
+  const int l0 = lane & 1, l2 = (lane >> 2) & 1;
+  rs_swap_stage<4, 32>(v);
+  rs_swap_stage<2, 16>(v);
+  rs_stage<1, 0>(v, l0 ^ l2);
+  double r = v[0];
+  r = r + dpp_f64<0x4E>(r);   // quad_perm [2,3,0,1]: lane ^ 2
+  r = r + dpp_f64<0x141>(r);  // row_half_mirror:     lane ^ 7
+  r = r + dpp_f64<0x140>(r);  // row_mirror:          lane ^ 15
+  return r;
+}
+
+
 template <int NV, int NWAVES>
 GL_DEV void block_reduce(double* v /*[32] in, [NV] out*/, double* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

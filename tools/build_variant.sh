@@ -11,7 +11,11 @@ for o in *.o; do
   src=${o%.o}.hip
   hit=0; for f in "$@"; do [ "$f" = "$src" ] && hit=1; done
   if [ $hit = 1 ]; then
-    /opt/rocm/bin/hipcc $FL --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I../../include -I. -c $src -o /tmp/glv_$NAME/$o
+    # the per-file LLVM flags of the Makefile (NOLICM list, gl_ba_fast.o): a variant differs from the library by $FL alone
+    PF=""
+    case " gl_ba_fast.hip gl_ba_gen.hip gl_ba.hip gl_refine_pose.hip gl_point.hip gl_view.hip gl_match.hip " in *" $src "*) PF="-mllvm -disable-machine-licm";; esac
+    [ "$src" = "gl_ba_fast.hip" ] && PF="$PF -mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-machine-sink"
+    /opt/rocm/bin/hipcc $FL $PF --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I../../include -I. -c $src -o /tmp/glv_$NAME/$o
     OBJS="$OBJS /tmp/glv_$NAME/$o"
   else OBJS="$OBJS $o"; fi
 done

@@ -79,6 +79,12 @@ one = pack(frames[:1])
 chain1 = lambda: api.track_frame_chain(ctx, cam, prm, one)
 with torch.cuda.stream(ctx.stream):
     t_chain = median_ms(chain1)
+    # the latency of a frame follows the number of Levenberg trials its two pose optimisations take (the tail of a converged optimisation
+    # is decided by rounding: 37 .. 69 evaluations on like frames): the mean over 16 frames beside the first one's
+    t_each = []
+    for b in range(16):
+        fb = pack(frames[b:b + 1])
+        t_each.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb), n=12, skip=2))
 t_four = median_ms(lambda: four_calls(one))
 t_four_nosync = median_ms(lambda: four_calls(one, sync=False))
 # the stages alone (one call + synchronise each), on the chain's own intermediate shapes
@@ -104,7 +110,8 @@ big = pack([frames[b % 64] for b in range(B)])
 with torch.cuda.stream(ctx.stream):
     t_batch = median_ms(lambda: api.track_frame_chain(ctx, cam, prm, big), n=8, skip=2)
 print(json.dumps({"config": "one tracked frame (trackWithMotionModel -> searchLocalPoints -> trackLocalMap): %d features, %d last-frame map points, %d local map points" % (NF, NL, NP),
-                  "chain_one_frame_ms": t_chain, "four_calls_with_sync_between_ms": t_four, "four_calls_enqueued_without_sync_ms": t_four_nosync,
+                  "chain_one_frame_ms": t_chain, "chain_one_frame_ms_mean_of_16_frames": float(np.mean(t_each)), "chain_one_frame_ms_min_max_of_16": [float(np.min(t_each)), float(np.max(t_each))],
+                  "four_calls_with_sync_between_ms": t_four, "four_calls_enqueued_without_sync_ms": t_four_nosync,
                   "single_call_ms": {"searchByProjection(frame)": t_s1, "optimizeCurrentPose": t_s2, "searchLocalPoints": t_s3, "sum_of_four": t_s1 + 2 * t_s2 + t_s3},
                   "chain_batch_frames_per_s": B / (t_batch * 1e-3), "batch": B,
                   "note": "wall clock incl. the Python wrapper, median of 25; the four-call form does its glue as torch ops on the device"}))
