@@ -20,6 +20,7 @@ python tools/fixed_time.py 4096 300 2 > gpurun_out/${TAG}_fixed_time.txt 2>/dev/
 python tools/fixed_time.py 2048 1000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/fixed_time.py 1024 2000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 ./build_tmp/bench_mfma_point 2000 > gpurun_out/${TAG}_mfma_point.txt 2>/dev/null
+./build_tmp/bench_f64_rate > gpurun_out/${TAG}_f64_rate.txt 2>/dev/null   # (hipcc --offload-arch=gfx950 -O3 tools/bench_f64_rate.hip: built in the build container)
 python tools/chain_time.py > gpurun_out/${TAG}_chain_time.json 2>/dev/null
 bash tools/pmc_match.sh ${TAG} > gpurun_out/${TAG}_pmc_match.log 2>&1
 rm -rf gpurun_out/pmc_match_${TAG}
