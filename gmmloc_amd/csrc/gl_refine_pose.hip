@@ -326,33 +326,35 @@ GL_DEV void pose_edge(const PoseKParams& kp, const double* __restrict__ s2tab, c
 #define POSE_PARG
 #endif
 struct EdgeRegs {
-  double X[4][3], O[4][3], c2[4];
-  int oc[4];   // octave | stereo << 4, < 0: no edge in the slot (no map point, or beyond the frame); O = the NORMALISED observation
-  int lv[4];   // level = is_outlier_
-};
-// REGS == 3, the SPLIT shape of a frame of five groups (1 025 .. 1 280 edges: the reference's 1 200 features): a wave per group
-// leaves one SIMD with two waves and three with one - every pass waits for that SIMD (9.5 k of a pass's 13.2 k ticks at 1 200 edges
-// against 4.7 k of 8.1 k at 1 000, profiles/r5_pose_ab.txt).  Eight waves instead: waves 0..3 own the groups 0..3 as ever (coordinates
-// in LDS), waves 4..7 ONE chunk of group 4 each (its slot k on wave 4 + k, the edge in registers); group 4's level 1 - lane j adds its
-// slots' terms in slot order - runs through an LDS transpose [value][slot][lane], then the four waves share the 28 values in rounds of
-// 8 and finish with wave_reduce_scatter8, which pairs the lanes like wave_reduce_scatter32: the same canonical order, the same bits
-// (the SPREAD shape of the structure refine does the same, gl_ba_fast_impl.hpp).  Two waves on every SIMD, five chunks each.
-constexpr int kSplitLower = 256;  // threads of the waves 0..3
+  double X[5][3], O[5][3], c2[5];
+  int oc[5];   // octave | stereo << 4, < 0: no edge in the slot (no map point, or beyond the frame); O = the NORMALISED observation
+  int lv[5];   // level = is_outlier_
+};             // (slot 4: REGS == 3 only)
+// REGS == 3, a frame of FIVE groups (1 025 .. 1 280 edges: the reference's 1 200 features) at the frame-at-a-time caller.  A wave per
+// group puts two waves on one SIMD and one on the other three, and every pass waits for that SIMD: 13.2 k ticks per pass at 1 200 edges
+// against 8.1 k at 1 000 (profiles/r5_pose_ab.txt).  Eight waves - the groups 0..3 on the waves 0..3, one chunk of group 4 on each of the
+// waves 4..7 - were built first and bought 6 % (profiles/r5_pose_split.txt): two waves per SIMD repeat the serial solve beside each other
+// and the older one waits 1.2 k ticks for the younger at every evaluation's first barrier.  So: FOUR waves, a SIMD each, wave w owns
+// group w as ever and, as a FIFTH edge per thread, chunk w of group 4.  Group 4's level 1 - lane j adds its slots' terms in slot order
+// - runs through an LDS transpose [value][slot][lane]; the four waves then share its 28 values in rounds of 8 and finish with
+// wave_reduce_scatter8, which pairs the lanes like wave_reduce_scatter32: the same canonical order, the same bits (what the SPREAD shape
+// of the structure refine does, gl_ba_fast_impl.hpp).
+template <int REGS>
+constexpr int pose_slots() { return REGS == 3 ? 5 : 4; }
 // frame-local edge of slot i of this thread, or -1 (the caller tests e < M)
 template <int REGS>
 GL_DEV int pose_edge_index(int S, int i) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  if (REGS == 3 && w >= 4) return (i == 0 && w - 4 < S) ? (4 * S + (w - 4)) * 64 + l : -1;
+  if (REGS == 3 && i == 4) return w < S ? (4 * S + w) * 64 + l : -1;
   return i < S ? (w * S + i) * 64 + l : -1;
 }
 template <int MODE>
 GL_DEV void edge_xo(const EdgeRegs& E, const double* xo, int i, double* X, double* O) {
-  const int T = MODE == 3 ? kSplitLower : blockDim.x, t = threadIdx.x;
-  const bool regs = MODE == 1 || (MODE == 3 && t >= kSplitLower);
+  const int T = blockDim.x, t = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    X[j] = regs ? E.X[MODE == 3 ? 0 : i][j] : xo[(i * 6 + j) * T + t];
-    O[j] = regs ? E.O[MODE == 3 ? 0 : i][j] : xo[(i * 6 + 3 + j) * T + t];
+    X[j] = (MODE == 1 || MODE == 3) ? E.X[i][j] : xo[(i * 6 + j) * T + t];
+    O[j] = (MODE == 1 || MODE == 3) ? E.O[i][j] : xo[(i * 6 + 3 + j) * T + t];
   }
 }
 template <int MODE>
@@ -369,16 +371,21 @@ GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2t
   POSE_PT(tq1);
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-  if (MODE == 3 && wave >= 4) {
-    // the split shape's upper waves: the terms of ONE edge of group 4 (acc starts from +0.0: 0 + t = t) into the transpose
-    if (E.oc[0] >= 0 && E.lv[0] == 0) {
-      double X[3], O[3];
-      edge_xo<MODE>(E, xo, 0, X, O);
-      pose_edge_v(kp, s2tab, P, robust, E.oc[0] & 15, (E.oc[0] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[0], acc);
-    }
-    double* tb = const_cast<double*>(xo) + 24 * kSplitLower;  // [value < 28][slot < 4][lane]
+  if (MODE == 3) {
+    // five groups: the thread's four edges of group `wave` and, into sums of its own, chunk `wave` of group 4 - one basic block
+    double acc5[28];
 #pragma unroll
-    for (int v = 0; v < 28; ++v) tb[(v * 4 + (wave - 4)) * 64 + (threadIdx.x & 63)] = acc[v];
+    for (int i = 0; i < 28; ++i) acc5[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      double X[3], O[3];
+      edge_xo<MODE>(E, xo, i, X, O);
+      pose_edge_v(kp, s2tab, P, robust, E.oc[i] & 15, (E.oc[i] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], i < 4 ? acc : acc5,
+                  E.oc[i] >= 0 && E.lv[i] == 0);
+    }
+    double* tb = const_cast<double*>(xo);  // [value < 28][slot < 4][lane]: the terms of group 4 (0 + t = t)
+#pragma unroll
+    for (int v = 0; v < 28; ++v) tb[(v * 4 + wave) * 64 + (threadIdx.x & 63)] = acc5[v];
   } else if (S == 4) {
     // the frame's groups have four chunks (every frame of more than 768 edges): the thread's four edges as ONE basic block - no region
     // per edge -, so that the scheduler interleaves their dependent chains (a wave of these shapes has its SIMD to itself); an
@@ -400,12 +407,12 @@ GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2t
       }
   }
   POSE_PT(tq2);
-  if (MODE != 3 || wave < 4) group_totals28(acc, red, wave);
+  group_totals28(acc, red, wave);
   if (MODE == 3) {
     __syncthreads();
-    if (wave >= 4) {  // group 4: level 1 in slot order, level 2 = the butterfly; wave 4 + k takes the values 8 k .. 8 k + 7
-      const double* tb = xo + 24 * kSplitLower;
-      const int k = wave - 4, l = threadIdx.x & 63;
+    {  // group 4: level 1 in slot order, level 2 = the butterfly; wave k takes the values 8 k .. 8 k + 7
+      const double* tb = xo;
+      const int k = wave, l = threadIdx.x & 63;
       double y[8];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -465,7 +472,7 @@ GL_DEV void pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, c
 // SIMD, no barrier does anything), 4 / 8 when the frames are fewer than the SIMDs; launched with nw <= NW waves
 // (never more than the frame has groups).  Every wave repeats the serial part (solve, pose update) on its own so that
 // no broadcast is needed.
-template <int NW, int REGS>  // REGS: 0 edges from global memory, 1 in registers, 2 coordinates in LDS, 3 the split shape of five groups
+template <int NW, int REGS>  // REGS: 0 edges from global memory, 1 in registers, 2 coordinates in LDS, 3 five groups on four waves (registers)
 __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS == 2) ? 2 : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M, int G, int S,
                                                                  double* __restrict__ pose_io,
                                                                  const double* __restrict__ Xw_all,
@@ -484,7 +491,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   const int f = blockIdx.x, lane = threadIdx.x;  // "lane" = thread of the workgroup's waves
   if (f >= B) return;
   const int e0 = lane, es = blockDim.x;  // counting / gating loops: any order (integers, per-edge decisions)
-  const int xs = REGS == 3 ? kSplitLower : es;  // thread stride of the coordinates in LDS
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   EdgeRegs E;
   if (REGS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < pose_slots<REGS>(); ++i) {
       const int e = pose_edge_index<REGS>(S, i);
       E.oc[i] = (e >= 0 && e < M) ? octave[e] : -1;
       E.lv[i] = 0;  // is_outlier_[i] is reset only where mappoints_[i] exists (:63-69): written back for those only
@@ -514,26 +520,21 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const double on = fma(obs[(size_t)e * 3 + j], j == 1 ? kp.ify : kp.ifx, j == 1 ? kp.ncy : kp.ncx);
-          if (REGS == 1 || (REGS == 3 && lane >= kSplitLower)) {
-            E.X[REGS == 3 ? 0 : i][j] = Xw[(size_t)e * 3 + j];
-            E.O[REGS == 3 ? 0 : i][j] = on;
+          if (REGS == 1 || REGS == 3) {
+            E.X[i][j] = Xw[(size_t)e * 3 + j];
+            E.O[i][j] = on;
           } else {
-            xo[(i * 6 + j) * xs + lane] = Xw[(size_t)e * 3 + j];
-            xo[(i * 6 + 3 + j) * xs + lane] = on;
+            xo[(i * 6 + j) * es + lane] = Xw[(size_t)e * 3 + j];
+            xo[(i * 6 + 3 + j) * es + lane] = on;
           }
         }
         cnt += 1.0;
-      } else if (REGS == 1) {
+      } else if (REGS == 1 || REGS == 3) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) E.X[i][j] = E.O[i][j] = 0.0;
-      } else if (REGS == 3 && lane >= kSplitLower) {
-        if (i == 0) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) E.X[0][j] = E.O[0][j] = 0.0;
-        }
       } else {  // (an absent edge is evaluated with zero weights: its coordinates must be finite)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) xo[(i * 6 + j) * xs + lane] = 0.0;
+        for (int j = 0; j < 6; ++j) xo[(i * 6 + j) * es + lane] = 0.0;
       }
     }
   } else {
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   if (n_init < 3) {  // :139-140
     if (REGS) {  // the on-chip shapes keep the flags in registers: the reset of :63-69 happened before this return
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < pose_slots<REGS>(); ++i) {
         if (E.oc[i] >= 0) level[pose_edge_index<REGS>(S, i)] = 0;
       }
     }
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     __syncthreads();  // level[] of the previous round's gating is read by other threads below
     if (REGS) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < pose_slots<REGS>(); ++i)
         if (E.oc[i] >= 0 && E.lv[i] == 0) cnt += 1.0;
     } else {
       for (int e = e0; e < M; e += es)
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     __syncthreads();  // chi2_e[] of the last evaluation was written by other threads (edge -> thread maps differ)
     if (REGS) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < pose_slots<REGS>(); ++i) {
         if (E.oc[i] < 0) continue;
         double X[3], O[3];
         edge_xo<REGS ? REGS : 1>(E, xo, i, X, O);
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   }
   if (REGS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < pose_slots<REGS>(); ++i)
       if (E.oc[i] >= 0) level[pose_edge_index<REGS>(S, i)] = (uint8_t)E.lv[i];
   }
   if (lane == 0) {
@@ -773,12 +774,13 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   k_optimize_current_pose<NWC, REGS><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, \
                                                                      ninlier_dev, (double*)scratch)
     const bool on_chip = nw > 1 && nw == G && c->opt.pose_regs != 0;  // a wave per group: the frame's edges stay on chip
-    const bool split5 = G == 5 && on_chip && c->opt.pose_waves <= 0;  // (five groups on eight waves, see kSplitLower)
-    if (split5) {
-      nw = 8;
-      lds += (size_t)(24 + 28) * kSplitLower * sizeof(double);
-      GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<8, 3>, lds));
-      GL_POSE_LAUNCH(8, 3);
+    // five groups at the frame-at-a-time caller (every frame has a CU): four waves, five edges per thread (REGS == 3)
+    const bool five = G == 5 && on_chip && B <= c->ncu && c->opt.pose_waves <= 0;
+    if (five) {
+      nw = 4;
+      lds += (size_t)28 * 256 * sizeof(double);
+      GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<4, 3>, lds));
+      GL_POSE_LAUNCH(4, 3);
     } else if (nw > 4) {
       if (on_chip) {
         lds += (size_t)24 * 64 * nw * sizeof(double);

@@ -1,5 +1,5 @@
 // Issue rate of the fp64 vector instructions of gfx950, per wave: v_fma_f64 / v_mul_f64 / v_add_f64 in NCH independent chains,
-// one, two or four waves per SIMD (a workgroup of 256 / 512 / 1024 threads on every CU).  Prints clock64() cycles per instruction
+// one to four waves per SIMD (a workgroup of 256 / 512 / 768 / 1024 threads on every CU).  Prints clock64() cycles per instruction
 // and wave.   hipcc --offload-arch=gfx950 -O3 tools/bench_f64_rate.hip -o build_tmp/bench_f64_rate && build_tmp/bench_f64_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,26 +34,39 @@ __global__ void k_rate(double* out, long long* cyc, int iters, double seed) {
 
 template <int OP, int NCH>
 void run(const char* name, int threads) {
-  const int blocks = 256, iters = 200;
+  const int blocks = 256, iters = 4000;  // (long launches: the launch overhead is < 1 % of them)
   double* out;
   long long* cyc;
   hipMalloc(&out, sizeof(double) * blocks * threads);
   hipMalloc(&cyc, sizeof(long long) * blocks * threads / 64);
   for (int w = 0; w < 3; ++w) k_rate<OP, NCH><<<blocks, threads>>>(out, cyc, iters, 0.0);
   hipDeviceSynchronize();
+  // the same launch under HIP events: instructions per second and SIMD against the 0.6 G/s (2.4 GHz / 4 cycles per wave64 fp64
+  // instruction) the 78.6 TFLOP/s are computed from - clock64() ticks are not core cycles
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int reps = 20;
+  hipEventRecord(e0);
+  for (int w = 0; w < reps; ++w) k_rate<OP, NCH><<<blocks, threads>>>(out, cyc, iters, 0.0);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double ginst = (double)iters * 8 * NCH * (threads / 256) / (ms * 1e-3 / reps) * 1e-9;
   std::vector<long long> h(blocks * threads / 64);
   hipMemcpy(h.data(), cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
   double mean = 0;
   for (long long v : h) mean += (double)v;
   mean /= h.size();
-  printf("%-28s %2d chains, %d waves per SIMD: %6.2f cycles per instruction and wave (%.2f per SIMD)\n", name, NCH, threads / 256,
-         mean / ((double)iters * 8 * NCH), mean / ((double)iters * 8 * NCH) / (threads / 256));
+  printf("%-28s %2d chains, %d waves per SIMD: %6.2f ticks per instruction and wave (%.2f per SIMD); %.3f G instructions/s per SIMD by HIP events = %.2f of 0.6\n",
+         name, NCH, threads / 256, mean / ((double)iters * 8 * NCH), mean / ((double)iters * 8 * NCH) / (threads / 256), ginst, ginst / 0.6);
   hipFree(out);
   hipFree(cyc);
 }
 
 int main() {
-  for (int threads : {256, 512, 1024}) {
+  for (int threads : {256, 512, 768, 1024}) {
     run<0, 8>("v_fma_f64", threads);
     run<1, 8>("v_mul_f64", threads);
     run<2, 8>("v_add_f64", threads);
@@ -62,6 +75,7 @@ int main() {
     run<2, 1>("v_add_f64 (dependent)", threads);
     run<0, 2>("v_fma_f64", threads);
     run<0, 4>("v_fma_f64", threads);
+    run<0, 16>("v_fma_f64", threads);
   }
   return 0;
 }
