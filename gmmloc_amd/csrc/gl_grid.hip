@@ -115,16 +115,29 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
 // records: 6 loads of 16 bytes per candidate with 64 different lines per instruction.  Here the wave lists its candidates
 // (<= 3 per lane from the packed cell, compacted with a prefix sum over the lanes), six lanes fetch one record as six
 // neighbouring 16-byte pieces and the records reach their points through LDS, 60 records per round; lanes whose cell holds
-// more than three candidates (rare) walk their list as before.  Same arithmetic per pair, same (chi2, index) minimum.
+// more than three candidates walked their list alone until round 5 (LONG = false; see below).  Same arithmetic per pair, same (chi2, index) minimum.
 // Measured on the bench points: 0.421 -> 0.392 ms per 8.19 M points - the address cycles of the gather drop to a third, the
 // ~50 M line requests per launch to the XCDs' L2 (two lines per record, the 393 KB of records do not live in a 32 KB L1) do not.
-constexpr int CG_REC = 60;  // records per round: 10 per load instruction (6 lanes each, 4 lanes idle), 6 instructions
-__global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restrict__ rec12, GridDev G,
+// STRIDE = 16 (round 5): the gather reads the copy of the records that holds one record per 128-byte line (CellIndex::rec16) - one
+// line request per record instead of 1.75 on average; the long lists and the global list stay on rec12 (the same values).
+#ifndef GL_CG_REC
+#define GL_CG_REC 60
+#endif
+#ifndef GL_CG_PIPE
+#define GL_CG_PIPE 1
+#endif
+#ifndef GL_CG_IDS
+#define GL_CG_IDS 384
+#endif
+constexpr int CG_REC = GL_CG_REC;  // records per round: 10 per load instruction (6 lanes each, 4 lanes idle), 6 instructions
+constexpr int CG_IDS = GL_CG_IDS;  // candidates of a wave per chunk of its table (the bench points: 201 per wave on average)
+template <int STRIDE, bool LONG>
+__global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restrict__ rec12, const double* __restrict__ recg, GridDev G,
                                                           const double* __restrict__ pts, int N,
                                                           int32_t* __restrict__ out_idx, double* __restrict__ out_d2,
                                                           int32_t* __restrict__ rest_list, int32_t* __restrict__ rest_count) {
   __shared__ __attribute__((aligned(16))) double s_rec[4][CG_REC * 12];
-  __shared__ int s_id[4][192];
+  __shared__ int s_id[4][CG_IDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 256 + threadIdx.x;
   const bool live = n < N;
@@ -147,7 +160,12 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
                       fz < (double)G.dim[2];  // false for NaN
   int4 q = make_int4(0, 0, 0, 0);
   if (inside) q = G.cell4[((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx];
-  const int cnt = q.x <= 3 ? q.x : 0;
+  // EVERY list goes through the cooperative gather (round 5, LONG = true): a cell with more than three candidates keeps its list in the
+  // CSR array, and until round 5 such a lane walked it alone behind the gather - one dependent index load and six 16-byte record loads
+  // per candidate while the rest of the wave waited (a third of the bench points; the time of the kernel followed THEM:
+  // profiles/r5_assoc_cell_sweep.txt, the 3 cm row).  Now the lane copies its list's indices into the wave's candidate table like
+  // the short lists' three, in chunks of CG_IDS candidates.
+  const int cnt = LONG ? q.x : (q.x <= 3 ? q.x : 0);
   // exclusive prefix sum of the counts over the wave
   int pos = cnt;
 #pragma unroll
@@ -157,34 +175,48 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
   }
   const int total = __shfl(pos, 63);
   pos -= cnt;
-  if (cnt > 0) s_id[wave][pos] = q.y;
-  if (cnt > 1) s_id[wave][pos + 1] = q.z;
-  if (cnt > 2) s_id[wave][pos + 2] = q.w;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
   const int sub = lane / 6, part = lane - 6 * sub;  // lanes 60 .. 63 idle in the gather
-  for (int r0 = 0; r0 < total; r0 += CG_REC) {
-    const int nr = min(CG_REC, total - r0);
-    double2 piece[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      const int rr = t * 10 + sub;
-      const bool ld = lane < 60 && rr < nr;
-      const int id = s_id[wave][ld ? r0 + rr : 0];
-      piece[t] = ld ? *(const double2*)(rec12 + (size_t)id * 12 + part * 2) : make_double2(0.0, 0.0);
-    }
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      const int rr = t * 10 + sub;
-      if (lane < 60 && rr < nr) *(double2*)(&s_rec[wave][rr * 12 + part * 2]) = piece[t];
+  for (int c0 = 0; c0 < total; c0 += CG_IDS) {
+    const int jlo = max(0, c0 - pos), jhi = min(cnt, c0 + CG_IDS - pos);  // this lane's candidates of the chunk
+    if (q.x <= 3) {
+      if (0 >= jlo && 0 < jhi) s_id[wave][pos - c0] = q.y;
+      if (1 >= jlo && 1 < jhi) s_id[wave][pos + 1 - c0] = q.z;
+      if (2 >= jlo && 2 < jhi) s_id[wave][pos + 2 - c0] = q.w;
+    } else if (LONG) {
+      for (int j = jlo; j < jhi; ++j) s_id[wave][pos + j - c0] = G.idx[q.y + j];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const int nch = min(CG_IDS, total - c0);
+    // the loads of round r + 1 are in flight while round r is evaluated out of LDS (a round was: request, wait a whole L2 round trip,
+    // write to LDS, evaluate - one after the other; the time of the kernel was linear in the rounds per wave)
+    double2 piece[CG_REC / 10];
+    auto request = [&](int r0) {
+      const int nr = min(CG_REC, nch - r0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int r = pos + j - r0;
-      if (j < cnt && r >= 0 && r < nr) {
-        const int k = j == 0 ? q.y : j == 1 ? q.z : q.w;
+      for (int t = 0; t < CG_REC / 10; ++t) {
+        const int rr = t * 10 + sub;
+        const bool ld = lane < 60 && rr < nr;
+        const int id = s_id[wave][ld ? r0 + rr : 0];
+        piece[t] = ld ? *(const double2*)(recg + (size_t)id * STRIDE + part * 2) : make_double2(0.0, 0.0);
+      }
+    };
+    if (GL_CG_PIPE) request(0);
+    for (int r0 = 0; r0 < nch; r0 += CG_REC) {
+      const int nr = min(CG_REC, nch - r0);
+      if (!GL_CG_PIPE) request(r0);
+#pragma unroll
+      for (int t = 0; t < CG_REC / 10; ++t) {
+        const int rr = t * 10 + sub;
+        if (lane < 60 && rr < nr) *(double2*)(&s_rec[wave][rr * 12 + part * 2]) = piece[t];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (GL_CG_PIPE && r0 + CG_REC < nch) request(r0 + CG_REC);
+      const int ja = max(jlo, c0 + r0 - pos), jb = min(jhi, c0 + r0 + nr - pos);
+      for (int j = ja; j < jb; ++j) {
+        const int r = pos + j - c0 - r0;
+        const int k = s_id[wave][r0 + r];
         double rec[12];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
@@ -194,10 +226,10 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
         }
         upd_min(chi2_rec(rec, x, y, z), k, best, bi);
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
-  if (inside && q.x > 3) {  // long list: by the lane itself
+  if (!LONG && inside && q.x > 3) {  // long list: by the lane itself
     for (int e = q.y; e < q.y + q.x; ++e) {
       const int k = G.idx[e];
       upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
@@ -303,6 +335,12 @@ __global__ void k_index_csr(const unsigned long long* __restrict__ keys, size_t 
   }
 }
 // packed cells from the CSR: {count, i0, i1, i2} for lists of up to three, {count, offset, 0, 0} above
+__global__ void k_rec_pad(const double* __restrict__ rec12, int K, double* __restrict__ rec16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * 16) return;
+  const int k = i >> 4, e = i & 15;
+  rec16[i] = e < 12 ? rec12[(size_t)k * 12 + e] : 0.0;
+}
 __global__ void k_index_pack(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, size_t ncell, int4* __restrict__ cell4) {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell) return;
@@ -388,6 +426,7 @@ void free_cell_index(Gmm* g) {
   if (g->grid.idx) (void)hipFree(g->grid.idx);
   if (g->grid.glob) (void)hipFree(g->grid.glob);
   if (g->grid.cell4) (void)hipFree(g->grid.cell4);
+  if (g->grid.rec16) (void)hipFree(g->grid.rec16);
   g->grid = CellIndex();
 }
 
@@ -606,6 +645,19 @@ int build_cell_index(Ctx* c, Gmm* g) {
       G.cell4 = nullptr;
     }
   }
+  G.rec16 = nullptr;
+  if (G.cell4) {  // one record per 128-byte line for the cooperative gather (K x 128 B: 512 KB for 4 096 Gaussians)
+    if (hipMalloc(&G.rec16, (size_t)g->K * 128) == hipSuccess) {
+      k_rec_pad<<<(g->K * 16 + 255) / 256, 256, 0, c->stream>>>(g->rec12, g->K, G.rec16);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(G.rec16);
+        G.rec16 = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      G.rec16 = nullptr;
+    }
+  }
   G.enabled = true;
   return GL_OK;
 }
@@ -642,9 +694,19 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   int32_t* list = count + 16;
   TimerScope ts(c, GL_TIMER_ASSOC);
   if (resolve_all) GL_HIP(hipMemsetAsync(count, 0, 4, c->stream));
-  if (G.cell4 && c->opt.assoc_coop != 0 && N >= 4096)
-    k_assoc_cells_coop<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr, count);
-  else
+  if (G.cell4 && c->opt.assoc_coop != 0 && N >= 4096) {
+    const bool pad = g->grid.rec16 && c->opt.assoc_rec_pad != 0;
+    const double* recg = pad ? g->grid.rec16 : g->rec12;
+    int32_t* rl = resolve_all ? list : nullptr;
+    const dim3 gr((N + 255) / 256);
+    if (c->opt.assoc_coop_long != 0) {
+      if (pad) k_assoc_cells_coop<16, true><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+      else k_assoc_cells_coop<12, true><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+    } else {
+      if (pad) k_assoc_cells_coop<16, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+      else k_assoc_cells_coop<12, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+    }
+  } else
     k_assoc_cells<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr, count);
   GL_HIP(hipGetLastError());
   if (resolve_all)  // the unresolved points go through the all-pairs sweep (grid sized for N, empty tiles exit)

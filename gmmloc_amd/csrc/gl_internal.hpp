@@ -65,6 +65,9 @@ struct CellIndex {
   // packed cells (round 3): {count, then the list itself when count <= 3, else the offset into idx}: ONE random 16-byte
   // read per point where ptr[c], ptr[c + 1] and idx[...] are two (the kernel is bound by the fabric's random sectors)
   void* cell4 = nullptr;    // ncell x int4, or null (table above the memory budget)
+  // the records again, one per 128-byte line (K x 16 doubles, the last four unused): a 96-byte record of rec12 lies across
+  // two lines three times out of four, and the cooperative gather is bound by line requests (round 5; null without cell4)
+  double* rec16 = nullptr;
 };
 
 struct Gmm {
@@ -110,6 +113,8 @@ struct Options {
   double view_threads = 0;      //   0 auto, 256 / 1024
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
   double assoc_grid = -1;       // 0: never use the cell index (every association is the N x K sweep); A/B and bench
+  double assoc_coop_long = 1;   // 1: lists of more than three candidates go through the cooperative gather too, 0: the lane walks them alone (A/B; same results)
+  double assoc_rec_pad = 1;     // 1: k_assoc_cells_coop gathers from the one-line-per-record copy (CellIndex::rec16), 0: from rec12 (A/B; same results)
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
   double assoc_pack_mb = 512;   // memory budget (MB) of the packed cell table a GMM built with this context may add to its cell index (0: none)
   double assoc_cell = 0;        // > 0: cell size (m) of the index instead of the automatic one (tuning)

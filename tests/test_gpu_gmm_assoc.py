@@ -187,6 +187,41 @@ def test_cell_index_equals_exhaustive(gpu, oracle, map_v1, map_v2, opt, which, N
     oracle.gmm_destroy(h)
 
 
+def test_cell_index_record_copy_option_same_bits(gpu, opt):
+    """assoc_rec_pad: the cooperative gather from the one-record-per-128-byte-line copy (default) and from the 96-byte records
+    give the same indices and the same chi2 bits (and both equal the all-pairs sweep)."""
+    torch, ctx = gpu
+    mean, cov = synth.synth_gmm(4096, 41)
+    g = api.GMM(ctx, mean, cov)
+    rng = np.random.default_rng(41)
+    lo, hi = mean.min(0), mean.max(0)
+    pts = np.concatenate([synth.synth_points(mean, cov, 60000, 41), rng.uniform(lo - 2, hi + 2, (8000, 3))])
+    out = {}
+    for pad, lng in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        opt("assoc_rec_pad", pad)
+        opt("assoc_coop_long", lng)   # lists of more than three candidates through the cooperative gather (default) / by their lane
+        out[pad, lng] = _both(torch, g, pts)
+    (i1, d1), (ie, de) = out[1, 1]
+    assert np.array_equal(i1, ie) and np.array_equal(d1, de)
+    for key in ((0, 1), (1, 0), (0, 0)):
+        (i0, d0), _ = out[key]
+        assert np.array_equal(i1, i0) and np.array_equal(d1, d0), key
+
+
+def test_cell_index_long_lists_in_chunks(gpu):
+    """Many overlapping components: cells with tens of candidates, more than one chunk of the wave's candidate table (384) per wave."""
+    torch, ctx = gpu
+    rng = np.random.default_rng(77)
+    K = 600
+    mean = rng.uniform(-0.5, 0.5, (K, 3))
+    cov = np.tile((np.eye(3) * 0.04).reshape(1, 9), (K, 1)) * rng.uniform(0.5, 1.5, (K, 1))
+    g = api.GMM(ctx, mean, cov)
+    pts = rng.uniform(-0.7, 0.7, (30000, 3))
+    (i1, d1), (i2, d2) = _both(torch, g, pts)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    assert (i1 >= 0).sum() > 10000
+
+
 def test_cell_index_adversarial_components(gpu):
     """Components the index cannot bound (singular, indefinite, huge, needle-like with cond > 1e8,
     non-finite) must not change the result; duplicates must keep the lowest index."""
