@@ -126,18 +126,26 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
 #ifndef GL_CG_PIPE
 #define GL_CG_PIPE 1
 #endif
+#ifndef GL_CG_IDXB
+#define GL_CG_IDXB 1
+#endif
+#ifndef GL_CG_BAL
+#define GL_CG_BAL 1
+#endif
 #ifndef GL_CG_IDS
-#define GL_CG_IDS 384
+#define GL_CG_IDS 304
 #endif
 constexpr int CG_REC = GL_CG_REC;  // records per round: 10 per load instruction (6 lanes each, 4 lanes idle), 6 instructions
-constexpr int CG_IDS = GL_CG_IDS;  // candidates of a wave per chunk of its table (the bench points: 201 per wave on average)
-template <int STRIDE, bool LONG>
+constexpr int CG_TAG = 26, CG_KMASK = (1 << CG_TAG) - 1;  // (component indices below 2^26: launch_assoc_index)
+constexpr int CG_IDS = GL_CG_IDS;  // candidates of a wave per chunk of its table (the bench points: 201 per wave on average; 192 - a second chunk for most waves - costs 15 %)
+template <int STRIDE, bool LONG, bool BAL>
 __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restrict__ rec12, const double* __restrict__ recg, GridDev G,
                                                           const double* __restrict__ pts, int N,
                                                           int32_t* __restrict__ out_idx, double* __restrict__ out_d2,
                                                           int32_t* __restrict__ rest_list, int32_t* __restrict__ rest_count) {
   __shared__ __attribute__((aligned(16))) double s_rec[4][CG_REC * 12];
   __shared__ int s_id[4][CG_IDS];
+  __shared__ double s_d[BAL ? 4 : 1][BAL ? CG_IDS : 1];  // BAL: chi2 of the wave's candidates, by position in its table
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 256 + threadIdx.x;
   const bool live = n < N;
@@ -176,14 +184,26 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
   const int total = __shfl(pos, 63);
   pos -= cnt;
   const int sub = lane / 6, part = lane - 6 * sub;  // lanes 60 .. 63 idle in the gather
+  const int otag = BAL ? lane << CG_TAG : 0;        // BAL: a candidate carries its point's lane in the bits above the component index
   for (int c0 = 0; c0 < total; c0 += CG_IDS) {
     const int jlo = max(0, c0 - pos), jhi = min(cnt, c0 + CG_IDS - pos);  // this lane's candidates of the chunk
     if (q.x <= 3) {
-      if (0 >= jlo && 0 < jhi) s_id[wave][pos - c0] = q.y;
-      if (1 >= jlo && 1 < jhi) s_id[wave][pos + 1 - c0] = q.z;
-      if (2 >= jlo && 2 < jhi) s_id[wave][pos + 2 - c0] = q.w;
+      if (0 >= jlo && 0 < jhi) s_id[wave][pos - c0] = q.y | otag;
+      if (1 >= jlo && 1 < jhi) s_id[wave][pos + 1 - c0] = q.z | otag;
+      if (2 >= jlo && 2 < jhi) s_id[wave][pos + 2 - c0] = q.w | otag;
     } else if (LONG) {
-      for (int j = jlo; j < jhi; ++j) s_id[wave][pos + j - c0] = G.idx[q.y + j];
+#if GL_CG_IDXB > 1
+      for (int j0 = jlo; j0 < jhi; j0 += GL_CG_IDXB) {  // GL_CG_IDXB index loads in flight together (one after the other they were a list's length of round trips)
+        int v[GL_CG_IDXB];
+#pragma unroll
+        for (int u = 0; u < GL_CG_IDXB; ++u) v[u] = j0 + u < jhi ? G.idx[q.y + j0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < GL_CG_IDXB; ++u)
+          if (j0 + u < jhi) s_id[wave][pos + j0 + u - c0] = v[u] | otag;
+      }
+#else
+      for (int j = jlo; j < jhi; ++j) s_id[wave][pos + j - c0] = G.idx[q.y + j] | otag;
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
       for (int t = 0; t < CG_REC / 10; ++t) {
         const int rr = t * 10 + sub;
         const bool ld = lane < 60 && rr < nr;
-        const int id = s_id[wave][ld ? r0 + rr : 0];
+        const int id = s_id[wave][ld ? r0 + rr : 0] & CG_KMASK;
         piece[t] = ld ? *(const double2*)(recg + (size_t)id * STRIDE + part * 2) : make_double2(0.0, 0.0);
       }
     };
@@ -213,18 +233,47 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (GL_CG_PIPE && r0 + CG_REC < nch) request(r0 + CG_REC);
-      const int ja = max(jlo, c0 + r0 - pos), jb = min(jhi, c0 + r0 + nr - pos);
-      for (int j = ja; j < jb; ++j) {
-        const int r = pos + j - c0 - r0;
-        const int k = s_id[wave][r0 + r];
+      if (BAL) {
+        // BALANCED evaluation (round 5): candidate r0 + l of the table is evaluated by LANE l against its point, whose coordinates come
+        // from the owner's registers (ds_bpermute) - one evaluation per lane and round.  Evaluated by their owners, a round cost as many
+        // passes through the ~40 instructions of a pair as its longest list is long, with most lanes masked out: 1 012 vector
+        // instructions per wave for 201 pairs, the SIMDs' vector ALUs 73 % busy (profiles/r5n_traffic.json).
+        const bool ev = lane < nr;
+        const int w = s_id[wave][ev ? r0 + lane : 0];
+        const int own = (int)((unsigned)w >> CG_TAG);
+        const double ox = __shfl(x, own), oy = __shfl(y, own), oz = __shfl(z, own);
         double rec[12];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
-          const double2 v = *(const double2*)(&s_rec[wave][r * 12 + e * 2]);
+          const double2 v = *(const double2*)(&s_rec[wave][(ev ? lane : 0) * 12 + e * 2]);
           rec[2 * e] = v.x;
           rec[2 * e + 1] = v.y;
         }
-        upd_min(chi2_rec(rec, x, y, z), k, best, bi);
+        const double d = chi2_rec(rec, ox, oy, oz);
+        if (ev) s_d[wave][r0 + lane] = d;
+      } else {
+        const int ja = max(jlo, c0 + r0 - pos), jb = min(jhi, c0 + r0 + nr - pos);
+        for (int j = ja; j < jb; ++j) {
+          const int r = pos + j - c0 - r0;
+          const int k = s_id[wave][r0 + r];
+          double rec[12];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const double2 v = *(const double2*)(&s_rec[wave][r * 12 + e * 2]);
+            rec[2 * e] = v.x;
+            rec[2 * e + 1] = v.y;
+          }
+          upd_min(chi2_rec(rec, x, y, z), k, best, bi);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (BAL) {  // the owner takes the lexicographic minimum over its candidates' (chi2, index): a read and a compare per candidate
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int j = jlo; j < jhi; ++j) {
+        const int i = pos + j - c0;
+        upd_min(s_d[wave][i], s_id[wave][i] & CG_KMASK, best, bi);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -699,12 +748,15 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
     const double* recg = pad ? g->grid.rec16 : g->rec12;
     int32_t* rl = resolve_all ? list : nullptr;
     const dim3 gr((N + 255) / 256);
-    if (c->opt.assoc_coop_long != 0) {
-      if (pad) k_assoc_cells_coop<16, true><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
-      else k_assoc_cells_coop<12, true><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+    if (c->opt.assoc_coop_long != 0 && GL_CG_BAL && g->K < (1 << 26) && c->opt.assoc_coop_bal != 0) {
+      if (pad) k_assoc_cells_coop<16, true, true><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+      else k_assoc_cells_coop<12, true, true><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+    } else if (c->opt.assoc_coop_long != 0) {
+      if (pad) k_assoc_cells_coop<16, true, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+      else k_assoc_cells_coop<12, true, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
     } else {
-      if (pad) k_assoc_cells_coop<16, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
-      else k_assoc_cells_coop<12, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+      if (pad) k_assoc_cells_coop<16, false, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
+      else k_assoc_cells_coop<12, false, false><<<gr, 256, 0, c->stream>>>(g->rec12, recg, G, pts, N, idx, d2, rl, count);
     }
   } else
     k_assoc_cells<<<(N + 255) / 256, 256, 0, c->stream>>>(g->rec12, G, pts, N, idx, d2, resolve_all ? list : nullptr, count);

@@ -113,6 +113,7 @@ struct Options {
   double view_threads = 0;      //   0 auto, 256 / 1024
   double assoc_index_min = -1;  // pairs below which GL_ASSOC_BRUTE stays on the sweep (-1 = built-in)
   double assoc_grid = -1;       // 0: never use the cell index (every association is the N x K sweep); A/B and bench
+  double assoc_coop_bal = 1;    // 1: the cooperative gather's pairs are evaluated one per lane and round (needs assoc_coop_long), 0: by the lane that owns the point (A/B; same results)
   double assoc_coop_long = 1;   // 1: lists of more than three candidates go through the cooperative gather too, 0: the lane walks them alone (A/B; same results)
   double assoc_rec_pad = 1;     // 1: k_assoc_cells_coop gathers from the one-line-per-record copy (CellIndex::rec16), 0: from rec12 (A/B; same results)
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record

@@ -90,6 +90,7 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   assoc_coop (1; 0: the indexed association gathers a record per lane instead of per six lanes - A/B),
  *   assoc_rec_pad (1; 0: the cooperative gather reads the 96-byte records instead of their one-per-128-byte-line copy - A/B),
  *   assoc_coop_long (1; 0: a point whose cell lists more than three candidates walks that list alone after the cooperative gather - A/B),
+ *   assoc_coop_bal (1; 0: the pairs of the cooperative gather are evaluated by the lane that owns the point instead of one per lane and round - A/B),
  *   ba_rendezvous_us (200): time limit of every exchange between the workgroups of a frame on the latency shape of
  *     gl_track_frames (one point per thread, up to 8 workgroups per frame, launched plainly).  A frame whose workgroups do
  *     not find each other in time - another launch holds the CUs - or lose each other later gives up; its results only

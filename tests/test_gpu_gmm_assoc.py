@@ -197,13 +197,14 @@ def test_cell_index_record_copy_option_same_bits(gpu, opt):
     lo, hi = mean.min(0), mean.max(0)
     pts = np.concatenate([synth.synth_points(mean, cov, 60000, 41), rng.uniform(lo - 2, hi + 2, (8000, 3))])
     out = {}
-    for pad, lng in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    for pad, lng, bal in ((1, 1, 1), (0, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 0)):
         opt("assoc_rec_pad", pad)
         opt("assoc_coop_long", lng)   # lists of more than three candidates through the cooperative gather (default) / by their lane
-        out[pad, lng] = _both(torch, g, pts)
-    (i1, d1), (ie, de) = out[1, 1]
+        opt("assoc_coop_bal", bal)    # a pair per lane and round (default) / the pairs of a point by the lane that owns it
+        out[pad, lng, bal] = _both(torch, g, pts)
+    (i1, d1), (ie, de) = out[1, 1, 1]
     assert np.array_equal(i1, ie) and np.array_equal(d1, de)
-    for key in ((0, 1), (1, 0), (0, 0)):
+    for key in ((0, 1, 1), (1, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 0)):
         (i0, d0), _ = out[key]
         assert np.array_equal(i1, i0) and np.array_equal(d1, d0), key
 
