@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
 #define GL_CG_IDS 304
 #endif
 constexpr int CG_REC = GL_CG_REC;  // records per round: 10 per load instruction (6 lanes each, 4 lanes idle), 6 instructions
+constexpr int CG_LONE_LANES = 32;  // a wave gathers its long lists cooperatively while at most half of its lanes have one
 constexpr int CG_TAG = 26, CG_KMASK = (1 << CG_TAG) - 1;  // (component indices below 2^26: launch_assoc_index)
 constexpr int CG_IDS = GL_CG_IDS;  // candidates of a wave per chunk of its table (the bench points: 201 per wave on average; 192 - a second chunk for most waves - costs 15 %)
 template <int STRIDE, bool LONG, bool BAL>
@@ -173,7 +174,11 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
   // per candidate while the rest of the wave waited (a third of the bench points; the time of the kernel followed THEM:
   // profiles/r5_assoc_cell_sweep.txt, the 3 cm row).  Now the lane copies its list's indices into the wave's candidate table like
   // the short lists' three, in chunks of CG_IDS candidates.
-  const int cnt = LONG ? q.x : (q.x <= 3 ? q.x : 0);
+  // ... unless the wave's lists are long throughout (the stress map: 74 candidates per point): then every lane is busy walking its own
+  // list and the gather's rounds of 60 are the slower way (measured 1.05 against 0.38 ms per 50 000 points).  Decided per wave by
+  // the number of lanes with a long list.
+  const bool lone = !LONG || __popcll(__ballot(q.x > 3)) > CG_LONE_LANES;
+  const int cnt = lone ? (q.x <= 3 ? q.x : 0) : q.x;
   // exclusive prefix sum of the counts over the wave
   int pos = cnt;
 #pragma unroll
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
       if (0 >= jlo && 0 < jhi) s_id[wave][pos - c0] = q.y | otag;
       if (1 >= jlo && 1 < jhi) s_id[wave][pos + 1 - c0] = q.z | otag;
       if (2 >= jlo && 2 < jhi) s_id[wave][pos + 2 - c0] = q.w | otag;
-    } else if (LONG) {
+    } else if (!lone) {
 #if GL_CG_IDXB > 1
       for (int j0 = jlo; j0 < jhi; j0 += GL_CG_IDXB) {  // GL_CG_IDXB index loads in flight together (one after the other they were a list's length of round trips)
         int v[GL_CG_IDXB];
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (!LONG && inside && q.x > 3) {  // long list: by the lane itself
+  if (lone && inside && q.x > 3) {  // long list: by the lane itself
     for (int e = q.y; e < q.y + q.x; ++e) {
       const int k = G.idx[e];
       upd_min(chi2_rec(rec12 + (size_t)k * 12, x, y, z), k, best, bi);
