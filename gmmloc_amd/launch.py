@@ -19,6 +19,9 @@ def free_port():
     return p
 
 
+RENDEZVOUS_RETRY_S = 20.0  # spawn_ranks: a launcher that fails sooner than this is started again (port taken between probe and bind)
+
+
 def is_rank():
     """True when a launcher (torchrun) already made this process one rank of a job."""
     return "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -36,9 +39,19 @@ def spawn_ranks(n, script, argv, need_gpus=True):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
-    return subprocess.call(cmd, env=env)
+    # free_port() closes its socket before the launcher binds the port: another process can take it in between.  A launch that
+    # dies inside the first seconds (the rendezvous) is tried again on another port; one that ran longer failed for its own reasons.
+    import time
+    rc = 1
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+        t0 = time.monotonic()
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0 or time.monotonic() - t0 > RENDEZVOUS_RETRY_S:
+            break
+        sys.stderr.write("%s: the launcher exited with %d after %.1f s (attempt %d of 3)\n" % (os.path.basename(script), rc, time.monotonic() - t0, attempt + 1))
+    return rc
 
 
 class Ranks:

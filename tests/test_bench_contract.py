@@ -56,6 +56,21 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert d["steps_run_all_ranks"] == 2 * (7 + 2)  # both ranks ran every step (all_reduce SUM over the group)
 
 
+def test_bench_gpus_8_walks_the_whole_node_on_cpu():
+    """The node of the north star has 8 GPUs and no session has had one: walk `bench.py --gpus 8` once on CPU (gloo, stand-in
+    step) so that the first real run meets no surprise of the launch itself - eight ranks in ONE group, every rank ran every step,
+    eight per-rank rates that agree with the headline's clock."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GMMLOC_STUB_STEP_MS"] = "40"
+    d = _stub_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--stub", "gloo"], env)
+    assert d["n_gpus"] == 8 and d["ranks_in_group"] == 8 and d["backend"] == "gloo"
+    assert d["steps_run_all_ranks"] == 8 * (4 + 1)
+    assert len(d["per_rank_rate"]) == 8
+    share = 1e3 / d["ms_per_step"]
+    for r in d["per_rank_rate"]:
+        assert share * 0.999 <= r <= 1.25 * share, (r, share)  # (8 processes on a few host cores: the slowest rank sets the headline)
+
+
 def test_per_rank_rate_is_a_throughput_not_an_enqueue_time():
     """The steps of the real bench only ENQUEUE kernels.  A rank's own rate must be taken after its device is idle: with an
     asynchronous stand-in step (60 ms of 'device' work per step) every rank's rate has to sit within 5 % of its share of the
