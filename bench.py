@@ -84,6 +84,19 @@ def measured_traffic(kernel, frames_per_launch):
     return None, None, None
 
 
+def measured_counter(kernel, counter):
+    """one PMC counter of `kernel` per launch, with the launch size it was measured at, from the same committed summary
+    (profiles/r*_traffic.json: SQ_INSTS_VALU, SQ_WAVE_CYCLES ... per launch) -> (value, frames_per_launch) or (None, None)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        with open(path) as f:
+            doc = json.load(f)
+        t = doc.get(kernel)
+        if t and counter in t and t.get("frames_per_launch"):
+            return float(t[counter]), int(t["frames_per_launch"])
+    return None, None
+
+
 _W = {}
 
 
@@ -497,6 +510,8 @@ def main():
         ba_bytes = B * (N_PTS * (24 + 24 + 4 + 4 + 8 + 24 + 4) + 2 * 56)  # Xw, obs, octave, assoc, d2 in; points, final assoc out; pose in/out
         ba_traffic, ba_traffic_src, ba_traffic_stale = measured_traffic("k_ba1_fast", B)
         sw_traffic, sw_traffic_src, _ = measured_traffic("k_assoc_brute", B)
+        ba_insts, ba_insts_frames = measured_counter("k_ba1_fast", "SQ_INSTS_VALU")
+        insts_pt = (ba_insts * 64.0 / (ba_insts_frames * N_PTS * (n_trials / B))) if ba_insts else None
         if ba_traffic_stale:
             sys.stderr.write("bench.py: %s was measured on other kernel sources than the ones in gmmloc_amd/csrc "
                              "(roofline.traffic_stale = true): re-run tools/profile_bench.sh\n" % ba_traffic_src)
@@ -543,6 +558,12 @@ def main():
                 "frac_all_points_model_what": "rounds 1-4 priced every one of the %d points in every trial; since round 5 `frac` prices the "
                                               "level-0 reprojection edges only (edges gated out at :799-825 are in no linearisation)" % N_PTS,
                 "trials_per_frame": n_trials / B,
+                # VALU instructions the kernel ISSUES per point and Levenberg trial (SQ_INSTS_VALU counts wave instructions: x 64 lanes,
+                # / the point-trials of the profiled launch) beside the model's FMA slots: the instruction efficiency of the trial
+                "insts_per_point_trial": insts_pt,
+                "insts_per_point_trial_what": "SQ_INSTS_VALU of %s x 64 / (frames x %d points x %.1f trials) of the profiled launch; the flop model "
+                                              "prices a trial at %d FMA slots per point (%d for a re-trial)"
+                                              % (ba_traffic_src, N_PTS, n_trials / B, FLOP_PER_POINT_TRIAL // 2, FLOP_PER_POINT_RETRIAL // 2),
                 "outer_iterations_per_frame": n_outer / B,
                 "frac_pricing_every_trial_as_a_linearisation": (ba_flop_every_trial / ba_s / 1e12 / PEAK_FP64_VALU_TFLOPS) if ba_n else None,
                 "flop_model": "SURVEY 8d: 800 flop per point and outer iteration (linearise + 3x3 inverse + Schur + error); a Levenberg trial "

@@ -82,6 +82,8 @@ def load():
         "gl_project_map_points": (i32, [vp, vp, C.c_float, i32, i32] + [vp] * 12),
         "gl_level_steps": (i32, [C.c_float, vp]),
         "gl_track_frame_chain": (i32, [vp, vp, vp, C.c_float, i32, i32, i32, i32, vp, C.c_float, C.c_float, C.c_float, i32]),
+        "gl_track_frame_chain_front": (i32, [vp, vp, vp, C.c_float, i32, i32, i32, i32, vp, C.c_float, i32]),
+        "gl_track_frame_chain_back": (i32, [vp, vp, vp, C.c_float, i32, i32, i32, i32, vp, C.c_float, C.c_float]),
         "gl_search_local_points": (i32, [vp, vp, C.c_float, i32, i32, i32] + [vp] * 13 + [C.c_float, C.c_float, vp, vp, vp]),
         "gl_gather_triangulation_matches": (i32, [vp, i32, i32, i32, i32, i32] + [vp] * 32),
         "gl_optimize_point": (i32, [vp, vp, P(gl_camera), P(gl_params), i32] + [vp] * 10),

@@ -533,33 +533,104 @@ CHAIN_DTYPES = {"feat_uv": "float64", "feat_ur": "float32", "feat_oct": "int32",
                 "mp_max_dist": "float32", "mp_min_dist": "float32", "mp_cand": "uint8", "mp_desc": "uint8", "pose_cw": "float64"}
 
 
+# round 6: optional inputs (a key absent from `a` = NULL).  last_observed: countObservations() > 0 of the last frame's map points; the
+# kf_* / feat_node_* buffers switch the trackKeyFrame fallback on.
+CHAIN_OPT_DTYPES = {"last_observed": "uint8", "kf_angle": "float32", "kf_desc": "uint8", "kf_has_mp": "uint8", "kf_nnode": "int32",
+                    "kf_node_id": "int32", "kf_node_ptr": "int32", "kf_node_idx": "int32", "kf_pt": "float64", "kf_to_local": "int32",
+                    "feat_nnode": "int32", "feat_node_id": "int32", "feat_node_ptr": "int32", "feat_node_idx": "int32"}
+CHAIN_FIELDS2A = ("last_observed", "drop_src", "counts2")
+CHAIN_FIELDS2B = ("kf_angle", "kf_desc", "kf_has_mp", "kf_nnode", "kf_node_id", "kf_node_ptr", "kf_node_idx", "kf_pt", "kf_to_local",
+                  "feat_nnode", "feat_node_id", "feat_node_ptr", "feat_node_idx", "match_kf", "drop_kf")
+
+
 class _ChainIO(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in CHAIN_FIELDS]
+    _fields_ = ([(k, C.c_void_p) for k in CHAIN_FIELDS] + [(k, C.c_void_p) for k in CHAIN_FIELDS2A] +
+                [("NK", C.c_int32), ("NNK", C.c_int32), ("NNF", C.c_int32), ("reserved_", C.c_int32)] + [(k, C.c_void_p) for k in CHAIN_FIELDS2B])
 
 
-def track_frame_chain(ctx, cam, prm, a, th_mm=7.0, th_local=3.0, nn_ratio=0.8, mono=False, scale_factor=1.2):
-    """gl_track_frame_chain: trackWithMotionModel -> searchLocalPoints -> trackLocalMap for B frames, device resident.  `a`: dict of
-    CUDA tensors with the input keys of CHAIN_DTYPES (pose_cw (B,7): the motion-model prediction; it is NOT modified - the result
-    comes back as a new tensor).  Returns dict(pose, pose_mm, match_last, match_local, outlier, counts (B,4), inview)."""
+def _chain_io(a, out):
     import torch
     for k, dt in CHAIN_DTYPES.items():
         t = a[k]
         assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch." + dt, (k, t.dtype, t.is_contiguous())
+    for k, dt in CHAIN_OPT_DTYPES.items():
+        if k in a and a[k] is not None:
+            t = a[k]
+            assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch." + dt, (k, t.dtype, t.is_contiguous())
+    io = _ChainIO()
+    for k in CHAIN_FIELDS + CHAIN_FIELDS2A + CHAIN_FIELDS2B:
+        t = out["pose"] if k == "pose_cw" else (out[k] if k in out else a.get(k))
+        setattr(io, k, _ptr(t) if t is not None else None)
+    if a.get("kf_desc") is not None:
+        io.NK, io.NNK, io.NNF = a["kf_desc"].shape[1], a["kf_node_id"].shape[1], a["feat_node_id"].shape[1]
+    return io
+
+
+def _chain_out(a, front_only=False):
+    import torch
+    B, NF = a["feat_oct"].shape
+    NP = a["mp_cand"].shape[1]
+    dev = a["feat_oct"].device
+    i32 = lambda *sh: torch.full(sh, -1, dtype=torch.int32, device=dev)
+    out = dict(pose=a["pose_cw"].clone(), pose_mm=torch.empty((B, 7), dtype=torch.float64, device=dev), match_last=i32(B, NF),
+               match_local=i32(B, NF), outlier=torch.zeros((B, NF), dtype=torch.uint8, device=dev),
+               counts=torch.zeros((B, 4), dtype=torch.int32, device=dev), inview=torch.zeros((B, NP), dtype=torch.uint8, device=dev),
+               drop_src=i32(B, NF), counts2=torch.zeros((B, 4), dtype=torch.int32, device=dev))
+    if a.get("kf_desc") is not None:
+        out["match_kf"] = i32(B, NF)
+        out["drop_kf"] = i32(B, NF)
+    return out
+
+
+def track_frame_chain(ctx, cam, prm, a, th_mm=7.0, th_local=3.0, nn_ratio=0.8, mono=False, scale_factor=1.2):
+    """gl_track_frame_chain: trackWithMotionModel (-> trackKeyFrame where it fails, if `a` holds the key-frame buffers) ->
+    searchLocalPoints -> trackLocalMap for B frames, device resident.  `a`: dict of CUDA tensors with the input keys of CHAIN_DTYPES
+    (+ optionally those of CHAIN_OPT_DTYPES); pose_cw (B,7): the motion-model prediction, NOT modified - the result comes back as a
+    new tensor.  Returns dict(pose, pose_mm, match_last, match_local, outlier, counts (B,4), inview, drop_src, counts2 (B,4)
+    [, match_kf, drop_kf])."""
     B, NF = a["feat_oct"].shape
     NL, NP = a["last_oct"].shape[1], a["mp_cand"].shape[1]
-    dev = a["feat_oct"].device
-    out = dict(pose=a["pose_cw"].clone(), pose_mm=torch.empty((B, 7), dtype=torch.float64, device=dev),
-               match_last=torch.empty((B, NF), dtype=torch.int32, device=dev), match_local=torch.empty((B, NF), dtype=torch.int32, device=dev),
-               outlier=torch.empty((B, NF), dtype=torch.uint8, device=dev), counts=torch.zeros((B, 4), dtype=torch.int32, device=dev),
-               inview=torch.empty((B, NP), dtype=torch.uint8, device=dev))
-    io = _ChainIO()
-    for k in CHAIN_FIELDS:
-        t = out["pose"] if k == "pose_cw" else (out[k] if k in out else a[k])
-        setattr(io, k, _ptr(t))
+    out = _chain_out(a)
+    io = _chain_io(a, out)
     ctx._enter()
     try:
         _check(ctx.lib.gl_track_frame_chain(ctx.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), B, NF, NL, NP, C.byref(io),
                                             float(th_mm), float(th_local), float(nn_ratio), int(bool(mono))))
+    finally:
+        ctx._exit()
+    return out
+
+
+def track_frame_chain_front(ctx, cam, prm, a, th_mm=7.0, mono=False, scale_factor=1.2):
+    """gl_track_frame_chain_front: stages 1, 2 (and the trackKeyFrame fallback) of the chain.  Returns the same dict as
+    track_frame_chain (pose = the pose after stage 2 / 2b; match_local / inview / counts[2:] untouched); hand it to
+    track_frame_chain_back together with the local map Tracking::updateLocalMap made from it."""
+    B, NF = a["feat_oct"].shape
+    NL, NP = a["last_oct"].shape[1], a["mp_cand"].shape[1]
+    out = _chain_out(a)
+    io = _chain_io(a, out)
+    ctx._enter()
+    try:
+        _check(ctx.lib.gl_track_frame_chain_front(ctx.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), B, NF, NL, NP, C.byref(io),
+                                                  float(th_mm), int(bool(mono))))
+    finally:
+        ctx._exit()
+    return out
+
+
+def track_frame_chain_back(ctx, cam, prm, a, out, th_local=3.0, nn_ratio=0.8, scale_factor=1.2):
+    """gl_track_frame_chain_back: stages 3, 4 on the associations `out` (of track_frame_chain_front) and the local map in `a`
+    (mp_*, last_to_local, kf_to_local: indices into THIS local map).  `out` is updated in place and returned."""
+    B, NF = a["feat_oct"].shape
+    NL, NP = a["last_oct"].shape[1], a["mp_cand"].shape[1]
+    import torch
+    if out["inview"].shape[1] != NP:
+        out["inview"] = torch.zeros((B, NP), dtype=torch.uint8, device=a["feat_oct"].device)
+    io = _chain_io(a, out)
+    ctx._enter()
+    try:
+        _check(ctx.lib.gl_track_frame_chain_back(ctx.h, C.byref(cam.c()), C.byref(prm.c()), float(scale_factor), B, NF, NL, NP, C.byref(io),
+                                                 float(th_local), float(nn_ratio)))
     finally:
         ctx._exit()
     return out

@@ -220,6 +220,11 @@ int launch_build_neighbours(Ctx* c, Gmm* g);
 int build_cell_index(Ctx* c, Gmm* g);
 void free_cell_index(Gmm* g);
 // gl_search_by_projection_frame with a per-frame gate (gl_match.hip): frames with gate_nm[f] >= gate_min are left untouched
+int launch_bow_gated(gl_ctx_t* ctx, float nn_ratio, int check_orientation, int B, int N1, int N2, int NN1, int NN2, const float* angle1_dev,
+                     const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev, const int32_t* node_id1_dev,
+                     const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev, const float* angle2_dev, const uint8_t* desc2_dev,
+                     const int32_t* nnode2_dev, const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
+                     int32_t* match21_dev, int32_t* nmatches_dev, const int32_t* run_flag);
 int launch_match_frame_gated(gl_ctx_t* ctx, const gl_camera* cam, float scale_factor, int B, int NF, int NL, const double* pose_cw, const double* pose_lw,
                              const double* feat_uv, const float* feat_ur, const int32_t* feat_oct, const float* feat_angle, const uint8_t* feat_desc,
                              const uint8_t* feat_taken, const double* last_pt, const uint8_t* last_valid, const int32_t* last_oct, const float* last_angle,

@@ -93,10 +93,10 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     const uint8_t* __restrict__ feat_taken_all, const double* __restrict__ mp_uvr_all,
     const int32_t* __restrict__ mp_level_all, const double* __restrict__ mp_viewcos_all,
     const uint8_t* __restrict__ mp_valid_all, const uint8_t* __restrict__ mp_desc_all,
-    int32_t* __restrict__ feat_match_all, int32_t* __restrict__ nmatches_all,
+    int32_t* __restrict__ feat_match_all, int32_t* nmatches_all,  // (not restrict: the chain's wider second search gates on the counts it rewrites)
     const double* __restrict__ pose_cw_all, const double* __restrict__ pose_lw_all,
     const float* __restrict__ feat_angle_all, const float* __restrict__ mp_angle_all, int32_t* __restrict__ counters,
-    uint4* __restrict__ cache_all, const int32_t* __restrict__ gate_nm, int gate_min) {
+    uint4* __restrict__ cache_all, const int32_t* gate_nm, int gate_min) {
   constexpr int TM = DL ? 1024 : T_M;  // threads per frame: the latency shape doubles them
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* cell_ptr = lds;                   // NCELL + 1

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
                                                        const uint8_t* __restrict__ desc2_all, const int32_t* __restrict__ nn2_all,
                                                        const int32_t* __restrict__ nid2_all, const int32_t* __restrict__ nptr2_all,
                                                        const int32_t* __restrict__ nidx2_all, int32_t* __restrict__ match_all,
-                                                       int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters, uint4* __restrict__ cache_all) {
+                                                       int32_t* __restrict__ nmatches_all, int32_t* __restrict__ counters, uint4* __restrict__ cache_all,
+                                                       const int32_t* __restrict__ run_flag) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   int32_t* owner = lds;            // N2: lowest query that claimed the frame feature in the previous round (INT_MAX: nobody)
   int32_t* owner_n = owner + N2;   // N2: being rebuilt
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(T_B) void k_search_by_bow(int B, int N1, int N2, in
   __shared__ int s_changed, s_hist[32], s_keep[4], s_cnt[T_B / 64];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
+  if (run_flag && run_flag[f] == 0) return;  // (gl_track_frame_chain's trackKeyFrame fallback: only the frames that need it)
   const uint32_t* desc1 = (const uint32_t*)(desc1_all + (size_t)f * N1 * 32);
   const uint8_t* mp1 = mp1_all + (size_t)f * N1;
   const uint32_t* desc2 = (const uint32_t*)(desc2_all + (size_t)f * N2 * 32);
@@ -343,6 +345,17 @@ extern "C" int gl_search_by_bow(gl_ctx_t* ctx, float nn_ratio, int check_orienta
                                 const int32_t* node_id1_dev, const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev,
                                 const float* angle2_dev, const uint8_t* desc2_dev, const int32_t* nnode2_dev, const int32_t* node_id2_dev,
                                 const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev, int32_t* match21_dev, int32_t* nmatches_dev) {
+  return gl::launch_bow_gated(ctx, nn_ratio, check_orientation, B, N1, N2, NN1, NN2, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev, node_id1_dev,
+                              node_ptr1_dev, node_idx1_dev, angle2_dev, desc2_dev, nnode2_dev, node_id2_dev, node_ptr2_dev, node_idx2_dev, match21_dev,
+                              nmatches_dev, nullptr);
+}
+
+// the same with a per-frame switch (run_flag B int32, 0: the frame's workgroup returns at once and writes nothing; null: every frame)
+int gl::launch_bow_gated(gl_ctx_t* ctx, float nn_ratio, int check_orientation, int B, int N1, int N2, int NN1, int NN2, const float* angle1_dev,
+                         const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev, const int32_t* node_id1_dev,
+                         const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev, const float* angle2_dev, const uint8_t* desc2_dev,
+                         const int32_t* nnode2_dev, const int32_t* node_id2_dev, const int32_t* node_ptr2_dev, const int32_t* node_idx2_dev,
+                         int32_t* match21_dev, int32_t* nmatches_dev, const int32_t* run_flag) {
   GL_REQUIRE(ctx, "null context");
   if (B == 0) return GL_OK;
   GL_REQUIRE(B > 0 && N1 >= 1 && N2 >= 1 && NN1 >= 1 && NN2 >= 1, "bad B / N1 / N2 / NN1 / NN2");
@@ -362,7 +375,7 @@ extern "C" int gl_search_by_bow(gl_ctx_t* ctx, float nn_ratio, int check_orienta
   }
   k_search_by_bow<<<B, T_B, lds, c->stream>>>(B, N1, N2, NN1, NN2, nn_ratio, check_orientation, angle1_dev, desc1_dev, has_mp1_dev, nnode1_dev,
                                               node_id1_dev, node_ptr1_dev, node_idx1_dev, angle2_dev, desc2_dev, nnode2_dev, node_id2_dev,
-                                              node_ptr2_dev, node_idx2_dev, match21_dev, nmatches_dev, c->counters, (uint4*)cache);
+                                              node_ptr2_dev, node_idx2_dev, match21_dev, nmatches_dev, c->counters, (uint4*)cache, run_flag);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -499,13 +499,19 @@ def synth_local_points_frame(NF, NP, seed, cam, scale_factor=1.2, float_uv=True)
     return f
 
 
-def synth_chain_frame(NF, NL, NP, seed, cam, scale_factor=1.2):
+def synth_chain_frame(NF, NL, NP, seed, cam, scale_factor=1.2, temporal_frac=0.0, NK=0, n_nodes=120, pred_rot_deg=None):
     """One tracked frame for gl_track_frame_chain (trackWithMotionModel -> searchLocalPoints -> trackLocalMap), geometrically
     CONSISTENT so that both pose optimisations have inliers: a last frame at the identity with NL map points, a current frame at a
     small true motion whose features re-observe 60 % of them (sub-pixel noise scaled by the octave, 8 % gross outliers), a
     motion-model prediction a fraction of a degree / a centimetre off, and a local map of NP points = the last frame's valid map
     points (last_to_local) + points seen by half of the remaining features (position from the TRUE pose, descriptor = the feature's
-    with flipped bits, distance bounds that predict the feature's octave) + distractors."""
+    with flipped bits, distance bounds that predict the feature's octave) + distractors.
+    Round 6 (drawn from a generator of their own: the frames of the earlier seeds are what they were):
+    temporal_frac > 0: that share of the last frame's map points are TEMPORAL points (createTemporalPoints, tracking.cpp:44-46:
+    last_observed = 0, not in the local map through last_to_local - but the local map still holds a real point at the same place, so
+    that searchLocalPoints can replace them); NK > 0: a reference key-frame that sees the last frame's map points (features, DBoW2
+    feature vector as CSR, kf_pt / kf_to_local) and the frame's own feature vector - the inputs of the trackKeyFrame fallback;
+    pred_rot_deg: the motion-model prediction is off by that many degrees (10: no th = 14 window holds a match any more)."""
     rng = np.random.default_rng(seed)
     W, H = cam.width, cam.height
     sf = scale_factor ** np.arange(8)
@@ -516,6 +522,10 @@ def synth_chain_frame(NF, NL, NP, seed, cam, scale_factor=1.2):
     q0, q1 = pose_true[:4], dq  # prediction = dq * true (Hamilton product on (x, y, z, w))
     qp = np.concatenate([q1[3] * q0[:3] + q0[3] * q1[:3] + np.cross(q1[:3], q0[:3]), [q1[3] * q0[3] - q1[:3] @ q0[:3]]])
     pose_pred = np.concatenate([qp / np.linalg.norm(qp), quat_to_R(dq) @ pose_true[4:] + rng.uniform(-0.01, 0.01, 3)])
+    if pred_rot_deg is not None:
+        dq2 = rotv([0.0, 1.0, 0.0], np.deg2rad(pred_rot_deg))
+        qp = np.concatenate([dq2[3] * q0[:3] + q0[3] * dq2[:3] + np.cross(dq2[:3], q0[:3]), [dq2[3] * q0[3] - dq2[:3] @ q0[:3]]])
+        pose_pred = np.concatenate([qp / np.linalg.norm(qp), quat_to_R(dq2) @ pose_true[4:]])
     R, t = quat_to_R(pose_true[:4]), pose_true[4:]
     proj = lambda X: (lambda pc: (cam.fx * pc[:, 0] / pc[:, 2] + cam.cx, cam.fy * pc[:, 1] / pc[:, 2] + cam.cy, pc[:, 2]))(X @ R.T + t)
     # last frame
@@ -579,6 +589,34 @@ def synth_chain_frame(NF, NL, NP, seed, cam, scale_factor=1.2):
     normal = ray + tilt
     normal /= np.linalg.norm(normal, axis=1)[:, None]
     cand = (rng.uniform(size=NP) < 0.95).astype(np.uint8)
-    return dict(feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_angle=angle, feat_desc=desc, feat_taken=taken, pose_lw=pose_lw, last_pt=last_pt,
-                last_valid=last_valid, last_oct=last_oct, last_angle=last_angle, last_desc=last_desc, last_to_local=last_to_local, mp_pos=mp_pos,
-                mp_normal=normal, mp_max_dist=max_dist, mp_min_dist=min_dist, mp_cand=cand, mp_desc=mp_desc, pose_cw=pose_pred, pose_true=pose_true)
+    f = dict(feat_uv=uv, feat_ur=ur, feat_oct=octv, feat_angle=angle, feat_desc=desc, feat_taken=taken, pose_lw=pose_lw, last_pt=last_pt,
+             last_valid=last_valid, last_oct=last_oct, last_angle=last_angle, last_desc=last_desc, last_to_local=last_to_local, mp_pos=mp_pos,
+             mp_normal=normal, mp_max_dist=max_dist, mp_min_dist=min_dist, mp_cand=cand, mp_desc=mp_desc, pose_cw=pose_pred, pose_true=pose_true)
+    r2 = np.random.default_rng(seed + 424242)
+    f["last_observed"] = (r2.uniform(size=NL) >= temporal_frac).astype(np.uint8)
+    if temporal_frac > 0:
+        f["last_to_local"] = np.where(f["last_observed"] != 0, last_to_local, -1).astype(np.int32)
+    if NK > 0:
+        flip = lambda d, nmax: [np.bitwise_xor.at(d[i], b // 8, (1 << (b % 8)).astype(np.uint8)) for i in range(len(d))
+                                for b in [r2.choice(256, int(r2.integers(0, nmax + 1)), replace=False)]]
+        node_pt = r2.integers(0, n_nodes, NL) * 5 + 2  # the vocabulary node of a map point's patch (sparse ids)
+        lk = r2.choice(np.nonzero(last_valid)[0], NK, replace=True)
+        kf_desc = last_desc[lk].copy()
+        flip(kf_desc, 30)
+        kf_angle = np.where(r2.uniform(size=NK) < 0.1, r2.uniform(0, 360, NK), (last_angle[lk] + 4.0 + r2.normal(0, 3, NK)) % 360.0).astype(np.float32)
+        kf_node = np.where(r2.uniform(size=NK) < 0.9, node_pt[lk], r2.integers(0, n_nodes, NK) * 5 + 2)
+        fr_node = np.where(reobs & (r2.uniform(size=NF) < 0.85), node_pt[src], r2.integers(0, n_nodes, NF) * 5 + 2)
+
+        def csr(node, ok):
+            ids = np.unique(node[ok])
+            ptr, idx = [0], []
+            for n in ids:
+                idx.extend(np.nonzero((node == n) & ok)[0].tolist())
+                ptr.append(len(idx))
+            return ids.astype(np.int32), np.array(ptr, np.int32), np.array(idx, np.int32)
+        kid, kptr, kidx = csr(kf_node, np.ones(NK, bool))
+        fid, fptr, fidx = csr(fr_node, octv >= 0)
+        f.update(kf_angle=kf_angle, kf_desc=kf_desc, kf_has_mp=(r2.uniform(size=NK) < 0.9).astype(np.uint8), kf_node_id=kid, kf_node_ptr=kptr,
+                 kf_node_idx=kidx, kf_pt=last_pt[lk].copy(), kf_to_local=f["last_to_local"][lk].astype(np.int32), feat_node_id=fid, feat_node_ptr=fptr,
+                 feat_node_idx=fidx)
+    return f

@@ -343,19 +343,35 @@ int gl_search_local_points(gl_ctx_t* ctx, const gl_camera* cam, float scale_fact
                            const uint8_t* mp_cand_dev, const uint8_t* mp_desc_dev, float th, float nn_ratio, int32_t* feat_match_dev,
                            int32_t* nmatches_dev, uint8_t* inview_dev);
 
-/* One tracked frame, device resident (round 5): Tracking::trackWithMotionModel (tracking.cpp:326-376) -> Tracking::searchLocalPoints
- * (:210-270) -> Tracking::trackLocalMap (:272-299) for B frames as ONE enqueued sequence on the context's stream - no host round trip
- * between its four stages, every intermediate array stays in the context's scratch:
+/* One tracked frame, device resident (round 5; round 6: the fallback, temporal points, the two halves): what Tracking::track
+ * (tracking.cpp:34-118) runs per frame - trackWithMotionModel (:333-376), trackKeyFrame when that fails (:297-331),
+ * searchLocalPoints (:210-270), trackLocalMap (:272-299) - for B frames as ONE enqueued sequence on the context's stream, every
+ * intermediate array in the context's scratch:
  *   1  gl_search_by_projection_frame(th_mm, check_orientation = 1): ORBmatcher(0.9, true).searchByProjection(curr, last, 7); a frame
- *      with fewer than 20 matches is searched again with 2 x th_mm (:335-342; the second launch skips the other frames)
+ *      with fewer than 20 matches is searched again with 2 x th_mm (:340-346; the second launch skips the other frames)
  *   2  gl_optimize_current_pose on the matched features (Xw = the last frame's map point), then the outliers lose their map point
- *      and their is_outlier_ flag (:360-371)
+ *      and their is_outlier_ flag (:360-371; drop_src remembers the map point: it has been seen, :367).  counts2[0] = what
+ *      trackWithMotionModel returns: the kept matches whose map point has observations (last_observed), 0 below 20 matches.
+ *   2b (only with the key-frame buffers, kf_desc != NULL) a frame with counts2[0] < 10 (:50-58) goes through trackKeyFrame instead:
+ *      gl_search_by_bow(0.7, check_orientation = 1) against the reference key-frame, pose = the LAST frame's, gl_optimize_current_pose,
+ *      outliers dropped (drop_kf); its associations are then the key-frame's alone (match_last = -1, match_kf).  The other frames'
+ *      workgroups return at once.  counts2[3] = 1 (tracked through the key-frame) or 2 (fewer than 10 kept matches: the reference
+ *      reports a tracking failure, :66-71, and the later outputs of the frame mean nothing).
  *   3  gl_search_local_points from the refined pose (t_wc = -R^T t computed on the device): candidates = mp_cand minus the local map
- *      points the frame has seen in stage 1 (inliers AND discarded outliers: last_visible_idx_ == idx, :243), features with a map
- *      point are taken
+ *      points the frame holds or dropped (last_visible_idx_ == idx, :243); a feature is taken if its map point has observations -
+ *      a TEMPORAL point (createTemporalPoints, :44-46: no observation; last_observed = 0) stays matchable and is REPLACED by the
+ *      local map point found for its feature (orb_matcher.cpp:74-76, 104: match_last of that feature ends as -1)
  *   4  gl_optimize_current_pose on all features with a map point (trackLocalMap, :276); its outliers are reported, not cleared.
- * What the host keeps doing: num_visible_ / num_found_ / countObservations bookkeeping, the decision on counts[0] < 20 (tracking
- * lost: the later stages' outputs of such a frame mean nothing).  All pointers are DEVICE pointers; layouts as in the four calls. */
+ * THE LOCAL MAP: the reference rebuilds local_mappoints_ between 2 and 3 (Tracking::updateLocalMap, :119-207: the key-frames that
+ * observe the frame's CURRENT map points and their neighbours) - host code on host containers.  gl_track_frame_chain takes ONE
+ * local map, fixed before stage 1: it reproduces Tracking::track only if that list is the one updateLocalMap would produce
+ * (e.g. the previous frame's local map when the covisibility set did not change); stage 3's matches are order-exact for the
+ * list it is given, not for a list it never saw.  A host that wants the reference's sequence exactly calls the two halves -
+ *      gl_track_frame_chain_front (1, 2, 2b)  ->  its own updateLocalMap  ->  gl_track_frame_chain_back (3, 4)
+ * - one round trip instead of three; front needs drop_src (and drop_kf with the fallback) as OUTPUT buffers, back reads match_last /
+ * match_kf / drop_src / drop_kf and the to_local maps against the NEW local map.
+ * What the host keeps doing: num_visible_ / num_found_ / countObservations bookkeeping, the decision on counts2[0] / counts2[3]
+ * (without the fallback buffers: on counts[0] < 20 as before).  All pointers are DEVICE pointers; layouts as in the single calls. */
 typedef struct gl_track_chain_io {
   /* current frame: B x NF (x 2 / x 32) */
   const double* feat_uv;
@@ -380,16 +396,43 @@ typedef struct gl_track_chain_io {
   const uint8_t* mp_cand;
   const uint8_t* mp_desc;
   /* in / out */
-  double* pose_cw;      /* B x 7: in the motion-model prediction, out the pose after trackLocalMap                                  */
-  double* pose_mm;      /* B x 7 out (may be NULL): the pose after stage 2                                                          */
-  int32_t* match_last;  /* B x NF out: last-frame feature kept after stage 2, or -1                                                 */
+  double* pose_cw;      /* B x 7: in the motion-model prediction, out the pose after trackLocalMap (front: after stage 2 / 2b)       */
+  double* pose_mm;      /* B x 7 out (may be NULL): the pose after stage 2 / 2b                                                     */
+  int32_t* match_last;  /* B x NF out: last-frame feature whose map point the feature holds, or -1                                  */
   int32_t* match_local; /* B x NF out: local map point found in stage 3, or -1                                                      */
   uint8_t* outlier;     /* B x NF out: is_outlier_ after stage 4                                                                    */
-  int32_t* counts;      /* B x 4 out: matches of stage 1 (after the retry), inliers of stage 2, matches of stage 3, inliers of stage 4 */
+  int32_t* counts;      /* B x 4 out: matches of stage 1 (after the retry), inliers of stage 2 (2b), matches of stage 3, inliers of stage 4 */
   uint8_t* inview;      /* B x NP out (may be NULL): is_in_view_ of stage 3                                                         */
+  /* ---- round 6; every pointer below may be NULL (a zero-initialised struct behaves as in round 5) ---- */
+  const uint8_t* last_observed; /* B x NL: countObservations() > 0 of the last-frame feature's map point (NULL: all of them)        */
+  int32_t* drop_src;    /* B x NF out: the last-frame feature whose map point stage 2 dropped as an outlier, or -1                  */
+  int32_t* counts2;     /* B x 4 out: {return value of trackWithMotionModel, searchByBoW matches, return value of trackKeyFrame,
+                           mode 0 motion model / 1 key-frame / 2 lost}; required with the fallback                                  */
+  /* the fallback (trackKeyFrame): the reference key-frame, side 1 of gl_search_by_bow, B x NK; kf_desc == NULL: no fallback        */
+  int32_t NK, NNK, NNF; /* key-frame features; node capacities of the key-frame's and the frame's feature vectors                   */
+  int32_t reserved_;
+  const float* kf_angle;
+  const uint8_t* kf_desc;
+  const uint8_t* kf_has_mp;
+  const int32_t* kf_nnode;
+  const int32_t* kf_node_id;
+  const int32_t* kf_node_ptr;
+  const int32_t* kf_node_idx;
+  const double* kf_pt;          /* B x NK x 3: position of the key-frame feature's map point                                         */
+  const int32_t* kf_to_local;   /* B x NK: index of that map point in the local map, or -1                                           */
+  const int32_t* feat_nnode;    /* the frame's DBoW2::FeatureVector as CSR (ORBVocabulary::transform, :298): B, B x NNF, B x (NNF+1), B x NF */
+  const int32_t* feat_node_id;
+  const int32_t* feat_node_ptr;
+  const int32_t* feat_node_idx;
+  int32_t* match_kf;    /* B x NF out: key-frame feature whose map point the feature holds (mode 1), or -1                          */
+  int32_t* drop_kf;     /* B x NF out: the key-frame feature whose map point stage 2b dropped, or -1                                */
 } gl_track_chain_io;
 int gl_track_frame_chain(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, float scale_factor, int B, int NF, int NL, int NP,
                          const gl_track_chain_io* io, float th_mm, float th_local, float nn_ratio, int mono);
+int gl_track_frame_chain_front(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, float scale_factor, int B, int NF, int NL, int NP,
+                               const gl_track_chain_io* io, float th_mm, int mono);
+int gl_track_frame_chain_back(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, float scale_factor, int B, int NF, int NL, int NP,
+                              const gl_track_chain_io* io, float th_local, float nn_ratio);
 
 /* Localization::fuseObservations (localization.cpp:226-318), the matching half, for B key-frames: per candidate map point the most
  * similar feature inside Frame::getFeaturesInArea(u, v, th * scale_factors[level]) (frame.cpp:121-177) with octave level - 1 or

@@ -1,59 +1,44 @@
-"""gl_track_frame_chain (Tracking::trackWithMotionModel -> searchLocalPoints -> trackLocalMap, tracking.cpp:210-376, device resident)
-against the oracle's four functions run in sequence with the host's glue in numpy.
-
-The stages feed each other, and the pose of an optimisation agrees with the oracle's to 1e-6, not to the bit - a map point that
-projects onto the very edge of a search window could then go either way.  Every stage is therefore checked EXACTLY on the inputs
-the device really gave it (the oracle's stage 3 runs from the device's stage-2 pose and associations, its stage 4 from the device's
-stage-3 matches), and the free-running oracle chain beside it has to agree on the poses to 1e-6 and on (nearly) all matches."""
+"""gl_track_frame_chain (Tracking::track's device half, tracking.cpp:34-118: trackWithMotionModel -> trackKeyFrame when it fails ->
+searchLocalPoints -> trackLocalMap, device resident) against the oracle's functions run in sequence with the host's glue in numpy
+(tests/chain_glue.py): every stage exact on the inputs the device really gave it, poses within 1e-6."""
 import numpy as np
 import pytest
 
 from gmmloc_amd import api, synth
+from tests import chain_glue as G
+from tests.chain_glue import S1_KEYS, TH_LOCAL, TH_MM, oracle_stage1, pose_inputs
 from tests.test_gpu_match import CamF
 
 pytestmark = pytest.mark.gpu
 
-TH_MM, TH_LOCAL = 7.0, 3.0
 
-
-def pose_inputs(f, m_last, m_local=None):
-    has_l = m_last >= 0
-    has_m = (m_local >= 0) if m_local is not None else np.zeros_like(has_l)
-    Xw = np.where(has_l[:, None], f["last_pt"][np.maximum(m_last, 0)],
-                  np.where(has_m[:, None], f["mp_pos"][np.maximum(m_local, 0)] if m_local is not None else 0.0, 0.0))
-    obs = np.concatenate([f["feat_uv"], f["feat_ur"][:, None].astype(np.float64)], 1)
-    oc = np.where(has_l | has_m, f["feat_oct"], -1).astype(np.int32)
-    return Xw, obs, oc
-
-
-def oracle_stage1(o, f):
-    k = ("pose_cw", "pose_lw", "feat_uv", "feat_ur", "feat_oct", "feat_angle", "feat_desc", "feat_taken", "last_pt", "last_valid", "last_oct",
-         "last_angle", "last_desc")
-    m, n = o.search_by_projection_frame(CamF, *[f[x] for x in k], th=TH_MM, mono=False, check_orientation=True)
-    if n < 20:  # tracking.cpp:335-342
-        m, n = o.search_by_projection_frame(CamF, *[f[x] for x in k], th=2 * TH_MM, mono=False, check_orientation=True)
-    return m, n
-
-
-def oracle_stage3(o, cam, f, pose_mm, m_last_before, m_last_kept):
-    """searchLocalPoints from pose_mm: candidates minus the local map points the frame saw in stage 1, kept features taken"""
-    NP = len(f["mp_cand"])
-    seen = np.zeros(NP, bool)
-    l = f["last_to_local"][m_last_before[m_last_before >= 0]]
-    seen[l[l >= 0]] = True
-    cand = (f["mp_cand"] != 0) & ~seen
-    taken = (f["feat_taken"] != 0) | (m_last_kept >= 0)
-    twc = o.pose_twc(pose_mm)
-    uvr, lvl, vc, dd, iv, n = o.project_map_points(cam, pose_mm, twc, f["mp_pos"], f["mp_normal"], f["mp_max_dist"], f["mp_min_dist"], cand.astype(np.uint8))
-    m, nm = o.search_by_projection(cam.width, cam.height, f["feat_uv"], f["feat_ur"], f["feat_oct"], f["feat_desc"], taken.astype(np.uint8), uvr, lvl, vc,
-                                   iv, f["mp_desc"], th=TH_LOCAL, nn_ratio=0.8)
-    return m, nm, iv
+def pack(torch, frames):
+    """list of frame dicts -> dict of batched CUDA tensors (the CSR feature vectors padded to the batch's maxima)"""
+    a = {k: torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in frames]).astype(api.CHAIN_DTYPES[k]))).cuda() for k in api.CHAIN_DTYPES}
+    if all("last_observed" in f for f in frames):
+        a["last_observed"] = torch.from_numpy(np.stack([f["last_observed"] for f in frames]).astype(np.uint8)).cuda()
+    if all(G.has_fallback(f) for f in frames):
+        B = len(frames)
+        for k in ("kf_angle", "kf_desc", "kf_has_mp", "kf_pt", "kf_to_local"):
+            a[k] = torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in frames]).astype(api.CHAIN_OPT_DTYPES[k]))).cuda()
+        for side, n_feat in (("kf", len(frames[0]["kf_angle"])), ("feat", len(frames[0]["feat_oct"]))):
+            NN = max(len(f[side + "_node_id"]) for f in frames)
+            nn, nid, nptr, nidx = np.zeros(B, np.int32), np.zeros((B, NN), np.int32), np.zeros((B, NN + 1), np.int32), np.zeros((B, n_feat), np.int32)
+            for b, f in enumerate(frames):
+                n = len(f[side + "_node_id"])
+                nn[b] = n
+                nid[b, :n] = f[side + "_node_id"]
+                nptr[b, :n + 1] = f[side + "_node_ptr"]
+                nptr[b, n + 1:] = f[side + "_node_ptr"][-1]
+                nidx[b, :len(f[side + "_node_idx"])] = f[side + "_node_idx"]
+            for k, v in (("nnode", nn), ("node_id", nid), ("node_ptr", nptr), ("node_idx", nidx)):
+                a[side + "_" + k] = torch.from_numpy(v).cuda()
+    return a
 
 
 def run_chain(torch, ctx, frames):
     cam, prm = api.Camera(), api.Params()
-    a = {k: torch.from_numpy(np.ascontiguousarray(np.stack([f[k] for f in frames]).astype(api.CHAIN_DTYPES[k]))).cuda() for k in api.CHAIN_DTYPES}
-    out = api.track_frame_chain(ctx, cam, prm, a, th_mm=TH_MM, th_local=TH_LOCAL, nn_ratio=0.8, mono=False)
+    out = api.track_frame_chain(ctx, cam, prm, pack(torch, frames), th_mm=TH_MM, th_local=TH_LOCAL, nn_ratio=0.8, mono=False)
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in out.items()}
 
@@ -66,33 +51,16 @@ def test_track_frame_chain_matches_oracle_sequence(gpu, oracle, NF, NL, NP):
     out = run_chain(torch, ctx, frames)
     n_local_total = 0
     for b, f in enumerate(frames):
-        # stage 1: bit-exact matches
-        m1, n1 = oracle_stage1(oracle, f)
-        assert out["counts"][b, 0] == n1
-        # stage 2 on those matches: pose 1e-6, the same outliers
-        Xw, obs, oc = pose_inputs(f, m1)
-        pose2, outl2, ninl2 = oracle.optimize_current_pose(cam, f["pose_cw"], Xw, obs, oc)
-        assert np.abs(out["pose_mm"][b] - pose2).max() < 1e-6
-        assert out["counts"][b, 1] == ninl2
-        kept = np.where(outl2 != 0, -1, m1)
-        assert np.array_equal(out["match_last"][b], kept)
-        # stage 3 from the DEVICE's stage-2 pose: bit-exact matches and in-view flags
-        m3, n3, iv = oracle_stage3(oracle, cam, f, out["pose_mm"][b], m1, kept)
-        assert out["counts"][b, 2] == n3 and np.array_equal(out["match_local"][b], m3)
-        assert np.array_equal(out["inview"][b], iv)
-        n_local_total += n3
-        # stage 4 from the device's associations and stage-2 pose: pose 1e-6, the same outliers
-        Xw, obs, oc = pose_inputs(f, kept, m3)
-        pose4, outl4, ninl4 = oracle.optimize_current_pose(cam, out["pose_mm"][b], Xw, obs, oc)
-        assert np.abs(out["pose"][b] - pose4).max() < 1e-6
-        assert out["counts"][b, 3] == ninl4
-        assert np.array_equal(out["outlier"][b][oc >= 0], outl4[oc >= 0])
+        c = G.check_chain(oracle, cam, f, out, b)
+        r = c["front"]
+        assert r["mode"] == 0 and c["replaced"] == 0
+        n_local_total += c["n3"]
         # the free-running oracle chain (its own stage-2 pose): poses within 1e-6, matches all but identical
-        m3f, n3f, _ = oracle_stage3(oracle, cam, f, pose2, m1, kept)
-        assert (m3f != m3).mean() < 0.01
-        Xwf, obsf, ocf = pose_inputs(f, kept, m3f)
-        pose4f, _, _ = oracle.optimize_current_pose(cam, pose2, Xwf, obsf, ocf)
-        if np.array_equal(m3f, m3):
+        m3f, n3f, _ = G.oracle_stage3(oracle, cam, f, r["pose"], r["match_last"], r["match_kf"], r["drop_src"], r["drop_kf"])
+        assert (m3f != c["m3"]).mean() < 0.01
+        Xwf, obsf, ocf = pose_inputs(f, r["match_last"], m3f)
+        pose4f, _, _ = oracle.optimize_current_pose(cam, r["pose"], Xwf, obsf, ocf)
+        if np.array_equal(m3f, c["m3"]):
             assert np.abs(out["pose"][b] - pose4f).max() < 1e-6
         # and the chain tracks: the final pose is closer to the generating pose than the prediction was
         assert np.abs(out["pose"][b] - f["pose_true"]).max() < np.abs(f["pose_cw"] - f["pose_true"]).max()
@@ -100,7 +68,7 @@ def test_track_frame_chain_matches_oracle_sequence(gpu, oracle, NF, NL, NP):
 
 
 def test_track_frame_chain_wide_retry(gpu, oracle):
-    """a prediction so far off that th = 7 finds fewer than 20 matches: the frame is searched again with th = 14 (tracking.cpp:335-342),
+    """a prediction so far off that th = 7 finds fewer than 20 matches: the frame is searched again with th = 14 (tracking.cpp:340-346),
     the frames beside it are not"""
     torch, ctx = gpu
     cam = api.Camera()
@@ -113,13 +81,100 @@ def test_track_frame_chain_wide_retry(gpu, oracle):
     out = run_chain(torch, ctx, frames)
     retried = 0
     for b, f in enumerate(frames):
-        k = ("pose_cw", "pose_lw", "feat_uv", "feat_ur", "feat_oct", "feat_angle", "feat_desc", "feat_taken", "last_pt", "last_valid", "last_oct",
-             "last_angle", "last_desc")
-        m7, n7 = oracle.search_by_projection_frame(CamF, *[f[x] for x in k], th=TH_MM, mono=False, check_orientation=True)
+        m7, n7 = oracle.search_by_projection_frame(CamF, *[f[x] for x in S1_KEYS], th=TH_MM, mono=False, check_orientation=True)
         m1, n1 = oracle_stage1(oracle, f)
         retried += int(n7 < 20)
         assert out["counts"][b, 0] == n1
         Xw, obs, oc = pose_inputs(f, m1)
         pose2, outl2, _ = oracle.optimize_current_pose(cam, f["pose_cw"], Xw, obs, oc)
-        assert np.array_equal(out["match_last"][b], np.where(outl2 != 0, -1, m1))
+        kept = np.where(outl2 != 0, -1, m1)
+        assert np.array_equal(np.where(out["match_local"][b] >= 0, -1, kept), out["match_last"][b])
     assert retried == 1
+
+
+def test_track_frame_chain_temporal_points_stay_matchable(gpu, oracle):
+    """a feature whose last-frame map point is a TEMPORAL point (createTemporalPoints, tracking.cpp:44-46: no observation) is
+    not taken in searchLocalPoints (orb_matcher.cpp:74-76) and the local map point found for it replaces the temporal one (:104): it is
+    the local point's position that trackLocalMap optimises on, and the feature's last-frame association ends as -1."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    frames = [synth.synth_chain_frame(900, 800, 1800, 5300 + b, cam, temporal_frac=tf) for b, tf in enumerate((0.3, 0.0, 0.6, 1.0))]
+    out = run_chain(torch, ctx, frames)
+    replaced = [G.check_chain(oracle, cam, f, out, b)["replaced"] for b, f in enumerate(frames)]
+    assert replaced[0] > 5 and replaced[1] == 0 and replaced[2] > replaced[0] and replaced[3] > replaced[2], replaced
+    assert out["counts2"][3, 0] == 0  # every kept match of frame 3 is a temporal point: trackWithMotionModel returns 0 (no fallback buffers: mode 0)
+    assert (out["counts2"][:, 3] == 0).all()
+
+
+def test_track_frame_chain_key_frame_fallback(gpu, oracle):
+    """Tracking::trackKeyFrame (tracking.cpp:297-331) as the chain's stage 2b, chosen per frame on the device: a prediction 10 degrees
+    off (no match in any window), a frame whose matches are all temporal points (20+ matches, return value 0: the outliers of BOTH
+    optimisations have been seen), a frame that tracks normally beside them (its key-frame buffers are never touched), and a
+    key-frame too poor to track from (mode 2)."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    NF, NL, NP, NK = 800, 700, 1500, 600
+    frames = [synth.synth_chain_frame(NF, NL, NP, 5500, cam, NK=NK, pred_rot_deg=10.0),
+              synth.synth_chain_frame(NF, NL, NP, 5501, cam, NK=NK),
+              synth.synth_chain_frame(NF, NL, NP, 5502, cam, NK=NK, temporal_frac=1.0),
+              synth.synth_chain_frame(NF, NL, NP, 5503, cam, NK=NK, pred_rot_deg=10.0)]
+    frames[3]["kf_has_mp"][25:] = 0  # a key-frame with 25 map points: fewer than 10 survive
+    out = run_chain(torch, ctx, frames)
+    res = [G.check_chain(oracle, cam, f, out, b) for b, f in enumerate(frames)]
+    assert [r["front"]["mode"] for r in res] == [1, 0, 1, 2]
+    assert (res[2]["front"]["drop_src"] >= 0).sum() > 0 and (res[2]["front"]["drop_kf"] >= 0).sum() > 0
+    for b in (0, 2):  # tracked through the key-frame: the last frame's pose was the start, the result is near the truth
+        assert (out["match_last"][b] == -1).all() and (out["match_kf"][b] >= 0).sum() >= 10
+        assert np.abs(out["pose"][b] - frames[b]["pose_true"]).max() < 5e-3
+    assert (out["match_kf"][1] == -1).all() and (out["drop_kf"][1] == -1).all()
+
+
+def test_track_frame_chain_in_two_halves(gpu, oracle):
+    """ADVICE r5: the reference rebuilds the local map between trackWithMotionModel and searchLocalPoints (Tracking::updateLocalMap,
+    tracking.cpp:119-207).  front -> (host: new local map) -> back: with the SAME local map the two halves give the bits of the one
+    call; with a local map made after the front half (here: re-ordered and thinned, the index maps re-made) the back half is exact for
+    THAT list."""
+    torch, ctx = gpu
+    cam, prm = api.Camera(), api.Params()
+    frames = [synth.synth_chain_frame(700, 600, 1400, 5700 + b, cam, NK=500, temporal_frac=0.2, pred_rot_deg=(10.0 if b == 1 else None)) for b in range(3)]
+    one = run_chain(torch, ctx, frames)
+    a = pack(torch, frames)
+    front = api.track_frame_chain_front(ctx, cam, prm, a, th_mm=TH_MM)
+    torch.cuda.synchronize()
+    fr = {k: v.cpu().numpy().copy() for k, v in front.items()}
+    for b, f in enumerate(frames):
+        r = G.oracle_front(oracle, cam, f)
+        assert np.array_equal(fr["match_last"][b], r["match_last"]) and np.array_equal(fr["match_kf"][b], r["match_kf"])
+        assert np.array_equal(fr["drop_src"][b], r["drop_src"]) and fr["counts2"][b, 3] == r["mode"]
+        assert np.abs(fr["pose"][b] - r["pose"]).max() < 1e-6
+    both = api.track_frame_chain_back(ctx, cam, prm, a, front, th_local=TH_LOCAL, nn_ratio=0.8)
+    torch.cuda.synchronize()
+    for k in one:
+        assert np.array_equal(both[k].cpu().numpy(), one[k]), k
+    # a different local map for the back half: permuted, every seventh point gone
+    frames2 = []
+    for b, f in enumerate(frames):
+        NP = len(f["mp_cand"])
+        perm = np.random.default_rng(9 + b).permutation(NP)
+        keep = perm[perm % 7 != 3]
+        newidx = -np.ones(NP, np.int32)
+        newidx[keep] = np.arange(len(keep), dtype=np.int32)
+        g = dict(f)
+        pad = NP - len(keep)
+        for k in ("mp_pos", "mp_normal", "mp_max_dist", "mp_min_dist", "mp_cand", "mp_desc"):
+            g[k] = np.concatenate([f[k][keep], np.zeros((pad,) + f[k].shape[1:], f[k].dtype)])  # (padding slots: not candidates)
+        for k in ("last_to_local", "kf_to_local"):
+            g[k] = np.where(f[k] >= 0, newidx[np.maximum(f[k], 0)], -1).astype(np.int32)
+        frames2.append(g)
+    a2 = pack(torch, frames2)
+    front2 = {k: torch.from_numpy(v).cuda() for k, v in fr.items()}
+    out2 = api.track_frame_chain_back(ctx, cam, prm, a2, front2, th_local=TH_LOCAL, nn_ratio=0.8)
+    torch.cuda.synchronize()
+    o2 = {k: v.cpu().numpy() for k, v in out2.items()}
+    for b, g in enumerate(frames2):
+        m3, n3, iv = G.oracle_stage3(oracle, cam, g, fr["pose"][b], fr["match_last"][b], fr["match_kf"][b], fr["drop_src"][b], fr["drop_kf"][b])
+        assert o2["counts"][b, 2] == n3 and np.array_equal(o2["match_local"][b], m3) and np.array_equal(o2["inview"][b], iv)
+        Xw, obs, oc = pose_inputs(g, fr["match_last"][b], m3, fr["match_kf"][b])
+        pose4, outl4, ninl4 = oracle.optimize_current_pose(cam, fr["pose"][b], Xw, obs, oc)
+        assert np.abs(o2["pose"][b] - pose4).max() < 1e-6 and o2["counts"][b, 3] == ninl4
+        assert np.array_equal(o2["outlier"][b][oc >= 0], outl4[oc >= 0])

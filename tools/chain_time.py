@@ -105,6 +105,20 @@ with torch.cuda.stream(ctx.stream):
     twc = torch.zeros((1, 3), dtype=torch.float64, device="cuda")
     t_s3 = median_ms(lambda: api.search_local_points(ctx, cam, one["feat_uv"], one["feat_ur"], one["feat_oct"], one["feat_desc"], one["feat_taken"], out["pose_mm"], twc,
                                                      one["mp_pos"], one["mp_normal"], one["mp_max_dist"], one["mp_min_dist"], one["mp_cand"], one["mp_desc"], th=3.0))
+# round 6: the same frame with the reference key-frame's buffers attached (the fallback's launches return at once: what the option
+# costs a frame that tracks), and a frame that NEEDS the fallback (prediction 10 degrees off: trackKeyFrame, tracking.cpp:297-331)
+from tests.test_gpu_chain import pack as pack_kf  # noqa: E402
+kf_ok = pack_kf(torch, [synth.synth_chain_frame(NF, NL, NP, 7000, cam, NK=NL)])
+kf_fb = pack_kf(torch, [synth.synth_chain_frame(NF, NL, NP, 7000, cam, NK=NL, pred_rot_deg=10.0)])
+with torch.cuda.stream(ctx.stream):
+    t_kf_ok = median_ms(lambda: api.track_frame_chain(ctx, cam, prm, kf_ok))
+    t_kf_fb = median_ms(lambda: api.track_frame_chain(ctx, cam, prm, kf_fb))
+    o_fb = api.track_frame_chain(ctx, cam, prm, kf_fb)
+    torch.cuda.synchronize()
+    t_front = median_ms(lambda: api.track_frame_chain_front(ctx, cam, prm, kf_ok))
+    fr_out = api.track_frame_chain_front(ctx, cam, prm, kf_ok)
+    torch.cuda.synchronize()
+    t_back = median_ms(lambda: api.track_frame_chain_back(ctx, cam, prm, kf_ok, {k: v.clone() for k, v in fr_out.items()}))
 B = 2048
 big = pack([frames[b % 64] for b in range(B)])
 with torch.cuda.stream(ctx.stream):
@@ -114,4 +128,7 @@ print(json.dumps({"config": "one tracked frame (trackWithMotionModel -> searchLo
                   "four_calls_with_sync_between_ms": t_four, "four_calls_enqueued_without_sync_ms": t_four_nosync,
                   "single_call_ms": {"searchByProjection(frame)": t_s1, "optimizeCurrentPose": t_s2, "searchLocalPoints": t_s3, "sum_of_four": t_s1 + 2 * t_s2 + t_s3},
                   "chain_batch_frames_per_s": B / (t_batch * 1e-3), "batch": B,
+                  "with_key_frame_buffers_frame_that_tracks_ms": t_kf_ok, "frame_through_trackKeyFrame_fallback_ms": t_kf_fb,
+                  "fallback_frame_mode_and_counts2": [int(v) for v in o_fb["counts2"][0].cpu().numpy()],
+                  "two_halves_ms": {"front": t_front, "back": t_back},
                   "note": "wall clock incl. the Python wrapper, median of 25; the four-call form does its glue as torch ops on the device"}))
