@@ -191,6 +191,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 }  // namespace
 
 // (namespace, LDS capacity in points, waves at most, SPREAD, fp32-cached step, gauge anchor of the pose)
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd496  // DENSE, exact step: 4 frames per CU
 #define GL_BAF_MCAP 496
 #define GL_BAF_NW 2
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd1000  // 2 frames per CU
 #define GL_BAF_MCAP 1000
 #define GL_BAF_NW 4
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
 #define GL_BAF_NS bafd2000  // 1 frame per CU
 #if GL_BAF_W3
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_FIXED
 
 // fp32-cached point step (option ba_step32): the SPREAD kernel and the largest DENSE class
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafs32  // 
 #define GL_BAF_MCAP 256
 #define GL_BAF_NW 8
@@ -278,7 +283,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd2000s32  // 
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
@@ -294,8 +301,10 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
 // anchored instances (gl_track_frames_anchored: prior edge on the frame's pose, or fixed pose), exact step
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd2000x  // 2 frames per CU: two groups of the canonical order per wave, the hand-over slots in global memory (GL_BAF_GPW)
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
@@ -315,7 +324,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd496p  // 
 #define GL_BAF_MCAP 496
 #define GL_BAF_NW 2
@@ -331,7 +342,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd1000p  // (992 points: two frames per CU with the 512 bytes of the prior edge's records)
 #define GL_BAF_MCAP 992
 #define GL_BAF_NW 4
@@ -347,7 +360,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd2000p  // 
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
@@ -363,7 +378,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafsp  // 
 #define GL_BAF_MCAP 256
 #define GL_BAF_NW 8
@@ -379,8 +396,10 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
 // anchored instances WITH fixed observer key-frames (F = 1 .. 4; the prior edge / fixed pose stays a per-frame flag), batch shape
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd496f
 #define GL_BAF_MCAP 496
 #define GL_BAF_NW 2
@@ -396,7 +415,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd1000f  // (984 points: two frames per CU with the prior edge's records and the key-frames' poses)
 #define GL_BAF_MCAP 984
 #define GL_BAF_NW 4
@@ -412,7 +433,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK
 #define GL_BAF_NS bafd2000f
 #define GL_BAF_MCAP 2000
 #define GL_BAF_NW 8
@@ -428,7 +451,9 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
 #undef GL_BAF_STEP32
 #undef GL_BAF_PRIOR
 #undef GL_BAF_FIXED
+#endif
 
+#ifndef GL_BAF_QUICK  // (tools/baf_quick.sh: the 2 000-point batch instance and the latency shape alone, for register / ISA checks)
 namespace {
 // HW_REG_XCC_ID (hwreg 20, 4 bits): the XCD the wave runs on
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15; }
@@ -665,3 +690,4 @@ int launch_ba1_fast(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params*
 }
 
 }  // namespace gl
+#endif  // GL_BAF_QUICK
