@@ -1321,6 +1321,65 @@ GL_DEV bool ldlt6_packed(double* a, const double* b, double lambda, double* x) {
   return ok;
 }
 
+#ifndef GL_BAF_SOLVE_BLOCKED
+#define GL_BAF_SOLVE_BLOCKED 1  // (0: the sequential LDL^T of rounds 1 - 5; profiles/r6_solve_blocked.txt)
+#endif
+// The same 6 x 6 system by BLOCKS (round 6): H + lambda I = [[A, B], [B^T, C]] with the rotation block A and the translation block C,
+//     A = L_a D_a L_a^T,   Y = A^-1 [B | b_r],   S = C - B^T Y_B,   s = b_t - B^T y,   S = L_s D_s L_s^T,   x_t = S^-1 s,   x_r = y - Y_B x_t.
+// The pivots are those of the unpivoted LDL^T of the whole matrix (D_a, then D_s): the same failure test.  What changes is the SHAPE of
+// the work: the serial section of a trial - one wave, every other wave of the frame waiting - was a chain of ~190 dependent fp64
+// instructions (six reciprocals one after the other, each behind the eliminations of the column before); here four right-hand sides
+// go through the factors of A side by side and the two 3 x 3 factorisations have their first two reciprocals independent
+// (ldl3_factor_fast): about 50 instructions deep for the same count.  Other rounding, same system: held to the oracle like everything else.
+GL_DEV bool ldl3_factor_chk(const double* D, double* f) {  // ldl3_factor_fast + the pivot test of SimplicialLDLT (zero / non-finite pivot)
+  const double i0 = rcp_nr(D[0]);
+  const double m2 = fma(D[0], D[3], -(D[1] * D[1]));  // d0 d1
+  const double e2 = fma(D[0], D[4], -(D[1] * D[2]));  // d0 (D12 - l10 D02)
+  const double im = rcp_nr(m2);
+  const double l1 = D[1] * i0, l2 = D[2] * i0;
+  const double i1 = D[0] * im, l3 = e2 * im;
+  const double e = e2 * i0;
+  const double d2 = fma(-l3, e, fma(-l2, D[2], D[5]));
+  f[0] = l1;
+  f[1] = l2;
+  f[2] = l3;
+  f[3] = i0;
+  f[4] = i1;
+  f[5] = rcp_nr(d2);
+  const double d1 = m2 * i0;
+  return D[0] != 0.0 && isfinite(D[0]) && d1 != 0.0 && isfinite(d1) && d2 != 0.0 && isfinite(d2);
+}
+GL_DEV bool ldlt6_blocked(const double* a, const double* b, double lambda, double* x) {
+  const double A[6] = {a[GL_U(0, 0)] + lambda, a[GL_U(0, 1)], a[GL_U(0, 2)], a[GL_U(1, 1)] + lambda, a[GL_U(1, 2)], a[GL_U(2, 2)] + lambda};
+  double fa[6];
+  const bool ok_a = ldl3_factor_chk(A, fa);
+  double Y[3][3], y[3];  // Y[j] = A^-1 (column j of B)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double col[3] = {a[GL_U(0, 3 + j)], a[GL_U(1, 3 + j)], a[GL_U(2, 3 + j)]};
+    ldl3_solve_fast(fa, col, Y[j]);
+  }
+  ldl3_solve_fast(fa, b, y);
+  double S[6], s[3];
+  {
+    const int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int i = ri[e], j = ci[e];
+      const double c = a[GL_U(3 + i, 3 + j)] + (i == j ? lambda : 0.0);
+      S[e] = fma(-a[GL_U(2, 3 + i)], Y[j][2], fma(-a[GL_U(1, 3 + i)], Y[j][1], fma(-a[GL_U(0, 3 + i)], Y[j][0], c)));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = fma(-a[GL_U(2, 3 + i)], y[2], fma(-a[GL_U(1, 3 + i)], y[1], fma(-a[GL_U(0, 3 + i)], y[0], b[3 + i])));
+  }
+  double fs[6];
+  const bool ok_s = ldl3_factor_chk(S, fs);
+  ldl3_solve_fast(fs, s, x + 3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) x[k] = fma(-Y[2][k], x[5], fma(-Y[1][k], x[4], fma(-Y[0][k], x[3], y[k])));
+  return ok_a && ok_s;
+}
+
 // backup of the current point in the slot (pass B) / restore on a rejected trial.  The fp32 cache of
 // GL_BAF_STEP32 is read by its owner just before, but planes of OTHER points alias a double-indexed slot,
 // so that variant keeps the {lo, hi} words in the owner's own 32-bit entries.
@@ -1871,7 +1930,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
         for (int i = 0; i < 6; ++i) gsc[i] = acc[21 + i];
         gsc[6] = acc[28];
         if (qmax == 0) currentChi = acc[27];
-        if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
+        if (pose_active) ok = GL_BAF_SOLVE_BLOCKED ? ldlt6_blocked(acc, acc + 21, lambda, dxs) : ldlt6_packed(acc, acc + 21, lambda, dxs);
 #pragma unroll
         for (int i = 0; i < 6; ++i) dx[i] = dxs[i];
         ok2 = ok;
@@ -1889,7 +1948,7 @@ GL_DEV int optimize_fast(const Uni& U, const GmmDev& gm, const Lds& D, const Map
 #pragma unroll
           for (int i = 0; i < 28; ++i) acc[i] += rc[i];
         }
-        if (pose_active) ok = ldlt6_packed(acc, acc + 21, lambda, dxs);
+        if (pose_active) ok = GL_BAF_SOLVE_BLOCKED ? ldlt6_blocked(acc, acc + 21, lambda, dxs) : ldlt6_packed(acc, acc + 21, lambda, dxs);
         if (threadIdx.x == 0) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) bc[i] = dxs[i];
@@ -2404,7 +2463,9 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
 #endif
 #ifdef GL_BA_PROF
     if (f == 0) {  // debug build only: phase cycles instead of pose 0, per-wave markers instead of the points of frame 0
-      for (int i = 0; i < 7; ++i) pose_io[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections
+      // (a latency-shape launch stages its results: the follow-up kernel copies them over the caller's buffers)
+      double* const pr = staged ? st_pose : pose_io;
+      for (int i = 0; i < 7; ++i) pr[i] = (double)g_prof[i == 5 ? 7 : i];  // slot 5 reports the rejections
     }
     if (f != 0 && f != 1024 && !kSpread) {  // every other frame: when and where its workgroup ran, in place of its pose (tools/prof_ba.py: CU timelines)
       pose_io[(size_t)f * 7] = (double)prof_wg_t0;
@@ -2416,7 +2477,7 @@ GL_DEV void ba1_fast_frame(double* smem, const unsigned fblock, kargs_t* ka) {
       for (int i = 0; i < 7; ++i) pose_io[(size_t)f * 7 + i] = (double)g_prof_k[i];
       for (int i = 7; i < 13; ++i) pts_io[(size_t)f * L * 3 + (i - 7)] = (double)g_prof_k[i];
     }
-    if (f == 0) {
+    if (f == 0 && !staged) {
       for (int i = 0; i < 64 * 8 * 4 && i < L * 3; ++i) pts_io[i] = (double)g_prof_w[i];
       for (int i = 0; i < 16 * 8 * 2 * 5 && 2048 + i < L * 3; ++i) pts_io[2048 + i] = (double)g_prof_s[i];
       for (int i = 0; i < 10 * 8 * 2 * 4 * 3 && 2048 + 1280 + i < L * 3; ++i) pts_io[2048 + 1280 + i] = (double)g_prof_q[i];

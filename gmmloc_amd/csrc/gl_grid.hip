@@ -48,7 +48,19 @@ struct GridDev {
   const int32_t* idx;
   const int32_t* glob;
   const int4* cell4;
+  const unsigned long long* cell8;  // round 6: the packed cell in 8 bytes (K < 2^20), or null
 };
+
+// A packed cell: the count and, for up to three candidates, the component indices themselves (ascending, like the CSR list); a longer
+// list keeps its place in the CSR array.  16-byte form {n, a, b, c} / {n, e0, -, -}; 8-byte form (round 6: half the table - 87 MB on the
+// bench map, inside the 256 MB of Infinity Cache - for one 128-byte line per point either way):
+//     bit 63 = 0: n in bits 0..1, the three indices in 20 bits each from bit 2;    bit 63 = 1: e0 in bits 0..31, n in bits 32..61
+GL_DEV int4 cell_unpack8(unsigned long long w) {
+  if (w >> 63) return make_int4((int)((w >> 32) & 0x3fffffffull), (int)(w & 0xffffffffull), 0, 0);
+  return make_int4((int)(w & 3ull), (int)((w >> 2) & 0xfffffull), (int)((w >> 22) & 0xfffffull), (int)((w >> 42) & 0xfffffull));
+}
+GL_DEV bool grid_packed(const GridDev& G) { return G.cell4 != nullptr || G.cell8 != nullptr; }
+GL_DEV int4 cell_load(const GridDev& G, int c) { return G.cell8 ? cell_unpack8(G.cell8[c]) : G.cell4[c]; }
 
 // lexicographic (chi2, index) minimum: the all-pairs sweep keeps the FIRST index of the minimum
 GL_DEV void upd_min(double d, int k, double& best, int& bi) {
@@ -81,8 +93,8 @@ __global__ __launch_bounds__(256) void k_assoc_cells(const double* __restrict__ 
                       fz < (double)G.dim[2];  // false for NaN
   if (inside) {
     const int c = ((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx;
-    if (G.cell4) {  // packed cell: the list of up to three candidates arrives with the count (ascending, like the CSR list)
-      const int4 q = G.cell4[c];
+    if (grid_packed(G)) {  // packed cell: the list of up to three candidates arrives with the count (ascending, like the CSR list)
+      const int4 q = cell_load(G, c);
       if (q.x <= 3) {
         if (q.x > 0) upd_min(chi2_rec(rec12 + (size_t)q.y * 12, x, y, z), q.y, best, bi);
         if (q.x > 1) upd_min(chi2_rec(rec12 + (size_t)q.z * 12, x, y, z), q.z, best, bi);
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) void k_assoc_cells_coop(const double* __restri
   const bool inside = live && fx >= 0.0 && fx < (double)G.dim[0] && fy >= 0.0 && fy < (double)G.dim[1] && fz >= 0.0 &&
                       fz < (double)G.dim[2];  // false for NaN
   int4 q = make_int4(0, 0, 0, 0);
-  if (inside) q = G.cell4[((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx];
+  if (inside) q = cell_load(G, ((int)fz * G.dim[1] + (int)fy) * G.dim[0] + (int)fx);
   // EVERY list goes through the cooperative gather (round 5, LONG = true): a cell with more than three candidates keeps its list in the
   // CSR array, and until round 5 such a lane walked it alone behind the gather - one dependent index load and six 16-byte record loads
   // per candidate while the rest of the wave waited (a third of the bench points; the time of the kernel followed THEM:
@@ -409,6 +421,21 @@ __global__ void k_index_pack(const int32_t* __restrict__ ptr, const int32_t* __r
   }
   cell4[c] = q;
 }
+__global__ void k_index_pack8(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, size_t ncell, unsigned long long* __restrict__ cell8) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int e0 = ptr[c], n = ptr[c + 1] - e0;
+  unsigned long long w;
+  if (n > 3) {
+    w = (1ull << 63) | ((unsigned long long)(unsigned)n << 32) | (unsigned long long)(unsigned)e0;
+  } else {
+    w = (unsigned long long)n;
+    if (n > 0) w |= (unsigned long long)(unsigned)idx[e0] << 2;
+    if (n > 1) w |= (unsigned long long)(unsigned)idx[e0 + 1] << 22;
+    if (n > 2) w |= (unsigned long long)(unsigned)idx[e0 + 2] << 42;
+  }
+  cell8[c] = w;
+}
 // sum over the registered components of the list length at their own mean (does the index prune?)
 __global__ void k_index_mean_lists(const CompReg* __restrict__ regs, int nreg, GridGeom gg, const int32_t* __restrict__ ptr,
                                    unsigned long long* __restrict__ sum) {
@@ -480,6 +507,7 @@ void free_cell_index(Gmm* g) {
   if (g->grid.idx) (void)hipFree(g->grid.idx);
   if (g->grid.glob) (void)hipFree(g->grid.glob);
   if (g->grid.cell4) (void)hipFree(g->grid.cell4);
+  if (g->grid.cell8) (void)hipFree(g->grid.cell8);
   if (g->grid.rec16) (void)hipFree(g->grid.rec16);
   g->grid = CellIndex();
 }
@@ -685,22 +713,29 @@ int build_cell_index(Ctx* c, Gmm* g) {
   G.nnz = (size_t)nnz;
   G.ncell = ncell;
   G.cell4 = nullptr;
-  // the packed cell table (16 bytes per cell; the bench map: 11 M cells = 176 MB) within the option's memory budget (assoc_pack_mb,
-  // default 512, 0 = never); gl_gmm_index_info reports its size
-  if ((double)ncell * 16.0 <= c->opt.assoc_pack_mb * 1048576.0) {
-    if (hipMalloc(&G.cell4, ncell * 16) == hipSuccess) {
-      k_index_pack<<<(unsigned)((ncell + 255) / 256), 256, 0, c->stream>>>(d_ptr, d_idx, ncell, (int4*)G.cell4);
+  G.cell8 = nullptr;
+  // the packed cell table within the option's memory budget (assoc_pack_mb, default 512, 0 = never): 8 bytes per cell where the
+  // component indices fit 20 bits and the option assoc_cell8 says so (default; the bench map: 11 M cells = 87 MB), else 16 bytes per
+  // cell (174 MB); gl_gmm_index_bytes reports its size
+  const bool want8 = c->opt.assoc_cell8 != 0 && g->K < (1 << 20) && nnz < (1ll << 31);
+  const double cell_bytes = want8 ? 8.0 : 16.0;
+  if ((double)ncell * cell_bytes <= c->opt.assoc_pack_mb * 1048576.0) {
+    void* tab = nullptr;
+    if (hipMalloc(&tab, ncell * (size_t)cell_bytes) == hipSuccess) {
+      if (want8) k_index_pack8<<<(unsigned)((ncell + 255) / 256), 256, 0, c->stream>>>(d_ptr, d_idx, ncell, (unsigned long long*)tab);
+      else k_index_pack<<<(unsigned)((ncell + 255) / 256), 256, 0, c->stream>>>(d_ptr, d_idx, ncell, (int4*)tab);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
-        (void)hipFree(G.cell4);
-        G.cell4 = nullptr;
+        (void)hipFree(tab);
+        tab = nullptr;
       }
     } else {
       (void)hipGetLastError();
-      G.cell4 = nullptr;
+      tab = nullptr;
     }
+    (want8 ? G.cell8 : G.cell4) = tab;
   }
   G.rec16 = nullptr;
-  if (G.cell4) {  // one record per 128-byte line for the cooperative gather (K x 128 B: 512 KB for 4 096 Gaussians)
+  if (G.cell4 || G.cell8) {  // one record per 128-byte line for the cooperative gather (K x 128 B: 512 KB for 4 096 Gaussians)
     if (hipMalloc(&G.rec16, (size_t)g->K * 128) == hipSuccess) {
       k_rec_pad<<<(g->K * 16 + 255) / 256, 256, 0, c->stream>>>(g->rec12, g->K, G.rec16);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -735,6 +770,7 @@ static GridDev grid_dev(const CellIndex& I) {
   G.idx = I.idx;
   G.glob = I.glob;
   G.cell4 = (const int4*)I.cell4;
+  G.cell8 = (const unsigned long long*)I.cell8;
   return G;
 }
 
@@ -748,7 +784,7 @@ int launch_assoc_index(Ctx* c, const Gmm* g, const double* pts, int N, int32_t* 
   int32_t* list = count + 16;
   TimerScope ts(c, GL_TIMER_ASSOC);
   if (resolve_all) GL_HIP(hipMemsetAsync(count, 0, 4, c->stream));
-  if (G.cell4 && c->opt.assoc_coop != 0 && N >= 4096) {
+  if ((G.cell4 || G.cell8) && c->opt.assoc_coop != 0 && N >= 4096) {
     const bool pad = g->grid.rec16 && c->opt.assoc_rec_pad != 0;
     const double* recg = pad ? g->grid.rec16 : g->rec12;
     int32_t* rl = resolve_all ? list : nullptr;
@@ -780,7 +816,7 @@ int gl_gmm_index_bytes(const gl_gmm_t* gmm, double bytes[3]) {
   const gl::CellIndex& I = gl::G(gmm)->grid;
   bytes[0] = I.enabled ? (double)(I.ncell + 1) * 4.0 : 0.0;  // cell pointers
   bytes[1] = I.enabled ? (double)I.nnz * 4.0 + (double)I.nglob * 4.0 : 0.0;  // candidate lists
-  bytes[2] = I.cell4 ? (double)I.ncell * 16.0 : 0.0;  // packed cell table (option assoc_pack_mb)
+  bytes[2] = I.cell8 ? (double)I.ncell * 8.0 : I.cell4 ? (double)I.ncell * 16.0 : 0.0;  // packed cell table (options assoc_pack_mb, assoc_cell8)
   return GL_OK;
 }
 

@@ -64,7 +64,8 @@ struct CellIndex {
   int32_t* glob = nullptr;  // nglob, ascending
   // packed cells (round 3): {count, then the list itself when count <= 3, else the offset into idx}: ONE random 16-byte
   // read per point where ptr[c], ptr[c + 1] and idx[...] are two (the kernel is bound by the fabric's random sectors)
-  void* cell4 = nullptr;    // ncell x int4, or null (table above the memory budget)
+  void* cell4 = nullptr;    // ncell x int4, or null (table above the memory budget, or the 8-byte form in use)
+  void* cell8 = nullptr;    // ncell x 8 bytes (round 6: option assoc_cell8, K < 2^20), or null
   // the records again, one per 128-byte line (K x 16 doubles, the last four unused): a 96-byte record of rec12 lies across
   // two lines three times out of four, and the cooperative gather is bound by line requests (round 5; null without cell4)
   double* rec16 = nullptr;
@@ -117,6 +118,7 @@ struct Options {
   double assoc_coop_long = 1;   // 1: lists of more than three candidates go through the cooperative gather too, 0: the lane walks them alone (A/B; same results)
   double assoc_rec_pad = 1;     // 1: k_assoc_cells_coop gathers from the one-line-per-record copy (CellIndex::rec16), 0: from rec12 (A/B; same results)
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
+  double assoc_cell8 = 1;       // the packed cell table in 8 bytes per cell where the component indices fit 20 bits (0: 16 bytes per cell as in rounds 3 - 5)
   double assoc_pack_mb = 512;   // memory budget (MB) of the packed cell table a GMM built with this context may add to its cell index (0: none)
   double assoc_cell = 0;        // > 0: cell size (m) of the index instead of the automatic one (tuning)
   double assoc_globcells = 0;   // > 0: components whose box covers more cells than this are evaluated for every point (tuning)

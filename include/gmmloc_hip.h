@@ -120,6 +120,7 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *     Same arithmetic everywhere, every mode held to the oracle; the shapes add their partial sums in different orders, so a
  *     window may take a different number of trials in each,
  *   assoc_pack_mb (512; memory budget in MB of the packed cell table of a GMM created with this context, 0 = none),
+ *   assoc_cell8 (1; that table in 8 bytes per cell where K < 2^20, 0 = 16 bytes per cell; same results),
  *   assoc_cell, assoc_globcells (> 0: cell size in metres / cell-count threshold of the index instead of the automatic ones),
  *   ba_fixed_pack (1: fixed observers of gl_track_frames_anchored always through the general kernel),
  *   pipe_lanes, pipe_judge, schur_kper (-1 automatic; A/B switches of the pipelined local BA in batches: streams a call is split over,

@@ -209,6 +209,37 @@ def test_cell_index_record_copy_option_same_bits(gpu, opt):
         assert np.array_equal(i1, i0) and np.array_equal(d1, d0), key
 
 
+def test_cell_index_8_byte_cells_same_bits(gpu, opt):
+    """assoc_cell8 (round 6): the packed cell table in 8 bytes per cell (count + three 20-bit component indices, or the place of a longer
+    list) against the 16-byte cells of rounds 3 - 5: half the table, the same indices and chi2 bits, both walks (cooperative gather and a
+    lane per record), short and long lists, and both equal the all-pairs sweep."""
+    torch, ctx = gpu
+    rng = np.random.default_rng(43)
+    cases = []
+    mean, cov = synth.synth_gmm(4096, 43)
+    lo, hi = mean.min(0), mean.max(0)
+    cases.append((mean, cov, np.concatenate([synth.synth_points(mean, cov, 60000, 43), rng.uniform(lo - 2, hi + 2, (8000, 3))])))
+    K = 600  # many overlapping components: cells with tens of candidates
+    m2 = rng.uniform(-0.5, 0.5, (K, 3))
+    c2 = np.tile((np.eye(3) * 0.04).reshape(1, 9), (K, 1)) * rng.uniform(0.5, 1.5, (K, 1))
+    cases.append((m2, c2, rng.uniform(-0.7, 0.7, (30000, 3))))
+    for mean, cov, pts in cases:
+        res, size = {}, {}
+        for c8 in (1, 0):
+            opt("assoc_cell8", c8)  # read when the GMM's index is built
+            g = api.GMM(ctx, mean, cov)
+            size[c8] = g.index_info()["bytes"]["packed_cells"]
+            for coop in (1, 0):
+                opt("assoc_coop", coop)
+                res[c8, coop] = _both(torch, g, pts)
+        (i1, d1), (ie, de) = res[1, 1]
+        assert np.array_equal(i1, ie) and np.array_equal(d1, de)
+        for key in ((1, 0), (0, 1), (0, 0)):
+            (i0, d0), _ = res[key]
+            assert np.array_equal(i1, i0) and np.array_equal(d1, d0), key
+        assert size[1] * 2 == size[0] and size[1] > 0
+
+
 def test_cell_index_long_lists_in_chunks(gpu):
     """Many overlapping components: cells with tens of candidates, more than one chunk of the wave's candidate table (384) per wave."""
     torch, ctx = gpu
