@@ -870,9 +870,17 @@ GL_DEV void prior_record_wave(const cdouble_k* mi, const Pose& P, double* rec, d
 
 // The terms of a point enter the sums through a sink: DENSE adds them to the thread's registers (level 1 of the
 // canonical order), SPREAD just keeps them (they go to the LDS transpose).  Each index is written once per point.
+#ifndef GL_BAF_FEWACC
+#define GL_BAF_FEWACC 0
+#endif
+// (GL_BAF_FEWACC: TIMING EXPERIMENT ONLY, results are garbage - the 27 Schur terms of a point are folded into four accumulators, so that
+// the passes keep their arithmetic but not the 29 live sums: what a kernel with 50 fewer registers would cost per pass, profiles/r6_w3_fewacc.txt)
 struct SinkAcc {
   double* a;
-  GL_DEV void put(int i, double v) const { a[i] = add_nc(a[i], v); }
+  GL_DEV void put(int i, double v) const {
+    if (GL_BAF_FEWACC && i < 27) a[i & 3] = add_nc(a[i & 3], v);
+    else a[i] = add_nc(a[i], v);
+  }
 };
 struct SinkSet {
   double* a;

@@ -1966,6 +1966,7 @@ struct PipeA {  // kernel arguments (by value)
   int ext_judge;
   int kper;           // chunks of a block per wave of the Schur pass (1; 2 in batches: the wave's set-up once for two chunks - the
                       // partial sums stay per chunk, so the bits do not depend on it)
+  int fuse_asm;       // round 6, calls of a few windows: kp_solve adds the chunks of the blocks itself (no kp_assemble in the cycle)
 };
 struct PipeCtl {
   int stage, init, pend, adv;
@@ -2699,13 +2700,8 @@ __global__ __launch_bounds__(T_BA, 2) void kp_schur(PipeA a) {
 // ---- P2b: the chunks of a block added in chunk order -> the assembled system (a thread per (block, sum); the solve kernel
 // read nblk x nchunk x 48 partials itself at first - 63 us of its 155 at 20 poses; letting the last wave of a block do it
 // behind device-scope fences made the Schur pass 3.5 x slower) ------------------------------------------------------------
-__global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
-  const long g = (long)blockIdx.x * T_BA + threadIdx.x;
-  const int per_prob = a.nblk * 48;
-  const int f = (int)(g / per_prob), r0 = (int)(g % per_prob), b = r0 / 48, sidx = r0 % 48;
-  if (f >= a.B) return;
-  const PipeCtl ctl = pipe_ctl(st_cur(a, f));
-  if ((ctl.stage >= 3) | ctl.adv) return;
+// one sum of one block of window f: its chunks added in chunk order, the total to its place in the assembled system
+GL_DEV void assemble_sum(const PipeA& a, const GenP& G, int f, int b, int sidx) {
   const int P = a.P, ld = 6 * P + GL_LD_PAD;
   int j1 = 0, rem = b;
   while (rem >= P - j1) {
@@ -2720,8 +2716,6 @@ __global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
   double v = 0.0;
 #pragma unroll
   for (int c = 0; c < 16; ++c) v += x[c];
-  GenP G;
-  genp_init(G, a, f, 1, 0);
   if (sidx < 36) {  // only the lower triangle of S is read: block (j2, j1) = block (j1, j2)^T
     const int r = sidx / 6, c = sidx % 6;
     G.S[j1 == j2 ? (size_t)(6 * j1 + r) * ld + 6 * j1 + c : (size_t)(6 * j2 + c) * ld + 6 * j1 + r] = v;
@@ -2729,6 +2723,17 @@ __global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
     if (sidx < 42) G.gv[6 * j1 + (sidx - 36)] = v;
     else G.bp[6 * j1 + (sidx - 42)] = v;
   }
+}
+__global__ __launch_bounds__(T_BA) void kp_assemble(PipeA a) {
+  const long g = (long)blockIdx.x * T_BA + threadIdx.x;
+  const int per_prob = a.nblk * 48;
+  const int f = (int)(g / per_prob), r0 = (int)(g % per_prob), b = r0 / 48, sidx = r0 % 48;
+  if (f >= a.B) return;
+  const PipeCtl ctl = pipe_ctl(st_cur(a, f));
+  if ((ctl.stage >= 3) | ctl.adv) return;
+  GenP G;
+  genp_init(G, a, f, 1, 0);
+  assemble_sum(a, G, f, b, sidx);
 }
 
 // ---- solve: (lambda init |) LDL^T of the assembled system, trial poses; at the end of a stage the gate / the next stage's
@@ -2755,6 +2760,10 @@ __global__ __launch_bounds__(T_SOLVE) void kp_solve(PipeA a) {
   if (ctl.adv) {  // the stage ended at the head of this cycle: gate, next stage (or the outputs)
     pipe_adv_open(a, G, st, f, s_cnt);
     return;
+  }
+  if (a.fuse_asm) {  // (a call of a few windows: the 5 us of a kernel of its own for 1 - 2 us of adds; the same sums in the same order)
+    for (int r0 = tid; r0 < a.nblk * 48; r0 += T_SOLVE) assemble_sum(a, G, f, r0 / 48, r0 % 48);
+    __syncthreads();
   }
 #ifdef GL_PIPE_PROF
   const long long s0 = clock64();
@@ -3121,6 +3130,9 @@ static int pipe_lane_setup(Ctx* c, PipeLane& ln, int stats_off, bool stats_ok, c
       }
   }
   if (!kper_ok(a.kper)) a.kper = 1;
+  // the chunks of the blocks added by the solve kernel itself when the call is a few windows (option pipe_fuse_asm: -1 by the size of
+  // the call, 0 never, 1 always): a single 8 + 4 window 66 -> 62 us per cycle; in batches the adds belong on the whole chip
+  a.fuse_asm = c->opt.pipe_fuse_asm >= 0 ? (c->opt.pipe_fuse_asm != 0 ? 1 : 0) : ((long)B * a.nblk * a.nchunk <= 600 ? 1 : 0);
   ln.schur_blocks = pipe_grid(B, a.nblk * a.nchunk / a.kper / NW_BA);  // (XCD-aware workgroup map: pipe_wg)
   ln.B = B;
   return GL_OK;
@@ -3136,7 +3148,7 @@ static void pipe_lane_cycle(PipeLane& ln, int cyc) {
   const int B = ln.B;
   kp_lin<<<pipe_grid(B, a.nba), T_BA, 0, ln.s>>>(a);
   kp_schur<<<ln.schur_blocks, T_BA, 0, ln.s>>>(a);
-  kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, ln.s>>>(a);
+  if (!a.fuse_asm) kp_assemble<<<(int)(((long)B * a.nblk * 48 + T_BA - 1) / T_BA), T_BA, 0, ln.s>>>(a);
   kp_solve<<<B, T_SOLVE, ln.s_bytes, ln.s>>>(a);
   kp_trial<<<pipe_grid(B, a.nba), T_BA, 0, ln.s>>>(a);
   if (a.ext_judge) kp_judge<<<B, 64, 0, ln.s>>>(a);

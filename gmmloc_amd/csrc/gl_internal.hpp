@@ -118,6 +118,7 @@ struct Options {
   double assoc_coop_long = 1;   // 1: lists of more than three candidates go through the cooperative gather too, 0: the lane walks them alone (A/B; same results)
   double assoc_rec_pad = 1;     // 1: k_assoc_cells_coop gathers from the one-line-per-record copy (CellIndex::rec16), 0: from rec12 (A/B; same results)
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
+  double pipe_fuse_asm = -1;    // pipelined local BA: the solve kernel assembles the system itself (-1: calls of a few windows, 0 never, 1 always; same bits)
   double assoc_cell8 = 1;       // the packed cell table in 8 bytes per cell where the component indices fit 20 bits (0: 16 bytes per cell as in rounds 3 - 5)
   double assoc_pack_mb = 512;   // memory budget (MB) of the packed cell table a GMM built with this context may add to its cell index (0: none)
   double assoc_cell = 0;        // > 0: cell size (m) of the index instead of the automatic one (tuning)

@@ -243,6 +243,69 @@ GL_DEV bool ldlt6_packed_pos(const double* H, const double* b, double lambda, do
   return ok;
 }
 
+// The same system by 3 x 3 BLOCKS (round 6; see ldlt6_blocked in gl_ba_fast_impl.hpp): [[A, B], [B^T, C]] - A = L_a D_a L_a^T, Y = A^-1 [B | b_r],
+// S = C - B^T Y_B, x_t = S^-1 (b_t - B^T y), x_r = y - Y_B x_t - the pivots (and the failure test) of the unpivoted LDL^T of the whole matrix,
+// about 50 instructions deep where the column-by-column factorisation is a chain of ~190: every wave of the frame-at-a-time shapes runs
+// this solve on a SIMD of its own, once per pass.
+#ifndef GL_POSE_SOLVE_BLOCKED
+#define GL_POSE_SOLVE_BLOCKED 1
+#endif
+GL_DEV bool pose_ldl3_factor(const double* D, double* f) {  // f = {l10, l20, l21, 1/d0, 1/d1, 1/d2}; false on a non-positive / non-finite pivot
+  const double i0 = rcp_nr(D[0]);
+  const double m2 = fma(D[0], D[3], -(D[1] * D[1]));  // d0 d1
+  const double e2 = fma(D[0], D[4], -(D[1] * D[2]));  // d0 (D12 - l10 D02)
+  const double im = rcp_nr(m2);
+  const double l1 = D[1] * i0, l2 = D[2] * i0;
+  const double i1 = D[0] * im, l3 = e2 * im;
+  const double e = e2 * i0;
+  const double d2 = fma(-l3, e, fma(-l2, D[2], D[5]));
+  f[0] = l1;
+  f[1] = l2;
+  f[2] = l3;
+  f[3] = i0;
+  f[4] = i1;
+  f[5] = rcp_nr(d2);
+  const double d1 = m2 * i0;
+  return D[0] > 0.0 && isfinite(D[0]) && d1 > 0.0 && isfinite(d1) && d2 > 0.0 && isfinite(d2);
+}
+GL_DEV void pose_ldl3_solve(const double* f, const double* b, double* x) {
+  const double y1 = fma(-f[0], b[0], b[1]);
+  const double y2 = fma(-f[2], y1, fma(-f[1], b[0], b[2]));
+  x[2] = y2 * f[5];
+  x[1] = fma(-f[2], x[2], y1 * f[4]);
+  x[0] = fma(-f[1], x[2], fma(-f[0], x[1], b[0] * f[3]));
+}
+GL_DEV bool ldlt6_blocked_pos(const double* a, const double* b, double lambda, double* x) {
+  const double A[6] = {a[GL_PU(0, 0)] + lambda, a[GL_PU(0, 1)], a[GL_PU(0, 2)], a[GL_PU(1, 1)] + lambda, a[GL_PU(1, 2)], a[GL_PU(2, 2)] + lambda};
+  double fa[6];
+  const bool ok_a = pose_ldl3_factor(A, fa);
+  double Y[3][3], y[3];  // Y[j] = A^-1 (column j of B)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double col[3] = {a[GL_PU(0, 3 + j)], a[GL_PU(1, 3 + j)], a[GL_PU(2, 3 + j)]};
+    pose_ldl3_solve(fa, col, Y[j]);
+  }
+  pose_ldl3_solve(fa, b, y);
+  double S[6], s[3];
+  {
+    const int ri[6] = {0, 0, 0, 1, 1, 2}, ci[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int i = ri[e], j = ci[e];
+      const double c = a[GL_PU(3 + i, 3 + j)] + (i == j ? lambda : 0.0);
+      S[e] = fma(-a[GL_PU(2, 3 + i)], Y[j][2], fma(-a[GL_PU(1, 3 + i)], Y[j][1], fma(-a[GL_PU(0, 3 + i)], Y[j][0], c)));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = fma(-a[GL_PU(2, 3 + i)], y[2], fma(-a[GL_PU(1, 3 + i)], y[1], fma(-a[GL_PU(0, 3 + i)], y[0], b[3 + i])));
+  }
+  double fs[6];
+  const bool ok_s = pose_ldl3_factor(S, fs);
+  pose_ldl3_solve(fs, s, x + 3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) x[k] = fma(-Y[2][k], x[5], fma(-Y[1][k], x[4], fma(-Y[0][k], x[3], y[k])));
+  return ok_a && ok_s;
+}
+
 // one edge: residual, chi2, Huber weight, and its terms of the pose system into acc[0..27].  With j_r the rows of the projection
 // Jacobian in normalised coordinates - (iz, 0, c0), (0, iz, c1) and, stereo, (iz, 0, c2) - the edge's Jacobian is -j G,
 // G = dq / dxi = [-[q]x | I] (VertexSE3Expmap: exp(xi) q), so  H += G^T A G,  b += G^T a  with the 3 x 3 block
@@ -615,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
           // (eight-wave instances: letting only the waves 0..3 solve and handing step + trial pose to the others through LDS was built and
           //  measured - the first barrier's wait halves, but the extra barrier and 28 - 81 spilled registers cost more: 14.0 k against
           //  13.3 k ticks per pass at 1 200 edges)
-          const bool ok2 = ldlt6_packed_pos(H, H + 21, lambda, dx);
+          const bool ok2 = GL_POSE_SOLVE_BLOCKED ? ldlt6_blocked_pos(H, H + 21, lambda, dx) : ldlt6_packed_pos(H, H + 21, lambda, dx);
           POSE_PT(ts1);
           POSE_PADD(4, ts0, ts1);  // 6 x 6 solve
           PoseRt Pn = P;
