@@ -1644,7 +1644,11 @@ GL_DEV int gen_optimize(const BaK& k, const GmmDev& gm, GenP& G, k_genp* sG, boo
   return cj;
 }
 
-__global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB, int P, int F, int L, int NOBS,
+// (TABLE: the same argument list and prologue, one launch in front of the real one: it WRITES the address table and returns, so that
+// the table is constant - as the constant address space of the scalar loads in genp_fresh promises - for the whole dispatch that reads
+// it: ADVICE r5.  Until round 6 every workgroup of the dispatch wrote the table itself and read it back behind a fence.)
+template <bool TABLE>
+__global__ __launch_bounds__(T_BA) void k_ba_gen_t(BaK k, GmmDev gm, int B, int NB, int P, int F, int L, int NOBS,
                                                  double* __restrict__ poses_all, const uint8_t* __restrict__ prior_all,
                                                  double* __restrict__ pts_all, const int32_t* __restrict__ assoc_all,
                                                  const int32_t* __restrict__ optr_all,
@@ -1739,14 +1743,13 @@ __global__ __launch_bounds__(T_BA) void k_ba_gen(BaK k, GmmDev gm, int B, int NB
   G.pfree = takeB(P + F);
   G.pact = takeB(P);
   G.lact = takeB(L);
-  // the address table (header comment of genp_fresh): every workgroup of the problem writes the same words, then reads them back
+  // the address table (header comment of genp_fresh): written by the TABLE launch in front of this one, read-only here
   GenP* const tab = (GenP*)(scratch + (size_t)B * 512 + (size_t)(f + 1) * scratch_per_problem - GEN_TABLE_BYTES);
   k_genp* const sG = (k_genp*)tab;
-  if (tid == 0) {
-    *tab = G;
-    __threadfence();
+  if (TABLE) {
+    if (tid == 0 && G.pb == 0) *tab = G;
+    return;
   }
-  __syncthreads();
   GFRESH();
 
   // ---- setup --------------------------------------------------------------------------------------
@@ -2922,6 +2925,8 @@ size_t ba_gen_scratch_bytes(int B, int P, int F, int L, int NOBS) {
 }
 
 // the launch proper; scratch: ba_gen_scratch_bytes() bytes of the context's scratch block
+// the persistent kernel proper and the launch that writes its address table (k_ba_gen_t<true>: same arguments, one wave per window)
+static const auto k_ba_gen = &k_ba_gen_t<false>;
 int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* prm, int B, int P, int F, int L, int NOBS,
                   double* poses_dev, const uint8_t* prior_dev, double* points_dev, const int32_t* assoc_dev,
                   const int32_t* obs_ptr_dev, const int32_t* obs_pose_dev, const double* obs_uvr_dev,
@@ -2994,10 +2999,15 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
       // workgroups are not co-resident after all, another context holds CUs - the sub-batch is HALVED at the same NB until it
       // fits.  Only when a single window does not fit does the call fall back to one workgroup per problem (other bits, the same
       // arithmetic): GL_COUNTER_BA_COOP_FALLBACK counts those windows.
+      auto write_table = [&](int bs) {  // (the table's addresses depend on the sub-batch size: again for every size that is tried)
+        k_ba_gen_t<true><<<bs, 64, 0, c->stream>>>(kk, gm, bs, 1, P, F, L, NOBS, poses_s, prior_s, points_s, assoc_s, optr_s, opose_s, ouvr_s, ooct_s,
+                                                   dropped_s, erase_s, iters_s, scr, per_v, s_in_lds, stop_dev, stats);
+      };
       while (NB > 1 && !launched) {
         void* args[] = {&kk, &gm, &Bs, &NB, &P, &F, &L, &NOBS, &poses_s, &prior_s, &points_s, &assoc_s, &optr_s,
                         &opose_s, &ouvr_s, &ooct_s, &dropped_s, &erase_s, &iters_s, &scr, &per_v,
                         &s_in_lds, &stop_dev, &stats};
+        write_table(Bs);
         hipError_t e = hipLaunchCooperativeKernel((const void*)k_ba_gen, dim3(Bs * NB), dim3(T_BA), args, lds, c->stream);
         launched = e == hipSuccess;
         if (!launched) {
@@ -3008,6 +3018,7 @@ int launch_ba_gen(Ctx* c, const Gmm* g, const gl_camera* cam, const gl_params* p
       }
       if (!launched) {
         if (NB > 1) c->coop_fallbacks += Bs;
+        write_table(Bs);
         k_ba_gen<<<Bs, T_BA, lds, c->stream>>>(kk, gm, Bs, 1, P, F, L, NOBS, poses_s, prior_s, points_s, assoc_s, optr_s,
                                                opose_s, ouvr_s, ooct_s, dropped_s, erase_s, iters_s,
                                                scr, per_v, s_in_lds, stop_dev, stats);
