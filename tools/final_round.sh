@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's numbers come from, on one box: tools/final_round.sh <tag>   -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r4}
+TAG=${1:-r6}
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt
 # (tools/kernel_meta.py reads the object files of the build container: run it there -> profiles/<tag>_kernel_meta.txt)
@@ -19,8 +19,7 @@ python tools/ba_modes.py 2>/dev/null | grep "^P" > gpurun_out/${TAG}_ba_modes.tx
 python tools/fixed_time.py 4096 300 2 > gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/fixed_time.py 2048 1000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/fixed_time.py 1024 2000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
-./build_tmp/bench_mfma_point 2000 > gpurun_out/${TAG}_mfma_point.txt 2>/dev/null
-./build_tmp/bench_f64_rate > gpurun_out/${TAG}_f64_rate.txt 2>/dev/null   # (hipcc --offload-arch=gfx950 -O3 tools/bench_f64_rate.hip: built in the build container)
+python tools/lat1.py 2>/dev/null | grep -v amdgpu > gpurun_out/${TAG}_lat1.txt
 python tools/chain_time.py > gpurun_out/${TAG}_chain_time.json 2>/dev/null
 bash tools/pmc_match.sh ${TAG} > gpurun_out/${TAG}_pmc_match.log 2>&1
 rm -rf gpurun_out/pmc_match_${TAG}
