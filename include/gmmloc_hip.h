@@ -411,7 +411,9 @@ typedef struct gl_track_chain_io {
                            mode 0 motion model / 1 key-frame / 2 lost}; required with the fallback                                  */
   /* the fallback (trackKeyFrame): the reference key-frame, side 1 of gl_search_by_bow, B x NK; kf_desc == NULL: no fallback        */
   int32_t NK, NNK, NNF; /* key-frame features; node capacities of the key-frame's and the frame's feature vectors                   */
-  int32_t reserved_;
+  int32_t max_edges;    /* > 0: capacity of the COMPACTED pose problems (features with a map point, in feature order, to the first slots of
+                           a problem of this stride: 512 or 1 024 for a frame of 1 200 features - 0.36 -> 0.20 ms per optimisation);
+                           a frame with more edges takes the full-stride problem, chosen on the device.  0: stride NF as in round 5.  */
   const float* kf_angle;
   const uint8_t* kf_desc;
   const uint8_t* kf_has_mp;

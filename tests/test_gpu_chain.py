@@ -36,9 +36,11 @@ def pack(torch, frames):
     return a
 
 
-def run_chain(torch, ctx, frames):
+def run_chain(torch, ctx, frames, max_edges=0):
     cam, prm = api.Camera(), api.Params()
-    out = api.track_frame_chain(ctx, cam, prm, pack(torch, frames), th_mm=TH_MM, th_local=TH_LOCAL, nn_ratio=0.8, mono=False)
+    a = pack(torch, frames)
+    a["max_edges"] = max_edges
+    out = api.track_frame_chain(ctx, cam, prm, a, th_mm=TH_MM, th_local=TH_LOCAL, nn_ratio=0.8, mono=False)
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in out.items()}
 
@@ -65,6 +67,28 @@ def test_track_frame_chain_matches_oracle_sequence(gpu, oracle, NF, NL, NP):
         # and the chain tracks: the final pose is closer to the generating pose than the prediction was
         assert np.abs(out["pose"][b] - f["pose_true"]).max() < np.abs(f["pose_cw"] - f["pose_true"]).max()
     assert n_local_total > 0
+
+
+def test_track_frame_chain_compacted_pose_problems(gpu, oracle):
+    """io->max_edges (round 6): the pose problems of stages 2 and 4 hold the features WITH a map point in the first slots of a problem
+    of that stride (a frame of 1 200 feature slots: four groups of the summation order instead of five).  Three capacities, from the
+    frames' own edge counts: every problem fits / stage 2 fits and stage 4 of some frames does not (those take the full-stride
+    problem, chosen on the device) / nothing fits.  Whatever the route: every stage exact on the inputs the device gave it, poses within
+    1e-6 of the oracle - and within 1e-7 of the uncompacted call's (another summation order, the same problem), all decisions equal."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    frames = [synth.synth_chain_frame(1200, 1000, 3000, 6100 + b, cam, temporal_frac=(0.3 if b == 2 else 0.0)) for b in range(4)]
+    ref = run_chain(torch, ctx, frames)
+    n2 = ref["counts"][:, 0]                                                      # edges of stage 2 = the matches of stage 1
+    n4 = ((ref["match_last"] >= 0) | (ref["match_local"] >= 0)).sum(1)          # edges of stage 4
+    assert n2.max() < n4.min() and n4.max() < 1024, (n2, n4)
+    for max_edges in (1024, int((n4.min() + n4.max()) // 2), int(n2.min()) - 1):
+        out = run_chain(torch, ctx, frames, max_edges=max_edges)
+        for b, f in enumerate(frames):
+            G.check_chain(oracle, cam, f, out, b)
+            assert np.abs(out["pose"][b] - ref["pose"][b]).max() < 1e-7 and np.abs(out["pose_mm"][b] - ref["pose_mm"][b]).max() < 1e-7
+        for k in ("match_last", "match_local", "outlier", "counts", "counts2", "drop_src", "inview"):
+            assert np.array_equal(out[k], ref[k]), (max_edges, k)
 
 
 def test_track_frame_chain_wide_retry(gpu, oracle):
