@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void k_chain_pose_inputs_c(int B, int NF, int 
   const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
   const bool over = total > MC;
   if (tid == 0) ovf[b] = over ? 1 : 0;
+  // the summation order of k_optimize_current_pose for a frame of stride MC (gl_optimize_current_pose): G groups of S <= 4 chunks
+  const int nch = (MC + 63) / 64, DG = (nch + 3) / 4, DS = (nch + DG - 1) / DG;
+  const bool deal = DG * DS == nch && (MC & 63) == 0;  // (a stride whose groups are not all full keeps the list in order)
   for (int s = tid; s < MC; s += 256) {
     oct_c[(size_t)b * MC + s] = -1;
     outl_c[(size_t)b * MC + s] = 0;  // (the optimisation writes the flags of edges only)
@@ -116,9 +119,13 @@ __global__ __launch_bounds__(256) void k_chain_pose_inputs_c(int B, int NF, int 
       obs[g * 3 + 2] = (double)feat_ur[g];
       oct[g] = full ? feat_oct[g] : -1;
       outl_f[g] = 0;
-      slot_of[g] = comp ? pre : -1;
+      // the r-th edge goes to chunk r / 64 of the edge list, and the list's chunks are DEALT over the groups of the optimisation's
+      // summation order (chunk c -> group c % G, its c / G-th chunk): a frame of 250 edges then gives each of the four waves of the
+      // frame-at-a-time shape ONE slot to evaluate per pass instead of giving wave 0 four and the others none
+      const int cch = pre >> 6, slot = deal ? (((cch % DG) * DS + cch / DG) << 6) + (pre & 63) : pre;
+      slot_of[g] = comp ? slot : -1;
       if (comp) {
-        const size_t sc = (size_t)b * MC + pre;
+        const size_t sc = (size_t)b * MC + slot;
         Xw_c[sc * 3] = X[0];
         Xw_c[sc * 3 + 1] = X[1];
         Xw_c[sc * 3 + 2] = X[2];

@@ -453,12 +453,25 @@ GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2t
     // the frame's groups have four chunks (every frame of more than 768 edges): the thread's four edges as ONE basic block - no region
     // per edge -, so that the scheduler interleaves their dependent chains (a wave of these shapes has its SIMD to itself); an
     // absent / level-1 edge adds exact zeros (pose_edge_res): the same bits as the loop below
+    // (round 6: a slot in which NO lane of the wave holds an edge is skipped - a wave-uniform test; its terms would all be exact zeros.
+    // Frames whose edges were compacted and dealt over the waves - gl_track_frame_chain, io->max_edges - leave most slots empty.)
+    if (__builtin_amdgcn_readfirstlane((int)(__ballot(E.oc[0] >= 0 && E.oc[1] >= 0 && E.oc[2] >= 0 && E.oc[3] >= 0) != 0ull))) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double X[3], O[3];
-      edge_xo<MODE>(E, xo, i, X, O);
-      pose_edge_v(kp, s2tab, P, robust, E.oc[i] & 15, (E.oc[i] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc,
-                  E.oc[i] >= 0 && E.lv[i] == 0);
+      for (int i = 0; i < 4; ++i) {
+        double X[3], O[3];
+        edge_xo<MODE>(E, xo, i, X, O);
+        pose_edge_v(kp, s2tab, P, robust, E.oc[i] & 15, (E.oc[i] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc,
+                    E.oc[i] >= 0 && E.lv[i] == 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!__builtin_amdgcn_readfirstlane((int)(__ballot(E.oc[i] >= 0) != 0ull))) continue;
+        double X[3], O[3];
+        edge_xo<MODE>(E, xo, i, X, O);
+        pose_edge_v(kp, s2tab, P, robust, E.oc[i] & 15, (E.oc[i] & 16) != 0, X[0], X[1], X[2], O[0], O[1], O[2], E.c2[i], acc,
+                    E.oc[i] >= 0 && E.lv[i] == 0);
+      }
     }
   } else {
 #pragma unroll
