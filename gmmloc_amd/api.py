@@ -583,15 +583,19 @@ def _chain_out(a, front_only=False):
     return out
 
 
-def track_frame_chain(ctx, cam, prm, a, th_mm=7.0, th_local=3.0, nn_ratio=0.8, mono=False, scale_factor=1.2):
+def track_frame_chain(ctx, cam, prm, a, th_mm=7.0, th_local=3.0, nn_ratio=0.8, mono=False, scale_factor=1.2, out=None):
     """gl_track_frame_chain: trackWithMotionModel (-> trackKeyFrame where it fails, if `a` holds the key-frame buffers) ->
     searchLocalPoints -> trackLocalMap for B frames, device resident.  `a`: dict of CUDA tensors with the input keys of CHAIN_DTYPES
     (+ optionally those of CHAIN_OPT_DTYPES); pose_cw (B,7): the motion-model prediction, NOT modified - the result comes back as a
     new tensor.  Returns dict(pose, pose_mm, match_last, match_local, outlier, counts (B,4), inview, drop_src, counts2 (B,4)
-    [, match_kf, drop_kf])."""
+    [, match_kf, drop_kf]).  `out`: the dict of an earlier call, to be used again (a host that tracks frame after frame keeps its buffers:
+    0.05 ms of allocations less per call); its pose is reset to a["pose_cw"] first."""
     B, NF = a["feat_oct"].shape
     NL, NP = a["last_oct"].shape[1], a["mp_cand"].shape[1]
-    out = _chain_out(a)
+    if out is None:
+        out = _chain_out(a)
+    else:
+        out["pose"].copy_(a["pose_cw"])
     io = _chain_io(a, out)
     ctx._enter()
     try:

@@ -91,6 +91,32 @@ def test_track_frame_chain_compacted_pose_problems(gpu, oracle):
             assert np.array_equal(out[k], ref[k]), (max_edges, k)
 
 
+def test_track_frame_chain_buffers_kept_from_call_to_call(gpu, oracle):
+    """A host that tracks frame after frame keeps its input AND output buffers (`out=` of the wrapper): five calls on the same buffers
+    whose CONTENTS change from call to call (other frames, one of them through the key-frame fallback) - every call equal, bit for bit,
+    to a call on fresh buffers: nothing of a frame survives in the outputs or in the context's scratch."""
+    torch, ctx = gpu
+    cam, prm = api.Camera(), api.Params()
+    sets = [[synth.synth_chain_frame(700, 600, 1400, 6300 + 10 * k + b, cam, NK=500, temporal_frac=0.2, pred_rot_deg=(10.0 if (k == 3 and b == 0) else None))
+             for b in range(2)] for k in range(5)]
+    allp = pack(torch, [f for fs in sets for f in fs])  # (one packing: the same CSR capacities for every call)
+    packed = [{name: v[2 * k:2 * k + 2].contiguous() for name, v in allp.items()} for k in range(5)]
+    for p_ in packed:
+        p_["max_edges"] = 512
+    fresh = [{k: v.cpu().numpy().copy() for k, v in api.track_frame_chain(ctx, cam, prm, p_).items()} for p_ in packed]
+    a = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in packed[0].items()}  # THE buffers of the host
+    keep = None
+    for k, p_ in enumerate(packed):
+        for name, v in p_.items():
+            if hasattr(v, "clone"):
+                a[name].copy_(v)
+        keep = api.track_frame_chain(ctx, cam, prm, a, out=keep)
+        torch.cuda.synchronize()
+        for name in fresh[k]:
+            assert np.array_equal(keep[name].cpu().numpy(), fresh[k][name]), (k, name)
+    assert fresh[3]["counts2"][0, 3] == 1  # the fourth call took a frame through trackKeyFrame
+
+
 def test_track_frame_chain_wide_retry(gpu, oracle):
     """a prediction so far off that th = 7 finds fewer than 20 matches: the frame is searched again with th = 14 (tracking.cpp:340-346),
     the frames beside it are not"""

@@ -129,6 +129,17 @@ with torch.cuda.stream(ctx.stream):
             fb["max_edges"] = mc
             t_one.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb), n=12, skip=2))
         t_mc[mc] = [float(np.mean(t_one)), float(np.min(t_one)), float(np.max(t_one))]
+# ... and with the caller's OUTPUT buffers kept from frame to frame (`out=`: no allocations in the wrapper)
+t_keep = {}
+for mc in (0, 1024):
+    t_one = []
+    with torch.cuda.stream(ctx.stream):
+        for b in range(16):
+            fb = pack(frames[b:b + 1])
+            fb["max_edges"] = mc
+            keep = api.track_frame_chain(ctx, cam, prm, fb)
+            t_one.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb, out=keep), n=14, skip=4))
+    t_keep["max_edges_%d" % mc] = [float(np.mean(t_one)), float(np.min(t_one)), float(np.max(t_one))]
 B = 2048
 big = pack([frames[b % 64] for b in range(B)])
 big_c = dict(big)
@@ -147,4 +158,5 @@ print(json.dumps({"config": "one tracked frame (trackWithMotionModel -> searchLo
                   "two_halves_ms": {"front": t_front, "back": t_back},
                   "compacted_pose_problems_one_frame_ms_mean_min_max_of_16": {"max_edges_1024": t_mc[1024], "max_edges_512": t_mc[512]},
                   "compacted_512_batch_frames_per_s": B / (t_batch_c * 1e-3),
+                  "buffers_kept_one_frame_ms_mean_min_max_of_16": t_keep,
                   "note": "wall clock incl. the Python wrapper, median of 25; the four-call form does its glue as torch ops on the device"}))
