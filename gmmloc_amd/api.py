@@ -545,7 +545,7 @@ CHAIN_FIELDS2B = ("kf_angle", "kf_desc", "kf_has_mp", "kf_nnode", "kf_node_id", 
 
 class _ChainIO(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in CHAIN_FIELDS] + [(k, C.c_void_p) for k in CHAIN_FIELDS2A] +
-                [("NK", C.c_int32), ("NNK", C.c_int32), ("NNF", C.c_int32), ("max_edges", C.c_int32)] + [(k, C.c_void_p) for k in CHAIN_FIELDS2B])
+                [("NK", C.c_int32), ("NNK", C.c_int32), ("NNF", C.c_int32), ("reserved_", C.c_int32)] + [(k, C.c_void_p) for k in CHAIN_FIELDS2B])
 
 
 def _chain_io(a, out):
@@ -563,7 +563,6 @@ def _chain_io(a, out):
         setattr(io, k, _ptr(t) if t is not None else None)
     if a.get("kf_desc") is not None:
         io.NK, io.NNK, io.NNF = a["kf_desc"].shape[1], a["kf_node_id"].shape[1], a["feat_node_id"].shape[1]
-    io.max_edges = int(a.get("max_edges", 0) or 0)  # (a plain int in the dict: capacity of the compacted pose problems, 0 = none)
     return io
 
 

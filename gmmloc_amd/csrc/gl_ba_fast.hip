@@ -81,6 +81,9 @@ __host__ __device__ inline PrepView prep_view(double* scratch, int B, int L) {
 // point and pass).  The order is a function of the frame's data alone, so the canonical summation order built on it stays
 // independent of the launch shape and of the batch.
 constexpr int PREP_T = 256, PREP_C = 8;  // rounds of 256 consecutive points: frames up to 2 048 points
+#ifndef GL_PREP_EMPTY_LAST
+#define GL_PREP_EMPTY_LAST 1  // (0: the order of rounds 3 - 5, for A/B runs: profiles/r6_track_sparse.txt)
+#endif
 __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, int L, const double* __restrict__ obs_all,
                                                     const int32_t* __restrict__ oct_all, int32_t* __restrict__ assoc_all,
                                                     const double* __restrict__ d2_all, double* __restrict__ scratch,
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
                                                     double* __restrict__ prior_mi, int F, const double* __restrict__ fpose_all,
                                                     const double* __restrict__ fobs_all, const int32_t* __restrict__ foct_all, double* __restrict__ fRt,
                                                     double* __restrict__ fobn, int32_t* __restrict__ foct, double* __restrict__ chif, int* __restrict__ frame_ctr) {
-  __shared__ int cnt[PREP_C][PREP_T / 64];  // non-degenerate-component points per (round, wave)
+  __shared__ int cnt[PREP_C][PREP_T / 64];   // non-degenerate-component points per (round, wave)
+  __shared__ int cnt0[PREP_C][PREP_T / 64];  // slots WITHOUT a map point per (round, wave) (round 6: they go last, see below)
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (f >= B) return;
   if (frame_ctr && f == 0 && tid == 0) *frame_ctr = 0;  // the queue the refine's persistent workgroups draw their frames from
@@ -143,28 +147,45 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
       fl_[j] = fl;
     }
     const unsigned long long bal = __ballot((fl_[j] & 12) == 4);  // associated and not degenerate
-    if (lane == 0) cnt[j][wave] = __popcll(bal);
+    const unsigned long long bal0 = __ballot(GL_PREP_EMPTY_LAST && fl_[j] == 0 && j < rounds && j * PREP_T + tid < L);  // no map point in the slot
+    if (lane == 0) {
+      cnt[j][wave] = __popcll(bal);
+      cnt0[j][wave] = __popcll(bal0);
+    }
   }
   __syncthreads();
-  int total = 0;
+  int total = 0, total0 = 0;
 #pragma unroll
   for (int j = 0; j < PREP_C; ++j)
 #pragma unroll
-    for (int w = 0; w < PREP_T / 64; ++w) total += cnt[j][w];
-  const int n_others = L - total;
+    for (int w = 0; w < PREP_T / 64; ++w) {
+      total += cnt[j][w];
+      total0 += cnt0[j][w];
+    }
+  // Round 6: a stable partition in THREE classes - the points of planar components (and the unassociated ones), the points of
+  // non-degenerate components, the slots without a map point.  The reference's frame has one slot per FEATURE (1 200) and a few hundred
+  // map points: with the empty slots LAST the chunks behind the frame's points hold nothing, every wave skips them with one test
+  // (load_pt: no active edge in any lane), and since a group's chunks are interleaved (g, g + G, ...) the points still spread evenly
+  // over the waves - the refine costs what its POINTS cost, not what its slots cost.
+  const int n_others = L - total - total0, n_exist = L - total0;
   const double ifx = 1.0 / k.fx, ify = 1.0 / k.fy;
-  int base = 0;  // non-degenerate-component points before this (round, wave)
+  int base = 0, base0 = 0;  // non-degenerate-component points / empty slots before this (round, wave)
 #pragma unroll
   for (int j = 0; j < PREP_C; ++j) {
 #pragma unroll
     for (int w = 0; w < PREP_T / 64; ++w)
-      if (w < wave) base += cnt[j][w];
+      if (w < wave) {
+        base += cnt[j][w];
+        base0 += cnt0[j][w];
+      }
     const int l = j * PREP_T + tid;
     const bool isnd = (fl_[j] & 12) == 4;
-    const unsigned long long bal = __ballot(isnd);
+    const bool isempty = GL_PREP_EMPTY_LAST && fl_[j] == 0 && j < rounds && l < L;
+    const unsigned long long bal = __ballot(isnd), bal0 = __ballot(isempty);
     const int before = base + __popcll(bal & ((1ull << lane) - 1ull));
+    const int before0 = base0 + __popcll(bal0 & ((1ull << lane) - 1ull));
     if (j < rounds && l < L) {
-      const int lp = isnd ? n_others + before : l - before;  // stable on both sides
+      const int lp = isempty ? n_exist + before0 : isnd ? n_others + before : l - before - before0;  // stable in all three classes
       const size_t g = gbase + l, gp = gbase + lp;
       pv.perm[gp] = l;
       pv.pfl[gp] = fl_[j];
@@ -185,7 +206,10 @@ __global__ __launch_bounds__(PREP_T) void k_ba1_prep(BaK k, GmmDev gm, int B, in
     }
 #pragma unroll
     for (int w = 0; w < PREP_T / 64; ++w)
-      if (w >= wave) base += cnt[j][w];  // the rest of this round: base now counts every point before round j + 1
+      if (w >= wave) {  // the rest of this round: the bases now count everything before round j + 1
+        base += cnt[j][w];
+        base0 += cnt0[j][w];
+      }
   }
 }
 }  // namespace

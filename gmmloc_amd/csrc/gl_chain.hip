@@ -49,109 +49,6 @@ __global__ __launch_bounds__(256) void k_chain_pose_inputs(int B, int NF, int NL
   oct[g] = X ? feat_oct[g] : -1;
 }
 
-// The same pose problem COMPACTED (round 6, io->max_edges = MC > 0).  A tracked frame has 1 200 feature slots and a few hundred
-// features with a map point; k_optimize_current_pose costs what its SLOTS cost (an empty slot is evaluated with zero weights), and
-// 1 200 slots are five groups of its summation order where <= 1 024 are four: 0.36 against 0.20 ms for one frame, twice per tracked
-// frame.  One workgroup per frame: the features with a map point, in feature order, go to the first slots of a problem of stride MC
-// (slot_of remembers where); a frame with MORE than MC of them (flag ovf) keeps the full-stride problem instead - both problems are
-// always written, the one that is not used with no edge at all (the optimisation returns at once for it and leaves the pose alone).
-__global__ __launch_bounds__(256) void k_chain_pose_inputs_c(int B, int NF, int NL, int NP, int NK, int MC, const double* __restrict__ feat_uv,
-                                                            const float* __restrict__ feat_ur, const int32_t* __restrict__ feat_oct,
-                                                            int32_t* __restrict__ match_last, const double* __restrict__ last_pt,
-                                                            const int32_t* __restrict__ match_local, const double* __restrict__ mp_pos,
-                                                            const int32_t* __restrict__ match_kf, const double* __restrict__ kf_pt,
-                                                            double* __restrict__ Xw, double* __restrict__ obs, int32_t* __restrict__ oct,
-                                                            double* __restrict__ Xw_c, double* __restrict__ obs_c, int32_t* __restrict__ oct_c,
-                                                            int32_t* __restrict__ slot_of, int32_t* __restrict__ ovf, uint8_t* __restrict__ outl_c,
-                                                            uint8_t* __restrict__ outl_f, int finalise) {
-  __shared__ int s_w[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (b >= B) return;
-  auto point_of = [&](int i, int& j, int& k) -> const double* {
-    const size_t g = (size_t)b * NF + i;
-    j = match_last[g];
-    k = match_local ? match_local[g] : -1;
-    const int q = match_kf ? match_kf[g] : -1;
-    if (feat_oct[g] < 0) return nullptr;
-    return k >= 0 ? mp_pos + ((size_t)b * NP + k) * 3 : (j >= 0 ? last_pt + ((size_t)b * NL + j) * 3 : (q >= 0 ? kf_pt + ((size_t)b * NK + q) * 3 : nullptr));
-  };
-  // pass 1: how many edges
-  int cnt = 0;
-  for (int i = tid; i < NF; i += 256) {
-    int j, k;
-    cnt += point_of(i, j, k) != nullptr;
-  }
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if (lane == 0) s_w[wave] = cnt;
-  __syncthreads();
-  const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-  const bool over = total > MC;
-  if (tid == 0) ovf[b] = over ? 1 : 0;
-  // the summation order of k_optimize_current_pose for a frame of stride MC (gl_optimize_current_pose): G groups of S <= 4 chunks
-  const int nch = (MC + 63) / 64, DG = (nch + 3) / 4, DS = (nch + DG - 1) / DG;
-  const bool deal = DG * DS == nch && (MC & 63) == 0;  // (a stride whose groups are not all full keeps the list in order)
-  for (int s = tid; s < MC; s += 256) {
-    oct_c[(size_t)b * MC + s] = -1;
-    outl_c[(size_t)b * MC + s] = 0;  // (the optimisation writes the flags of edges only)
-  }
-  __syncthreads();
-  // pass 2: the problems, slots in feature order
-  int base = 0;
-  for (int i0 = 0; i0 < NF; i0 += 256) {
-    const int i = i0 + tid;
-    int j = -1, k = -1;
-    const double* X = i < NF ? point_of(i, j, k) : nullptr;
-    const unsigned long long bal = __ballot(X != nullptr);
-    if (lane == 0) s_w[wave] = __popcll(bal);
-    __syncthreads();
-    int pre = base + __popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) pre += s_w[w];
-    const int round_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    if (i < NF) {
-      const size_t g = (size_t)b * NF + i;
-      if (finalise && k >= 0 && j >= 0) match_last[g] = -1;
-      const bool full = X != nullptr && over, comp = X != nullptr && !over;
-      Xw[g * 3] = full ? X[0] : 0.0;
-      Xw[g * 3 + 1] = full ? X[1] : 0.0;
-      Xw[g * 3 + 2] = full ? X[2] : 0.0;
-      obs[g * 3] = feat_uv[g * 2];
-      obs[g * 3 + 1] = feat_uv[g * 2 + 1];
-      obs[g * 3 + 2] = (double)feat_ur[g];
-      oct[g] = full ? feat_oct[g] : -1;
-      outl_f[g] = 0;
-      // the r-th edge goes to chunk r / 64 of the edge list, and the list's chunks are DEALT over the groups of the optimisation's
-      // summation order (chunk c -> group c % G, its c / G-th chunk): a frame of 250 edges then gives each of the four waves of the
-      // frame-at-a-time shape ONE slot to evaluate per pass instead of giving wave 0 four and the others none
-      const int cch = pre >> 6, slot = deal ? (((cch % DG) * DS + cch / DG) << 6) + (pre & 63) : pre;
-      slot_of[g] = comp ? slot : -1;
-      if (comp) {
-        const size_t sc = (size_t)b * MC + slot;
-        Xw_c[sc * 3] = X[0];
-        Xw_c[sc * 3 + 1] = X[1];
-        Xw_c[sc * 3 + 2] = X[2];
-        obs_c[sc * 3] = feat_uv[g * 2];
-        obs_c[sc * 3 + 1] = feat_uv[g * 2 + 1];
-        obs_c[sc * 3 + 2] = (double)feat_ur[g];
-        oct_c[sc] = feat_oct[g];
-      }
-    }
-    base += round_total;
-    __syncthreads();
-  }
-}
-// ... and the optimisation's outlier flags and inlier count back in feature order
-__global__ __launch_bounds__(256) void k_chain_outliers_c(int B, int NF, int MC, const int32_t* __restrict__ slot_of, const int32_t* __restrict__ ovf,
-                                                         const uint8_t* __restrict__ outl_c, const uint8_t* __restrict__ outl_f,
-                                                         const int32_t* __restrict__ ninl_c, const int32_t* __restrict__ ninl_f,
-                                                         uint8_t* __restrict__ outlier, int32_t* __restrict__ ninl) {
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= (size_t)B * NF) return;
-  const size_t b = g / NF;
-  const int s = slot_of[g];
-  outlier[g] = ovf[b] ? outl_f[g] : (s >= 0 ? outl_c[b * MC + s] : 0);
-  if (g == b * NF) ninl[b] = ovf[b] ? ninl_f[b] : ninl_c[b];
-}
-
 // after the first optimisation (tracking.cpp:360-374): an outlier's feature loses its map point and its flag (drop_src remembers which
 // last-frame feature it had: that map point has been SEEN by this frame, last_visible_idx_ = idx, :367); what trackWithMotionModel
 // returns is the number of kept matches whose map point has observations (:370) - 0 when the search found fewer than 20 (:344-345).
@@ -331,18 +228,12 @@ struct ChainScratch {
   double *Xw, *obs, *t_wc, *pose_fb;
   int32_t *oct, *nm, *ninl, *fb_flag, *nm_bow, *drop_src, *drop_kf;
   uint8_t *taken, *cand, *outl_fb;
-  // the compacted pose problem (max_edges = MC > 0)
-  int MC;
-  double *Xw_c, *obs_c;
-  int32_t *oct_c, *slot_of, *ovf, *ninl_c;
-  uint8_t *outl_c, *outl_f;
 };
-int chain_scratch(gl::Ctx* c, int B, int NF, int NP, int MC, ChainScratch* S) {
-  const size_t nf = (size_t)B * NF, np = (size_t)B * NP, nc = (size_t)B * MC;
+int chain_scratch(gl::Ctx* c, int B, int NF, int NP, ChainScratch* S) {
+  const size_t nf = (size_t)B * NF, np = (size_t)B * NP;
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
   void* scratch = nullptr;
-  const int rc = gl::ctx_scratch_c(c, 2 * up(nf * 24) + 3 * up(nf * 4) + 2 * up(nf) + up(np) + up((size_t)B * 24) + up((size_t)B * 56) + 4 * up((size_t)B * 4) +
-                                          (MC > 0 ? 2 * up(nc * 24) + up(nc * 4) + up(nf * 4) + 2 * up((size_t)B * 4) + up(nc) + up(nf) : 0), &scratch);
+  const int rc = gl::ctx_scratch_c(c, 2 * up(nf * 24) + 3 * up(nf * 4) + 2 * up(nf) + up(np) + up((size_t)B * 24) + up((size_t)B * 56) + 4 * up((size_t)B * 4), &scratch);
   if (rc != GL_OK) return rc;
   char* s = (char*)scratch;
   auto take = [&](size_t bytes) {
@@ -364,47 +255,22 @@ int chain_scratch(gl::Ctx* c, int B, int NF, int NP, int MC, ChainScratch* S) {
   S->ninl = (int32_t*)take((size_t)B * 4);
   S->fb_flag = (int32_t*)take((size_t)B * 4);
   S->nm_bow = (int32_t*)take((size_t)B * 4);
-  S->MC = MC;
-  if (MC > 0) {
-    S->Xw_c = (double*)take(nc * 24);
-    S->obs_c = (double*)take(nc * 24);
-    S->oct_c = (int32_t*)take(nc * 4);
-    S->slot_of = (int32_t*)take(nf * 4);
-    S->ovf = (int32_t*)take((size_t)B * 4);
-    S->ninl_c = (int32_t*)take((size_t)B * 4);
-    S->outl_c = (uint8_t*)take(nc);
-    S->outl_f = (uint8_t*)take(nf);
-  }
   return GL_OK;
 }
-// capacity of the compacted pose problem: io->max_edges where it is smaller than the frame's feature slots, else none
-int chain_mc(const gl_track_chain_io* io, int NF) { return (io->max_edges > 0 && io->max_edges < NF) ? io->max_edges : 0; }
-
-// optimizeCurrentPose of the chain: the problem of the frame's current associations (match_local / match_kf may be null), compacted when
-// the caller gave a capacity; outlier flags in feature order, the inlier count to counts[., slot]
+// optimizeCurrentPose of the chain: the problem of the frame's current associations (match_local / match_kf may be null), outlier flags in
+// feature order, the inlier count to counts[., slot]
 int chain_optimise(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int NF, int NL, int NP, int NK, const gl_track_chain_io* io,
                    const ChainScratch& S, double* pose, const int32_t* match_local, const int32_t* match_kf, int finalise, int count_slot) {
   gl::Ctx* c = gl::C(ctx);
   const size_t nf = (size_t)B * NF;
   const unsigned gf = (unsigned)((nf + 255) / 256), gb = (unsigned)((B + 63) / 64);
-  int rc;
-  if (S.MC > 0) {
-    k_chain_pose_inputs_c<<<B, 256, 0, c->stream>>>(B, NF, NL, NP, NK, S.MC, io->feat_uv, io->feat_ur, io->feat_oct, io->match_last, io->last_pt, match_local,
-                                                    io->mp_pos, match_kf, io->kf_pt, S.Xw, S.obs, S.oct, S.Xw_c, S.obs_c, S.oct_c, S.slot_of, S.ovf, S.outl_c,
-                                                    S.outl_f, finalise);
-    GL_HIP(hipGetLastError());
-    rc = gl_optimize_current_pose(ctx, cam, prm, B, S.MC, pose, S.Xw_c, S.obs_c, S.oct_c, S.outl_c, S.ninl_c);
-    if (rc != GL_OK) return rc;
-    rc = gl_optimize_current_pose(ctx, cam, prm, B, NF, pose, S.Xw, S.obs, S.oct, S.outl_f, S.ninl);  // (only the frames above the capacity have edges here)
-    if (rc != GL_OK) return rc;
-    k_chain_outliers_c<<<gf, 256, 0, c->stream>>>(B, NF, S.MC, S.slot_of, S.ovf, S.outl_c, S.outl_f, S.ninl_c, S.ninl, io->outlier, S.ninl);
-  } else {
-    k_chain_pose_inputs<<<gf, 256, 0, c->stream>>>(B, NF, NL, NP, NK, io->feat_uv, io->feat_ur, io->feat_oct, io->match_last, io->last_pt, match_local, io->mp_pos,
-                                                  match_kf, io->kf_pt, S.Xw, S.obs, S.oct, finalise);
-    GL_HIP(hipGetLastError());
-    rc = gl_optimize_current_pose(ctx, cam, prm, B, NF, pose, S.Xw, S.obs, S.oct, io->outlier, S.ninl);
-    if (rc != GL_OK) return rc;
-  }
+  // (gl_optimize_current_pose compacts a problem of more than 1 024 slots itself - option pose_compact: the frame's 1 200 feature slots
+  // hold a few hundred edges)
+  k_chain_pose_inputs<<<gf, 256, 0, c->stream>>>(B, NF, NL, NP, NK, io->feat_uv, io->feat_ur, io->feat_oct, io->match_last, io->last_pt, match_local, io->mp_pos,
+                                                match_kf, io->kf_pt, S.Xw, S.obs, S.oct, finalise);
+  GL_HIP(hipGetLastError());
+  const int rc = gl_optimize_current_pose(ctx, cam, prm, B, NF, pose, S.Xw, S.obs, S.oct, io->outlier, S.ninl);
+  if (rc != GL_OK) return rc;
   k_chain_counts<<<gb, 64, 0, c->stream>>>(B, S.ninl, io->counts, count_slot);
   GL_HIP(hipGetLastError());
   return GL_OK;
@@ -508,7 +374,7 @@ extern "C" int gl_track_frame_chain(gl_ctx_t* ctx, const gl_camera* cam, const g
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   ChainScratch S;
-  rc = chain_scratch(c, B, NF, NP, chain_mc(io, NF), &S);
+  rc = chain_scratch(c, B, NF, NP, &S);
   if (rc != GL_OK) return rc;
   int32_t* drop = io->drop_src ? io->drop_src : S.drop_src;
   int32_t* dropk = io->drop_kf ? io->drop_kf : S.drop_kf;
@@ -526,7 +392,7 @@ extern "C" int gl_track_frame_chain_front(gl_ctx_t* ctx, const gl_camera* cam, c
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   ChainScratch S;
-  rc = chain_scratch(c, B, NF, NP, chain_mc(io, NF), &S);
+  rc = chain_scratch(c, B, NF, NP, &S);
   if (rc != GL_OK) return rc;
   return chain_front(ctx, cam, prm, scale_factor, B, NF, NL, NP, io, th_mm, mono, S, io->drop_src, io->drop_kf ? io->drop_kf : S.drop_kf);
 }
@@ -538,7 +404,7 @@ extern "C" int gl_track_frame_chain_back(gl_ctx_t* ctx, const gl_camera* cam, co
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   ChainScratch S;
-  rc = chain_scratch(c, B, NF, NP, chain_mc(io, NF), &S);
+  rc = chain_scratch(c, B, NF, NP, &S);
   if (rc != GL_OK) return rc;
   return chain_back(ctx, cam, prm, scale_factor, B, NF, NL, NP, io, th_local, nn_ratio, S, io->drop_src, io->drop_kf);
 }

@@ -119,6 +119,7 @@ struct Options {
   double assoc_rec_pad = 1;     // 1: k_assoc_cells_coop gathers from the one-line-per-record copy (CellIndex::rec16), 0: from rec12 (A/B; same results)
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
   double pipe_fuse_asm = -1;    // pipelined local BA: the solve kernel assembles the system itself (-1: calls of a few windows, 0 never, 1 always; same bits)
+  double pose_compact = -1;     // gl_optimize_current_pose: problems of more than 1 024 slots compacted to 1 024 where their edges fit (-1, default); 1: every problem of more than 256 slots; 0: never
   double assoc_cell8 = 1;       // the packed cell table in 8 bytes per cell where the component indices fit 20 bits (0: 16 bytes per cell as in rounds 3 - 5)
   double assoc_pack_mb = 512;   // memory budget (MB) of the packed cell table a GMM built with this context may add to its cell index (0: none)
   double assoc_cell = 0;        // > 0: cell size (m) of the index instead of the automatic one (tuning)
@@ -223,6 +224,8 @@ int launch_build_neighbours(Ctx* c, Gmm* g);
 int build_cell_index(Ctx* c, Gmm* g);
 void free_cell_index(Gmm* g);
 // gl_search_by_projection_frame with a per-frame gate (gl_match.hip): frames with gate_nm[f] >= gate_min are left untouched
+int optimize_current_pose_plain(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M, double* pose_dev, const double* Xw_dev,
+                                const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev);
 int launch_bow_gated(gl_ctx_t* ctx, float nn_ratio, int check_orientation, int B, int N1, int N2, int NN1, int NN2, const float* angle1_dev,
                      const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev, const int32_t* node_id1_dev,
                      const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev, const float* angle2_dev, const uint8_t* desc2_dev,

@@ -454,7 +454,7 @@ GL_DEV void pose_eval_regs(const PoseKParams& kp, const double* __restrict__ s2t
     // per edge -, so that the scheduler interleaves their dependent chains (a wave of these shapes has its SIMD to itself); an
     // absent / level-1 edge adds exact zeros (pose_edge_res): the same bits as the loop below
     // (round 6: a slot in which NO lane of the wave holds an edge is skipped - a wave-uniform test; its terms would all be exact zeros.
-    // Frames whose edges were compacted and dealt over the waves - gl_track_frame_chain, io->max_edges - leave most slots empty.)
+    // Problems whose edges were compacted and dealt over the waves - k_pose_compact below - leave most slots empty.)
     if (__builtin_amdgcn_readfirstlane((int)(__ballot(E.oc[0] >= 0 && E.oc[1] >= 0 && E.oc[2] >= 0 && E.oc[3] >= 0) != 0ull))) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -798,17 +798,78 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   }
 }
 
-}  // namespace
+// ---- compacted problems (round 6) ---------------------------------------------------------------------------------------------------
+// The kernel costs what its SLOTS cost, and the reference's frame has one slot per FEATURE (1 200) of which a few hundred hold a map
+// point: five groups of the summation order where <= 1 024 slots are four, every wave evaluating four mostly empty slots per pass.
+// k_pose_compact (one workgroup per frame) moves the edges, in slot order, to the front of a problem of stride MC <= 1 024 and DEALS the
+// list's chunks over the groups (chunk c -> group c % G, its c / G-th chunk: the waves of the frame-at-a-time shapes get equal shares and
+// skip the slots nobody uses); a frame with more than MC edges keeps its full-stride problem (oct_f: the caller's octaves for those
+// frames, -1 everywhere else, so that the second launch returns at once for the frames that fitted).  k_pose_scatter puts the flags back.
+__global__ __launch_bounds__(256) void k_pose_compact(int B, int M, int MC, const double* __restrict__ Xw, const double* __restrict__ obs,
+                                                     const int32_t* __restrict__ oct, double* __restrict__ Xw_c, double* __restrict__ obs_c,
+                                                     int32_t* __restrict__ oct_c, uint8_t* __restrict__ outl_c, int32_t* __restrict__ slot_of,
+                                                     int32_t* __restrict__ ovf, int32_t* __restrict__ oct_f) {
+  __shared__ int s_w[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (b >= B) return;
+  const int32_t* oc = oct + (size_t)b * M;
+  int cnt = 0;
+  for (int i = tid; i < M; i += 256) cnt += oc[i] >= 0;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) s_w[wave] = cnt;
+  __syncthreads();
+  const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  const bool over = total > MC;
+  if (tid == 0) ovf[b] = over ? 1 : 0;
+  const int nch = (MC + 63) / 64, DG = (nch + 3) / 4, DS = (nch + DG - 1) / DG;
+  const bool deal = DG * DS == nch && (MC & 63) == 0;
+  for (int s_ = tid; s_ < MC; s_ += 256) {
+    oct_c[(size_t)b * MC + s_] = -1;
+    outl_c[(size_t)b * MC + s_] = 0;
+  }
+  __syncthreads();
+  int base = 0;
+  for (int i0 = 0; i0 < M; i0 += 256) {
+    const int i = i0 + tid;
+    const bool act = i < M && oc[i] >= 0;
+    const unsigned long long bal = __ballot(act);
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int pre = base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pre += s_w[w];
+    const int round_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (i < M) {
+      const size_t g = (size_t)b * M + i;
+      if (oct_f) oct_f[g] = over ? oc[i] : -1;
+      const bool comp = act && !over;
+      const int cch = pre >> 6, slot = deal ? (((cch % DG) * DS + cch / DG) << 6) + (pre & 63) : pre;
+      slot_of[g] = comp ? slot : -1;
+      if (comp) {
+        const size_t sc = (size_t)b * MC + slot;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          Xw_c[sc * 3 + j] = Xw[g * 3 + j];
+          obs_c[sc * 3 + j] = obs[g * 3 + j];
+        }
+        oct_c[sc] = oc[i];
+      }
+    }
+    base += round_total;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_pose_scatter(int B, int M, int MC, const int32_t* __restrict__ slot_of, const int32_t* __restrict__ ovf,
+                                                     const uint8_t* __restrict__ outl_c, const int32_t* __restrict__ ninl_c,
+                                                     const int32_t* __restrict__ ninl_f, uint8_t* __restrict__ outlier, int32_t* __restrict__ ninl) {
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (size_t)B * M) return;
+  const size_t b = g / M;
+  const int s_ = slot_of[g];
+  if (!ovf[b] && s_ >= 0) outlier[g] = outl_c[b * MC + s_];  // (the flags of the slots without an edge stay the caller's)
+  if (g == b * M) ninl[b] = (ovf[b] && ninl_f) ? ninl_f[b] : ninl_c[b];
+}
 
-extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M,
-                                        double* pose_dev, const double* Xw_dev, const double* obs_dev,
-                                        const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev) {
-  GL_REQUIRE(ctx && cam && prm, "null argument");
-  if (B == 0) return GL_OK;
-  GL_REQUIRE(B > 0 && M >= 0, "bad B / M");
-  GL_REQUIRE(pose_dev && ninlier_dev && (M == 0 || (Xw_dev && obs_dev && octave_dev && outlier_dev)), "null buffer");
-  gl::Ctx* c = gl::C(ctx);
-  GL_HIP(hipSetDevice(c->device));
+PoseKParams pose_kparams(const gl_camera* cam, const gl_params* prm) {
   PoseKParams kp;
   kp.ifx = 1.0 / cam->fx;
   kp.ify = 1.0 / cam->fy;
@@ -821,11 +882,12 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   }
   kp.delta_mono = (double)(float)sqrt(5.991);    // const float delta_mono = sqrt(5.991)   (:57)
   kp.delta_stereo = (double)(float)sqrt(7.815);  // const float delta_stereo = sqrt(7.815) (:58)
-  GL_REQUIRE(M <= 64 * 4 * 512, "M above 131 072 edges per frame");
-  void* scratch = nullptr;
-  const size_t chi_bytes = (((size_t)B * (M > 0 ? M : 1) * sizeof(double) + 63) / 64) * 64;
-  int rc = gl::ctx_scratch(c, chi_bytes, &scratch);
-  if (rc != GL_OK) return rc;
+  return kp;
+}
+
+// the launch proper: B problems of stride M (scratch: B x max(M, 1) doubles, the edges' chi2)
+int pose_launch(gl::Ctx* c, const PoseKParams& kp, int B, int M, double* pose_dev, const double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
+                uint8_t* outlier_dev, int32_t* ninlier_dev, void* scratch) {
   {
     gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
     // the canonical summation order of a frame of stride M (see group_totals28): G groups of S <= 4 chunks of 64 edges
@@ -880,6 +942,75 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
     }
 #undef GL_POSE_LAUNCH
   }
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+}  // namespace
+
+// gl_optimize_current_pose without the automatic compaction (the tracked-frame chain compacts while it gathers its problems)
+int gl::optimize_current_pose_plain(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M, double* pose_dev, const double* Xw_dev,
+                                    const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev) {
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  void* scratch = nullptr;
+  const size_t chi_bytes = (((size_t)B * (M > 0 ? M : 1) * sizeof(double) + 63) / 64) * 64;
+  const int rc = gl::ctx_scratch(c, chi_bytes, &scratch);
+  if (rc != GL_OK) return rc;
+  return pose_launch(c, pose_kparams(cam, prm), B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, scratch);
+}
+
+extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M,
+                                        double* pose_dev, const double* Xw_dev, const double* obs_dev,
+                                        const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev) {
+  GL_REQUIRE(ctx && cam && prm, "null argument");
+  if (B == 0) return GL_OK;
+  GL_REQUIRE(B > 0 && M >= 0, "bad B / M");
+  GL_REQUIRE(pose_dev && ninlier_dev && (M == 0 || (Xw_dev && obs_dev && octave_dev && outlier_dev)), "null buffer");
+  GL_REQUIRE(M <= 64 * 4 * 512, "M above 131 072 edges per frame");
+  gl::Ctx* c = gl::C(ctx);
+  // option pose_compact: -1 (default) problems of more than 1 024 slots - the reference's frame: one slot per feature, 1 200 - are
+  // compacted to 1 024 where their edges fit (0.31 -> 0.21 ms for one frame of 420 edges); 1: every problem of more than 256 slots
+  // (pays when at most about half of the slots hold an edge); 0: never.  Decisions and tolerances as ever; the bits of a frame are a
+  // function of the frame and this option, never of the batch.
+  const int mode = (int)c->opt.pose_compact;
+  const bool compact = mode != 0 && M > (mode > 0 ? 256 : 1024);
+  if (!compact) return gl::optimize_current_pose_plain(ctx, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev);
+  GL_HIP(hipSetDevice(c->device));
+  const int MC = std::min(1024, 256 * ((M + 255) / 256));
+  const bool can_overflow = M > MC;
+  auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+  const size_t nc = (size_t)B * MC, nm = (size_t)B * M;
+  void* scratch = nullptr;
+  int rc = gl::ctx_scratch(c, up(nc * 8) + (can_overflow ? up(nm * 8) + up(nm * 4) : 0) + 2 * up(nc * 24) + up(nc * 4) + up(nm * 4) + 3 * up((size_t)B * 4) + up(nc), &scratch);
+  if (rc != GL_OK) return rc;
+  char* s = (char*)scratch;
+  auto take = [&](size_t bytes) {
+    char* p = s;
+    s += up(bytes);
+    return (void*)p;
+  };
+  void* chi_c = take(nc * 8);
+  void* chi_f = can_overflow ? take(nm * 8) : nullptr;
+  int32_t* oct_f = can_overflow ? (int32_t*)take(nm * 4) : nullptr;
+  double* Xw_c = (double*)take(nc * 24);
+  double* obs_c = (double*)take(nc * 24);
+  int32_t* oct_c = (int32_t*)take(nc * 4);
+  int32_t* slot_of = (int32_t*)take(nm * 4);
+  int32_t* ovf = (int32_t*)take((size_t)B * 4);
+  int32_t* ninl_c = (int32_t*)take((size_t)B * 4);
+  int32_t* ninl_f = (int32_t*)take((size_t)B * 4);
+  uint8_t* outl_c = (uint8_t*)take(nc);
+  const PoseKParams kp = pose_kparams(cam, prm);
+  k_pose_compact<<<B, 256, 0, c->stream>>>(B, M, MC, Xw_dev, obs_dev, octave_dev, Xw_c, obs_c, oct_c, outl_c, slot_of, ovf, oct_f);
+  GL_HIP(hipGetLastError());
+  rc = pose_launch(c, kp, B, MC, pose_dev, Xw_c, obs_c, oct_c, outl_c, ninl_c, chi_c);
+  if (rc != GL_OK) return rc;
+  if (can_overflow) {
+    rc = pose_launch(c, kp, B, M, pose_dev, Xw_dev, obs_dev, oct_f, outlier_dev, ninl_f, chi_f);
+    if (rc != GL_OK) return rc;
+  }
+  k_pose_scatter<<<(unsigned)((nm + 255) / 256), 256, 0, c->stream>>>(B, M, MC, slot_of, ovf, outl_c, ninl_c, can_overflow ? ninl_f : nullptr, outlier_dev, ninlier_dev);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -121,6 +121,9 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *     window may take a different number of trials in each,
  *   assoc_pack_mb (512; memory budget in MB of the packed cell table of a GMM created with this context, 0 = none),
  *   assoc_cell8 (1; that table in 8 bytes per cell where K < 2^20, 0 = 16 bytes per cell; same results),
+ *   pose_compact (-1; gl_optimize_current_pose moves the edges of a problem of more than 1 024 slots - one slot per feature, 1 200 in the
+ *     reference - to the front of a problem of 1 024 where they fit: one frame of 420 edges 0.31 -> 0.21 ms; 1: every problem of more than
+ *     256 slots; 0: never.  Same decisions, poses within 1e-9 of the uncompacted problem's),
  *   assoc_cell, assoc_globcells (> 0: cell size in metres / cell-count threshold of the index instead of the automatic ones),
  *   ba_fixed_pack (1: fixed observers of gl_track_frames_anchored always through the general kernel),
  *   pipe_lanes, pipe_judge, schur_kper (-1 automatic; A/B switches of the pipelined local BA in batches: streams a call is split over,
@@ -411,9 +414,7 @@ typedef struct gl_track_chain_io {
                            mode 0 motion model / 1 key-frame / 2 lost}; required with the fallback                                  */
   /* the fallback (trackKeyFrame): the reference key-frame, side 1 of gl_search_by_bow, B x NK; kf_desc == NULL: no fallback        */
   int32_t NK, NNK, NNF; /* key-frame features; node capacities of the key-frame's and the frame's feature vectors                   */
-  int32_t max_edges;    /* > 0: capacity of the COMPACTED pose problems (features with a map point, in feature order, to the first slots of
-                           a problem of this stride: 512 or 1 024 for a frame of 1 200 features - 0.36 -> 0.20 ms per optimisation);
-                           a frame with more edges takes the full-stride problem, chosen on the device.  0: stride NF as in round 5.  */
+  int32_t reserved_;
   const float* kf_angle;
   const uint8_t* kf_desc;
   const uint8_t* kf_has_mp;

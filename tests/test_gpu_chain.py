@@ -36,11 +36,9 @@ def pack(torch, frames):
     return a
 
 
-def run_chain(torch, ctx, frames, max_edges=0):
+def run_chain(torch, ctx, frames):
     cam, prm = api.Camera(), api.Params()
-    a = pack(torch, frames)
-    a["max_edges"] = max_edges
-    out = api.track_frame_chain(ctx, cam, prm, a, th_mm=TH_MM, th_local=TH_LOCAL, nn_ratio=0.8, mono=False)
+    out = api.track_frame_chain(ctx, cam, prm, pack(torch, frames), th_mm=TH_MM, th_local=TH_LOCAL, nn_ratio=0.8, mono=False)
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in out.items()}
 
@@ -69,26 +67,23 @@ def test_track_frame_chain_matches_oracle_sequence(gpu, oracle, NF, NL, NP):
     assert n_local_total > 0
 
 
-def test_track_frame_chain_compacted_pose_problems(gpu, oracle):
-    """io->max_edges (round 6): the pose problems of stages 2 and 4 hold the features WITH a map point in the first slots of a problem
-    of that stride (a frame of 1 200 feature slots: four groups of the summation order instead of five).  Three capacities, from the
-    frames' own edge counts: every problem fits / stage 2 fits and stage 4 of some frames does not (those take the full-stride
-    problem, chosen on the device) / nothing fits.  Whatever the route: every stage exact on the inputs the device gave it, poses within
-    1e-6 of the oracle - and within 1e-7 of the uncompacted call's (another summation order, the same problem), all decisions equal."""
+def test_track_frame_chain_compacted_pose_problems(gpu, oracle, opt):
+    """gl_optimize_current_pose compacts a problem of more than 1 024 slots (option pose_compact, tests/test_gpu_pose.py): the chain's two
+    optimisations of a frame of 1 200 feature slots run on a few hundred edges.  With the option on (default) and off: every stage
+    exact on the inputs the device gave it, poses within 1e-6 of the oracle and within 1e-7 of each other, all decisions equal."""
     torch, ctx = gpu
     cam = api.Camera()
     frames = [synth.synth_chain_frame(1200, 1000, 3000, 6100 + b, cam, temporal_frac=(0.3 if b == 2 else 0.0)) for b in range(4)]
+    opt("pose_compact", 0)
     ref = run_chain(torch, ctx, frames)
-    n2 = ref["counts"][:, 0]                                                      # edges of stage 2 = the matches of stage 1
-    n4 = ((ref["match_last"] >= 0) | (ref["match_local"] >= 0)).sum(1)          # edges of stage 4
-    assert n2.max() < n4.min() and n4.max() < 1024, (n2, n4)
-    for max_edges in (1024, int((n4.min() + n4.max()) // 2), int(n2.min()) - 1):
-        out = run_chain(torch, ctx, frames, max_edges=max_edges)
-        for b, f in enumerate(frames):
-            G.check_chain(oracle, cam, f, out, b)
-            assert np.abs(out["pose"][b] - ref["pose"][b]).max() < 1e-7 and np.abs(out["pose_mm"][b] - ref["pose_mm"][b]).max() < 1e-7
-        for k in ("match_last", "match_local", "outlier", "counts", "counts2", "drop_src", "inview"):
-            assert np.array_equal(out[k], ref[k]), (max_edges, k)
+    opt("pose_compact", -1)
+    out = run_chain(torch, ctx, frames)
+    for b, f in enumerate(frames):
+        G.check_chain(oracle, cam, f, out, b)
+        G.check_chain(oracle, cam, f, ref, b)
+        assert np.abs(out["pose"][b] - ref["pose"][b]).max() < 1e-7 and np.abs(out["pose_mm"][b] - ref["pose_mm"][b]).max() < 1e-7
+    for k in ("match_last", "match_local", "outlier", "counts", "counts2", "drop_src", "inview"):
+        assert np.array_equal(out[k], ref[k]), k
 
 
 def test_track_frame_chain_buffers_kept_from_call_to_call(gpu, oracle):
@@ -101,8 +96,6 @@ def test_track_frame_chain_buffers_kept_from_call_to_call(gpu, oracle):
              for b in range(2)] for k in range(5)]
     allp = pack(torch, [f for fs in sets for f in fs])  # (one packing: the same CSR capacities for every call)
     packed = [{name: v[2 * k:2 * k + 2].contiguous() for name, v in allp.items()} for k in range(5)]
-    for p_ in packed:
-        p_["max_edges"] = 512
     fresh = [{k: v.cpu().numpy().copy() for k, v in api.track_frame_chain(ctx, cam, prm, p_).items()} for p_ in packed]
     a = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in packed[0].items()}  # THE buffers of the host
     keep = None

@@ -135,6 +135,60 @@ def test_optimize_current_pose_resets_flags_before_the_too_few_edges_return(gpu,
     assert np.array_equal(got, want), (got[keep], int((got != want).sum()))
 
 
+@pytest.mark.parametrize("mode,M", [(-1, 1200), (1, 1200), (1, 1000), (1, 700)])
+def test_optimize_current_pose_compacted_problems(gpu, oracle, map_v1, gt_sync, opt, mode, M):
+    """option pose_compact (round 6): a problem with one slot per FEATURE (the reference's frame: 1 200, a few hundred with a map
+    point) is compacted to a stride of at most 1 024 where its edges fit, its edge list dealt over the waves.  A batch that mixes
+    sparse frames (compacted), full frames (more than 1 024 edges: the full-stride problem, on the device's own decision) and a frame
+    without an edge: every frame within 1e-6 of the oracle with equal masks and counts, within 1e-8 of the uncompacted run - bit-equal
+    to it where the full-stride problem was kept -, untouched flags where there is no edge, the same bits alone as in the batch."""
+    torch, ctx = gpu
+    mean, cov = map_v1
+    cam, prm = api.Camera(), api.Params()
+    frames = make_frames(mean, cov, gt_sync["V1_02_medium"], cam, 6, M, 9100 + M)
+    rng = np.random.default_rng(M)
+    for b, keep in enumerate((0.3, 1.0, 0.45, 0.0, 0.7, 0.15)):  # share of the slots that keep their edge
+        drop = rng.uniform(size=M) >= keep
+        frames[b]["octave"] = np.where(drop, -1, frames[b]["octave"]).astype(np.int32)
+    n_edges = [int((f["octave"] >= 0).sum()) for f in frames]
+
+    def run(fr, flags_in):
+        pose = torch.from_numpy(np.stack([f["pose_init"] for f in fr])).cuda()
+        Xw = torch.from_numpy(np.stack([f["Xw"] for f in fr])).cuda()
+        obs = torch.from_numpy(np.stack([f["obs"] for f in fr])).cuda()
+        octv = torch.from_numpy(np.stack([f["octave"] for f in fr])).cuda()
+        outl = torch.from_numpy(flags_in.copy()).cuda()
+        nin = torch.zeros(len(fr), dtype=torch.int32).cuda()
+        ctx._enter()
+        try:
+            api._check(ctx.lib.gl_optimize_current_pose(ctx.h, api.C.byref(cam.c()), api.C.byref(prm.c()), len(fr), M, api._ptr(pose), api._ptr(Xw),
+                                                        api._ptr(obs), api._ptr(octv), api._ptr(outl), api._ptr(nin)))
+        finally:
+            ctx._exit()
+        torch.cuda.synchronize()
+        return pose.cpu().numpy(), outl.cpu().numpy(), nin.cpu().numpy()
+
+    flags = rng.integers(0, 2, (6, M)).astype(np.uint8)  # the caller's is_outlier_: kept where a feature has no map point
+    opt("pose_compact", 0)
+    p0, o0, n0 = run(frames, flags)
+    opt("pose_compact", mode)
+    p1, o1, n1 = run(frames, flags)
+    assert np.array_equal(o0, o1) and np.array_equal(n0, n1)
+    for b, f in enumerate(frames):
+        no_edge = f["octave"] < 0
+        assert np.array_equal(o1[b][no_edge], flags[b][no_edge])
+        assert np.abs(p1[b] - p0[b]).max() < 1e-8
+        if n_edges[b] > 1024 or n_edges[b] < 3:
+            assert np.array_equal(p1[b], p0[b]), b  # the full-stride problem / no optimisation at all
+        pr, outl_r, nin_r = oracle.optimize_current_pose(cam, f["pose_init"], f["Xw"], f["obs"], f["octave"])
+        et, er = pose_err(p1[b], pr)
+        assert et < TOL_T and er < TOL_R and n1[b] == nin_r and np.array_equal(o1[b][~no_edge], outl_r[~no_edge])
+    ps, os_, ns = run(frames[2:3], flags[2:3])
+    assert np.array_equal(ps[0], p1[2]) and np.array_equal(os_[0], o1[2])
+    if M == 1200:
+        assert max(n_edges) > 1024 and 3 <= min(n for n in n_edges if n) < 400, n_edges
+
+
 def test_optimize_current_pose_bit_identical_across_shapes_and_batches(gpu, map_v1, gt_sync, opt):
     """One canonical summation order (gl_refine_pose.hip): the refined pose, the outlier mask and the inlier count of a
     frame are the same BITS on one wave (batch shape), on a wave per group (few frames), and whatever rides in the call."""

@@ -119,33 +119,28 @@ with torch.cuda.stream(ctx.stream):
     fr_out = api.track_frame_chain_front(ctx, cam, prm, kf_ok)
     torch.cuda.synchronize()
     t_back = median_ms(lambda: api.track_frame_chain_back(ctx, cam, prm, kf_ok, {k: v.clone() for k, v in fr_out.items()}))
-# round 6: the pose problems compacted (io->max_edges): the same frames, stride 1 024 / 512 instead of the 1 200 feature slots
-t_mc = {}
+# round 6: gl_optimize_current_pose compacts the frame's 1 200-slot problems itself (option pose_compact); the same with the option off
+t_nc = []
+ctx.set_option("pose_compact", 0)
 with torch.cuda.stream(ctx.stream):
-    for mc in (1024, 512):
-        t_one = []
-        for b in range(16):
-            fb = pack(frames[b:b + 1])
-            fb["max_edges"] = mc
-            t_one.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb), n=12, skip=2))
-        t_mc[mc] = [float(np.mean(t_one)), float(np.min(t_one)), float(np.max(t_one))]
+    for b in range(16):
+        fb = pack(frames[b:b + 1])
+        t_nc.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb), n=12, skip=2))
+ctx.set_option("pose_compact", -1)
 # ... and with the caller's OUTPUT buffers kept from frame to frame (`out=`: no allocations in the wrapper)
-t_keep = {}
-for mc in (0, 1024):
-    t_one = []
-    with torch.cuda.stream(ctx.stream):
-        for b in range(16):
-            fb = pack(frames[b:b + 1])
-            fb["max_edges"] = mc
-            keep = api.track_frame_chain(ctx, cam, prm, fb)
-            t_one.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb, out=keep), n=14, skip=4))
-    t_keep["max_edges_%d" % mc] = [float(np.mean(t_one)), float(np.min(t_one)), float(np.max(t_one))]
+t_one = []
+with torch.cuda.stream(ctx.stream):
+    for b in range(16):
+        fb = pack(frames[b:b + 1])
+        keep = api.track_frame_chain(ctx, cam, prm, fb)
+        t_one.append(median_ms(lambda: api.track_frame_chain(ctx, cam, prm, fb, out=keep), n=14, skip=4))
+t_keep = [float(np.mean(t_one)), float(np.min(t_one)), float(np.max(t_one))]
 B = 2048
 big = pack([frames[b % 64] for b in range(B)])
-big_c = dict(big)
-big_c["max_edges"] = 512
+ctx.set_option("pose_compact", 0)
 with torch.cuda.stream(ctx.stream):
-    t_batch_c = median_ms(lambda: api.track_frame_chain(ctx, cam, prm, big_c), n=8, skip=2)
+    t_batch_nc = median_ms(lambda: api.track_frame_chain(ctx, cam, prm, big), n=8, skip=2)
+ctx.set_option("pose_compact", -1)
 with torch.cuda.stream(ctx.stream):
     t_batch = median_ms(lambda: api.track_frame_chain(ctx, cam, prm, big), n=8, skip=2)
 print(json.dumps({"config": "one tracked frame (trackWithMotionModel -> searchLocalPoints -> trackLocalMap): %d features, %d last-frame map points, %d local map points" % (NF, NL, NP),
@@ -156,7 +151,7 @@ print(json.dumps({"config": "one tracked frame (trackWithMotionModel -> searchLo
                   "with_key_frame_buffers_frame_that_tracks_ms": t_kf_ok, "frame_through_trackKeyFrame_fallback_ms": t_kf_fb,
                   "fallback_frame_mode_and_counts2": [int(v) for v in o_fb["counts2"][0].cpu().numpy()],
                   "two_halves_ms": {"front": t_front, "back": t_back},
-                  "compacted_pose_problems_one_frame_ms_mean_min_max_of_16": {"max_edges_1024": t_mc[1024], "max_edges_512": t_mc[512]},
-                  "compacted_512_batch_frames_per_s": B / (t_batch_c * 1e-3),
+                  "pose_compact_off_one_frame_ms_mean_min_max_of_16": [float(np.mean(t_nc)), float(np.min(t_nc)), float(np.max(t_nc))],
+                  "pose_compact_off_batch_frames_per_s": B / (t_batch_nc * 1e-3),
                   "buffers_kept_one_frame_ms_mean_min_max_of_16": t_keep,
                   "note": "wall clock incl. the Python wrapper, median of 25; the four-call form does its glue as torch ops on the device"}))

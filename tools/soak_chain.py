@@ -43,8 +43,7 @@ for r in range(rounds):
         dq, q0 = np.array([0, np.sin(a / 2), 0, np.cos(a / 2)]), f["pose_cw"][:4]
         qp = np.concatenate([dq[3] * q0[:3] + q0[3] * dq[:3] + np.cross(dq[:3], q0[:3]), [dq[3] * q0[3] - dq[:3] @ q0[:3]]])
         f["pose_cw"] = np.concatenate([qp, synth.quat_to_R(dq) @ f["pose_cw"][4:]])
-    mc = int(rng.choice([0, 0, 1024, 512, 200]))  # capacity of the compacted pose problems (0: none; 200: most frames overflow)
-    out = run_chain(torch, ctx, frames, max_edges=mc)
+    out = run_chain(torch, ctx, frames)
     for b, f in enumerate(frames):
         frames_checked += 1
         try:
@@ -53,6 +52,6 @@ for r in range(rounds):
             replaced += c["replaced"]
         except AssertionError as e:
             bad[str(e)] = bad.get(str(e), 0) + 1
-            print("MISMATCH %s: round %d frame %d NF %d NL %d NP %d NK %d max_edges %d" % (e, r, b, NF, NL, NP, NK, mc), flush=True)
+            print("MISMATCH %s: round %d frame %d NF %d NL %d NP %d NK %d" % (e, r, b, NF, NL, NP, NK), flush=True)
 print("chain soak: %d rounds, %d frames (modes motion model / key-frame / lost: %s; %d temporal points replaced): mismatches %s; %.0f s"
       % (rounds, frames_checked, modes, replaced, bad or "none", time.time() - t0))
