@@ -224,8 +224,13 @@ int launch_build_neighbours(Ctx* c, Gmm* g);
 int build_cell_index(Ctx* c, Gmm* g);
 void free_cell_index(Gmm* g);
 // gl_search_by_projection_frame with a per-frame gate (gl_match.hip): frames with gate_nm[f] >= gate_min are left untouched
+struct PoseCompacted;  // gl_pose_compact.hpp
+// (gl_refine_pose.hip) problems whose compacted form exists: see there
+int pose_compacted_launch(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M, double* pose_dev, const double* Xw_dev,
+                          const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev, int nin_stride,
+                          const PoseCompacted& pc);
 int optimize_current_pose_plain(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M, double* pose_dev, const double* Xw_dev,
-                                const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev);
+                                const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev, int nin_stride);
 int launch_bow_gated(gl_ctx_t* ctx, float nn_ratio, int check_orientation, int B, int N1, int N2, int NN1, int NN2, const float* angle1_dev,
                      const uint8_t* desc1_dev, const uint8_t* has_mp1_dev, const int32_t* nnode1_dev, const int32_t* node_id1_dev,
                      const int32_t* node_ptr1_dev, const int32_t* node_idx1_dev, const float* angle2_dev, const uint8_t* desc2_dev,

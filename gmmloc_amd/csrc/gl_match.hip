@@ -113,7 +113,7 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
   // survives the window test otherwise costs a dependent global load of 32 bytes
   uint4* rec_desc = (uint4*)(rec_ro + ((P.NF + 1) & ~1));  // 2 x uint4 per entry, 16-byte aligned
   __shared__ int s_changed, s_scan[32], s_hist[32], s_keep[4];
-  __shared__ int s_fast, s_cls[17];
+  __shared__ int s_fast, s_cls[17], s_nrw;
   __shared__ double s_pose[8];
   __shared__ int s_dir;
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -322,6 +322,10 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     for (int m = tid; m < NP; m += TM) qorder[atomicAdd(&s_cls[cls_of(m)], 1)] = (uint16_t)m;
     __syncthreads();
   }
+#ifdef GL_MATCH_PROF
+  const long long tp1b = clock64();
+  long long tp_r0 = 0;
+#endif
   constexpr uint32_t EMPTY = 0xffffffffu;
   uint16_t* lst = (uint16_t*)cursor;  // 4 x TM entry indices: a thread's collected candidates (the cursors are dead after the grid build)
   uint4* cache = cache_all + (size_t)f * NP;
@@ -330,11 +334,19 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
   // keys among its candidates NOT owned by a lower query (k0 <= k1 <= k2), their number, and `bad` when a key cannot hold them
   // key while walking: dist << 48 | position << 20 | octave << 12 | feature
   constexpr unsigned long long EMPTY64 = ~0ull;
+#ifdef GL_MATCH_PROF
+  long long pw_setup = 0, pw_loop = 0, pw_flush = 0, pr_a = 0, pr_b = 0, pr_c = 0;
+  int pw_iter = 0, pw_nflush = 0, pw_walks = 0;
+#define PW_T(v) const long long v = clock64()
+#else
+#define PW_T(v)
+#endif
   auto walk = [&](bool act, int m, const Query& q, unsigned long long& k0, unsigned long long& k1, unsigned long long& k2, uint32_t& npass, bool& bad) {
     k0 = k1 = k2 = EMPTY64;
     npass = 0;
     bad = false;
     uint32_t seq = 0;
+    PW_T(pw0);
     const float rr = q.rr, x = q.x, y = q.y;
     int x0 = 1, x1 = 0, y0 = 0, y1 = 0;
     if (act) {
@@ -351,15 +363,18 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     for (int w = 0; w < 8; ++w) dm[w] = act ? mp_desc[(size_t)m * 8 + w] : 0u;
     int cnt = 0;
     auto flush = [&]() {  // Hamming distances of the <= 4 collected candidates, their descriptors requested together
+      PW_T(pf0);
       uint4 da[4], db[4];
-      int roy[4];
+      int roy[4], own[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         roy[j] = 0;
+        own[j] = INT_MAX;
         da[j] = db[j] = make_uint4(0, 0, 0, 0);
         if (j < cnt) {
           const int ej = lst[j * TM + tid];
           roy[j] = rec_ro[ej].y;
+          own[j] = owner[roy[j] >> 8];
           if (DL) {
             da[j] = rec_desc[2 * ej];
             db[j] = rec_desc[2 * ej + 1];
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j < cnt) {
+        if (j < cnt && own[j] >= m) {  // not taken on entry (-1), not owned by an earlier map point
           const int dist = __popc(dm[0] ^ da[j].x) + __popc(dm[1] ^ da[j].y) + __popc(dm[2] ^ da[j].z) + __popc(dm[3] ^ da[j].w) +
                            __popc(dm[4] ^ db[j].x) + __popc(dm[5] ^ db[j].y) + __popc(dm[6] ^ db[j].z) + __popc(dm[7] ^ db[j].w);
           const int oc = roy[j] & 0xff, idx = roy[j] >> 8;
@@ -398,8 +413,18 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
         }
       }
       cnt = 0;
+#ifdef GL_MATCH_PROF
+      pw_flush += clock64() - pf0;
+      ++pw_nflush;
+#endif
     };
     int ix = x0 - 1, e = 0, e1 = 0;
+#ifdef GL_MATCH_PROF
+    dm[0] += __builtin_amdgcn_readfirstlane(dm[0]) & 0;  // (the descriptor's load has landed before the clock is read)
+    const long long pw1 = clock64();
+    pw_setup += pw1 - pw0;
+    ++pw_walks;
+#endif
     bool more = act && x0 <= x1;
     if (s_fast) {
       // level filter as a bit mask over the octaves 0..15 (getFeaturesInArea: minLevel / maxLevel, frame.cpp:121-177)
@@ -411,32 +436,53 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
           if (!(o < minLevel) && !(maxLevel >= 0 && o > maxLevel)) lm |= 1u << o;
       }
       const float4* rec16 = (const float4*)rec_uv;
+      // Round 6: the loop is a chain of LDS round trips, not of instructions (profiles/r6_match_stations.txt: ~0.4 us per iteration with
+      // the CU to itself) - a column's range, then an entry, then its feature's owner, one after the other.  Now an iteration waits ONCE:
+      // the NEXT column's range is requested a column ahead, two entries are read per iteration, and the owner test moved into the
+      // flush, where the (<= 4) owners are requested together with the descriptors.
+      int ne = 0, ne1 = 0;  // the range of column ix + 1
+      if (more) {
+        ne = cell_ptr[x0 * GR + y0];
+        ne1 = cell_ptr[x0 * GR + y1 + 1];
+      }
+      auto entry = [&](const float4 r, int ee) {
+        const int pk = __float_as_int(r.w);
+        bool ok = ((lm >> (pk & 0xff)) & 1u) != 0 && fabsf(r.x - x) < rr && fabsf(r.y - y) < rr;
+        if (ok && r.z > 0) {
+          const float er = q.ur_float ? fabsf(q.ur_f - r.z) : (float)fabs(q.ur_d - (double)r.z);
+          if (er > rr) ok = false;
+        }
+        if (ok) {
+          lst[cnt * TM + tid] = (uint16_t)ee;
+          ++cnt;
+        }
+      };
       while (__any(more)) {
         if (more && e >= e1) {  // next column: cells (ix, y0..y1) are contiguous in the CSR
           ++ix;
           if (ix > x1) {
             more = false;
           } else {
-            e = cell_ptr[ix * GR + y0];
-            e1 = cell_ptr[ix * GR + y1 + 1];
+            e = ne;
+            e1 = ne1;
+            if (ix < x1) {
+              ne = cell_ptr[(ix + 1) * GR + y0];
+              ne1 = cell_ptr[(ix + 1) * GR + y1 + 1];
+            }
           }
         }
-        if (more && e < e1) {
-          const float4 r = rec16[e];
-          const int pk = __float_as_int(r.w);
-          bool ok = ((lm >> (pk & 0xff)) & 1u) != 0 && fabsf(r.x - x) < rr && fabsf(r.y - y) < rr;
-          if (ok) ok = owner[pk >> 8] >= m;  // not taken on entry (-1), not owned by an earlier map point
-          if (ok && r.z > 0) {
-            const float er = q.ur_float ? fabsf(q.ur_f - r.z) : (float)fabs(q.ur_d - (double)r.z);
-            if (er > rr) ok = false;
-          }
-          if (ok) {
-            lst[cnt * TM + tid] = (uint16_t)e;
-            ++cnt;
-          }
-          ++e;
-        }
+        const bool h0 = more && e < e1, h1 = more && e + 1 < e1;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (h0) r0 = rec16[e];
+        if (h1) r1 = rec16[e + 1];
+        if (h0) entry(r0, e);
         if (__any(cnt == 4)) flush();
+        if (h1) entry(r1, e + 1);
+        if (__any(cnt == 4)) flush();
+        e += h1 ? 2 : (h0 ? 1 : 0);
+#ifdef GL_MATCH_PROF
+        ++pw_iter;
+#endif
       }
     } else {
       while (__any(more)) {
@@ -485,6 +531,9 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
       }
     }
     if (__any(cnt > 0)) flush();
+#ifdef GL_MATCH_PROF
+    pw_loop += clock64() - pw1;
+#endif
   };
   // the reference's verdict on (best, second best) = the two smallest keys
   auto pack = [&](unsigned long long k) -> uint32_t {
@@ -507,15 +556,26 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
   int rewalks = 0;
 #endif
   const int nq_rounds = ((NP + TM - 1) / TM) * TM;  // every thread makes the same number of trips (the walk is wave-uniform)
+  // Round 6: the queries that must walk again in a later round (a few per cent) are LISTED and walked densely - a wave per 64 of them -
+  // instead of where they sit: one such query in a wave made the whole wave walk, and round 2 cost half of round 1
+  // (profiles/r6_match_stations.txt).  The list lives behind the walk's candidate lists in the grid build's dead cursors; a query that
+  // finds it full walks in place, as before.
+  uint16_t* rw_list = lst + 4 * TM;
+  constexpr int RW_CAP = 2 * NCELL - 4 * TM;
+  static_assert(RW_CAP >= 1024, "the cursors hold the walk's lists and the list of queries that walk again");
   while (true) {
     for (int i = tid; i < NF; i += TM) owner_n[i] = feat_taken[i] ? -1 : INT_MAX;
-    if (tid == 0) s_changed = 0;
+    if (tid == 0) {
+      s_changed = 0;
+      s_nrw = 0;
+    }
     __syncthreads();
+    PW_T(pr0);
     for (int sq = tid; sq < nq_rounds; sq += TM) {
       const bool in = sq < NP;
       const int m = in ? (int)qorder[sq] : NP;  // (the same thread has the query in every round: it reads its own record)
       int bestIdx = -1;
-      bool need_walk = in && rounds == 0;
+      bool need_walk = in && rounds == 0, listed = false;
       uint4 rec = make_uint4(EMPTY, EMPTY, EMPTY, 0);
       if (in && rounds > 0) {  // the record of round 1 minus what lower queries own now
         rec = cache[m];
@@ -530,8 +590,17 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
             ++nav;
           }
         }
-        if (rec.w != EMPTY && (nav >= 2 || rec.w <= 3u)) bestIdx = decide(unpack(a), unpack(b), MODE == 0);
-        else need_walk = true;
+        if (rec.w != EMPTY && (nav >= 2 || rec.w <= 3u)) {
+          bestIdx = decide(unpack(a), unpack(b), MODE == 0);
+        } else {
+          const int pos = atomicAdd(&s_nrw, 1);
+          if (pos < RW_CAP) {
+            rw_list[pos] = (uint16_t)m;
+            listed = true;
+          } else {
+            need_walk = true;
+          }
+        }
       }
       if (__any(need_walk)) {
         Query q;
@@ -555,12 +624,45 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
 #endif
         }
       }
-      if (in) {
+      if (in && !listed) {
         choice[m] = bestIdx;
         if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
       }
     }
+    PW_T(pr1);
+    if (rounds > 0) {  // the listed queries, dealt over ALL waves (a few lanes of each: a walk lasts as long as the wave's longest, and one
+      __syncthreads();  // wave walking alone was the round's tail); the owners they read are the previous round's: any order
+      constexpr int NWV = TM / 64;
+      const int nrw = min(s_nrw, RW_CAP);
+      for (int k0_ = 0; k0_ < nrw; k0_ += TM) {
+        const int k = k0_ + (tid & 63) * NWV + (tid >> 6);
+        const bool in = k < nrw;
+        const int m = in ? (int)rw_list[k] : NP;
+        Query q;
+        q.valid = false;
+        q.x = q.y = q.rr = 0.f;
+        q.minLevel = q.maxLevel = -1;
+        q.ratio_test = MODE == 0;
+        q.ur_float = MODE == 1;
+        q.ur_d = 0.0;
+        q.ur_f = 0.f;
+        if (in) q = make_query(m);
+        unsigned long long k0, k1, k2;
+        uint32_t npass;
+        bool bad;
+        walk(in && q.valid, m, q, k0, k1, k2, npass, bad);
+        if (in) {
+          const int bestIdx = decide(k0, k1, MODE == 0);
+          choice[m] = bestIdx;
+          if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
+#ifdef GL_MATCH_PROF
+          ++rewalks;
+#endif
+        }
+      }
+    }
     __syncthreads();
+    PW_T(pr2);
     int ch = 0;
     for (int i = tid; i < NF; i += TM) {
       const int o = owner_n[i];
@@ -570,6 +672,14 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     if (ch) s_changed = 1;
     __syncthreads();
     ++rounds;
+#ifdef GL_MATCH_PROF
+    if (rounds == 1) tp_r0 = clock64();
+    else {
+      pr_a += pr1 - pr0;
+      pr_b += pr2 - pr1;
+      pr_c += clock64() - pr2;
+    }
+#endif
     if (!s_changed || rounds > NP + 1) break;
     __syncthreads();
   }
@@ -667,6 +777,19 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     feat_match[1] = (int)((tp2 - tp1) >> 4);
     feat_match[2] = (int)((clock64() - tp2) >> 4);
     feat_match[3] = rounds;
+    feat_match[4] = (int)((tp1b - tp1) >> 4);   // the queries sorted by window class
+    feat_match[5] = (int)((tp_r0 - tp1b) >> 4);  // round 1 (every query walks its window)
+    feat_match[6] = rewalks;                     // thread 0's walks in later rounds
+    feat_match[7] = (int)(pw_setup >> 4);        // thread 0's walks: query set-up (its descriptor's load), ...
+    feat_match[8] = (int)(pw_loop >> 4);         // ... the window loop with its flushes, ...
+    feat_match[9] = (int)(pw_flush >> 4);        // ... of which flushes
+    feat_match[10] = pw_iter;                    // iterations of the window loop, flushes, walks
+    feat_match[11] = pw_nflush;
+    feat_match[12] = pw_walks;
+    feat_match[13] = s_nrw;
+    feat_match[14] = (int)(pr_a >> 4);           // later rounds: the queries from their records, the listed walks + barrier, the owners compared
+    feat_match[15] = (int)(pr_b >> 4);
+    feat_match[16] = (int)(pr_c >> 4);                      // queries listed to walk again in the last round
 #endif
   }
 }

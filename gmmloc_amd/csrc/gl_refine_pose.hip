@@ -22,6 +22,7 @@
 
 #include "gl_device.hpp"
 #include "gl_internal.hpp"
+#include "gl_pose_compact.hpp"
 
 #pragma clang fp contract(fast)
 
@@ -544,28 +545,43 @@ GL_DEV void pose_eval(const PoseKParams& kp, const double* __restrict__ s2tab, c
 #ifndef GL_POSE_WPS
 #define GL_POSE_WPS 3  // waves per SIMD the register budget is capped for (measured: 3 > 2 > 4, tools/pose_ab.py)
 #endif
+// B problems of stride M as a launch sees them.  On-chip shapes (REGS != 0) can write an edge's final flag straight into ANOTHER problem:
+// src_of[f M + slot] = the edge's place in a problem of stride M_dst whose flags are outlier_dst (a compacted problem answering for the
+// caller's, gl_pose_compact.hpp).  skip: the frame's workgroup returns at once when (skip[f] != 0) == skip_if (the compacted and the
+// full-stride problem of a frame: one of the two runs).
+struct PoseProb {
+  int M, G, S;
+  double* pose_io;
+  const double* Xw;
+  const double* obs;
+  const int32_t* oct;
+  uint8_t* outlier;
+  int32_t* ninlier;
+  int nin_stride;
+  double* chi2;
+  const int32_t* src_of;
+  uint8_t* outlier_dst;
+  int M_dst;
+  const int32_t* skip;
+  int skip_if;
+};
+
 // NW = waves per frame the instance is compiled for (register budget): 1 for large batches (GL_POSE_WPS frames per
 // SIMD, no barrier does anything), 4 / 8 when the frames are fewer than the SIMDs; launched with nw <= NW waves
 // (never more than the frame has groups).  Every wave repeats the serial part (solve, pose update) on its own so that
 // no broadcast is needed.
 template <int NW, int REGS>  // REGS: 0 edges from global memory, 1 in registers, 2 coordinates in LDS, 3 five groups on four waves (registers)
-__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS == 2) ? 2 : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, int M, int G, int S,
-                                                                 double* __restrict__ pose_io,
-                                                                 const double* __restrict__ Xw_all,
-                                                                 const double* __restrict__ obs_all,
-                                                                 const int32_t* __restrict__ oct_all,
-                                                                 uint8_t* __restrict__ outlier_all,
-                                                                 int32_t* __restrict__ ninlier,
-                                                                 double* __restrict__ chi2_all) {
+__device__ __forceinline__ void pose_frame(const PoseKParams& kp, const int f, const PoseProb& pr) {
   __shared__ double s2tab[16];  // {sx[8], sy[8]}
   __shared__ double Hbuf[64];       // current / trial system {H upper (21), b (6), chi2}: two rows that swap roles when a trial is accepted
   double* H = Hbuf;                 // (no copy, no barrier pair: the next writer of the row that was current is wave 0 behind the next
   double* Hn = Hbuf + 32;           //  evaluation's two barriers, every reader of it is through by then)
   __shared__ double part[NW];       // per-wave counts
   extern __shared__ double red[];   // G x 32 group totals (then, REGS == 2: 4 slots x 6 coordinates x threads)
+  const int M = pr.M, G = pr.G, S = pr.S;
   double* xo = red + G * 32;
-  const int f = blockIdx.x, lane = threadIdx.x;  // "lane" = thread of the workgroup's waves
-  if (f >= B) return;
+  const int lane = threadIdx.x;  // "lane" = thread of the workgroup's waves
+  if (pr.skip && (pr.skip[f] != 0) == (pr.skip_if != 0)) return;
   const int e0 = lane, es = blockDim.x;  // counting / gating loops: any order (integers, per-edge decisions)
   if (lane == 0) {
 #pragma unroll
@@ -575,11 +591,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     }
   }
   __syncthreads();  // single wave: orders the table write before the reads
-  const double* Xw = Xw_all + (size_t)f * M * 3;
-  const double* obs = obs_all + (size_t)f * M * 3;
-  const int32_t* octave = oct_all + (size_t)f * M;
-  uint8_t* level = outlier_all + (size_t)f * M;  // is_outlier_ <=> level 1
-  double* chi2_e = chi2_all + (size_t)f * M;
+  const double* Xw = pr.Xw + (size_t)f * M * 3;
+  const double* obs = pr.obs + (size_t)f * M * 3;
+  const int32_t* octave = pr.oct + (size_t)f * M;
+  uint8_t* level = pr.outlier + (size_t)f * M;  // is_outlier_ <=> level 1
+  double* chi2_e = pr.chi2 + (size_t)f * M;
+  double* const pose_io = pr.pose_io;
+  int32_t* const ninl_f = pr.ninlier + (size_t)f * pr.nin_stride;
+  // an edge's final flag (on-chip shapes): into the problem's own array, or through src_of into the problem it was compacted from
+  auto put_flag = [&](int idx, uint8_t v) {
+    if (pr.src_of) pr.outlier_dst[(size_t)f * pr.M_dst + pr.src_of[(size_t)f * M + idx]] = v;
+    else level[idx] = v;
+  };
 
   // graph construction: count edges, clear outlier flags (tracking_opt.cpp:60-137)
   double cnt = 0.0;
@@ -626,10 +649,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     if (REGS) {  // the on-chip shapes keep the flags in registers: the reset of :63-69 happened before this return
 #pragma unroll
       for (int i = 0; i < pose_slots<REGS>(); ++i) {
-        if (E.oc[i] >= 0) level[pose_edge_index<REGS>(S, i)] = 0;
+        if (E.oc[i] >= 0) put_flag(pose_edge_index<REGS>(S, i), 0);
       }
     }
-    if (lane == 0) ninlier[f] = 0;
+    if (lane == 0) *ninl_f = 0;
     return;
   }
   PoseRt P0;
@@ -776,7 +799,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
   if (REGS) {
 #pragma unroll
     for (int i = 0; i < pose_slots<REGS>(); ++i)
-      if (E.oc[i] >= 0) level[pose_edge_index<REGS>(S, i)] = (uint8_t)E.lv[i];
+      if (E.oc[i] >= 0) put_flag(pose_edge_index<REGS>(S, i), (uint8_t)E.lv[i]);
   }
   if (lane == 0) {
     SE3 T;
@@ -786,87 +809,51 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS =
     T.t[2] = P.t[2];
     normalize_rotation(T);
     se3_store(T, pose_io + (size_t)f * 7);
-    ninlier[f] = n_init - nbad;
+    *ninl_f = n_init - nbad;
 #ifdef GL_POSE_PROF
     if (REGS) {  // {entry barrier, edges, reduce-scatter, barriers + blocks, solve, pose update, kernel total}; ninlier = passes
       g_pf[7] = clock64() - tk0;
       for (int i = 0; i < 6; ++i) pose_io[(size_t)f * 7 + i] = (double)g_pf[i];
       pose_io[(size_t)f * 7 + 6] = (double)g_pf[7];
-      ninlier[f] = (int)g_pf[6];
+      *ninl_f = (int)g_pf[6];
     }
 #endif
   }
 }
 
-// ---- compacted problems (round 6) ---------------------------------------------------------------------------------------------------
-// The kernel costs what its SLOTS cost, and the reference's frame has one slot per FEATURE (1 200) of which a few hundred hold a map
-// point: five groups of the summation order where <= 1 024 slots are four, every wave evaluating four mostly empty slots per pass.
-// k_pose_compact (one workgroup per frame) moves the edges, in slot order, to the front of a problem of stride MC <= 1 024 and DEALS the
-// list's chunks over the groups (chunk c -> group c % G, its c / G-th chunk: the waves of the frame-at-a-time shapes get equal shares and
-// skip the slots nobody uses); a frame with more than MC edges keeps its full-stride problem (oct_f: the caller's octaves for those
-// frames, -1 everywhere else, so that the second launch returns at once for the frames that fitted).  k_pose_scatter puts the flags back.
-__global__ __launch_bounds__(256) void k_pose_compact(int B, int M, int MC, const double* __restrict__ Xw, const double* __restrict__ obs,
-                                                     const int32_t* __restrict__ oct, double* __restrict__ Xw_c, double* __restrict__ obs_c,
-                                                     int32_t* __restrict__ oct_c, uint8_t* __restrict__ outl_c, int32_t* __restrict__ slot_of,
-                                                     int32_t* __restrict__ ovf, int32_t* __restrict__ oct_f) {
-  __shared__ int s_w[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (b >= B) return;
-  const int32_t* oc = oct + (size_t)b * M;
-  int cnt = 0;
-  for (int i = tid; i < M; i += 256) cnt += oc[i] >= 0;
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if (lane == 0) s_w[wave] = cnt;
-  __syncthreads();
-  const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-  const bool over = total > MC;
-  if (tid == 0) ovf[b] = over ? 1 : 0;
-  const int nch = (MC + 63) / 64, DG = (nch + 3) / 4, DS = (nch + DG - 1) / DG;
-  const bool deal = DG * DS == nch && (MC & 63) == 0;
-  for (int s_ = tid; s_ < MC; s_ += 256) {
-    oct_c[(size_t)b * MC + s_] = -1;
-    outl_c[(size_t)b * MC + s_] = 0;
-  }
-  __syncthreads();
-  int base = 0;
-  for (int i0 = 0; i0 < M; i0 += 256) {
-    const int i = i0 + tid;
-    const bool act = i < M && oc[i] >= 0;
-    const unsigned long long bal = __ballot(act);
-    if (lane == 0) s_w[wave] = __popcll(bal);
-    __syncthreads();
-    int pre = base + __popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) pre += s_w[w];
-    const int round_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    if (i < M) {
-      const size_t g = (size_t)b * M + i;
-      if (oct_f) oct_f[g] = over ? oc[i] : -1;
-      const bool comp = act && !over;
-      const int cch = pre >> 6, slot = deal ? (((cch % DG) * DS + cch / DG) << 6) + (pre & 63) : pre;
-      slot_of[g] = comp ? slot : -1;
-      if (comp) {
-        const size_t sc = (size_t)b * MC + slot;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          Xw_c[sc * 3 + j] = Xw[g * 3 + j];
-          obs_c[sc * 3 + j] = obs[g * 3 + j];
-        }
-        oct_c[sc] = oc[i];
-      }
-    }
-    base += round_total;
-    __syncthreads();
-  }
+template <int NW, int REGS>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? GL_POSE_WPS : (NW == 4 && REGS == 2) ? 2 : (NW + 3) / 4) void k_optimize_current_pose(PoseKParams kp, int B, PoseProb pr) {
+  if ((int)blockIdx.x < B) pose_frame<NW, REGS>(kp, (int)blockIdx.x, pr);
 }
+// ---- compacted problems (round 6; gl_pose_compact.hpp) ---------------------------------------------------------------------------------
+struct PlainSrc {  // edge i of a caller's problem
+  const double* Xw;
+  const double* obs;
+  const int32_t* oct;
+  __device__ int octave(int i) const { return oct[i]; }
+  __device__ void load(int i, double* X, double* O) const {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      X[j] = Xw[(size_t)i * 3 + j];
+      O[j] = obs[(size_t)i * 3 + j];
+    }
+  }
+};
+__global__ __launch_bounds__(256) void k_pose_compact(int B, int M, const double* __restrict__ Xw, const double* __restrict__ obs,
+                                                     const int32_t* __restrict__ oct, gl::PoseCompacted pc) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const PlainSrc src = {Xw + (size_t)b * M * 3, obs + (size_t)b * M * 3, oct + (size_t)b * M};
+  gl::pose_compact_frame<256>(src, b, M, pc);
+}
+// the flags of compacted problems whose launch shape keeps them in memory (large batches), back to the caller's slots
 __global__ __launch_bounds__(256) void k_pose_scatter(int B, int M, int MC, const int32_t* __restrict__ slot_of, const int32_t* __restrict__ ovf,
-                                                     const uint8_t* __restrict__ outl_c, const int32_t* __restrict__ ninl_c,
-                                                     const int32_t* __restrict__ ninl_f, uint8_t* __restrict__ outlier, int32_t* __restrict__ ninl) {
+                                                     const uint8_t* __restrict__ outl_c, uint8_t* __restrict__ outlier) {
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= (size_t)B * M) return;
   const size_t b = g / M;
   const int s_ = slot_of[g];
   if (!ovf[b] && s_ >= 0) outlier[g] = outl_c[b * MC + s_];  // (the flags of the slots without an edge stay the caller's)
-  if (g == b * M) ninl[b] = (ovf[b] && ninl_f) ? ninl_f[b] : ninl_c[b];
 }
 
 PoseKParams pose_kparams(const gl_camera* cam, const gl_params* prm) {
@@ -885,79 +872,162 @@ PoseKParams pose_kparams(const gl_camera* cam, const gl_params* prm) {
   return kp;
 }
 
-// the launch proper: B problems of stride M (scratch: B x max(M, 1) doubles, the edges' chi2)
-int pose_launch(gl::Ctx* c, const PoseKParams& kp, int B, int M, double* pose_dev, const double* Xw_dev, const double* obs_dev, const int32_t* octave_dev,
-                uint8_t* outlier_dev, int32_t* ninlier_dev, void* scratch) {
-  {
-    gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
-    // the canonical summation order of a frame of stride M (see group_totals28): G groups of S <= 4 chunks of 64 edges
-    const int nch = std::max(1, (M + 63) / 64), G = (nch + 3) / 4, S = (nch + G - 1) / G;
-    // Waves per frame and where the edges live (tools/pose_ab.py, tools/latency.py; the sums are built in the same order
-    // whatever the shape, so it never shows in the results; option pose_waves (1 | 4 | 8) forces the cap, pose_regs = 0 the
-    // global-memory variants):
-    //  * a wave per group of <= 256 edges with the frame's edges ON CHIP whenever that fills the CU's wave slots: frames of
-    //    <= 4 groups - in registers (424 VGPRs, one workgroup per CU) while every frame gets a CU of its own, coordinates in
-    //    LDS (two workgroups per CU) beyond; frames of 5 - 8 groups: coordinates in LDS, eight waves.  One frame of 1 000
-    //    edges 0.26 ms (0.40 from global memory, 1.2 ms on one wave); 4 096 full frames of 1 000 edges 3.2 ms (4.9 on one
-    //    wave each), of 2 000 edges 7.0 ms (11.4), of 300 edges 1.49 ms (1.75);
-    //  * one wave per frame, edges from global memory, 12 frames per CU in flight and no barrier, for the large batches whose
-    //    wave-per-group shape would leave wave slots empty: 3 groups (6 of 8 slots: 2.7 vs 2.5 ms ragged), 5 - 7 groups
-    //    (config 3, 2 149 frames of up to 1 200 edges: 0.78 M frames/s against 0.74 M).
-    const bool big = B > 1536;
-    int nw = std::min(G, 8);
-    if (big && !(G <= 4 && G != 3) && G != 8) nw = 1;
-    if (c->opt.pose_waves > 0) nw = std::min(G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
-    size_t lds = (size_t)G * 32 * sizeof(double);
-#define GL_POSE_LAUNCH(NWC, REGS) \
-  k_optimize_current_pose<NWC, REGS><<<B, 64 * nw, lds, c->stream>>>(kp, B, M, G, S, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, \
-                                                                     ninlier_dev, (double*)scratch)
-    const bool on_chip = nw > 1 && nw == G && c->opt.pose_regs != 0;  // a wave per group: the frame's edges stay on chip
-    // five groups at the frame-at-a-time caller (every frame has a CU): four waves, five edges per thread (REGS == 3)
-    const bool five = G == 5 && on_chip && B <= c->ncu && c->opt.pose_waves <= 0;
-    if (five) {
-      nw = 4;
-      lds += (size_t)28 * 256 * sizeof(double);
-      GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<4, 3>, lds));
-      GL_POSE_LAUNCH(4, 3);
-    } else if (nw > 4) {
-      if (on_chip) {
-        lds += (size_t)24 * 64 * nw * sizeof(double);
-        GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<8, 2>, lds));
-        GL_POSE_LAUNCH(8, 2);
-      } else {
-        GL_POSE_LAUNCH(8, 0);
-      }
-    } else if (nw > 1) {
-      if (on_chip && B > c->ncu) {
-        lds += (size_t)24 * 64 * nw * sizeof(double);
-        GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<4, 2>, lds));
-        GL_POSE_LAUNCH(4, 2);
-      } else if (on_chip) {
-        GL_POSE_LAUNCH(4, 1);
-      } else {
-        GL_POSE_LAUNCH(4, 0);
-      }
-    } else {
-      GL_POSE_LAUNCH(1, 0);
-    }
-#undef GL_POSE_LAUNCH
+// the launch shape of B problems of stride M (tools/pose_ab.py, tools/latency.py; the sums are built in the same order whatever the
+// shape, so it never shows in the results; option pose_waves (1 | 4 | 8) forces the cap, pose_regs = 0 the global-memory variants):
+//  * a wave per group of <= 256 edges with the frame's edges ON CHIP whenever that fills the CU's wave slots: frames of
+//    <= 4 groups - in registers (424 VGPRs, one workgroup per CU) while every frame gets a CU of its own, coordinates in
+//    LDS (two workgroups per CU) beyond; frames of 5 - 8 groups: coordinates in LDS, eight waves.  One frame of 1 000
+//    edges 0.26 ms (0.40 from global memory, 1.2 ms on one wave); 4 096 full frames of 1 000 edges 3.2 ms (4.9 on one
+//    wave each), of 2 000 edges 7.0 ms (11.4), of 300 edges 1.49 ms (1.75);
+//  * one wave per frame, edges from global memory, 12 frames per CU in flight and no barrier, for the large batches whose
+//    wave-per-group shape would leave wave slots empty: 3 groups (6 of 8 slots: 2.7 vs 2.5 ms ragged), 5 - 7 groups
+//    (config 3, 2 149 frames of up to 1 200 edges: 0.78 M frames/s against 0.74 M);
+//  * five groups at the frame-at-a-time caller (every frame has a CU): four waves, five edges per thread (REGS == 3).
+struct PoseShape {
+  int G, S, nw, NWC, REGS;
+  size_t lds;
+};
+PoseShape pose_shape(const gl::Ctx* c, int B, int M) {
+  PoseShape h;
+  // the canonical summation order of a frame of stride M (see group_totals28): G groups of S <= 4 chunks of 64 edges
+  const int nch = std::max(1, (M + 63) / 64);
+  h.G = (nch + 3) / 4;
+  h.S = (nch + h.G - 1) / h.G;
+  const bool big = B > 1536;
+  int nw = std::min(h.G, 8);
+  if (big && !(h.G <= 4 && h.G != 3) && h.G != 8) nw = 1;
+  if (c->opt.pose_waves > 0) nw = std::min(h.G, (int)c->opt.pose_waves >= 8 ? 8 : (int)c->opt.pose_waves >= 4 ? 4 : 1);
+  h.lds = (size_t)h.G * 32 * sizeof(double);
+  const bool on_chip = nw > 1 && nw == h.G && c->opt.pose_regs != 0;  // a wave per group: the frame's edges stay on chip
+  const bool five = h.G == 5 && on_chip && B <= c->ncu && c->opt.pose_waves <= 0;
+  if (five) {
+    nw = 4;
+    h.lds += (size_t)28 * 256 * sizeof(double);
+    h.NWC = 4;
+    h.REGS = 3;
+  } else if (nw > 4) {
+    h.NWC = 8;
+    h.REGS = on_chip ? 2 : 0;
+    if (on_chip) h.lds += (size_t)24 * 64 * nw * sizeof(double);
+  } else if (nw > 1) {
+    h.NWC = 4;
+    h.REGS = on_chip ? (B > c->ncu ? 2 : 1) : 0;
+    if (h.REGS == 2) h.lds += (size_t)24 * 64 * nw * sizeof(double);
+  } else {
+    h.NWC = 1;
+    h.REGS = 0;
   }
+  h.nw = nw;
+  return h;
+}
+PoseProb pose_prob(const PoseShape& h, int M, double* pose, const double* Xw, const double* obs, const int32_t* oct, uint8_t* outlier, int32_t* ninlier,
+                   int nin_stride, void* chi2) {
+  PoseProb p;
+  p.M = M;
+  p.G = h.G;
+  p.S = h.S;
+  p.pose_io = pose;
+  p.Xw = Xw;
+  p.obs = obs;
+  p.oct = oct;
+  p.outlier = outlier;
+  p.ninlier = ninlier;
+  p.nin_stride = nin_stride;
+  p.chi2 = (double*)chi2;
+  p.src_of = nullptr;
+  p.outlier_dst = nullptr;
+  p.M_dst = 0;
+  p.skip = nullptr;
+  p.skip_if = 0;
+  return p;
+}
+// the launch proper
+int pose_launch(gl::Ctx* c, const PoseKParams& kp, int B, const PoseShape& h, const PoseProb& p) {
+  gl::TimerScope ts(c, GL_TIMER_REFINE_POSE);
+#define GL_POSE_LAUNCH(NWC, REGS)                                                                              \
+  do {                                                                                                         \
+    GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_optimize_current_pose<NWC, REGS>, h.lds));                 \
+    k_optimize_current_pose<NWC, REGS><<<B, 64 * h.nw, h.lds, c->stream>>>(kp, B, p);                          \
+  } while (0)
+  if (h.NWC == 4 && h.REGS == 3) GL_POSE_LAUNCH(4, 3);
+  else if (h.NWC == 8 && h.REGS == 2) GL_POSE_LAUNCH(8, 2);
+  else if (h.NWC == 8) GL_POSE_LAUNCH(8, 0);
+  else if (h.NWC == 4 && h.REGS == 2) GL_POSE_LAUNCH(4, 2);
+  else if (h.NWC == 4 && h.REGS == 1) GL_POSE_LAUNCH(4, 1);
+  else if (h.NWC == 4) GL_POSE_LAUNCH(4, 0);
+  else GL_POSE_LAUNCH(1, 0);
+#undef GL_POSE_LAUNCH
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
 
 }  // namespace
 
-// gl_optimize_current_pose without the automatic compaction (the tracked-frame chain compacts while it gathers its problems)
+// gl_optimize_current_pose without the compaction
 int gl::optimize_current_pose_plain(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M, double* pose_dev, const double* Xw_dev,
-                                    const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev) {
+                                    const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev, int nin_stride) {
   gl::Ctx* c = gl::C(ctx);
   GL_HIP(hipSetDevice(c->device));
   void* scratch = nullptr;
   const size_t chi_bytes = (((size_t)B * (M > 0 ? M : 1) * sizeof(double) + 63) / 64) * 64;
   const int rc = gl::ctx_scratch(c, chi_bytes, &scratch);
   if (rc != GL_OK) return rc;
-  return pose_launch(c, pose_kparams(cam, prm), B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, scratch);
+  const PoseShape h = pose_shape(c, B, M);
+  return pose_launch(c, pose_kparams(cam, prm), B, h, pose_prob(h, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, nin_stride, scratch));
+}
+
+// B problems of M slots whose compacted form `pc` exists (k_pose_compact, or the tracked-frame chain's gather): the compacted problem of
+// every frame whose edges fitted, the full-stride one of the others; flags into outlier_dev (stride M), inlier counts into
+// ninlier_dev[f * nin_stride].  Launches: the compacted problems', the full-stride problems' where M > MC (a frame's workgroup returns at
+// once in one of the two) and - where the compacted problems' shape keeps its flags in memory - k_pose_scatter.
+int gl::pose_compacted_launch(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M, double* pose_dev, const double* Xw_dev,
+                              const double* obs_dev, const int32_t* octave_dev, uint8_t* outlier_dev, int32_t* ninlier_dev, int nin_stride,
+                              const gl::PoseCompacted& pc) {
+  gl::Ctx* c = gl::C(ctx);
+  GL_HIP(hipSetDevice(c->device));
+  const int MC = pc.MC;
+  const bool can_overflow = M > MC;
+  void *chi_c = pc.chi_c, *chi_f = pc.chi_f;
+  if (!chi_c || (can_overflow && !chi_f)) {
+    auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
+    void* scratch = nullptr;
+    const int rc = gl::ctx_scratch(c, up((size_t)B * MC * 8) + (can_overflow ? up((size_t)B * M * 8) : 0), &scratch);
+    if (rc != GL_OK) return rc;
+    chi_c = scratch;
+    chi_f = can_overflow ? (char*)scratch + up((size_t)B * MC * 8) : nullptr;
+  }
+  const PoseKParams kp = pose_kparams(cam, prm);
+  const PoseShape hc = pose_shape(c, B, MC);
+  PoseProb p = pose_prob(hc, MC, pose_dev, pc.Xw_c, pc.obs_c, pc.oct_c, pc.outl_c, ninlier_dev, nin_stride, chi_c);
+  p.skip = pc.ovf;
+  p.skip_if = 1;
+  const bool direct = hc.REGS != 0;  // the on-chip shapes put the flags where they belong themselves
+  if (direct) {
+    p.src_of = pc.src_of;
+    p.outlier_dst = outlier_dev;
+    p.M_dst = M;
+  }
+  if (!can_overflow) {
+    const int rc = pose_launch(c, kp, B, hc, p);
+    if (rc != GL_OK) return rc;
+  } else {
+    const PoseShape hf = pose_shape(c, B, M);
+    PoseProb pf = pose_prob(hf, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, nin_stride, chi_f);
+    pf.skip = pc.ovf;
+    pf.skip_if = 0;
+    // (both problems of a frame in ONE launch - workgroup f the compacted, B + f the full-stride one - was built and measured: the
+    //  kernel that holds both bodies is 9 us slower per call than the launch it saves, 245 spilled SGPRs; profiles/r6_chain_fused_ab.txt)
+    int rc = pose_launch(c, kp, B, hc, p);
+    if (rc != GL_OK) return rc;
+    rc = pose_launch(c, kp, B, hf, pf);
+    if (rc != GL_OK) return rc;
+  }
+  if (!direct) {
+    const size_t nm = (size_t)B * M;
+    k_pose_scatter<<<(unsigned)((nm + 255) / 256), 256, 0, c->stream>>>(B, M, MC, pc.slot_of, pc.ovf, pc.outl_c, outlier_dev);
+    GL_HIP(hipGetLastError());
+  }
+  return GL_OK;
 }
 
 extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, const gl_params* prm, int B, int M,
@@ -973,44 +1043,20 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   // compacted to 1 024 where their edges fit (0.31 -> 0.21 ms for one frame of 420 edges); 1: every problem of more than 256 slots
   // (pays when at most about half of the slots hold an edge); 0: never.  Decisions and tolerances as ever; the bits of a frame are a
   // function of the frame and this option, never of the batch.
-  const int mode = (int)c->opt.pose_compact;
-  const bool compact = mode != 0 && M > (mode > 0 ? 256 : 1024);
-  if (!compact) return gl::optimize_current_pose_plain(ctx, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev);
+  const int MC = gl::pose_compact_stride((int)c->opt.pose_compact, M);
+  if (MC == 0) return gl::optimize_current_pose_plain(ctx, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, 1);
   GL_HIP(hipSetDevice(c->device));
-  const int MC = std::min(1024, 256 * ((M + 255) / 256));
-  const bool can_overflow = M > MC;
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
-  const size_t nc = (size_t)B * MC, nm = (size_t)B * M;
+  const bool can_overflow = M > MC;
+  const size_t chi_c_bytes = up((size_t)B * MC * 8), chi_f_bytes = can_overflow ? up((size_t)B * M * 8) : 0;
   void* scratch = nullptr;
-  int rc = gl::ctx_scratch(c, up(nc * 8) + (can_overflow ? up(nm * 8) + up(nm * 4) : 0) + 2 * up(nc * 24) + up(nc * 4) + up(nm * 4) + 3 * up((size_t)B * 4) + up(nc), &scratch);
+  const int rc = gl::ctx_scratch(c, chi_c_bytes + chi_f_bytes + gl::pose_compacted_bytes(B, M, MC), &scratch);
   if (rc != GL_OK) return rc;
-  char* s = (char*)scratch;
-  auto take = [&](size_t bytes) {
-    char* p = s;
-    s += up(bytes);
-    return (void*)p;
-  };
-  void* chi_c = take(nc * 8);
-  void* chi_f = can_overflow ? take(nm * 8) : nullptr;
-  int32_t* oct_f = can_overflow ? (int32_t*)take(nm * 4) : nullptr;
-  double* Xw_c = (double*)take(nc * 24);
-  double* obs_c = (double*)take(nc * 24);
-  int32_t* oct_c = (int32_t*)take(nc * 4);
-  int32_t* slot_of = (int32_t*)take(nm * 4);
-  int32_t* ovf = (int32_t*)take((size_t)B * 4);
-  int32_t* ninl_c = (int32_t*)take((size_t)B * 4);
-  int32_t* ninl_f = (int32_t*)take((size_t)B * 4);
-  uint8_t* outl_c = (uint8_t*)take(nc);
-  const PoseKParams kp = pose_kparams(cam, prm);
-  k_pose_compact<<<B, 256, 0, c->stream>>>(B, M, MC, Xw_dev, obs_dev, octave_dev, Xw_c, obs_c, oct_c, outl_c, slot_of, ovf, oct_f);
+  gl::PoseCompacted pc;
+  gl::pose_compacted_place((char*)scratch + chi_c_bytes + chi_f_bytes, B, M, MC, &pc);
+  pc.chi_c = scratch;
+  pc.chi_f = can_overflow ? (char*)scratch + chi_c_bytes : nullptr;
+  k_pose_compact<<<B, 256, 0, c->stream>>>(B, M, Xw_dev, obs_dev, octave_dev, pc);
   GL_HIP(hipGetLastError());
-  rc = pose_launch(c, kp, B, MC, pose_dev, Xw_c, obs_c, oct_c, outl_c, ninl_c, chi_c);
-  if (rc != GL_OK) return rc;
-  if (can_overflow) {
-    rc = pose_launch(c, kp, B, M, pose_dev, Xw_dev, obs_dev, oct_f, outlier_dev, ninl_f, chi_f);
-    if (rc != GL_OK) return rc;
-  }
-  k_pose_scatter<<<(unsigned)((nm + 255) / 256), 256, 0, c->stream>>>(B, M, MC, slot_of, ovf, outl_c, ninl_c, can_overflow ? ninl_f : nullptr, outlier_dev, ninlier_dev);
-  GL_HIP(hipGetLastError());
-  return GL_OK;
+  return gl::pose_compacted_launch(ctx, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, 1, pc);
 }

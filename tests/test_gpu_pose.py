@@ -185,6 +185,13 @@ def test_optimize_current_pose_compacted_problems(gpu, oracle, map_v1, gt_sync, 
         assert et < TOL_T and er < TOL_R and n1[b] == nin_r and np.array_equal(o1[b][~no_edge], outl_r[~no_edge])
     ps, os_, ns = run(frames[2:3], flags[2:3])
     assert np.array_equal(ps[0], p1[2]) and np.array_equal(os_[0], o1[2])
+    if (mode, M) in ((-1, 1200), (1, 700)):
+        # a batch large enough for the one-wave-per-frame shapes (edges and flags in memory: the full-stride problems of 1 200 slots,
+        # the compacted ones of stride 768; the flags come back through k_pose_scatter): the same bits as in the batch of six
+        rep = 260
+        pb, ob, nb = run(frames * rep, np.tile(flags, (rep, 1)))
+        for r in (0, 131, rep - 1):
+            assert np.array_equal(pb[6 * r:6 * r + 6], p1) and np.array_equal(ob[6 * r:6 * r + 6], o1) and np.array_equal(nb[6 * r:6 * r + 6], n1), r
     if M == 1200:
         assert max(n_edges) > 1024 and 3 <= min(n for n in n_edges if n) < 400, n_edges
 

@@ -16,7 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # algorithmic bytes per unit (= what tools/run_configs.py prices): every input array once, the outputs once
-NF, NP, NL = 1200, 1500, 1000
+NF, NP, NL = 1200, int(os.environ.get("MATCH_LEGS_NP", "1500")), 1000
 BYTES = {
     "proj": NF * (16 + 4 + 4 + 32 + 1 + 4) + NP * (24 + 4 + 8 + 1 + 32),
     "frame": NF * (16 + 4 + 4 + 4 + 32 + 1 + 4) + NL * (24 + 1 + 4 + 4 + 32) + 112,
@@ -99,10 +99,13 @@ def main():
                 res = fn()
             torch.cuda.synchronize()
             fm = res[0] if isinstance(res, (tuple, list)) else res
-            w = fm[:, :4].cpu().numpy().astype(np.float64)
+            w = fm[:, :17].cpu().numpy().astype(np.float64)
+            rec["prof_walks_of_thread_0"] = {"setup_x16": float(w[:, 7].mean()), "loop_x16": float(w[:, 8].mean()), "of_loop_flush_x16": float(w[:, 9].mean()),
+                                            "iterations": float(w[:, 10].mean()), "flushes": float(w[:, 11].mean()), "walks": float(w[:, 12].mean()), "listed_in_last_round": float(w[:, 13].mean()), "later_rounds_records_x16": float(w[:, 14].mean()), "later_rounds_listed_walks_x16": float(w[:, 15].mean()), "later_rounds_compare_x16": float(w[:, 16].mean())}
             rec["prof_mean_clocks_x16"] = {"grid_build": float(w[:, 0].mean()), "rounds": float(w[:, 1].mean()),
                                           "output": float(w[:, 2].mean()), "n_rounds": float(w[:, 3].mean()),
-                                          "n_rounds_max": float(w[:, 3].max())}
+                                          "n_rounds_max": float(w[:, 3].max()), "of_rounds_class_sort": float(w[:, 4].mean()),
+                                          "of_rounds_round_1": float(w[:, 5].mean())}
         print(json.dumps(rec), flush=True)
 
 
