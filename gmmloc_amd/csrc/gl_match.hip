@@ -87,7 +87,7 @@ __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* __r
 //         points (mp_uvr = world position, mp_level = octave of the last frame's feature), projected here
 //         with the current pose; rotation-consistency histogram at the end (feat_angle / mp_angle).
 template <int MODE, bool DL>
-__global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
+__global__ __launch_bounds__(DL ? 1024 : T_M, 4) void k_search_by_projection(  // (four waves per SIMD: two frames per CU in batches)
     MatchP P, int B, const double* __restrict__ feat_uv_all, const float* __restrict__ feat_ur_all,
     const int32_t* __restrict__ feat_oct_all, const uint8_t* __restrict__ feat_desc_all,
     const uint8_t* __restrict__ feat_taken_all, const double* __restrict__ mp_uvr_all,
@@ -551,6 +551,106 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
     return bestIdx;
   };
 
+  // A listed query walked by a WHOLE wave (round 6): lane c takes the range of the window's column c, a scan numbers the window's entries
+  // t = 0 .. T - 1 in visiting order (columns ascending, a column's cells are contiguous in the CSR: ascending entry index), the lanes
+  // take the entries t = lane, lane + 64, ... - level / window / u_right tests, owner, Hamming distance - and the two smallest keys
+  // {distance, entry index = visiting order} meet in a butterfly: four LDS round trips where the lane-per-query walk makes ~20 dependent
+  // iterations (profiles/r6_match_walk_ab.txt).  m is wave-uniform; returns the feature the reference's loop would choose, or -1.
+  auto wave_min64 = [&](unsigned long long v) -> unsigned long long {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long w = __shfl_xor(v, o, 64);
+      v = w < v ? w : v;
+    }
+    return v;
+  };
+  auto wave_walk = [&](int m) -> int {
+    const int lane = tid & 63;
+    const Query q = make_query(m);
+    if (!q.valid) return -1;
+    const float rr = q.rr, x = q.x, y = q.y;
+    const int x0 = max(0, (int)floorf((x - 0.0f - rr) * P.col_inv)), x1 = min(GC - 1, (int)ceilf((x - 0.0f + rr) * P.col_inv));
+    const int y0 = max(0, (int)floorf((y - 0.0f - rr) * P.row_inv)), y1 = min(GR - 1, (int)ceilf((y - 0.0f + rr) * P.row_inv));
+    if (!(x0 < GC && x1 >= 0 && y0 < GR && y1 >= 0) || y0 > y1 || x0 > x1) return -1;
+    const int ncols = x1 - x0 + 1;
+    int cs = 0, cn = 0;
+    if (lane < ncols) {
+      cs = cell_ptr[(x0 + lane) * GR + y0];
+      cn = cell_ptr[(x0 + lane) * GR + y1 + 1] - cs;
+    }
+    uint32_t dm[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dm[w] = mp_desc[(size_t)m * 8 + w];
+    int inc = cn;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    const int cp = inc - cn, T = __shfl(inc, 63, 64);
+    const int minLevel = q.minLevel, maxLevel = q.maxLevel;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    unsigned long long b0 = EMPTY64, b1 = EMPTY64;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      int e = -1;
+      for (int c = 0; c < ncols; ++c) {  // (c is uniform: three broadcasts per column)
+        const int pc = __shfl(cp, c, 64), nc = __shfl(cn, c, 64), sc = __shfl(cs, c, 64);
+        if (t >= pc && t < pc + nc) e = sc + (t - pc);
+      }
+      if (e >= 0) {
+        const int2 ro = rec_ro[e];
+        const int oc = ro.y & 0xff, idx = ro.y >> 8;
+        bool ok = true;
+        if (bCheckLevels) {
+          if (oc < minLevel) ok = false;
+          if (maxLevel >= 0 && oc > maxLevel) ok = false;
+        }
+        if (s_fast) {
+          const float4 r = ((const float4*)rec_uv)[e];
+          if (!(fabsf(r.x - x) < rr && fabsf(r.y - y) < rr)) ok = false;
+        } else {
+          const double2 fuv = rec_uv[e];
+          const float distx = (float)(fuv.x - (double)x), disty = (float)(fuv.y - (double)y);
+          if (!(fabsf(distx) < rr && fabsf(disty) < rr)) ok = false;
+        }
+        if (ok && owner[idx] < m) ok = false;  // taken on entry (-1) or by an earlier map point
+        if (ok) {
+          const float ur = __int_as_float(ro.x);
+          if (ur > 0) {
+            const float er = q.ur_float ? fabsf(q.ur_f - ur) : (float)fabs(q.ur_d - (double)ur);
+            if (er > rr) ok = false;
+          }
+        }
+        if (ok) {
+          uint4 da, db;
+          if (DL) {
+            da = rec_desc[2 * e];
+            db = rec_desc[2 * e + 1];
+          } else {
+            const uint4* src = (const uint4*)(feat_desc + (size_t)idx * 8);
+            da = src[0];
+            db = src[1];
+          }
+          const int dist = __popc(dm[0] ^ da.x) + __popc(dm[1] ^ da.y) + __popc(dm[2] ^ da.z) + __popc(dm[3] ^ da.w) + __popc(dm[4] ^ db.x) +
+                           __popc(dm[5] ^ db.y) + __popc(dm[6] ^ db.z) + __popc(dm[7] ^ db.w);
+          if (dist < 256) {
+            const unsigned long long kx = ((unsigned long long)dist << 48) | ((unsigned long long)e << 20) | ((unsigned long long)oc << 12) | (unsigned long long)idx;
+            if (kx < b0) {
+              b1 = b0;
+              b0 = kx;
+            } else if (kx < b1) {
+              b1 = kx;
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long m0 = wave_min64(b0);
+    const unsigned long long m1 = wave_min64(b0 == m0 ? b1 : b0);  // (keys are distinct: the entry index is part of them)
+    return decide(m0, m1, MODE == 0);
+  };
+
   int rounds = 0;
 #ifdef GL_MATCH_PROF
   int rewalks = 0;
@@ -630,35 +730,20 @@ __global__ __launch_bounds__(DL ? 1024 : T_M) void k_search_by_projection(
       }
     }
     PW_T(pr1);
-    if (rounds > 0) {  // the listed queries, dealt over ALL waves (a few lanes of each: a walk lasts as long as the wave's longest, and one
-      __syncthreads();  // wave walking alone was the round's tail); the owners they read are the previous round's: any order
+    if (rounds > 0) {  // the listed queries: a WAVE each (the owners they read are the previous round's: any order)
+      __syncthreads();
       constexpr int NWV = TM / 64;
       const int nrw = min(s_nrw, RW_CAP);
-      for (int k0_ = 0; k0_ < nrw; k0_ += TM) {
-        const int k = k0_ + (tid & 63) * NWV + (tid >> 6);
-        const bool in = k < nrw;
-        const int m = in ? (int)rw_list[k] : NP;
-        Query q;
-        q.valid = false;
-        q.x = q.y = q.rr = 0.f;
-        q.minLevel = q.maxLevel = -1;
-        q.ratio_test = MODE == 0;
-        q.ur_float = MODE == 1;
-        q.ur_d = 0.0;
-        q.ur_f = 0.f;
-        if (in) q = make_query(m);
-        unsigned long long k0, k1, k2;
-        uint32_t npass;
-        bool bad;
-        walk(in && q.valid, m, q, k0, k1, k2, npass, bad);
-        if (in) {
-          const int bestIdx = decide(k0, k1, MODE == 0);
+      for (int k = tid >> 6; k < nrw; k += NWV) {
+        const int m = (int)rw_list[k];
+        const int bestIdx = wave_walk(m);
+        if ((tid & 63) == 0) {
           choice[m] = bestIdx;
           if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
-#ifdef GL_MATCH_PROF
-          ++rewalks;
-#endif
         }
+#ifdef GL_MATCH_PROF
+        ++rewalks;
+#endif
       }
     }
     __syncthreads();
