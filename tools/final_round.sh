@@ -21,6 +21,7 @@ python tools/fixed_time.py 2048 1000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/de
 python tools/fixed_time.py 1024 2000 2 >> gpurun_out/${TAG}_fixed_time.txt 2>/dev/null
 python tools/lat1.py 2>/dev/null | grep -v amdgpu > gpurun_out/${TAG}_lat1.txt
 python tools/chain_time.py > gpurun_out/${TAG}_chain_time.json 2>/dev/null
+python tools/chain_ab.py $TAG 2>/dev/null | grep label > gpurun_out/${TAG}_chain_device_time.json
 bash tools/pmc_match.sh ${TAG} > gpurun_out/${TAG}_pmc_match.log 2>&1
 rm -rf gpurun_out/pmc_match_${TAG}
 python tools/soak_match.py ${SOAK_MATCH:-300} 2>/dev/null | tail -3 > gpurun_out/${TAG}_soak_match.txt
