@@ -30,6 +30,9 @@ struct FuseP {
   float sf[8], sigma2_inv[8];
 };
 
+// REC: the frame's features also as 16-byte records in LDS, in CSR order (the launcher sets it when they fit next to the grid and the
+// queries' order), and the walk below waits for the LDS instead of for three dependent global loads per visited entry.
+template <bool REC>
 __global__ __launch_bounds__(T_F) void k_fuse_search(FuseP P, int B, const double* __restrict__ feat_uv_all, const float* __restrict__ feat_ur_all,
                                                      const int32_t* __restrict__ feat_oct_all, const uint8_t* __restrict__ feat_desc_all,
                                                      const double* __restrict__ mp_uvr_all, const int32_t* __restrict__ mp_level_all,
@@ -39,7 +42,9 @@ __global__ __launch_bounds__(T_F) void k_fuse_search(FuseP P, int B, const doubl
   int32_t* cell_ptr = lds;                 // NCELL + 1
   int32_t* cursor = cell_ptr + NCELL + 1;  // NCELL (grid build only)
   int32_t* cell_idx = cursor + NCELL;      // NF
-  __shared__ int s_scan[T_F / 64];
+  float4* rec16 = (float4*)(lds + ((2 * NCELL + 1 + P.NF + 3) & ~3));  // REC: {u, v, u_right, octave | feature << 8} per CSR entry
+  uint16_t* qorder = (uint16_t*)(rec16 + P.NF);                         // REC: the queries sorted by window class
+  __shared__ int s_scan[T_F / 64], s_fast, s_cls[9];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= B) return;
   const int NF = P.NF, NP = P.NP;
@@ -54,6 +59,8 @@ __global__ __launch_bounds__(T_F) void k_fuse_search(FuseP P, int B, const doubl
 
   // ---- assignFeaturesToGrid: CSR by cell (ix * GR + iy), ascending feature index inside a cell (as in gl_match.hip) ----
   for (int c = tid; c <= NCELL; c += T_F) cell_ptr[c] = 0;
+  if (tid == 0) s_fast = 1;
+  if (tid < 9) s_cls[tid] = 0;
   __syncthreads();
   auto cell_of = [&](int i) -> int {
     if (feat_oct[i] < 0) return -1;  // padding slot
@@ -61,9 +68,19 @@ __global__ __launch_bounds__(T_F) void k_fuse_search(FuseP P, int B, const doubl
     if (!(px >= 0 && px < GC && py >= 0 && py < GR)) return -1;  // also rejects NaN
     return (int)px * GR + (int)py;
   };
-  for (int i = tid; i < NF; i += T_F) {
-    const int c = cell_of(i);
-    if (c >= 0) atomicAdd(&cell_ptr[c + 1], 1);
+  {
+    // the record walk is exact iff every feature coordinate is a float value (the reference's (float)(double u - (double)x) is then the
+    // correctly rounded float difference, and (double)(float)u is u in its double expressions) and the octaves fit the record
+    bool fok = true;
+    for (int i = tid; i < NF; i += T_F) {
+      const int c = cell_of(i);
+      if (c >= 0) {
+        atomicAdd(&cell_ptr[c + 1], 1);
+        const double u = feat_uv[2 * i], v = feat_uv[2 * i + 1];
+        fok = fok && (double)(float)u == u && (double)(float)v == v && feat_oct[i] <= 255;
+      }
+    }
+    if (!fok) s_fast = 0;
   }
   __syncthreads();
   {
@@ -109,6 +126,144 @@ __global__ __launch_bounds__(T_F) void k_fuse_search(FuseP P, int B, const doubl
   }
   __syncthreads();
 
+  if (REC && s_fast) {
+    // ---- round 6: the walk of gl_match.hip's first round (no owners here: the map points do not interact) -------------------------
+    for (int e = tid; e < cell_ptr[NCELL]; e += T_F) {
+      const int i = cell_idx[e];
+      rec16[e] = make_float4((float)feat_uv[2 * i], (float)feat_uv[2 * i + 1], feat_ur[i], __int_as_float((feat_oct[i] & 0xff) | (i << 8)));
+    }
+    // queries by window class (the half size of the window is a factor x the scale of the predicted level), the LARGEST first, so that
+    // the lanes of a wave walk windows of like size (the order only decides which thread takes which query)
+    auto cls_of = [&](int m) -> int { return mp_valid[m] ? (mp_level[m] & 7) : 8; };
+    for (int m = tid; m < NP; m += T_F) atomicAdd(&s_cls[cls_of(m)], 1);
+    __syncthreads();
+    if (tid == 0) {
+      const int ord[9] = {7, 6, 5, 4, 3, 2, 1, 0, 8};
+      int run = 0;
+      for (int k = 0; k < 9; ++k) {
+        const int n = s_cls[ord[k]];
+        s_cls[ord[k]] = run;
+        run += n;
+      }
+    }
+    __syncthreads();
+    for (int m = tid; m < NP; m += T_F) qorder[atomicAdd(&s_cls[cls_of(m)], 1)] = (uint16_t)m;
+    __syncthreads();
+    uint16_t* lst = (uint16_t*)cursor;  // 4 x T_F entry indices: a thread's collected candidates (the cursors are dead after the grid build)
+    const int nq_rounds = ((NP + T_F - 1) / T_F) * T_F;
+    for (int sq = tid; sq < nq_rounds; sq += T_F) {
+      const bool in = sq < NP;
+      const int m = in ? (int)qorder[sq] : 0;
+      const bool act = in && mp_valid[m] != 0;
+      int best_dist = 256, best_idx = -1;
+      int lvl_pred = 0;
+      double ux = 0.0, uy = 0.0, ur = 0.0;
+      float x = 0.f, y = 0.f, rr = 0.f;
+      int x0 = 1, x1 = 0, y0 = 0, y1 = 0;
+      uint32_t dm[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) dm[w] = act ? mp_desc[(size_t)m * 8 + w] : 0u;
+      if (act) {
+        lvl_pred = mp_level[m];
+        ux = mp_uvr[3 * m];
+        uy = mp_uvr[3 * m + 1];
+        ur = mp_uvr[3 * m + 2];
+        rr = P.th * P.sf[lvl_pred & 7];
+        x = (float)ux;
+        y = (float)uy;
+        x0 = max(0, (int)floorf((x - 0.0f - rr) * P.col_inv));
+        x1 = min(GC - 1, (int)ceilf((x - 0.0f + rr) * P.col_inv));
+        y0 = max(0, (int)floorf((y - 0.0f - rr) * P.row_inv));
+        y1 = min(GR - 1, (int)ceilf((y - 0.0f + rr) * P.row_inv));
+        if (!(x0 < GC && x1 >= 0 && y0 < GR && y1 >= 0) || y0 > y1) x1 = x0 - 1;  // nothing to visit
+      }
+      int cnt = 0;
+      auto flush = [&]() {  // Hamming distances of the <= 4 collected candidates (in visiting order), their descriptors requested together
+        uint4 da[4], db[4];
+        int fi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fi[j] = 0;
+          da[j] = db[j] = make_uint4(0, 0, 0, 0);
+          if (j < cnt) {
+            fi[j] = __float_as_int(rec16[lst[j * T_F + tid]].w) >> 8;
+            const uint4* src = (const uint4*)(feat_desc + (size_t)fi[j] * 8);
+            da[j] = src[0];
+            db[j] = src[1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < cnt) {
+            const int dist = __popc(dm[0] ^ da[j].x) + __popc(dm[1] ^ da[j].y) + __popc(dm[2] ^ da[j].z) + __popc(dm[3] ^ da[j].w) +
+                             __popc(dm[4] ^ db[j].x) + __popc(dm[5] ^ db[j].y) + __popc(dm[6] ^ db[j].z) + __popc(dm[7] ^ db[j].w);
+            if (dist < best_dist) {
+              best_dist = dist;
+              best_idx = fi[j];
+            }
+          }
+        }
+        cnt = 0;
+      };
+      auto entry = [&](const float4 r, int ee) {
+        const int pk = __float_as_int(r.w), kpLevel = pk & 0xff;
+        bool ok = fabsf(r.x - x) < rr && fabsf(r.y - y) < rr && !(kpLevel < lvl_pred - 1 || kpLevel > lvl_pred);
+        if (ok) {
+          const double dx = (double)r.x - ux, dy = (double)r.y - uy;
+          double err;  // Feature::error(Vector3d): squared norm of (uv - obs) or of (uvr - obs)
+          if (r.z < 0.0f) {
+            err = dx * dx + dy * dy;
+          } else {
+            const double dz = (double)r.z - ur;
+            err = dx * dx + dy * dy + dz * dz;
+          }
+          err *= P.sigma2_inv[kpLevel & 7];
+          const double thresh = r.z >= 0 ? 7.8 : 5.99;
+          if (err > thresh) ok = false;
+        }
+        if (ok) {
+          lst[cnt * T_F + tid] = (uint16_t)ee;
+          ++cnt;
+        }
+      };
+      bool more = act && x0 <= x1;
+      int ix = x0 - 1, e = 0, e1 = 0, ne = 0, ne1 = 0;  // (ne, ne1): the range of column ix + 1, requested a column ahead
+      if (more) {
+        ne = cell_ptr[x0 * GR + y0];
+        ne1 = cell_ptr[x0 * GR + y1 + 1];
+      }
+      while (__any(more)) {
+        if (more && e >= e1) {  // next column: cells (ix, y0..y1) are contiguous in the CSR
+          ++ix;
+          if (ix > x1) {
+            more = false;
+          } else {
+            e = ne;
+            e1 = ne1;
+            if (ix < x1) {
+              ne = cell_ptr[(ix + 1) * GR + y0];
+              ne1 = cell_ptr[(ix + 1) * GR + y1 + 1];
+            }
+          }
+        }
+        const bool h0 = more && e < e1, h1 = more && e + 1 < e1;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (h0) r0 = rec16[e];
+        if (h1) r1 = rec16[e + 1];
+        if (h0) entry(r0, e);
+        if (__any(cnt == 4)) flush();
+        if (h1) entry(r1, e + 1);
+        if (__any(cnt == 4)) flush();
+        e += h1 ? 2 : (h0 ? 1 : 0);
+      }
+      if (__any(cnt > 0)) flush();
+      if (in) {
+        best_idx_all[(size_t)f * NP + m] = best_dist <= 50 ? best_idx : -1;  // TH_LOW
+        best_dist_all[(size_t)f * NP + m] = best_dist;
+      }
+    }
+    return;
+  }
   // ---- one window walk per map point (:250-291) ------------------------------------------------------------------------
   for (int m = tid; m < NP; m += T_F) {
     int best_dist = 256, best_idx = -1;
@@ -189,10 +344,15 @@ extern "C" int gl_fuse_search(gl_ctx_t* ctx, const gl_camera* cam, float scale_f
     const float s2 = P.sf[i] * P.sf[i];
     P.sigma2_inv[i] = 1.0f / s2;
   }
-  const size_t lds = ((size_t)2 * NCELL + 1 + NF) * sizeof(int32_t);
+  size_t lds = ((size_t)2 * NCELL + 1 + NF) * sizeof(int32_t);
+  // the record walk: 16 bytes per feature and 2 per map point more; two key-frames per CU must still fit (NP <= 65 535: 16-bit query order)
+  const size_t lds_rec = (((size_t)2 * NCELL + 1 + NF + 3) & ~(size_t)3) * sizeof(int32_t) + (size_t)NF * 16 + (size_t)NP * 2;
+  const bool rec = NP <= 65535 && lds_rec <= 80 * 1024 && c->opt.fuse_records != 0;
+  if (rec) lds = lds_rec;
   GL_REQUIRE_LDS(c, lds);
-  GL_HIP(gl::ensure_dynamic_lds(c, (const void*)k_fuse_search, lds));
-  k_fuse_search<<<B, T_F, lds, c->stream>>>(P, B, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev, mp_uvr_dev, mp_level_dev, mp_valid_dev,
+  auto kern = rec ? k_fuse_search<true> : k_fuse_search<false>;
+  GL_HIP(gl::ensure_dynamic_lds(c, (const void*)kern, lds));
+  kern<<<B, T_F, lds, c->stream>>>(P, B, feat_uv_dev, feat_ur_dev, feat_oct_dev, feat_desc_dev, mp_uvr_dev, mp_level_dev, mp_valid_dev,
                                             mp_desc_dev, best_idx_dev, best_dist_dev);
   GL_HIP(hipGetLastError());
   return GL_OK;

@@ -389,17 +389,20 @@ def synth_bow_pair(N1, N2, seed, cam, n_nodes=160, mp_frac=0.7):
     return kf, fr
 
 
-def synth_fuse_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2):
+def synth_fuse_frame(NF, NP, seed, width=752, height=480, scale_factor=1.2, float_coords=False):
     """Inputs of the matching half of Localization::fuseObservations for one key-frame: NF features (clustered, so that windows
     hold several candidates; some with the SAME descriptor: ties) and NP projected map points - 75 % made from a feature with a
     pixel error around the chi2 gates (5.99 / 7.8 at the feature's level, so that some pass and some do not), level = the feature's
     octave or one above, descriptor with 0 .. 70 flipped bits (TH_LOW = 50 in between), the rest distractors; padding slots, points
-    outside the image, invalid points."""
+    outside the image, invalid points.  float_coords: the feature coordinates are float values, as cv::KeyPoint's are (the record walk of
+    gl_fuse_search, round 6); the default keeps the frames of the earlier rounds (arbitrary doubles: the walk from global memory)."""
     rng = np.random.default_rng(seed)
     sf = scale_factor ** np.arange(8)
     ncl = max(1, NF // 6)
     centres = np.stack([rng.uniform(0, width, ncl), rng.uniform(0, height, ncl)], 1)
     uv = centres[rng.integers(0, ncl, NF)] + rng.normal(0, 4.0, (NF, 2))
+    if float_coords:
+        uv = uv.astype(np.float32).astype(np.float64)
     octv = rng.integers(0, 8, NF).astype(np.int32)
     octv[rng.uniform(size=NF) < 0.03] = -1
     ur = np.where(rng.uniform(size=NF) < 0.7, uv[:, 0] - rng.uniform(2, 60, NF), -1.0).astype(np.float32)

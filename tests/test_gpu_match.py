@@ -352,15 +352,22 @@ def _pack_fuse(torch, frames):
     return [torch.from_numpy(t[k]).cuda() for k in FUSE_KEYS]
 
 
-def test_fuse_search_matches_oracle(gpu, oracle):
+@pytest.mark.parametrize("coords", ["double", "float", "mixed", "float_records_off"])
+def test_fuse_search_matches_oracle(gpu, oracle, opt, coords):
     """gl_fuse_search (Localization::fuseObservations, localization.cpp:226-318, the matching half) against the sequential oracle:
     best feature and best distance of every map point bit for bit - crowded windows, equal distances (the first in the grid's
     visiting order), the level band, the chi2 gates, points outside the image, padding slots, key-frames of different sizes in one
-    batch; then 120 random key-frames."""
+    batch; then 120 random key-frames.  coords: feature coordinates that are float values (cv::KeyPoint's: the record walk of round 6),
+    arbitrary doubles (the walk from global memory, chosen per key-frame on the device), both in one batch, and the option
+    fuse_records = 0."""
     torch, ctx = gpu
     cam = api.Camera()
     cam.width, cam.height = 752, 480
-    frames = [synth.synth_fuse_frame(NF, NP, 800 + i) for i, (NF, NP) in enumerate(((300, 260), (1200, 1500), (2000, 3000), (40, 900), (700, 30), (5, 5)))]
+    if coords == "float_records_off":
+        opt("fuse_records", 0)
+    fc = lambda i: coords.startswith("float") or (coords == "mixed" and i % 2 == 0)
+    frames = [synth.synth_fuse_frame(NF, NP, 800 + i, float_coords=fc(i))
+              for i, (NF, NP) in enumerate(((300, 260), (1200, 1500), (2000, 3000), (40, 900), (700, 30), (5, 5)))]
     for th in (3.0, 5.0):
         bi, bd = api.fuse_search(ctx, cam, *_pack_fuse(torch, frames), th=th)
         torch.cuda.synchronize()
@@ -374,7 +381,7 @@ def test_fuse_search_matches_oracle(gpu, oracle):
             tot += n
         assert tot > 1000
     rng = np.random.default_rng(79)
-    frames = [synth.synth_fuse_frame(int(rng.integers(5, 1800)), int(rng.integers(5, 2200)), 9000 + i) for i in range(120)]
+    frames = [synth.synth_fuse_frame(int(rng.integers(5, 1800)), int(rng.integers(5, 2200)), 9000 + i, float_coords=fc(i)) for i in range(120)]
     bi, bd = api.fuse_search(ctx, cam, *_pack_fuse(torch, frames), th=3.0)
     torch.cuda.synchronize()
     bi, bd = bi.cpu().numpy(), bd.cpu().numpy()

@@ -68,7 +68,7 @@ def build_legs(torch, ctx, B, legs):
         bk, bf = _pack_bow(torch, [ub[b % U] for b in range(B)])
         out["bow"] = (lambda: api.search_by_bow(ctx, bk, bf, 0.7, True), None)
     if "fuse" in legs:
-        uf = [synth.synth_fuse_frame(NF, NP, 1900 + b) for b in range(U)]
+        uf = [synth.synth_fuse_frame(NF, NP, 1900 + b, float_coords=True) for b in range(U)]
         fa = _pack_fuse(torch, [uf[b % U] for b in range(B)])
         out["fuse"] = (lambda: api.fuse_search(ctx, cam, *fa, th=3.0), None)
     return out

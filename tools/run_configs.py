@@ -405,7 +405,7 @@ def config_match(torch, ctx, out):
          "frames_per_s": B / t6, "single_frame_latency_us": 1e6 * t6l, "cpu_oracle_1thread_frames_per_s": 1.0 / tc6})
     # fuseObservations, the matching half: 1 200 features of a neighbour key-frame x 1 500 projected map points
     from tests.test_gpu_match import _pack_fuse, FUSE_KEYS
-    uf = [synth.synth_fuse_frame(NF, NP, 1900 + b) for b in range(64)]
+    uf = [synth.synth_fuse_frame(NF, NP, 1900 + b, float_coords=True) for b in range(64)]
     fa = _pack_fuse(torch, [uf[b % 64] for b in range(B)])
     t7 = ev_time(torch, lambda: api.fuse_search(ctx, cam, *fa, th=3.0), 5, ctx.stream)
     t0 = time.perf_counter()
