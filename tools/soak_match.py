@@ -1,4 +1,5 @@
-"""Randomised parity soak of the four matchers (gl_search_by_projection: ORBmatcher::searchByProjection of
+"""Randomised parity soak of the five matchers (gl_fuse_search: the matching half of Localization::fuseObservations, localization.cpp:226-318;
+gl_search_by_projection: ORBmatcher::searchByProjection of
 searchLocalPoints, orb_matcher.cpp:27-110; gl_search_by_projection_frame: the trackWithMotionModel overload,
 orb_matcher.cpp:410-542; gl_search_for_triangulation :141-293; gl_search_by_bow :295-408) against the oracle's sequential
 restatement: integer work, every index and count must be equal.
@@ -14,14 +15,14 @@ import torch
 import gmmloc_amd
 from gmmloc_amd import api, synth
 from tests import oracle_lib
-from tests.test_gpu_match import CamF, run_gpu, run_gpu_frame, _pack_pairs, _pack_bow
+from tests.test_gpu_match import CamF, FUSE_KEYS, run_gpu, run_gpu_frame, _pack_pairs, _pack_bow, _pack_fuse
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 orc = oracle_lib.load()
 ctx = gmmloc_amd.Context(0)
-bad = dict(local=0, frame=0, tri=0, bow=0)
-n_checked = dict(local=0, frame=0, tri=0, bow=0)
-matched = dict(local=0, frame=0, tri=0, bow=0)
+bad = dict(local=0, frame=0, tri=0, bow=0, fuse=0)
+n_checked = dict(local=0, frame=0, tri=0, bow=0, fuse=0)
+matched = dict(local=0, frame=0, tri=0, bow=0, fuse=0)
 t0 = time.time()
 for r in range(rounds):
     rng = np.random.default_rng(90000 + r)
@@ -86,6 +87,21 @@ for r in range(rounds):
         if n[b] != n_ref or not np.array_equal(m[b, :len(m_ref)], m_ref):
             bad["bow"] += 1
             print("MISMATCH bow    round %d pair %d ratio %.1f chk %s: %d vs %d matches" % (r, b, ratio, chk, int(n[b]), n_ref), flush=True)
+    # the matching half of fuseObservations: float coordinates (the record walk), arbitrary doubles (the walk from global memory), mixed batches
+    camf = api.Camera()
+    camf.width, camf.height = 752, 480
+    th = float(rng.choice([3.0, 5.0]))
+    fuses = [synth.synth_fuse_frame(int(rng.integers(5, 2400)), int(rng.integers(5, 3200)), 611953 * r + b, float_coords=(r + b) % 3 != 0) for b in range(B)]
+    bi, bd = api.fuse_search(ctx, camf, *_pack_fuse(torch, fuses), th=th)
+    torch.cuda.synchronize()
+    bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+    for b, f in enumerate(fuses):
+        ri, rd, n_ref = orc.fuse_search(f["width"], f["height"], *[f[k] for k in FUSE_KEYS], th=th)
+        n_checked["fuse"] += 1
+        matched["fuse"] += int(n_ref)
+        if not (np.array_equal(bi[b, :len(ri)], ri) and np.array_equal(bd[b, :len(ri)], rd)):
+            bad["fuse"] += 1
+            print("MISMATCH fuse   round %d key-frame %d th %.0f: %d indices differ" % (r, b, th, int((bi[b, :len(ri)] != ri).sum())), flush=True)
 ctx.set_option("match_desc_lds", -1)
 print("matcher soak: %d rounds; frames checked %s, matches compared %s; mismatching frames %s; %.0f s"
       % (rounds, n_checked, matched, bad, time.time() - t0))
