@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 // option table: name as in gl_ctx_set_option; the environment variable is GMMLOC_<NAME IN CAPITALS>
 #define GL_OPTION_LIST(X) \
-  X(ba_shape) X(ba_step32) X(ba_persist) X(ba_two_frames) X(ba_slow) X(ba_fixed_pack) X(ba_rendezvous_us) X(ba_test_abort_seq) X(ba_same_xcd) X(pose_waves) X(pose_regs) X(pose_compact) X(fuse_records) X(bagen_nb) X(bagen_mode) X(view_slot_lds) X(view_threads) \
+  X(ba_shape) X(ba_step32) X(ba_persist) X(ba_two_frames) X(ba_slow) X(ba_fixed_pack) X(ba_rendezvous_us) X(ba_test_abort_seq) X(ba_same_xcd) X(pose_waves) X(pose_regs) X(pose_compact) X(pose_compact_cap) X(fuse_records) X(bagen_nb) X(bagen_mode) X(view_slot_lds) X(view_threads) \
   X(assoc_index_min) X(assoc_grid) X(assoc_coop) X(assoc_rec_pad) X(assoc_coop_long) X(assoc_coop_bal) X(assoc_pack_mb) X(assoc_cell8) X(assoc_cell) X(assoc_globcells) X(match_desc_lds) X(pipe_lanes) X(pipe_judge) X(pipe_fuse_asm) X(schur_kper)
 double* option_slot(Options& o, const char* name) {
 #define X(n) \

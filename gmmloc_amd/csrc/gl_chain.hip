@@ -79,20 +79,23 @@ __global__ __launch_bounds__(T_GATHER) void k_chain_gather(int B, int NF, int NL
   const ChainSrc src = {feat_uv + fb * 2, feat_ur + fb, feat_oct + fb, (on && match_last) ? match_last + fb : nullptr, last_pt + (size_t)b * NL * 3,
                         (on && match_local) ? match_local + fb : nullptr, mp_pos + (size_t)b * NP * 3, (on && match_kf) ? match_kf + fb : nullptr,
                         kf_pt ? kf_pt + (size_t)b * NK * 3 : nullptr};
+  // (the full-stride problem is what a frame with more edges than the compacted stride runs on: only such a frame writes it - 62 KB of
+  //  the 190 KB a frame of 1 200 features moved here)
+  const bool full = pc.MC > 0 ? gl::pose_compact_frame<T_GATHER>(src, b, NF, pc) : true;
   for (int i = tid; i < NF; i += T_GATHER) {
     const size_t g = fb + i;
-    double X[3], O[3];
-    src.load(i, X, O);
-    const int oc = src.octave(i);
+    if (full) {
+      double X[3], O[3];
+      src.load(i, X, O);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      Xw[g * 3 + k] = X[k];
-      obs[g * 3 + k] = O[k];
+      for (int k = 0; k < 3; ++k) {
+        Xw[g * 3 + k] = X[k];
+        obs[g * 3 + k] = O[k];
+      }
+      oct[g] = src.octave(i);
     }
-    oct[g] = oc;
     if (outlier_clear) outlier_clear[g] = 0;
   }
-  if (pc.MC > 0) gl::pose_compact_frame<T_GATHER>(src, b, NF, pc);
   if (finalise && match_last && match_local) {  // (after the last read of the frame's associations; the local match wins either way)
     for (int i = tid; i < NF; i += T_GATHER)
       if (match_local[fb + i] >= 0 && match_last[fb + i] >= 0) match_last[fb + i] = -1;
@@ -270,7 +273,7 @@ struct ChainScratch {
 int chain_scratch(gl::Ctx* c, int B, int NF, int NP, ChainScratch* S) {
   const size_t nf = (size_t)B * NF, np = (size_t)B * NP;
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };
-  const int MC = gl::pose_compact_stride((int)c->opt.pose_compact, NF);
+  const int MC = gl::pose_compact_stride((int)c->opt.pose_compact, NF, (int)c->opt.pose_compact_cap);
   void* scratch = nullptr;
   const int rc = gl::ctx_scratch_c(c, 2 * up(nf * 24) + 3 * up(nf * 4) + 2 * up(nf) + up(np) + up((size_t)B * 24) + up((size_t)B * 56) + 4 * up((size_t)B * 4) +
                                        (MC ? gl::pose_compacted_bytes(B, NF, MC) : 0), &scratch);

@@ -119,6 +119,7 @@ struct Options {
   double assoc_rec_pad = 1;     // 1: k_assoc_cells_coop gathers from the one-line-per-record copy (CellIndex::rec16), 0: from rec12 (A/B; same results)
   double assoc_coop = 1;        // 1: wave-cooperative record gather in the indexed association (k_assoc_cells_coop), 0: a lane per record
   double pipe_fuse_asm = -1;    // pipelined local BA: the solve kernel assembles the system itself (-1: calls of a few windows, 0 never, 1 always; same bits)
+  double pose_compact_cap = 1024;  // the largest stride of a compacted pose problem (tests: 512 / 256 drive frames into the full-stride problem)
   double fuse_records = 1;      // gl_fuse_search: 0 = the walk that reads the features from global memory (A/B)
   double pose_compact = -1;     // gl_optimize_current_pose: problems of more than 1 024 slots compacted to 1 024 where their edges fit (-1, default); 1: every problem of more than 256 slots; 0: never
   double assoc_cell8 = 1;       // the packed cell table in 8 bytes per cell where the component indices fit 20 bits (0: 16 bytes per cell as in rounds 3 - 5)

@@ -48,8 +48,10 @@ struct MatchP {
   int width, height, mono, check_orientation;
 };
 
-// 32-bit words of the kernel's LDS in front of the per-entry records: cell_ptr, cursor, cell_idx, owner, owner_n, choice, qorder (u16)
-__host__ __device__ inline int lds_ints(int NF, int NP) { return (2 * NCELL + 1 + 3 * NF + NP + (NP + 1) / 2 + 3) & ~3; }
+// 32-bit words of the kernel's LDS in front of the per-entry records: cell_ptr, cursor, cell_idx, owner, owner_n, qorder (u16)
+// (round 6: the per-query `choice` table - written every round, read by nobody - is gone: 4 bytes per map point that kept a frame with
+//  3 000 local map points from sharing its CU with a second one - 85.8 KB -> 73.8 KB)
+__host__ __device__ inline int lds_ints(int NF, int NP) { return (2 * NCELL + 1 + 3 * NF + (NP + 1) / 2 + 3) & ~3; }
 
 // what one query point (a projected map point) asks of the feature grid
 struct Query {
@@ -104,9 +106,8 @@ __global__ __launch_bounds__(DL ? 1024 : T_M, 4) void k_search_by_projection(  /
   int32_t* cell_idx = cursor + NCELL;        // NF
   int32_t* owner = cell_idx + P.NF;          // NF   owner of the previous round (-1: taken on entry)
   int32_t* owner_n = owner + P.NF;           // NF   being rebuilt
-  int32_t* choice = owner_n + P.NF;          // NP
   // per CSR entry, so that the window walk touches LDS only: {u, v} double, {u_right bits, octave}
-  uint16_t* qorder = (uint16_t*)(choice + P.NP);  // NP: the queries sorted by window class (round 5: equal work per lane)
+  uint16_t* qorder = (uint16_t*)(owner_n + P.NF);  // NP: the queries sorted by window class (round 5: equal work per lane)
   double2* rec_uv = (double2*)(lds + lds_ints(P.NF, P.NP));  // 16-byte aligned
   int2* rec_ro = (int2*)(rec_uv + P.NF);
   // DL (few frames: one workgroup per CU anyway): the 256-bit descriptors too, in CSR order - a candidate that
@@ -725,7 +726,6 @@ __global__ __launch_bounds__(DL ? 1024 : T_M, 4) void k_search_by_projection(  /
         }
       }
       if (in && !listed) {
-        choice[m] = bestIdx;
         if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
       }
     }
@@ -738,7 +738,6 @@ __global__ __launch_bounds__(DL ? 1024 : T_M, 4) void k_search_by_projection(  /
         const int m = (int)rw_list[k];
         const int bestIdx = wave_walk(m);
         if ((tid & 63) == 0) {
-          choice[m] = bestIdx;
           if (bestIdx >= 0) atomicMin(&owner_n[bestIdx], m);
         }
 #ifdef GL_MATCH_PROF

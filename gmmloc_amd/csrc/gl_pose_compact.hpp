@@ -31,7 +31,7 @@ struct PoseCompacted {
 // SRC: int octave(int i) const (< 0: no edge);  void load(int i, double* X, double* O) const   - edge i of THIS frame
 // NT = threads of the workgroup (a multiple of 64)
 template <int NT, class SRC>
-__device__ __forceinline__ void pose_compact_frame(const SRC& src, int b, int M, const PoseCompacted& pc) {
+__device__ __forceinline__ bool pose_compact_frame(const SRC& src, int b, int M, const PoseCompacted& pc) {  // -> the frame has more than MC edges
   constexpr int NWV = NT / 64;
   __shared__ int s_w[NWV];
   const int MC = pc.MC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,6 +88,7 @@ __device__ __forceinline__ void pose_compact_frame(const SRC& src, int b, int M,
     base += round_total;
     __syncthreads();
   }
+  return over;
 }
 
 // bytes of the buffers of a PoseCompacted (without chi_c / chi_f) and their placement in a block
@@ -116,11 +117,12 @@ inline char* pose_compacted_place(char* s, int B, int M, int MC, PoseCompacted* 
   return s;
 }
 // the stride the compaction uses for problems of M slots, or 0: not compacted (option pose_compact: -1 problems of more than 1 024 slots,
-// 1 of more than 256, 0 never)
-inline int pose_compact_stride(int mode, int M) {
+// 1 of more than 256, 0 never; cap: option pose_compact_cap, 1 024 - the tests lower it to drive frames into the full-stride problem)
+inline int pose_compact_stride(int mode, int M, int cap) {
   if (mode == 0 || M <= (mode > 0 ? 256 : 1024)) return 0;
+  cap = cap < 256 ? 256 : cap > 1024 ? 1024 : 256 * (cap / 256);
   const int r = 256 * ((M + 255) / 256);
-  return r < 1024 ? r : 1024;
+  return r < cap ? r : cap;
 }
 
 }  // namespace gl

@@ -1043,7 +1043,7 @@ extern "C" int gl_optimize_current_pose(gl_ctx_t* ctx, const gl_camera* cam, con
   // compacted to 1 024 where their edges fit (0.31 -> 0.21 ms for one frame of 420 edges); 1: every problem of more than 256 slots
   // (pays when at most about half of the slots hold an edge); 0: never.  Decisions and tolerances as ever; the bits of a frame are a
   // function of the frame and this option, never of the batch.
-  const int MC = gl::pose_compact_stride((int)c->opt.pose_compact, M);
+  const int MC = gl::pose_compact_stride((int)c->opt.pose_compact, M, (int)c->opt.pose_compact_cap);
   if (MC == 0) return gl::optimize_current_pose_plain(ctx, cam, prm, B, M, pose_dev, Xw_dev, obs_dev, octave_dev, outlier_dev, ninlier_dev, 1);
   GL_HIP(hipSetDevice(c->device));
   auto up = [](size_t v) { return ((v + 255) / 256) * 256; };

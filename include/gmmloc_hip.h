@@ -128,7 +128,7 @@ void* gl_ctx_stream(gl_ctx_t* ctx);
  *   ba_fixed_pack (1: fixed observers of gl_track_frames_anchored always through the general kernel),
  *   pipe_lanes, pipe_judge, schur_kper (-1 automatic; A/B switches of the pipelined local BA in batches: streams a call is split over,
  *     the verdict on a trial as a kernel of its own, chunks per wave of the Schur pass - none changes a bit),
- *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds, fuse_records. */
+ *   ba_slow, ba_test_abort_seq, pose_waves, pose_regs, bagen_nb, view_slot_lds, view_threads, assoc_index_min, match_desc_lds, fuse_records, pose_compact_cap. */
 int gl_ctx_set_option(gl_ctx_t* ctx, const char* name, double value);
 int gl_ctx_get_option(gl_ctx_t* ctx, const char* name, double* value);
 /* Kernel timing with HIP events on the context's stream: while enabled, every

@@ -84,6 +84,22 @@ def test_track_frame_chain_compacted_pose_problems(gpu, oracle, opt):
         assert np.abs(out["pose"][b] - ref["pose"][b]).max() < 1e-7 and np.abs(out["pose_mm"][b] - ref["pose_mm"][b]).max() < 1e-7
     for k in ("match_last", "match_local", "outlier", "counts", "counts2", "drop_src", "inview"):
         assert np.array_equal(out[k], ref[k]), k
+    # a compacted stride the frames' edges do NOT fit (option pose_compact_cap: 512 - some of the first optimisation's problems fit, the
+    # second's ~750 edges do not; 256 - none fits): those frames run their full-stride problem, chosen on the device - with 256, the
+    # BITS of the uncompacted chain
+    for cap in (512, 256):
+        opt("pose_compact_cap", cap)
+        o2 = run_chain(torch, ctx, frames)
+        for b, f in enumerate(frames):
+            G.check_chain(oracle, cam, f, o2, b)
+            n4 = int(((o2["match_last"][b] >= 0) | (o2["match_local"][b] >= 0)).sum())
+            assert n4 > cap
+            if cap == 256:  # (every problem of the frame at full stride)
+                assert np.array_equal(o2["pose"][b], ref["pose"][b]) and np.array_equal(o2["pose_mm"][b], ref["pose_mm"][b]), (cap, b)
+            else:
+                assert np.abs(o2["pose"][b] - ref["pose"][b]).max() < 1e-7, (cap, b)
+        for k in ("match_last", "match_local", "outlier", "counts", "counts2", "drop_src", "inview"):
+            assert np.array_equal(o2[k], ref[k]), (cap, k)
 
 
 def test_track_frame_chain_buffers_kept_from_call_to_call(gpu, oracle):
