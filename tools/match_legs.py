@@ -16,7 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # algorithmic bytes per unit (= what tools/run_configs.py prices): every input array once, the outputs once
-NF, NP, NL = 1200, int(os.environ.get("MATCH_LEGS_NP", "1500")), 1000
+NF, NP, NL = int(os.environ.get("MATCH_LEGS_NF", "1200")), int(os.environ.get("MATCH_LEGS_NP", "1500")), 1000
 BYTES = {
     "proj": NF * (16 + 4 + 4 + 32 + 1 + 4) + NP * (24 + 4 + 8 + 1 + 32),
     "frame": NF * (16 + 4 + 4 + 4 + 32 + 1 + 4) + NL * (24 + 1 + 4 + 4 + 32) + 112,
