@@ -135,7 +135,7 @@ def test_optimize_current_pose_resets_flags_before_the_too_few_edges_return(gpu,
     assert np.array_equal(got, want), (got[keep], int((got != want).sum()))
 
 
-@pytest.mark.parametrize("mode,M", [(-1, 1200), (1, 1200), (1, 1000), (1, 700)])
+@pytest.mark.parametrize("mode,M", [(-1, 1200), (1, 1200), (1, 1000), (1, 700), (-1, 1025), (-1, 2500), (1, 300)])
 def test_optimize_current_pose_compacted_problems(gpu, oracle, map_v1, gt_sync, opt, mode, M):
     """option pose_compact (round 6): a problem with one slot per FEATURE (the reference's frame: 1 200, a few hundred with a map
     point) is compacted to a stride of at most 1 024 where its edges fit, its edge list dealt over the waves.  A batch that mixes
