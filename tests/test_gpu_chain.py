@@ -43,6 +43,18 @@ def run_chain(torch, ctx, frames):
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
+@pytest.mark.parametrize("NF,NL,NP", [(64, 64, 64), (30, 25, 40), (8, 6, 5), (130, 20, 300)])
+def test_track_frame_chain_tiny_frames(gpu, oracle, NF, NL, NP):
+    """Frames too small to track (fewer than 20 matches: trackWithMotionModel returns 0, optimisations of a handful of edges or of none):
+    every stage still equal to the oracle's sequence on the inputs the device gave it."""
+    torch, ctx = gpu
+    cam = api.Camera()
+    frames = [synth.synth_chain_frame(NF, NL, NP, 4800 + 7 * NF + b, cam) for b in range(3)]
+    out = run_chain(torch, ctx, frames)
+    for b, f in enumerate(frames):
+        G.check_chain(oracle, cam, f, out, b)
+
+
 @pytest.mark.parametrize("NF,NL,NP", [(1200, 1000, 3000), (600, 500, 1200), (300, 1500, 700)])
 def test_track_frame_chain_matches_oracle_sequence(gpu, oracle, NF, NL, NP):
     torch, ctx = gpu
